@@ -1,0 +1,95 @@
+"""Pins the CPU oracle (oracle/gcra_oracle.c) against the reference's own
+known-answer tests (tests/golden/reference_kat.json)."""
+import pytest
+
+from oracle import oracle as O
+from tests import kat
+
+KAT = kat.load()
+T0 = KAT["t0_ns"]
+
+
+@pytest.mark.parametrize("sc", KAT["scenarios"], ids=[s["name"] for s in KAT["scenarios"]])
+def test_scenario_adaptive_store(sc):
+    kat.replay_scenario(sc, O.AdaptiveOracle(capacity=1000, created_ns=T0))
+
+
+@pytest.mark.parametrize("case", KAT["store_contract"], ids=[c["name"] for c in KAT["store_contract"]])
+def test_store_contract_adaptive(case):
+    kat.replay_store_contract(case, O.AdaptiveOracle(capacity=100, created_ns=T0), T0)
+
+
+def test_rate_from_count_and_period():
+    for c in KAT["rates"]["cases"]:
+        assert O.emission_interval(c["count"], c["period"]) == c["period_ns"]
+
+
+def test_exact_numbers_survey_appendix_b():
+    """Exact values implied by the reference's arithmetic (rate_limiter.rs:207-238)."""
+    lim = O.AdaptiveOracle(created_ns=T0)
+    # (10,100,60): ei = 0.6 s, dvt = 5.4 s; first request: reset_after = 5.4 s -> 5
+    st, allowed, limit, rem, reset_ns, retry_ns = lim.rate_limit(b"k", 10, 100, 60, 1, T0)
+    assert (st, allowed, limit, rem, reset_ns, retry_ns) == (0, True, 10, 9, 5_400_000_000, 0)
+    # burst exhausted -> retry_after = ei exactly for (5,10,60): 6 s
+    lim = O.AdaptiveOracle(created_ns=T0)
+    for _ in range(5):
+        lim.rate_limit(b"b", 5, 10, 60, 1, T0)
+    st, allowed, limit, rem, reset_ns, retry_ns = lim.rate_limit(b"b", 5, 10, 60, 1, T0)
+    assert (allowed, rem, retry_ns) == (False, 0, 6_000_000_000)
+    # burst 10 then 5 on one key -> allowed, remaining exactly 3 (clamp observable)
+    lim = O.AdaptiveOracle(created_ns=T0)
+    lim.rate_limit(b"d", 10, 100, 60, 1, T0)
+    st, allowed, limit, rem, *_ = lim.rate_limit(b"d", 5, 100, 60, 1, T0)
+    assert (allowed, limit, rem) == (True, 5, 3)
+    # (3,7,60): ei = 8 571 428 571 ns
+    assert O.emission_interval(7, 60) == 8_571_428_571
+
+
+def test_error_precedence_and_state_untouched():
+    lim = O.AdaptiveOracle(created_ns=T0)
+    assert lim.rate_limit(b"e", 0, 0, 0, -1, T0)[0] == O.NEGATIVE_QUANTITY  # q<0 checked first
+    assert lim.rate_limit(b"e", 0, 10, 60, 1, T0)[0] == O.INVALID_RATE_LIMIT
+    assert len(lim) == 0
+    assert lim.get(b"e", T0) is None
+
+
+def test_burst_one_expires_immediately():
+    """burst=1 => dvt=0, ttl=0 => entry dead at the same `now` (expiry > now is strict,
+    adaptive_cleanup.rs:248): every request at one timestamp is allowed."""
+    lim = O.AdaptiveOracle(created_ns=T0)
+    for _ in range(4):
+        st, allowed, limit, rem, reset_ns, retry_ns = lim.rate_limit(b"one", 1, 1, 1, 1, T0)
+        assert (st, allowed, limit, rem) == (0, True, 1, 0)
+
+
+def test_zero_quantity_burst_one_never_expires():
+    """q=0 on a fresh burst=1 key: ttl = (i64)(-ei) as u64 ~ 584 y (rate_limiter.rs:179-183)."""
+    lim = O.AdaptiveOracle(created_ns=T0)
+    assert lim.rate_limit(b"z", 1, 1, 1, 0, T0)[1] is True
+    assert lim.get(b"z", T0 + 200 * 365 * 86400 * 10**9) == T0 - 10**9
+    # the key is now live forever with tat clamped to `now`: q=1 is denied
+    st, allowed, *_ = lim.rate_limit(b"z", 1, 1, 1, 1, T0 + 5 * 10**9)
+    assert (st, allowed) == (0, False)
+
+
+def test_internal_domain():
+    lim = O.AdaptiveOracle(created_ns=T0)
+    # pre-1970 now -> reference reads the wall clock; we return Internal
+    assert lim.rate_limit(b"i", 5, 10, 60, 1, -1)[0] == O.INTERNAL
+    # Duration * u32 overflow (reference panics): ei saturates to u64::MAX ns, mult ~ 4.29e9
+    assert lim.rate_limit(b"i", 2**32, 1, 2**62, 1, T0)[0] == O.INTERNAL
+    assert len(lim) == 0
+
+
+def test_adaptive_cleanup_runs_and_is_decision_neutral():
+    a = O.AdaptiveOracle(capacity=1000, created_ns=T0, max_operations=50)
+    d = O.DenseOracle(4096)
+    import numpy as np
+    rng = np.random.default_rng(7)
+    slots = rng.integers(0, 300, 5000).astype(np.uint32)
+    for i, s in enumerate(slots):
+        now = T0 + i * 20_000_000
+        ka = a.rate_limit(b"key_%d" % s, 3, 30, 60, 1, now)
+        kd = d.rate_limit(int(s).to_bytes(4, "little"), 3, 30, 60, 1, now)
+        assert ka == kd
+    assert a.cleanups > 10
