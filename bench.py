@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""bench.py -- GCRA decisions/s of the MI355X engine on BASELINE.json's workload.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload uniform|zipf]
+
+One "step" = one batch of 1 Mi requests (u32 slots already resident in HBM)
+decided and applied against a 10 M-key resident store through the C ABI
+(tc_rate_limit_batch_slots, device pointers, per-slot registered rate
+parameters (100, 1000/3600 s), quantity 1, one timestamp per batch,
+decisions-only output).  Duplicate keys inside a batch are honoured exactly.
+
+N > 1 (torchrun, one rank per GPU): the key space is hash-sharded, every rank
+owns 10 M keys and serves its own 1 Mi-request batch per step (weak scaling, no
+collective on the decision path); the per-GPU counter blocks are all-gathered
+over RCCL every step (the only exchange the path has).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_KEYS = 10_000_000
+BATCH = 1 << 20
+ALG_BYTES_PER_DECISION = 36.125  # SURVEY.md section 8(d), slot mode, decisions only
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--keys", type=int, default=N_KEYS)
+    ap.add_argument("--batch", type=int, default=BATCH)
+    ap.add_argument("--cpu-sample-batches", type=int, default=8)
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    return ap.parse_args()
+
+
+def make_batches(kind, n_keys, batch, count, seed_shift=0):
+    from throttlecrab_amd import workload as W
+    if kind == "zipf":
+        z = W.Zipf(n_keys)
+        return [z.slots(batch, seed=3 + seed_shift, start=i * batch) for i in range(count)]
+    return [W.uniform_slots(n_keys, batch, seed=2 + seed_shift, start=i * batch) for i in range(count)]
+
+
+def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",)):
+    """warmup + timed region; returns seconds for `steps` batches (max over ranks)."""
+    import torch
+    it = 0
+
+    def one(i):
+        eng.rate_limit_batch_slots(d_batches[i % len(d_batches)], registered=True, quantity=1,
+                                   now_ns=now0 + i * 1_000_000, want=want, out=out)
+        if dist is not None:
+            dist.all_gather_into_tensor(gathered, cnt_view)
+
+    for _ in range(warmup):
+        one(it)
+        it += 1
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one(it)
+        it += 1
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt, it
+
+
+def stage_profile(eng, d_batches, out, now0, steps, it0):
+    """Same steps again with HIP events between the engine's kernels."""
+    import torch
+    eng.profile_enable(True)
+    for i in range(steps):
+        eng.rate_limit_batch_slots(d_batches[(it0 + i) % len(d_batches)], registered=True, quantity=1,
+                                   now_ns=now0 + (it0 + i) * 1_000_000, want=("allowed",), out=out)
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    return prof
+
+
+def cpu_baseline(kind, n_keys, batch, n_batches):
+    """The oracle (a port of RateLimiter<AdaptiveStore>, string keys "key_<slot>")
+    timed on this box's host cores over the first n_batches of the same stream."""
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    slots = np.concatenate(make_batches(kind, n_keys, batch, n_batches))
+    kb, ko = O.format_keys(slots)
+    now = (W.T0_NS + (np.arange(slots.size, dtype=np.int64) // batch) * 1_000_000)
+    b, c, p = W.REF_PARAMS
+    # single thread == the reference's one actor task (throttlecrab-server/src/actor.rs:217-236);
+    # store sized like the server would for this key count, server-default max_operations (config.rs:301)
+    st = O.AdaptiveOracle(capacity=n_keys, created_ns=W.T0_NS, max_operations=1_000_000)
+    t0 = time.perf_counter()
+    st.batch_keys(kb, ko, b, c, p, 1, now)
+    t1 = time.perf_counter() - t0
+    ncores = os.cpu_count() or 1
+    tm, _ = O.batch_keys_mt(ncores, max(1000, n_keys // ncores), W.T0_NS, kb, ko, b, c, p, 1, now)
+    return {"value": slots.size / t1, "unit": "decisions/s", "cores": 1, "kind": "port",
+            "sample": f"first {n_batches} batches ({slots.size} requests) of the same {kind} stream, "
+                      f"string keys key_<slot>, AdaptiveStore port, 1 thread",
+            "all_cores": {"value": slots.size / tm, "cores": ncores,
+                          "note": "keys hash-sharded over one AdaptiveStore port per thread"}}
+
+
+def main():
+    a = parse()
+    import torch
+
+    import throttlecrab_amd as t
+    from throttlecrab_amd import workload as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    dev = torch.device(f"cuda:{local}")
+
+    eng = t.Engine(a.keys, a.batch, device=local)
+    eng.use_torch_stream()
+    eng.register_params_uniform(*W.REF_PARAMS)
+
+    # per-rank request stream over this rank's shard of the key space (slots are shard-local ids)
+    nb = a.steps + a.warmup
+    host_batches = make_batches(a.workload, a.keys, a.batch, min(nb, 64), seed_shift=100 * rank)
+    d_batches = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in host_batches]
+    out = t.BatchResult()
+
+    cnt_view = gathered = None
+    if dist is not None:
+        from throttlecrab_amd.sharded import device_counter_view
+        cnt_view = device_counter_view(eng)
+        gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
+
+    dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered)
+    decisions = a.steps * a.batch * world
+    value = decisions / dt
+    counters = eng.counters()
+
+    result = {
+        "metric": "GCRA decisions/sec, 10M keys", "value": value, "unit": "decisions/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": f"configs[{1 if a.workload == 'uniform' else 2}]: {a.keys} pre-hashed keys SoA per GPU, "
+                               f"{a.workload} request stream, batch={a.batch}, params (100,1000/3600s), q=1",
+                   "keys_per_gpu": a.keys, "batch": a.batch, "stream": a.workload,
+                   "parallelism": f"hash-shard x{world}", "outputs": "allowed u8 (decisions only)"},
+        "allowed_fraction": counters["allowed"] / max(1, counters["total"]),
+    }
+
+    if rank == 0:
+        # roofline of the dominant stage, from HIP events on the engine's stream
+        prof = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it)
+        stages = {k: v[0] / max(1, v[1]) for k, v in prof.items() if v[1]}
+        dom = max(stages, key=stages.get)
+        alg_bytes = ALG_BYTES_PER_DECISION * a.batch
+        ach = alg_bytes / (stages[dom] * 1e-3) / 1e9
+        result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                              "avg_ms": stages[dom], "stage_ms": stages,
+                              "whole_batch_GBs": alg_bytes * a.steps / dt / 1e9}
+        if not a.no_also and world == 1:
+            also = {}
+            other = "zipf" if a.workload == "uniform" else "uniform"
+            ob = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in make_batches(other, a.keys, a.batch, min(nb, 32))]
+            eng2 = t.Engine(a.keys, a.batch, device=local)
+            eng2.use_torch_stream()
+            eng2.register_params_uniform(*W.REF_PARAMS)
+            dt2, _ = run_gpu(eng2, ob, out, W.T0_NS, a.steps, a.warmup, None, None, None)
+            c2 = eng2.counters()
+            also[f"{other}_stream"] = {"value": a.steps * a.batch / dt2, "unit": "decisions/s",
+                                       "allowed_fraction": c2["allowed"] / max(1, c2["total"])}
+            full = t.BatchResult()
+            dt3, _ = run_gpu(eng2, ob, full, W.T0_NS + 10**9, a.steps, 2, None, None, None,
+                             want=t.Engine.ALL_FIELDS)
+            also[f"{other}_stream_full_result"] = {"value": a.steps * a.batch / dt3, "unit": "decisions/s"}
+            eng2.close()
+            result["also"] = also
+        if not a.no_cpu:
+            result["cpu_baseline"] = cpu_baseline(a.workload, a.keys, a.batch, a.cpu_sample_batches)
+        print(json.dumps(result))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,219 @@
+/*
+ * tcgpu.h -- C ABI of the MI355X-native batched GCRA engine (libtcgpu.so).
+ *
+ * This is the drop-in boundary for ONE hot path of lazureykis/throttlecrab:
+ *     RateLimiter<AdaptiveStore>::rate_limit
+ *         throttlecrab/src/core/rate_limiter.rs:102-250      (decision + advance)
+ *         throttlecrab/src/core/rate/mod.rs:164-176          (emission interval)
+ *         throttlecrab/src/core/store/mod.rs:85-133          (Store trait)
+ *         throttlecrab/src/core/store/adaptive_cleanup.rs:138-279 (AdaptiveStore)
+ * The reference has no FFI layer (it is 100 % Rust); the seam is the generic
+ * `RateLimiter<S: Store>` that the server calls from
+ *     throttlecrab-server/src/actor.rs:178-215 (StoreType::rate_limit).
+ * A Rust maintainer binds these symbols with `extern "C"` (INTEGRATION.md
+ * shows the stub) and gets `rate_limit` + the new `rate_limit_batch`.
+ *
+ * Semantics: a batch behaves EXACTLY as if its requests were applied one by
+ * one, in index order, through the reference's `rate_limit` (duplicate keys
+ * inside a batch included).  Integer results are bit-exact with the reference
+ * inside the validated domain; outside it (where the reference panics or is
+ * build-mode dependent) the request gets TC_INTERNAL and state is untouched:
+ *     now_ns < 0                       (rate_limiter.rs:126-144 reads the wall clock)
+ *     Duration * u32 overflow          (rate_limiter.rs:122 panics)
+ *     now_ns + dvt overflows i64       (rate_limiter.rs:217 plain add)
+ *
+ * Ownership / threading: the handle is owned by the caller and is NOT
+ * thread-safe (same contract as `&mut RateLimiter`, store/mod.rs:40-43): one
+ * caller at a time, work is issued on one HIP stream per engine.
+ * Plain pointers and sizes only; no C++/torch types cross this boundary.
+ */
+#ifndef TCGPU_H
+#define TCGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TCGPU_ABI_VERSION 1
+
+typedef struct tc_engine tc_engine;
+
+/* Per-request status = CellError (throttlecrab/src/core/mod.rs:49-56); 0 = Ok. */
+enum {
+    TC_OK = 0,
+    TC_NEGATIVE_QUANTITY = 1,  /* CellError::NegativeQuantity  (rate_limiter.rs:111-113) */
+    TC_INVALID_RATE_LIMIT = 2, /* CellError::InvalidRateLimit  (rate_limiter.rs:115-117) */
+    TC_INTERNAL = 3            /* CellError::Internal          (outside validated domain) */
+};
+
+/* Call-level return codes (0 = success).  A negative return means the whole
+ * call failed and NO request of the batch was applied. */
+enum {
+    TC_E_OK = 0,
+    TC_E_INVALID_ARG = -1,
+    TC_E_HIP = -2,            /* HIP runtime error; see tc_last_error() */
+    TC_E_NOMEM = -3,
+    TC_E_BATCH_TOO_LARGE = -4,
+    TC_E_TABLE_FULL = -5,     /* string mode: no free slot / arena space for a new key */
+    TC_E_NO_DEVICE = -6,
+    TC_E_UNSUPPORTED = -7
+};
+
+/* tc_config.flags */
+#define TC_CFG_KEY_MODE 0x1u /* enable the on-device key->slot hash table (string keys) */
+
+typedef struct tc_config {
+    uint32_t struct_size;     /* = sizeof(tc_config) */
+    uint32_t flags;           /* TC_CFG_* */
+    int32_t device_id;        /* HIP device ordinal */
+    int32_t reserved0;
+    uint64_t capacity;        /* number of key slots resident in HBM */
+    uint64_t max_batch;       /* largest n accepted by one rate_limit_batch call */
+    uint64_t key_arena_bytes; /* string mode: bytes reserved for key storage (0 = 32 B/slot) */
+} tc_config;
+
+/* tc_batch.flags */
+#define TC_B_DEVICE_PTRS 0x1u       /* every pointer in the batch is a device pointer (async on the stream) */
+#define TC_B_REGISTERED_PARAMS 0x2u /* use the per-slot (burst,count,period) set by tc_register_params */
+#define TC_B_UNIQUE_SLOTS 0x4u      /* caller guarantees no slot occurs twice (skips grouping) */
+
+/* One batch of requests = the argument list of RateLimiter::rate_limit
+ * (rate_limiter.rs:102-110), columnar.  A NULL input column means "use the
+ * scalar of the same name for every request". */
+typedef struct tc_batch {
+    uint32_t struct_size; /* = sizeof(tc_batch) */
+    uint32_t flags;       /* TC_B_* */
+    uint64_t n;           /* number of requests */
+
+    /* key: slots (tc_rate_limit_batch_slots) or a key arena (…_keys) */
+    const uint32_t* slot;      /* [n] slot ids in [0, capacity) */
+    const uint8_t* key_bytes;  /* key arena */
+    const uint32_t* key_off;   /* [n+1] offsets into key_bytes */
+
+    const int64_t* max_burst;        /* [n] or NULL */
+    const int64_t* count_per_period; /* [n] or NULL */
+    const int64_t* period;           /* [n] or NULL (seconds) */
+    const int64_t* quantity;         /* [n] or NULL */
+    const int64_t* now_ns;           /* [n] or NULL; SystemTime as ns since UNIX_EPOCH */
+    int64_t max_burst_scalar;
+    int64_t count_per_period_scalar;
+    int64_t period_scalar;
+    int64_t quantity_scalar;
+    int64_t now_ns_scalar;
+
+    /* outputs = (bool, RateLimitResult) (rate_limiter.rs:13-22) + status; any may be NULL */
+    uint8_t* allowed;        /* [n] 0/1 */
+    uint64_t* allowed_bits;  /* [(n+63)/64] bit i%64 of word i/64 = allowed[i] */
+    int64_t* limit;          /* [n] */
+    int64_t* remaining;      /* [n] */
+    int64_t* reset_after_ns; /* [n] Duration as ns */
+    int64_t* retry_after_ns; /* [n] Duration as ns */
+    uint8_t* status;         /* [n] TC_OK / TC_NEGATIVE_QUANTITY / ... */
+} tc_batch;
+
+/* Single-request result (the tuple rate_limit returns). */
+typedef struct tc_result {
+    int64_t limit;
+    int64_t remaining;
+    int64_t reset_after_ns;
+    int64_t retry_after_ns;
+    uint8_t allowed;
+    uint8_t status;
+} tc_result;
+
+/* Counter block (the payload all-gathered across GPUs; cf. the reference's
+ * Metrics counters, throttlecrab-server/src/metrics.rs:84-94). */
+enum {
+    TC_CNT_TOTAL = 0,    /* requests decided */
+    TC_CNT_ALLOWED = 1,
+    TC_CNT_DENIED = 2,
+    TC_CNT_ERRORS = 3,   /* status != TC_OK */
+    TC_CNT_SWEPT = 4,    /* entries removed by tc_sweep_expired */
+    TC_CNT_BATCHES = 5,
+    TC_CNT_KEYS_INSERTED = 6,
+    TC_CNT_LIVE_SLOTS = 7, /* occupied slots (refreshed by tc_sweep_expired) */
+    TC_CNT_COUNT = 8
+};
+
+uint32_t tc_abi_version(void);
+
+/* RateLimiter::new(AdaptiveStore::with_capacity(..)) (rate_limiter.rs:56-58,
+ * adaptive_cleanup.rs:93-106).  Returns NULL and sets *err on failure. */
+tc_engine* tc_engine_create(const tc_config* cfg, int* err);
+void tc_engine_destroy(tc_engine* e);
+
+/* Issue all work on `hip_stream` (a hipStream_t) instead of the engine's own
+ * stream; NULL restores the engine's stream. */
+int tc_engine_set_stream(tc_engine* e, void* hip_stream);
+/* Block until everything issued so far has finished. */
+int tc_synchronize(tc_engine* e);
+/* Message for the last negative return code (owned by the engine). */
+const char* tc_last_error(const tc_engine* e);
+
+/* Per-slot rate parameters kept as columns in HBM (emission interval, burst
+ * tolerance, burst capacity).  slots == NULL registers slots [0, n).  Host
+ * pointers.  Invalid parameter triples are rejected (TC_E_INVALID_ARG). */
+int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slots, const int64_t* max_burst,
+                       const int64_t* count_per_period, const int64_t* period);
+/* Same triple for every slot. */
+int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64_t count_per_period, int64_t period);
+
+/* rate_limit_batch over pre-resolved slots / over string keys.
+ * Host-pointer batches return after the results are in the output arrays;
+ * TC_B_DEVICE_PTRS batches are asynchronous on the engine's stream. */
+int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* b);
+int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* b);
+
+/* RateLimiter::rate_limit (rate_limiter.rs:102-250), one request, string key.
+ * Returns 0 and fills *out (out->status carries the CellError). */
+int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, int64_t max_burst,
+                  int64_t count_per_period, int64_t period, int64_t quantity, int64_t now_ns,
+                  tc_result* out);
+
+/* AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203): drop every entry with
+ * expiry <= now.  Decision-neutral. */
+int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed);
+
+/* Copy the counter block to host. */
+int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]);
+/* Per-stage timing of the batch pipeline with HIP events recorded on the
+ * engine's stream between its kernels (diagnostics for the roofline report;
+ * leave off in production -- every event is an extra stream operation). */
+enum {
+    TC_STAGE_PREP = 0,   /* sort-key preparation */
+    TC_STAGE_SORT = 1,   /* (slot, index) grouping */
+    TC_STAGE_EVAL = 2,   /* GCRA decide + advance */
+    TC_STAGE_COMMIT = 3, /* deferred cell stores */
+    TC_STAGE_PACK = 4,   /* decision bit packing */
+    TC_STAGE_HASH = 5,   /* string mode: key -> slot resolution */
+    TC_STAGE_COUNT = 6
+};
+int tc_profile_enable(tc_engine* e, int on);
+/* Accumulated milliseconds and launches per stage since tc_profile_enable. */
+int tc_profile_read(tc_engine* e, double total_ms[TC_STAGE_COUNT], uint64_t calls[TC_STAGE_COUNT]);
+
+/* Device address of the counter block (uint64[TC_CNT_COUNT]) for an on-device
+ * collective (RCCL all-gather) without a host round trip. */
+int tc_counters_device_ptr(tc_engine* e, void** dptr);
+
+/* `trait Store` parity shims (store/mod.rs:85-133), one key per call. */
+int tc_store_get(tc_engine* e, const uint8_t* key, size_t key_len, int64_t now_ns, int64_t* value, int* found);
+int tc_store_compare_and_swap_with_ttl(tc_engine* e, const uint8_t* key, size_t key_len, int64_t old_value,
+                                       int64_t new_value, uint64_t ttl_ns, int64_t now_ns, int* swapped);
+int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* key, size_t key_len, int64_t value,
+                                        uint64_t ttl_ns, int64_t now_ns, int* was_set);
+
+/* Introspection for differential tests: raw (tat, expiry) columns of slots
+ * [first, first+n) copied to host.  expiry is ns since epoch saturated to u64;
+ * 0 = vacant. */
+int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* tat, uint64_t* expiry);
+/* string mode: slot currently bound to `key`, or -1. */
+int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, int64_t* slot);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TCGPU_H */

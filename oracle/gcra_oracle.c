@@ -578,3 +578,22 @@ double tco_batch_keys_mt(int threads, size_t capacity_per_thread, int64_t create
     free(args);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
+
+/* `format!("{prefix}{id}")` key arena for a slot-id stream (bench helper). */
+size_t tco_format_keys(const char* prefix, const uint32_t* ids, size_t n, uint8_t* out_bytes,
+                       size_t out_cap, uint32_t* out_off) {
+    size_t plen = strlen(prefix), pos = 0;
+    for (size_t i = 0; i < n; i++) {
+        char tmp[16];
+        int len = 0;
+        uint32_t v = ids[i];
+        do { tmp[len++] = (char)('0' + v % 10); v /= 10; } while (v);
+        if (pos + plen + (size_t)len > out_cap) return 0;
+        out_off[i] = (uint32_t)pos;
+        memcpy(out_bytes + pos, prefix, plen);
+        pos += plen;
+        while (len) out_bytes[pos++] = (uint8_t)tmp[--len];
+    }
+    out_off[n] = (uint32_t)pos;
+    return pos;
+}

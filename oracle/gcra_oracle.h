@@ -137,6 +137,11 @@ double tco_batch_keys_mt(int threads, size_t capacity_per_thread, int64_t create
                          const uint8_t* key_bytes, const uint32_t* key_off,
                          const tco_batch_io* io);
 
+/* `format!("{prefix}{id}")` key arena for a slot-id stream; returns bytes used
+ * (0 if out_cap is too small). */
+size_t tco_format_keys(const char* prefix, const uint32_t* ids, size_t n, uint8_t* out_bytes,
+                       size_t out_cap, uint32_t* out_off);
+
 /* 64-bit key hash used only to place keys (results are hash independent). */
 uint64_t tco_hash_bytes(const uint8_t* p, size_t n);
 

@@ -91,6 +91,8 @@ def lib():
     L.tco_batch_slots.argtypes = [C.POINTER(_Store), C.c_void_p, C.POINTER(_BatchIO)]
     L.tco_batch_keys_mt.restype = C.c_double
     L.tco_batch_keys_mt.argtypes = [C.c_int, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(_BatchIO)]
+    L.tco_format_keys.restype = C.c_size_t
+    L.tco_format_keys.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.tco_hash_bytes.restype = C.c_uint64
     L.tco_hash_bytes.argtypes = [C.c_char_p, C.c_size_t]
     _lib = L
@@ -282,3 +284,13 @@ def batch_keys_mt(threads: int, capacity_per_thread: int, created_ns: int, key_b
     ko = np.ascontiguousarray(key_off, dtype=np.uint32)
     secs = lib().tco_batch_keys_mt(threads, capacity_per_thread, created_ns, kb.ctypes.data, ko.ctypes.data, C.byref(io))
     return float(secs), out
+
+
+def format_keys(ids: np.ndarray, prefix: bytes = b"key_"):
+    """`format!("key_{}", id)` arena for a slot-id stream -> (bytes, offsets[n+1])."""
+    ids = np.ascontiguousarray(ids, dtype=np.uint32)
+    cap = len(ids) * (len(prefix) + 10) + 1
+    buf = np.zeros(cap, np.uint8)
+    off = np.zeros(len(ids) + 1, np.uint32)
+    used = lib().tco_format_keys(prefix, ids.ctypes.data, len(ids), buf.ctypes.data, cap, off.ctypes.data)
+    return buf[:max(int(used), 1)], off

@@ -1,0 +1,324 @@
+"""GPU parity (slot mode): the HIP engine (through the C ABI) vs the CPU oracle
+on the same seeded streams -- bit-exact on all six outputs and on the resident
+(tat, expiry) state."""
+import numpy as np
+import pytest
+
+from tests import kat
+
+pytestmark = pytest.mark.gpu
+
+KAT = kat.load()
+T0 = KAT["t0_ns"]
+FIELDS = ("allowed", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+
+
+def _engine(capacity, max_batch=1 << 16):
+    import throttlecrab_amd as t
+    return t.Engine(capacity, max_batch)
+
+
+def _oracle(capacity):
+    from oracle import oracle as O
+    return O.DenseOracle(capacity)
+
+
+def assert_same(res, ref, ctx=""):
+    for f in FIELDS:
+        got = getattr(res, f)
+        if got is None:
+            continue
+        if not isinstance(got, np.ndarray):
+            got = got.cpu().numpy()
+        exp = getattr(ref, f)
+        if f in ("status", "allowed"):
+            got = got.astype(np.uint8)
+        bad = np.nonzero(got.astype(np.int64) != exp.astype(np.int64))[0]
+        assert bad.size == 0, f"{ctx}: field {f} differs at {bad[:8]} got {got[bad[:8]]} want {exp[bad[:8]]}"
+
+
+def assert_state_same(eng, orc, slots):
+    tat, exp = eng.read_state(0, eng.capacity)
+    for s in np.unique(slots):
+        if s >= eng.capacity:
+            continue
+        ot, oe, occ = orc.peek(int(s))
+        if not occ:
+            assert exp[s] == 0, f"slot {s} should be vacant"
+        else:
+            assert (int(tat[s]), int(exp[s])) == (ot, oe), f"slot {s}: state ({tat[s]},{exp[s]}) want ({ot},{oe})"
+
+
+class _SlotKeyed:
+    """Replays string-keyed scenarios on a slot-mode engine (key -> slot by first use)."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        self.slots = {}
+
+    def rate_limit(self, key, burst, count, period, q, now):
+        s = self.slots.setdefault(key, len(self.slots))
+        return self.eng.rate_limit(int(s).to_bytes(4, "little"), burst, count, period, q, now)
+
+
+@pytest.mark.parametrize("sc", KAT["scenarios"], ids=[s["name"] for s in KAT["scenarios"]])
+def test_reference_known_answers(sc):
+    eng = _engine(64, 64)
+    kat.replay_scenario(sc, _SlotKeyed(eng))
+    eng.close()
+
+
+@pytest.mark.parametrize("case", [c for c in KAT["store_contract"] if c["name"] not in ("special_keys", "many_keys")],
+                         ids=lambda c: c["name"])
+def test_store_contract(case):
+    eng = _engine(64, 64)
+
+    class S:
+        def __init__(self):
+            self.m = {}
+
+        def _k(self, key):
+            return int(self.m.setdefault(key, len(self.m))).to_bytes(4, "little")
+
+        def get(self, key, now):
+            return eng.get(self._k(key), now)
+
+        def set_if_not_exists_with_ttl(self, key, val, ttl, now):
+            return eng.set_if_not_exists_with_ttl(self._k(key), val, ttl, now)
+
+        def compare_and_swap_with_ttl(self, key, old, new, ttl, now):
+            return eng.compare_and_swap_with_ttl(self._k(key), old, new, ttl, now)
+
+    kat.replay_store_contract(case, S(), T0)
+    eng.close()
+
+
+PARAM_SETS = np.array([
+    (5, 10, 60), (100, 1000, 3600), (1, 1, 1), (2, 120, 60), (3, 7, 60), (10, 100, 60),
+    (20, 600, 60), (10, 2**62, 60),                 # ei == 0
+    (2**63 - 1, 2**63 - 1, 2**63 - 1),              # redis boundary test
+    (0, 10, 60), (10, 0, 60), (10, 10, 0), (-3, 5, 5),  # invalid
+    (2**32, 1, 2**62),                               # Duration*u32 overflow -> Internal
+    (2**32 + 1, 10, 60),                             # (burst-1) as u32 wraps to 0
+    ((2**63 - 1) // 1000, 100, 60),
+], dtype=np.int64)
+
+
+def _random_stream(rng, n, n_slots, capacity):
+    slots = rng.integers(0, n_slots, n).astype(np.uint32)
+    bad = rng.random(n) < 0.01
+    slots[bad] = capacity + rng.integers(0, 5, bad.sum()).astype(np.uint32)  # out-of-range slots
+    ps = PARAM_SETS[rng.integers(0, len(PARAM_SETS), n)]
+    # most slots keep one param set so that state evolves meaningfully
+    sticky = PARAM_SETS[(slots % 7).astype(np.int64)]
+    use_sticky = rng.random(n) < 0.8
+    ps = np.where(use_sticky[:, None], sticky, ps)
+    q = rng.choice(np.array([0, 1, 1, 1, 2, 5, -1, 2**62], dtype=np.int64), n)
+    now = T0 + rng.integers(-5 * 10**9, 30 * 10**9, n).astype(np.int64)
+    now[rng.random(n) < 0.005] = -7  # pre-1970
+    return slots, ps[:, 0].copy(), ps[:, 1].copy(), ps[:, 2].copy(), q, now
+
+
+@pytest.mark.parametrize("seed,n,n_slots", [(1, 5000, 300), (2, 20000, 64), (3, 3000, 5000), (4, 40000, 7)])
+def test_general_random_differential_host_pointers(seed, n, n_slots):
+    cap = 6000
+    rng = np.random.default_rng(seed)
+    eng, orc = _engine(cap), _oracle(cap)
+    from oracle import oracle as O
+    for rnd in range(3):
+        slots, b, c, p, q, now = _random_stream(rng, n, n_slots, cap)
+        # out-of-range slots: Internal, outputs zero, nothing applied (our boundary
+        # rule -- the reference has no slots); the oracle only sees in-range requests
+        keep = slots < cap
+        part = orc.batch_slots(slots[keep], b[keep], c[keep], p[keep], q[keep], now[keep])
+        ref = O.BatchOut(n)
+        ref.status[:] = 3
+        for f in FIELDS:
+            getattr(ref, f)[keep] = getattr(part, f)
+        res = eng.rate_limit_batch_slots(slots, max_burst=b, count_per_period=c, period=p, quantity=q, now_ns=now)
+        assert_same(res, ref, f"seed {seed} round {rnd}")
+        assert_state_same(eng, orc, slots)
+    cnt = eng.counters()
+    assert cnt["total"] == 3 * n and cnt["allowed"] + cnt["denied"] + cnt["errors"] == cnt["total"]
+    eng.close()
+
+
+def test_general_device_pointers_match_host_pointers():
+    import torch
+    cap, n = 2000, 30000
+    rng = np.random.default_rng(11)
+    slots, b, c, p, q, now = _random_stream(rng, n, 150, cap)
+    slots = np.minimum(slots, cap - 1)
+    orc = _oracle(cap)
+    ref = orc.batch_slots(slots, b, c, p, q, now)
+    eng = _engine(cap)
+    eng.use_torch_stream()
+    dev = "cuda:0"
+    tt = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
+    res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).to(dev), max_burst=tt(b),
+                                     count_per_period=tt(c), period=tt(p), quantity=tt(q), now_ns=tt(now),
+                                     want=FIELDS + ("allowed_bits",))
+    torch.cuda.synchronize()
+    assert_same(res, ref, "device ptrs")
+    bits = res.allowed_bits.cpu().numpy().view(np.uint64)
+    unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).reshape(-1)[:n]
+    assert np.array_equal(unpacked.astype(np.uint8), ref.allowed)
+    assert_state_same(eng, orc, slots)
+    eng.close()
+
+
+UNIFORM_CASES = [
+    # (burst, count, period, q, label)
+    (100, 1000, 3600, 1, "bench params"),
+    (5, 10, 60, 1, "small burst"),
+    (1, 1, 1, 1, "burst 1: entries expire at once (irregular walk)"),
+    (1, 1, 1, 0, "q=0 burst 1: never-expiring poison"),
+    (10, 100, 60, 0, "q=0"),
+    (10, 2**62, 60, 1, "ei=0"),
+    (10, 100, 60, 3, "q=3"),
+    (10, 10, 60, 2**62, "huge q saturates"),
+    (2**63 - 1, 2**63 - 1, 2**63 - 1, 1, "i64::MAX triple"),
+    (2**32 + 1, 10, 60, 1, "u32 wrap of burst-1"),
+]
+
+
+@pytest.mark.parametrize("burst,count,period,q,label", UNIFORM_CASES, ids=[c[4] for c in UNIFORM_CASES])
+@pytest.mark.parametrize("registered", [False, True])
+def test_uniform_batches_with_heavy_duplicates(burst, count, period, q, label, registered):
+    """Scalar now/quantity + per-slot params: the closed-form path."""
+    cap, n = 5000, 60000
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(label.encode()))
+    eng, orc = _engine(cap), _oracle(cap)
+    if registered:
+        eng.register_params_uniform(burst, count, period)
+    z = rng.zipf(1.3, n).astype(np.int64)
+    for rnd in range(4):
+        slots = ((z * 2654435761 + rnd * 17) % 700).astype(np.uint32) if rnd % 2 == 0 else \
+            rng.integers(0, cap, n).astype(np.uint32)
+        now = T0 + rnd * 700_000_000  # 0.7 s apart; also goes back once
+        if rnd == 3:
+            now = T0 - 10**9
+        ref = orc.batch_slots(slots, burst, count, period, q, now)
+        kw = dict(registered=True) if registered else dict(max_burst=burst, count_per_period=count, period=period)
+        res = eng.rate_limit_batch_slots(slots, quantity=q, now_ns=now, **kw)
+        assert_same(res, ref, f"{label} round {rnd}")
+        assert_state_same(eng, orc, slots)
+    eng.close()
+
+
+def test_registered_params_per_slot_and_unregistered():
+    cap, n = 1000, 20000
+    rng = np.random.default_rng(5)
+    idx = rng.integers(0, 8, cap)
+    valid = PARAM_SETS[:8]
+    eng, orc = _engine(cap), _oracle(cap)
+    # slots 900.. stay unregistered -> InvalidRateLimit
+    eng.register_params(valid[idx[:900], 0], valid[idx[:900], 1], valid[idx[:900], 2])
+    slots = rng.integers(0, cap, n).astype(np.uint32)
+    b = np.where(slots < 900, valid[idx[slots], 0], 0)
+    c = np.where(slots < 900, valid[idx[slots], 1], 0)
+    p = np.where(slots < 900, valid[idx[slots], 2], 0)
+    for rnd in range(3):
+        now = T0 + rnd * 10**9
+        ref = orc.batch_slots(slots, b, c, p, 1, now)
+        res = eng.rate_limit_batch_slots(slots, registered=True, quantity=1, now_ns=now)
+        assert_same(res, ref, f"registered round {rnd}")
+    # per-request now with registered params -> general path
+    now = T0 + 5 * 10**9 + rng.integers(0, 10**9, n)
+    ref = orc.batch_slots(slots, b, c, p, 1, now)
+    res = eng.rate_limit_batch_slots(slots, registered=True, quantity=1, now_ns=now)
+    assert_same(res, ref, "registered + per-request now")
+    assert_state_same(eng, orc, slots)
+    eng.close()
+
+
+def test_register_rejects_invalid_triples():
+    import throttlecrab_amd as t
+    eng = _engine(16, 16)
+    with pytest.raises(t.TcError):
+        eng.register_params_uniform(0, 10, 60)
+    with pytest.raises(t.TcError):
+        eng.register_params(np.array([5, 5]), np.array([10, -1]), np.array([60, 60]))
+    eng.close()
+
+
+def test_unique_slots_fast_path():
+    cap, n = 50000, 20000
+    rng = np.random.default_rng(9)
+    eng, orc = _engine(cap), _oracle(cap)
+    for rnd in range(3):
+        slots = rng.permutation(cap)[:n].astype(np.uint32)
+        now = T0 + rng.integers(0, 10**9, n)
+        q = rng.integers(0, 4, n)
+        ref = orc.batch_slots(slots, 3, 30, 60, q, now)
+        res = eng.rate_limit_batch_slots(slots, max_burst=3, count_per_period=30, period=60, quantity=q, now_ns=now,
+                                         unique=True)
+        assert_same(res, ref, f"unique round {rnd}")
+    assert_state_same(eng, orc, np.arange(cap))
+    eng.close()
+
+
+def test_sweep_matches_adaptive_cleanup():
+    cap, n = 4000, 8000
+    rng = np.random.default_rng(21)
+    eng, orc = _engine(cap), _oracle(cap)
+    slots = rng.integers(0, cap, n).astype(np.uint32)
+    now = T0 + rng.integers(0, 20 * 10**9, n)
+    b, c, p = 3, 30, 60  # ttl <= ~8 s
+    ref = orc.batch_slots(slots, b, c, p, 1, now)
+    res = eng.rate_limit_batch_slots(slots, max_burst=b, count_per_period=c, period=p, quantity=1, now_ns=now)
+    assert_same(res, ref)
+    for t_sweep in (T0 + 10 * 10**9, T0 + 15 * 10**9, T0 + 100 * 10**9):
+        assert eng.sweep_expired(t_sweep) == orc.sweep(t_sweep)
+        assert eng.counters()["live_slots"] == orc.live()
+        assert_state_same(eng, orc, np.arange(cap))
+    # decisions after a sweep are unchanged (cleanup is decision-neutral)
+    now2 = T0 + 101 * 10**9
+    ref = orc.batch_slots(slots, b, c, p, 1, now2)
+    res = eng.rate_limit_batch_slots(slots, max_burst=b, count_per_period=c, period=p, quantity=1, now_ns=now2)
+    assert_same(res, ref, "after sweep")
+    eng.close()
+
+
+def test_empty_and_single_and_errors():
+    import throttlecrab_amd as t
+    eng = _engine(8, 8)
+    res = eng.rate_limit_batch_slots(np.zeros(0, np.uint32), max_burst=1, count_per_period=1, period=1, now_ns=T0)
+    assert res.allowed.size == 0
+    with pytest.raises(t.TcError) as ei:
+        eng.rate_limit_batch_slots(np.zeros(9, np.uint32), max_burst=1, count_per_period=1, period=1, now_ns=T0)
+    assert ei.value.code == -4
+    st = eng.rate_limit((3).to_bytes(4, "little"), 5, 10, 60, 1, T0)
+    assert st == (0, True, 5, 4, 24_000_000_000, 0)
+    eng.close()
+
+
+@pytest.mark.parametrize("kind", ["uniform", "zipf"])
+def test_full_size_10m_keys_1m_batch(kind):
+    """BASELINE configs 2 and 3 at full size: 10 M slots, 1 M-request batches."""
+    import torch
+    from throttlecrab_amd import workload as W
+    cap, B = 10_000_000, 1 << 20
+    eng, orc = _engine(cap, B), _oracle(cap)
+    eng.use_torch_stream()
+    eng.register_params_uniform(*W.REF_PARAMS)
+    z = W.Zipf(cap) if kind == "zipf" else None
+    tot_allowed = 0
+    for bidx in range(4):
+        slots = z.slots(B, start=bidx * B) if z else W.uniform_slots(cap, B, start=bidx * B)
+        now = T0 + bidx * 1_000_000
+        ref = orc.batch_slots(slots, *W.REF_PARAMS, 1, now)
+        d_slots = torch.from_numpy(slots.astype(np.int32)).cuda()
+        res = eng.rate_limit_batch_slots(d_slots, registered=True, quantity=1, now_ns=now)
+        torch.cuda.synchronize()
+        assert_same(res, ref, f"{kind} batch {bidx}")
+        tot_allowed += int(ref.allowed.sum())
+    cnt = eng.counters()
+    assert cnt["allowed"] == tot_allowed and cnt["total"] == 4 * B
+    tat, exp = eng.read_state(0, cap)
+    sample = np.unique(slots)[:: max(1, len(np.unique(slots)) // 5000)]
+    for s in sample:
+        ot, oe, occ = orc.peek(int(s))
+        assert occ and (int(tat[s]), int(exp[s])) == (ot, oe)
+    eng.close()

@@ -1,0 +1,96 @@
+"""ctypes loader for libtcgpu.so (HIP kernels + C ABI, include/tcgpu.h).
+
+There is NO CPU fallback: if the shared library is missing the import fails
+loudly -- build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C throttlecrab_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtcgpu.so")
+
+# per-request status (CellError, throttlecrab/src/core/mod.rs:49-56)
+TC_OK, TC_NEGATIVE_QUANTITY, TC_INVALID_RATE_LIMIT, TC_INTERNAL = 0, 1, 2, 3
+# call-level return codes
+(TC_E_OK, TC_E_INVALID_ARG, TC_E_HIP, TC_E_NOMEM, TC_E_BATCH_TOO_LARGE, TC_E_TABLE_FULL, TC_E_NO_DEVICE,
+ TC_E_UNSUPPORTED) = (0, -1, -2, -3, -4, -5, -6, -7)
+TC_CFG_KEY_MODE = 0x1
+TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS = 0x1, 0x2, 0x4
+TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
+TC_CNT_COUNT = 8
+TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash")
+TC_STAGE_COUNT = 6
+
+
+class tc_config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("device_id", C.c_int32),
+                ("reserved0", C.c_int32), ("capacity", C.c_uint64), ("max_batch", C.c_uint64),
+                ("key_arena_bytes", C.c_uint64)]
+
+
+class tc_batch(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("flags", C.c_uint32), ("n", C.c_uint64),
+                ("slot", C.c_void_p), ("key_bytes", C.c_void_p), ("key_off", C.c_void_p),
+                ("max_burst", C.c_void_p), ("count_per_period", C.c_void_p), ("period", C.c_void_p),
+                ("quantity", C.c_void_p), ("now_ns", C.c_void_p),
+                ("max_burst_scalar", C.c_int64), ("count_per_period_scalar", C.c_int64),
+                ("period_scalar", C.c_int64), ("quantity_scalar", C.c_int64), ("now_ns_scalar", C.c_int64),
+                ("allowed", C.c_void_p), ("allowed_bits", C.c_void_p), ("limit", C.c_void_p),
+                ("remaining", C.c_void_p), ("reset_after_ns", C.c_void_p), ("retry_after_ns", C.c_void_p),
+                ("status", C.c_void_p)]
+
+
+class tc_result(C.Structure):
+    _fields_ = [("limit", C.c_int64), ("remaining", C.c_int64), ("reset_after_ns", C.c_int64),
+                ("retry_after_ns", C.c_int64), ("allowed", C.c_uint8), ("status", C.c_uint8)]
+
+
+# every symbol include/tcgpu.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "tc_abi_version": (C.c_uint32, []),
+    "tc_engine_create": (C.c_void_p, [C.POINTER(tc_config), C.POINTER(C.c_int)]),
+    "tc_engine_destroy": (None, [C.c_void_p]),
+    "tc_engine_set_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "tc_synchronize": (C.c_int, [C.c_void_p]),
+    "tc_last_error": (C.c_char_p, [C.c_void_p]),
+    "tc_register_params": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tc_register_params_uniform": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
+    "tc_rate_limit_batch_slots": (C.c_int, [C.c_void_p, C.POINTER(tc_batch)]),
+    "tc_rate_limit_batch_keys": (C.c_int, [C.c_void_p, C.POINTER(tc_batch)]),
+    "tc_rate_limit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
+                                C.c_int64, C.POINTER(tc_result)]),
+    "tc_sweep_expired": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]),
+    "tc_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "tc_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "tc_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    "tc_counters_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "tc_store_get": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.POINTER(C.c_int64),
+                               C.POINTER(C.c_int)]),
+    "tc_store_compare_and_swap_with_ttl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.c_int64,
+                                                     C.c_uint64, C.c_int64, C.POINTER(C.c_int)]),
+    "tc_store_set_if_not_exists_with_ttl": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.c_uint64,
+                                                      C.c_int64, C.POINTER(C.c_int)]),
+    "tc_read_state": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
+    "tc_lookup_slot": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libtcgpu.so and bind every declared symbol.  Raises if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: the HIP extension is not built.  There is no CPU fallback; "
+            "run `make -C throttlecrab_amd/csrc` (or __graft_entry__.build()).")
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L

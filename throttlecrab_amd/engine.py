@@ -1,0 +1,272 @@
+"""Thin object wrapper over the C ABI (include/tcgpu.h).
+
+Inputs may be numpy arrays (host pointers: staged by the library, the call
+returns with results) or torch CUDA tensors (device pointers: asynchronous on
+the engine's stream, results written into CUDA tensors).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib as L
+
+
+class TcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"tcgpu error {code}: {msg}")
+        self.code = code
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+class BatchResult:
+    """Columnar (bool, RateLimitResult) + status for one batch."""
+    __slots__ = ("allowed", "allowed_bits", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+
+    def __init__(self):
+        for s in self.__slots__:
+            setattr(self, s, None)
+
+
+_NP_DTYPES = {"allowed": np.uint8, "allowed_bits": np.uint64, "limit": np.int64, "remaining": np.int64,
+              "reset_after_ns": np.int64, "retry_after_ns": np.int64, "status": np.uint8}
+
+
+class Engine:
+    ALL_FIELDS = ("allowed", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+
+    def __init__(self, capacity: int, max_batch: int = 1 << 20, device: int = 0, key_mode: bool = False,
+                 key_arena_bytes: int = 0):
+        self._lib = L.load()
+        cfg = L.tc_config()
+        cfg.struct_size = C.sizeof(L.tc_config)
+        cfg.flags = L.TC_CFG_KEY_MODE if key_mode else 0
+        cfg.device_id = device
+        cfg.capacity = capacity
+        cfg.max_batch = max_batch
+        cfg.key_arena_bytes = key_arena_bytes
+        err = C.c_int(0)
+        self._h = self._lib.tc_engine_create(C.byref(cfg), C.byref(err))
+        if not self._h:
+            raise TcError(err.value, "tc_engine_create failed (is an MI355X visible and libtcgpu.so built for gfx950?)")
+        self.capacity = capacity
+        self.max_batch = max_batch
+        self.device = device
+        self.key_mode = key_mode
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tc_engine_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self._lib.tc_last_error(self._h)
+            raise TcError(rc, msg.decode() if msg else "")
+
+    # ---- configuration ----
+    def set_stream(self, hip_stream: Optional[int]):
+        self._check(self._lib.tc_engine_set_stream(self._h, C.c_void_p(hip_stream or 0)))
+
+    def use_torch_stream(self):
+        import torch
+        self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def synchronize(self):
+        self._check(self._lib.tc_synchronize(self._h))
+
+    def register_params_uniform(self, max_burst: int, count_per_period: int, period: int):
+        self._check(self._lib.tc_register_params_uniform(self._h, max_burst, count_per_period, period))
+
+    def register_params(self, max_burst, count_per_period, period, slots=None):
+        b = np.ascontiguousarray(max_burst, dtype=np.int64)
+        c = np.ascontiguousarray(count_per_period, dtype=np.int64)
+        p = np.ascontiguousarray(period, dtype=np.int64)
+        s = None if slots is None else np.ascontiguousarray(slots, dtype=np.uint32)
+        self._check(self._lib.tc_register_params(self._h, len(b), None if s is None else s.ctypes.data,
+                                                 b.ctypes.data, c.ctypes.data, p.ctypes.data))
+
+    # ---- batches ----
+    def _column(self, batch, name, val, n, dev, keep):
+        """Set batch.<name> (pointer) or batch.<name>_scalar."""
+        if val is None:
+            return
+        if _is_torch(val):
+            if not dev:
+                raise ValueError("torch CUDA columns need CUDA slots/keys (device-pointer batch)")
+            assert val.is_cuda and val.is_contiguous() and val.numel() == n, name
+            keep.append(val)
+            setattr(batch, name, val.data_ptr())
+            return
+        arr = np.asarray(val)
+        if arr.ndim == 0 or (arr.size == 1 and n != 1):
+            setattr(batch, name + "_scalar", int(arr.reshape(-1)[0]))
+            return
+        if dev:
+            raise ValueError(f"{name}: per-request column must be a CUDA tensor in a device-pointer batch")
+        arr = np.ascontiguousarray(arr, dtype=np.int64)
+        if arr.size != n:
+            raise ValueError(f"{name}: length {arr.size} != batch size {n}")
+        keep.append(arr)
+        setattr(batch, name, arr.ctypes.data)
+
+    def _prepare(self, n, dev, max_burst, count_per_period, period, quantity, now_ns, registered, unique,
+                 want, out: Optional[BatchResult]):
+        keep = []
+        b = L.tc_batch()
+        b.struct_size = C.sizeof(L.tc_batch)
+        b.n = n
+        flags = 0
+        if dev:
+            flags |= L.TC_B_DEVICE_PTRS
+        if registered:
+            flags |= L.TC_B_REGISTERED_PARAMS
+        if unique:
+            flags |= L.TC_B_UNIQUE_SLOTS
+        b.flags = flags
+        b.quantity_scalar = 1
+        if not registered:
+            if max_burst is None or count_per_period is None or period is None:
+                raise ValueError("max_burst/count_per_period/period required unless registered=True")
+            self._column(b, "max_burst", max_burst, n, dev, keep)
+            self._column(b, "count_per_period", count_per_period, n, dev, keep)
+            self._column(b, "period", period, n, dev, keep)
+        self._column(b, "quantity", quantity, n, dev, keep)
+        if now_ns is None:
+            raise ValueError("now_ns is required")
+        self._column(b, "now_ns", now_ns, n, dev, keep)
+        res = out or BatchResult()
+        for name in want:
+            cur = getattr(res, name)
+            ln = (n + 63) // 64 if name == "allowed_bits" else n
+            if cur is None:
+                if dev:
+                    import torch
+                    tdt = torch.uint8 if _NP_DTYPES[name] == np.uint8 else torch.int64
+                    cur = torch.empty(ln, dtype=tdt, device=f"cuda:{self.device}")
+                else:
+                    cur = np.zeros(ln, dtype=_NP_DTYPES[name])
+                setattr(res, name, cur)
+            keep.append(cur)
+            setattr(b, name, cur.data_ptr() if _is_torch(cur) else cur.ctypes.data)
+        return b, res, keep
+
+    def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
+                               now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
+                               out: Optional[BatchResult] = None) -> BatchResult:
+        """rate_limit_batch over pre-resolved slots (sequential semantics, index order)."""
+        dev = _is_torch(slots)
+        keep = []
+        if dev:
+            import torch
+            assert slots.is_cuda and slots.is_contiguous() and slots.dtype in (torch.int32, torch.uint32)
+            n = slots.numel()
+            sp = slots.data_ptr()
+        else:
+            sl = np.ascontiguousarray(slots, dtype=np.uint32)
+            keep.append(sl)
+            n = sl.size
+            sp = sl.ctypes.data
+        b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
+                                   unique, want, out)
+        b.slot = sp
+        if n:
+            self._check(self._lib.tc_rate_limit_batch_slots(self._h, C.byref(b)))
+        return res
+
+    def rate_limit_batch_keys(self, key_bytes, key_off, *, max_burst=None, count_per_period=None, period=None,
+                              quantity=None, now_ns=None, want=ALL_FIELDS,
+                              out: Optional[BatchResult] = None) -> BatchResult:
+        """rate_limit_batch over string keys (arena bytes + offsets[n+1])."""
+        dev = _is_torch(key_bytes)
+        keep = []
+        if dev:
+            assert key_bytes.is_cuda and key_off.is_cuda
+            n = key_off.numel() - 1
+            kb, ko = key_bytes.data_ptr(), key_off.data_ptr()
+        else:
+            kbytes = np.ascontiguousarray(key_bytes, dtype=np.uint8)
+            koff = np.ascontiguousarray(key_off, dtype=np.uint32)
+            keep += [kbytes, koff]
+            n = koff.size - 1
+            kb, ko = kbytes.ctypes.data, koff.ctypes.data
+        b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, False, False,
+                                   want, out)
+        b.key_bytes = kb
+        b.key_off = ko
+        if n:
+            self._check(self._lib.tc_rate_limit_batch_keys(self._h, C.byref(b)))
+        return res
+
+    def rate_limit(self, key: bytes, max_burst: int, count_per_period: int, period: int, quantity: int, now_ns: int):
+        """RateLimiter::rate_limit -> (status, allowed, limit, remaining, reset_after_ns, retry_after_ns)."""
+        r = L.tc_result()
+        self._check(self._lib.tc_rate_limit(self._h, key, len(key), max_burst, count_per_period, period, quantity,
+                                            now_ns, C.byref(r)))
+        return (r.status, bool(r.allowed), r.limit, r.remaining, r.reset_after_ns, r.retry_after_ns)
+
+    # ---- maintenance / introspection ----
+    def sweep_expired(self, now_ns: int) -> int:
+        removed = C.c_uint64(0)
+        self._check(self._lib.tc_sweep_expired(self._h, now_ns, C.byref(removed)))
+        return int(removed.value)
+
+    def counters(self) -> dict:
+        arr = (C.c_uint64 * L.TC_CNT_COUNT)()
+        self._check(self._lib.tc_counters(self._h, arr))
+        return {k: int(arr[i]) for i, k in enumerate(L.TC_CNT_NAMES)}
+
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.tc_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self) -> dict:
+        """-> {stage: (total_ms, launches)} measured with HIP events on the engine's stream."""
+        ms = (C.c_double * L.TC_STAGE_COUNT)()
+        calls = (C.c_uint64 * L.TC_STAGE_COUNT)()
+        self._check(self._lib.tc_profile_read(self._h, ms, calls))
+        return {k: (float(ms[i]), int(calls[i])) for i, k in enumerate(L.TC_STAGE_NAMES)}
+
+    def counters_device_ptr(self) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.tc_counters_device_ptr(self._h, C.byref(p)))
+        return int(p.value)
+
+    def read_state(self, first: int, n: int):
+        tat = np.zeros(n, np.int64)
+        exp = np.zeros(n, np.uint64)
+        self._check(self._lib.tc_read_state(self._h, first, n, tat.ctypes.data, exp.ctypes.data))
+        return tat, exp
+
+    def lookup_slot(self, key: bytes) -> int:
+        s = C.c_int64(-1)
+        self._check(self._lib.tc_lookup_slot(self._h, key, len(key), C.byref(s)))
+        return int(s.value)
+
+    # ---- `trait Store` shims (store/mod.rs:85-133) ----
+    def get(self, key: bytes, now_ns: int):
+        v, f = C.c_int64(), C.c_int()
+        self._check(self._lib.tc_store_get(self._h, key, len(key), now_ns, C.byref(v), C.byref(f)))
+        return v.value if f.value else None
+
+    def compare_and_swap_with_ttl(self, key: bytes, old: int, new: int, ttl_ns: int, now_ns: int) -> bool:
+        ok = C.c_int()
+        self._check(self._lib.tc_store_compare_and_swap_with_ttl(self._h, key, len(key), old, new, ttl_ns, now_ns,
+                                                                 C.byref(ok)))
+        return bool(ok.value)
+
+    def set_if_not_exists_with_ttl(self, key: bytes, value: int, ttl_ns: int, now_ns: int) -> bool:
+        ok = C.c_int()
+        self._check(self._lib.tc_store_set_if_not_exists_with_ttl(self._h, key, len(key), value, ttl_ns, now_ns,
+                                                                  C.byref(ok)))
+        return bool(ok.value)
