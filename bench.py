@@ -64,6 +64,7 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
         eng.rate_limit_batch_slots(d_batches[i % len(d_batches)], registered=True, quantity=1,
                                    now_ns=now0 + i * 1_000_000, want=want, out=out)
         if dist is not None:
+            eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
 
     for _ in range(warmup):

@@ -177,8 +177,12 @@ int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, int64_t max_
  * expiry <= now.  Decision-neutral. */
 int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed);
 
-/* Copy the counter block to host. */
+/* Copy the counter block to host (refreshes it first). */
 int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]);
+/* Fold the engine's sharded decision counters into the device-resident counter
+ * block (asynchronous on the stream).  Call before reading the block through
+ * tc_counters_device_ptr, e.g. right before the RCCL all-gather. */
+int tc_counters_refresh(tc_engine* e);
 /* Per-stage timing of the batch pipeline with HIP events recorded on the
  * engine's stream between its kernels (diagnostics for the roofline report;
  * leave off in production -- every event is an extra stream operation). */

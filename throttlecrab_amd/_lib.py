@@ -62,6 +62,7 @@ SYMBOLS = {
                                 C.c_int64, C.POINTER(tc_result)]),
     "tc_sweep_expired": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]),
     "tc_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "tc_counters_refresh": (C.c_int, [C.c_void_p]),
     "tc_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "tc_profile_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "tc_counters_device_ptr": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -67,6 +67,16 @@ struct __attribute__((aligned(16))) Rate {
     int64_t dvt;
 };
 
+// One resident key = one 32-byte record: the mutable cell followed by its
+// registered rate.  A decision gathers ONE record (two global_load_dwordx4 from
+// the same 128-byte fabric request) instead of touching a line per column:
+// measured on MI355X the separate-column layout fetched 3 x 128 B lines per
+// decision (profiles/r01_v1_uniform_1M.txt), this one fetches one.
+struct __attribute__((aligned(32))) Slot {
+    Cell cell;
+    Rate rate;
+};
+
 // rate_limiter.rs:119-123,154-155: ei and dvt from (burst, count, period).
 // Returns ST_OK / ST_INVALID_RATE_LIMIT / ST_INTERNAL (Duration*u32 overflow,
 // where the reference panics).

@@ -1,0 +1,278 @@
+// radix_sort.hpp -- stable LSD radix sort of one batch's (slot, request index)
+// pairs for gfx950, hand-written (no rocPRIM): 8-bit digits, one histogram
+// kernel for all passes + one "onesweep" kernel per pass with decoupled
+// look-back between tiles (single launch per pass, no inter-kernel scan).
+//
+// Element = u64 (slot << 32 | request index); only the slot bits are sorted
+// on, so equal slots keep ascending request index (stability is what gives the
+// reference's sequential order inside a key, rate_limiter.rs:102-250 applied in
+// queue order, throttlecrab-server/src/actor.rs:217-236).
+//
+// Wave64 specifics: ranking uses 64-bit __ballot match masks (8 ballots per
+// 8-bit digit) and per-wave LDS digit counters; no 32-lane assumptions.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#ifndef RS_ABLATE
+#define RS_ABLATE 0 // tools/sortbench.hip sets 1..4 to time the kernel with phases cut off
+#endif
+
+namespace rs {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / 64;
+constexpr int HIST_THREADS = 1024; // k_hist: few big blocks -> few global atomics per histogram line
+constexpr int HIST_BLOCKS = 128;
+constexpr int RADIX = 256;
+constexpr int MAX_PASSES = 4;
+constexpr int LB_WINDOW = 8;       // predecessors examined per look-back round trip
+constexpr uint32_t RESIDENT_TILES = 1024; // <= this many tiles are co-resident on 256 CUs (>= 4 blocks/CU)
+
+constexpr uint32_t FLAG_PARTIAL = 1u << 30;
+constexpr uint32_t FLAG_INCLUSIVE = 2u << 30;
+constexpr uint32_t FLAG_MASK = 3u << 30;
+constexpr uint32_t VALUE_MASK = ~FLAG_MASK;
+
+// Scratch the sort needs, laid out in one device allocation.
+struct Workspace {
+    uint32_t* hist;      // [MAX_PASSES][RADIX] digit histograms of this batch (zero on entry)
+    uint32_t* hist_next; // the other parity's histograms: cleared here for the next batch
+    uint32_t* ticket;  // [MAX_PASSES] dynamic tile ids (forward progress for the look-back)
+    uint32_t* status;  // [MAX_PASSES][max_tiles][RADIX] look-back words (flag | count)
+    uint32_t max_tiles;
+};
+
+__device__ __forceinline__ uint32_t clamp_slot(uint32_t s, uint32_t cap) { return s < cap ? s : cap; }
+
+// ---------------------------------------------------------------------------
+// histogram of every pass's digit in one read of the slot column; also clears
+// the look-back state of this sort (so no separate memset launches)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
+                                                  int passes, Workspace ws, uint32_t tiles) {
+    __shared__ uint32_t s_h[MAX_PASSES][RADIX];
+    for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += HIST_THREADS) (&s_h[0][0])[i] = 0;
+    // clear look-back words for `tiles` tiles of every pass + tickets
+    const uint32_t total_status = (uint32_t)passes * tiles * RADIX;
+    for (uint32_t i = blockIdx.x * HIST_THREADS + threadIdx.x; i < total_status; i += gridDim.x * HIST_THREADS) {
+        const uint32_t p = i / (tiles * RADIX), r = i % (tiles * RADIX);
+        ws.status[(size_t)p * ws.max_tiles * RADIX + r] = 0;
+    }
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < MAX_PASSES) ws.ticket[threadIdx.x] = 0;
+        for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += HIST_THREADS) ws.hist_next[i] = 0;
+    }
+    __syncthreads();
+    {
+        // 4 independent loads in flight per lane (the loop is latency-, not bandwidth-bound)
+        const uint32_t stride = gridDim.x * HIST_THREADS;
+        uint32_t i = blockIdx.x * HIST_THREADS + threadIdx.x;
+        for (; i + 3 * stride < n; i += 4 * stride) {
+            uint32_t k[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) k[u] = slot[i + u * stride];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t kk = clamp_slot(k[u], cap);
+                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+            }
+        }
+        for (; i < n; i += stride) {
+            const uint32_t kk = clamp_slot(slot[i], cap);
+            for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS) {
+        const uint32_t v = (&s_h[0][0])[i];
+        if (v) atomicAdd(&ws.hist[i], v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// one LSD pass.  FIRST: input is the raw slot column (value = position).
+// ---------------------------------------------------------------------------
+template <int ITEMS, bool FIRST>
+__global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict__ slot_in,
+                                                      const uint64_t* __restrict__ elem_in,
+                                                      uint64_t* __restrict__ elem_out, uint32_t n, uint32_t cap,
+                                                      int pass, Workspace ws) {
+    constexpr int TILE = THREADS * ITEMS;
+    __shared__ uint32_t s_base[RADIX];          // global exclusive start of each digit
+    __shared__ uint32_t s_wave[WAVES][RADIX];   // per-wave digit counts -> exclusive prefix over waves
+    __shared__ uint32_t s_off[RADIX];           // where this tile's run of each digit starts
+    __shared__ uint32_t s_tstart[RADIX];        // where each digit's run starts inside this tile
+    __shared__ uint64_t s_elem[TILE];           // the tile in sorted order (coalesced write-out)
+    __shared__ uint32_t s_scan[WAVES];
+    __shared__ uint32_t s_tile;
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // Tile order must guarantee that every predecessor a tile waits for is running.
+    // With <= RESIDENT_TILES tiles the whole grid is co-resident, so blockIdx will do;
+    // beyond that, tiles take a ticket (one contended atomic per block: ~12 ns each).
+    if (threadIdx.x == 0) s_tile = (gridDim.x <= RESIDENT_TILES) ? blockIdx.x : atomicAdd(&ws.ticket[pass], 1u);
+    for (int i = threadIdx.x; i < WAVES * RADIX; i += THREADS) (&s_wave[0][0])[i] = 0;
+
+    // exclusive scan of the batch histogram of this pass's digit (RADIX == THREADS)
+    {
+        const uint32_t h = ws.hist[pass * RADIX + threadIdx.x];
+        uint32_t v = h;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(v, off, 64);
+            if (lane >= off) v += o;
+        }
+        if (lane == 63) s_scan[wave] = v;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int w = 0; w < wave; ++w) carry += s_scan[w];
+        s_base[threadIdx.x] = carry + v - h;
+    }
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const uint32_t shift = 8u * (uint32_t)pass;
+
+    // wave-striped tile: item j of lane l of wave w sits at tile*TILE + w*64*ITEMS + j*64 + l
+    uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+    const uint32_t wbase = tile * TILE + wave * 64 * ITEMS + lane;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t pos = wbase + j * 64;
+        if (pos < n) {
+            if (FIRST) {
+                key[j] = clamp_slot(slot_in[pos], cap);
+                val[j] = pos;
+            } else {
+                const uint64_t e = elem_in[pos];
+                key[j] = (uint32_t)(e >> 32);
+                val[j] = (uint32_t)e;
+            }
+        } else {
+            key[j] = 0xFFFFFFFFu;
+            val[j] = 0;
+        }
+    }
+    if (RS_ABLATE == 1) { // loads only
+        uint32_t acc = 0;
+        for (int j = 0; j < ITEMS; ++j) acc ^= key[j] ^ val[j];
+        if (acc == 0x12345678u) elem_out[0] = acc;
+        return;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const bool valid = (wbase + j * 64) < n;
+        const uint32_t d = (key[j] >> shift) & 255u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        // m = lanes of this wave (this round) holding the same digit
+        const uint32_t before = valid ? s_wave[wave][d] : 0u; // all lanes read, then the leader adds
+        rank[j] = before + (uint32_t)__popcll(m & lt);
+        if (valid && (m & lt) == 0ull) s_wave[wave][d] = before + (uint32_t)__popcll(m);
+        // same-wave LDS ops execute in program order: the next round's read follows this write
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    if (RS_ABLATE == 2) { // + ranking
+        uint32_t acc = 0;
+        for (int j = 0; j < ITEMS; ++j) acc ^= rank[j];
+        if (acc == 0x12345678u) elem_out[0] = acc;
+        return;
+    }
+    // digit = threadIdx.x: prefix over waves -> tile count; tile-local digit starts
+    uint32_t run = 0;
+    {
+        const int d = threadIdx.x;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = s_wave[w][d];
+            s_wave[w][d] = run;
+            run += c;
+        }
+        // publish this tile's digit counts right away so successors can look back
+        uint32_t* st = ws.status + (size_t)pass * ws.max_tiles * RADIX;
+        __hip_atomic_store(&st[(size_t)tile * RADIX + d], (tile == 0 ? FLAG_INCLUSIVE : FLAG_PARTIAL) | run,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t v = run;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(v, off, 64);
+            if (lane >= off) v += o;
+        }
+        if (lane == 63) s_scan[wave] = v;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int w = 0; w < wave; ++w) carry += s_scan[w];
+        s_tstart[d] = carry + v - run;
+    }
+    __syncthreads();
+
+    // stage the tile in LDS in its sorted order: the global writes below are then
+    // contiguous per digit run (full lines) instead of 4096 scattered 8-byte stores
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((wbase + j * 64) < n) {
+            const uint32_t d = (key[j] >> shift) & 255u;
+            s_elem[s_tstart[d] + s_wave[wave][d] + rank[j]] = ((uint64_t)key[j] << 32) | val[j];
+        }
+    }
+
+    // look back for the exclusive prefix of each digit over the preceding tiles
+    {
+        const int d = threadIdx.x;
+        uint32_t* st = ws.status + (size_t)pass * ws.max_tiles * RADIX;
+        uint32_t excl = 0;
+        if (tile != 0 && RS_ABLATE != 3) {
+            // LB_WINDOW predecessors per round trip (independent loads in flight): all
+            // tiles of a 1 Mi batch start together, so a one-at-a-time walk would
+            // serialise ~tiles L2 round trips on the last tile
+            int t = (int)tile - 1;
+            while (true) {
+                uint32_t s[LB_WINDOW];
+#pragma unroll
+                for (int u = 0; u < LB_WINDOW; ++u)
+                    s[u] = (t - u >= 0) ? __hip_atomic_load(&st[(size_t)(t - u) * RADIX + d], __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT)
+                                        : FLAG_INCLUSIVE; // virtual tile -1: inclusive prefix 0
+                bool done = false;
+                int used = 0;
+#pragma unroll
+                for (int u = 0; u < LB_WINDOW; ++u) {
+                    if (done || used < u) continue;
+                    const uint32_t f = s[u] & FLAG_MASK;
+                    if (f == 0) continue; // not published yet: retry from here
+                    excl += s[u] & VALUE_MASK;
+                    used = u + 1;
+                    done = (f == FLAG_INCLUSIVE);
+                }
+                if (done) break;
+                t -= used;
+                if (used == 0) __builtin_amdgcn_s_sleep(1);
+            }
+            __hip_atomic_store(&st[(size_t)tile * RADIX + d], FLAG_INCLUSIVE | (excl + run), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_off[d] = s_base[d] + excl - s_tstart[d]; // global position = tile-local position + this
+    }
+    __syncthreads();
+
+    if (RS_ABLATE == 4) return; // everything but the write-out
+    const uint32_t tile_first = tile * TILE;
+    const uint32_t nvalid = (n - tile_first) < (uint32_t)TILE ? (n - tile_first) : (uint32_t)TILE;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t i = j * THREADS + threadIdx.x;
+        if (i < nvalid) {
+            const uint64_t e = s_elem[i];
+            const uint32_t d = ((uint32_t)(e >> 32) >> shift) & 255u;
+            elem_out[i + s_off[d]] = e;
+        }
+    }
+}
+
+} // namespace rs

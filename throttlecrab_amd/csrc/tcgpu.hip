@@ -1,19 +1,17 @@
 // tcgpu.hip -- MI355X (gfx950) batched GCRA engine: HIP kernels + the C ABI of
 // include/tcgpu.h.  One engine = one GPU-resident key store:
 //
-//   cells[capacity]   {tat i64, expiry u64}   16 B / slot   (mutable state)
-//   rates[capacity]   {ei i64, dvt i64}       16 B / slot   (registered params)
-//   bursts[capacity]  i64                      8 B / slot   (limit, result only)
+//   table[capacity]   Slot {tat i64, expiry u64, ei i64, dvt i64}  32 B / key
+//   bursts[capacity]  i64   burst capacity (= `limit` of the result)  8 B / key
 //
 // A batch is applied with the reference's sequential semantics
 // (throttlecrab/src/core/rate_limiter.rs:102-250 applied in index order):
-//   unique slots  : k_eval_unique        one lane per request
-//   duplicates    : k_prep -> radix sort (slot, index) -> k_eval_sorted
-//                   (closed form for uniform runs, serial walk otherwise)
-//                   -> k_commit
+//   unique slots : k_eval_unique   one lane per request
+//   duplicates   : rs::k_hist + rs::k_onesweep x passes  (stable (slot,index) sort)
+//                  k_eval_sorted   closed form for uniform runs / serial walk
+//                  k_commit_list   the few cells whose segment spans waves
 // HBM-bound integer work; MFMA is not used (no dense contraction).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
 
 #include <algorithm>
 #include <cstdio>
@@ -24,15 +22,19 @@
 
 #include "../../include/tcgpu.h"
 #include "gcra_math.hpp"
+#include "radix_sort.hpp"
 
 using tc::Cell;
 using tc::Decision;
 using tc::Rate;
+using tc::Slot;
 
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr uint32_t F_REGISTERED = 1u; // Params.flags
+constexpr int SORT_ITEMS = 16; // items per thread of a sort tile (tile = 4096 requests)
+constexpr uint32_t F_REGISTERED = 1u; // Params.flags: per-slot registered rate
+constexpr uint32_t F_NEED_BURST = 2u; // read bursts[] (limit wanted, or not every slot registered)
 
 // ---------------------------------------------------------------------------
 // kernel argument block
@@ -53,8 +55,7 @@ struct Params {
     int64_t* reset;
     int64_t* retry;
     uint8_t* status;
-    Cell* cells;
-    const Rate* rates;
+    Slot* table;
     const int64_t* bursts;
     uint64_t capacity;
     unsigned long long* counters;
@@ -65,7 +66,8 @@ struct Req {
     int status;
 };
 
-__device__ __forceinline__ Req load_req(const Params& p, uint32_t i, uint32_t slot) {
+// Request i against `slot`, whose record `rec` is already in registers.
+__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot, const Rate& rate) {
     Req r;
     r.q = p.q ? p.q[i] : p.q_s;
     r.now = p.now ? p.now[i] : p.now_s;
@@ -75,12 +77,11 @@ __device__ __forceinline__ Req load_req(const Params& p, uint32_t i, uint32_t sl
         return r;
     }
     if (p.flags & F_REGISTERED) {
-        const Rate rt = p.rates[slot];
-        r.limit = p.bursts[slot];
-        r.ei = rt.ei;
-        r.dvt = rt.dvt;
-        if (r.q < 0) r.status = tc::ST_NEGATIVE_QUANTITY;          // rate_limiter.rs:111
-        else if (r.limit <= 0) r.status = tc::ST_INVALID_RATE_LIMIT; // never registered
+        r.ei = rate.ei;
+        r.dvt = rate.dvt;
+        r.limit = (p.flags & F_NEED_BURST) ? p.bursts[slot] : 1;
+        if (r.q < 0) r.status = tc::ST_NEGATIVE_QUANTITY;            // rate_limiter.rs:111
+        else if (r.limit <= 0) r.status = tc::ST_INVALID_RATE_LIMIT; // slot never registered
         else r.status = tc::check_request(r.q, r.now, r.dvt);
     } else {
         const int64_t burst = p.burst ? p.burst[i] : p.burst_s;
@@ -102,7 +103,14 @@ __device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req
     if (p.retry) p.retry[i] = ok ? d.retry_after : 0;
 }
 
-// sum three small per-thread counts over the block, one atomic each per block
+// Decision counters are accumulated in NSHARD shards (block b -> shard b % NSHARD):
+// a device-scope atomic on ONE address costs ~12 ns and serialises, so 4096
+// blocks hitting one counter would add ~50 us to a 1 Mi-request batch.
+// k_fold_counters sums the shards into the canonical TC_CNT_* block on demand.
+constexpr int NSHARD = 256;
+constexpr int SHARD_WORDS = 4; // allowed, denied, errors, pad
+
+// sum three per-thread counts over the block, one atomic each per block
 __device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c, unsigned long long* counters) {
     __shared__ uint32_t s_cnt[3][BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
@@ -121,9 +129,8 @@ __device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c,
         uint32_t t = 0;
         for (int w = 0; w < BLOCK / 64; ++w) t += s_cnt[threadIdx.x][w];
         if (t) {
-            const int which = threadIdx.x == 0 ? TC_CNT_ALLOWED : (threadIdx.x == 1 ? TC_CNT_DENIED : TC_CNT_ERRORS);
-            atomicAdd(&counters[which], (unsigned long long)t);
-            atomicAdd(&counters[TC_CNT_TOTAL], (unsigned long long)t);
+            unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + (blockIdx.x % NSHARD) * SHARD_WORDS;
+            atomicAdd(&shard[threadIdx.x], (unsigned long long)t);
         }
     }
 }
@@ -137,14 +144,19 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
     uint32_t na = 0, nd = 0, ne = 0;
     if (i < p.n) {
         const uint32_t slot = p.slot[i];
-        const Req r = load_req(p, i, slot);
+        Slot rec;
+        rec.cell.tat = 0;
+        rec.cell.expiry = 0;
+        rec.rate.ei = rec.rate.dvt = 0;
+        if (slot < p.capacity) rec = p.table[slot];
+        const Req r = make_req(p, i, slot, rec.rate);
         Decision d;
         d.allowed = false;
         d.remaining = d.reset_after = d.retry_after = 0;
         if (r.status == tc::ST_OK) {
-            Cell c = p.cells[slot];
+            Cell c = rec.cell;
             d = tc::gcra_step<FULL>(c, r.ei, r.dvt, r.q, r.now);
-            if (d.allowed) p.cells[slot] = c;
+            if (d.allowed) p.table[slot].cell = c;
             na = d.allowed;
             nd = !d.allowed;
         } else {
@@ -153,19 +165,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
         write_out(p, i, r, d);
     }
     block_count3(na, nd, ne, p.counters);
-}
-
-// ---------------------------------------------------------------------------
-// K2a: sort keys = min(slot, capacity) (one sentinel segment for bad slots)
-// ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_prep(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
-                                                uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        const uint32_t s = slot[i];
-        keys[i] = s < cap ? s : cap;
-        vals[i] = i;
-    }
 }
 
 // block-wide inclusive max-scan (values are position+1, 0 = none)
@@ -183,39 +182,51 @@ __device__ __forceinline__ uint32_t block_scan_max(uint32_t v) {
     return max(v, carry);
 }
 
+// Deferred cell store for a segment that spans waves (see k_eval_sorted).
+struct __attribute__((aligned(16))) PendEntry {
+    Cell cell;
+    uint32_t slot;
+    uint32_t pad[3];
+};
+
 // ---------------------------------------------------------------------------
-// K2b: evaluate over the (slot, index)-sorted batch.
+// K2: evaluate over the (slot, index)-sorted batch; one lane per sorted position.
 //   UNIFORM (one `now`, one `quantity`, per-slot or scalar params): every
-//     request of a slot's segment is identical, so lane r of the segment
-//     derives the state left by its r predecessors in closed form
-//     (tc::run_form) and applies the ordinary step to it.  The single lane
-//     that performs the segment's last allowed step parks the new cell in
-//     pend[] (k_commit stores it) so that no lane of the segment can read a
-//     half-updated cell.
+//     request of a slot's segment is identical, so lane r of the segment derives
+//     the cell left by its r predecessors in closed form (tc::run_form) and
+//     applies the ordinary step to it.  Exactly one lane per segment -- the one
+//     performing the last allowed step -- produces the new cell.  If the whole
+//     segment sits inside this wave the lane stores it directly (every lane of
+//     the segment loaded the old cell earlier in program order); otherwise the
+//     store is parked in pend[] and applied by k_commit_list after this kernel,
+//     so no lane of another wave can read a half-updated cell.
 //   otherwise: the segment head walks its segment in index order.
 // ---------------------------------------------------------------------------
 template <bool FULL, bool UNIFORM>
-__global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint32_t* __restrict__ ss,
-                                                       const uint32_t* __restrict__ si, Cell* __restrict__ pend,
-                                                       uint8_t* __restrict__ pend_flag) {
+__global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
+                                                       PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count) {
     const uint32_t n = p.n;
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = k < n;
-    const uint32_t slot = valid ? ss[k] : 0xFFFFFFFFu;
-    const bool head = valid && (k == 0 || ss[k - 1] != slot);
+    const uint64_t me = valid ? sorted[k] : ~0ull;
+    const uint32_t slot = (uint32_t)(me >> 32);
+    const uint32_t idx = (uint32_t)me;
+    const bool head = valid && (k == 0 || (uint32_t)(sorted[k - 1] >> 32) != slot);
     uint32_t na = 0, nd = 0, ne = 0;
 
     if (!UNIFORM) {
         if (head) {
-            Cell c;
-            c.tat = 0;
-            c.expiry = 0;
+            Slot rec;
+            rec.cell.tat = 0;
+            rec.cell.expiry = 0;
+            rec.rate.ei = rec.rate.dvt = 0;
             const bool in_range = slot < p.capacity;
-            if (in_range) c = p.cells[slot];
+            if (in_range) rec = p.table[slot];
+            Cell c = rec.cell;
             bool dirty = false;
-            for (uint32_t j = k; j < n && ss[j] == slot; ++j) {
-                const uint32_t i = si[j];
-                const Req r = load_req(p, i, slot);
+            uint32_t i = idx;
+            for (uint32_t j = k;;) {
+                const Req r = make_req(p, i, slot, rec.rate);
                 Decision d;
                 d.allowed = false;
                 d.remaining = d.reset_after = d.retry_after = 0;
@@ -228,66 +239,82 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint32_t*
                     ne += 1;
                 }
                 write_out(p, i, r, d);
+                if (++j >= n) break;
+                const uint64_t nx = sorted[j];
+                if ((uint32_t)(nx >> 32) != slot) break;
+                i = (uint32_t)nx;
             }
-            if (dirty) p.cells[slot] = c;
+            if (dirty) p.table[slot].cell = c;
         }
         block_count3(na, nd, ne, p.counters);
         return;
     }
 
-    // ---- UNIFORM: rank of this lane inside its segment ----
+    // ---- UNIFORM ----
+    const bool is_last = valid && ((k + 1 == n) || ((uint32_t)(sorted[k + 1] >> 32) != slot));
     __shared__ uint32_t s_start;
     const uint32_t block_start = blockIdx.x * BLOCK;
     if (threadIdx.x == 0 && valid && !head) {
-        // segment of ss[block_start] began in an earlier block: lower_bound
+        // segment of sorted[block_start] began in an earlier block: lower_bound on the slot
         uint32_t lo = 0, hi = block_start;
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
-            if (ss[mid] < slot) lo = mid + 1;
+            if ((uint32_t)(sorted[mid] >> 32) < slot) lo = mid + 1;
             else hi = mid;
         }
         s_start = lo;
     }
-    const uint32_t hp = block_scan_max(head ? k + 1 : 0u); // has a __syncthreads()
+    const uint32_t hp = block_scan_max(head ? k + 1 : 0u); // contains a __syncthreads()
     const uint32_t seg_start = hp ? hp - 1 : s_start;
+    // does my whole segment live inside this wave?
+    const int lane = threadIdx.x & 63;
+    const unsigned long long heads = __ballot(head), lasts = __ballot(is_last);
+    const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const bool seg_in_wave = ((heads & upto) != 0ull) && ((lasts >> lane) != 0ull);
+
     bool writer = false;
     Cell wcell;
     wcell.tat = 0;
     wcell.expiry = 0;
     if (valid) {
         const uint32_t r = k - seg_start;
-        const bool is_last = (k + 1 == n) || (ss[k + 1] != slot);
-        const uint32_t i = si[k];
-        const Req rq = load_req(p, i, slot);
+        Slot rec;
+        rec.cell.tat = 0;
+        rec.cell.expiry = 0;
+        rec.rate.ei = rec.rate.dvt = 0;
+        if (slot < p.capacity) rec = p.table[slot];
+        const Req rq = make_req(p, idx, slot, rec.rate);
         Decision d;
         d.allowed = false;
         d.remaining = d.reset_after = d.retry_after = 0;
         if (rq.status != tc::ST_OK) {
             ne = 1;
-            write_out(p, i, rq, d);
+            write_out(p, idx, rq, d);
         } else {
-            Cell c = p.cells[slot];
+            Cell c = rec.cell;
             const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
             if (!d0.allowed) {
-                // request 0 denied => state untouched => every request of the run is request 0
+                // request 0 denied => state untouched => every request of the run equals request 0
                 nd = 1;
-                write_out(p, i, rq, d0);
+                write_out(p, idx, rq, d0);
             } else {
                 const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
                 if (r == 0) {
                     na = 1;
-                    write_out(p, i, rq, d0);
+                    write_out(p, idx, rq, d0);
                     if (is_last || (f.regular && f.n_tot == 1)) {
                         writer = true;
                         wcell = c;
                     } else if (!f.regular) {
                         // irregular run (saturation, zero increment, immediate expiry):
                         // walk the rest of the segment one request at a time
-                        for (uint32_t j = k + 1; j < n && ss[j] == slot; ++j) {
+                        for (uint32_t j = k + 1; j < n; ++j) {
+                            const uint64_t nx = sorted[j];
+                            if ((uint32_t)(nx >> 32) != slot) break;
                             const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
                             na += dj.allowed;
                             nd += !dj.allowed;
-                            write_out(p, si[j], rq, dj);
+                            write_out(p, (uint32_t)nx, rq, dj);
                         }
                         writer = true;
                         wcell = c;
@@ -300,7 +327,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint32_t*
                     d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
                     na = d.allowed;
                     nd = !d.allowed;
-                    write_out(p, i, rq, d);
+                    write_out(p, idx, rq, d);
                     if (d.allowed && (is_last || (int64_t)r + 1 == f.n_tot)) {
                         writer = true;
                         wcell = v;
@@ -309,17 +336,58 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint32_t*
                 // irregular && r > 0: the head lane produced this request's outputs
             }
         }
-        pend_flag[k] = writer ? 1 : 0;
-        if (writer) pend[k] = wcell;
+    }
+    if (writer) {
+        if (seg_in_wave) {
+            p.table[slot].cell = wcell;
+        } else {
+            const uint32_t at = atomicAdd(pend_count, 1u);
+            PendEntry pe;
+            pe.cell = wcell;
+            pe.slot = slot;
+            pe.pad[0] = pe.pad[1] = pe.pad[2] = 0;
+            pend[at] = pe;
+        }
     }
     block_count3(na, nd, ne, p.counters);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_commit(const uint32_t* __restrict__ ss, uint32_t n,
-                                                  const Cell* __restrict__ pend, const uint8_t* __restrict__ pend_flag,
-                                                  Cell* __restrict__ cells) {
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    if (k < n && pend_flag[k]) cells[ss[k]] = pend[k];
+__global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restrict__ pend,
+                                                       uint32_t* __restrict__ pend_count, Slot* __restrict__ table) {
+    // pend_count[0] = entries, pend_count[1] = blocks of this launch that are done
+    const uint32_t cnt = pend_count[0];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < cnt; i += gridDim.x * BLOCK) {
+        const PendEntry pe = pend[i];
+        table[pe.slot].cell = pe.cell;
+    }
+    __syncthreads(); // every lane of this block has consumed `cnt`
+    if (threadIdx.x == 0) {
+        // the last block to finish re-arms the list for the next batch (no extra launch)
+        if (atomicAdd(&pend_count[1], 1u) == gridDim.x - 1) {
+            pend_count[0] = 0;
+            pend_count[1] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NSHARD) void k_fold_counters(unsigned long long* counters) {
+    __shared__ unsigned long long s[3][NSHARD / 64];
+    const unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + threadIdx.x * SHARD_WORDS;
+    unsigned long long v[3] = {shard[0], shard[1], shard[2]};
+    for (int off = 32; off > 0; off >>= 1)
+        for (int j = 0; j < 3; ++j) v[j] += __shfl_down(v[j], off, 64);
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < 3; ++j) s[j][threadIdx.x >> 6] = v[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t[3] = {0, 0, 0};
+        for (int j = 0; j < 3; ++j)
+            for (int w = 0; w < NSHARD / 64; ++w) t[j] += s[j][w];
+        counters[TC_CNT_ALLOWED] = t[0];
+        counters[TC_CNT_DENIED] = t[1];
+        counters[TC_CNT_ERRORS] = t[2];
+        counters[TC_CNT_TOTAL] = t[0] + t[1] + t[2];
+    }
 }
 
 // allowed[] bytes -> bitmask (wavefront ballot, one u64 per wave)
@@ -334,16 +402,16 @@ __global__ __launch_bounds__(BLOCK) void k_pack_bits(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------
 // K4: expiry sweep == AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint64_t capacity, int64_t now,
+__global__ __launch_bounds__(BLOCK) void k_sweep(Slot* __restrict__ table, uint64_t capacity, int64_t now,
                                                  unsigned long long* counters, unsigned long long* removed_out) {
     uint32_t removed = 0, live = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        Cell c = cells[i];
+        Cell c = table[i].cell;
         if (c.expiry != 0) {
             if (!(c.expiry > (uint64_t)now)) { // retain(|exp| *exp > now)
                 c.tat = 0;
                 c.expiry = 0;
-                cells[i] = c;
+                table[i].cell = c;
                 removed++;
             } else {
                 live++;
@@ -374,21 +442,21 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint6
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_fill_rates(Rate* __restrict__ rates, int64_t* __restrict__ bursts,
+__global__ __launch_bounds__(BLOCK) void k_fill_rates(Slot* __restrict__ table, int64_t* __restrict__ bursts,
                                                       uint64_t capacity, Rate r, int64_t burst) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        rates[i] = r;
+        table[i].rate = r;
         bursts[i] = burst;
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_scatter_rates(Rate* __restrict__ rates, int64_t* __restrict__ bursts,
+__global__ __launch_bounds__(BLOCK) void k_scatter_rates(Slot* __restrict__ table, int64_t* __restrict__ bursts,
                                                          const uint32_t* __restrict__ slots, const Rate* __restrict__ src_r,
                                                          const int64_t* __restrict__ src_b, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) {
         const uint64_t s = slots ? slots[i] : i;
-        rates[s] = src_r[i];
+        table[s].rate = src_r[i];
         bursts[s] = src_b[i];
     }
 }
@@ -400,10 +468,10 @@ struct StoreOpResult {
     int32_t flag;
     int32_t pad;
 };
-__global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
+__global__ void k_store_op(Slot* table, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
                            StoreOpResult* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Cell c = cells[slot];
+    Cell c = table[slot].cell;
     const bool live = c.expiry > (uint64_t)now;
     StoreOpResult r;
     r.value = 0;
@@ -420,14 +488,14 @@ __global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_
         if (live && c.tat == a) {
             c.tat = b;
             c.expiry = e;
-            cells[slot] = c;
+            table[slot].cell = c;
             r.flag = 1;
         }
     } else {
         if (!live) {
             c.tat = a;
             c.expiry = e;
-            cells[slot] = c;
+            table[slot].cell = c;
             r.flag = 1;
         }
     }
@@ -456,17 +524,18 @@ struct tc_engine {
     uint64_t capacity = 0, max_batch = 0;
     uint32_t cfg_flags = 0;
 
-    Cell* cells = nullptr;
-    Rate* rates = nullptr;
+    Slot* table = nullptr;
     int64_t* bursts = nullptr;
-    unsigned long long* counters = nullptr; // TC_CNT_COUNT + 1 (scratch word)
+    bool all_registered = false;
+    unsigned long long* counters = nullptr; // TC_CNT_COUNT canonical + 1 scratch + NSHARD*SHARD_WORDS shards
 
-    // grouping scratch (max_batch each)
-    uint32_t *keys_a = nullptr, *keys_b = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    void* sort_tmp = nullptr;
-    size_t sort_tmp_bytes = 0;
-    Cell* pend = nullptr;
-    uint8_t* pend_flag = nullptr;
+    // grouping scratch
+    uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
+    uint32_t* sort_ws = nullptr;                   // hist x2 | ticket | status
+    uint32_t sort_max_tiles = 0;
+    uint32_t hist_parity = 0;
+    PendEntry* pend = nullptr;
+    uint32_t* pend_count = nullptr;
     uint8_t* allowed_tmp = nullptr;
     StoreOpResult* op_result = nullptr;
 
@@ -526,32 +595,33 @@ extern "C" uint32_t tc_abi_version(void) { return TCGPU_ABI_VERSION; }
 
 extern "C" const char* tc_last_error(const tc_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
+static size_t sort_ws_words(uint32_t max_tiles) {
+    return (size_t)2 * rs::MAX_PASSES * rs::RADIX + rs::MAX_PASSES + (size_t)rs::MAX_PASSES * max_tiles * rs::RADIX;
+}
+
 static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipSetDevice(e->device));
     TC_HIP(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
     e->stream = e->own_stream;
     const uint64_t cap = e->capacity, mb = e->max_batch;
-    TC_HIP(e, hipMalloc(&e->cells, cap * sizeof(Cell)));
-    TC_HIP(e, hipMalloc(&e->rates, cap * sizeof(Rate)));
+    TC_HIP(e, hipMalloc(&e->table, cap * sizeof(Slot)));
     TC_HIP(e, hipMalloc(&e->bursts, cap * sizeof(int64_t)));
-    TC_HIP(e, hipMalloc(&e->counters, (TC_CNT_COUNT + 1) * sizeof(unsigned long long)));
-    TC_HIP(e, hipMemsetAsync(e->cells, 0, cap * sizeof(Cell), e->stream));
-    TC_HIP(e, hipMemsetAsync(e->rates, 0, cap * sizeof(Rate), e->stream));
+    const size_t cnt_words = (TC_CNT_COUNT + 1) + (size_t)NSHARD * SHARD_WORDS;
+    TC_HIP(e, hipMalloc(&e->counters, cnt_words * sizeof(unsigned long long)));
+    TC_HIP(e, hipMemsetAsync(e->table, 0, cap * sizeof(Slot), e->stream));
     TC_HIP(e, hipMemsetAsync(e->bursts, 0, cap * sizeof(int64_t), e->stream));
-    TC_HIP(e, hipMemsetAsync(e->counters, 0, (TC_CNT_COUNT + 1) * sizeof(unsigned long long), e->stream));
-    TC_HIP(e, hipMalloc(&e->keys_a, mb * sizeof(uint32_t)));
-    TC_HIP(e, hipMalloc(&e->keys_b, mb * sizeof(uint32_t)));
-    TC_HIP(e, hipMalloc(&e->vals_a, mb * sizeof(uint32_t)));
-    TC_HIP(e, hipMalloc(&e->vals_b, mb * sizeof(uint32_t)));
-    TC_HIP(e, hipMalloc(&e->pend, mb * sizeof(Cell)));
-    TC_HIP(e, hipMalloc(&e->pend_flag, mb));
+    TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), e->stream));
+    TC_HIP(e, hipMalloc(&e->elem_a, mb * sizeof(uint64_t)));
+    TC_HIP(e, hipMalloc(&e->elem_b, mb * sizeof(uint64_t)));
+    e->sort_max_tiles = (uint32_t)((mb + rs::THREADS * SORT_ITEMS - 1) / (rs::THREADS * SORT_ITEMS));
+    const size_t words = sort_ws_words(e->sort_max_tiles);
+    TC_HIP(e, hipMalloc(&e->sort_ws, words * sizeof(uint32_t)));
+    TC_HIP(e, hipMemsetAsync(e->sort_ws, 0, words * sizeof(uint32_t), e->stream));
+    TC_HIP(e, hipMalloc(&e->pend, (mb / 32 + 1024) * sizeof(PendEntry)));
+    TC_HIP(e, hipMalloc(&e->pend_count, 2 * sizeof(uint32_t)));
+    TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), e->stream));
     TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
     TC_HIP(e, hipMalloc(&e->op_result, sizeof(StoreOpResult)));
-    size_t tmp = 0;
-    TC_HIP(e, hipcub::DeviceRadixSort::SortPairs(nullptr, tmp, e->keys_a, e->keys_b, e->vals_a, e->vals_b,
-                                                 (int)mb, 0, 32, e->stream));
-    e->sort_tmp_bytes = tmp;
-    TC_HIP(e, hipMalloc(&e->sort_tmp, tmp ? tmp : 16));
     TC_HIP(e, hipStreamSynchronize(e->stream));
     return TC_E_OK;
 }
@@ -561,7 +631,7 @@ extern "C" tc_engine* tc_engine_create(const tc_config* cfg, int* err) {
     if (!err) err = &dummy;
     *err = TC_E_OK;
     if (!cfg || cfg->struct_size < sizeof(tc_config) || cfg->capacity == 0 || cfg->max_batch == 0 ||
-        cfg->capacity >= 0x7FFFFFFFull || cfg->max_batch >= 0x7FFFFFFFull) {
+        cfg->capacity >= 0x7FFFFFFFull || cfg->max_batch >= 0x3FFFFFFFull) {
         *err = TC_E_INVALID_ARG;
         return nullptr;
     }
@@ -598,11 +668,10 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    void* ptrs[] = {e->cells, e->rates, e->bursts, e->counters, e->keys_a, e->keys_b, e->vals_a, e->vals_b,
-                    e->sort_tmp, e->pend, e->pend_flag, e->allowed_tmp, e->op_result, e->stage.slot,
-                    e->stage.in[0], e->stage.in[1], e->stage.in[2], e->stage.in[3], e->stage.in[4],
-                    e->stage.allowed, e->stage.bits, e->stage.out[0], e->stage.out[1], e->stage.out[2],
-                    e->stage.out[3], e->stage.status};
+    void* ptrs[] = {e->table, e->bursts, e->counters, e->elem_a, e->elem_b, e->sort_ws, e->pend, e->pend_count,
+                    e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
+                    e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
+                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
@@ -630,9 +699,10 @@ extern "C" int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64
         return fail(e, TC_E_INVALID_ARG, "tc_register_params_uniform: invalid (burst,count,period)");
     TC_HIP(e, hipSetDevice(e->device));
     hipLaunchKernelGGL(k_fill_rates, dim3(std::min<uint64_t>(nblocks(e->capacity), 4096)), dim3(BLOCK), 0, e->stream,
-                       e->rates, e->bursts, e->capacity, r, max_burst);
+                       e->table, e->bursts, e->capacity, r, max_burst);
     TC_HIP(e, hipGetLastError());
     TC_HIP(e, hipStreamSynchronize(e->stream));
+    e->all_registered = true;
     return TC_E_OK;
 }
 
@@ -657,12 +727,13 @@ extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slot
     TC_HIP(e, hipMemcpyAsync(d_r, hr.data(), n * sizeof(Rate), hipMemcpyHostToDevice, e->stream));
     TC_HIP(e, hipMemcpyAsync(d_b, max_burst, n * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
     if (slots) TC_HIP(e, hipMemcpyAsync(d_s, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_scatter_rates, dim3(nblocks(n)), dim3(BLOCK), 0, e->stream, e->rates, e->bursts, d_s, d_r, d_b, n);
+    hipLaunchKernelGGL(k_scatter_rates, dim3(nblocks(n)), dim3(BLOCK), 0, e->stream, e->table, e->bursts, d_s, d_r, d_b, n);
     TC_HIP(e, hipGetLastError());
     TC_HIP(e, hipStreamSynchronize(e->stream));
     (void)hipFree(d_r);
     (void)hipFree(d_b);
     if (d_s) (void)hipFree(d_s);
+    if (!slots && n == e->capacity) e->all_registered = true;
     return TC_E_OK;
 }
 
@@ -680,12 +751,47 @@ static int stage_ensure(tc_engine* e) {
     return TC_E_OK;
 }
 
+// stable sort of (slot, index) by slot; returns the buffer holding the result
+static const uint64_t* sort_by_slot(tc_engine* e, const uint32_t* d_slot, uint32_t n) {
+    hipStream_t s = e->stream;
+    const uint32_t cap = (uint32_t)e->capacity;
+    const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
+    const int passes = (bits + 7) / 8;
+    const uint32_t tile = rs::THREADS * SORT_ITEMS;
+    const uint32_t tiles = (n + tile - 1) / tile;
+    rs::Workspace ws;
+    uint32_t* base = e->sort_ws;
+    ws.hist = base + (size_t)e->hist_parity * rs::MAX_PASSES * rs::RADIX;
+    ws.hist_next = base + (size_t)(e->hist_parity ^ 1u) * rs::MAX_PASSES * rs::RADIX;
+    ws.ticket = base + (size_t)2 * rs::MAX_PASSES * rs::RADIX;
+    ws.status = ws.ticket + rs::MAX_PASSES;
+    ws.max_tiles = e->sort_max_tiles;
+    e->hist_parity ^= 1u;
+    prof_mark(e, TC_STAGE_PREP);
+    hipLaunchKernelGGL(rs::k_hist, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap,
+                       passes, ws, tiles);
+    prof_mark(e, TC_STAGE_SORT);
+    uint64_t* bufs[2] = {e->elem_a, e->elem_b};
+    const uint64_t* in = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        uint64_t* out = bufs[p & 1];
+        if (p == 0)
+            hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
+                               (const uint64_t*)nullptr, out, n, cap, p, ws);
+        else
+            hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
+                               (const uint32_t*)nullptr, in, out, n, cap, p, ws);
+        in = out;
+    }
+    return in;
+}
+
 // all pointers in `b` are device pointers here
 static int run_slots_device(tc_engine* e, const tc_batch& b) {
     const uint32_t n = (uint32_t)b.n;
     Params p;
     p.n = n;
-    p.flags = (b.flags & TC_B_REGISTERED_PARAMS) ? F_REGISTERED : 0u;
+    p.flags = 0;
     p.slot = b.slot;
     p.burst = b.max_burst;
     p.count = b.count_per_period;
@@ -703,11 +809,14 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     p.reset = b.reset_after_ns;
     p.retry = b.retry_after_ns;
     p.status = b.status;
-    p.cells = e->cells;
-    p.rates = e->rates;
+    p.table = e->table;
     p.bursts = e->bursts;
     p.capacity = e->capacity;
     p.counters = e->counters;
+    if (b.flags & TC_B_REGISTERED_PARAMS) {
+        p.flags |= F_REGISTERED;
+        if (p.limit || !e->all_registered) p.flags |= F_NEED_BURST;
+    }
     const bool full = p.remaining || p.reset || p.retry;
     const dim3 grid(nblocks(n)), block(BLOCK);
     hipStream_t s = e->stream;
@@ -717,24 +826,18 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
         if (full) hipLaunchKernelGGL(k_eval_unique<true>, grid, block, 0, s, p);
         else hipLaunchKernelGGL(k_eval_unique<false>, grid, block, 0, s, p);
     } else {
-        prof_mark(e, TC_STAGE_PREP);
-        hipLaunchKernelGGL(k_prep, grid, block, 0, s, b.slot, n, (uint32_t)e->capacity, e->keys_a, e->vals_a);
-        prof_mark(e, TC_STAGE_SORT);
-        size_t tmp = e->sort_tmp_bytes;
-        const int end_bit = std::max(1, bit_width_u64(e->capacity));
-        TC_HIP(e, hipcub::DeviceRadixSort::SortPairs(e->sort_tmp, tmp, e->keys_a, e->keys_b, e->vals_a, e->vals_b,
-                                                     (int)n, 0, end_bit, s));
+        const uint64_t* sorted = sort_by_slot(e, b.slot, n);
         const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!p.burst && !p.count && !p.period);
         const bool uniform = !p.q && !p.now && params_by_slot;
         prof_mark(e, TC_STAGE_EVAL);
         if (uniform) {
-            if (full) hipLaunchKernelGGL((k_eval_sorted<true, true>), grid, block, 0, s, p, e->keys_b, e->vals_b, e->pend, e->pend_flag);
-            else hipLaunchKernelGGL((k_eval_sorted<false, true>), grid, block, 0, s, p, e->keys_b, e->vals_b, e->pend, e->pend_flag);
+            if (full) hipLaunchKernelGGL((k_eval_sorted<true, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
+            else hipLaunchKernelGGL((k_eval_sorted<false, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
             prof_mark(e, TC_STAGE_COMMIT);
-            hipLaunchKernelGGL(k_commit, grid, block, 0, s, e->keys_b, n, e->pend, e->pend_flag, e->cells);
+            hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->table);
         } else {
-            if (full) hipLaunchKernelGGL((k_eval_sorted<true, false>), grid, block, 0, s, p, e->keys_b, e->vals_b, e->pend, e->pend_flag);
-            else hipLaunchKernelGGL((k_eval_sorted<false, false>), grid, block, 0, s, p, e->keys_b, e->vals_b, e->pend, e->pend_flag);
+            if (full) hipLaunchKernelGGL((k_eval_sorted<true, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
+            else hipLaunchKernelGGL((k_eval_sorted<false, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
         }
     }
     if (b.allowed_bits) {
@@ -745,7 +848,6 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
-
 
 extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
@@ -846,7 +948,7 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), e->stream));
     TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), e->stream));
     hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, e->stream,
-                       e->cells, e->capacity, now_ns, e->counters, scratch);
+                       e->table, e->capacity, now_ns, e->counters, scratch);
     TC_HIP(e, hipGetLastError());
     unsigned long long r = 0;
     TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, e->stream));
@@ -855,9 +957,18 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     return TC_E_OK;
 }
 
+extern "C" int tc_counters_refresh(tc_engine* e) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(NSHARD), 0, e->stream, e->counters);
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
 extern "C" int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]) {
     if (!e || !out) return TC_E_INVALID_ARG;
-    TC_HIP(e, hipSetDevice(e->device));
+    int rc = tc_counters_refresh(e);
+    if (rc != TC_E_OK) return rc;
     TC_HIP(e, hipMemcpyAsync(out, e->counters, TC_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
     TC_HIP(e, hipStreamSynchronize(e->stream));
     out[TC_CNT_BATCHES] = e->batches;
@@ -916,7 +1027,7 @@ static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, u
                     StoreOpResult* r) {
     if (now < 0) return fail(e, TC_E_INVALID_ARG, "now_ns < 0");
     TC_HIP(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, e->stream, e->cells, slot, op, a, b, ttl, now, e->op_result);
+    hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, e->stream, e->table, slot, op, a, b, ttl, now, e->op_result);
     TC_HIP(e, hipGetLastError());
     TC_HIP(e, hipMemcpyAsync(r, e->op_result, sizeof *r, hipMemcpyDeviceToHost, e->stream));
     TC_HIP(e, hipStreamSynchronize(e->stream));
@@ -966,12 +1077,12 @@ extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* 
     if (!e || first + n > e->capacity) return TC_E_INVALID_ARG;
     if (n == 0) return TC_E_OK;
     TC_HIP(e, hipSetDevice(e->device));
-    std::vector<Cell> h(n);
-    TC_HIP(e, hipMemcpyAsync(h.data(), e->cells + first, n * sizeof(Cell), hipMemcpyDeviceToHost, e->stream));
+    std::vector<Slot> h(n);
+    TC_HIP(e, hipMemcpyAsync(h.data(), e->table + first, n * sizeof(Slot), hipMemcpyDeviceToHost, e->stream));
     TC_HIP(e, hipStreamSynchronize(e->stream));
     for (uint64_t i = 0; i < n; ++i) {
-        if (tat) tat[i] = h[i].tat;
-        if (expiry) expiry[i] = h[i].expiry;
+        if (tat) tat[i] = h[i].cell.tat;
+        if (expiry) expiry[i] = h[i].cell.expiry;
     }
     return TC_E_OK;
 }

@@ -227,6 +227,10 @@ class Engine:
         self._check(self._lib.tc_counters(self._h, arr))
         return {k: int(arr[i]) for i, k in enumerate(L.TC_CNT_NAMES)}
 
+    def counters_refresh(self):
+        """Fold the sharded device counters into the device counter block (async)."""
+        self._check(self._lib.tc_counters_refresh(self._h))
+
     def profile_enable(self, on: bool = True):
         self._check(self._lib.tc_profile_enable(self._h, 1 if on else 0))
 

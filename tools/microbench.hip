@@ -1,0 +1,78 @@
+// microbench.hip -- what do the memory patterns of the eval kernel cost on MI355X?
+// build: hipcc --offload-arch=gfx950 -O3 tools/microbench.hip -o gpurun_out/microbench
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <random>
+#include <vector>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+struct __attribute__((aligned(32))) Rec { long long a, b, c, d; };
+
+// mode bits: 1 = gather 32B record, 2 = store 16B back, 4 = scattered byte store by idx, 8 = coalesced byte store
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pat(const uint64_t* __restrict__ sorted, uint32_t n, Rec* __restrict__ table,
+                                             uint8_t* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t e = sorted[k];
+    const uint32_t slot = (uint32_t)(e >> 32), idx = (uint32_t)e;
+    long long v = slot;
+    if (MODE & 1) {
+        const Rec r = table[slot];
+        v = r.a + r.b + r.c + r.d;
+    }
+    if (MODE & 2) {
+        long long* p = &table[slot].a;
+        p[0] = v + 1;
+        p[1] = v + 2;
+    }
+    if (MODE & 4) out[idx] = (uint8_t)(v & 1);
+    if (MODE & 8) out[k] = (uint8_t)(v & 1);
+}
+
+template <int MODE>
+float run(const uint64_t* d_sorted, uint32_t n, Rec* table, uint8_t* out, int iters) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_pat<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_pat<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return 1e3f * ms / iters;
+}
+
+int main() {
+    const uint32_t n = 1 << 20, cap = 10000000;
+    std::mt19937_64 rng(1);
+    std::vector<uint64_t> h(n);
+    for (uint32_t i = 0; i < n; ++i) h[i] = ((uint64_t)(rng() % cap) << 32) | i;
+    std::vector<uint64_t> hs = h;
+    std::sort(hs.begin(), hs.end());
+    uint64_t *d_sorted, *d_unsorted;
+    Rec* table;
+    uint8_t* out;
+    CK(hipMalloc(&d_sorted, n * 8));
+    CK(hipMalloc(&d_unsorted, n * 8));
+    CK(hipMalloc(&table, (size_t)cap * sizeof(Rec)));
+    CK(hipMalloc(&out, n));
+    CK(hipMemset(table, 0, (size_t)cap * sizeof(Rec)));
+    CK(hipMemcpy(d_sorted, hs.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_unsorted, h.data(), n * 8, hipMemcpyHostToDevice));
+    printf("pattern (1Mi requests over 10M x 32B records)             sorted_us  unsorted_us\n");
+#define ROW(M, name) printf("%-58s %9.1f  %9.1f\n", name, run<M>(d_sorted, n, table, out, 20), run<M>(d_unsorted, n, table, out, 20));
+    ROW(0, "read elems only");
+    ROW(8, "read elems + coalesced byte store");
+    ROW(4, "read elems + byte store scattered by idx");
+    ROW(1 | 8, "gather 32B + coalesced byte store");
+    ROW(1 | 4, "gather 32B + scattered byte store");
+    ROW(1 | 2 | 8, "gather 32B + store 16B + coalesced byte store");
+    ROW(1 | 2 | 4, "gather 32B + store 16B + scattered byte store");
+    return 0;
+}
