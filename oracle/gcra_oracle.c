@@ -207,6 +207,7 @@ struct tco_adaptive {
     /* history (:50-52) */
     size_t last_removed, last_total;
     uint64_t cleanups;
+    int auto_off; /* test knob: 1 = maybe_clean_expired never cleans (explicit cleanup only) */
 };
 
 static size_t cap_to_buckets(size_t cap) { /* hashbrown capacity_to_buckets */
@@ -338,8 +339,9 @@ void tco_adaptive_force_cleanup(tco_adaptive* s, int64_t now) { ad_cleanup(s, no
 /* adaptive_cleanup.rs:205-211 */
 static void ad_maybe_clean(tco_adaptive* s, int64_t now) {
     s->ops_since_cleanup++;
-    if (ad_should_clean(s, now)) ad_cleanup(s, now);
+    if (!s->auto_off && ad_should_clean(s, now)) ad_cleanup(s, now);
 }
+void tco_adaptive_set_auto_cleanup(tco_adaptive* s, int on) { s->auto_off = !on; }
 
 /* adaptive_cleanup.rs:246-252 */
 static int ad_get(void* self, const uint8_t* key, size_t klen, int64_t now, int64_t* val, int* found) {

@@ -94,6 +94,11 @@ tco_store tco_adaptive_as_store(tco_adaptive*);
 size_t tco_adaptive_len(const tco_adaptive*);
 uint64_t tco_adaptive_cleanups(const tco_adaptive*);       /* number of cleanup() runs */
 void tco_adaptive_force_cleanup(tco_adaptive*, int64_t now); /* AdaptiveStore::cleanup */
+/* Test knob (no reference analogue): on = 0 makes maybe_clean_expired a no-op so
+ * that cleanup only happens through tco_adaptive_force_cleanup.  Needed to compare
+ * streams whose timestamps go backwards, where the reference's own results depend
+ * on when its cleanup heuristics fire. */
+void tco_adaptive_set_auto_cleanup(tco_adaptive*, int on);
 
 /* ---- Dense slot store (keys are u32 slot ids; no hashing) --------------- */
 typedef struct tco_dense tco_dense;

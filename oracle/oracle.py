@@ -77,6 +77,7 @@ def lib():
     L.tco_adaptive_cleanups.restype = C.c_uint64
     L.tco_adaptive_cleanups.argtypes = [C.c_void_p]
     L.tco_adaptive_force_cleanup.argtypes = [C.c_void_p, C.c_int64]
+    L.tco_adaptive_set_auto_cleanup.argtypes = [C.c_void_p, C.c_int]
     L.tco_dense_new.restype = C.c_void_p
     L.tco_dense_new.argtypes = [C.c_size_t]
     L.tco_dense_free.argtypes = [C.c_void_p]
@@ -214,9 +215,11 @@ class AdaptiveOracle(_StoreBase):
     """RateLimiter<AdaptiveStore> -- string keys."""
 
     def __init__(self, capacity: int = 1000, created_ns: int = 0, *, min_interval_ns: int = 10**9,
-                 max_interval_ns: int = 300 * 10**9, max_operations: int = 100_000):
+                 max_interval_ns: int = 300 * 10**9, max_operations: int = 100_000, auto_cleanup: bool = True):
         super().__init__()
         self._h = lib().tco_adaptive_new(capacity, min_interval_ns, max_interval_ns, max_operations, created_ns)
+        if not auto_cleanup:
+            lib().tco_adaptive_set_auto_cleanup(self._h, 0)
         self._st = lib().tco_adaptive_as_store(self._h)
 
     def __del__(self):

@@ -1,0 +1,218 @@
+"""GPU parity (string-key mode): on-device key table + GCRA engine vs the
+string-keyed AdaptiveStore oracle -- bit-exact outputs on the same streams."""
+import numpy as np
+import pytest
+
+from tests import kat
+
+pytestmark = pytest.mark.gpu
+
+KAT = kat.load()
+T0 = KAT["t0_ns"]
+FIELDS = ("allowed", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+
+
+def _engine(capacity, max_batch=1 << 16, **kw):
+    import throttlecrab_amd as t
+    return t.Engine(capacity, max_batch, key_mode=True, **kw)
+
+
+def _oracle(capacity=1000):
+    """AdaptiveStore port whose cleanup heuristics never fire on their own.  With
+    timestamps that go BACKWARDS the reference's result depends on when its store
+    happened to clean (an entry that expired at t1 is live again for a request
+    stamped t0 < t1 unless a cleanup ran in between -- see
+    tests/test_oracle_golden.py::test_cleanup_is_not_neutral_when_time_goes_back);
+    the engine matches the reference with cleanup deferred to tc_sweep_expired."""
+    from oracle import oracle as O
+    return O.AdaptiveOracle(capacity=max(capacity, 100000), created_ns=T0, auto_cleanup=False)
+
+
+def assert_same(res, ref, ctx=""):
+    for f in FIELDS:
+        got = getattr(res, f)
+        if not isinstance(got, np.ndarray):
+            got = got.cpu().numpy()
+        exp = getattr(ref, f)
+        bad = np.nonzero(got.astype(np.int64) != exp.astype(np.int64))[0]
+        assert bad.size == 0, f"{ctx}: field {f} differs at {bad[:8]} got {got[bad[:8]]} want {exp[bad[:8]]}"
+
+
+@pytest.mark.parametrize("sc", KAT["scenarios"], ids=[s["name"] for s in KAT["scenarios"]])
+def test_reference_known_answers_string_keys(sc):
+    eng = _engine(256, 64)
+    kat.replay_scenario(sc, eng)
+    eng.close()
+
+
+@pytest.mark.parametrize("case", KAT["store_contract"], ids=[c["name"] for c in KAT["store_contract"]])
+def test_store_contract_string_keys(case):
+    eng = _engine(1024, 64)
+    kat.replay_store_contract(case, eng, T0)
+    eng.close()
+
+
+def _keyset(rng, n_keys):
+    from oracle import oracle as O
+    keys = []
+    for i in range(n_keys):
+        kind = i % 5
+        if kind == 0:
+            keys.append(b"key_%d" % i)
+        elif kind == 1:
+            keys.append(b"user:%d:api/v1/endpoint/%d" % (i, i * 7919))            # ~35 B (> one cell)
+        elif kind == 2:
+            keys.append(bytes(rng.integers(33, 127, int(rng.integers(1, 80))).astype(np.uint8)) + b"#%d" % i)
+        elif kind == 3:
+            keys.append(("kéy-\U0001F980-%d" % i).encode())
+        else:
+            keys.append(b"x" * 31 + b"%d" % (i % 10) if i < 50 else b"p%dq" % i)     # shared 31-byte prefixes
+    keys[0] = b""  # the empty key is a key (store_test_suite.rs:289-300)
+    return keys
+
+
+def _stream(rng, keys, n):
+    from oracle import oracle as O
+    idx = np.minimum(rng.zipf(1.4, n) - 1, len(keys) - 1) if rng.random() < 0.5 else rng.integers(0, len(keys), n)
+    kb, ko = O.pack_keys([keys[i] for i in idx])
+    return idx, kb, ko
+
+
+PSETS = np.array([(5, 10, 60), (100, 1000, 3600), (1, 1, 1), (3, 7, 60), (10, 100, 60), (0, 1, 1), (2**63 - 1,) * 3],
+                 dtype=np.int64)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_differential_host_pointers(seed):
+    rng = np.random.default_rng(seed)
+    keys = _keyset(rng, 700)
+    eng, orc = _engine(2048), _oracle()
+    for rnd in range(4):
+        n = 20000
+        idx, kb, ko = _stream(rng, keys[: 200 + 150 * rnd], n)  # new keys keep appearing
+        ps = PSETS[idx % len(PSETS)]
+        q = rng.choice(np.array([0, 1, 1, 2, -1], dtype=np.int64), n)
+        now = T0 + rnd * 3 * 10**9 + rng.integers(0, 2 * 10**9, n)
+        ref = orc.batch_keys(kb, ko, ps[:, 0].copy(), ps[:, 1].copy(), ps[:, 2].copy(), q, now)
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=ps[:, 0].copy(), count_per_period=ps[:, 1].copy(),
+                                        period=ps[:, 2].copy(), quantity=q, now_ns=now)
+        assert_same(res, ref, f"seed {seed} round {rnd}")
+    # every key the oracle holds live is bound on the device with the same value
+    t_end = T0 + 20 * 10**9
+    for k in keys[:200]:
+        assert eng.get(k, t_end) == orc.get(k, t_end), k
+    eng.close()
+
+
+def test_uniform_batches_device_pointers():
+    import torch
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    keys = [b"key_%d" % i for i in range(3000)]
+    eng, orc = _engine(4096), _oracle(4096)
+    eng.use_torch_stream()
+    for rnd in range(4):
+        n = 50000
+        idx = np.minimum(rng.zipf(1.2, n) - 1, len(keys) - 1)
+        kb, ko = O.pack_keys([keys[i] for i in idx])
+        now = T0 + rnd * 500_000_000
+        ref = orc.batch_keys(kb, ko, 10, 100, 60, 1, now)
+        res = eng.rate_limit_batch_keys(torch.from_numpy(kb).cuda(), torch.from_numpy(ko.astype(np.int32)).cuda(),
+                                        max_burst=10, count_per_period=100, period=60, quantity=1, now_ns=now)
+        torch.cuda.synchronize()
+        assert_same(res, ref, f"round {rnd}")
+    c = eng.counters()
+    assert c["keys_inserted"] == len(set(idx.tolist()) | set()) or c["keys_inserted"] <= len(keys)
+    eng.close()
+
+
+def test_sweep_unbinds_keys_and_matches_cleanup():
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    keys = [b"k%d" % i for i in range(5000)]
+    # an oracle store that never cleans on its own (no time / op-count trigger), so that
+    # "removed" of the forced cleanup is comparable with the device sweep
+    eng, orc = _engine(6000), O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
+    kb, ko = O.pack_keys(keys)
+    now = T0 + rng.integers(0, 20 * 10**9, len(keys))
+    ref = orc.batch_keys(kb, ko, 3, 30, 60, 1, now)      # ttl <= 8 s
+    res = eng.rate_limit_batch_keys(kb, ko, max_burst=3, count_per_period=30, period=60, quantity=1, now_ns=now)
+    assert_same(res, ref)
+    for rnd, t_sweep in enumerate((T0 + 10 * 10**9, T0 + 15 * 10**9, T0 + 40 * 10**9)):
+        before, forced = len(orc), orc.cleanups
+        orc.force_cleanup(t_sweep)
+        assert orc.cleanups == forced + 1 == rnd + 1, "oracle cleaned on its own"
+        assert eng.sweep_expired(t_sweep) == before - len(orc)
+        assert eng.counters()["live_slots"] == len(orc)
+        # swept keys are unbound, live keys still resolve
+        for k in keys[::97]:
+            assert (eng.lookup_slot(k) >= 0) == (orc.get(k, t_sweep) is not None), k
+        # and they can come back: same decisions as a fresh key in the reference
+        now2 = t_sweep + 1000
+        ref = orc.batch_keys(kb, ko, 3, 30, 60, 1, now2)
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=3, count_per_period=30, period=60, quantity=1, now_ns=now2)
+        assert_same(res, ref, f"after sweep {rnd}")
+    eng.close()
+
+
+def test_many_sweeps_trigger_table_rebuild():
+    from oracle import oracle as O
+    eng, orc = _engine(512), _oracle()
+    for gen in range(12):  # 12 generations x 400 fresh keys through a 512-slot store (1024-entry table)
+        keys = [b"gen%d-%d" % (gen, i) for i in range(400)]
+        kb, ko = O.pack_keys(keys)
+        now = T0 + gen * 100 * 10**9
+        ref = orc.batch_keys(kb, ko, 2, 60, 60, 1, now)
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=2, count_per_period=60, period=60, quantity=1, now_ns=now)
+        assert_same(res, ref, f"gen {gen}")
+        eng.sweep_expired(now + 50 * 10**9)
+        assert eng.counters()["live_slots"] == 0
+    eng.close()
+
+
+def test_table_full_reports_and_keeps_working():
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    eng = _engine(100, 1024)
+    keys = [b"full-%d" % i for i in range(150)]
+    kb, ko = O.pack_keys(keys)
+    with pytest.raises(t.TcError) as ei:
+        eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0)
+    assert ei.value.code == -5
+    # the first 100 distinct keys were served; after a sweep far in the future the rest fit
+    assert eng.counters()["keys_inserted"] == 100
+    eng.sweep_expired(T0 + 10**12)
+    kb2, ko2 = O.pack_keys(keys[100:])
+    res = eng.rate_limit_batch_keys(kb2, ko2, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 10**12 + 1)
+    assert res.status.max() == 0 and res.allowed.min() == 1
+    eng.close()
+
+
+def test_config5_shape_mixed_insert_lookup_1m_keys():
+    """BASELINE configs[4] shape at 1 M keys: hit / new / re-hit-after-expiry mix + sweeps."""
+    import torch
+    from oracle import oracle as O
+    n_keys, B = 1_000_000, 200_000
+    eng, orc = _engine(n_keys + 1000, B), O.AdaptiveOracle(capacity=4 * n_keys, created_ns=T0,
+                                                           auto_cleanup=False)
+    eng.use_torch_stream()
+    rng = np.random.default_rng(12)
+    seen = 0
+    for step in range(6):
+        new = rng.integers(seen, min(n_keys, seen + B // 4), B // 5) if seen < n_keys else np.zeros(0, np.int64)
+        old = rng.integers(0, max(seen, 1), B - len(new))
+        ids = np.concatenate([old, new])
+        rng.shuffle(ids)
+        seen = min(n_keys, seen + B // 4)
+        kb, ko = O.format_keys(ids.astype(np.uint32))
+        now = T0 + step * 4 * 10**9  # ttl of (10,100,60) <= 11 s: some keys expire between steps
+        ref = orc.batch_keys(kb, ko, 10, 100, 60, 1, now)
+        res = eng.rate_limit_batch_keys(torch.from_numpy(kb).cuda(), torch.from_numpy(ko.astype(np.int32)).cuda(),
+                                        max_burst=10, count_per_period=100, period=60, quantity=1, now_ns=now)
+        torch.cuda.synchronize()
+        assert_same(res, ref, f"step {step}")
+        if step % 2 == 1:
+            orc.force_cleanup(now)  # (the oracle may also have cleaned on its own: compare what is left)
+            eng.sweep_expired(now)
+            assert eng.counters()["live_slots"] == len(orc)
+    eng.close()

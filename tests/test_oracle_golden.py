@@ -93,3 +93,19 @@ def test_adaptive_cleanup_runs_and_is_decision_neutral():
         kd = d.rate_limit(int(s).to_bytes(4, "little"), 3, 30, 60, 1, now)
         assert ka == kd
     assert a.cleanups > 10
+
+
+def test_cleanup_is_not_neutral_when_time_goes_back():
+    """AdaptiveStore::cleanup is decision-neutral only for non-decreasing timestamps:
+    burst=1 leaves expiry == t1; a later request stamped t0 < t1 sees a LIVE entry
+    (adaptive_cleanup.rs:248) and is denied -- unless a cleanup at t >= t1 dropped the
+    entry first (adaptive_cleanup.rs:176-182), in which case it is allowed."""
+    t1, t0 = T0 + 10**9, T0 + 10**9 - 217_000_000
+    a = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)  # never cleans
+    assert a.rate_limit(b"k", 1, 1, 1, 1, t1)[1] is True
+    st, allowed, _, _, reset_ns, retry_ns = a.rate_limit(b"k", 1, 1, 1, 1, t0)
+    assert (st, allowed, reset_ns, retry_ns) == (0, False, 217_000_000, 1_217_000_000)
+    b = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
+    assert b.rate_limit(b"k", 1, 1, 1, 1, t1)[1] is True
+    b.force_cleanup(t1)
+    assert b.rate_limit(b"k", 1, 1, 1, 1, t0)[1] is True

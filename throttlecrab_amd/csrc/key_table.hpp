@@ -1,0 +1,276 @@
+// key_table.hpp -- on-device key -> slot resolution for string keys (gfx950).
+//
+// Replaces what AHashMap<String, ...> does for the reference's stores
+// (throttlecrab/src/core/store/adaptive_cleanup.rs:39-41, get/insert at
+// :231-277): find the entry of a key, or bind a fresh one.  The hash only
+// PLACES keys; hits are confirmed by a full key comparison, so results never
+// depend on the hash function (same as the reference with ahash).
+//
+// Layout (all in HBM):
+//   ktab[NB]        u64 open-addressing table, linear probing, NB = 2^k >= 2*capacity
+//                   entry = tag(32) << 32 | val(32);  val: 0 empty, 1 tombstone,
+//                   >= 2 bound to slot val-2, bit 31 set = "being inserted by
+//                   request (val & 0x7fffffff) of the current batch"
+//   key_hash[cap]   u64 full hash of the key bound to a slot
+//   key_len[cap]    u32 key length (0xFFFFFFFF = slot not bound)
+//   key_pos[cap]    u32 position of the slot's entry in ktab (for unbinding)
+//   key_cell[cap]   fixed cells of cell_bytes each; a key that does not fit keeps
+//                   an 8-byte offset into the overflow arena in its cell
+//   free_slots[cap] stack of unbound slots, free_top = number of free slots
+//
+// Inserting inside a batch is a three-kernel protocol without spinning (a wave
+// cannot wait for its own lanes): k_probe claims an empty entry with the
+// REQUEST INDEX, duplicates of the same new key find that claim and compare
+// against the claimant's key bytes in the input arena; k_bind (claimants)
+// takes a slot, stores the key and publishes the slot; k_follow copies the
+// claimant's slot to its duplicates.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kt {
+
+constexpr int THREADS = 256;
+constexpr uint32_t VAL_EMPTY = 0u, VAL_TOMB = 1u, VAL_PENDING = 0x80000000u;
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+constexpr uint32_t ST_FOUND = 0u, ST_CLAIMANT = 1u, ST_FOLLOWER = 2u, ST_MISSING = 3u;
+
+struct Table {
+    unsigned long long* ktab;
+    uint64_t nb_mask;
+    uint64_t* key_hash;
+    uint32_t* key_len;
+    uint32_t* key_pos;
+    uint8_t* key_cell;
+    uint32_t cell_bytes;
+    uint8_t* overflow;
+    uint64_t overflow_bytes;
+    unsigned long long* overflow_used;
+    uint32_t* free_slots;
+    int* free_top;
+    uint32_t* tombs;        // tombstones currently in ktab
+    uint32_t* error_flag;   // != 0: a key could not be bound (no slot / no overflow space)
+    uint32_t capacity;
+};
+
+__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+    x ^= x >> 33;
+    x *= 0xff51afd7ed558ccdull;
+    x ^= x >> 33;
+    x *= 0xc4ceb9fe1a85ec53ull;
+    x ^= x >> 33;
+    return x;
+}
+
+__device__ __forceinline__ uint64_t hash_key(const uint8_t* __restrict__ p, uint32_t len) {
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)len;
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t w = 0;
+#pragma unroll
+        for (int b = 0; b < 8; ++b) w |= (uint64_t)p[i + b] << (8 * b);
+        h = mix64(h ^ w) + 0x9e3779b97f4a7c15ull;
+    }
+    if (i < len) {
+        uint64_t w = 0;
+        for (uint32_t b = 0; i + b < len; ++b) w |= (uint64_t)p[i + b] << (8 * b);
+        h = mix64(h ^ w ^ ((uint64_t)(len - i) << 56));
+    }
+    return mix64(h);
+}
+
+__device__ __forceinline__ const uint8_t* stored_key(const Table& t, uint32_t slot, uint32_t len) {
+    const uint8_t* cell = t.key_cell + (size_t)slot * t.cell_bytes;
+    if (len <= t.cell_bytes) return cell;
+    uint64_t off;
+    __builtin_memcpy(&off, cell, 8);
+    return t.overflow + off;
+}
+
+__device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t len) {
+    for (uint32_t i = 0; i < len; ++i)
+        if (a[i] != b[i]) return false;
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// probe: one lane per request.  INSERT: unseen keys claim an entry.
+// outputs: slot_out[i] (found), state[i], aux[i] (claimant: ktab position;
+// follower: request index of the claimant), hash_out[i]
+// ---------------------------------------------------------------------------
+template <bool INSERT>
+__global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __restrict__ key_bytes,
+                                                   const uint32_t* __restrict__ key_off, uint32_t n,
+                                                   uint32_t* __restrict__ slot_out, uint32_t* __restrict__ state,
+                                                   uint32_t* __restrict__ aux, uint64_t* __restrict__ hash_out) {
+    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t off = key_off[i], len = key_off[i + 1] - off;
+    const uint8_t* key = key_bytes + off;
+    const uint64_t h = hash_key(key, len);
+    const uint32_t tag = (uint32_t)(h >> 32);
+    hash_out[i] = h;
+    uint64_t pos = h & t.nb_mask;
+    uint32_t st = ST_MISSING, slot = NO_SLOT, ax = 0;
+    for (uint64_t probes = 0; probes <= t.nb_mask; ++probes) {
+        unsigned long long e = __hip_atomic_load(&t.ktab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (e == 0ull) {
+            if (!INSERT) break;
+            const unsigned long long mine = ((unsigned long long)tag << 32) | (VAL_PENDING | i);
+            unsigned long long expected = 0ull;
+            if (__hip_atomic_compare_exchange_strong(&t.ktab[pos], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                st = ST_CLAIMANT;
+                ax = (uint32_t)pos;
+                break;
+            }
+            e = expected; // somebody else took this entry: examine what is there now
+        }
+        const uint32_t val = (uint32_t)e, etag = (uint32_t)(e >> 32);
+        if (val == VAL_TOMB) {
+            // skip; tombstones are only reclaimed by a rebuild
+        } else if (val & VAL_PENDING) {
+            if (etag == tag) {
+                const uint32_t j = val & ~VAL_PENDING; // request index of the claimant (this batch)
+                const uint32_t joff = key_off[j], jlen = key_off[j + 1] - joff;
+                if (jlen == len && bytes_equal(key_bytes + joff, key, len)) {
+                    st = ST_FOLLOWER;
+                    ax = j;
+                    break;
+                }
+            }
+        } else if (etag == tag) {
+            const uint32_t s = val - 2u;
+            if (t.key_hash[s] == h && t.key_len[s] == len && bytes_equal(stored_key(t, s, len), key, len)) {
+                st = ST_FOUND;
+                slot = s;
+                break;
+            }
+        }
+        pos = (pos + 1) & t.nb_mask;
+    }
+    slot_out[i] = slot;
+    state[i] = st;
+    aux[i] = ax;
+}
+
+// rank of each flagged lane inside its block + the block total (one barrier)
+__device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t& total) {
+    __shared__ uint32_t s_w[THREADS / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long m = __ballot(flag);
+    if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    uint32_t before = 0, tot = 0;
+    for (int w = 0; w < THREADS / 64; ++w) {
+        if (w < wave) before += s_w[w];
+        tot += s_w[w];
+    }
+    total = tot;
+    return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// claimants: take a slot, store the key, publish the binding.  Slots are popped
+// from the free stack once per BLOCK (a per-request atomic on one address would
+// serialise at ~12 ns each: 200 k new keys = 2.4 ms).
+__global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
+                                                  const uint32_t* __restrict__ key_off, uint32_t n,
+                                                  uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ state,
+                                                  const uint32_t* __restrict__ aux, const uint64_t* __restrict__ hash_in,
+                                                  unsigned long long* inserted_counter) {
+    __shared__ int s_old_top;
+    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    const bool claimant = i < n && state[i] == ST_CLAIMANT;
+    uint32_t off = 0, len = 0;
+    unsigned long long ovf = 0;
+    bool want = claimant;
+    if (claimant) {
+        off = key_off[i];
+        len = key_off[i + 1] - off;
+        if (len > t.cell_bytes) { // long key: reserve overflow bytes first
+            ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
+            if (ovf + len > t.overflow_bytes) want = false;
+        }
+    }
+    uint32_t total = 0;
+    const uint32_t rank = block_rank(want, total);
+    if (threadIdx.x == 0) {
+        int old = 0;
+        if (total) {
+            old = atomicSub(t.free_top, (int)total);
+            const int got = old < 0 ? 0 : (old < (int)total ? old : (int)total);
+            if (got < (int)total) atomicAdd(t.free_top, (int)total - got); // stack ran dry: undo the excess
+        }
+        s_old_top = old;
+    }
+    __syncthreads();
+    bool bound = false;
+    if (claimant) {
+        const uint8_t* key = key_bytes + off;
+        const uint32_t pos = aux[i];
+        const uint64_t h = hash_in[i];
+        uint32_t slot = NO_SLOT;
+        if (want) {
+            const int idx = s_old_top - 1 - (int)rank;
+            if (idx >= 0) slot = t.free_slots[idx];
+        }
+        if (slot != NO_SLOT) {
+            uint8_t* cell = t.key_cell + (size_t)slot * t.cell_bytes;
+            if (len > t.cell_bytes) {
+                for (uint32_t b = 0; b < len; ++b) t.overflow[ovf + b] = key[b];
+                const uint64_t o64 = ovf;
+                __builtin_memcpy(cell, &o64, 8);
+            } else {
+                for (uint32_t b = 0; b < len; ++b) cell[b] = key[b];
+            }
+            t.key_hash[slot] = h;
+            t.key_len[slot] = len;
+            t.key_pos[slot] = pos;
+            t.ktab[pos] = ((unsigned long long)(uint32_t)(h >> 32) << 32) | (unsigned long long)(slot + 2u);
+            bound = true;
+        } else {
+            t.ktab[pos] = ((unsigned long long)(uint32_t)(h >> 32) << 32) | VAL_TOMB;
+            atomicAdd(t.tombs, 1u);
+            atomicExch(t.error_flag, 1u);
+        }
+        slot_out[i] = slot;
+    }
+    const unsigned long long m = __ballot(bound);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(inserted_counter, (unsigned long long)__popcll(m));
+}
+
+// duplicates of a key first seen in this batch take the claimant's slot
+__global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __restrict__ slot_out,
+                                                    const uint32_t* __restrict__ state, const uint32_t* __restrict__ aux) {
+    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    if (i < n && state[i] == ST_FOLLOWER) slot_out[i] = slot_out[aux[i]];
+}
+
+__global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint32_t* key_len, uint32_t capacity) {
+    for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < capacity; i += gridDim.x * THREADS) {
+        free_slots[i] = capacity - 1u - i; // slot 0 is handed out first
+        key_len[i] = NO_SLOT;
+    }
+}
+
+// rebuild: clear ktab (memset by the host) and re-enter every bound slot
+__global__ __launch_bounds__(THREADS) void k_reinsert(Table t) {
+    for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
+        if (t.key_len[s] == NO_SLOT) continue;
+        const uint64_t h = t.key_hash[s];
+        const unsigned long long mine = ((unsigned long long)(uint32_t)(h >> 32) << 32) | (unsigned long long)(s + 2u);
+        uint64_t pos = h & t.nb_mask;
+        while (true) {
+            unsigned long long expected = 0ull;
+            if (__hip_atomic_compare_exchange_strong(&t.ktab[pos], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+                t.key_pos[s] = (uint32_t)pos;
+                break;
+            }
+            pos = (pos + 1) & t.nb_mask;
+        }
+    }
+}
+
+} // namespace kt

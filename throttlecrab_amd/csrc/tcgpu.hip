@@ -22,6 +22,7 @@
 
 #include "../../include/tcgpu.h"
 #include "gcra_math.hpp"
+#include "key_table.hpp"
 #include "radix_sort.hpp"
 
 using tc::Cell;
@@ -442,6 +443,66 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Slot* __restrict__ table, uint6
     }
 }
 
+// Key-mode sweep: same retain rule, and an expired (or never written) bound slot
+// also loses its key: tombstone in the hash table, slot back on the free stack
+// (one stack push per block, not per slot).
+__global__ __launch_bounds__(BLOCK) void k_sweep_keys(Slot* __restrict__ table, kt::Table t, int64_t now,
+                                                      unsigned long long* counters, unsigned long long* removed_out) {
+    __shared__ int s_base;
+    uint32_t removed = 0, live = 0;
+    const uint64_t rounds = ((uint64_t)t.capacity + (uint64_t)gridDim.x * BLOCK - 1) / ((uint64_t)gridDim.x * BLOCK);
+    for (uint64_t rd = 0; rd < rounds; ++rd) {
+        const uint64_t i = rd * gridDim.x * BLOCK + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+        bool unbind = false;
+        if (i < t.capacity && t.key_len[i] != kt::NO_SLOT) {
+            Cell c = table[i].cell;
+            if (!(c.expiry > (uint64_t)now)) {
+                if (c.expiry != 0) removed++; // the reference's map only ever held written entries
+                c.tat = 0;
+                c.expiry = 0;
+                table[i].cell = c;
+                unbind = true;
+            } else {
+                live++;
+            }
+        }
+        uint32_t total = 0;
+        const uint32_t rank = kt::block_rank(unbind, total);
+        if (threadIdx.x == 0 && total) s_base = atomicAdd(t.free_top, (int)total);
+        __syncthreads();
+        if (unbind) {
+            const uint32_t pos = t.key_pos[i];
+            t.ktab[pos] = (t.ktab[pos] & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
+            t.key_len[i] = kt::NO_SLOT;
+            t.free_slots[s_base + (int)rank] = (uint32_t)i;
+        }
+        if (threadIdx.x == 0 && total) atomicAdd(t.tombs, total);
+        __syncthreads();
+    }
+    __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        removed += __shfl_down(removed, off, 64);
+        live += __shfl_down(live, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_r[threadIdx.x >> 6] = removed;
+        s_l[threadIdx.x >> 6] = live;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t r = 0, l = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            r += s_r[w];
+            l += s_l[w];
+        }
+        if (r) {
+            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)r);
+            atomicAdd(removed_out, (unsigned long long)r);
+        }
+        if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
+    }
+}
+
 __global__ __launch_bounds__(BLOCK) void k_fill_rates(Slot* __restrict__ table, int64_t* __restrict__ bursts,
                                                       uint64_t capacity, Rate r, int64_t burst) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
@@ -552,6 +613,16 @@ struct tc_engine {
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
 
+    // string-key mode (TC_CFG_KEY_MODE): device hash table + per-batch resolution scratch
+    bool key_mode = false;
+    kt::Table kt;
+    void* kt_block = nullptr;        // one allocation backing every kt.* array
+    uint32_t *k_slot = nullptr, *k_state = nullptr, *k_aux = nullptr; // max_batch each
+    uint64_t* k_hash = nullptr;
+    uint8_t* k_stage_bytes = nullptr; // host-pointer batches: staged key arena
+    size_t k_stage_bytes_cap = 0;
+    uint32_t* k_stage_off = nullptr;  // max_batch + 1
+
     // optional per-stage HIP-event timing (tc_profile_*)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;
@@ -626,6 +697,124 @@ static int engine_alloc(tc_engine* e) {
     return TC_E_OK;
 }
 
+// ---- string-key mode ----------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
+    const uint64_t cap = e->capacity, mb = e->max_batch;
+    uint64_t nb = 1;
+    while (nb < 2 * cap) nb <<= 1; // load factor <= 0.5
+    uint32_t cell = 32;
+    if (key_arena_bytes) {
+        uint64_t per = key_arena_bytes / cap;
+        per = per / 16 * 16;
+        cell = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 16), 256);
+    }
+    const uint64_t overflow = std::max<uint64_t>(1u << 20, cap * 4); // long keys are the exception
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const size_t o_ktab = take(nb * 8), o_hash = take(cap * 8), o_len = take(cap * 4), o_pos = take(cap * 4),
+                 o_cell = take(cap * (size_t)cell), o_ovf = take(overflow), o_free = take(cap * 4), o_misc = take(64);
+    TC_HIP(e, hipMalloc(&e->kt_block, off));
+    uint8_t* base = (uint8_t*)e->kt_block;
+    TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * 8, e->stream));
+    TC_HIP(e, hipMemsetAsync(base + o_misc, 0, 64, e->stream));
+    kt::Table& t = e->kt;
+    t.ktab = (unsigned long long*)(base + o_ktab);
+    t.nb_mask = nb - 1;
+    t.key_hash = (uint64_t*)(base + o_hash);
+    t.key_len = (uint32_t*)(base + o_len);
+    t.key_pos = (uint32_t*)(base + o_pos);
+    t.key_cell = base + o_cell;
+    t.cell_bytes = cell;
+    t.overflow = base + o_ovf;
+    t.overflow_bytes = overflow;
+    t.overflow_used = (unsigned long long*)(base + o_misc);
+    t.free_top = (int*)(base + o_misc + 8);
+    t.tombs = (uint32_t*)(base + o_misc + 12);
+    t.error_flag = (uint32_t*)(base + o_misc + 16);
+    t.free_slots = (uint32_t*)(base + o_free);
+    t.capacity = (uint32_t)cap;
+    hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, e->stream,
+                       t.free_slots, t.key_len, (uint32_t)cap);
+    const int top = (int)cap;
+    TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, e->stream));
+    TC_HIP(e, hipMalloc(&e->k_slot, mb * 4));
+    TC_HIP(e, hipMalloc(&e->k_state, mb * 4));
+    TC_HIP(e, hipMalloc(&e->k_aux, mb * 4));
+    TC_HIP(e, hipMalloc(&e->k_hash, mb * 8));
+    TC_HIP(e, hipMalloc(&e->k_stage_off, (mb + 1) * 4));
+    TC_HIP(e, hipStreamSynchronize(e->stream));
+    e->key_mode = true;
+    return TC_E_OK;
+}
+
+// keys (device arena) -> e->k_slot[0..n): found slot, freshly bound slot, or NO_SLOT
+static int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert) {
+    hipStream_t s = e->stream;
+    const dim3 grid(nblocks(n)), block(kt::THREADS);
+    prof_mark(e, TC_STAGE_HASH);
+    if (insert) {
+        hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state, e->k_aux,
+                           e->k_hash);
+        hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state, e->k_aux,
+                           e->k_hash, e->counters + TC_CNT_KEYS_INSERTED);
+        hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, e->k_slot, e->k_state, e->k_aux);
+    } else {
+        hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state,
+                           e->k_aux, e->k_hash);
+    }
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
+// host key arena -> staged on device
+static int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n,
+                      const uint8_t** d_bytes, const uint32_t** d_off) {
+    const size_t total = key_off[n];
+    if (total > e->k_stage_bytes_cap) {
+        if (e->k_stage_bytes) (void)hipFree(e->k_stage_bytes);
+        e->k_stage_bytes = nullptr;
+        const size_t want = std::max<size_t>(total * 2, 1 << 16);
+        TC_HIP(e, hipMalloc(&e->k_stage_bytes, want));
+        e->k_stage_bytes_cap = want;
+    }
+    if (total) TC_HIP(e, hipMemcpyAsync(e->k_stage_bytes, key_bytes, total, hipMemcpyHostToDevice, e->stream));
+    TC_HIP(e, hipMemcpyAsync(e->k_stage_off, key_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    *d_bytes = e->k_stage_bytes ? e->k_stage_bytes : (const uint8_t*)e->k_stage_off;
+    *d_off = e->k_stage_off;
+    return TC_E_OK;
+}
+
+// one key (host bytes) -> slot on the host; insert binds a fresh slot if unseen
+static int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint32_t* slot) {
+    if (key_len > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "key too long");
+    const uint32_t off[2] = {0u, (uint32_t)key_len};
+    const uint8_t* d_bytes;
+    const uint32_t* d_off;
+    int rc = stage_keys(e, key, off, 1, &d_bytes, &d_off);
+    if (rc != TC_E_OK) return rc;
+    rc = resolve_keys_device(e, d_bytes, d_off, 1, insert);
+    if (rc != TC_E_OK) return rc;
+    TC_HIP(e, hipMemcpyAsync(slot, e->k_slot, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
+    TC_HIP(e, hipStreamSynchronize(e->stream));
+    return TC_E_OK;
+}
+
+static int rebuild_key_table(tc_engine* e) {
+    kt::Table& t = e->kt;
+    TC_HIP(e, hipMemsetAsync(t.ktab, 0, (t.nb_mask + 1) * 8, e->stream));
+    TC_HIP(e, hipMemsetAsync(t.tombs, 0, sizeof(uint32_t), e->stream));
+    hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), dim3(kt::THREADS), 0,
+                       e->stream, t);
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
 extern "C" tc_engine* tc_engine_create(const tc_config* cfg, int* err) {
     int dummy;
     if (!err) err = &dummy;
@@ -649,12 +838,8 @@ extern "C" tc_engine* tc_engine_create(const tc_config* cfg, int* err) {
     e->capacity = cfg->capacity;
     e->max_batch = cfg->max_batch;
     e->cfg_flags = cfg->flags;
-    if (cfg->flags & TC_CFG_KEY_MODE) {
-        *err = TC_E_UNSUPPORTED;
-        delete e;
-        return nullptr;
-    }
     int rc = engine_alloc(e);
+    if (rc == TC_E_OK && (cfg->flags & TC_CFG_KEY_MODE)) rc = key_mode_alloc(e, cfg->key_arena_bytes);
     if (rc != TC_E_OK) {
         fprintf(stderr, "tcgpu: engine_create failed: %s\n", e->err.c_str());
         *err = rc;
@@ -673,6 +858,9 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status};
     for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    void* kptrs[] = {e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_hash, e->k_stage_bytes, e->k_stage_off};
+    for (void* p : kptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
@@ -849,26 +1037,16 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     return TC_E_OK;
 }
 
-extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
-    if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
-    const tc_batch& b = *bp;
-    if (b.n == 0) return TC_E_OK;
-    if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
-    if (!b.slot) return fail(e, TC_E_INVALID_ARG, "slot column is NULL");
-    TC_HIP(e, hipSetDevice(e->device));
-    if (b.flags & TC_B_DEVICE_PTRS) {
-        e->batches++;
-        return run_slots_device(e, b);
-    }
-    // host pointers: stage in, run, stage out, synchronise
-    int rc = stage_ensure(e);
-    if (rc != TC_E_OK) return rc;
+// Host-pointer batch whose slot column is already in e->stage.slot: stage the
+// other inputs, run, copy the outputs back, synchronise.
+static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     const uint64_t n = b.n;
     hipStream_t s = e->stream;
     tc_batch d = b;
     d.flags |= TC_B_DEVICE_PTRS;
-    TC_HIP(e, hipMemcpyAsync(e->stage.slot, b.slot, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
     d.slot = e->stage.slot;
+    d.key_bytes = nullptr;
+    d.key_off = nullptr;
     const int64_t* hin[5] = {b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns};
     const int64_t** din[5] = {&d.max_burst, &d.count_per_period, &d.period, &d.quantity, &d.now_ns};
     for (int j = 0; j < 5; ++j) {
@@ -885,7 +1063,7 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     d.retry_after_ns = b.retry_after_ns ? e->stage.out[3] : nullptr;
     d.status = b.status ? e->stage.status : nullptr;
     e->batches++;
-    rc = run_slots_device(e, d);
+    int rc = run_slots_device(e, d);
     if (rc != TC_E_OK) return rc;
     if (b.allowed) TC_HIP(e, hipMemcpyAsync(b.allowed, e->stage.allowed, n, hipMemcpyDeviceToHost, s));
     if (b.allowed_bits)
@@ -898,27 +1076,86 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     return TC_E_OK;
 }
 
-extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* b) {
-    (void)b;
-    return fail(e, TC_E_UNSUPPORTED, "key mode not built yet");
+extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
+    if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
+    const tc_batch& b = *bp;
+    if (b.n == 0) return TC_E_OK;
+    if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
+    if (!b.slot) return fail(e, TC_E_INVALID_ARG, "slot column is NULL");
+    if (e->key_mode) return fail(e, TC_E_INVALID_ARG, "key-mode engine: slots are assigned by the key table; use tc_rate_limit_batch_keys");
+    TC_HIP(e, hipSetDevice(e->device));
+    if (b.flags & TC_B_DEVICE_PTRS) {
+        e->batches++;
+        return run_slots_device(e, b);
+    }
+    // host pointers: stage in, run, stage out, synchronise
+    int rc = stage_ensure(e);
+    if (rc != TC_E_OK) return rc;
+    TC_HIP(e, hipMemcpyAsync(e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    return run_slots_host_staged(e, b);
+}
+
+// did any key of the batches since the last check fail to get a slot?
+static int check_key_errors(tc_engine* e) {
+    uint32_t flag = 0;
+    TC_HIP(e, hipMemcpyAsync(&flag, e->kt.error_flag, sizeof flag, hipMemcpyDeviceToHost, e->stream));
+    TC_HIP(e, hipStreamSynchronize(e->stream));
+    if (flag) {
+        TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, e->stream));
+        return fail(e, TC_E_TABLE_FULL, "key table full: some keys got status Internal (raise capacity or sweep)");
+    }
+    return TC_E_OK;
+}
+
+extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
+    if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    const tc_batch& b = *bp;
+    if (b.n == 0) return TC_E_OK;
+    if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
+    if (!b.key_bytes || !b.key_off) return fail(e, TC_E_INVALID_ARG, "key_bytes/key_off is NULL");
+    if (b.flags & (TC_B_REGISTERED_PARAMS | TC_B_UNIQUE_SLOTS))
+        return fail(e, TC_E_INVALID_ARG, "registered params / unique-slot promise do not apply to string keys");
+    TC_HIP(e, hipSetDevice(e->device));
+    const uint8_t* d_bytes = b.key_bytes;
+    const uint32_t* d_off = b.key_off;
+    const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
+    if (!dev) {
+        int rc = stage_keys(e, b.key_bytes, b.key_off, b.n, &d_bytes, &d_off);
+        if (rc != TC_E_OK) return rc;
+    }
+    int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true);
+    if (rc != TC_E_OK) return rc;
+    tc_batch s = b;
+    s.key_bytes = nullptr;
+    s.key_off = nullptr;
+    if (dev) {
+        s.slot = e->k_slot;
+        e->batches++;
+        return run_slots_device(e, s);
+    }
+    // host pointers for everything else: reuse the slot path's staging, with the
+    // slot column already on the device
+    rc = stage_ensure(e);
+    if (rc != TC_E_OK) return rc;
+    TC_HIP(e, hipMemcpyAsync(e->stage.slot, e->k_slot, b.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+    rc = run_slots_host_staged(e, b);
+    if (rc != TC_E_OK) return rc;
+    return check_key_errors(e);
 }
 
 extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, int64_t max_burst,
                              int64_t count_per_period, int64_t period, int64_t quantity, int64_t now_ns,
                              tc_result* out) {
     if (!e || !out || (!key && key_len)) return TC_E_INVALID_ARG;
-    if (e->cfg_flags & TC_CFG_KEY_MODE) return fail(e, TC_E_UNSUPPORTED, "key mode not built yet");
-    // slot-mode engines: the key is the 4-byte little-endian slot id
-    if (key_len != 4) return fail(e, TC_E_INVALID_ARG, "slot-mode engine: key must be a 4-byte slot id");
-    uint32_t slot;
-    memcpy(&slot, key, 4);
+    uint32_t slot = 0;
+    uint32_t off[2] = {0u, (uint32_t)key_len};
     uint8_t allowed = 0, status = 0;
     int64_t limit = 0, remaining = 0, reset = 0, retry = 0;
     tc_batch b;
     memset(&b, 0, sizeof b);
     b.struct_size = sizeof b;
     b.n = 1;
-    b.slot = &slot;
     b.max_burst_scalar = max_burst;
     b.count_per_period_scalar = count_per_period;
     b.period_scalar = period;
@@ -930,7 +1167,19 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
     b.remaining = &remaining;
     b.reset_after_ns = &reset;
     b.retry_after_ns = &retry;
-    int rc = tc_rate_limit_batch_slots(e, &b);
+    int rc;
+    if (e->key_mode) {
+        static const uint8_t empty = 0;
+        b.key_bytes = key_len ? key : &empty;
+        b.key_off = off;
+        rc = tc_rate_limit_batch_keys(e, &b);
+    } else {
+        // slot-mode engines: the key is the 4-byte little-endian slot id
+        if (key_len != 4) return fail(e, TC_E_INVALID_ARG, "slot-mode engine: key must be a 4-byte slot id");
+        memcpy(&slot, key, 4);
+        b.slot = &slot;
+        rc = tc_rate_limit_batch_slots(e, &b);
+    }
     if (rc != TC_E_OK) return rc;
     out->allowed = allowed;
     out->status = status;
@@ -947,13 +1196,21 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     unsigned long long* scratch = e->counters + TC_CNT_COUNT;
     TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), e->stream));
     TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), e->stream));
-    hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, e->stream,
-                       e->table, e->capacity, now_ns, e->counters, scratch);
+    if (e->key_mode)
+        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, e->stream,
+                           e->table, e->kt, now_ns, e->counters, scratch);
+    else
+        hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, e->stream,
+                           e->table, e->capacity, now_ns, e->counters, scratch);
     TC_HIP(e, hipGetLastError());
     unsigned long long r = 0;
+    uint32_t tombs = 0;
     TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, e->stream));
+    if (e->key_mode) TC_HIP(e, hipMemcpyAsync(&tombs, e->kt.tombs, sizeof tombs, hipMemcpyDeviceToHost, e->stream));
     TC_HIP(e, hipStreamSynchronize(e->stream));
     if (removed) *removed = r;
+    // tombstones lengthen probe chains: rebuild the table once they fill 1/4 of it
+    if (e->key_mode && (uint64_t)tombs > (e->kt.nb_mask + 1) / 4) return rebuild_key_table(e);
     return TC_E_OK;
 }
 
@@ -1013,8 +1270,18 @@ extern "C" int tc_counters_device_ptr(tc_engine* e, void** dptr) {
     return TC_E_OK;
 }
 
-static int store_slot_of(tc_engine* e, const uint8_t* key, size_t key_len, uint64_t* slot) {
-    if (e->cfg_flags & TC_CFG_KEY_MODE) return fail(e, TC_E_UNSUPPORTED, "key mode not built yet");
+// *slot = NO_SLOT when a key-mode lookup (insert == false) does not find the key
+static int store_slot_of(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint64_t* slot) {
+    if (e->key_mode) {
+        if (!key && key_len) return TC_E_INVALID_ARG;
+        static const uint8_t empty = 0;
+        uint32_t s32 = kt::NO_SLOT;
+        int rc = resolve_one_key(e, key_len ? key : &empty, key_len, insert, &s32);
+        if (rc != TC_E_OK) return rc;
+        if (insert && s32 == kt::NO_SLOT) return check_key_errors(e) == TC_E_OK ? fail(e, TC_E_TABLE_FULL, "key table full") : TC_E_TABLE_FULL;
+        *slot = s32;
+        return TC_E_OK;
+    }
     if (!key || key_len != 4) return fail(e, TC_E_INVALID_ARG, "slot-mode engine: key must be a 4-byte slot id");
     uint32_t s;
     memcpy(&s, key, 4);
@@ -1037,8 +1304,13 @@ static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, u
 extern "C" int tc_store_get(tc_engine* e, const uint8_t* key, size_t key_len, int64_t now_ns, int64_t* value, int* found) {
     if (!e || !value || !found) return TC_E_INVALID_ARG;
     uint64_t slot;
-    int rc = store_slot_of(e, key, key_len, &slot);
+    int rc = store_slot_of(e, key, key_len, false, &slot);
     if (rc != TC_E_OK) return rc;
+    if (slot == kt::NO_SLOT) { // key-mode: key never seen -> None
+        *value = 0;
+        *found = 0;
+        return TC_E_OK;
+    }
     StoreOpResult r;
     rc = store_op(e, slot, 0, 0, 0, 0, now_ns, &r);
     if (rc != TC_E_OK) return rc;
@@ -1051,8 +1323,12 @@ extern "C" int tc_store_compare_and_swap_with_ttl(tc_engine* e, const uint8_t* k
                                                   int64_t new_value, uint64_t ttl_ns, int64_t now_ns, int* swapped) {
     if (!e || !swapped) return TC_E_INVALID_ARG;
     uint64_t slot;
-    int rc = store_slot_of(e, key, key_len, &slot);
+    int rc = store_slot_of(e, key, key_len, false, &slot);
     if (rc != TC_E_OK) return rc;
+    if (slot == kt::NO_SLOT) { // adaptive_cleanup.rs:242: None => Ok(false)
+        *swapped = 0;
+        return TC_E_OK;
+    }
     StoreOpResult r;
     rc = store_op(e, slot, 1, old_value, new_value, ttl_ns, now_ns, &r);
     if (rc != TC_E_OK) return rc;
@@ -1064,7 +1340,7 @@ extern "C" int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* 
                                                    uint64_t ttl_ns, int64_t now_ns, int* was_set) {
     if (!e || !was_set) return TC_E_INVALID_ARG;
     uint64_t slot;
-    int rc = store_slot_of(e, key, key_len, &slot);
+    int rc = store_slot_of(e, key, key_len, true, &slot);
     if (rc != TC_E_OK) return rc;
     StoreOpResult r;
     rc = store_op(e, slot, 2, value, 0, ttl_ns, now_ns, &r);
@@ -1088,8 +1364,12 @@ extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* 
 }
 
 extern "C" int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, int64_t* slot) {
-    (void)key;
-    (void)key_len;
-    (void)slot;
-    return fail(e, TC_E_UNSUPPORTED, "key mode not built yet");
+    if (!e || !slot) return TC_E_INVALID_ARG;
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    TC_HIP(e, hipSetDevice(e->device));
+    uint64_t s = kt::NO_SLOT;
+    int rc = store_slot_of(e, key, key_len, false, &s);
+    if (rc != TC_E_OK) return rc;
+    *slot = s == kt::NO_SLOT ? -1 : (int64_t)s;
+    return TC_E_OK;
 }
