@@ -33,6 +33,25 @@ ALG_BYTES_PER_DECISION = 36.125  # SURVEY.md section 8(d), slot mode, decisions 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep (one pass)", "eval": "k_eval_sorted",
+                   "commit": "k_commit_list", "pack": "k_pack_bits", "hash": "kt::k_probe+k_bind+k_follow"}
+
+
+def pmc_traffic(stage):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
+    (profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    ks = json.load(open(files[-1]))["kernels"]
+    want = {"eval": "k_eval_sorted<false, true>", "sort": "k_onesweep", "prep": "k_hist", "commit": "k_commit_list"}.get(stage)
+    for name, v in ks.items():
+        if want and want in name:
+            return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,6 +120,55 @@ def stage_profile(eng, d_batches, out, now0, steps, it0):
     return prof
 
 
+def keys_bench(a, dev):
+    """BASELINE configs[4]: string keys "key_<id>" through the on-device key table;
+    per 1 Mi batch 80 % of the requests hit keys seen before (some of them already
+    expired), 20 % bring new keys; params (10,100,60) so TTLs are <= 11 s; `now`
+    advances 1 s per batch; expiry sweep every 4 batches (inside the timed region)."""
+    import torch
+
+    import throttlecrab_amd as t
+    from throttlecrab_amd import workload as W
+    B, steps, pre = a.batch, min(a.steps, 24), 5
+    cap = a.keys + (steps + pre) * B // 5 + B
+    eng = t.Engine(cap, B, device=dev.index or 0, key_mode=True)
+    eng.use_torch_stream()
+    rng = np.random.default_rng(5)
+    seen, batches = 0, []
+    for s in range(pre + steps):
+        n_new = B if s < pre else B // 5
+        new = np.arange(seen, seen + n_new, dtype=np.int64)
+        old = rng.integers(0, max(seen, 1), B - n_new)
+        ids = np.concatenate([old, new])
+        rng.shuffle(ids)
+        seen += n_new
+        kb, ko = W.string_keys(ids)
+        batches.append((torch.from_numpy(kb).to(dev), torch.from_numpy(ko.astype(np.int32)).to(dev)))
+    out = t.BatchResult()
+
+    def one(s):
+        kb, ko = batches[s]
+        eng.rate_limit_batch_keys(kb, ko, max_burst=10, count_per_period=100, period=60, quantity=1,
+                                  now_ns=W.T0_NS + s * 10**9, want=("allowed",), out=out)
+
+    for s in range(pre):
+        one(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    swept = 0
+    for s in range(pre, pre + steps):
+        one(s)
+        if (s - pre) % 4 == 3:
+            swept += eng.sweep_expired(W.T0_NS + s * 10**9)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    c = eng.counters()
+    eng.close()
+    return {"value": steps * B / dt, "unit": "decisions/s", "steps": steps, "keys_inserted": c["keys_inserted"],
+            "swept": swept, "allowed_fraction": c["allowed"] / max(1, c["total"]),
+            "workload": f"string keys key_<id>, {B} requests/batch, 20% new keys, sweep every 4 batches"}
+
+
 def cpu_baseline(kind, n_keys, batch, n_batches):
     """The oracle (a port of RateLimiter<AdaptiveStore>, string keys "key_<slot>")
     timed on this box's host cores over the first n_batches of the same stream."""
@@ -116,7 +184,7 @@ def cpu_baseline(kind, n_keys, batch, n_batches):
     t0 = time.perf_counter()
     st.batch_keys(kb, ko, b, c, p, 1, now)
     t1 = time.perf_counter() - t0
-    ncores = os.cpu_count() or 1
+    ncores = min(os.cpu_count() or 1, 64)
     tm, _ = O.batch_keys_mt(ncores, max(1000, n_keys // ncores), W.T0_NS, kb, ko, b, c, p, 1, now)
     return {"value": slots.size / t1, "unit": "decisions/s", "cores": 1, "kind": "port",
             "sample": f"first {n_batches} batches ({slots.size} requests) of the same {kind} stream, "
@@ -187,7 +255,7 @@ def main():
         alg_bytes = ALG_BYTES_PER_DECISION * a.batch
         ach = alg_bytes / (stages[dom] * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": ach / HBM_PEAK_GBS, "traffic": None, "kernel": dom,
+                              "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "kernel": KERNEL_OF_STAGE[dom],
                               "avg_ms": stages[dom], "stage_ms": stages,
                               "whole_batch_GBs": alg_bytes * a.steps / dt / 1e9}
         if not a.no_also and world == 1:
@@ -205,7 +273,18 @@ def main():
             dt3, _ = run_gpu(eng2, ob, full, W.T0_NS + 10**9, a.steps, 2, None, None, None,
                              want=t.Engine.ALL_FIELDS)
             also[f"{other}_stream_full_result"] = {"value": a.steps * a.batch / dt3, "unit": "decisions/s"}
+            # PCIe-inclusive rate: the same stream handed over as HOST buffers (never `value`)
+            hb = make_batches(other, a.keys, a.batch, 8)
+            hout = t.BatchResult()
+            for i in range(2):
+                eng2.rate_limit_batch_slots(hb[i], registered=True, quantity=1, now_ns=W.T0_NS + 2 * 10**9, want=("allowed",), out=hout)
+            t0 = time.perf_counter()
+            for i in range(8):
+                eng2.rate_limit_batch_slots(hb[i], registered=True, quantity=1, now_ns=W.T0_NS + 2 * 10**9 + i, want=("allowed",), out=hout)
+            also[f"{other}_stream_host_buffers_pcie_inclusive"] = {"value": 8 * a.batch / (time.perf_counter() - t0),
+                                                                  "unit": "decisions/s"}
             eng2.close()
+            also["string_keys_config4"] = keys_bench(a, dev)
             result["also"] = also
         if not a.no_cpu:
             result["cpu_baseline"] = cpu_baseline(a.workload, a.keys, a.batch, a.cpu_sample_batches)

@@ -187,8 +187,8 @@ int tc_counters_refresh(tc_engine* e);
  * engine's stream between its kernels (diagnostics for the roofline report;
  * leave off in production -- every event is an extra stream operation). */
 enum {
-    TC_STAGE_PREP = 0,   /* sort-key preparation */
-    TC_STAGE_SORT = 1,   /* (slot, index) grouping */
+    TC_STAGE_PREP = 0,   /* digit histograms of the batch (rs::k_hist) */
+    TC_STAGE_SORT = 1,   /* one radix pass (rs::k_onesweep); counted once per pass */
     TC_STAGE_EVAL = 2,   /* GCRA decide + advance */
     TC_STAGE_COMMIT = 3, /* deferred cell stores */
     TC_STAGE_PACK = 4,   /* decision bit packing */

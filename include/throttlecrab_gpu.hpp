@@ -1,0 +1,200 @@
+// throttlecrab_gpu.hpp -- host-side mirror (C++17, header only) of the reference's
+// interface for the accelerated path, over the C ABI of tcgpu.h.
+//
+// The reference is Rust and this image has no Rust toolchain, so the host side is
+// written in C++ with the reference's names, argument meaning and error behaviour:
+//   throttlecrab::RateLimiter<S>::{new, rate_limit}   throttlecrab/src/core/rate_limiter.rs:42-110
+//   throttlecrab::RateLimitResult                      throttlecrab/src/core/rate_limiter.rs:13-22
+//   throttlecrab::CellError                            throttlecrab/src/core/mod.rs:49-56
+//   throttlecrab::Store                                throttlecrab/src/core/store/mod.rs:85-133
+// plus the batched entry point north_star adds: RateLimiter::rate_limit_batch.
+// INTEGRATION.md shows the equivalent Rust `extern "C"` binding.
+#pragma once
+
+#include <chrono>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "tcgpu.h"
+
+namespace throttlecrab {
+
+using SystemTime = std::chrono::time_point<std::chrono::system_clock, std::chrono::nanoseconds>;
+using Duration = std::chrono::nanoseconds;
+
+inline int64_t to_ns(SystemTime t) { return t.time_since_epoch().count(); }
+
+// CellError (core/mod.rs:49-56)
+struct CellError {
+    enum Kind { NegativeQuantity = TC_NEGATIVE_QUANTITY, InvalidRateLimit = TC_INVALID_RATE_LIMIT, Internal = TC_INTERNAL } kind;
+    int64_t quantity = 0; // NegativeQuantity(n)
+    std::string message;  // Internal(msg)
+    std::string to_string() const {
+        switch (kind) { // Display impl, core/mod.rs:58-66
+            case NegativeQuantity: return "negative quantity: " + std::to_string(quantity);
+            case InvalidRateLimit: return "invalid rate limit parameters";
+            default: return "internal error: " + message;
+        }
+    }
+};
+
+// RateLimitResult (rate_limiter.rs:13-22)
+struct RateLimitResult {
+    int64_t limit;
+    int64_t remaining;
+    Duration reset_after;
+    Duration retry_after;
+};
+
+// Result<(bool, RateLimitResult), CellError>
+using RateLimitOutcome = std::variant<std::pair<bool, RateLimitResult>, CellError>;
+inline bool is_ok(const RateLimitOutcome& o) { return o.index() == 0; }
+
+// One request = the argument list of rate_limit (rate_limiter.rs:102-110)
+struct Request {
+    std::string_view key;
+    int64_t max_burst;
+    int64_t count_per_period;
+    int64_t period;
+    int64_t quantity;
+    SystemTime now;
+};
+
+// The GPU-resident store; plays the role of AdaptiveStore (adaptive_cleanup.rs) and
+// implements the Store trait's three operations.
+class GpuStore {
+  public:
+    // AdaptiveStore::with_capacity (adaptive_cleanup.rs:93-106); max_batch bounds rate_limit_batch
+    explicit GpuStore(uint64_t capacity = 1000, uint64_t max_batch = 1 << 16, int device = 0) {
+        tc_config cfg{};
+        cfg.struct_size = sizeof cfg;
+        cfg.flags = TC_CFG_KEY_MODE;
+        cfg.device_id = device;
+        cfg.capacity = capacity;
+        cfg.max_batch = max_batch;
+        int err = 0;
+        e_ = tc_engine_create(&cfg, &err);
+        if (!e_) throw std::runtime_error("tc_engine_create failed: " + std::to_string(err));
+    }
+    GpuStore(const GpuStore&) = delete;
+    GpuStore& operator=(const GpuStore&) = delete;
+    GpuStore(GpuStore&& o) noexcept : e_(o.e_) { o.e_ = nullptr; }
+    ~GpuStore() { tc_engine_destroy(e_); }
+
+    // trait Store (store/mod.rs:85-133); Err(String) -> exception
+    bool compare_and_swap_with_ttl(std::string_view key, int64_t old_v, int64_t new_v, Duration ttl, SystemTime now) {
+        int ok = 0;
+        check(tc_store_compare_and_swap_with_ttl(e_, bytes(key), key.size(), old_v, new_v, (uint64_t)ttl.count(), to_ns(now), &ok));
+        return ok != 0;
+    }
+    std::optional<int64_t> get(std::string_view key, SystemTime now) {
+        int64_t v = 0;
+        int found = 0;
+        check(tc_store_get(e_, bytes(key), key.size(), to_ns(now), &v, &found));
+        return found ? std::optional<int64_t>(v) : std::nullopt;
+    }
+    bool set_if_not_exists_with_ttl(std::string_view key, int64_t value, Duration ttl, SystemTime now) {
+        int ok = 0;
+        check(tc_store_set_if_not_exists_with_ttl(e_, bytes(key), key.size(), value, (uint64_t)ttl.count(), to_ns(now), &ok));
+        return ok != 0;
+    }
+    // AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203), explicit instead of heuristic
+    uint64_t cleanup(SystemTime now) {
+        uint64_t removed = 0;
+        check(tc_sweep_expired(e_, to_ns(now), &removed));
+        return removed;
+    }
+    tc_engine* handle() { return e_; }
+
+  private:
+    static const uint8_t* bytes(std::string_view k) { return reinterpret_cast<const uint8_t*>(k.data()); }
+    void check(int rc) {
+        if (rc != TC_E_OK) throw std::runtime_error(std::string("tcgpu: ") + tc_last_error(e_));
+    }
+    tc_engine* e_;
+};
+
+// RateLimiter<GpuStore> (rate_limiter.rs:42-58)
+class RateLimiter {
+  public:
+    explicit RateLimiter(GpuStore store) : store_(std::move(store)) {}
+
+    // rate_limiter.rs:102-250
+    RateLimitOutcome rate_limit(std::string_view key, int64_t max_burst, int64_t count_per_period, int64_t period,
+                                int64_t quantity, SystemTime now) {
+        tc_result r{};
+        int rc = tc_rate_limit(store_.handle(), reinterpret_cast<const uint8_t*>(key.data()), key.size(), max_burst,
+                               count_per_period, period, quantity, to_ns(now), &r);
+        if (rc != TC_E_OK) return CellError{CellError::Internal, 0, tc_last_error(store_.handle())};
+        return outcome(r.status, r.allowed, r.limit, r.remaining, r.reset_after_ns, r.retry_after_ns, quantity);
+    }
+
+    // The batched entry point: exactly rate_limit applied to reqs[0], reqs[1], ... in order.
+    std::vector<RateLimitOutcome> rate_limit_batch(const std::vector<Request>& reqs) {
+        const size_t n = reqs.size();
+        std::vector<RateLimitOutcome> out;
+        out.reserve(n);
+        if (!n) return out;
+        std::vector<uint8_t> arena;
+        std::vector<uint32_t> off(n + 1, 0);
+        std::vector<int64_t> burst(n), count(n), period(n), qty(n), now(n), limit(n), remaining(n), reset(n), retry(n);
+        std::vector<uint8_t> allowed(n), status(n);
+        for (size_t i = 0; i < n; ++i) {
+            arena.insert(arena.end(), reqs[i].key.begin(), reqs[i].key.end());
+            off[i + 1] = (uint32_t)arena.size();
+            burst[i] = reqs[i].max_burst;
+            count[i] = reqs[i].count_per_period;
+            period[i] = reqs[i].period;
+            qty[i] = reqs[i].quantity;
+            now[i] = to_ns(reqs[i].now);
+        }
+        if (arena.empty()) arena.push_back(0);
+        tc_batch b{};
+        b.struct_size = sizeof b;
+        b.n = n;
+        b.key_bytes = arena.data();
+        b.key_off = off.data();
+        b.max_burst = burst.data();
+        b.count_per_period = count.data();
+        b.period = period.data();
+        b.quantity = qty.data();
+        b.now_ns = now.data();
+        b.allowed = allowed.data();
+        b.status = status.data();
+        b.limit = limit.data();
+        b.remaining = remaining.data();
+        b.reset_after_ns = reset.data();
+        b.retry_after_ns = retry.data();
+        int rc = tc_rate_limit_batch_keys(store_.handle(), &b);
+        for (size_t i = 0; i < n; ++i) {
+            if (rc != TC_E_OK && rc != TC_E_TABLE_FULL)
+                out.push_back(CellError{CellError::Internal, 0, tc_last_error(store_.handle())});
+            else
+                out.push_back(outcome(status[i], allowed[i], limit[i], remaining[i], reset[i], retry[i], qty[i]));
+        }
+        return out;
+    }
+
+    GpuStore& store() { return store_; }
+
+  private:
+    static RateLimitOutcome outcome(uint8_t status, uint8_t allowed, int64_t limit, int64_t remaining, int64_t reset_ns,
+                                    int64_t retry_ns, int64_t quantity) {
+        switch (status) {
+            case TC_OK:
+                return std::make_pair(allowed != 0, RateLimitResult{limit, remaining, Duration(reset_ns), Duration(retry_ns)});
+            case TC_NEGATIVE_QUANTITY: return CellError{CellError::NegativeQuantity, quantity, {}};
+            case TC_INVALID_RATE_LIMIT: return CellError{CellError::InvalidRateLimit, 0, {}};
+            default: return CellError{CellError::Internal, 0, "outside the validated domain (see tcgpu.h)"};
+        }
+    }
+    GpuStore store_;
+};
+
+} // namespace throttlecrab

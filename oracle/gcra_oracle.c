@@ -540,18 +540,32 @@ typedef struct {
     const uint8_t* key_bytes;
     const uint32_t* key_off;
     const tco_batch_io* io;
+    uint16_t* owner;
 } mt_arg;
 
+/* phase 1: every thread routes a contiguous chunk of the stream (owner[i] = shard of key i);
+ * phase 2: every thread serves its own keys, in stream order, from its own AdaptiveStore. */
+static void* mt_route(void* p) {
+    mt_arg* a = (mt_arg*)p;
+    const size_t n = a->io->n, lo = n * (size_t)a->tid / (size_t)a->threads, hi = n * (size_t)(a->tid + 1) / (size_t)a->threads;
+    for (size_t i = lo; i < hi; i++) {
+        const uint8_t* k = a->key_bytes + a->key_off[i];
+        size_t kl = a->key_off[i + 1] - a->key_off[i];
+        /* shard by a hash decorrelated from the in-store placement hash */
+        a->owner[i] = (uint16_t)(mix64(tco_hash_bytes(k, kl) ^ 0xa5a5a5a5a5a5a5a5ull) % (uint64_t)a->threads);
+    }
+    return NULL;
+}
 static void* mt_worker(void* p) {
     mt_arg* a = (mt_arg*)p;
     tco_adaptive* s = tco_adaptive_with_capacity(a->cap, a->created);
     tco_store st = tco_adaptive_as_store(s);
     const tco_batch_io* io = a->io;
+    const uint16_t me = (uint16_t)a->tid;
     for (size_t i = 0; i < io->n; i++) {
+        if (a->owner[i] != me) continue;
         const uint8_t* k = a->key_bytes + a->key_off[i];
         size_t kl = a->key_off[i + 1] - a->key_off[i];
-        /* shard by a hash decorrelated from the in-store placement hash */
-        if ((int)(mix64(tco_hash_bytes(k, kl) ^ 0xa5a5a5a5a5a5a5a5ull) % (uint64_t)a->threads) != a->tid) continue;
         tco_result r;
         tco_rate_limit(&st, k, kl, IO_ARGS(io, i), &r);
         io_store(io, i, &r);
@@ -564,20 +578,25 @@ double tco_batch_keys_mt(int threads, size_t capacity_per_thread, int64_t create
                          const uint8_t* key_bytes, const uint32_t* key_off,
                          const tco_batch_io* io) {
     if (threads < 1) threads = 1;
+    if (threads > 60000) threads = 60000;
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof *th);
     mt_arg* args = (mt_arg*)calloc((size_t)threads, sizeof *args);
+    uint16_t* owner = (uint16_t*)malloc((io->n ? io->n : 1) * sizeof *owner);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     for (int t = 0; t < threads; t++) {
         args[t].tid = t; args[t].threads = threads; args[t].cap = capacity_per_thread;
         args[t].created = created_ns; args[t].key_bytes = key_bytes; args[t].key_off = key_off;
-        args[t].io = io;
-        pthread_create(&th[t], NULL, mt_worker, &args[t]);
+        args[t].io = io; args[t].owner = owner;
+        pthread_create(&th[t], NULL, mt_route, &args[t]);
     }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, mt_worker, &args[t]);
     for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     free(th);
     free(args);
+    free(owner);
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 

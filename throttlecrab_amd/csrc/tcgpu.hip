@@ -958,11 +958,11 @@ static const uint64_t* sort_by_slot(tc_engine* e, const uint32_t* d_slot, uint32
     prof_mark(e, TC_STAGE_PREP);
     hipLaunchKernelGGL(rs::k_hist, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap,
                        passes, ws, tiles);
-    prof_mark(e, TC_STAGE_SORT);
     uint64_t* bufs[2] = {e->elem_a, e->elem_b};
     const uint64_t* in = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
+        prof_mark(e, TC_STAGE_SORT); // one mark per pass: the stage average is per kernel launch
         if (p == 0)
             hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
                                (const uint64_t*)nullptr, out, n, cap, p, ws);

@@ -64,9 +64,27 @@ def shard_of(key_id: np.ndarray, world: int) -> np.ndarray:
 
 
 def string_keys(ids: np.ndarray, prefix: bytes = b"key_"):
-    """`format!("key_{}", i)` arena for ids -> (bytes uint8[], offsets uint32[n+1])."""
-    strs = [prefix + str(int(i)).encode() for i in ids]
-    off = np.zeros(len(strs) + 1, dtype=np.uint32)
-    off[1:] = np.cumsum([len(s) for s in strs])
-    buf = np.frombuffer(b"".join(strs), dtype=np.uint8).copy() if strs else np.zeros(1, np.uint8)
+    """`format!("key_{}", i)` key arena for ids -> (bytes uint8[], offsets uint32[n+1]);
+    vectorised (the benches format millions of keys)."""
+    ids = np.asarray(ids, dtype=np.uint64)
+    n, plen = len(ids), len(prefix)
+    nd = np.ones(n, dtype=np.int64)
+    p10 = np.uint64(10)
+    lim = p10
+    for _ in range(19):
+        nd += ids >= lim
+        lim = lim * p10 if lim < np.uint64(10**18) else np.uint64(2**64 - 1)
+    lens = nd + plen
+    off = np.zeros(n + 1, dtype=np.uint32)
+    off[1:] = np.cumsum(lens)
+    buf = np.zeros(max(int(off[-1]), 1), dtype=np.uint8)
+    base = off[:-1].astype(np.int64)
+    for j, ch in enumerate(prefix):
+        buf[base + j] = ch
+    rem = ids.copy()
+    # least significant digit goes to the last position
+    for d in range(int(nd.max()) if n else 0):
+        m = nd > d
+        buf[base[m] + plen + nd[m] - 1 - d] = (rem[m] % p10).astype(np.uint8) + ord("0")
+        rem //= p10
     return buf, off
