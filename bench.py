@@ -12,7 +12,8 @@ decisions-only output).  Duplicate keys inside a batch are honoured exactly.
 N > 1 (torchrun, one rank per GPU): the key space is hash-sharded, every rank
 owns 10 M keys and serves its own 1 Mi-request batch per step (weak scaling, no
 collective on the decision path); the per-GPU counter blocks are all-gathered
-over RCCL every step (the only exchange the path has).
+over RCCL every METRICS_EVERY steps and after the last one, inside the timed
+region (the only exchange the path has: aggregate metrics).
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +32,7 @@ N_KEYS = 10_000_000
 BATCH = 1 << 20
 ALG_BYTES_PER_DECISION = 36.125  # SURVEY.md section 8(d), slot mode, decisions only
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
+METRICS_EVERY = 8                # N > 1: RCCL all-gather of the counter blocks every this many steps (+ the last)
 
 
 KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep (one pass)", "eval": "k_eval_sorted",
@@ -79,10 +81,10 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
     import torch
     it = 0
 
-    def one(i):
+    def one(i, last=False):
         eng.rate_limit_batch_slots(d_batches[i % len(d_batches)], registered=True, quantity=1,
-                                   now_ns=now0 + i * 1_000_000, want=want, out=out)
-        if dist is not None:
+                                   now_ns=now0 + i * 1_000_000, want=want, out=out, inputs_ready=True)
+        if dist is not None and (i % METRICS_EVERY == METRICS_EVERY - 1 or last):
             eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
 
@@ -93,8 +95,8 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(steps):
-        one(it)
+    for k in range(steps):
+        one(it, last=(k == steps - 1))
         it += 1
     torch.cuda.synchronize()
     if dist is not None:
@@ -107,13 +109,15 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
     return dt, it
 
 
-def stage_profile(eng, d_batches, out, now0, steps, it0):
-    """Same steps again with HIP events between the engine's kernels."""
+def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True):
+    """Same steps again with a HIP event pair around each of the engine's kernels (recorded on
+    the stream the kernel runs on).  piped=True: as in the timed region, the sort of later batches
+    overlaps the evaluation of earlier ones, so the durations include that contention."""
     import torch
     eng.profile_enable(True)
     for i in range(steps):
         eng.rate_limit_batch_slots(d_batches[(it0 + i) % len(d_batches)], registered=True, quantity=1,
-                                   now_ns=now0 + (it0 + i) * 1_000_000, want=("allowed",), out=out)
+                                   now_ns=now0 + (it0 + i) * 1_000_000, want=("allowed",), out=out, inputs_ready=piped)
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile_enable(False)
@@ -243,20 +247,31 @@ def main():
         "config": {"workload": f"configs[{1 if a.workload == 'uniform' else 2}]: {a.keys} pre-hashed keys SoA per GPU, "
                                f"{a.workload} request stream, batch={a.batch}, params (100,1000/3600s), q=1",
                    "keys_per_gpu": a.keys, "batch": a.batch, "stream": a.workload,
-                   "parallelism": f"hash-shard x{world}", "outputs": "allowed u8 (decisions only)"},
+                   "parallelism": f"hash-shard x{world}", "outputs": "allowed u8 (decisions only)",
+                   "pipelining": "TC_B_INPUTS_READY: batch k+1.. grouped on auxiliary streams while batch k is evaluated",
+                   "metrics_allgather_every": METRICS_EVERY if world > 1 else None},
         "allowed_fraction": counters["allowed"] / max(1, counters["total"]),
     }
 
     if rank == 0:
-        # roofline of the dominant stage, from HIP events on the engine's stream
-        prof = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it)
+        # roofline of the dominant kernel: a HIP event pair around every launch, on the stream
+        # it runs on, over the same pipelined steps as the timed region (so the durations carry
+        # the contention between the grouping kernels of later batches and the evaluation of
+        # earlier ones, exactly as rocprofv3 sees them); `isolated` = the same kernels with the
+        # batches issued strictly in order on one stream
+        prof = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True)
         stages = {k: v[0] / max(1, v[1]) for k, v in prof.items() if v[1]}
+        iso = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False)
+        iso_stages = {k: v[0] / max(1, v[1]) for k, v in iso.items() if v[1]}
         dom = max(stages, key=stages.get)
         alg_bytes = ALG_BYTES_PER_DECISION * a.batch
         ach = alg_bytes / (stages[dom] * 1e-3) / 1e9
+        ach_iso = alg_bytes / (iso_stages[dom] * 1e-3) / 1e9
         result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "kernel": KERNEL_OF_STAGE[dom],
                               "avg_ms": stages[dom], "stage_ms": stages,
+                              "isolated": {"avg_ms": iso_stages[dom], "achieved": ach_iso,
+                                           "frac": ach_iso / HBM_PEAK_GBS, "stage_ms": iso_stages},
                               "whole_batch_GBs": alg_bytes * a.steps / dt / 1e9}
         if not a.no_also and world == 1:
             also = {}

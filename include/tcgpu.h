@@ -79,6 +79,11 @@ typedef struct tc_config {
 #define TC_B_DEVICE_PTRS 0x1u       /* every pointer in the batch is a device pointer (async on the stream) */
 #define TC_B_REGISTERED_PARAMS 0x2u /* use the per-slot (burst,count,period) set by tc_register_params */
 #define TC_B_UNIQUE_SLOTS 0x4u      /* caller guarantees no slot occurs twice (skips grouping) */
+#define TC_B_INPUTS_READY 0x8u      /* device-pointer batch whose `slot` column is already complete in device memory at
+                                     * call time and stays untouched until the call's results are ready: the engine may
+                                     * group (sort) it on an internal stream while earlier batches are still being
+                                     * evaluated.  Evaluation order, results and visibility on the engine's stream are
+                                     * unchanged; without the flag the whole batch runs in order on the engine's stream */
 
 /* One batch of requests = the argument list of RateLimiter::rate_limit
  * (rate_limiter.rs:102-110), columnar.  A NULL input column means "use the

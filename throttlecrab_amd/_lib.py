@@ -16,7 +16,7 @@ TC_OK, TC_NEGATIVE_QUANTITY, TC_INVALID_RATE_LIMIT, TC_INTERNAL = 0, 1, 2, 3
 (TC_E_OK, TC_E_INVALID_ARG, TC_E_HIP, TC_E_NOMEM, TC_E_BATCH_TOO_LARGE, TC_E_TABLE_FULL, TC_E_NO_DEVICE,
  TC_E_UNSUPPORTED) = (0, -1, -2, -3, -4, -5, -6, -7)
 TC_CFG_KEY_MODE = 0x1
-TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS = 0x1, 0x2, 0x4
+TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY = 0x1, 0x2, 0x4, 0x8
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
 TC_CNT_COUNT = 8
 TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash")

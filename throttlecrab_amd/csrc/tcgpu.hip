@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -33,7 +34,10 @@ using tc::Slot;
 namespace {
 
 constexpr int BLOCK = 256;
-constexpr int SORT_ITEMS = 16; // items per thread of a sort tile (tile = 4096 requests)
+constexpr int SORT_ITEMS = 8;  // items per thread of a sort tile (tile = 2048 requests; 512 tiles per 1 Mi batch)
+constexpr int PIPE_DEPTH_MAX = 8;
+constexpr int AUX_MAX = 4, AUX_DEFAULT = 2; // auxiliary (grouping) streams: main + aux must fit the 4 HW queues HIP uses
+constexpr int PIPE_DEPTH_DEFAULT = 3; // grouping scratch sets: batches whose sort may be in flight at once
 constexpr uint32_t F_REGISTERED = 1u; // Params.flags: per-slot registered rate
 constexpr uint32_t F_NEED_BURST = 2u; // read bursts[] (limit wanted, or not every slot registered)
 
@@ -199,7 +203,8 @@ struct __attribute__((aligned(16))) PendEntry {
 //     performing the last allowed step -- produces the new cell.  If the whole
 //     segment sits inside this wave the lane stores it directly (every lane of
 //     the segment loaded the old cell earlier in program order); otherwise the
-//     store is parked in pend[] and applied by k_commit_list after this kernel,
+//     store is parked in pend[] and applied by k_commit_list after this kernel (folding it into
+//     the kernel's last block was measured slower: the hand-off needs every block to drain its stores),
 //     so no lane of another wave can read a half-updated cell.
 //   otherwise: the segment head walks its segment in index order.
 // ---------------------------------------------------------------------------
@@ -580,8 +585,12 @@ inline int bit_width_u64(uint64_t v) {
 // ---------------------------------------------------------------------------
 struct tc_engine {
     int device = 0;
+    // The stream evaluations are ordered on: the caller's (tc_engine_set_stream) or a private
+    // one that is only created when first needed -- HIP multiplexes streams onto few hardware
+    // queues (4 by default), and a main stream that shares a queue with an auxiliary stream
+    // serialises the pipeline (measured: 12 -> 5.7 G decisions/s), so no stream is created idly.
     hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
+    hipStream_t user_stream = nullptr;
     uint64_t capacity = 0, max_batch = 0;
     uint32_t cfg_flags = 0;
 
@@ -590,11 +599,23 @@ struct tc_engine {
     bool all_registered = false;
     unsigned long long* counters = nullptr; // TC_CNT_COUNT canonical + 1 scratch + NSHARD*SHARD_WORDS shards
 
-    // grouping scratch
-    uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
-    uint32_t* sort_ws = nullptr;                   // hist x2 | ticket | status
+    // grouping scratch: a ring of `depth` sets.  A batch flagged TC_B_INPUTS_READY is
+    // sorted on its set's auxiliary stream while earlier batches are still being evaluated
+    // on `stream` (the sort never touches the resident state); evaluation stays in order.
+    struct SortSet {
+        uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
+        uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
+        uint32_t hist_parity = 0;
+        hipEvent_t sorted = nullptr;   // recorded on the auxiliary stream after the last pass
+        hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
+        bool in_use = false;
+    } sets[PIPE_DEPTH_MAX];
+    uint32_t depth = PIPE_DEPTH_DEFAULT; // sets actually allocated
+    hipStream_t aux[AUX_MAX] = {};       // set k groups on aux[k % n_aux]
+    uint32_t n_aux = AUX_DEFAULT;
+    uint32_t next_aux = 0;
+    uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
-    uint32_t hist_parity = 0;
     PendEntry* pend = nullptr;
     uint32_t* pend_count = nullptr;
     uint8_t* allowed_tmp = nullptr;
@@ -623,28 +644,40 @@ struct tc_engine {
     size_t k_stage_bytes_cap = 0;
     uint32_t* k_stage_off = nullptr;  // max_batch + 1
 
-    // optional per-stage HIP-event timing (tc_profile_*)
+    // optional per-stage HIP-event timing (tc_profile_*): a (begin, end) event pair per
+    // kernel, recorded on the stream the kernel is launched on
     bool prof_on = false;
-    std::vector<hipEvent_t> prof_ev;
+    std::vector<hipEvent_t> prof_ev; // 2 per record
     std::vector<int> prof_stage;
-    size_t prof_used = 0;
+    size_t prof_used = 0;            // records
     double prof_ms[TC_STAGE_COUNT] = {0};
     uint64_t prof_calls[TC_STAGE_COUNT] = {0};
 
     std::string err;
 };
 
-// record "stage begins here" (stage < 0: end of the batch) on the engine's stream
-static void prof_mark(tc_engine* e, int stage) {
+static hipStream_t cur_stream(tc_engine* e) {
+    if (e->user_stream) return e->user_stream;
+    if (!e->own_stream && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return e->own_stream;
+}
+
+// begin / end of one kernel of `stage` on stream `s` (no-ops unless profiling)
+static void prof_begin(tc_engine* e, int stage, hipStream_t s) {
     if (!e->prof_on) return;
-    if (e->prof_used == e->prof_ev.size()) {
-        hipEvent_t ev;
-        if (hipEventCreate(&ev) != hipSuccess) return;
-        e->prof_ev.push_back(ev);
+    if (e->prof_used == e->prof_stage.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        e->prof_ev.push_back(a);
+        e->prof_ev.push_back(b);
         e->prof_stage.push_back(-1);
     }
     e->prof_stage[e->prof_used] = stage;
-    (void)hipEventRecord(e->prof_ev[e->prof_used], e->stream);
+    (void)hipEventRecord(e->prof_ev[2 * e->prof_used], s);
+}
+static void prof_end(tc_engine* e, hipStream_t s) {
+    if (!e->prof_on || e->prof_used == e->prof_stage.size()) return;
+    (void)hipEventRecord(e->prof_ev[2 * e->prof_used + 1], s);
     e->prof_used++;
 }
 
@@ -666,34 +699,44 @@ extern "C" uint32_t tc_abi_version(void) { return TCGPU_ABI_VERSION; }
 
 extern "C" const char* tc_last_error(const tc_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
-static size_t sort_ws_words(uint32_t max_tiles) {
-    return (size_t)2 * rs::MAX_PASSES * rs::RADIX + rs::MAX_PASSES + (size_t)rs::MAX_PASSES * max_tiles * rs::RADIX;
-}
+static size_t sort_ws_words(uint32_t max_tiles) { return rs::workspace_words(max_tiles); }
 
 static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipSetDevice(e->device));
-    TC_HIP(e, hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-    e->stream = e->own_stream;
     const uint64_t cap = e->capacity, mb = e->max_batch;
     TC_HIP(e, hipMalloc(&e->table, cap * sizeof(Slot)));
     TC_HIP(e, hipMalloc(&e->bursts, cap * sizeof(int64_t)));
     const size_t cnt_words = (TC_CNT_COUNT + 1) + (size_t)NSHARD * SHARD_WORDS;
     TC_HIP(e, hipMalloc(&e->counters, cnt_words * sizeof(unsigned long long)));
-    TC_HIP(e, hipMemsetAsync(e->table, 0, cap * sizeof(Slot), e->stream));
-    TC_HIP(e, hipMemsetAsync(e->bursts, 0, cap * sizeof(int64_t), e->stream));
-    TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), e->stream));
-    TC_HIP(e, hipMalloc(&e->elem_a, mb * sizeof(uint64_t)));
-    TC_HIP(e, hipMalloc(&e->elem_b, mb * sizeof(uint64_t)));
+    TC_HIP(e, hipMemsetAsync(e->table, 0, cap * sizeof(Slot), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->bursts, 0, cap * sizeof(int64_t), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), (hipStream_t)0));
     e->sort_max_tiles = (uint32_t)((mb + rs::THREADS * SORT_ITEMS - 1) / (rs::THREADS * SORT_ITEMS));
     const size_t words = sort_ws_words(e->sort_max_tiles);
-    TC_HIP(e, hipMalloc(&e->sort_ws, words * sizeof(uint32_t)));
-    TC_HIP(e, hipMemsetAsync(e->sort_ws, 0, words * sizeof(uint32_t), e->stream));
+    if (const char* d = getenv("TCGPU_PIPE_DEPTH")) e->depth = (uint32_t)std::min(std::max(atoi(d), 1), PIPE_DEPTH_MAX);
+    int prio_lo = 0, prio_hi = 0;
+    TC_HIP(e, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    const char* pe = getenv("TCGPU_AUX_PRIORITY");
+    const bool aux_high = !pe || atoi(pe) != 0;
+    if (const char* d = getenv("TCGPU_AUX_STREAMS")) e->n_aux = (uint32_t)std::min(std::max(atoi(d), 1), AUX_MAX);
+    // grouping kernels are small and latency-bound: let them in ahead of the wide evaluation kernel
+    for (uint32_t ai = 0; ai < e->n_aux; ++ai)
+        TC_HIP(e, hipStreamCreateWithPriority(&e->aux[ai], hipStreamNonBlocking, aux_high ? prio_hi : prio_lo));
+    for (uint32_t si = 0; si < e->depth; ++si) {
+        tc_engine::SortSet& ss = e->sets[si];
+        TC_HIP(e, hipMalloc(&ss.elem_a, mb * sizeof(uint64_t)));
+        TC_HIP(e, hipMalloc(&ss.elem_b, mb * sizeof(uint64_t)));
+        TC_HIP(e, hipMalloc(&ss.ws, words * sizeof(uint32_t)));
+        TC_HIP(e, hipMemsetAsync(ss.ws, 0, words * sizeof(uint32_t), (hipStream_t)0));
+        TC_HIP(e, hipEventCreateWithFlags(&ss.sorted, hipEventDisableTiming));
+        TC_HIP(e, hipEventCreateWithFlags(&ss.consumed, hipEventDisableTiming));
+    }
     TC_HIP(e, hipMalloc(&e->pend, (mb / 32 + 1024) * sizeof(PendEntry)));
     TC_HIP(e, hipMalloc(&e->pend_count, 2 * sizeof(uint32_t)));
-    TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), e->stream));
+    TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
     TC_HIP(e, hipMalloc(&e->op_result, sizeof(StoreOpResult)));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
     return TC_E_OK;
 }
 
@@ -721,8 +764,8 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
                  o_cell = take(cap * (size_t)cell), o_ovf = take(overflow), o_free = take(cap * 4), o_misc = take(64);
     TC_HIP(e, hipMalloc(&e->kt_block, off));
     uint8_t* base = (uint8_t*)e->kt_block;
-    TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * 8, e->stream));
-    TC_HIP(e, hipMemsetAsync(base + o_misc, 0, 64, e->stream));
+    TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * 8, (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(base + o_misc, 0, 64, (hipStream_t)0));
     kt::Table& t = e->kt;
     t.ktab = (unsigned long long*)(base + o_ktab);
     t.nb_mask = nb - 1;
@@ -739,25 +782,25 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     t.error_flag = (uint32_t*)(base + o_misc + 16);
     t.free_slots = (uint32_t*)(base + o_free);
     t.capacity = (uint32_t)cap;
-    hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, e->stream,
+    hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, (hipStream_t)0,
                        t.free_slots, t.key_len, (uint32_t)cap);
     const int top = (int)cap;
-    TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, e->stream));
+    TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->k_slot, mb * 4));
     TC_HIP(e, hipMalloc(&e->k_state, mb * 4));
     TC_HIP(e, hipMalloc(&e->k_aux, mb * 4));
     TC_HIP(e, hipMalloc(&e->k_hash, mb * 8));
     TC_HIP(e, hipMalloc(&e->k_stage_off, (mb + 1) * 4));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
     e->key_mode = true;
     return TC_E_OK;
 }
 
 // keys (device arena) -> e->k_slot[0..n): found slot, freshly bound slot, or NO_SLOT
 static int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert) {
-    hipStream_t s = e->stream;
+    hipStream_t s = cur_stream(e);
     const dim3 grid(nblocks(n)), block(kt::THREADS);
-    prof_mark(e, TC_STAGE_HASH);
+    prof_begin(e, TC_STAGE_HASH, s);
     if (insert) {
         hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state, e->k_aux,
                            e->k_hash);
@@ -768,6 +811,7 @@ static int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint3
         hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state,
                            e->k_aux, e->k_hash);
     }
+    prof_end(e, s);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
@@ -783,8 +827,8 @@ static int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* ke
         TC_HIP(e, hipMalloc(&e->k_stage_bytes, want));
         e->k_stage_bytes_cap = want;
     }
-    if (total) TC_HIP(e, hipMemcpyAsync(e->k_stage_bytes, key_bytes, total, hipMemcpyHostToDevice, e->stream));
-    TC_HIP(e, hipMemcpyAsync(e->k_stage_off, key_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    if (total) TC_HIP(e, hipMemcpyAsync(e->k_stage_bytes, key_bytes, total, hipMemcpyHostToDevice, cur_stream(e)));
+    TC_HIP(e, hipMemcpyAsync(e->k_stage_off, key_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
     *d_bytes = e->k_stage_bytes ? e->k_stage_bytes : (const uint8_t*)e->k_stage_off;
     *d_off = e->k_stage_off;
     return TC_E_OK;
@@ -800,17 +844,17 @@ static int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, boo
     if (rc != TC_E_OK) return rc;
     rc = resolve_keys_device(e, d_bytes, d_off, 1, insert);
     if (rc != TC_E_OK) return rc;
-    TC_HIP(e, hipMemcpyAsync(slot, e->k_slot, sizeof(uint32_t), hipMemcpyDeviceToHost, e->stream));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipMemcpyAsync(slot, e->k_slot, sizeof(uint32_t), hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     return TC_E_OK;
 }
 
 static int rebuild_key_table(tc_engine* e) {
     kt::Table& t = e->kt;
-    TC_HIP(e, hipMemsetAsync(t.ktab, 0, (t.nb_mask + 1) * 8, e->stream));
-    TC_HIP(e, hipMemsetAsync(t.tombs, 0, sizeof(uint32_t), e->stream));
+    TC_HIP(e, hipMemsetAsync(t.ktab, 0, (t.nb_mask + 1) * 8, cur_stream(e)));
+    TC_HIP(e, hipMemsetAsync(t.tombs, 0, sizeof(uint32_t), cur_stream(e)));
     hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), dim3(kt::THREADS), 0,
-                       e->stream, t);
+                       cur_stream(e), t);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
@@ -852,8 +896,21 @@ extern "C" tc_engine* tc_engine_create(const tc_config* cfg, int* err) {
 extern "C" void tc_engine_destroy(tc_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    if (e->user_stream) (void)hipStreamSynchronize(e->user_stream);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    void* ptrs[] = {e->table, e->bursts, e->counters, e->elem_a, e->elem_b, e->sort_ws, e->pend, e->pend_count,
+    for (hipStream_t a : e->aux)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
+    for (tc_engine::SortSet& ss : e->sets) {
+        if (ss.sorted) (void)hipEventDestroy(ss.sorted);
+        if (ss.consumed) (void)hipEventDestroy(ss.consumed);
+        void* sp[] = {ss.elem_a, ss.elem_b, ss.ws};
+        for (void* p : sp)
+            if (p) (void)hipFree(p);
+    }
+    void* ptrs[] = {e->table, e->bursts, e->counters, e->pend, e->pend_count,
                     e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status};
@@ -869,14 +926,16 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
 
 extern "C" int tc_engine_set_stream(tc_engine* e, void* hip_stream) {
     if (!e) return TC_E_INVALID_ARG;
-    e->stream = hip_stream ? (hipStream_t)hip_stream : e->own_stream;
+    TC_HIP(e, hipSetDevice(e->device));
+    if (e->user_stream || e->own_stream) TC_HIP(e, hipStreamSynchronize(cur_stream(e))); // drain the old one first
+    e->user_stream = (hipStream_t)hip_stream;
     return TC_E_OK;
 }
 
 extern "C" int tc_synchronize(tc_engine* e) {
     if (!e) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     return TC_E_OK;
 }
 
@@ -886,10 +945,10 @@ extern "C" int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64
     if (tc::derive_rate(max_burst, count_per_period, period, r.ei, r.dvt) != tc::ST_OK)
         return fail(e, TC_E_INVALID_ARG, "tc_register_params_uniform: invalid (burst,count,period)");
     TC_HIP(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_fill_rates, dim3(std::min<uint64_t>(nblocks(e->capacity), 4096)), dim3(BLOCK), 0, e->stream,
+    hipLaunchKernelGGL(k_fill_rates, dim3(std::min<uint64_t>(nblocks(e->capacity), 4096)), dim3(BLOCK), 0, cur_stream(e),
                        e->table, e->bursts, e->capacity, r, max_burst);
     TC_HIP(e, hipGetLastError());
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     e->all_registered = true;
     return TC_E_OK;
 }
@@ -912,12 +971,12 @@ extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slot
     TC_HIP(e, hipMalloc(&d_r, n * sizeof(Rate)));
     TC_HIP(e, hipMalloc(&d_b, n * sizeof(int64_t)));
     if (slots) TC_HIP(e, hipMalloc(&d_s, n * sizeof(uint32_t)));
-    TC_HIP(e, hipMemcpyAsync(d_r, hr.data(), n * sizeof(Rate), hipMemcpyHostToDevice, e->stream));
-    TC_HIP(e, hipMemcpyAsync(d_b, max_burst, n * sizeof(int64_t), hipMemcpyHostToDevice, e->stream));
-    if (slots) TC_HIP(e, hipMemcpyAsync(d_s, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
-    hipLaunchKernelGGL(k_scatter_rates, dim3(nblocks(n)), dim3(BLOCK), 0, e->stream, e->table, e->bursts, d_s, d_r, d_b, n);
+    TC_HIP(e, hipMemcpyAsync(d_r, hr.data(), n * sizeof(Rate), hipMemcpyHostToDevice, cur_stream(e)));
+    TC_HIP(e, hipMemcpyAsync(d_b, max_burst, n * sizeof(int64_t), hipMemcpyHostToDevice, cur_stream(e)));
+    if (slots) TC_HIP(e, hipMemcpyAsync(d_s, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+    hipLaunchKernelGGL(k_scatter_rates, dim3(nblocks(n)), dim3(BLOCK), 0, cur_stream(e), e->table, e->bursts, d_s, d_r, d_b, n);
     TC_HIP(e, hipGetLastError());
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     (void)hipFree(d_r);
     (void)hipFree(d_b);
     if (d_s) (void)hipFree(d_s);
@@ -939,36 +998,32 @@ static int stage_ensure(tc_engine* e) {
     return TC_E_OK;
 }
 
-// stable sort of (slot, index) by slot; returns the buffer holding the result
-static const uint64_t* sort_by_slot(tc_engine* e, const uint32_t* d_slot, uint32_t n) {
-    hipStream_t s = e->stream;
+// stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
+// returns the buffer holding the result
+static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
     const int passes = (bits + 7) / 8;
     const uint32_t tile = rs::THREADS * SORT_ITEMS;
     const uint32_t tiles = (n + tile - 1) / tile;
-    rs::Workspace ws;
-    uint32_t* base = e->sort_ws;
-    ws.hist = base + (size_t)e->hist_parity * rs::MAX_PASSES * rs::RADIX;
-    ws.hist_next = base + (size_t)(e->hist_parity ^ 1u) * rs::MAX_PASSES * rs::RADIX;
-    ws.ticket = base + (size_t)2 * rs::MAX_PASSES * rs::RADIX;
-    ws.status = ws.ticket + rs::MAX_PASSES;
-    ws.max_tiles = e->sort_max_tiles;
-    e->hist_parity ^= 1u;
-    prof_mark(e, TC_STAGE_PREP);
+    const rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
+    ss.hist_parity ^= 1u;
+    prof_begin(e, TC_STAGE_PREP, s);
     hipLaunchKernelGGL(rs::k_hist, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap,
                        passes, ws, tiles);
-    uint64_t* bufs[2] = {e->elem_a, e->elem_b};
+    prof_end(e, s);
+    uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
     const uint64_t* in = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
-        prof_mark(e, TC_STAGE_SORT); // one mark per pass: the stage average is per kernel launch
+        prof_begin(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
         if (p == 0)
             hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
                                (const uint64_t*)nullptr, out, n, cap, p, ws);
         else
             hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
                                (const uint32_t*)nullptr, in, out, n, cap, p, ws);
+        prof_end(e, s);
         in = out;
     }
     return in;
@@ -1007,32 +1062,56 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     }
     const bool full = p.remaining || p.reset || p.retry;
     const dim3 grid(nblocks(n)), block(BLOCK);
-    hipStream_t s = e->stream;
+    hipStream_t s = cur_stream(e);
 
     if (b.flags & TC_B_UNIQUE_SLOTS) {
-        prof_mark(e, TC_STAGE_EVAL);
+        prof_begin(e, TC_STAGE_EVAL, s);
         if (full) hipLaunchKernelGGL(k_eval_unique<true>, grid, block, 0, s, p);
         else hipLaunchKernelGGL(k_eval_unique<false>, grid, block, 0, s, p);
+        prof_end(e, s);
     } else {
-        const uint64_t* sorted = sort_by_slot(e, b.slot, n);
+        // grouping: on the set's auxiliary stream when the caller vouches for the inputs
+        // (overlaps with the evaluation of earlier batches), else in order on `s`
+        tc_engine::SortSet& ss = e->sets[e->next_set];
+        e->next_set = (e->next_set + 1) % e->depth;
+        const bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        const uint64_t* sorted;
+        if (piped) {
+            hipStream_t ax = e->aux[e->next_aux];
+            e->next_aux = (e->next_aux + 1) % e->n_aux;
+            if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
+            sorted = sort_by_slot(e, ss, ax, b.slot, n);
+            TC_HIP(e, hipEventRecord(ss.sorted, ax));
+            TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
+        } else {
+            // everything that used this set earlier is ordered before us on `s`: evaluations ran on `s`,
+            // and every auxiliary sort was joined into `s` before its evaluation
+            sorted = sort_by_slot(e, ss, s, b.slot, n);
+        }
         const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!p.burst && !p.count && !p.period);
         const bool uniform = !p.q && !p.now && params_by_slot;
-        prof_mark(e, TC_STAGE_EVAL);
+        prof_begin(e, TC_STAGE_EVAL, s);
         if (uniform) {
             if (full) hipLaunchKernelGGL((k_eval_sorted<true, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
             else hipLaunchKernelGGL((k_eval_sorted<false, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
-            prof_mark(e, TC_STAGE_COMMIT);
+            prof_end(e, s);
+            prof_begin(e, TC_STAGE_COMMIT, s);
             hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->table);
+            prof_end(e, s);
         } else {
             if (full) hipLaunchKernelGGL((k_eval_sorted<true, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
             else hipLaunchKernelGGL((k_eval_sorted<false, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
+            prof_end(e, s);
         }
+        // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream
+        TC_HIP(e, hipEventRecord(ss.consumed, s));
+        ss.in_use = true;
     }
     if (b.allowed_bits) {
-        prof_mark(e, TC_STAGE_PACK);
+        prof_begin(e, TC_STAGE_PACK, s);
         hipLaunchKernelGGL(k_pack_bits, grid, block, 0, s, p.allowed, n, b.allowed_bits);
+        prof_end(e, s);
     }
-    prof_mark(e, -1);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
@@ -1041,7 +1120,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
 // other inputs, run, copy the outputs back, synchronise.
 static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     const uint64_t n = b.n;
-    hipStream_t s = e->stream;
+    hipStream_t s = cur_stream(e);
     tc_batch d = b;
     d.flags |= TC_B_DEVICE_PTRS;
     d.slot = e->stage.slot;
@@ -1091,17 +1170,17 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     // host pointers: stage in, run, stage out, synchronise
     int rc = stage_ensure(e);
     if (rc != TC_E_OK) return rc;
-    TC_HIP(e, hipMemcpyAsync(e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, e->stream));
+    TC_HIP(e, hipMemcpyAsync(e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
     return run_slots_host_staged(e, b);
 }
 
 // did any key of the batches since the last check fail to get a slot?
 static int check_key_errors(tc_engine* e) {
     uint32_t flag = 0;
-    TC_HIP(e, hipMemcpyAsync(&flag, e->kt.error_flag, sizeof flag, hipMemcpyDeviceToHost, e->stream));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipMemcpyAsync(&flag, e->kt.error_flag, sizeof flag, hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     if (flag) {
-        TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, e->stream));
+        TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, cur_stream(e)));
         return fail(e, TC_E_TABLE_FULL, "key table full: some keys got status Internal (raise capacity or sweep)");
     }
     return TC_E_OK;
@@ -1138,7 +1217,7 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     // slot column already on the device
     rc = stage_ensure(e);
     if (rc != TC_E_OK) return rc;
-    TC_HIP(e, hipMemcpyAsync(e->stage.slot, e->k_slot, b.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, e->stream));
+    TC_HIP(e, hipMemcpyAsync(e->stage.slot, e->k_slot, b.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, cur_stream(e)));
     rc = run_slots_host_staged(e, b);
     if (rc != TC_E_OK) return rc;
     return check_key_errors(e);
@@ -1194,20 +1273,20 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     if (!e) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));
     unsigned long long* scratch = e->counters + TC_CNT_COUNT;
-    TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), e->stream));
-    TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), e->stream));
+    TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), cur_stream(e)));
+    TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), cur_stream(e)));
     if (e->key_mode)
-        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, e->stream,
+        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
                            e->table, e->kt, now_ns, e->counters, scratch);
     else
-        hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, e->stream,
+        hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
                            e->table, e->capacity, now_ns, e->counters, scratch);
     TC_HIP(e, hipGetLastError());
     unsigned long long r = 0;
     uint32_t tombs = 0;
-    TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, e->stream));
-    if (e->key_mode) TC_HIP(e, hipMemcpyAsync(&tombs, e->kt.tombs, sizeof tombs, hipMemcpyDeviceToHost, e->stream));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, cur_stream(e)));
+    if (e->key_mode) TC_HIP(e, hipMemcpyAsync(&tombs, e->kt.tombs, sizeof tombs, hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     if (removed) *removed = r;
     // tombstones lengthen probe chains: rebuild the table once they fill 1/4 of it
     if (e->key_mode && (uint64_t)tombs > (e->kt.nb_mask + 1) / 4) return rebuild_key_table(e);
@@ -1217,7 +1296,7 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
 extern "C" int tc_counters_refresh(tc_engine* e) {
     if (!e) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(NSHARD), 0, e->stream, e->counters);
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(NSHARD), 0, cur_stream(e), e->counters);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
@@ -1226,8 +1305,8 @@ extern "C" int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]) {
     if (!e || !out) return TC_E_INVALID_ARG;
     int rc = tc_counters_refresh(e);
     if (rc != TC_E_OK) return rc;
-    TC_HIP(e, hipMemcpyAsync(out, e->counters, TC_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, e->stream));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipMemcpyAsync(out, e->counters, TC_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     out[TC_CNT_BATCHES] = e->batches;
     return TC_E_OK;
 }
@@ -1246,12 +1325,14 @@ extern "C" int tc_profile_enable(tc_engine* e, int on) {
 extern "C" int tc_profile_read(tc_engine* e, double total_ms[TC_STAGE_COUNT], uint64_t calls[TC_STAGE_COUNT]) {
     if (!e || !total_ms || !calls) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
-    for (size_t i = 0; i + 1 < e->prof_used; ++i) {
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    for (hipStream_t a : e->aux)
+        if (a) TC_HIP(e, hipStreamSynchronize(a));
+    for (size_t i = 0; i < e->prof_used; ++i) {
         const int st = e->prof_stage[i];
         if (st < 0) continue;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]) == hipSuccess) {
+        if (hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]) == hipSuccess) {
             e->prof_ms[st] += ms;
             e->prof_calls[st] += 1;
         }
@@ -1294,10 +1375,10 @@ static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, u
                     StoreOpResult* r) {
     if (now < 0) return fail(e, TC_E_INVALID_ARG, "now_ns < 0");
     TC_HIP(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, e->stream, e->table, slot, op, a, b, ttl, now, e->op_result);
+    hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, cur_stream(e), e->table, slot, op, a, b, ttl, now, e->op_result);
     TC_HIP(e, hipGetLastError());
-    TC_HIP(e, hipMemcpyAsync(r, e->op_result, sizeof *r, hipMemcpyDeviceToHost, e->stream));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipMemcpyAsync(r, e->op_result, sizeof *r, hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     return TC_E_OK;
 }
 
@@ -1354,8 +1435,8 @@ extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* 
     if (n == 0) return TC_E_OK;
     TC_HIP(e, hipSetDevice(e->device));
     std::vector<Slot> h(n);
-    TC_HIP(e, hipMemcpyAsync(h.data(), e->table + first, n * sizeof(Slot), hipMemcpyDeviceToHost, e->stream));
-    TC_HIP(e, hipStreamSynchronize(e->stream));
+    TC_HIP(e, hipMemcpyAsync(h.data(), e->table + first, n * sizeof(Slot), hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     for (uint64_t i = 0; i < n; ++i) {
         if (tat) tat[i] = h[i].cell.tat;
         if (expiry) expiry[i] = h[i].cell.expiry;

@@ -122,7 +122,7 @@ class Engine:
         setattr(batch, name, arr.ctypes.data)
 
     def _prepare(self, n, dev, max_burst, count_per_period, period, quantity, now_ns, registered, unique,
-                 want, out: Optional[BatchResult]):
+                 want, out: Optional[BatchResult], inputs_ready=False):
         keep = []
         b = L.tc_batch()
         b.struct_size = C.sizeof(L.tc_batch)
@@ -134,6 +134,10 @@ class Engine:
             flags |= L.TC_B_REGISTERED_PARAMS
         if unique:
             flags |= L.TC_B_UNIQUE_SLOTS
+        if inputs_ready:
+            if not dev:
+                raise ValueError("inputs_ready applies to device-pointer batches")
+            flags |= L.TC_B_INPUTS_READY
         b.flags = flags
         b.quantity_scalar = 1
         if not registered:
@@ -164,8 +168,11 @@ class Engine:
 
     def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
                                now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
-                               out: Optional[BatchResult] = None) -> BatchResult:
-        """rate_limit_batch over pre-resolved slots (sequential semantics, index order)."""
+                               out: Optional[BatchResult] = None, inputs_ready=False) -> BatchResult:
+        """rate_limit_batch over pre-resolved slots (sequential semantics, index order).
+        inputs_ready=True (TC_B_INPUTS_READY): the CUDA `slots` tensor is already complete and
+        stays untouched until the results are ready, so the engine may group this batch on its
+        auxiliary stream while earlier batches are still being evaluated."""
         dev = _is_torch(slots)
         keep = []
         if dev:
@@ -179,7 +186,7 @@ class Engine:
             n = sl.size
             sp = sl.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
-                                   unique, want, out)
+                                   unique, want, out, inputs_ready)
         b.slot = sp
         if n:
             self._check(self._lib.tc_rate_limit_batch_slots(self._h, C.byref(b)))

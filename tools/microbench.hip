@@ -33,6 +33,44 @@ __global__ __launch_bounds__(256) void k_pat(const uint64_t* __restrict__ sorted
     if (MODE & 8) out[k] = (uint8_t)(v & 1);
 }
 
+// 16-byte records (cell only; 160 MB for 10 M keys -> fits the 256 MiB Infinity Cache)
+struct __attribute__((aligned(16))) Rec16 { long long a, b; };
+template <int MODE>
+__global__ __launch_bounds__(256) void k_pat16(const uint64_t* __restrict__ sorted, uint32_t n, Rec16* __restrict__ table,
+                                               uint8_t* __restrict__ out) {
+    const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t e = sorted[k];
+    const uint32_t slot = (uint32_t)(e >> 32), idx = (uint32_t)e;
+    long long v = slot;
+    if (MODE & 1) {
+        const Rec16 r = table[slot];
+        v = r.a + r.b;
+    }
+    if (MODE & 2) {
+        Rec16 w;
+        w.a = v + 1;
+        w.b = v + 2;
+        table[slot] = w;
+    }
+    if (MODE & 4) out[idx] = (uint8_t)(v & 1);
+    if (MODE & 8) out[k] = (uint8_t)(v & 1);
+}
+template <int MODE>
+float run16(const uint64_t* d_sorted, uint32_t n, Rec16* table, uint8_t* out, int iters) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_pat16<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
+    CK(hipEventRecord(a));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_pat16<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    return 1e3f * ms / iters;
+}
+
 template <int MODE>
 float run(const uint64_t* d_sorted, uint32_t n, Rec* table, uint8_t* out, int iters) {
     hipEvent_t a, b;
@@ -74,5 +112,13 @@ int main() {
     ROW(1 | 4, "gather 32B + scattered byte store");
     ROW(1 | 2 | 8, "gather 32B + store 16B + coalesced byte store");
     ROW(1 | 2 | 4, "gather 32B + store 16B + scattered byte store");
+    Rec16* t16;
+    CK(hipMalloc(&t16, (size_t)cap * sizeof(Rec16)));
+    CK(hipMemset(t16, 0, (size_t)cap * sizeof(Rec16)));
+    printf("-- 16-byte records (160 MB table)\n");
+#define ROW16(M, name) printf("%-58s %9.1f  %9.1f\n", name, run16<M>(d_sorted, n, t16, out, 20), run16<M>(d_unsorted, n, t16, out, 20));
+    ROW16(1 | 8, "gather 16B + coalesced byte store");
+    ROW16(1 | 2 | 8, "gather 16B + store 16B + coalesced byte store");
+    ROW16(1 | 2 | 4, "gather 16B + store 16B + scattered byte store");
     return 0;
 }

@@ -15,6 +15,7 @@ from throttlecrab_amd import workload as W  # noqa: E402
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
+piped = (sys.argv[3] != '0') if len(sys.argv) > 3 else True
 keys = 10_000_000
 
 for kind in ("uniform", "zipf"):
@@ -27,18 +28,19 @@ for kind in ("uniform", "zipf"):
         eng.register_params_uniform(*W.REF_PARAMS)
         out = t.BatchResult()
         for i in range(3):
-            eng.rate_limit_batch_slots(db[i], registered=True, quantity=1, now_ns=W.T0_NS + i * 10**6, want=want, out=out)
+            eng.rate_limit_batch_slots(db[i], registered=True, quantity=1, now_ns=W.T0_NS + i * 10**6, want=want, out=out, inputs_ready=piped)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (3 + i) * 10**6, want=want, out=out)
+            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (3 + i) * 10**6, want=want, out=out, inputs_ready=piped)
+        t_issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         eng.profile_enable(True)
         for i in range(steps):
-            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (30 + i) * 10**6, want=want, out=out)
+            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (30 + i) * 10**6, want=want, out=out, inputs_ready=piped)
         prof = eng.profile_read()
         st = {k: round(1e3 * v[0] / max(1, v[1]), 1) for k, v in prof.items() if v[1]}
-        print(f"{kind:8s} {'full' if len(want) > 1 else 'bits':5s} {steps * batch / dt / 1e9:7.2f} G/s  "
-              f"{1e6 * dt / steps:7.1f} us/batch  stages(us)={st}", flush=True)
+        print(f"piped={int(piped)} {kind:8s} {'full' if len(want) > 1 else 'bits':5s} {steps * batch / dt / 1e9:7.2f} G/s  "
+              f"{1e6 * dt / steps:7.1f} us/batch  host-issue {1e6 * t_issue / steps:6.1f} us/batch  stages(us)={st}", flush=True)
         eng.close()
