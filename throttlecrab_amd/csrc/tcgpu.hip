@@ -1,8 +1,9 @@
 // tcgpu.hip -- MI355X (gfx950) batched GCRA engine: HIP kernels + the C ABI of
 // include/tcgpu.h.  One engine = one GPU-resident key store:
 //
-//   table[capacity]   Slot {tat i64, expiry u64, ei i64, dvt i64}  32 B / key
-//   bursts[capacity]  i64   burst capacity (= `limit` of the result)  8 B / key
+//   cells[capacity]    Cell {tat i64, expiry u64}                    16 B / key  (the state)
+//   rate_id[capacity]  u16  registered rate plan of the key, 0 = none    2 B / key
+//   classes[65536]     RateClass {ei, dvt, burst}   dictionary of the registered plans
 //
 // A batch is applied with the reference's sequential semantics
 // (throttlecrab/src/core/rate_limiter.rs:102-250 applied in index order):
@@ -19,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tcgpu.h"
@@ -29,7 +31,7 @@
 using tc::Cell;
 using tc::Decision;
 using tc::Rate;
-using tc::Slot;
+using tc::RateClass;
 
 namespace {
 
@@ -38,8 +40,9 @@ constexpr int SORT_ITEMS = 8;  // items per thread of a sort tile (tile = 2048 r
 constexpr int PIPE_DEPTH_MAX = 8;
 constexpr int AUX_MAX = 4, AUX_DEFAULT = 2; // auxiliary (grouping) streams: main + aux must fit the 4 HW queues HIP uses
 constexpr int PIPE_DEPTH_DEFAULT = 3; // grouping scratch sets: batches whose sort may be in flight at once
-constexpr uint32_t F_REGISTERED = 1u; // Params.flags: per-slot registered rate
-constexpr uint32_t F_NEED_BURST = 2u; // read bursts[] (limit wanted, or not every slot registered)
+constexpr uint32_t F_REGISTERED = 1u;    // Params.flags: per-slot registered rate plan
+constexpr uint32_t F_UNIFORM_CLASS = 2u; // every slot carries plan `uniform_class`: skip the rate_id[] read
+constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
 
 // ---------------------------------------------------------------------------
 // kernel argument block
@@ -60,8 +63,10 @@ struct Params {
     int64_t* reset;
     int64_t* retry;
     uint8_t* status;
-    Slot* table;
-    const int64_t* bursts;
+    Cell* cells;
+    const uint16_t* rate_id;
+    const RateClass* classes;
+    uint32_t uniform_class;
     uint64_t capacity;
     unsigned long long* counters;
 };
@@ -71,8 +76,8 @@ struct Req {
     int status;
 };
 
-// Request i against `slot`, whose record `rec` is already in registers.
-__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot, const Rate& rate) {
+// Request i against `slot`: arguments, derived rate and status (rate_limiter.rs:111-123).
+__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot) {
     Req r;
     r.q = p.q ? p.q[i] : p.q_s;
     r.now = p.now ? p.now[i] : p.now_s;
@@ -82,9 +87,11 @@ __device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t sl
         return r;
     }
     if (p.flags & F_REGISTERED) {
-        r.ei = rate.ei;
-        r.dvt = rate.dvt;
-        r.limit = (p.flags & F_NEED_BURST) ? p.bursts[slot] : 1;
+        const uint32_t id = (p.flags & F_UNIFORM_CLASS) ? p.uniform_class : (uint32_t)p.rate_id[slot];
+        const RateClass rc = p.classes[id]; // class 0 is all zero: burst 0 = never registered
+        r.ei = rc.ei;
+        r.dvt = rc.dvt;
+        r.limit = rc.burst;
         if (r.q < 0) r.status = tc::ST_NEGATIVE_QUANTITY;            // rate_limiter.rs:111
         else if (r.limit <= 0) r.status = tc::ST_INVALID_RATE_LIMIT; // slot never registered
         else r.status = tc::check_request(r.q, r.now, r.dvt);
@@ -149,19 +156,18 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
     uint32_t na = 0, nd = 0, ne = 0;
     if (i < p.n) {
         const uint32_t slot = p.slot[i];
-        Slot rec;
-        rec.cell.tat = 0;
-        rec.cell.expiry = 0;
-        rec.rate.ei = rec.rate.dvt = 0;
-        if (slot < p.capacity) rec = p.table[slot];
-        const Req r = make_req(p, i, slot, rec.rate);
+        Cell cell;
+        cell.tat = 0;
+        cell.expiry = 0;
+        if (slot < p.capacity) cell = p.cells[slot];
+        const Req r = make_req(p, i, slot);
         Decision d;
         d.allowed = false;
         d.remaining = d.reset_after = d.retry_after = 0;
         if (r.status == tc::ST_OK) {
-            Cell c = rec.cell;
+            Cell c = cell;
             d = tc::gcra_step<FULL>(c, r.ei, r.dvt, r.q, r.now);
-            if (d.allowed) p.table[slot].cell = c;
+            if (d.allowed) p.cells[slot] = c;
             na = d.allowed;
             nd = !d.allowed;
         } else {
@@ -222,17 +228,14 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
 
     if (!UNIFORM) {
         if (head) {
-            Slot rec;
-            rec.cell.tat = 0;
-            rec.cell.expiry = 0;
-            rec.rate.ei = rec.rate.dvt = 0;
-            const bool in_range = slot < p.capacity;
-            if (in_range) rec = p.table[slot];
-            Cell c = rec.cell;
+            Cell c;
+            c.tat = 0;
+            c.expiry = 0;
+            if (slot < p.capacity) c = p.cells[slot];
             bool dirty = false;
             uint32_t i = idx;
             for (uint32_t j = k;;) {
-                const Req r = make_req(p, i, slot, rec.rate);
+                const Req r = make_req(p, i, slot);
                 Decision d;
                 d.allowed = false;
                 d.remaining = d.reset_after = d.retry_after = 0;
@@ -250,7 +253,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                 if ((uint32_t)(nx >> 32) != slot) break;
                 i = (uint32_t)nx;
             }
-            if (dirty) p.table[slot].cell = c;
+            if (dirty) p.cells[slot] = c;
         }
         block_count3(na, nd, ne, p.counters);
         return;
@@ -284,12 +287,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     wcell.expiry = 0;
     if (valid) {
         const uint32_t r = k - seg_start;
-        Slot rec;
-        rec.cell.tat = 0;
-        rec.cell.expiry = 0;
-        rec.rate.ei = rec.rate.dvt = 0;
-        if (slot < p.capacity) rec = p.table[slot];
-        const Req rq = make_req(p, idx, slot, rec.rate);
+        Cell cell;
+        cell.tat = 0;
+        cell.expiry = 0;
+        if (slot < p.capacity) cell = p.cells[slot];
+        const Req rq = make_req(p, idx, slot);
         Decision d;
         d.allowed = false;
         d.remaining = d.reset_after = d.retry_after = 0;
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
             ne = 1;
             write_out(p, idx, rq, d);
         } else {
-            Cell c = rec.cell;
+            Cell c = cell;
             const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
             if (!d0.allowed) {
                 // request 0 denied => state untouched => every request of the run equals request 0
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     }
     if (writer) {
         if (seg_in_wave) {
-            p.table[slot].cell = wcell;
+            p.cells[slot] = wcell;
         } else {
             const uint32_t at = atomicAdd(pend_count, 1u);
             PendEntry pe;
@@ -359,12 +361,12 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
 }
 
 __global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restrict__ pend,
-                                                       uint32_t* __restrict__ pend_count, Slot* __restrict__ table) {
+                                                       uint32_t* __restrict__ pend_count, Cell* __restrict__ cells) {
     // pend_count[0] = entries, pend_count[1] = blocks of this launch that are done
     const uint32_t cnt = pend_count[0];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < cnt; i += gridDim.x * BLOCK) {
         const PendEntry pe = pend[i];
-        table[pe.slot].cell = pe.cell;
+        cells[pe.slot] = pe.cell;
     }
     __syncthreads(); // every lane of this block has consumed `cnt`
     if (threadIdx.x == 0) {
@@ -408,16 +410,16 @@ __global__ __launch_bounds__(BLOCK) void k_pack_bits(const uint8_t* __restrict__
 // ---------------------------------------------------------------------------
 // K4: expiry sweep == AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_sweep(Slot* __restrict__ table, uint64_t capacity, int64_t now,
+__global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint64_t capacity, int64_t now,
                                                  unsigned long long* counters, unsigned long long* removed_out) {
     uint32_t removed = 0, live = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        Cell c = table[i].cell;
+        Cell c = cells[i];
         if (c.expiry != 0) {
             if (!(c.expiry > (uint64_t)now)) { // retain(|exp| *exp > now)
                 c.tat = 0;
                 c.expiry = 0;
-                table[i].cell = c;
+                cells[i] = c;
                 removed++;
             } else {
                 live++;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Slot* __restrict__ table, uint6
 // Key-mode sweep: same retain rule, and an expired (or never written) bound slot
 // also loses its key: tombstone in the hash table, slot back on the free stack
 // (one stack push per block, not per slot).
-__global__ __launch_bounds__(BLOCK) void k_sweep_keys(Slot* __restrict__ table, kt::Table t, int64_t now,
+__global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
                                                       unsigned long long* counters, unsigned long long* removed_out) {
     __shared__ int s_base;
     uint32_t removed = 0, live = 0;
@@ -460,12 +462,12 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Slot* __restrict__ table, 
         const uint64_t i = rd * gridDim.x * BLOCK + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
         bool unbind = false;
         if (i < t.capacity && t.key_len[i] != kt::NO_SLOT) {
-            Cell c = table[i].cell;
+            Cell c = cells[i];
             if (!(c.expiry > (uint64_t)now)) {
                 if (c.expiry != 0) removed++; // the reference's map only ever held written entries
                 c.tat = 0;
                 c.expiry = 0;
-                table[i].cell = c;
+                cells[i] = c;
                 unbind = true;
             } else {
                 live++;
@@ -508,23 +510,15 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Slot* __restrict__ table, 
     }
 }
 
-__global__ __launch_bounds__(BLOCK) void k_fill_rates(Slot* __restrict__ table, int64_t* __restrict__ bursts,
-                                                      uint64_t capacity, Rate r, int64_t burst) {
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        table[i].rate = r;
-        bursts[i] = burst;
-    }
+__global__ __launch_bounds__(BLOCK) void k_fill_rate_id(uint16_t* __restrict__ rate_id, uint64_t capacity, uint16_t id) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK)
+        rate_id[i] = id;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_scatter_rates(Slot* __restrict__ table, int64_t* __restrict__ bursts,
-                                                         const uint32_t* __restrict__ slots, const Rate* __restrict__ src_r,
-                                                         const int64_t* __restrict__ src_b, uint64_t n) {
+__global__ __launch_bounds__(BLOCK) void k_scatter_rate_id(uint16_t* __restrict__ rate_id, const uint32_t* __restrict__ slots,
+                                                           const uint16_t* __restrict__ src, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        const uint64_t s = slots ? slots[i] : i;
-        table[s].rate = src_r[i];
-        bursts[s] = src_b[i];
-    }
+    if (i < n) rate_id[slots ? slots[i] : i] = src[i];
 }
 
 // `trait Store` shims on one resolved slot (store/mod.rs:85-133,
@@ -534,10 +528,10 @@ struct StoreOpResult {
     int32_t flag;
     int32_t pad;
 };
-__global__ void k_store_op(Slot* table, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
+__global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
                            StoreOpResult* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    Cell c = table[slot].cell;
+    Cell c = cells[slot];
     const bool live = c.expiry > (uint64_t)now;
     StoreOpResult r;
     r.value = 0;
@@ -554,14 +548,14 @@ __global__ void k_store_op(Slot* table, uint64_t slot, int op, int64_t a, int64_
         if (live && c.tat == a) {
             c.tat = b;
             c.expiry = e;
-            table[slot].cell = c;
+            cells[slot] = c;
             r.flag = 1;
         }
     } else {
         if (!live) {
             c.tat = a;
             c.expiry = e;
-            table[slot].cell = c;
+            cells[slot] = c;
             r.flag = 1;
         }
     }
@@ -594,9 +588,12 @@ struct tc_engine {
     uint64_t capacity = 0, max_batch = 0;
     uint32_t cfg_flags = 0;
 
-    Slot* table = nullptr;
-    int64_t* bursts = nullptr;
-    bool all_registered = false;
+    Cell* cells = nullptr;
+    uint16_t* rate_id = nullptr;
+    RateClass* classes = nullptr;            // device, MAX_CLASSES entries, [0] = all zero
+    std::vector<RateClass> host_classes;     // host mirror, index = class id
+    std::unordered_map<std::string, uint16_t> class_of; // (burst,count,period) bytes -> id
+    uint16_t uniform_id = 0;                 // != 0: every slot carries this plan
     unsigned long long* counters = nullptr; // TC_CNT_COUNT canonical + 1 scratch + NSHARD*SHARD_WORDS shards
 
     // grouping scratch: a ring of `depth` sets.  A batch flagged TC_B_INPUTS_READY is
@@ -704,12 +701,15 @@ static size_t sort_ws_words(uint32_t max_tiles) { return rs::workspace_words(max
 static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipSetDevice(e->device));
     const uint64_t cap = e->capacity, mb = e->max_batch;
-    TC_HIP(e, hipMalloc(&e->table, cap * sizeof(Slot)));
-    TC_HIP(e, hipMalloc(&e->bursts, cap * sizeof(int64_t)));
+    TC_HIP(e, hipMalloc(&e->cells, cap * sizeof(Cell)));
+    TC_HIP(e, hipMalloc(&e->rate_id, cap * sizeof(uint16_t)));
+    TC_HIP(e, hipMalloc(&e->classes, (size_t)MAX_CLASSES * sizeof(RateClass)));
+    e->host_classes.assign(1, RateClass{0, 0, 0, 0});
     const size_t cnt_words = (TC_CNT_COUNT + 1) + (size_t)NSHARD * SHARD_WORDS;
     TC_HIP(e, hipMalloc(&e->counters, cnt_words * sizeof(unsigned long long)));
-    TC_HIP(e, hipMemsetAsync(e->table, 0, cap * sizeof(Slot), (hipStream_t)0));
-    TC_HIP(e, hipMemsetAsync(e->bursts, 0, cap * sizeof(int64_t), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->cells, 0, cap * sizeof(Cell), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->rate_id, 0, cap * sizeof(uint16_t), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->classes, 0, (size_t)MAX_CLASSES * sizeof(RateClass), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), (hipStream_t)0));
     e->sort_max_tiles = (uint32_t)((mb + rs::THREADS * SORT_ITEMS - 1) / (rs::THREADS * SORT_ITEMS));
     const size_t words = sort_ws_words(e->sort_max_tiles);
@@ -910,7 +910,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->table, e->bursts, e->counters, e->pend, e->pend_count,
+    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->counters, e->pend, e->pend_count,
                     e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status};
@@ -939,17 +939,46 @@ extern "C" int tc_synchronize(tc_engine* e) {
     return TC_E_OK;
 }
 
+// (burst, count, period) -> class id, creating (and uploading) the class if new.
+// 0 = invalid triple; -1 = dictionary full.
+static int intern_class(tc_engine* e, int64_t burst, int64_t count, int64_t period, bool* grew) {
+    RateClass rc{0, 0, 0, 0};
+    if (tc::derive_rate(burst, count, period, rc.ei, rc.dvt) != tc::ST_OK) return 0;
+    rc.burst = burst;
+    const int64_t key[3] = {burst, count, period};
+    const std::string k((const char*)key, sizeof key);
+    auto it = e->class_of.find(k);
+    if (it != e->class_of.end()) return it->second;
+    if (e->host_classes.size() >= MAX_CLASSES) return -1;
+    const uint16_t id = (uint16_t)e->host_classes.size();
+    e->host_classes.push_back(rc);
+    e->class_of.emplace(k, id);
+    *grew = true;
+    return id;
+}
+
+static int upload_classes(tc_engine* e) {
+    TC_HIP(e, hipMemcpyAsync(e->classes, e->host_classes.data(), e->host_classes.size() * sizeof(RateClass),
+                             hipMemcpyHostToDevice, cur_stream(e)));
+    return TC_E_OK;
+}
+
 extern "C" int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64_t count_per_period, int64_t period) {
     if (!e) return TC_E_INVALID_ARG;
-    Rate r;
-    if (tc::derive_rate(max_burst, count_per_period, period, r.ei, r.dvt) != tc::ST_OK)
-        return fail(e, TC_E_INVALID_ARG, "tc_register_params_uniform: invalid (burst,count,period)");
+    bool grew = false;
+    const int id = intern_class(e, max_burst, count_per_period, period, &grew);
+    if (id == 0) return fail(e, TC_E_INVALID_ARG, "tc_register_params_uniform: invalid (burst,count,period)");
+    if (id < 0) return fail(e, TC_E_UNSUPPORTED, "more than 65535 distinct rate plans registered");
     TC_HIP(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_fill_rates, dim3(std::min<uint64_t>(nblocks(e->capacity), 4096)), dim3(BLOCK), 0, cur_stream(e),
-                       e->table, e->bursts, e->capacity, r, max_burst);
+    if (grew) {
+        int rc = upload_classes(e);
+        if (rc != TC_E_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_fill_rate_id, dim3(std::min<uint64_t>(nblocks(e->capacity), 4096)), dim3(BLOCK), 0, cur_stream(e),
+                       e->rate_id, e->capacity, (uint16_t)id);
     TC_HIP(e, hipGetLastError());
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
-    e->all_registered = true;
+    e->uniform_id = (uint16_t)id;
     return TC_E_OK;
 }
 
@@ -958,29 +987,42 @@ extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slot
     if (!e || !max_burst || !count_per_period || !period) return TC_E_INVALID_ARG;
     if (n == 0) return TC_E_OK;
     if (!slots && n > e->capacity) return fail(e, TC_E_INVALID_ARG, "tc_register_params: n > capacity");
-    std::vector<Rate> hr(n);
+    // validate everything before touching the dictionary or the device
     for (uint64_t i = 0; i < n; ++i) {
         if (slots && slots[i] >= e->capacity) return fail(e, TC_E_INVALID_ARG, "tc_register_params: slot out of range");
-        if (tc::derive_rate(max_burst[i], count_per_period[i], period[i], hr[i].ei, hr[i].dvt) != tc::ST_OK)
+        int64_t ei, dvt;
+        if (tc::derive_rate(max_burst[i], count_per_period[i], period[i], ei, dvt) != tc::ST_OK)
             return fail(e, TC_E_INVALID_ARG, "tc_register_params: invalid (burst,count,period)");
     }
+    std::vector<uint16_t> ids(n);
+    bool grew = false;
+    int last_id = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i && max_burst[i] == max_burst[i - 1] && count_per_period[i] == count_per_period[i - 1] && period[i] == period[i - 1]) {
+            ids[i] = (uint16_t)last_id; // runs of one plan are the common case
+            continue;
+        }
+        last_id = intern_class(e, max_burst[i], count_per_period[i], period[i], &grew);
+        if (last_id < 0) return fail(e, TC_E_UNSUPPORTED, "more than 65535 distinct rate plans registered");
+        ids[i] = (uint16_t)last_id;
+    }
     TC_HIP(e, hipSetDevice(e->device));
-    Rate* d_r = nullptr;
-    int64_t* d_b = nullptr;
+    if (grew) {
+        int rc = upload_classes(e);
+        if (rc != TC_E_OK) return rc;
+    }
+    uint16_t* d_id = nullptr;
     uint32_t* d_s = nullptr;
-    TC_HIP(e, hipMalloc(&d_r, n * sizeof(Rate)));
-    TC_HIP(e, hipMalloc(&d_b, n * sizeof(int64_t)));
+    TC_HIP(e, hipMalloc(&d_id, n * sizeof(uint16_t)));
     if (slots) TC_HIP(e, hipMalloc(&d_s, n * sizeof(uint32_t)));
-    TC_HIP(e, hipMemcpyAsync(d_r, hr.data(), n * sizeof(Rate), hipMemcpyHostToDevice, cur_stream(e)));
-    TC_HIP(e, hipMemcpyAsync(d_b, max_burst, n * sizeof(int64_t), hipMemcpyHostToDevice, cur_stream(e)));
+    TC_HIP(e, hipMemcpyAsync(d_id, ids.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice, cur_stream(e)));
     if (slots) TC_HIP(e, hipMemcpyAsync(d_s, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
-    hipLaunchKernelGGL(k_scatter_rates, dim3(nblocks(n)), dim3(BLOCK), 0, cur_stream(e), e->table, e->bursts, d_s, d_r, d_b, n);
+    hipLaunchKernelGGL(k_scatter_rate_id, dim3(nblocks(n)), dim3(BLOCK), 0, cur_stream(e), e->rate_id, d_s, d_id, n);
     TC_HIP(e, hipGetLastError());
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
-    (void)hipFree(d_r);
-    (void)hipFree(d_b);
+    (void)hipFree(d_id);
     if (d_s) (void)hipFree(d_s);
-    if (!slots && n == e->capacity) e->all_registered = true;
+    e->uniform_id = 0; // per-slot plans from now on: evaluation reads rate_id[]
     return TC_E_OK;
 }
 
@@ -1052,13 +1094,15 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     p.reset = b.reset_after_ns;
     p.retry = b.retry_after_ns;
     p.status = b.status;
-    p.table = e->table;
-    p.bursts = e->bursts;
+    p.cells = e->cells;
+    p.rate_id = e->rate_id;
+    p.classes = e->classes;
+    p.uniform_class = e->uniform_id;
     p.capacity = e->capacity;
     p.counters = e->counters;
     if (b.flags & TC_B_REGISTERED_PARAMS) {
         p.flags |= F_REGISTERED;
-        if (p.limit || !e->all_registered) p.flags |= F_NEED_BURST;
+        if (e->uniform_id) p.flags |= F_UNIFORM_CLASS;
     }
     const bool full = p.remaining || p.reset || p.retry;
     const dim3 grid(nblocks(n)), block(BLOCK);
@@ -1096,7 +1140,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
             else hipLaunchKernelGGL((k_eval_sorted<false, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
             prof_end(e, s);
             prof_begin(e, TC_STAGE_COMMIT, s);
-            hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->table);
+            hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells);
             prof_end(e, s);
         } else {
             if (full) hipLaunchKernelGGL((k_eval_sorted<true, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
@@ -1277,10 +1321,10 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), cur_stream(e)));
     if (e->key_mode)
         hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
-                           e->table, e->kt, now_ns, e->counters, scratch);
+                           e->cells, e->kt, now_ns, e->counters, scratch);
     else
         hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
-                           e->table, e->capacity, now_ns, e->counters, scratch);
+                           e->cells, e->capacity, now_ns, e->counters, scratch);
     TC_HIP(e, hipGetLastError());
     unsigned long long r = 0;
     uint32_t tombs = 0;
@@ -1375,7 +1419,7 @@ static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, u
                     StoreOpResult* r) {
     if (now < 0) return fail(e, TC_E_INVALID_ARG, "now_ns < 0");
     TC_HIP(e, hipSetDevice(e->device));
-    hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, cur_stream(e), e->table, slot, op, a, b, ttl, now, e->op_result);
+    hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, cur_stream(e), e->cells, slot, op, a, b, ttl, now, e->op_result);
     TC_HIP(e, hipGetLastError());
     TC_HIP(e, hipMemcpyAsync(r, e->op_result, sizeof *r, hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
@@ -1434,12 +1478,12 @@ extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* 
     if (!e || first + n > e->capacity) return TC_E_INVALID_ARG;
     if (n == 0) return TC_E_OK;
     TC_HIP(e, hipSetDevice(e->device));
-    std::vector<Slot> h(n);
-    TC_HIP(e, hipMemcpyAsync(h.data(), e->table + first, n * sizeof(Slot), hipMemcpyDeviceToHost, cur_stream(e)));
+    std::vector<Cell> h(n);
+    TC_HIP(e, hipMemcpyAsync(h.data(), e->cells + first, n * sizeof(Cell), hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     for (uint64_t i = 0; i < n; ++i) {
-        if (tat) tat[i] = h[i].cell.tat;
-        if (expiry) expiry[i] = h[i].cell.expiry;
+        if (tat) tat[i] = h[i].tat;
+        if (expiry) expiry[i] = h[i].expiry;
     }
     return TC_E_OK;
 }

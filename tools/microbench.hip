@@ -10,6 +10,7 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 struct __attribute__((aligned(32))) Rec { long long a, b, c, d; };
+constexpr int NB = 16; // distinct batches rotated through (fresh random slots per launch, like the real stream)
 
 // mode bits: 1 = gather 32B record, 2 = store 16B back, 4 = scattered byte store by idx, 8 = coalesced byte store
 template <int MODE>
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256) void k_pat16(const uint64_t* __restrict__ sort
     if (MODE & 4) out[idx] = (uint8_t)(v & 1);
     if (MODE & 8) out[k] = (uint8_t)(v & 1);
 }
+ // distinct batches rotated through (d_sorted holds NB batches back to back)
 template <int MODE>
 float run16(const uint64_t* d_sorted, uint32_t n, Rec16* table, uint8_t* out, int iters) {
     hipEvent_t a, b;
@@ -63,7 +65,7 @@ float run16(const uint64_t* d_sorted, uint32_t n, Rec16* table, uint8_t* out, in
     CK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_pat16<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
     CK(hipEventRecord(a));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_pat16<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_pat16<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted + (size_t)(i % NB) * n, n, table, out);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms;
@@ -78,7 +80,7 @@ float run(const uint64_t* d_sorted, uint32_t n, Rec* table, uint8_t* out, int it
     CK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_pat<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
     CK(hipEventRecord(a));
-    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_pat<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted, n, table, out);
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_pat<MODE>, dim3((n + 255) / 256), dim3(256), 0, 0, d_sorted + (size_t)(i % NB) * n, n, table, out);
     CK(hipEventRecord(b));
     CK(hipEventSynchronize(b));
     float ms;
@@ -89,22 +91,23 @@ float run(const uint64_t* d_sorted, uint32_t n, Rec* table, uint8_t* out, int it
 int main() {
     const uint32_t n = 1 << 20, cap = 10000000;
     std::mt19937_64 rng(1);
-    std::vector<uint64_t> h(n);
-    for (uint32_t i = 0; i < n; ++i) h[i] = ((uint64_t)(rng() % cap) << 32) | i;
+    std::vector<uint64_t> h((size_t)n * NB);
+    for (int b = 0; b < NB; ++b)
+        for (uint32_t i = 0; i < n; ++i) h[(size_t)b * n + i] = ((uint64_t)(rng() % cap) << 32) | i;
     std::vector<uint64_t> hs = h;
-    std::sort(hs.begin(), hs.end());
+    for (int b = 0; b < NB; ++b) std::sort(hs.begin() + (size_t)b * n, hs.begin() + (size_t)(b + 1) * n);
     uint64_t *d_sorted, *d_unsorted;
     Rec* table;
     uint8_t* out;
-    CK(hipMalloc(&d_sorted, n * 8));
-    CK(hipMalloc(&d_unsorted, n * 8));
+    CK(hipMalloc(&d_sorted, (size_t)n * NB * 8));
+    CK(hipMalloc(&d_unsorted, (size_t)n * NB * 8));
     CK(hipMalloc(&table, (size_t)cap * sizeof(Rec)));
     CK(hipMalloc(&out, n));
     CK(hipMemset(table, 0, (size_t)cap * sizeof(Rec)));
-    CK(hipMemcpy(d_sorted, hs.data(), n * 8, hipMemcpyHostToDevice));
-    CK(hipMemcpy(d_unsorted, h.data(), n * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_sorted, hs.data(), (size_t)n * NB * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(d_unsorted, h.data(), (size_t)n * NB * 8, hipMemcpyHostToDevice));
     printf("pattern (1Mi requests over 10M x 32B records)             sorted_us  unsorted_us\n");
-#define ROW(M, name) printf("%-58s %9.1f  %9.1f\n", name, run<M>(d_sorted, n, table, out, 20), run<M>(d_unsorted, n, table, out, 20));
+#define ROW(M, name) printf("%-58s %9.1f  %9.1f\n", name, run<M>(d_sorted, n, table, out, 32), run<M>(d_unsorted, n, table, out, 32));
     ROW(0, "read elems only");
     ROW(8, "read elems + coalesced byte store");
     ROW(4, "read elems + byte store scattered by idx");
@@ -116,7 +119,7 @@ int main() {
     CK(hipMalloc(&t16, (size_t)cap * sizeof(Rec16)));
     CK(hipMemset(t16, 0, (size_t)cap * sizeof(Rec16)));
     printf("-- 16-byte records (160 MB table)\n");
-#define ROW16(M, name) printf("%-58s %9.1f  %9.1f\n", name, run16<M>(d_sorted, n, t16, out, 20), run16<M>(d_unsorted, n, t16, out, 20));
+#define ROW16(M, name) printf("%-58s %9.1f  %9.1f\n", name, run16<M>(d_sorted, n, t16, out, 32), run16<M>(d_unsorted, n, t16, out, 32));
     ROW16(1 | 8, "gather 16B + coalesced byte store");
     ROW16(1 | 2 | 8, "gather 16B + store 16B + coalesced byte store");
     ROW16(1 | 2 | 4, "gather 16B + store 16B + scattered byte store");
