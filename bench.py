@@ -288,6 +288,11 @@ def main():
             dt3, _ = run_gpu(eng2, ob, full, W.T0_NS + 10**9, a.steps, 2, None, None, None,
                              want=t.Engine.ALL_FIELDS)
             also[f"{other}_stream_full_result"] = {"value": a.steps * a.batch / dt3, "unit": "decisions/s"}
+            rec = t.BatchResult()
+            dt4, _ = run_gpu(eng2, ob, rec, W.T0_NS + 3 * 10**9, a.steps, 2, None, None, None,
+                             want=t.Engine.RECORD_FIELDS)
+            also[f"{other}_stream_full_result_records"] = {"value": a.steps * a.batch / dt4, "unit": "decisions/s",
+                                                          "note": "result4: one 32-byte RateLimitResult record per request"}
             # PCIe-inclusive rate: the same stream handed over as HOST buffers (never `value`)
             hb = make_batches(other, a.keys, a.batch, 8)
             hout = t.BatchResult()

@@ -117,6 +117,10 @@ typedef struct tc_batch {
     int64_t* reset_after_ns; /* [n] Duration as ns */
     int64_t* retry_after_ns; /* [n] Duration as ns */
     uint8_t* status;         /* [n] TC_OK / TC_NEGATIVE_QUANTITY / ... */
+    /* RateLimitResult as ONE 32-byte record per request, {limit, remaining, reset_after_ns,
+     * retry_after_ns}: a request's result then costs one scattered store instead of four
+     * (use it instead of the four columns above when all fields are wanted). 16-byte aligned. */
+    int64_t* result4;        /* [n][4] */
 } tc_batch;
 
 /* Single-request result (the tuple rate_limit returns). */

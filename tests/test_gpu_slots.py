@@ -37,6 +37,17 @@ def assert_same(res, ref, ctx=""):
         assert bad.size == 0, f"{ctx}: field {f} differs at {bad[:8]} got {got[bad[:8]]} want {exp[bad[:8]]}"
 
 
+def assert_record_same(res, ref, ctx=""):
+    """result4[i] = (limit, remaining, reset_after_ns, retry_after_ns) of request i."""
+    r4 = res.result4
+    if not isinstance(r4, np.ndarray):
+        r4 = r4.cpu().numpy()
+    r4 = r4.reshape(-1, 4)
+    for col, f in enumerate(("limit", "remaining", "reset_after_ns", "retry_after_ns")):
+        bad = np.nonzero(r4[:, col] != getattr(ref, f).astype(np.int64))[0]
+        assert bad.size == 0, f"{ctx}: result4.{f} differs at {bad[:8]}"
+
+
 def assert_state_same(eng, orc, slots):
     tat, exp = eng.read_state(0, eng.capacity)
     for s in np.unique(slots):
@@ -157,9 +168,10 @@ def test_general_device_pointers_match_host_pointers():
     tt = lambda a: torch.from_numpy(a.astype(np.int64)).to(dev)
     res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).to(dev), max_burst=tt(b),
                                      count_per_period=tt(c), period=tt(p), quantity=tt(q), now_ns=tt(now),
-                                     want=FIELDS + ("allowed_bits",))
+                                     want=FIELDS + ("allowed_bits", "result4"))
     torch.cuda.synchronize()
     assert_same(res, ref, "device ptrs")
+    assert_record_same(res, ref, "device ptrs")
     bits = res.allowed_bits.cpu().numpy().view(np.uint64)
     unpacked = ((bits[:, None] >> np.arange(64, dtype=np.uint64)[None, :]) & np.uint64(1)).reshape(-1)[:n]
     assert np.array_equal(unpacked.astype(np.uint8), ref.allowed)
@@ -366,4 +378,25 @@ def test_pipelined_batches_inputs_ready(own_stream, mode):
     for bidx in range(nb):
         assert_same(outs[bidx], refs[bidx], f"{mode} piped batch {bidx}")
     assert_state_same(eng, orc, np.arange(cap))
+    eng.close()
+
+
+@pytest.mark.parametrize("uniform", [True, False])
+def test_result_records_host_pointers(uniform):
+    """RateLimitResult as one 32-byte record per request == the four columns."""
+    import throttlecrab_amd as t
+    cap, n = 800, 30000
+    rng = np.random.default_rng(31)
+    eng, orc = _engine(cap), _oracle(cap)
+    for rnd in range(3):
+        slots = rng.integers(0, cap, n).astype(np.uint32)
+        if uniform:
+            q, now = 1, T0 + rnd * 10**9
+        else:
+            q, now = rng.integers(0, 3, n), T0 + rnd * 10**9 + rng.integers(0, 10**9, n)
+        ref = orc.batch_slots(slots, 5, 10, 60, q, now)
+        res = eng.rate_limit_batch_slots(slots, max_burst=5, count_per_period=10, period=60, quantity=q, now_ns=now,
+                                         want=t.Engine.RECORD_FIELDS)
+        assert_same(res, ref, f"records round {rnd}")
+        assert_record_same(res, ref, f"records round {rnd}")
     eng.close()

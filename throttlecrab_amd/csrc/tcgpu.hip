@@ -63,6 +63,7 @@ struct Params {
     int64_t* reset;
     int64_t* retry;
     uint8_t* status;
+    int64_t* result4;
     Cell* cells;
     const uint16_t* rate_id;
     const RateClass* classes;
@@ -113,6 +114,12 @@ __device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req
     if (p.remaining) p.remaining[i] = ok ? d.remaining : 0;
     if (p.reset) p.reset[i] = ok ? d.reset_after : 0;
     if (p.retry) p.retry[i] = ok ? d.retry_after : 0;
+    if (p.result4) {
+        // one 32-byte record = two 16-byte stores into the same 64-byte granule
+        longlong2* r4 = reinterpret_cast<longlong2*>(p.result4 + (size_t)i * 4);
+        r4[0] = make_longlong2(ok ? r.limit : 0, ok ? d.remaining : 0);
+        r4[1] = make_longlong2(ok ? d.reset_after : 0, ok ? d.retry_after : 0);
+    }
 }
 
 // Decision counters are accumulated in NSHARD shards (block b -> shard b % NSHARD):
@@ -625,6 +632,7 @@ struct tc_engine {
         uint8_t* allowed = nullptr;
         uint64_t* bits = nullptr;
         int64_t* out[4] = {nullptr, nullptr, nullptr, nullptr};
+        int64_t* result4 = nullptr;
         uint8_t* status = nullptr;
         bool ready = false;
     } stage;
@@ -913,7 +921,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     void* ptrs[] = {e->cells, e->rate_id, e->classes, e->counters, e->pend, e->pend_count,
                     e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
-                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status};
+                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     void* kptrs[] = {e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_hash, e->k_stage_bytes, e->k_stage_off};
@@ -1035,6 +1043,7 @@ static int stage_ensure(tc_engine* e) {
     TC_HIP(e, hipMalloc(&e->stage.allowed, mb));
     TC_HIP(e, hipMalloc(&e->stage.bits, ((mb + 63) / 64) * sizeof(uint64_t)));
     for (int j = 0; j < 4; ++j) TC_HIP(e, hipMalloc(&e->stage.out[j], mb * sizeof(int64_t)));
+    TC_HIP(e, hipMalloc(&e->stage.result4, mb * 4 * sizeof(int64_t)));
     TC_HIP(e, hipMalloc(&e->stage.status, mb));
     e->stage.ready = true;
     return TC_E_OK;
@@ -1094,6 +1103,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     p.reset = b.reset_after_ns;
     p.retry = b.retry_after_ns;
     p.status = b.status;
+    p.result4 = b.result4;
     p.cells = e->cells;
     p.rate_id = e->rate_id;
     p.classes = e->classes;
@@ -1104,7 +1114,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
         p.flags |= F_REGISTERED;
         if (e->uniform_id) p.flags |= F_UNIFORM_CLASS;
     }
-    const bool full = p.remaining || p.reset || p.retry;
+    const bool full = p.remaining || p.reset || p.retry || p.result4;
     const dim3 grid(nblocks(n)), block(BLOCK);
     hipStream_t s = cur_stream(e);
 
@@ -1185,6 +1195,7 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     d.reset_after_ns = b.reset_after_ns ? e->stage.out[2] : nullptr;
     d.retry_after_ns = b.retry_after_ns ? e->stage.out[3] : nullptr;
     d.status = b.status ? e->stage.status : nullptr;
+    d.result4 = b.result4 ? e->stage.result4 : nullptr;
     e->batches++;
     int rc = run_slots_device(e, d);
     if (rc != TC_E_OK) return rc;
@@ -1195,6 +1206,7 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     for (int j = 0; j < 4; ++j)
         if (hout[j]) TC_HIP(e, hipMemcpyAsync(hout[j], e->stage.out[j], n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (b.status) TC_HIP(e, hipMemcpyAsync(b.status, e->stage.status, n, hipMemcpyDeviceToHost, s));
+    if (b.result4) TC_HIP(e, hipMemcpyAsync(b.result4, e->stage.result4, n * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
     return TC_E_OK;
 }

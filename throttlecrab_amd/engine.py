@@ -26,7 +26,8 @@ def _is_torch(x) -> bool:
 
 class BatchResult:
     """Columnar (bool, RateLimitResult) + status for one batch."""
-    __slots__ = ("allowed", "allowed_bits", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+    __slots__ = ("allowed", "allowed_bits", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status",
+                 "result4")
 
     def __init__(self):
         for s in self.__slots__:
@@ -34,11 +35,14 @@ class BatchResult:
 
 
 _NP_DTYPES = {"allowed": np.uint8, "allowed_bits": np.uint64, "limit": np.int64, "remaining": np.int64,
-              "reset_after_ns": np.int64, "retry_after_ns": np.int64, "status": np.uint8}
+              "reset_after_ns": np.int64, "retry_after_ns": np.int64, "status": np.uint8, "result4": np.int64}
 
 
 class Engine:
     ALL_FIELDS = ("allowed", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+    # the same information with RateLimitResult as one 32-byte record per request
+    # (result4[i] = limit, remaining, reset_after_ns, retry_after_ns)
+    RECORD_FIELDS = ("allowed", "status", "result4")
 
     def __init__(self, capacity: int, max_batch: int = 1 << 20, device: int = 0, key_mode: bool = False,
                  key_arena_bytes: int = 0):
@@ -153,7 +157,7 @@ class Engine:
         res = out or BatchResult()
         for name in want:
             cur = getattr(res, name)
-            ln = (n + 63) // 64 if name == "allowed_bits" else n
+            ln = (n + 63) // 64 if name == "allowed_bits" else (4 * n if name == "result4" else n)
             if cur is None:
                 if dev:
                     import torch
