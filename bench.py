@@ -153,7 +153,7 @@ def keys_bench(a, dev):
     def one(s):
         kb, ko = batches[s]
         eng.rate_limit_batch_keys(kb, ko, max_burst=10, count_per_period=100, period=60, quantity=1,
-                                  now_ns=W.T0_NS + s * 10**9, want=("allowed",), out=out)
+                                  now_ns=W.T0_NS + s * 10**9, want=("allowed",), out=out, inputs_ready=True)
 
     for s in range(pre):
         one(s)

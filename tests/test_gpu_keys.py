@@ -216,3 +216,48 @@ def test_config5_shape_mixed_insert_lookup_1m_keys():
             eng.sweep_expired(now)
             assert eng.counters()["live_slots"] == len(orc)
     eng.close()
+
+
+def test_pipelined_key_batches_inputs_ready():
+    """TC_B_INPUTS_READY key batches: the key stage runs on the key stream, grouping on the
+    auxiliary streams, evaluation in order; interleaved with host-pointer batches, single-key
+    store operations and a sweep (which all run their key stage on the main stream).  New keys
+    keep appearing and hot keys recur in every batch."""
+    import torch
+    from oracle import oracle as O
+    rng = np.random.default_rng(91)
+    keys = [b"pk_%d" % i for i in range(40000)] + [b"long-key-" + b"y" * 60 + b"%d" % i for i in range(500)]
+    eng, orc = _engine(60000, 60000), _oracle(60000)
+    eng.use_torch_stream()
+    n, nb = 50000, 10
+    staged = []
+    for bidx in range(nb):
+        hi = 4000 + 4000 * bidx
+        idx = np.where(rng.random(n) < 0.3, np.minimum(rng.zipf(1.3, n) - 1, hi - 1), rng.integers(0, hi, n))
+        idx[:50] = len(keys) - 1 - rng.integers(0, 500, 50)   # a few keys beyond the inline 48 bytes
+        kb, ko = O.pack_keys([keys[i] for i in idx])
+        staged.append((kb, ko, torch.from_numpy(kb).cuda(), torch.from_numpy(ko.astype(np.int32)).cuda()))
+    torch.cuda.synchronize()
+    outs, refs = [], []
+    for bidx, (kb, ko, dkb, dko) in enumerate(staged):
+        now = T0 + bidx * 2 * 10**9
+        refs.append(orc.batch_keys(kb, ko, 5, 10, 60, 1, now))
+        if bidx % 4 == 2:   # host-pointer batch in the middle of the pipeline
+            outs.append(eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1,
+                                                  now_ns=now))
+        else:
+            outs.append(eng.rate_limit_batch_keys(dkb, dko, max_burst=5, count_per_period=10, period=60, quantity=1,
+                                                  now_ns=now, inputs_ready=True))
+        if bidx == 5:       # single-key operations and a sweep between pipelined batches
+            assert eng.get(b"pk_0", now) == orc.get(b"pk_0", now)
+            orc.force_cleanup(now)
+            eng.sweep_expired(now)
+            assert eng.counters()["live_slots"] == len(orc)
+    eng.synchronize()
+    torch.cuda.synchronize()
+    for bidx in range(nb):
+        assert_same(outs[bidx], refs[bidx], f"piped key batch {bidx}")
+    t_end = T0 + nb * 2 * 10**9
+    for k in keys[:300] + keys[-50:]:
+        assert eng.get(k, t_end) == orc.get(k, t_end), k
+    eng.close()

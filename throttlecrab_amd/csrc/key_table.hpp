@@ -11,11 +11,12 @@
 //                   entry = tag(32) << 32 | val(32);  val: 0 empty, 1 tombstone,
 //                   >= 2 bound to slot val-2, bit 31 set = "being inserted by
 //                   request (val & 0x7fffffff) of the current batch"
-//   key_hash[cap]   u64 full hash of the key bound to a slot
-//   key_len[cap]    u32 key length (0xFFFFFFFF = slot not bound)
-//   key_pos[cap]    u32 position of the slot's entry in ktab (for unbinding)
-//   key_cell[cap]   fixed cells of cell_bytes each; a key that does not fit keeps
-//                   an 8-byte offset into the overflow arena in its cell
+//   rec[cap]        one 64-byte KeyRec per slot: full hash, key length, position of
+//                   the slot's ktab entry (for unbinding) and the key bytes inline
+//                   (<= 48 B; a longer key keeps an 8-byte offset into the overflow
+//                   arena).  Confirming a tag hit is ONE 64-byte access.
+//   bound[cap]      u8 1 = slot has a key (the compact column the expiry sweep scans:
+//                   walking the 64-byte records would read 4x the bytes)
 //   free_slots[cap] stack of unbound slots, free_top = number of free slots
 //
 // Inserting inside a batch is a three-kernel protocol without spinning (a wave
@@ -32,18 +33,24 @@
 namespace kt {
 
 constexpr int THREADS = 256;
+constexpr int BIND_THREADS = 1024; // k_bind: one free-stack pop per block, so few, fat blocks
 constexpr uint32_t VAL_EMPTY = 0u, VAL_TOMB = 1u, VAL_PENDING = 0x80000000u;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 constexpr uint32_t ST_FOUND = 0u, ST_CLAIMANT = 1u, ST_FOLLOWER = 2u, ST_MISSING = 3u;
+constexpr uint32_t INLINE_KEY = 48u;
+
+struct __attribute__((aligned(64))) KeyRec {
+    uint64_t hash;
+    uint32_t len; // NO_SLOT = slot not bound
+    uint32_t pos;
+    uint8_t bytes[INLINE_KEY];
+};
 
 struct Table {
     unsigned long long* ktab;
     uint64_t nb_mask;
-    uint64_t* key_hash;
-    uint32_t* key_len;
-    uint32_t* key_pos;
-    uint8_t* key_cell;
-    uint32_t cell_bytes;
+    KeyRec* rec;
+    uint8_t* bound;
     uint8_t* overflow;
     uint64_t overflow_bytes;
     unsigned long long* overflow_used;
@@ -63,35 +70,58 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     return x;
 }
 
+// 1..7 trailing bytes as a little-endian word, without reading past the key
+// (gfx950 runs with unaligned global access, so the 2/4/8-byte loads are single instructions)
+__device__ __forceinline__ uint64_t load_tail(const uint8_t* __restrict__ p, uint32_t r) {
+    uint64_t w = 0;
+    uint32_t sh = 0;
+    if (r & 4u) {
+        uint32_t v;
+        __builtin_memcpy(&v, p, 4);
+        w = v;
+        p += 4;
+        sh = 32;
+    }
+    if (r & 2u) {
+        uint16_t v;
+        __builtin_memcpy(&v, p, 2);
+        w |= (uint64_t)v << sh;
+        p += 2;
+        sh += 16;
+    }
+    if (r & 1u) w |= (uint64_t)p[0] << sh;
+    return w;
+}
+
 __device__ __forceinline__ uint64_t hash_key(const uint8_t* __restrict__ p, uint32_t len) {
     uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)len;
     uint32_t i = 0;
     for (; i + 8 <= len; i += 8) {
-        uint64_t w = 0;
-#pragma unroll
-        for (int b = 0; b < 8; ++b) w |= (uint64_t)p[i + b] << (8 * b);
+        uint64_t w;
+        __builtin_memcpy(&w, p + i, 8);
         h = mix64(h ^ w) + 0x9e3779b97f4a7c15ull;
     }
-    if (i < len) {
-        uint64_t w = 0;
-        for (uint32_t b = 0; i + b < len; ++b) w |= (uint64_t)p[i + b] << (8 * b);
-        h = mix64(h ^ w ^ ((uint64_t)(len - i) << 56));
-    }
+    if (i < len) h = mix64(h ^ load_tail(p + i, len - i) ^ ((uint64_t)(len - i) << 56));
     return mix64(h);
 }
 
 __device__ __forceinline__ const uint8_t* stored_key(const Table& t, uint32_t slot, uint32_t len) {
-    const uint8_t* cell = t.key_cell + (size_t)slot * t.cell_bytes;
-    if (len <= t.cell_bytes) return cell;
+    const uint8_t* in = t.rec[slot].bytes;
+    if (len <= INLINE_KEY) return in;
     uint64_t off;
-    __builtin_memcpy(&off, cell, 8);
+    __builtin_memcpy(&off, in, 8);
     return t.overflow + off;
 }
 
 __device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t len) {
-    for (uint32_t i = 0; i < len; ++i)
-        if (a[i] != b[i]) return false;
-    return true;
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t x, y;
+        __builtin_memcpy(&x, a + i, 8);
+        __builtin_memcpy(&y, b + i, 8);
+        if (x != y) return false;
+    }
+    return i == len || load_tail(a + i, len - i) == load_tail(b + i, len - i);
 }
 
 // ---------------------------------------------------------------------------
@@ -142,7 +172,7 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
             }
         } else if (etag == tag) {
             const uint32_t s = val - 2u;
-            if (t.key_hash[s] == h && t.key_len[s] == len && bytes_equal(stored_key(t, s, len), key, len)) {
+            if (t.rec[s].hash == h && t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len)) {
                 st = ST_FOUND;
                 slot = s;
                 break;
@@ -156,14 +186,15 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
 }
 
 // rank of each flagged lane inside its block + the block total (one barrier)
+template <int NT = THREADS>
 __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t& total) {
-    __shared__ uint32_t s_w[THREADS / 64];
+    __shared__ uint32_t s_w[NT / 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long m = __ballot(flag);
     if (lane == 0) s_w[wave] = (uint32_t)__popcll(m);
     __syncthreads();
     uint32_t before = 0, tot = 0;
-    for (int w = 0; w < THREADS / 64; ++w) {
+    for (int w = 0; w < NT / 64; ++w) {
         if (w < wave) before += s_w[w];
         tot += s_w[w];
     }
@@ -172,15 +203,16 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t& total) {
 }
 
 // claimants: take a slot, store the key, publish the binding.  Slots are popped
-// from the free stack once per BLOCK (a per-request atomic on one address would
-// serialise at ~12 ns each: 200 k new keys = 2.4 ms).
-__global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
+// from the free stack once per BLOCK and the insert counter is bumped once per
+// block: an atomic on one address costs ~12 ns and serialises (a per-wave add was
+// 197 us of a 225 us kernel), hence blocks of 1024.
+__global__ __launch_bounds__(BIND_THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
                                                   const uint32_t* __restrict__ key_off, uint32_t n,
                                                   uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ state,
                                                   const uint32_t* __restrict__ aux, const uint64_t* __restrict__ hash_in,
                                                   unsigned long long* inserted_counter) {
     __shared__ int s_old_top;
-    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    const uint32_t i = blockIdx.x * BIND_THREADS + threadIdx.x;
     const bool claimant = i < n && state[i] == ST_CLAIMANT;
     uint32_t off = 0, len = 0;
     unsigned long long ovf = 0;
@@ -188,19 +220,20 @@ __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __rest
     if (claimant) {
         off = key_off[i];
         len = key_off[i + 1] - off;
-        if (len > t.cell_bytes) { // long key: reserve overflow bytes first
+        if (len > INLINE_KEY) { // long key: reserve overflow bytes first
             ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
             if (ovf + len > t.overflow_bytes) want = false;
         }
     }
     uint32_t total = 0;
-    const uint32_t rank = block_rank(want, total);
+    const uint32_t rank = block_rank<BIND_THREADS>(want, total);
     if (threadIdx.x == 0) {
         int old = 0;
         if (total) {
             old = atomicSub(t.free_top, (int)total);
             const int got = old < 0 ? 0 : (old < (int)total ? old : (int)total);
             if (got < (int)total) atomicAdd(t.free_top, (int)total - got); // stack ran dry: undo the excess
+            if (got > 0) atomicAdd(inserted_counter, (unsigned long long)got);
         }
         s_old_top = old;
     }
@@ -216,17 +249,24 @@ __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __rest
             if (idx >= 0) slot = t.free_slots[idx];
         }
         if (slot != NO_SLOT) {
-            uint8_t* cell = t.key_cell + (size_t)slot * t.cell_bytes;
-            if (len > t.cell_bytes) {
-                for (uint32_t b = 0; b < len; ++b) t.overflow[ovf + b] = key[b];
+            KeyRec& kr = t.rec[slot];
+            uint8_t* dst = kr.bytes;
+            if (len > INLINE_KEY) {
                 const uint64_t o64 = ovf;
-                __builtin_memcpy(cell, &o64, 8);
-            } else {
-                for (uint32_t b = 0; b < len; ++b) cell[b] = key[b];
+                __builtin_memcpy(kr.bytes, &o64, 8);
+                dst = t.overflow + ovf; // reservations are 16-byte multiples: dst is 16-byte aligned
             }
-            t.key_hash[slot] = h;
-            t.key_len[slot] = len;
-            t.key_pos[slot] = pos;
+            uint32_t b = 0;
+            for (; b + 8 <= len; b += 8) {
+                uint64_t w;
+                __builtin_memcpy(&w, key + b, 8);
+                __builtin_memcpy(dst + b, &w, 8);
+            }
+            for (; b < len; ++b) dst[b] = key[b];
+            kr.hash = h;
+            kr.len = len;
+            kr.pos = pos;
+            t.bound[slot] = 1;
             t.ktab[pos] = ((unsigned long long)(uint32_t)(h >> 32) << 32) | (unsigned long long)(slot + 2u);
             bound = true;
         } else {
@@ -236,8 +276,7 @@ __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __rest
         }
         slot_out[i] = slot;
     }
-    const unsigned long long m = __ballot(bound);
-    if ((threadIdx.x & 63) == 0 && m) atomicAdd(inserted_counter, (unsigned long long)__popcll(m));
+    (void)bound;
 }
 
 // duplicates of a key first seen in this batch take the claimant's slot
@@ -247,25 +286,25 @@ __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __rest
     if (i < n && state[i] == ST_FOLLOWER) slot_out[i] = slot_out[aux[i]];
 }
 
-__global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint32_t* key_len, uint32_t capacity) {
+__global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint8_t* bound, uint32_t capacity) {
     for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < capacity; i += gridDim.x * THREADS) {
         free_slots[i] = capacity - 1u - i; // slot 0 is handed out first
-        key_len[i] = NO_SLOT;
+        bound[i] = 0;
     }
 }
 
 // rebuild: clear ktab (memset by the host) and re-enter every bound slot
 __global__ __launch_bounds__(THREADS) void k_reinsert(Table t) {
     for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
-        if (t.key_len[s] == NO_SLOT) continue;
-        const uint64_t h = t.key_hash[s];
+        if (!t.bound[s]) continue;
+        const uint64_t h = t.rec[s].hash;
         const unsigned long long mine = ((unsigned long long)(uint32_t)(h >> 32) << 32) | (unsigned long long)(s + 2u);
         uint64_t pos = h & t.nb_mask;
         while (true) {
             unsigned long long expected = 0ull;
             if (__hip_atomic_compare_exchange_strong(&t.ktab[pos], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT)) {
-                t.key_pos[s] = (uint32_t)pos;
+                t.rec[s].pos = (uint32_t)pos;
                 break;
             }
             pos = (pos + 1) & t.nb_mask;

@@ -458,17 +458,31 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint6
 }
 
 // Key-mode sweep: same retain rule, and an expired (or never written) bound slot
-// also loses its key: tombstone in the hash table, slot back on the free stack
-// (one stack push per block, not per slot).
+// also loses its key: tombstone in the hash table, slot back on the free stack.
+// Every block owns a contiguous range of slots, collects the slots it unbinds in
+// LDS and pushes them with ONE stack reservation per SWEEP_BUF slots (an atomic on
+// the stack top costs ~12 ns and serialises: one per 256 slots was most of the kernel).
+constexpr int SWEEP_BUF = 8192;
 __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
                                                       unsigned long long* counters, unsigned long long* removed_out) {
+    __shared__ uint32_t s_buf[SWEEP_BUF];
     __shared__ int s_base;
-    uint32_t removed = 0, live = 0;
-    const uint64_t rounds = ((uint64_t)t.capacity + (uint64_t)gridDim.x * BLOCK - 1) / ((uint64_t)gridDim.x * BLOCK);
-    for (uint64_t rd = 0; rd < rounds; ++rd) {
-        const uint64_t i = rd * gridDim.x * BLOCK + (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t removed = 0, live = 0, fill = 0; // fill is uniform over the block
+    const uint64_t per_block = (((uint64_t)t.capacity + gridDim.x - 1) / gridDim.x + BLOCK - 1) / BLOCK * BLOCK;
+    const uint64_t first = (uint64_t)blockIdx.x * per_block;
+    const uint64_t last = first + per_block < t.capacity ? first + per_block : t.capacity;
+    auto flush = [&]() {
+        if (threadIdx.x == 0) s_base = atomicAdd(t.free_top, (int)fill);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < fill; j += BLOCK) t.free_slots[s_base + (int)j] = s_buf[j];
+        __syncthreads();
+        fill = 0;
+    };
+    uint32_t unbound_total = 0;
+    for (uint64_t base = first; base < last; base += BLOCK) {
+        const uint64_t i = base + threadIdx.x;
         bool unbind = false;
-        if (i < t.capacity && t.key_len[i] != kt::NO_SLOT) {
+        if (i < last && t.bound[i]) {
             Cell c = cells[i];
             if (!(c.expiry > (uint64_t)now)) {
                 if (c.expiry != 0) removed++; // the reference's map only ever held written entries
@@ -481,18 +495,20 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, 
             }
         }
         uint32_t total = 0;
-        const uint32_t rank = kt::block_rank(unbind, total);
-        if (threadIdx.x == 0 && total) s_base = atomicAdd(t.free_top, (int)total);
-        __syncthreads();
+        const uint32_t rank = kt::block_rank<BLOCK>(unbind, total); // one barrier
+        if (fill + total > (uint32_t)SWEEP_BUF) flush();
         if (unbind) {
-            const uint32_t pos = t.key_pos[i];
+            const uint32_t pos = t.rec[i].pos;
             t.ktab[pos] = (t.ktab[pos] & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
-            t.key_len[i] = kt::NO_SLOT;
-            t.free_slots[s_base + (int)rank] = (uint32_t)i;
+            t.bound[i] = 0;
+            s_buf[fill + rank] = (uint32_t)i;
         }
-        if (threadIdx.x == 0 && total) atomicAdd(t.tombs, total);
-        __syncthreads();
+        fill += total;
+        unbound_total += total;
+        __syncthreads(); // block_rank's scratch is reused next round
     }
+    if (fill) flush();
+    if (threadIdx.x == 0 && unbound_total) atomicAdd(t.tombs, unbound_total);
     __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
         removed += __shfl_down(removed, off, 64);
@@ -609,6 +625,7 @@ struct tc_engine {
     struct SortSet {
         uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
         uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
+        uint32_t* k_slot = nullptr;                    // key mode: slots resolved for the batch using this set
         uint32_t hist_parity = 0;
         hipEvent_t sorted = nullptr;   // recorded on the auxiliary stream after the last pass
         hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
@@ -645,6 +662,13 @@ struct tc_engine {
     void* kt_block = nullptr;        // one allocation backing every kt.* array
     uint32_t *k_slot = nullptr, *k_state = nullptr, *k_aux = nullptr; // max_batch each
     uint64_t* k_hash = nullptr;
+    // Key stages mutate the key table and share the scratch above, so they run one after another in
+    // call order: on the key stream for TC_B_INPUTS_READY device batches (overlapping the grouping and
+    // evaluation of earlier batches), else on the main stream; the two events hand the order across.
+    hipStream_t key_stream = nullptr;
+    hipEvent_t k_done = nullptr, m_done = nullptr;
+    bool k_busy = false, m_busy = false;
+    hipEvent_t wait_before_sort = nullptr; // piped key batch: the auxiliary sort waits for its key stage
     uint8_t* k_stage_bytes = nullptr; // host-pointer batches: staged key arena
     size_t k_stage_bytes_cap = 0;
     uint32_t* k_stage_off = nullptr;  // max_batch + 1
@@ -755,21 +779,16 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     const uint64_t cap = e->capacity, mb = e->max_batch;
     uint64_t nb = 1;
     while (nb < 2 * cap) nb <<= 1; // load factor <= 0.5
-    uint32_t cell = 32;
-    if (key_arena_bytes) {
-        uint64_t per = key_arena_bytes / cap;
-        per = per / 16 * 16;
-        cell = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(per, 16), 256);
-    }
-    const uint64_t overflow = std::max<uint64_t>(1u << 20, cap * 4); // long keys are the exception
+    // keys up to 48 bytes live inside their slot's KeyRec; longer ones in the overflow arena
+    const uint64_t overflow = align_up(key_arena_bytes ? key_arena_bytes : std::max<uint64_t>(1u << 20, cap * 4), 256);
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t at = off;
         off = align_up(off + bytes, 256);
         return at;
     };
-    const size_t o_ktab = take(nb * 8), o_hash = take(cap * 8), o_len = take(cap * 4), o_pos = take(cap * 4),
-                 o_cell = take(cap * (size_t)cell), o_ovf = take(overflow), o_free = take(cap * 4), o_misc = take(64);
+    const size_t o_ktab = take(nb * 8), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(overflow),
+                 o_free = take(cap * 4), o_misc = take(64);
     TC_HIP(e, hipMalloc(&e->kt_block, off));
     uint8_t* base = (uint8_t*)e->kt_block;
     TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * 8, (hipStream_t)0));
@@ -777,11 +796,8 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     kt::Table& t = e->kt;
     t.ktab = (unsigned long long*)(base + o_ktab);
     t.nb_mask = nb - 1;
-    t.key_hash = (uint64_t*)(base + o_hash);
-    t.key_len = (uint32_t*)(base + o_len);
-    t.key_pos = (uint32_t*)(base + o_pos);
-    t.key_cell = base + o_cell;
-    t.cell_bytes = cell;
+    t.rec = (kt::KeyRec*)(base + o_rec);
+    t.bound = base + o_bound;
     t.overflow = base + o_ovf;
     t.overflow_bytes = overflow;
     t.overflow_used = (unsigned long long*)(base + o_misc);
@@ -791,10 +807,14 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     t.free_slots = (uint32_t*)(base + o_free);
     t.capacity = (uint32_t)cap;
     hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, (hipStream_t)0,
-                       t.free_slots, t.key_len, (uint32_t)cap);
+                       t.free_slots, t.bound, (uint32_t)cap);
     const int top = (int)cap;
     TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->k_slot, mb * 4));
+    for (uint32_t si = 0; si < e->depth; ++si) TC_HIP(e, hipMalloc(&e->sets[si].k_slot, mb * 4));
+    TC_HIP(e, hipStreamCreateWithFlags(&e->key_stream, hipStreamNonBlocking));
+    TC_HIP(e, hipEventCreateWithFlags(&e->k_done, hipEventDisableTiming));
+    TC_HIP(e, hipEventCreateWithFlags(&e->m_done, hipEventDisableTiming));
     TC_HIP(e, hipMalloc(&e->k_state, mb * 4));
     TC_HIP(e, hipMalloc(&e->k_aux, mb * 4));
     TC_HIP(e, hipMalloc(&e->k_hash, mb * 8));
@@ -804,23 +824,40 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     return TC_E_OK;
 }
 
-// keys (device arena) -> e->k_slot[0..n): found slot, freshly bound slot, or NO_SLOT
-static int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert) {
-    hipStream_t s = cur_stream(e);
+// keys (device arena) -> out_slot[0..n): found slot, freshly bound slot, or NO_SLOT.
+// on_key_stream: issue on the key stream (the caller vouched for the inputs), else on the main stream.
+static int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert,
+                               uint32_t* out_slot, bool on_key_stream) {
+    hipStream_t s = on_key_stream ? e->key_stream : cur_stream(e);
+    if (on_key_stream) {
+        if (e->m_busy) TC_HIP(e, hipStreamWaitEvent(s, e->m_done, 0));
+    } else {
+        if (e->k_busy) TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+    }
     const dim3 grid(nblocks(n)), block(kt::THREADS);
     prof_begin(e, TC_STAGE_HASH, s);
     if (insert) {
-        hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state, e->k_aux,
+        hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux,
                            e->k_hash);
-        hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state, e->k_aux,
-                           e->k_hash, e->counters + TC_CNT_KEYS_INSERTED);
-        hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, e->k_slot, e->k_state, e->k_aux);
+        hipLaunchKernelGGL(kt::k_bind, dim3((n + kt::BIND_THREADS - 1) / kt::BIND_THREADS), dim3(kt::BIND_THREADS), 0, s,
+                           e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_hash,
+                           e->counters + TC_CNT_KEYS_INSERTED);
+        hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, out_slot, e->k_state, e->k_aux);
     } else {
-        hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, e->k_slot, e->k_state,
+        hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state,
                            e->k_aux, e->k_hash);
     }
     prof_end(e, s);
     TC_HIP(e, hipGetLastError());
+    if (on_key_stream) {
+        TC_HIP(e, hipEventRecord(e->k_done, s));
+        e->k_busy = true;
+        e->m_busy = false;
+    } else {
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
+        e->k_busy = false;
+    }
     return TC_E_OK;
 }
 
@@ -850,7 +887,7 @@ static int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, boo
     const uint32_t* d_off;
     int rc = stage_keys(e, key, off, 1, &d_bytes, &d_off);
     if (rc != TC_E_OK) return rc;
-    rc = resolve_keys_device(e, d_bytes, d_off, 1, insert);
+    rc = resolve_keys_device(e, d_bytes, d_off, 1, insert, e->k_slot, false);
     if (rc != TC_E_OK) return rc;
     TC_HIP(e, hipMemcpyAsync(slot, e->k_slot, sizeof(uint32_t), hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
@@ -924,6 +961,14 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
+    if (e->key_stream) {
+        (void)hipStreamSynchronize(e->key_stream);
+        (void)hipStreamDestroy(e->key_stream);
+    }
+    if (e->k_done) (void)hipEventDestroy(e->k_done);
+    if (e->m_done) (void)hipEventDestroy(e->m_done);
+    for (tc_engine::SortSet& ss : e->sets)
+        if (ss.k_slot) (void)hipFree(ss.k_slot);
     void* kptrs[] = {e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_hash, e->k_stage_bytes, e->k_stage_off};
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
@@ -1134,6 +1179,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
             hipStream_t ax = e->aux[e->next_aux];
             e->next_aux = (e->next_aux + 1) % e->n_aux;
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
+            if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
             sorted = sort_by_slot(e, ss, ax, b.slot, n);
             TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
@@ -1157,6 +1203,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
             else hipLaunchKernelGGL((k_eval_sorted<false, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
             prof_end(e, s);
         }
+        e->wait_before_sort = nullptr;
         // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream
         TC_HIP(e, hipEventRecord(ss.consumed, s));
         ss.in_use = true;
@@ -1259,16 +1306,23 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
         int rc = stage_keys(e, b.key_bytes, b.key_off, b.n, &d_bytes, &d_off);
         if (rc != TC_E_OK) return rc;
     }
-    int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true);
-    if (rc != TC_E_OK) return rc;
     tc_batch s = b;
     s.key_bytes = nullptr;
     s.key_off = nullptr;
     if (dev) {
-        s.slot = e->k_slot;
+        // the slots go into the scratch set the grouping stage is about to use
+        tc_engine::SortSet& ss = e->sets[e->next_set];
+        const bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        if (piped && ss.in_use) TC_HIP(e, hipStreamWaitEvent(e->key_stream, ss.consumed, 0)); // ss.k_slot is free again
+        int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, ss.k_slot, piped);
+        if (rc != TC_E_OK) return rc;
+        if (piped) e->wait_before_sort = e->k_done;
+        s.slot = ss.k_slot;
         e->batches++;
         return run_slots_device(e, s);
     }
+    int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, e->k_slot, false);
+    if (rc != TC_E_OK) return rc;
     // host pointers for everything else: reuse the slot path's staging, with the
     // slot column already on the device
     rc = stage_ensure(e);
@@ -1329,10 +1383,14 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     if (!e) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));
     unsigned long long* scratch = e->counters + TC_CNT_COUNT;
+    if (e->k_busy) { // key stages still in flight on the key stream come first
+        TC_HIP(e, hipStreamWaitEvent(cur_stream(e), e->k_done, 0));
+        e->k_busy = false;
+    }
     TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), cur_stream(e)));
     TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), cur_stream(e)));
     if (e->key_mode)
-        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
+        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 1024)), dim3(BLOCK), 0, cur_stream(e),
                            e->cells, e->kt, now_ns, e->counters, scratch);
     else
         hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
@@ -1345,7 +1403,11 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     if (removed) *removed = r;
     // tombstones lengthen probe chains: rebuild the table once they fill 1/4 of it
-    if (e->key_mode && (uint64_t)tombs > (e->kt.nb_mask + 1) / 4) return rebuild_key_table(e);
+    if (e->key_mode && (uint64_t)tombs > (e->kt.nb_mask + 1) / 4) {
+        int rc = rebuild_key_table(e);
+        if (rc != TC_E_OK) return rc;
+        TC_HIP(e, hipStreamSynchronize(cur_stream(e))); // later key stages may run on the key stream
+    }
     return TC_E_OK;
 }
 
@@ -1384,6 +1446,7 @@ extern "C" int tc_profile_read(tc_engine* e, double total_ms[TC_STAGE_COUNT], ui
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     for (hipStream_t a : e->aux)
         if (a) TC_HIP(e, hipStreamSynchronize(a));
+    if (e->key_stream) TC_HIP(e, hipStreamSynchronize(e->key_stream));
     for (size_t i = 0; i < e->prof_used; ++i) {
         const int st = e->prof_stage[i];
         if (st < 0) continue;

@@ -198,8 +198,9 @@ class Engine:
 
     def rate_limit_batch_keys(self, key_bytes, key_off, *, max_burst=None, count_per_period=None, period=None,
                               quantity=None, now_ns=None, want=ALL_FIELDS,
-                              out: Optional[BatchResult] = None) -> BatchResult:
-        """rate_limit_batch over string keys (arena bytes + offsets[n+1])."""
+                              out: Optional[BatchResult] = None, inputs_ready=False) -> BatchResult:
+        """rate_limit_batch over string keys (arena bytes + offsets[n+1]).  inputs_ready: see
+        rate_limit_batch_slots (here it covers the key arena and the offsets)."""
         dev = _is_torch(key_bytes)
         keep = []
         if dev:
@@ -213,7 +214,7 @@ class Engine:
             n = koff.size - 1
             kb, ko = kbytes.ctypes.data, koff.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, False, False,
-                                   want, out)
+                                   want, out, inputs_ready)
         b.key_bytes = kb
         b.key_off = ko
         if n:
