@@ -400,3 +400,31 @@ def test_result_records_host_pointers(uniform):
         assert_same(res, ref, f"records round {rnd}")
         assert_record_same(res, ref, f"records round {rnd}")
     eng.close()
+
+
+@pytest.mark.parametrize("burst,count,period,label", [
+    (5, 10, 60, "mostly denied"),
+    (100000, 1000, 1, "long allowed runs (burst 100000)"),
+    (1, 1, 1, "burst 1: every entry expires as it is written"),
+    (50, 2**62, 60, "ei = 0: everything allowed"),
+])
+def test_general_batches_hot_keys_span_many_waves(burst, count, period, label):
+    """Per-request timestamps / quantities with a few very hot keys: segments of tens of
+    thousands of requests cross hundreds of waves and blocks (k_eval_general's hand-over chain)."""
+    cap, n = 4096, 200_000
+    import zlib
+    rng = np.random.default_rng(zlib.crc32(label.encode()))
+    eng, orc = _engine(cap, n), _oracle(cap)
+    for rnd in range(3):
+        hot = rng.random(n)
+        slots = np.where(hot < 0.45, 7, np.where(hot < 0.7, 4095, np.where(hot < 0.8, 63, rng.integers(0, cap, n)))).astype(np.uint32)
+        now = T0 + rnd * 5 * 10**9 + np.sort(rng.integers(0, 4 * 10**9, n))     # queue order ~ time order ...
+        jitter = rng.random(n) < 0.05
+        now[jitter] -= rng.integers(0, 10**9, jitter.sum())                      # ... but not monotone
+        q = rng.choice(np.array([1, 1, 1, 2, 0, -1], dtype=np.int64), n)
+        ref = orc.batch_slots(slots, burst, count, period, q, now)
+        res = eng.rate_limit_batch_slots(slots, max_burst=burst, count_per_period=count, period=period, quantity=q,
+                                         now_ns=now)
+        assert_same(res, ref, f"{label} round {rnd}")
+        assert_state_same(eng, orc, slots)
+    eng.close()

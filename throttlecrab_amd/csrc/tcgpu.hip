@@ -219,9 +219,9 @@ struct __attribute__((aligned(16))) PendEntry {
 //     store is parked in pend[] and applied by k_commit_list after this kernel (folding it into
 //     the kernel's last block was measured slower: the hand-off needs every block to drain its stores),
 //     so no lane of another wave can read a half-updated cell.
-//   otherwise: the segment head walks its segment in index order.
+//   Batches with per-request now / quantity / rate go through k_eval_general.
 // ---------------------------------------------------------------------------
-template <bool FULL, bool UNIFORM>
+template <bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
                                                        PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count) {
     const uint32_t n = p.n;
@@ -233,40 +233,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     const bool head = valid && (k == 0 || (uint32_t)(sorted[k - 1] >> 32) != slot);
     uint32_t na = 0, nd = 0, ne = 0;
 
-    if (!UNIFORM) {
-        if (head) {
-            Cell c;
-            c.tat = 0;
-            c.expiry = 0;
-            if (slot < p.capacity) c = p.cells[slot];
-            bool dirty = false;
-            uint32_t i = idx;
-            for (uint32_t j = k;;) {
-                const Req r = make_req(p, i, slot);
-                Decision d;
-                d.allowed = false;
-                d.remaining = d.reset_after = d.retry_after = 0;
-                if (r.status == tc::ST_OK) {
-                    d = tc::gcra_step<FULL>(c, r.ei, r.dvt, r.q, r.now);
-                    dirty |= d.allowed;
-                    na += d.allowed;
-                    nd += !d.allowed;
-                } else {
-                    ne += 1;
-                }
-                write_out(p, i, r, d);
-                if (++j >= n) break;
-                const uint64_t nx = sorted[j];
-                if ((uint32_t)(nx >> 32) != slot) break;
-                i = (uint32_t)nx;
-            }
-            if (dirty) p.cells[slot] = c;
-        }
-        block_count3(na, nd, ne, p.counters);
-        return;
-    }
-
-    // ---- UNIFORM ----
     const bool is_last = valid && ((k + 1 == n) || ((uint32_t)(sorted[k + 1] >> 32) != slot));
     __shared__ uint32_t s_start;
     const uint32_t block_start = blockIdx.x * BLOCK;
@@ -362,6 +328,223 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
             pe.slot = slot;
             pe.pad[0] = pe.pad[1] = pe.pad[2] = 0;
             pend[at] = pe;
+        }
+    }
+    block_count3(na, nd, ne, p.counters);
+}
+
+// ---------------------------------------------------------------------------
+// K2g: general batches (per-request now / quantity / rate) over the sorted batch.
+// The update is not an associative scan (a denied request leaves the TAT, an
+// allowed one moves it), but a DENIED request never changes the state, so a wave
+// evaluates all requests of a segment piece against the piece's current state at
+// once: everything before the first allowed request is final (denied against that
+// state), the first allowed request is final and hands its new state to the lanes
+// after it, repeat.  Iterations per wave = allowed requests in its longest piece
+// + 1: a run of denials of a hot key costs one step per 64 requests, and a wave
+// of 64 unrelated keys costs one step.  A segment that continues into the next
+// wave hands (state, dirty) over through chain[]: the next wave (same or next
+// block, dispatched no later than its successor) waits for it with its own
+// request columns already loaded.  The last lane of a segment stores the cell.
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(32))) ChainRec {
+    unsigned long long tat, expiry; // state the wave's last piece leaves (valid once fin == batch sequence number)
+    uint32_t fin;                   // low half of the 8-byte flag word
+    uint32_t spec;                  // == sequence number: "my lanes are all denied if my segment still has its
+                                    // resident state when it reaches me" (published before the wave waits)
+    uint32_t dirty;
+    uint32_t pad;
+};
+
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t* __restrict__ sorted,
+                                                        ChainRec* __restrict__ chain, uint32_t seq) {
+    const uint32_t n = p.n;
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = k >> 6; // global wave number
+    const bool valid = k < n;
+    const uint64_t me = valid ? sorted[k] : ~0ull;
+    const uint32_t slot = (uint32_t)(me >> 32);
+    const uint32_t idx = (uint32_t)me;
+    uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
+    if (lane == 0 && valid && k > 0) prev_slot = (uint32_t)(sorted[k - 1] >> 32);
+    if (lane == 63 && k + 1 < n) next_slot = (uint32_t)(sorted[k + 1] >> 32);
+    const bool head = valid && (k == 0 || prev_slot != slot);
+    const bool is_last = valid && (k + 1 == n || next_slot != slot);
+
+    Req r;
+    r.ei = r.dvt = r.q = r.now = r.limit = 0;
+    r.status = tc::ST_INTERNAL;
+    if (valid) r = make_req(p, idx, slot);
+    const bool ok = valid && r.status == tc::ST_OK;
+
+    // my piece = lanes [pstart, pend] of this wave that belong to my segment
+    const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long hb = __ballot(head) & upto;
+    const int pstart = hb ? 63 - __builtin_clzll(hb) : 0;
+    const bool continued = valid && hb == 0ull; // my segment began in an earlier wave
+    const unsigned long long lb = __ballot(is_last) >> lane;
+    const int pend = lb ? lane + __builtin_ctzll(lb) : 63;
+    const unsigned long long piece =
+        (pend == 63 ? ~0ull : ((2ull << pend) - 1ull)) & ~((1ull << pstart) - 1ull);
+
+    // State my piece starts from: the resident cell, or what the previous wave hands over.
+    // A hot key's segment crosses hundreds of waves; waiting wave by wave would serialise
+    // ~2 us hops (measured 3.5 ms for the Zipf head).  But a denied request leaves the state
+    // alone, and a saturated key is denied almost always, so every wave of a continued segment
+    // first checks its lanes against the segment's RESIDENT state c0 (every wave of the segment
+    // can load it: the cell is only rewritten by the segment's last lane, which needs all of
+    // them first).  "Nobody allowed under c0" is published at once (spec); a wave then looks
+    // back over 64 predecessors per round trip: spec, spec, ..., fin(v) with v == c0 proves that
+    // the state reaching it is c0.  Any mismatch falls back to the direct predecessor's record.
+    Cell c;
+    c.tat = 0;
+    c.expiry = 0;
+    bool dirty = false;
+    if (valid && slot < p.capacity) c = p.cells[slot]; // continued lanes: c0, the guess
+    if (__ballot(continued) != 0ull) { // wave-uniform: lane 0 is continued
+        bool spec_allow = false;
+        if (continued && ok) {
+            Cell t0 = c;
+            spec_allow = tc::gcra_step<false>(t0, r.ei, r.dvt, r.q, r.now).allowed;
+        }
+        const bool transparent = __ballot(spec_allow) == 0ull;
+        const bool through = __shfl((int)(continued && !is_last), 63, 64) != 0; // the segment runs through this whole wave
+        if (transparent && through && lane == 0)
+            __hip_atomic_store(&chain[gw].spec, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long c0_tat = __shfl((long long)c.tat, 0, 64);
+        const unsigned long long c0_exp = __shfl((unsigned long long)c.expiry, 0, 64);
+        long long in_tat = 0;
+        unsigned long long in_exp = 0;
+        uint32_t in_dirty = 0;
+        bool direct = false; // give up speculating: wait for the direct predecessor
+        uint32_t base = 0;   // records gw-1-base-lane are examined
+        while (true) {
+            const long long j = (long long)gw - 1 - (long long)base - lane;
+            unsigned long long fl = 0ull;
+            if (j >= 0 && (!direct || lane == 0))
+                fl = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&chain[j].fin), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            const bool is_fin = (uint32_t)fl == seq, is_spec = (uint32_t)(fl >> 32) == seq;
+            const unsigned long long fm = __ballot(is_fin), sm = __ballot(is_spec);
+            int d = -1; // lane whose record ends the look-back
+            if (direct) {
+                if (fm & 1ull) d = 0;
+            } else if (fm) {
+                const int f = __builtin_ctzll(fm);
+                const unsigned long long below = f ? ((1ull << f) - 1ull) : 0ull;
+                if ((~sm & below) == 0ull) d = f; // everything nearer than the final record is transparent
+            } else if (~sm == 0ull) {
+                base += 64; // 64 transparent waves: look further back
+                continue;
+            }
+            if (d < 0) {
+                base = 0; // something in between is not ready: look again from the nearest record
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            long long vt = 0;
+            unsigned long long vx = 0;
+            uint32_t vd = 0;
+            if (lane == d) {
+                vt = (long long)__hip_atomic_load(&chain[j].tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vx = __hip_atomic_load(&chain[j].expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vd = __hip_atomic_load(&chain[j].dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            vt = __shfl(vt, d, 64);
+            vx = __shfl(vx, d, 64);
+            vd = __shfl(vd, d, 64);
+            if (d == 0 && base == 0) { // the direct predecessor: exact
+                in_tat = vt;
+                in_exp = vx;
+                in_dirty = vd;
+                break;
+            }
+            if (vt == c0_tat && vx == c0_exp) { // the transparent waves in between were right
+                in_tat = vt;
+                in_exp = vx;
+                in_dirty = vd;
+                break;
+            }
+            direct = true; // the state changed on the way: no shortcut
+            base = 0;
+        }
+        if (continued) {
+            c.tat = in_tat;
+            c.expiry = in_exp;
+            dirty = in_dirty != 0u;
+        }
+    }
+
+    uint32_t na = 0, nd = 0, ne = 0;
+    bool fin = !valid, was_allowed = false;
+    Cell mine; // state after my request, if it was allowed
+    mine.tat = 0;
+    mine.expiry = 0;
+    if (valid && !ok) { // errors leave the state alone (rate_limiter.rs:111-117)
+        Decision z;
+        z.allowed = false;
+        z.remaining = z.reset_after = z.retry_after = 0;
+        write_out(p, idx, r, z);
+        ne = 1;
+        fin = true;
+    }
+    while (true) {
+        Cell c2 = c;
+        bool allow = false;
+        if (!fin) allow = tc::gcra_step<false>(c2, r.ei, r.dvt, r.q, r.now).allowed;
+        const unsigned long long open = __ballot(!fin);
+        if (open == 0ull) break;
+        const unsigned long long ap = __ballot(allow) & piece;
+        const int first = ap ? __builtin_ctzll(ap) : 64;
+        if (!fin && lane <= first) {
+            // lanes before the first allowed request are denied against the current state,
+            // the first allowed request is allowed against it: both final
+            Decision d;
+            if (FULL) {
+                Cell tmp = c;
+                d = tc::gcra_step<true>(tmp, r.ei, r.dvt, r.q, r.now);
+            } else {
+                d.allowed = allow;
+                d.remaining = d.reset_after = d.retry_after = 0;
+            }
+            write_out(p, idx, r, d);
+            if (lane == first) {
+                na = 1;
+                was_allowed = true;
+                mine = c2;
+            } else {
+                nd = 1;
+            }
+            fin = true;
+        }
+        // the lanes after `first` in its piece continue from the state it leaves
+        const int src = first < 64 ? first : lane;
+        const long long nt = __shfl((long long)c2.tat, src, 64);
+        const unsigned long long nx = __shfl((unsigned long long)c2.expiry, src, 64);
+        if (first < 64 && lane > first) { // (lanes beyond pend are masked out by `piece` in `ap`: first is in MY piece)
+            c.tat = nt;
+            c.expiry = nx;
+            dirty = true;
+        }
+    }
+    // the last lane of the piece owns the state the piece leaves
+    if (valid && lane == pend) {
+        const Cell out = was_allowed ? mine : c;
+        const bool out_dirty = dirty || was_allowed;
+        if (is_last) {
+            if (out_dirty && slot < p.capacity) p.cells[slot] = out;
+        } else {
+            ChainRec* o = &chain[gw];
+            __hip_atomic_store(&o->tat, (unsigned long long)out.tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->expiry, (unsigned long long)out.expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->dirty, out_dirty ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the record must be performed at agent scope before the flag that announces it
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __builtin_amdgcn_s_waitcnt(0);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __hip_atomic_store(&o->fin, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     block_count3(na, nd, ne, p.counters);
@@ -638,6 +821,8 @@ struct tc_engine {
     uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
     PendEntry* pend = nullptr;
+    ChainRec* chain = nullptr; // k_eval_general: per-wave hand-over records
+    uint32_t chain_seq = 0;
     uint32_t* pend_count = nullptr;
     uint8_t* allowed_tmp = nullptr;
     StoreOpResult* op_result = nullptr;
@@ -764,6 +949,8 @@ static int engine_alloc(tc_engine* e) {
         TC_HIP(e, hipEventCreateWithFlags(&ss.consumed, hipEventDisableTiming));
     }
     TC_HIP(e, hipMalloc(&e->pend, (mb / 32 + 1024) * sizeof(PendEntry)));
+    TC_HIP(e, hipMalloc(&e->chain, (mb / 64 + 2) * sizeof(ChainRec)));
+    TC_HIP(e, hipMemsetAsync(e->chain, 0, (mb / 64 + 2) * sizeof(ChainRec), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->pend_count, 2 * sizeof(uint32_t)));
     TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
@@ -955,7 +1142,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->counters, e->pend, e->pend_count,
+    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->counters, e->pend, e->chain, e->pend_count,
                     e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4};
@@ -1192,15 +1379,16 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
         const bool uniform = !p.q && !p.now && params_by_slot;
         prof_begin(e, TC_STAGE_EVAL, s);
         if (uniform) {
-            if (full) hipLaunchKernelGGL((k_eval_sorted<true, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
-            else hipLaunchKernelGGL((k_eval_sorted<false, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
+            if (full) hipLaunchKernelGGL(k_eval_sorted<true>, grid, block, 0, s, p, sorted, e->pend, e->pend_count);
+            else hipLaunchKernelGGL(k_eval_sorted<false>, grid, block, 0, s, p, sorted, e->pend, e->pend_count);
             prof_end(e, s);
             prof_begin(e, TC_STAGE_COMMIT, s);
             hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells);
             prof_end(e, s);
         } else {
-            if (full) hipLaunchKernelGGL((k_eval_sorted<true, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
-            else hipLaunchKernelGGL((k_eval_sorted<false, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count);
+            if (++e->chain_seq == 0u) e->chain_seq = 1u; // 0 = "never written"
+            if (full) hipLaunchKernelGGL(k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
+            else hipLaunchKernelGGL(k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
             prof_end(e, s);
         }
         e->wait_before_sort = nullptr;
