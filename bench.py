@@ -293,6 +293,26 @@ def main():
                              want=t.Engine.RECORD_FIELDS)
             also[f"{other}_stream_full_result_records"] = {"value": a.steps * a.batch / dt4, "unit": "decisions/s",
                                                           "note": "result4: one 32-byte RateLimitResult record per request"}
+            # general batches: every request carries its own timestamp (strictly increasing inside
+            # the batch), so the closed form does not apply and k_eval_general runs
+            nows = [torch.arange(a.batch, dtype=torch.int64, device=dev) + (W.T0_NS + 4 * 10**9 + b * 10**6)
+                    for b in range(a.warmup + a.steps)]
+            gout = t.BatchResult()
+            for label, streams in ((f"{other}_stream_per_request_timestamps", ob), (f"{a.workload}_stream_per_request_timestamps", d_batches)):
+                eng3 = t.Engine(a.keys, a.batch, device=local)
+                eng3.use_torch_stream()
+                eng3.register_params_uniform(*W.REF_PARAMS)
+                for i in range(a.warmup):
+                    eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
+                                                want=("allowed",), out=gout, inputs_ready=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(a.warmup, a.warmup + a.steps):
+                    eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
+                                                want=("allowed",), out=gout, inputs_ready=True)
+                torch.cuda.synchronize()
+                also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s"}
+                eng3.close()
             # PCIe-inclusive rate: the same stream handed over as HOST buffers (never `value`)
             hb = make_batches(other, a.keys, a.batch, 8)
             hout = t.BatchResult()
