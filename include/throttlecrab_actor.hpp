@@ -1,0 +1,234 @@
+// throttlecrab_actor.hpp -- the batch-draining actor (C++17, header only) over the host
+// mirror in throttlecrab_gpu.hpp: SURVEY.md section 8(f) row 1.
+//
+// Mirrors, with the reference's names and behaviour:
+//   ThrottleRequest / ThrottleResponse        throttlecrab-server/src/types.rs:32-96
+//       (reset_after / retry_after are whole seconds, truncated: types.rs:87-96)
+//   RateLimiterMessage::Throttle               throttlecrab-server/src/actor.rs:35-45
+//   RateLimiterHandle::throttle                throttlecrab-server/src/actor.rs:52-82
+//   RateLimiterActor::spawn_*                  throttlecrab-server/src/actor.rs:88-168
+//   run_actor / handle_throttle                throttlecrab-server/src/actor.rs:217-255
+//
+// What changes against the reference: its actor takes ONE message per loop turn
+// (`while let Some(msg) = rx.recv().await`, actor.rs:222) and calls rate_limit once; this one
+// takes EVERYTHING that is queued (tokio's `recv_many`), in queue order, and hands it to
+// RateLimiter::rate_limit_batch, whose result is by construction the result of the
+// one-by-one loop.  Requests keep the timestamp their transport stamped (types.rs:46), so a
+// batch carries per-request, possibly non-monotone `now` values, like the reference's queue.
+//
+// Channel semantics follow tokio's bounded mpsc: `throttle` blocks while the buffer is full
+// (back-pressure, actor.rs:71-77), the actor exits when every handle is gone (actor.rs:222,235),
+// a send after shutdown fails with "Rate limiter actor has shut down" (actor.rs:77).
+#pragma once
+
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <future>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <utility>
+#include <variant>
+#include <vector>
+
+#include "throttlecrab_gpu.hpp"
+
+namespace throttlecrab {
+namespace server {
+
+// anyhow::Result<T>: the value or the error's Display string
+template <class T>
+using Result = std::variant<T, std::string>;
+template <class T>
+inline bool is_ok(const Result<T>& r) { return r.index() == 0; }
+
+// types.rs:32-47
+struct ThrottleRequest {
+    std::string key;
+    int64_t max_burst;
+    int64_t count_per_period;
+    int64_t period;
+    int64_t quantity;
+    SystemTime timestamp;
+};
+
+// types.rs:71-83
+struct ThrottleResponse {
+    bool allowed;
+    int64_t limit;
+    int64_t remaining;
+    int64_t reset_after; // seconds
+    int64_t retry_after; // seconds
+    // impl From<(bool, RateLimitResult)> (types.rs:85-96): Duration::as_secs() truncates
+    static ThrottleResponse from(bool allowed, const RateLimitResult& r) {
+        return ThrottleResponse{allowed, r.limit, r.remaining, r.reset_after.count() / 1000000000LL,
+                                r.retry_after.count() / 1000000000LL};
+    }
+};
+
+// actor.rs:35-45
+struct RateLimiterMessage {
+    ThrottleRequest request;
+    std::promise<Result<ThrottleResponse>> response_tx;
+};
+
+namespace detail {
+// bounded multi-producer single-consumer channel + the actor thread that drains it
+struct Channel {
+    std::mutex mu;
+    std::condition_variable not_empty, not_full;
+    std::deque<RateLimiterMessage> queue;
+    size_t buffer_size = 1;
+    size_t senders = 0;
+    bool closed = false;
+    std::thread actor;
+
+    // statistics of the drain loop (how well the queue batches)
+    uint64_t batches = 0, requests = 0, largest_batch = 0;
+};
+} // namespace detail
+
+// actor.rs:52-82.  Copyable; the actor shuts down when the last copy is destroyed.
+class RateLimiterHandle {
+  public:
+    RateLimiterHandle() = default;
+    RateLimiterHandle(const RateLimiterHandle& o) : ch_(o.ch_) { retain(); }
+    RateLimiterHandle(RateLimiterHandle&& o) noexcept : ch_(std::move(o.ch_)) {}
+    RateLimiterHandle& operator=(RateLimiterHandle o) {
+        std::swap(ch_, o.ch_);
+        return *this;
+    }
+    ~RateLimiterHandle() { release(); }
+
+    // send + await (actor.rs:68-82).  Blocks while the buffer is full.
+    Result<ThrottleResponse> throttle(ThrottleRequest request) { return throttle_async(std::move(request)).get(); }
+
+    // the two halves separately: a transport thread can queue many requests before it waits
+    std::future<Result<ThrottleResponse>> throttle_async(ThrottleRequest request) {
+        RateLimiterMessage msg{std::move(request), {}};
+        std::future<Result<ThrottleResponse>> rx = msg.response_tx.get_future();
+        if (!ch_) {
+            msg.response_tx.set_value(std::string("Rate limiter actor has shut down"));
+            return rx;
+        }
+        std::unique_lock<std::mutex> lk(ch_->mu);
+        ch_->not_full.wait(lk, [&] { return ch_->closed || ch_->queue.size() < ch_->buffer_size; });
+        if (ch_->closed) {
+            msg.response_tx.set_value(std::string("Rate limiter actor has shut down"));
+            return rx;
+        }
+        ch_->queue.push_back(std::move(msg));
+        lk.unlock();
+        ch_->not_empty.notify_one();
+        return rx;
+    }
+
+    // (batches drained, requests served, largest batch) so far
+    std::tuple<uint64_t, uint64_t, uint64_t> drain_stats() const {
+        std::lock_guard<std::mutex> lk(ch_->mu);
+        return {ch_->batches, ch_->requests, ch_->largest_batch};
+    }
+
+  private:
+    friend class RateLimiterActor;
+    explicit RateLimiterHandle(std::shared_ptr<detail::Channel> ch) : ch_(std::move(ch)) { retain(); }
+    void retain() {
+        if (!ch_) return;
+        std::lock_guard<std::mutex> lk(ch_->mu);
+        ++ch_->senders;
+    }
+    void release() {
+        if (!ch_) return;
+        bool last;
+        {
+            std::lock_guard<std::mutex> lk(ch_->mu);
+            last = --ch_->senders == 0;
+            if (last) ch_->closed = true; // all senders dropped: rx.recv() returns None (actor.rs:222)
+        }
+        if (last) {
+            ch_->not_empty.notify_all();
+            ch_->not_full.notify_all();
+            if (ch_->actor.joinable()) ch_->actor.join();
+        }
+        ch_.reset();
+    }
+    std::shared_ptr<detail::Channel> ch_;
+};
+
+// actor.rs:88-168 (spawn_periodic / spawn_probabilistic / spawn_adaptive differ only in the
+// store's cleanup cadence, which never changes a decision; there is one GPU store)
+class RateLimiterActor {
+  public:
+    // buffer_size: channel capacity (the server's --buffer-size, config.rs:311, default 100 000)
+    // max_batch:   most messages taken per loop turn (<= the store's max_batch)
+    // linger:      after the first message, wait up to this long for the queue to reach
+    //              min_batch before draining (0 = drain whatever is there: lowest latency)
+    static RateLimiterHandle spawn_gpu(size_t buffer_size, GpuStore store, size_t max_batch = 1 << 16,
+                                       std::chrono::microseconds linger = std::chrono::microseconds(0),
+                                       size_t min_batch = 1) {
+        auto ch = std::make_shared<detail::Channel>();
+        ch->buffer_size = buffer_size ? buffer_size : 1;
+        detail::Channel* raw = ch.get();
+        auto limiter = std::make_shared<RateLimiter>(std::move(store));
+        ch->actor = std::thread([raw, limiter, max_batch, linger, min_batch] { run_actor(*raw, *limiter, max_batch, linger, min_batch); });
+        return RateLimiterHandle(std::move(ch));
+    }
+
+  private:
+    // actor.rs:217-236, draining the queue instead of taking one message
+    static void run_actor(detail::Channel& ch, RateLimiter& limiter, size_t max_batch, std::chrono::microseconds linger,
+                          size_t min_batch) {
+        std::vector<RateLimiterMessage> msgs;
+        while (true) {
+            msgs.clear();
+            {
+                std::unique_lock<std::mutex> lk(ch.mu);
+                ch.not_empty.wait(lk, [&] { return ch.closed || !ch.queue.empty(); });
+                if (ch.queue.empty()) break; // closed and drained
+                if (linger.count() > 0 && ch.queue.size() < min_batch && !ch.closed)
+                    ch.not_empty.wait_for(lk, linger, [&] { return ch.closed || ch.queue.size() >= min_batch; });
+                const size_t take = ch.queue.size() < max_batch ? ch.queue.size() : max_batch;
+                msgs.reserve(take);
+                for (size_t i = 0; i < take; ++i) {
+                    msgs.push_back(std::move(ch.queue.front()));
+                    ch.queue.pop_front();
+                }
+                ch.batches += 1;
+                ch.requests += take;
+                if (take > ch.largest_batch) ch.largest_batch = take;
+            }
+            ch.not_full.notify_all();
+            handle_throttle_batch(limiter, msgs);
+        }
+    }
+
+    // actor.rs:238-255 for a whole batch; send errors are ignored like in the reference
+    // (the receiver may have given up, actor.rs:229-230)
+    static void handle_throttle_batch(RateLimiter& limiter, std::vector<RateLimiterMessage>& msgs) {
+        std::vector<Request> reqs;
+        reqs.reserve(msgs.size());
+        for (const RateLimiterMessage& m : msgs)
+            reqs.push_back(Request{m.request.key, m.request.max_burst, m.request.count_per_period, m.request.period,
+                                   m.request.quantity, m.request.timestamp});
+        std::vector<RateLimitOutcome> out;
+        try {
+            out = limiter.rate_limit_batch(reqs);
+        } catch (const std::exception& ex) {
+            for (RateLimiterMessage& m : msgs) m.response_tx.set_value(std::string("Rate limit check failed: internal error: ") + ex.what());
+            return;
+        }
+        for (size_t i = 0; i < msgs.size(); ++i) {
+            if (throttlecrab::is_ok(out[i])) {
+                const auto& ok = std::get<0>(out[i]);
+                msgs[i].response_tx.set_value(ThrottleResponse::from(ok.first, ok.second));
+            } else {
+                msgs[i].response_tx.set_value("Rate limit check failed: " + std::get<1>(out[i]).to_string());
+            }
+        }
+    }
+};
+
+} // namespace server
+} // namespace throttlecrab

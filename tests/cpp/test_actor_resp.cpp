@@ -1,0 +1,165 @@
+// Batch-draining actor + RESP pipeline against libtcgpu.so on the GPU.  Written after
+// throttlecrab-server/src/actor_tests.rs:9-70 and transport/redis_test.rs (reply arrays).
+// build: g++ -std=c++17 -pthread -Iinclude tests/cpp/test_actor_resp.cpp -Lthrottlecrab_amd -ltcgpu
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <thread>
+
+#include "throttlecrab_actor.hpp"
+#include "throttlecrab_resp.hpp"
+
+using namespace throttlecrab;
+using namespace throttlecrab::server;
+using std::chrono::seconds;
+
+#define CHECK(c)                                                                \
+    do {                                                                        \
+        if (!(c)) {                                                             \
+            std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #c); \
+            std::exit(1);                                                       \
+        }                                                                       \
+    } while (0)
+
+static SystemTime now0() { return SystemTime(std::chrono::nanoseconds(1700000000LL * 1000000000LL)); }
+
+// actor_tests.rs:9-31
+static void test_basic_rate_limiting() {
+    RateLimiterHandle handle = RateLimiterActor::spawn_gpu(100, GpuStore(1000));
+    ThrottleRequest req{"test", 5, 10, 60, 1, now0()};
+    auto resp = handle.throttle(req);
+    CHECK(is_ok(resp));
+    const ThrottleResponse& r = std::get<0>(resp);
+    CHECK(r.allowed && r.limit == 5 && r.remaining == 4);
+}
+
+// actor_tests.rs:34-70: 20 concurrent identical requests, burst 10 -> exactly 10 allowed
+static void test_concurrent_requests() {
+    RateLimiterHandle handle = RateLimiterActor::spawn_gpu(100, GpuStore(1000));
+    ThrottleRequest req{"concurrent_test", 10, 10, 60, 1, now0()};
+    std::atomic<int> allowed{0};
+    std::vector<std::thread> ts;
+    for (int i = 0; i < 20; ++i)
+        ts.emplace_back([&, h = handle] () mutable {
+            auto r = h.throttle(req);
+            CHECK(is_ok(r));
+            if (std::get<0>(r).allowed) allowed++;
+        });
+    for (auto& t : ts) t.join();
+    CHECK(allowed.load() == 10);
+}
+
+// errors reach the caller as "Rate limit check failed: <CellError>" (actor.rs:252)
+static void test_errors_and_truncation() {
+    RateLimiterHandle handle = RateLimiterActor::spawn_gpu(16, GpuStore(1000));
+    auto neg = handle.throttle(ThrottleRequest{"e", 5, 10, 60, -1, now0()});
+    CHECK(!is_ok(neg) && std::get<1>(neg) == "Rate limit check failed: negative quantity: -1");
+    auto inv = handle.throttle(ThrottleRequest{"e", 0, 10, 60, 1, now0()});
+    CHECK(!is_ok(inv) && std::get<1>(inv) == "Rate limit check failed: invalid rate limit parameters");
+    // (10,100,60): reset_after 5.4 s -> 5, q=5: 7.8 s -> 7 (redis_test.rs:117-144)
+    auto a = handle.throttle(ThrottleRequest{"secs", 10, 100, 60, 1, now0()});
+    CHECK(is_ok(a) && std::get<0>(a).reset_after == 5 && std::get<0>(a).retry_after == 0 && std::get<0>(a).remaining == 9);
+}
+
+// many producers, one queue: every request answered, per key exactly `burst` allowed, and the
+// queue really is drained in batches
+static void test_many_producers_are_batched() {
+    const int producers = 16, per = 4000, keys = 50, burst = 30;
+    RateLimiterHandle handle = RateLimiterActor::spawn_gpu(4096, GpuStore(10000, 1 << 16), 1 << 16);
+    std::vector<std::atomic<int>> allowed(keys);
+    for (auto& a : allowed) a = 0;
+    std::atomic<int> answered{0};
+    std::vector<std::thread> ts;
+    for (int p = 0; p < producers; ++p)
+        ts.emplace_back([&, p, h = handle]() mutable {
+            std::vector<std::pair<int, std::future<Result<ThrottleResponse>>>> inflight;
+            for (int i = 0; i < per; ++i) {
+                const int k = (p * 7 + i) % keys;
+                inflight.emplace_back(k, h.throttle_async(ThrottleRequest{"k" + std::to_string(k), burst, 1, 3600, 1, now0()}));
+                if (inflight.size() == 256 || i + 1 == per) {
+                    for (auto& f : inflight) {
+                        auto r = f.second.get();
+                        CHECK(is_ok(r));
+                        if (std::get<0>(r).allowed) allowed[f.first]++;
+                        answered++;
+                    }
+                    inflight.clear();
+                }
+            }
+        });
+    for (auto& t : ts) t.join();
+    CHECK(answered.load() == producers * per);
+    for (int k = 0; k < keys; ++k) CHECK(allowed[k].load() == burst);
+    auto [batches, requests, largest] = handle.drain_stats();
+    CHECK(requests == (uint64_t)producers * per);
+    CHECK(batches < requests / 4 && largest > 16); // the reference's loop would have made `requests` turns
+    std::printf("actor: %llu requests in %llu batches (largest %llu)\n", (unsigned long long)requests,
+                (unsigned long long)batches, (unsigned long long)largest);
+}
+
+static void test_shutdown() {
+    RateLimiterHandle moved;
+    {
+        RateLimiterHandle h = RateLimiterActor::spawn_gpu(8, GpuStore(100));
+        CHECK(is_ok(h.throttle(ThrottleRequest{"x", 1, 1, 1, 1, now0()})));
+        moved = h; // a copy keeps the actor alive
+    }
+    CHECK(is_ok(moved.throttle(ThrottleRequest{"x", 1, 1, 1, 1, now0() + seconds(5)})));
+    RateLimiterHandle none;
+    auto r = none.throttle(ThrottleRequest{"x", 1, 1, 1, 1, now0()});
+    CHECK(!is_ok(r) && std::get<1>(r) == "Rate limiter actor has shut down");
+}
+
+static std::string cmd(std::initializer_list<std::string> args) {
+    std::string s = "*" + std::to_string(args.size()) + "\r\n";
+    for (const std::string& a : args) s += "$" + std::to_string(a.size()) + "\r\n" + a + "\r\n";
+    return s;
+}
+
+// redis_test.rs:117-144, 272-304, 384-395, 492-502, 678-717 through one pipelined buffer
+static void test_resp_pipeline() {
+    GpuStore store(1000, 4096);
+    const int64_t t0 = 1700000000LL * 1000000000LL;
+    std::string wire = cmd({"THROTTLE", "a", "10", "100", "60"}) + cmd({"THROTTLE", "b", "10", "100", "60", "5"}) + cmd({"PING"});
+    for (int i = 0; i < 4; ++i) wire += cmd({"THROTTLE", "c", "3", "100", "60"});
+    wire += cmd({"THROTTLE", "d", "10", "100", "60", "15"}) + cmd({"THROTTLE", "d", "10", "100", "60", "0"}) +
+            cmd({"THROTTLE", "e", "10", "100", "60", "-1"}) + cmd({"THROTTLE", "e", "0", "100", "60"}) +
+            cmd({"THROTTLE", "m", "9223372036854775807", "9223372036854775807", "9223372036854775807"}) +
+            cmd({"THROTTLE", "one", "1", "1", "1"}) + cmd({"NOPE"}) + cmd({"QUIT"}) + cmd({"PING"});
+    resp::Pipeline p;
+    const size_t consumed = p.parse((const uint8_t*)wire.data(), wire.size(), [&] { return t0; });
+    CHECK(p.protocol_error.empty() && p.quit && consumed == wire.size() - cmd({"PING"}).size());
+    std::string out;
+    CHECK(p.run(store.handle(), out) == TC_E_OK);
+    // expected numbers: the CPU oracle on the same sequence (and redis_test.rs:117-144 for a / b)
+    const std::string expect =
+        "*5\r\n:1\r\n:10\r\n:9\r\n:5\r\n:0\r\n"     // [1,10,9,5,0]
+        "*5\r\n:1\r\n:10\r\n:5\r\n:7\r\n:0\r\n"     // q=5: [1,10,5,7,0]
+        "+PONG\r\n"
+        "*5\r\n:1\r\n:3\r\n:2\r\n:1\r\n:0\r\n"      // (3,100,60): remaining 2,1,0 then denied
+        "*5\r\n:1\r\n:3\r\n:1\r\n:1\r\n:0\r\n"
+        "*5\r\n:1\r\n:3\r\n:0\r\n:2\r\n:0\r\n"
+        "*5\r\n:0\r\n:3\r\n:0\r\n:2\r\n:0\r\n"
+        "*5\r\n:0\r\n:10\r\n:10\r\n:4\r\n:3\r\n"    // q=15 on burst 10: denied, remaining 10
+        "*5\r\n:1\r\n:10\r\n:10\r\n:4\r\n:0\r\n"    // q=0: allowed, remaining 10
+        "-ERR Rate limit check failed: negative quantity: -1\r\n"
+        "-ERR Rate limit check failed: invalid rate limit parameters\r\n"
+        "*5\r\n:1\r\n:9223372036854775807\r\n:4294967294\r\n:4294967294\r\n:0\r\n" // redis_test.rs:678-699
+        "*5\r\n:1\r\n:1\r\n:0\r\n:0\r\n:0\r\n"      // (1,1,1): redis_test.rs:702-717
+        "-ERR unknown command 'NOPE'\r\n"
+        "+OK\r\n";
+    if (out != expect) std::fprintf(stderr, "got:\n%s\nwant:\n%s\n", out.c_str(), expect.c_str());
+    CHECK(out == expect);
+}
+
+int main() {
+    test_basic_rate_limiting();
+    test_concurrent_requests();
+    test_errors_and_truncation();
+    test_many_producers_are_batched();
+    test_shutdown();
+    test_resp_pipeline();
+    std::puts("all tests passed");
+    return 0;
+}

@@ -17,3 +17,25 @@ def test_cpp_host_mirror_program():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+@pytest.mark.gpu
+def test_cpp_actor_and_resp_pipeline_program():
+    """Batch-draining actor (actor.rs mirror) and the RESP THROTTLE pipeline on the GPU."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_actor_resp")
+    if not os.path.exists(exe):
+        import __graft_entry__ as g
+        g.build_actor_resp_tests()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
+
+
+def test_cpp_resp_parser_program():
+    """RESP parsing / argument validation / hardening limits: no GPU needed."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_resp_parse")
+    src = os.path.join(ROOT, "tests", "cpp", "test_resp_parse.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
