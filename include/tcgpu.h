@@ -64,6 +64,8 @@ enum {
 
 /* tc_config.flags */
 #define TC_CFG_KEY_MODE 0x1u /* enable the on-device key->slot hash table (string keys) */
+#define TC_CFG_TRACK_DENIED 0x2u /* keep a denial counter per key (4 B/slot) for tc_top_denied: the device-side
+                                  * TopDeniedKeys of throttlecrab-server/src/metrics.rs:24-76 */
 
 typedef struct tc_config {
     uint32_t struct_size;     /* = sizeof(tc_config) */
@@ -226,6 +228,19 @@ int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* key, size_t
 int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* tat, uint64_t* expiry);
 /* string mode: slot currently bound to `key`, or -1. */
 int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, int64_t* slot);
+
+/* Top denied keys (metrics.rs:24-76,296-309: `throttlecrab_top_denied_keys{key,rank}`).  Needs
+ * TC_CFG_TRACK_DENIED.  Counts are exact (the reference's capped HashMap forgets keys when it
+ * overflows) and live as long as the key's slot: a key-mode sweep that unbinds a key resets
+ * its counter.  Returns the k slots with the most denials since creation / tc_denied_reset,
+ * most denied first (ties: lower slot first), k is capped at 10 000 like the reference's
+ * MAX_DENIED_KEYS_LIMIT; slots never denied are not listed.  *n_out <= k entries are written. */
+int tc_top_denied(tc_engine* e, uint32_t k, uint32_t* slots, uint64_t* counts, uint32_t* n_out);
+int tc_denied_reset(tc_engine* e);
+/* string mode: the keys bound to `slots` as an arena (key_off[n+1]); an unbound slot yields an
+ * empty key.  TC_E_INVALID_ARG if key_bytes_cap is too small. */
+int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,
+                 uint32_t* key_off);
 
 #ifdef __cplusplus
 }

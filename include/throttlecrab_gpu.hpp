@@ -71,10 +71,11 @@ struct Request {
 class GpuStore {
   public:
     // AdaptiveStore::with_capacity (adaptive_cleanup.rs:93-106); max_batch bounds rate_limit_batch
-    explicit GpuStore(uint64_t capacity = 1000, uint64_t max_batch = 1 << 16, int device = 0) {
+    // track_denied: keep a denial counter per key for Metrics' top denied keys (metrics.rs:24-76)
+    explicit GpuStore(uint64_t capacity = 1000, uint64_t max_batch = 1 << 16, int device = 0, bool track_denied = false) {
         tc_config cfg{};
         cfg.struct_size = sizeof cfg;
-        cfg.flags = TC_CFG_KEY_MODE;
+        cfg.flags = TC_CFG_KEY_MODE | (track_denied ? TC_CFG_TRACK_DENIED : 0u);
         cfg.device_id = device;
         cfg.capacity = capacity;
         cfg.max_batch = max_batch;

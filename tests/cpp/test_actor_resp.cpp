@@ -8,6 +8,7 @@
 #include <thread>
 
 #include "throttlecrab_actor.hpp"
+#include "throttlecrab_metrics.hpp"
 #include "throttlecrab_resp.hpp"
 
 using namespace throttlecrab;
@@ -153,6 +154,34 @@ static void test_resp_pipeline() {
     CHECK(out == expect);
 }
 
+// tests/metrics_test.rs + denied_keys_test.rs:37-67 with the decisions counted on the device
+static void test_metrics_from_engine() {
+    GpuStore store(1000, 4096, 0, /*track_denied=*/true);
+    const int64_t t0 = 1700000000LL * 1000000000LL;
+    std::string wire;
+    for (int i = 0; i < 12; ++i) wire += cmd({"THROTTLE", "top_key", "2", "10", "60"});      // 2 allowed, 10 denied
+    for (int i = 0; i < 7; ++i) wire += cmd({"THROTTLE", "medium_key", "2", "10", "60"});    // 5 denied
+    for (int i = 0; i < 3; ++i) wire += cmd({"THROTTLE", "low_key", "2", "10", "60"});       // 1 denied
+    wire += cmd({"THROTTLE", "user:789", "2", "10", "60"}) + cmd({"THROTTLE", "bad", "0", "10", "60"});  // allowed; error
+    resp::Pipeline p;
+    p.parse((const uint8_t*)wire.data(), wire.size(), [&] { return t0; });
+    std::string out;
+    CHECK(p.run(store.handle(), out) == TC_E_OK);
+    Metrics m;
+    m.record_transport(Transport::Redis, p.commands());
+    CHECK(m.snapshot_from_engine(store.handle()) == TC_E_OK);
+    const std::string prom = m.export_prometheus();
+    CHECK(prom.find("throttlecrab_requests_total 24\n") != std::string::npos);
+    CHECK(prom.find("throttlecrab_requests_allowed 7\n") != std::string::npos);
+    CHECK(prom.find("throttlecrab_requests_denied 16\n") != std::string::npos);
+    CHECK(prom.find("throttlecrab_requests_errors 1\n") != std::string::npos);
+    CHECK(prom.find("throttlecrab_requests_by_transport{transport=\"redis\"} 24\n") != std::string::npos);
+    CHECK(prom.find("throttlecrab_top_denied_keys{key=\"top_key\",rank=\"1\"} 10\n") != std::string::npos);
+    CHECK(prom.find("throttlecrab_top_denied_keys{key=\"medium_key\",rank=\"2\"} 5\n") != std::string::npos);
+    CHECK(prom.find("throttlecrab_top_denied_keys{key=\"low_key\",rank=\"3\"} 1\n") != std::string::npos);
+    CHECK(prom.find("user:789") == std::string::npos); // never denied
+}
+
 int main() {
     test_basic_rate_limiting();
     test_concurrent_requests();
@@ -160,6 +189,7 @@ int main() {
     test_many_producers_are_batched();
     test_shutdown();
     test_resp_pipeline();
+    test_metrics_from_engine();
     std::puts("all tests passed");
     return 0;
 }

@@ -39,3 +39,13 @@ def test_cpp_resp_parser_program():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+def test_cpp_metrics_text_program():
+    """Prometheus text == throttlecrab-server/src/metrics.rs:236-311: no GPU needed."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_metrics_text")
+    src = os.path.join(ROOT, "tests", "cpp", "test_metrics_text.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout

@@ -1,0 +1,103 @@
+"""Denied-key metrics on the device (throttlecrab-server/src/metrics.rs:24-76 analogue): the
+per-key denial counters the evaluation kernels keep must equal the denials the oracle reports,
+for every evaluation path, and tc_top_denied must return the K most denied keys."""
+import collections
+
+import numpy as np
+import pytest
+
+from tests import kat
+
+pytestmark = pytest.mark.gpu
+T0 = kat.load()["t0_ns"]
+
+
+def _top_expected(counter, k):
+    items = [(key, c) for key, c in counter.items() if c > 0]
+    items.sort(key=lambda kv: (-kv[1], kv[0]))
+    return items[:k]
+
+
+@pytest.mark.parametrize("mode", ["uniform", "general", "unique", "irregular"])
+def test_denied_counts_match_oracle_slot_mode(mode):
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    cap, n = 3000, 60000
+    rng = np.random.default_rng(hash(mode) % 1000)
+    eng, orc = t.Engine(cap, n, track_denied=True), O.DenseOracle(cap)
+    want = collections.Counter()
+    for rnd in range(4):
+        if mode == "unique":
+            slots = rng.permutation(cap)[:2000].astype(np.uint32)
+        else:
+            slots = ((rng.zipf(1.3, n) * 2654435761) % cap).astype(np.uint32)
+        m = slots.size
+        if mode == "general":
+            q, now = rng.integers(0, 3, m), T0 + rnd * 10**9 + rng.integers(0, 10**9, m)
+            burst, count, period = 5, 10, 60
+        elif mode == "irregular":
+            q, now = 1, T0 + rnd * 10**8          # burst 1: entries expire as they are written -> run walked by its head
+            burst, count, period = 1, 1, 1
+            slots = (slots % 50).astype(np.uint32)
+            m = slots.size
+        else:
+            q, now = 1, T0 + rnd * 10**9
+            burst, count, period = 3, 10, 60
+        if mode == "unique":
+            q, now = rng.integers(1, 6, m), T0 + rnd * 10**8
+            burst = 2
+        ref = orc.batch_slots(slots, burst, count, period, q, now)
+        res = eng.rate_limit_batch_slots(slots, max_burst=burst, count_per_period=count, period=period, quantity=q,
+                                         now_ns=now, unique=(mode == "unique"), want=("allowed", "status"))
+        assert np.array_equal(res.allowed, ref.allowed)
+        denied = (ref.status == 0) & (ref.allowed == 0)
+        for s in slots[denied].tolist():
+            want[s] += 1
+    for k in (1, 10, 100, 10000):
+        got = eng.top_denied(k)
+        exp = _top_expected(want, k)
+        assert got == exp, (mode, k, got[:5], exp[:5])
+    assert eng.counters()["denied"] == sum(want.values())
+    eng.denied_reset()
+    assert eng.top_denied(10) == []
+    eng.close()
+
+
+def test_top_denied_keys_string_mode_and_sweep_reset():
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    keys = [b"user:%d" % i for i in range(2000)] + [b"very-long-key/" + b"z" * 70 + b"/%d" % i for i in range(20)]
+    eng = t.Engine(8192, 50000, key_mode=True, track_denied=True)
+    orc = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
+    want = collections.Counter()
+    for rnd in range(3):
+        idx = np.minimum(rng.zipf(1.2, 40000) - 1, len(keys) - 1)
+        idx[:200] = len(keys) - 1 - rng.integers(0, 20, 200)
+        kb, ko = O.pack_keys([keys[i] for i in idx])
+        now = T0 + rnd * 10**8
+        ref = orc.batch_keys(kb, ko, 4, 10, 60, 1, now)
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=4, count_per_period=10, period=60, quantity=1, now_ns=now,
+                                        want=("allowed", "status"))
+        assert np.array_equal(res.allowed, ref.allowed)
+        for i in idx[(ref.allowed == 0) & (ref.status == 0)].tolist():
+            want[keys[i]] += 1
+    got = eng.top_denied(25)
+    exp_counts = sorted(want.values(), reverse=True)[:25]
+    assert [c for _, c in got] == exp_counts
+    for key, c in got:
+        assert want[key] == c, key           # the right keys (ties may be ordered differently: slots, not key text)
+    assert any(len(k) > 48 for k, _ in eng.top_denied(2000))  # keys beyond the inline 48 bytes come back intact
+    # a sweep that unbinds every key resets their counters (the slots will serve other keys)
+    eng.sweep_expired(T0 + 10**12)
+    assert eng.top_denied(10) == []
+    eng.close()
+
+
+def test_top_denied_needs_the_flag():
+    import throttlecrab_amd as t
+    eng = t.Engine(16, 16)
+    with pytest.raises(t.TcError) as ei:
+        eng.top_denied(5)
+    assert ei.value.code == -7
+    eng.close()

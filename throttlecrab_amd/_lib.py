@@ -16,6 +16,7 @@ TC_OK, TC_NEGATIVE_QUANTITY, TC_INVALID_RATE_LIMIT, TC_INTERNAL = 0, 1, 2, 3
 (TC_E_OK, TC_E_INVALID_ARG, TC_E_HIP, TC_E_NOMEM, TC_E_BATCH_TOO_LARGE, TC_E_TABLE_FULL, TC_E_NO_DEVICE,
  TC_E_UNSUPPORTED) = (0, -1, -2, -3, -4, -5, -6, -7)
 TC_CFG_KEY_MODE = 0x1
+TC_CFG_TRACK_DENIED = 0x2
 TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY = 0x1, 0x2, 0x4, 0x8
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
 TC_CNT_COUNT = 8
@@ -74,6 +75,9 @@ SYMBOLS = {
                                                       C.c_int64, C.POINTER(C.c_int)]),
     "tc_read_state": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),
     "tc_lookup_slot": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "tc_top_denied": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "tc_denied_reset": (C.c_int, [C.c_void_p]),
+    "tc_slot_keys": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

@@ -43,6 +43,7 @@ constexpr int PIPE_DEPTH_DEFAULT = 3; // grouping scratch sets: batches whose so
 constexpr uint32_t F_REGISTERED = 1u;    // Params.flags: per-slot registered rate plan
 constexpr uint32_t F_UNIFORM_CLASS = 2u; // every slot carries plan `uniform_class`: skip the rate_id[] read
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
+constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
 
 // ---------------------------------------------------------------------------
 // kernel argument block
@@ -70,6 +71,7 @@ struct Params {
     uint32_t uniform_class;
     uint64_t capacity;
     unsigned long long* counters;
+    uint32_t* denied; // per-slot denial counters (TC_CFG_TRACK_DENIED) or nullptr
 };
 
 struct Req {
@@ -154,6 +156,25 @@ __device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c,
     }
 }
 
+// Denial counters per key (the device-side analogue of Metrics::record_request_with_key's
+// TopDeniedKeys update, throttlecrab-server/src/metrics.rs:24-50,162-173).  In the sorted kernels the
+// lanes of one key are contiguous, so the first lane of each run inside the wave adds the run's
+// denials with ONE atomic (a hot key would otherwise serialise ~12 ns per denied request).
+__device__ __forceinline__ void wave_denied_add(const Params& p, uint32_t slot, bool denied_here) {
+    if (!p.denied) return; // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const uint32_t prev = __shfl_up(slot, 1, 64);
+    const bool run_head = lane == 0 || prev != slot;
+    const unsigned long long heads = __ballot(run_head), dm = __ballot(denied_here);
+    if (run_head && slot < p.capacity) {
+        const unsigned long long later = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        const int end = later ? lane + __builtin_ctzll(later) : 63; // last lane of my run
+        const unsigned long long run = (end == 63 ? ~0ull : ((2ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+        const uint32_t cnt = (uint32_t)__popcll(dm & run);
+        if (cnt) atomicAdd(&p.denied[slot], cnt);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // K1: one lane per request, slots unique within the batch
 // ---------------------------------------------------------------------------
@@ -177,6 +198,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
             if (d.allowed) p.cells[slot] = c;
             na = d.allowed;
             nd = !d.allowed;
+            if (p.denied && nd) atomicAdd(&p.denied[slot], 1u); // unique slots: no contention
         } else {
             ne = 1;
         }
@@ -254,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const bool seg_in_wave = ((heads & upto) != 0ull) && ((lasts >> lane) != 0ull);
 
-    bool writer = false;
+    bool writer = false, walked = false;
     Cell wcell;
     wcell.tat = 0;
     wcell.expiry = 0;
@@ -297,6 +319,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                             nd += !dj.allowed;
                             write_out(p, (uint32_t)nx, rq, dj);
                         }
+                        if (p.denied && nd) atomicAdd(&p.denied[slot], nd); // the whole run's denials sit in this lane
+                        walked = true;
                         writer = true;
                         wcell = c;
                     }
@@ -330,6 +354,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
             pend[at] = pe;
         }
     }
+    wave_denied_add(p, slot, nd != 0 && !walked);
     block_count3(na, nd, ne, p.counters);
 }
 
@@ -547,6 +572,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             __hip_atomic_store(&o->fin, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
+    wave_denied_add(p, slot, nd != 0);
     block_count3(na, nd, ne, p.counters);
 }
 
@@ -647,7 +673,8 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint6
 // the stack top costs ~12 ns and serialises: one per 256 slots was most of the kernel).
 constexpr int SWEEP_BUF = 8192;
 __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
-                                                      unsigned long long* counters, unsigned long long* removed_out) {
+                                                      unsigned long long* counters, unsigned long long* removed_out,
+                                                      uint32_t* __restrict__ denied) {
     __shared__ uint32_t s_buf[SWEEP_BUF];
     __shared__ int s_base;
     uint32_t removed = 0, live = 0, fill = 0; // fill is uniform over the block
@@ -684,6 +711,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, 
             const uint32_t pos = t.rec[i].pos;
             t.ktab[pos] = (t.ktab[pos] & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
             t.bound[i] = 0;
+            if (denied) denied[i] = 0; // the slot will serve another key
             s_buf[fill + rank] = (uint32_t)i;
         }
         fill += total;
@@ -714,6 +742,56 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, 
         }
         if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
     }
+}
+
+// ---------------------------------------------------------------------------
+// top denied keys (metrics.rs:24-76 keeps a capped HashMap on the host; here the counts are
+// exact, one u32 per slot, and the top K are selected on demand: radix select of the K-th
+// largest count, 8 bits per pass, then one compaction pass)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_denied_hist(const uint32_t* __restrict__ denied, uint64_t capacity,
+                                                       uint32_t prefix, uint32_t prefix_mask, uint32_t shift,
+                                                       uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0; // BLOCK == 256
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t c = denied[i];
+        if (c != 0u && (c & prefix_mask) == prefix) atomicAdd(&s_h[(c >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+// entries with count > T go to list 0, entries with count == T to list 1 (each capped at `cap_out`)
+__global__ __launch_bounds__(BLOCK) void k_denied_collect(const uint32_t* __restrict__ denied, uint64_t capacity, uint32_t T,
+                                                          uint32_t* __restrict__ n_out /*[2]*/, uint32_t* __restrict__ lists,
+                                                          uint32_t cap_out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t c = denied[i];
+        if (c == 0u || c < T) continue;
+        const int which = c > T ? 0 : 1;
+        const uint32_t at = atomicAdd(&n_out[which], 1u);
+        if (at < cap_out) {
+            uint32_t* l = lists + (size_t)which * 2 * cap_out;
+            l[2 * at] = (uint32_t)i;
+            l[2 * at + 1] = c;
+        }
+    }
+}
+
+// key mode: copy the KeyRec of each listed slot into a dense array
+__global__ __launch_bounds__(BLOCK) void k_gather_keyrecs(kt::Table t, const uint32_t* __restrict__ slots, uint32_t n,
+                                                          kt::KeyRec* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = slots[i];
+    kt::KeyRec r;
+    r.hash = 0;
+    r.len = kt::NO_SLOT;
+    r.pos = 0;
+    if (s < t.capacity && t.bound[s]) r = t.rec[s];
+    out[i] = r;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_fill_rate_id(uint16_t* __restrict__ rate_id, uint64_t capacity, uint16_t id) {
@@ -800,6 +878,8 @@ struct tc_engine {
     std::vector<RateClass> host_classes;     // host mirror, index = class id
     std::unordered_map<std::string, uint16_t> class_of; // (burst,count,period) bytes -> id
     uint16_t uniform_id = 0;                 // != 0: every slot carries this plan
+    uint32_t* denied = nullptr;              // TC_CFG_TRACK_DENIED: denials per slot
+    uint32_t* topk_ws = nullptr;             // tc_top_denied scratch: 256 histogram words | 2 counters | lists
     unsigned long long* counters = nullptr; // TC_CNT_COUNT canonical + 1 scratch + NSHARD*SHARD_WORDS shards
 
     // grouping scratch: a ring of `depth` sets.  A batch flagged TC_B_INPUTS_READY is
@@ -922,6 +1002,11 @@ static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipMalloc(&e->rate_id, cap * sizeof(uint16_t)));
     TC_HIP(e, hipMalloc(&e->classes, (size_t)MAX_CLASSES * sizeof(RateClass)));
     e->host_classes.assign(1, RateClass{0, 0, 0, 0});
+    if (e->cfg_flags & TC_CFG_TRACK_DENIED) {
+        TC_HIP(e, hipMalloc(&e->denied, cap * sizeof(uint32_t)));
+        TC_HIP(e, hipMemsetAsync(e->denied, 0, cap * sizeof(uint32_t), (hipStream_t)0));
+        TC_HIP(e, hipMalloc(&e->topk_ws, (256 + 2 + 4 * (size_t)TOPK_MAX) * sizeof(uint32_t)));
+    }
     const size_t cnt_words = (TC_CNT_COUNT + 1) + (size_t)NSHARD * SHARD_WORDS;
     TC_HIP(e, hipMalloc(&e->counters, cnt_words * sizeof(unsigned long long)));
     TC_HIP(e, hipMemsetAsync(e->cells, 0, cap * sizeof(Cell), (hipStream_t)0));
@@ -1142,7 +1227,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->counters, e->pend, e->chain, e->pend_count,
+    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->counters, e->pend, e->chain, e->pend_count,
                     e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4};
@@ -1340,6 +1425,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     p.rate_id = e->rate_id;
     p.classes = e->classes;
     p.uniform_class = e->uniform_id;
+    p.denied = e->denied;
     p.capacity = e->capacity;
     p.counters = e->counters;
     if (b.flags & TC_B_REGISTERED_PARAMS) {
@@ -1579,7 +1665,7 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), cur_stream(e)));
     if (e->key_mode)
         hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 1024)), dim3(BLOCK), 0, cur_stream(e),
-                           e->cells, e->kt, now_ns, e->counters, scratch);
+                           e->cells, e->kt, now_ns, e->counters, scratch, e->denied);
     else
         hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
                            e->cells, e->capacity, now_ns, e->counters, scratch);
@@ -1759,5 +1845,128 @@ extern "C" int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, 
     int rc = store_slot_of(e, key, key_len, false, &s);
     if (rc != TC_E_OK) return rc;
     *slot = s == kt::NO_SLOT ? -1 : (int64_t)s;
+    return TC_E_OK;
+}
+
+// ---- denied-key metrics ---------------------------------------------------------
+extern "C" int tc_top_denied(tc_engine* e, uint32_t k, uint32_t* slots, uint64_t* counts, uint32_t* n_out) {
+    if (!e || !slots || !counts || !n_out) return TC_E_INVALID_ARG;
+    if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
+    *n_out = 0;
+    if (k == 0) return TC_E_OK;
+    if (k > TOPK_MAX) k = TOPK_MAX; // MAX_DENIED_KEYS_LIMIT
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
+    uint32_t* hist = e->topk_ws;
+    uint32_t* n2 = e->topk_ws + 256;
+    uint32_t* lists = e->topk_ws + 258;
+    const dim3 grid(std::min<uint64_t>(nblocks(e->capacity), 2048)), block(BLOCK);
+    // radix select: T = the k-th largest non-zero count (1 if fewer than k keys were ever denied)
+    uint32_t prefix = 0, mask = 0, want = k, T = 1;
+    bool all = false;
+    for (int shift = 24; shift >= 0 && !all; shift -= 8) {
+        uint32_t h[256];
+        TC_HIP(e, hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_denied_hist, grid, block, 0, s, e->denied, e->capacity, prefix, mask, (uint32_t)shift, hist);
+        TC_HIP(e, hipMemcpyAsync(h, hist, sizeof h, hipMemcpyDeviceToHost, s));
+        TC_HIP(e, hipStreamSynchronize(s));
+        if (shift == 24) {
+            uint64_t total = 0;
+            for (uint32_t v : h) total += v;
+            if (total <= k) { // everything that was ever denied fits
+                all = true;
+                break;
+            }
+        }
+        int d = 255;
+        for (; d > 0; --d) {
+            if (h[d] >= want) break;
+            want -= h[d];
+        }
+        prefix |= (uint32_t)d << shift;
+        mask |= 255u << shift;
+        T = prefix;
+    }
+    if (all) T = 1;
+    TC_HIP(e, hipMemsetAsync(n2, 0, 2 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_denied_collect, grid, block, 0, s, e->denied, e->capacity, T, n2, lists, TOPK_MAX);
+    TC_HIP(e, hipGetLastError());
+    uint32_t hn[2];
+    TC_HIP(e, hipMemcpyAsync(hn, n2, sizeof hn, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    const uint32_t n_gt = std::min(hn[0], TOPK_MAX), n_eq = std::min(hn[1], TOPK_MAX);
+    std::vector<uint32_t> gt(2 * (size_t)n_gt), eq(2 * (size_t)n_eq);
+    if (n_gt) TC_HIP(e, hipMemcpyAsync(gt.data(), lists, gt.size() * 4, hipMemcpyDeviceToHost, s));
+    if (n_eq) TC_HIP(e, hipMemcpyAsync(eq.data(), lists + 2 * (size_t)TOPK_MAX, eq.size() * 4, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    std::vector<std::pair<uint32_t, uint32_t>> ent; // (count, slot)
+    for (uint32_t i = 0; i < n_gt; ++i) ent.emplace_back(gt[2 * i + 1], gt[2 * i]);
+    std::vector<std::pair<uint32_t, uint32_t>> ties;
+    for (uint32_t i = 0; i < n_eq; ++i) ties.emplace_back(eq[2 * i + 1], eq[2 * i]);
+    std::sort(ties.begin(), ties.end(), [](auto& a, auto& b) { return a.second < b.second; }); // deterministic choice among ties
+    for (auto& t2 : ties) {
+        if (ent.size() >= k) break;
+        ent.push_back(t2);
+    }
+    std::sort(ent.begin(), ent.end(), [](auto& a, auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    if (ent.size() > k) ent.resize(k);
+    for (size_t i = 0; i < ent.size(); ++i) {
+        slots[i] = ent[i].second;
+        counts[i] = ent[i].first;
+    }
+    *n_out = (uint32_t)ent.size();
+    return TC_E_OK;
+}
+
+extern "C" int tc_denied_reset(tc_engine* e) {
+    if (!e) return TC_E_INVALID_ARG;
+    if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_HIP(e, hipMemsetAsync(e->denied, 0, e->capacity * sizeof(uint32_t), cur_stream(e)));
+    return TC_E_OK;
+}
+
+extern "C" int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,
+                            uint32_t* key_off) {
+    if (!e || (n && (!slots || !key_off)) || (key_bytes_cap && !key_bytes)) return TC_E_INVALID_ARG;
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    if (n == 0) return TC_E_OK;
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
+    if (e->k_busy) {
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        e->k_busy = false;
+    }
+    uint32_t* d_slots = nullptr;
+    kt::KeyRec* d_rec = nullptr;
+    TC_HIP(e, hipMalloc(&d_slots, n * sizeof(uint32_t)));
+    TC_HIP(e, hipMalloc(&d_rec, n * sizeof(kt::KeyRec)));
+    TC_HIP(e, hipMemcpyAsync(d_slots, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_keyrecs, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->kt, d_slots, n, d_rec);
+    std::vector<kt::KeyRec> h(n);
+    TC_HIP(e, hipMemcpyAsync(h.data(), d_rec, n * sizeof(kt::KeyRec), hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    (void)hipFree(d_slots);
+    (void)hipFree(d_rec);
+    size_t at = 0;
+    int rc = TC_E_OK;
+    key_off[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t len = h[i].len == kt::NO_SLOT ? 0u : h[i].len; // unbound slot: empty key
+        if (at + len <= key_bytes_cap) {
+            if (len <= kt::INLINE_KEY) {
+                memcpy(key_bytes + at, h[i].bytes, len);
+            } else {
+                uint64_t off;
+                memcpy(&off, h[i].bytes, 8);
+                TC_HIP(e, hipMemcpy(key_bytes + at, e->kt.overflow + off, len, hipMemcpyDeviceToHost));
+            }
+            at += len;
+        } else {
+            rc = TC_E_INVALID_ARG; // buffer too small: offsets still describe what fits
+        }
+        key_off[i + 1] = (uint32_t)at;
+    }
+    if (rc != TC_E_OK) return fail(e, rc, "tc_slot_keys: key_bytes_cap too small");
     return TC_E_OK;
 }

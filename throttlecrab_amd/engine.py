@@ -45,11 +45,11 @@ class Engine:
     RECORD_FIELDS = ("allowed", "status", "result4")
 
     def __init__(self, capacity: int, max_batch: int = 1 << 20, device: int = 0, key_mode: bool = False,
-                 key_arena_bytes: int = 0):
+                 key_arena_bytes: int = 0, track_denied: bool = False):
         self._lib = L.load()
         cfg = L.tc_config()
         cfg.struct_size = C.sizeof(L.tc_config)
-        cfg.flags = L.TC_CFG_KEY_MODE if key_mode else 0
+        cfg.flags = (L.TC_CFG_KEY_MODE if key_mode else 0) | (L.TC_CFG_TRACK_DENIED if track_denied else 0)
         cfg.device_id = device
         cfg.capacity = capacity
         cfg.max_batch = max_batch
@@ -263,6 +263,30 @@ class Engine:
         exp = np.zeros(n, np.uint64)
         self._check(self._lib.tc_read_state(self._h, first, n, tat.ctypes.data, exp.ctypes.data))
         return tat, exp
+
+    def top_denied(self, k: int = 100):
+        """Top denied keys (metrics.rs:24-76): [(slot, count)] most denied first; in key mode
+        [(key bytes, count)]."""
+        slots = np.zeros(max(k, 1), np.uint32)
+        counts = np.zeros(max(k, 1), np.uint64)
+        n = C.c_uint32(0)
+        self._check(self._lib.tc_top_denied(self._h, k, slots.ctypes.data, counts.ctypes.data, C.byref(n)))
+        slots, counts = slots[: n.value], counts[: n.value]
+        if not self.key_mode:
+            return [(int(s), int(c)) for s, c in zip(slots, counts)]
+        off = np.zeros(n.value + 1, np.uint32)
+        buf = np.zeros(max(1, 256 * n.value), np.uint8)
+        while True:
+            rc = self._lib.tc_slot_keys(self._h, n.value, slots.ctypes.data, buf.ctypes.data, buf.size, off.ctypes.data)
+            if rc == L.TC_E_INVALID_ARG and buf.size < (1 << 30):
+                buf = np.zeros(buf.size * 8, np.uint8)
+                continue
+            self._check(rc)
+            break
+        return [(bytes(buf[off[i]:off[i + 1]]), int(counts[i])) for i in range(n.value)]
+
+    def denied_reset(self):
+        self._check(self._lib.tc_denied_reset(self._h))
 
     def lookup_slot(self, key: bytes) -> int:
         s = C.c_int64(-1)
