@@ -242,6 +242,13 @@ int tc_denied_reset(tc_engine* e);
 int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,
                  uint32_t* key_off);
 
+/* Checkpoint / restore of everything resident (state cells, rate plans, denial counters, in
+ * string mode the key table, plus the counter block).  The reference keeps its state in memory
+ * only and loses it on restart; here a snapshot is a few device-to-host copies.  Load needs an
+ * engine created with the same capacity and flags.  Both calls drain the engine first. */
+int tc_snapshot_save(tc_engine* e, const char* path);
+int tc_snapshot_load(tc_engine* e, const char* path);
+
 #ifdef __cplusplus
 }
 #endif

@@ -285,6 +285,12 @@ class Engine:
             break
         return [(bytes(buf[off[i]:off[i + 1]]), int(counts[i])) for i in range(n.value)]
 
+    def snapshot_save(self, path: str):
+        self._check(self._lib.tc_snapshot_save(self._h, path.encode()))
+
+    def snapshot_load(self, path: str):
+        self._check(self._lib.tc_snapshot_load(self._h, path.encode()))
+
     def denied_reset(self):
         self._check(self._lib.tc_denied_reset(self._h))
 
