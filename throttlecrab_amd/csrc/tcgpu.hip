@@ -252,10 +252,15 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     const uint64_t me = valid ? sorted[k] : ~0ull;
     const uint32_t slot = (uint32_t)(me >> 32);
     const uint32_t idx = (uint32_t)me;
-    const bool head = valid && (k == 0 || (uint32_t)(sorted[k - 1] >> 32) != slot);
+    const int lane = threadIdx.x & 63;
+    // neighbours' slots by wave shuffles; only the wave's edge lanes look at memory
+    uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
+    if (lane == 0 && valid && k > 0) prev_slot = (uint32_t)(sorted[k - 1] >> 32);
+    if (lane == 63 && k + 1 < n) next_slot = (uint32_t)(sorted[k + 1] >> 32);
+    const bool head = valid && (k == 0 || prev_slot != slot);
     uint32_t na = 0, nd = 0, ne = 0;
 
-    const bool is_last = valid && ((k + 1 == n) || ((uint32_t)(sorted[k + 1] >> 32) != slot));
+    const bool is_last = valid && ((k + 1 == n) || next_slot != slot);
     __shared__ uint32_t s_start;
     const uint32_t block_start = blockIdx.x * BLOCK;
     if (threadIdx.x == 0 && valid && !head) {
@@ -271,7 +276,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     const uint32_t hp = block_scan_max(head ? k + 1 : 0u); // contains a __syncthreads()
     const uint32_t seg_start = hp ? hp - 1 : s_start;
     // does my whole segment live inside this wave?
-    const int lane = threadIdx.x & 63;
     const unsigned long long heads = __ballot(head), lasts = __ballot(is_last);
     const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
     const bool seg_in_wave = ((heads & upto) != 0ull) && ((lasts >> lane) != 0ull);
@@ -300,6 +304,13 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                 // request 0 denied => state untouched => every request of the run equals request 0
                 nd = 1;
                 write_out(p, idx, rq, d0);
+            } else if (head && is_last) {
+                // a key requested once in this batch (95 % of a uniform batch): no closed form,
+                // and in particular none of its 64-bit division
+                na = 1;
+                write_out(p, idx, rq, d0);
+                writer = true;
+                wcell = c;
             } else {
                 const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
                 if (r == 0) {
@@ -1019,9 +1030,10 @@ static int engine_alloc(tc_engine* e) {
     int prio_lo = 0, prio_hi = 0;
     TC_HIP(e, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     const char* pe = getenv("TCGPU_AUX_PRIORITY");
-    const bool aux_high = !pe || atoi(pe) != 0;
+    const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
     if (const char* d = getenv("TCGPU_AUX_STREAMS")) e->n_aux = (uint32_t)std::min(std::max(atoi(d), 1), AUX_MAX);
-    // grouping kernels are small and latency-bound: let them in ahead of the wide evaluation kernel
+    // the evaluation kernel on the main stream is the critical path of the pipeline: grouping runs at
+    // the lowest priority and fills what the evaluation leaves free (TCGPU_AUX_PRIORITY=1 flips it)
     for (uint32_t ai = 0; ai < e->n_aux; ++ai)
         TC_HIP(e, hipStreamCreateWithPriority(&e->aux[ai], hipStreamNonBlocking, aux_high ? prio_hi : prio_lo));
     for (uint32_t si = 0; si < e->depth; ++si) {

@@ -88,8 +88,9 @@ float run(const uint64_t* d_sorted, uint32_t n, Rec* table, uint8_t* out, int it
     return 1e3f * ms / iters;
 }
 
-int main() {
-    const uint32_t n = 1 << 20, cap = 10000000;
+int main(int argc, char** argv) {
+    const uint32_t n = 1 << 20, cap = argc > 1 ? (uint32_t)atol(argv[1]) : 10000000;
+    printf("== keys %u\n", cap);
     std::mt19937_64 rng(1);
     std::vector<uint64_t> h((size_t)n * NB);
     for (int b = 0; b < NB; ++b)
