@@ -428,3 +428,47 @@ def test_general_batches_hot_keys_span_many_waves(burst, count, period, label):
         assert_same(res, ref, f"{label} round {rnd}")
         assert_state_same(eng, orc, slots)
     eng.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 257, 2049])
+def test_tiny_and_odd_batch_sizes_all_paths(n):
+    """Wave / block / sort-tile edges: every evaluation path on batches around 64, 256 and 2048."""
+    import torch
+    cap = 300
+    rng = np.random.default_rng(n)
+    eng, orc = _engine(cap, 4096), _oracle(cap)
+    eng.use_torch_stream()
+    for rnd in range(3):
+        slots = rng.integers(0, 40, n).astype(np.uint32)
+        now = T0 + rnd * 10**9
+        ref = orc.batch_slots(slots, 3, 10, 60, 1, now)                                   # uniform, host pointers
+        assert_same(eng.rate_limit_batch_slots(slots, max_burst=3, count_per_period=10, period=60, quantity=1, now_ns=now), ref, "uniform")
+        nows = now + 10**8 + rng.integers(0, 10**8, n)
+        q = rng.integers(0, 3, n)
+        ref = orc.batch_slots(slots, 3, 10, 60, q, nows)                                  # general, piped device pointers
+        ds = torch.from_numpy(slots.astype(np.int32)).cuda()
+        dq, dn = torch.from_numpy(q.astype(np.int64)).cuda(), torch.from_numpy(nows.astype(np.int64)).cuda()
+        torch.cuda.synchronize()
+        res = eng.rate_limit_batch_slots(ds, max_burst=3, count_per_period=10, period=60, quantity=dq, now_ns=dn, inputs_ready=True)
+        torch.cuda.synchronize()
+        assert_same(res, ref, "general piped")
+    assert_state_same(eng, orc, np.arange(cap))
+    eng.close()
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["uniform", "per_request_now"])
+def test_whole_batch_on_one_key(general):
+    """500 000 requests for ONE key in one batch (16 k waves deep): closed form resp. the
+    speculative hand-over chain; then the same key again in the next batch."""
+    cap, n = 16, 500_000
+    eng, orc = _engine(cap, n), _oracle(cap)
+    slots = np.full(n, 5, np.uint32)
+    for rnd in range(3):
+        base = T0 + rnd * 2 * 10**9
+        now = base + np.arange(n, dtype=np.int64) * 1000 if general else base      # 1 us apart: 0.5 s per batch
+        ref = orc.batch_slots(slots, 100, 1000, 60, 1, now)
+        res = eng.rate_limit_batch_slots(slots, max_burst=100, count_per_period=1000, period=60, quantity=1, now_ns=now)
+        assert_same(res, ref, f"round {rnd}")
+        assert 0 < int(ref.allowed.sum()) < n
+    assert_state_same(eng, orc, slots[:1])
+    eng.close()
