@@ -164,16 +164,17 @@ def keys_bench(a, dev):
     for s in range(pre):
         one(s)
     torch.cuda.synchronize()
+    swept0 = eng.counters()["swept"]
     t0 = time.perf_counter()
-    swept = 0
     for s in range(pre, pre + steps):
         one(s)
         if (s - pre) % 4 == 3:
-            swept += eng.sweep_expired(W.T0_NS + s * 10**9)
+            eng.sweep_expired_async(W.T0_NS + s * 10**9)  # enqueued behind the batch, no host wait
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     c = eng.counters()
     eng.close()
+    swept = c["swept"] - swept0
     return {"value": steps * B / dt, "unit": "decisions/s", "steps": steps, "keys_inserted": c["keys_inserted"],
             "swept": swept, "allowed_fraction": c["allowed"] / max(1, c["total"]),
             "workload": f"string keys key_<id>, {B} requests/batch, 20% new keys, sweep every 4 batches"}

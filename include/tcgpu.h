@@ -186,7 +186,8 @@ int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, int64_t max_
                   tc_result* out);
 
 /* AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203): drop every entry with
- * expiry <= now.  Decision-neutral. */
+ * expiry <= now.  Decision-neutral.  removed == NULL: the sweep is only enqueued on the
+ * engine's stream (no host wait; the number removed is added to TC_CNT_SWEPT). */
 int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed);
 
 /* Copy the counter block to host (refreshes it first). */

@@ -293,8 +293,24 @@ __global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uin
     }
 }
 
-// rebuild: clear ktab (memset by the host) and re-enter every bound slot
-__global__ __launch_bounds__(THREADS) void k_reinsert(Table t) {
+// Rebuild (tombstones lengthen probe chains and are never reused): decided ON THE DEVICE so that
+// a sweep never waits for the host -- k_rebuild_decide latches "tombstones > 1/4 of the table" into
+// a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (three near-empty
+// launches, ~10 us, when no rebuild is due).
+__global__ void k_rebuild_decide(Table t, uint32_t* __restrict__ flag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *flag = (uint64_t)*t.tombs > (t.nb_mask + 1) / 4 ? 1u : 0u;
+}
+
+__global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32_t* __restrict__ flag) {
+    if (*flag == 0u) return;
+    for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i <= t.nb_mask; i += (uint64_t)gridDim.x * THREADS)
+        t.ktab[i] = 0ull;
+}
+
+// re-enter every bound slot into the cleared table
+__global__ __launch_bounds__(THREADS) void k_reinsert(Table t, const uint32_t* __restrict__ flag) {
+    if (*flag == 0u) return;
+    if (blockIdx.x == 0 && threadIdx.x == 0) *t.tombs = 0u;
     for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
         if (!t.bound[s]) continue;
         const uint64_t h = t.rec[s].hash;

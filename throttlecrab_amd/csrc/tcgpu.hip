@@ -1178,12 +1178,15 @@ static int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, boo
     return TC_E_OK;
 }
 
-static int rebuild_key_table(tc_engine* e) {
+// rebuild the key table if tombstones fill more than 1/4 of it (checked on the device)
+static int rebuild_key_table_if_due(tc_engine* e) {
     kt::Table& t = e->kt;
-    TC_HIP(e, hipMemsetAsync(t.ktab, 0, (t.nb_mask + 1) * 8, cur_stream(e)));
-    TC_HIP(e, hipMemsetAsync(t.tombs, 0, sizeof(uint32_t), cur_stream(e)));
-    hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), dim3(kt::THREADS), 0,
-                       cur_stream(e), t);
+    hipStream_t s = cur_stream(e);
+    uint32_t* flag = t.error_flag + 1; // spare word of the table's misc block
+    const dim3 grid(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block(kt::THREADS);
+    hipLaunchKernelGGL(kt::k_rebuild_decide, dim3(1), dim3(64), 0, s, t, flag);
+    hipLaunchKernelGGL(kt::k_rebuild_clear, grid, block, 0, s, t, flag);
+    hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, flag);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
@@ -1668,32 +1671,34 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
 extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed) {
     if (!e) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
     unsigned long long* scratch = e->counters + TC_CNT_COUNT;
     if (e->k_busy) { // key stages still in flight on the key stream come first
-        TC_HIP(e, hipStreamWaitEvent(cur_stream(e), e->k_done, 0));
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
         e->k_busy = false;
     }
-    TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), cur_stream(e)));
-    TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), cur_stream(e)));
+    TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s));
+    TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), s));
     if (e->key_mode)
-        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 1024)), dim3(BLOCK), 0, cur_stream(e),
+        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 1024)), dim3(BLOCK), 0, s,
                            e->cells, e->kt, now_ns, e->counters, scratch, e->denied);
     else
-        hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, cur_stream(e),
+        hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
                            e->cells, e->capacity, now_ns, e->counters, scratch);
     TC_HIP(e, hipGetLastError());
-    unsigned long long r = 0;
-    uint32_t tombs = 0;
-    TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, cur_stream(e)));
-    if (e->key_mode) TC_HIP(e, hipMemcpyAsync(&tombs, e->kt.tombs, sizeof tombs, hipMemcpyDeviceToHost, cur_stream(e)));
-    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
-    if (removed) *removed = r;
-    // tombstones lengthen probe chains: rebuild the table once they fill 1/4 of it
-    if (e->key_mode && (uint64_t)tombs > (e->kt.nb_mask + 1) / 4) {
-        int rc = rebuild_key_table(e);
+    if (e->key_mode) {
+        // tombstones lengthen probe chains: rebuild the table once they fill 1/4 of it
+        int rc = rebuild_key_table_if_due(e);
         if (rc != TC_E_OK) return rc;
-        TC_HIP(e, hipStreamSynchronize(cur_stream(e))); // later key stages may run on the key stream
+        // the sweep (and a rebuild) changed the key table: later key stages on the key stream wait for it
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
     }
+    if (!removed) return TC_E_OK; // asynchronous: the count goes to TC_CNT_SWEPT
+    unsigned long long r = 0;
+    TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    *removed = r;
     return TC_E_OK;
 }
 

@@ -229,6 +229,10 @@ class Engine:
         return (r.status, bool(r.allowed), r.limit, r.remaining, r.reset_after_ns, r.retry_after_ns)
 
     # ---- maintenance / introspection ----
+    def sweep_expired_async(self, now_ns: int) -> None:
+        """Enqueue the sweep on the engine's stream without waiting (count -> counters()["swept"])."""
+        self._check(self._lib.tc_sweep_expired(self._h, now_ns, None))
+
     def sweep_expired(self, now_ns: int) -> int:
         removed = C.c_uint64(0)
         self._check(self._lib.tc_sweep_expired(self._h, now_ns, C.byref(removed)))
