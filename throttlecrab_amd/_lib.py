@@ -90,6 +90,14 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # One HIP runtime per process: torch ships its own libamdhip64 and libtcgpu.so is linked against
+    # the system one (same SONAME).  Whichever is loaded first serves both, and with the system
+    # runtime loaded first torch's device bookkeeping and ours disagree (tc_engine_create then fails
+    # with TC_E_NO_DEVICE on a GPU box).  So torch, when present, is imported before the library.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} not found: the HIP extension is not built.  There is no CPU fallback; "
