@@ -33,6 +33,9 @@ sys.path.insert(0, ROOT)
 # shares a hardware queue with a grouping stream serialises the pipeline (measured 12 -> 5.7 G/s),
 # so ask the runtime for 8 queues before HIP initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("TC_BENCH_FORCE_DIST") == "1":
+    # RCCL brings its own stream: leave it a hardware queue (main + 2 grouping streams + RCCL = 4)
+    os.environ.setdefault("TCGPU_AUX_STREAMS", "2")
 
 N_KEYS = 10_000_000
 BATCH = 1 << 20

@@ -243,6 +243,10 @@ int tc_denied_reset(tc_engine* e);
 int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,
                  uint32_t* key_off);
 
+/* Number of internal invariant violations the kernels have flagged since creation (always 0
+ * unless there is a bug; the parity tests assert it). */
+int tc_selfcheck(tc_engine* e, uint64_t* violations);
+
 /* Checkpoint / restore of everything resident (state cells, rate plans, denial counters, in
  * string mode the key table, plus the counter block).  The reference keeps its state in memory
  * only and loses it on restart; here a snapshot is a few device-to-host copies.  Load needs an

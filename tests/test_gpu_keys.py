@@ -14,7 +14,9 @@ FIELDS = ("allowed", "limit", "remaining", "reset_after_ns", "retry_after_ns", "
 
 def _engine(capacity, max_batch=1 << 16, **kw):
     import throttlecrab_amd as t
-    return t.Engine(capacity, max_batch, key_mode=True, **kw)
+    e = t.Engine(capacity, max_batch, key_mode=True, **kw)
+    e.check_on_close = True  # close() asserts tc_selfcheck() == 0
+    return e
 
 
 def _oracle(capacity=1000):

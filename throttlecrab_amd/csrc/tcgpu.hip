@@ -38,8 +38,13 @@ namespace {
 constexpr int BLOCK = 256;
 constexpr int SORT_ITEMS = 8;  // items per thread of a sort tile (tile = 2048 requests; 512 tiles per 1 Mi batch)
 constexpr int PIPE_DEPTH_MAX = 8;
-constexpr int AUX_MAX = 4, AUX_DEFAULT = 2; // auxiliary (grouping) streams: main + aux must fit the 4 HW queues HIP uses
-constexpr int PIPE_DEPTH_DEFAULT = 3; // grouping scratch sets: batches whose sort may be in flight at once
+constexpr int AUX_MAX = 4;                  // auxiliary (grouping) streams
+// HIP multiplexes streams onto 4 hardware queues; two ACTIVE streams on one queue serialise each other
+// (a barrier packet of one blocks the other: measured 14.7 -> 7.4 G/s with a fifth stream).  Slot mode:
+// main + 3 grouping streams; string mode: main + key stream + 2.  TCGPU_AUX_STREAMS / TCGPU_PIPE_DEPTH
+// override (bench.py uses 2 when RCCL's stream is in the process too).
+constexpr int AUX_SLOT_MODE = 3, AUX_KEY_MODE = 2;
+// grouping scratch sets = batches whose sort may be in flight at once: one more than the grouping streams
 constexpr uint32_t F_REGISTERED = 1u;    // Params.flags: per-slot registered rate plan
 constexpr uint32_t F_UNIFORM_CLASS = 2u; // every slot carries plan `uniform_class`: skip the rate_id[] read
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
@@ -243,9 +248,17 @@ struct __attribute__((aligned(16))) PendEntry {
 //     so no lane of another wave can read a half-updated cell.
 //   Batches with per-request now / quantity / rate go through k_eval_general.
 // ---------------------------------------------------------------------------
-template <bool FULL>
+//   DIRECT (the host proved every run of this batch regular, see all_runs_regular()): no store is
+//     parked and no commit launch follows.  The lane owning a segment's new cell stores it itself
+//     once every wave holding EARLIER requests of the segment has announced (loaded[wave] = seq)
+//     that it read the old cell -- earlier waves were dispatched earlier, so the wait cannot
+//     deadlock.  Requests AFTER the owner (rank >= n_tot: denied) may read either cell: against the
+//     old one the closed form gives "denied against new0 + (n_tot-1) inc", against the new one the
+//     plain step gives the same, because the new cell IS that state.
+template <bool FULL, bool DIRECT>
 __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
-                                                       PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count) {
+                                                       PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
+                                                       uint32_t* __restrict__ loaded, uint32_t seq) {
     const uint32_t n = p.n;
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     const bool valid = k < n;
@@ -322,6 +335,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                     } else if (!f.regular) {
                         // irregular run (saturation, zero increment, immediate expiry):
                         // walk the rest of the segment one request at a time
+                        if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // shard 0's spare word; the host's proof was wrong: must stay 0
                         for (uint32_t j = k + 1; j < n; ++j) {
                             const uint64_t nx = sorted[j];
                             if ((uint32_t)(nx >> 32) != slot) break;
@@ -353,7 +367,28 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
             }
         }
     }
-    if (writer) {
+    if (DIRECT) {
+        const uint32_t gw = k >> 6;
+        // (every lane's cell load has returned: the values were consumed above; pin that down)
+        asm volatile("" ::"v"((uint32_t)wcell.tat), "v"((uint32_t)na), "v"((uint32_t)nd) : "memory");
+        // announce "this wave has read its cells" if a later wave may have to wait for it
+        if (lane == 63 && valid && !is_last)
+            __hip_atomic_store(&loaded[gw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // at most one segment of this wave began in an earlier wave (the one holding lane 0)
+        const uint32_t wave_first = k - (uint32_t)lane;
+        const bool must_wait = writer && seg_start < wave_first;
+        const unsigned long long wm = __ballot(must_wait);
+        if (wm) {
+            const int wl = __builtin_ctzll(wm);
+            const uint32_t w0 = __shfl(seg_start, wl, 64) >> 6;
+            for (uint32_t base = w0; base < gw; base += 64) { // 64 earlier waves per round trip
+                const uint32_t w = base + (uint32_t)lane;
+                while (__ballot(w < gw && __hip_atomic_load(&loaded[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq))
+                    __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (writer) p.cells[slot] = wcell;
+    } else if (writer) {
         if (seg_in_wave) {
             p.cells[slot] = wcell;
         } else {
@@ -905,15 +940,19 @@ struct tc_engine {
         hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
         bool in_use = false;
     } sets[PIPE_DEPTH_MAX];
-    uint32_t depth = PIPE_DEPTH_DEFAULT; // sets actually allocated
+    uint32_t depth = 0; // sets actually allocated
     hipStream_t aux[AUX_MAX] = {};       // set k groups on aux[k % n_aux]
-    uint32_t n_aux = AUX_DEFAULT;
+    uint32_t n_aux = 0;
     uint32_t next_aux = 0;
     uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
     PendEntry* pend = nullptr;
     ChainRec* chain = nullptr; // k_eval_general: per-wave hand-over records
     uint32_t chain_seq = 0;
+    uint32_t* loaded = nullptr; // k_eval_sorted<DIRECT>: per-wave "cells read" flags
+    uint32_t loaded_seq = 0;
+    // bounds over the registered rate plans (for all_runs_regular)
+    int64_t cls_min_ei = INT64_MAX, cls_max_ei = 0, cls_min_dvt = INT64_MAX, cls_max_dvt = 0;
     uint32_t* pend_count = nullptr;
     uint8_t* allowed_tmp = nullptr;
     StoreOpResult* op_result = nullptr;
@@ -1026,12 +1065,14 @@ static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), (hipStream_t)0));
     e->sort_max_tiles = (uint32_t)((mb + rs::THREADS * SORT_ITEMS - 1) / (rs::THREADS * SORT_ITEMS));
     const size_t words = sort_ws_words(e->sort_max_tiles);
+    e->n_aux = (e->cfg_flags & TC_CFG_KEY_MODE) ? AUX_KEY_MODE : AUX_SLOT_MODE;
+    if (const char* d = getenv("TCGPU_AUX_STREAMS")) e->n_aux = (uint32_t)std::min(std::max(atoi(d), 1), AUX_MAX);
+    e->depth = e->n_aux + 1;
     if (const char* d = getenv("TCGPU_PIPE_DEPTH")) e->depth = (uint32_t)std::min(std::max(atoi(d), 1), PIPE_DEPTH_MAX);
     int prio_lo = 0, prio_hi = 0;
     TC_HIP(e, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     const char* pe = getenv("TCGPU_AUX_PRIORITY");
     const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
-    if (const char* d = getenv("TCGPU_AUX_STREAMS")) e->n_aux = (uint32_t)std::min(std::max(atoi(d), 1), AUX_MAX);
     // the evaluation kernel on the main stream is the critical path of the pipeline: grouping runs at
     // the lowest priority and fills what the evaluation leaves free (TCGPU_AUX_PRIORITY=1 flips it)
     for (uint32_t ai = 0; ai < e->n_aux; ++ai)
@@ -1048,6 +1089,8 @@ static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipMalloc(&e->pend, (mb / 32 + 1024) * sizeof(PendEntry)));
     TC_HIP(e, hipMalloc(&e->chain, (mb / 64 + 2) * sizeof(ChainRec)));
     TC_HIP(e, hipMemsetAsync(e->chain, 0, (mb / 64 + 2) * sizeof(ChainRec), (hipStream_t)0));
+    TC_HIP(e, hipMalloc(&e->loaded, (mb / 64 + 2) * sizeof(uint32_t)));
+    TC_HIP(e, hipMemsetAsync(e->loaded, 0, (mb / 64 + 2) * sizeof(uint32_t), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->pend_count, 2 * sizeof(uint32_t)));
     TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
@@ -1242,7 +1285,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->counters, e->pend, e->chain, e->pend_count,
+    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4};
@@ -1291,6 +1334,10 @@ static int intern_class(tc_engine* e, int64_t burst, int64_t count, int64_t peri
     if (it != e->class_of.end()) return it->second;
     if (e->host_classes.size() >= MAX_CLASSES) return -1;
     const uint16_t id = (uint16_t)e->host_classes.size();
+    e->cls_min_ei = std::min(e->cls_min_ei, rc.ei);
+    e->cls_max_ei = std::max(e->cls_max_ei, rc.ei);
+    e->cls_min_dvt = std::min(e->cls_min_dvt, rc.dvt);
+    e->cls_max_dvt = std::max(e->cls_max_dvt, rc.dvt);
     e->host_classes.push_back(rc);
     e->class_of.emplace(k, id);
     *grew = true;
@@ -1412,6 +1459,39 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     return in;
 }
 
+// Uniform batch (one `now`, one `quantity`): is every run regular (tc::run_form) whatever the cells
+// hold?  With request 0 of a run allowed, new0 lies in [now - dvt + inc, now + dvt], so the
+// cell-dependent provisos of run_form hold by themselves once the parameters satisfy
+//     ei > 0,  dvt > 0 (burst >= 2: the entry outlives its own timestamp),  q > 0,
+//     ei * q < 2^62,  0 <= now,  now + dvt < 2^62,
+// checked here for the batch's scalar rate or for the bounds over all registered plans.
+static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params& p) {
+    const int64_t LIM = (int64_t)1 << 62;
+    const int64_t q = p.q_s, now = p.now_s;
+    if (q <= 0 || now < 0) return false;
+    int64_t lo_ei, hi_ei, lo_dvt, hi_dvt;
+    if (p.flags & F_REGISTERED) {
+        if (e->uniform_id) {
+            const RateClass& rc = e->host_classes[e->uniform_id];
+            lo_ei = hi_ei = rc.ei;
+            lo_dvt = hi_dvt = rc.dvt;
+        } else {
+            if (e->host_classes.size() <= 1) return false;
+            lo_ei = e->cls_min_ei, hi_ei = e->cls_max_ei, lo_dvt = e->cls_min_dvt, hi_dvt = e->cls_max_dvt;
+        }
+    } else {
+        int64_t ei, dvt;
+        if (tc::derive_rate(b.max_burst_scalar, b.count_per_period_scalar, b.period_scalar, ei, dvt) != tc::ST_OK) return false;
+        lo_ei = hi_ei = ei;
+        lo_dvt = hi_dvt = dvt;
+    }
+    int64_t inc, lim;
+    if (lo_ei <= 0 || lo_dvt <= 0) return false;
+    if (__builtin_mul_overflow(hi_ei, q, &inc) || inc >= LIM) return false;
+    if (__builtin_add_overflow(now, hi_dvt, &lim) || lim >= LIM) return false;
+    return true;
+}
+
 // all pointers in `b` are device pointers here
 static int run_slots_device(tc_engine* e, const tc_batch& b) {
     const uint32_t n = (uint32_t)b.n;
@@ -1480,12 +1560,20 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
         const bool uniform = !p.q && !p.now && params_by_slot;
         prof_begin(e, TC_STAGE_EVAL, s);
         if (uniform) {
-            if (full) hipLaunchKernelGGL(k_eval_sorted<true>, grid, block, 0, s, p, sorted, e->pend, e->pend_count);
-            else hipLaunchKernelGGL(k_eval_sorted<false>, grid, block, 0, s, p, sorted, e->pend, e->pend_count);
-            prof_end(e, s);
-            prof_begin(e, TC_STAGE_COMMIT, s);
-            hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells);
-            prof_end(e, s);
+            if (all_runs_regular(e, b, p)) {
+                // every run is regular whatever the cells hold: owners store directly, no commit launch
+                if (++e->loaded_seq == 0u) e->loaded_seq = 1u;
+                if (full) hipLaunchKernelGGL((k_eval_sorted<true, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, e->loaded_seq);
+                else hipLaunchKernelGGL((k_eval_sorted<false, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, e->loaded_seq);
+                prof_end(e, s);
+            } else {
+                if (full) hipLaunchKernelGGL((k_eval_sorted<true, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, 0u);
+                else hipLaunchKernelGGL((k_eval_sorted<false, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, 0u);
+                prof_end(e, s);
+                prof_begin(e, TC_STAGE_COMMIT, s);
+                hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells);
+                prof_end(e, s);
+            }
         } else {
             if (++e->chain_seq == 0u) e->chain_seq = 1u; // 0 = "never written"
             if (full) hipLaunchKernelGGL(k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
@@ -2121,5 +2209,17 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     c[(TC_CNT_COUNT + 1) + 2] = h.counters[TC_CNT_ERRORS];
     TC_HIP(e, hipMemcpy(e->counters, c.data(), cnt_words * sizeof(unsigned long long), hipMemcpyHostToDevice));
     e->batches = h.batches;
+    return TC_E_OK;
+}
+
+// Internal invariant violations seen so far (0 unless there is a bug): runs that turned out
+// irregular in a batch the host had proved regular (k_eval_sorted<DIRECT>).
+extern "C" int tc_selfcheck(tc_engine* e, uint64_t* violations) {
+    if (!e || !violations) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    unsigned long long v = 0;
+    TC_HIP(e, hipMemcpyAsync(&v, e->counters + (TC_CNT_COUNT + 1) + 3, sizeof v, hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    *violations = v;
     return TC_E_OK;
 }

@@ -62,9 +62,18 @@ class Engine:
         self.max_batch = max_batch
         self.device = device
         self.key_mode = key_mode
+        self.check_on_close = False
+
+    def selfcheck(self) -> int:
+        v = C.c_uint64(0)
+        self._check(self._lib.tc_selfcheck(self._h, C.byref(v)))
+        return int(v.value)
 
     def close(self):
         if getattr(self, "_h", None):
+            if self.check_on_close:
+                bad = self.selfcheck()
+                assert bad == 0, f"engine flagged {bad} internal invariant violations"
             self._lib.tc_engine_destroy(self._h)
             self._h = None
 
