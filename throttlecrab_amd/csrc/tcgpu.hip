@@ -8,10 +8,15 @@
 // A batch is applied with the reference's sequential semantics
 // (throttlecrab/src/core/rate_limiter.rs:102-250 applied in index order):
 //   unique slots : k_eval_unique   one lane per request
-//   duplicates   : rs::k_hist + rs::k_onesweep x passes  (stable (slot,index) sort)
-//                  k_eval_sorted   closed form for uniform runs / serial walk
-//                  k_commit_list   the few cells whose segment spans waves
-// HBM-bound integer work; MFMA is not used (no dense contraction).
+//   duplicates   : rs::k_hist + rs::k_onesweep x passes  (stable (slot,index) sort), then
+//                  k_eval_sorted   one `now`/`quantity` per batch: closed form per key run
+//                                  (direct stores, or k_commit_list for cells whose run spans waves)
+//                  k_eval_general  per-request now/quantity/rate: wave-cooperative runs of denials,
+//                                  cross-wave hand-over chain with speculative look-back
+//   string keys  : kt::k_probe / k_bind / k_follow resolve keys to slots first (key_table.hpp)
+// Batches flagged TC_B_INPUTS_READY are grouped on auxiliary streams while earlier batches are
+// evaluated on the engine's stream.  HBM-transaction-bound integer work; MFMA is not used (no
+// dense contraction).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
