@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef RS_SPIN_SLEEP
+#define RS_SPIN_SLEEP 8 // s_sleep argument (x64 clocks) between look-back polls
+#endif
 #ifndef RS_ABLATE
 #define RS_ABLATE 0 // tools/sortbench.hip sets 1..4 to time the kernel with phases cut off
 #endif
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
                             got |= 1u << u;
                         }
                     if (got == want) break;
-                    __builtin_amdgcn_s_sleep(1);
+                    __builtin_amdgcn_s_sleep(RS_SPIN_SLEEP);
                 }
             }
             // (2) whole groups before mine, newest first: a published inclusive prefix ends the
@@ -330,7 +333,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
                 }
                 if (done) break;
                 gg -= used;
-                if (used == 0) __builtin_amdgcn_s_sleep(1);
+                if (used == 0) __builtin_amdgcn_s_sleep(RS_SPIN_SLEEP);
             }
             if (j == GROUP - 1 && g + 1 < groups_of(gridDim.x))
                 __hip_atomic_store(&gincl[(size_t)g * RADIX + d], FLAG_INCLUSIVE | (excl + run), __ATOMIC_RELAXED,
