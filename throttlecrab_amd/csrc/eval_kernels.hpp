@@ -1,0 +1,646 @@
+// eval_kernels.hpp -- the evaluation kernels of the batched GCRA engine (gfx950): request
+// decoding, output writing, decision counters and
+//   k_eval_unique   one lane per request (caller promised unique slots)
+//   k_eval_sorted   batches with one `now` / `quantity`: closed form per key run
+//   k_eval_general  per-request now / quantity / rate: wave-cooperative, cross-wave hand-over chain
+//   k_commit_list, k_fold_counters, k_pack_bits
+// Included once, by tcgpu.hip (the engine and the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tcgpu.h"
+#include "gcra_math.hpp"
+
+namespace ev {
+
+using tc::Cell;
+using tc::Decision;
+using tc::RateClass;
+constexpr int BLOCK = 256;
+constexpr uint32_t F_REGISTERED = 1u;    // Params.flags: per-slot registered rate plan
+constexpr uint32_t F_UNIFORM_CLASS = 2u; // every slot carries plan `uniform_class`: skip the rate_id[] read
+constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
+constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
+
+// ---------------------------------------------------------------------------
+// kernel argument block
+// ---------------------------------------------------------------------------
+struct Params {
+    uint32_t n;
+    uint32_t flags;
+    const uint32_t* slot;
+    const int64_t* burst;
+    const int64_t* count;
+    const int64_t* period;
+    const int64_t* q;
+    const int64_t* now;
+    int64_t burst_s, count_s, period_s, q_s, now_s;
+    uint8_t* allowed;
+    int64_t* limit;
+    int64_t* remaining;
+    int64_t* reset;
+    int64_t* retry;
+    uint8_t* status;
+    int64_t* result4;
+    Cell* cells;
+    const uint16_t* rate_id;
+    const RateClass* classes;
+    uint32_t uniform_class;
+    uint64_t capacity;
+    unsigned long long* counters;
+    uint32_t* denied; // per-slot denial counters (TC_CFG_TRACK_DENIED) or nullptr
+};
+
+struct Req {
+    int64_t ei, dvt, q, now, limit;
+    int status;
+};
+
+// Request i against `slot`: arguments, derived rate and status (rate_limiter.rs:111-123).
+__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot) {
+    Req r;
+    r.q = p.q ? p.q[i] : p.q_s;
+    r.now = p.now ? p.now[i] : p.now_s;
+    r.ei = r.dvt = r.limit = 0;
+    if (slot >= p.capacity) {
+        r.status = tc::ST_INTERNAL;
+        return r;
+    }
+    if (p.flags & F_REGISTERED) {
+        const uint32_t id = (p.flags & F_UNIFORM_CLASS) ? p.uniform_class : (uint32_t)p.rate_id[slot];
+        const RateClass rc = p.classes[id]; // class 0 is all zero: burst 0 = never registered
+        r.ei = rc.ei;
+        r.dvt = rc.dvt;
+        r.limit = rc.burst;
+        if (r.q < 0) r.status = tc::ST_NEGATIVE_QUANTITY;            // rate_limiter.rs:111
+        else if (r.limit <= 0) r.status = tc::ST_INVALID_RATE_LIMIT; // slot never registered
+        else r.status = tc::check_request(r.q, r.now, r.dvt);
+    } else {
+        const int64_t burst = p.burst ? p.burst[i] : p.burst_s;
+        const int64_t count = p.count ? p.count[i] : p.count_s;
+        const int64_t period = p.period ? p.period[i] : p.period_s;
+        r.limit = burst;
+        r.status = tc::derive_request(burst, count, period, r.q, r.now, r.ei, r.dvt);
+    }
+    return r;
+}
+
+__device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req& r, const Decision& d) {
+    const bool ok = r.status == tc::ST_OK;
+    if (p.allowed) p.allowed[i] = (ok && d.allowed) ? 1 : 0;
+    if (p.status) p.status[i] = (uint8_t)r.status;
+    if (p.limit) p.limit[i] = ok ? r.limit : 0;
+    if (p.remaining) p.remaining[i] = ok ? d.remaining : 0;
+    if (p.reset) p.reset[i] = ok ? d.reset_after : 0;
+    if (p.retry) p.retry[i] = ok ? d.retry_after : 0;
+    if (p.result4) {
+        // one 32-byte record = two 16-byte stores into the same 64-byte granule
+        longlong2* r4 = reinterpret_cast<longlong2*>(p.result4 + (size_t)i * 4);
+        r4[0] = make_longlong2(ok ? r.limit : 0, ok ? d.remaining : 0);
+        r4[1] = make_longlong2(ok ? d.reset_after : 0, ok ? d.retry_after : 0);
+    }
+}
+
+// Decision counters are accumulated in NSHARD shards (block b -> shard b % NSHARD):
+// a device-scope atomic on ONE address costs ~12 ns and serialises, so 4096
+// blocks hitting one counter would add ~50 us to a 1 Mi-request batch.
+// k_fold_counters sums the shards into the canonical TC_CNT_* block on demand.
+constexpr int NSHARD = 256;
+constexpr int SHARD_WORDS = 4; // allowed, denied, errors, pad
+
+// sum three per-thread counts over the block, one atomic each per block
+__device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c, unsigned long long* counters) {
+    __shared__ uint32_t s_cnt[3][BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        a += __shfl_down(a, off, 64);
+        b += __shfl_down(b, off, 64);
+        c += __shfl_down(c, off, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        s_cnt[0][wave] = a;
+        s_cnt[1][wave] = b;
+        s_cnt[2][wave] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        uint32_t t = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) t += s_cnt[threadIdx.x][w];
+        if (t) {
+            unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + (blockIdx.x % NSHARD) * SHARD_WORDS;
+            atomicAdd(&shard[threadIdx.x], (unsigned long long)t);
+        }
+    }
+}
+
+// Denial counters per key (the device-side analogue of Metrics::record_request_with_key's
+// TopDeniedKeys update, throttlecrab-server/src/metrics.rs:24-50,162-173).  In the sorted kernels the
+// lanes of one key are contiguous, so the first lane of each run inside the wave adds the run's
+// denials with ONE atomic (a hot key would otherwise serialise ~12 ns per denied request).
+__device__ __forceinline__ void wave_denied_add(const Params& p, uint32_t slot, bool denied_here) {
+    if (!p.denied) return; // wave-uniform
+    const int lane = threadIdx.x & 63;
+    const uint32_t prev = __shfl_up(slot, 1, 64);
+    const bool run_head = lane == 0 || prev != slot;
+    const unsigned long long heads = __ballot(run_head), dm = __ballot(denied_here);
+    if (run_head && slot < p.capacity) {
+        const unsigned long long later = (lane == 63) ? 0ull : (heads >> (lane + 1));
+        const int end = later ? lane + __builtin_ctzll(later) : 63; // last lane of my run
+        const unsigned long long run = (end == 63 ? ~0ull : ((2ull << end) - 1ull)) & ~((1ull << lane) - 1ull);
+        const uint32_t cnt = (uint32_t)__popcll(dm & run);
+        if (cnt) atomicAdd(&p.denied[slot], cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// K1: one lane per request, slots unique within the batch
+// ---------------------------------------------------------------------------
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    uint32_t na = 0, nd = 0, ne = 0;
+    if (i < p.n) {
+        const uint32_t slot = p.slot[i];
+        Cell cell;
+        cell.tat = 0;
+        cell.expiry = 0;
+        if (slot < p.capacity) cell = p.cells[slot];
+        const Req r = make_req(p, i, slot);
+        Decision d;
+        d.allowed = false;
+        d.remaining = d.reset_after = d.retry_after = 0;
+        if (r.status == tc::ST_OK) {
+            Cell c = cell;
+            d = tc::gcra_step<FULL>(c, r.ei, r.dvt, r.q, r.now);
+            if (d.allowed) p.cells[slot] = c;
+            na = d.allowed;
+            nd = !d.allowed;
+            if (p.denied && nd) atomicAdd(&p.denied[slot], 1u); // unique slots: no contention
+        } else {
+            ne = 1;
+        }
+        write_out(p, i, r, d);
+    }
+    block_count3(na, nd, ne, p.counters);
+}
+
+// block-wide inclusive max-scan (values are position+1, 0 = none)
+__device__ __forceinline__ uint32_t block_scan_max(uint32_t v) {
+    __shared__ uint32_t s_wmax[BLOCK / 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, 64);
+        if (lane >= off) v = max(v, o);
+    }
+    if (lane == 63) s_wmax[wave] = v;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (int w = 0; w < wave; ++w) carry = max(carry, s_wmax[w]);
+    return max(v, carry);
+}
+
+// Deferred cell store for a segment that spans waves (see k_eval_sorted).
+struct __attribute__((aligned(16))) PendEntry {
+    Cell cell;
+    uint32_t slot;
+    uint32_t pad[3];
+};
+
+// ---------------------------------------------------------------------------
+// K2: evaluate over the (slot, index)-sorted batch; one lane per sorted position.
+//   UNIFORM (one `now`, one `quantity`, per-slot or scalar params): every
+//     request of a slot's segment is identical, so lane r of the segment derives
+//     the cell left by its r predecessors in closed form (tc::run_form) and
+//     applies the ordinary step to it.  Exactly one lane per segment -- the one
+//     performing the last allowed step -- produces the new cell.  If the whole
+//     segment sits inside this wave the lane stores it directly (every lane of
+//     the segment loaded the old cell earlier in program order); otherwise the
+//     store is parked in pend[] and applied by k_commit_list after this kernel (folding it into
+//     the kernel's last block was measured slower: the hand-off needs every block to drain its stores),
+//     so no lane of another wave can read a half-updated cell.
+//   Batches with per-request now / quantity / rate go through k_eval_general.
+// ---------------------------------------------------------------------------
+//   DIRECT (the host proved every run of this batch regular, see all_runs_regular()): no store is
+//     parked and no commit launch follows.  The lane owning a segment's new cell stores it itself
+//     once every wave holding EARLIER requests of the segment has announced (loaded[wave] = seq)
+//     that it read the old cell -- earlier waves were dispatched earlier, so the wait cannot
+//     deadlock.  Requests AFTER the owner (rank >= n_tot: denied) may read either cell: against the
+//     old one the closed form gives "denied against new0 + (n_tot-1) inc", against the new one the
+//     plain step gives the same, because the new cell IS that state.
+template <bool FULL, bool DIRECT>
+__global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
+                                                       PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
+                                                       uint32_t* __restrict__ loaded, uint32_t seq) {
+    const uint32_t n = p.n;
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    const bool valid = k < n;
+    const uint64_t me = valid ? sorted[k] : ~0ull;
+    const uint32_t slot = (uint32_t)(me >> 32);
+    const uint32_t idx = (uint32_t)me;
+    const int lane = threadIdx.x & 63;
+    // neighbours' slots by wave shuffles; only the wave's edge lanes look at memory
+    uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
+    if (lane == 0 && valid && k > 0) prev_slot = (uint32_t)(sorted[k - 1] >> 32);
+    if (lane == 63 && k + 1 < n) next_slot = (uint32_t)(sorted[k + 1] >> 32);
+    const bool head = valid && (k == 0 || prev_slot != slot);
+    uint32_t na = 0, nd = 0, ne = 0;
+
+    const bool is_last = valid && ((k + 1 == n) || next_slot != slot);
+    __shared__ uint32_t s_start;
+    const uint32_t block_start = blockIdx.x * BLOCK;
+    if (threadIdx.x == 0 && valid && !head) {
+        // segment of sorted[block_start] began in an earlier block: lower_bound on the slot
+        uint32_t lo = 0, hi = block_start;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if ((uint32_t)(sorted[mid] >> 32) < slot) lo = mid + 1;
+            else hi = mid;
+        }
+        s_start = lo;
+    }
+    const uint32_t hp = block_scan_max(head ? k + 1 : 0u); // contains a __syncthreads()
+    const uint32_t seg_start = hp ? hp - 1 : s_start;
+    // does my whole segment live inside this wave?
+    const unsigned long long heads = __ballot(head), lasts = __ballot(is_last);
+    const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const bool seg_in_wave = ((heads & upto) != 0ull) && ((lasts >> lane) != 0ull);
+
+    bool writer = false, walked = false;
+    Cell wcell;
+    wcell.tat = 0;
+    wcell.expiry = 0;
+    if (valid) {
+        const uint32_t r = k - seg_start;
+        Cell cell;
+        cell.tat = 0;
+        cell.expiry = 0;
+        if (slot < p.capacity) cell = p.cells[slot];
+        const Req rq = make_req(p, idx, slot);
+        Decision d;
+        d.allowed = false;
+        d.remaining = d.reset_after = d.retry_after = 0;
+        if (rq.status != tc::ST_OK) {
+            ne = 1;
+            write_out(p, idx, rq, d);
+        } else {
+            Cell c = cell;
+            const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
+            if (!d0.allowed) {
+                // request 0 denied => state untouched => every request of the run equals request 0
+                nd = 1;
+                write_out(p, idx, rq, d0);
+            } else if (head && is_last) {
+                // a key requested once in this batch (95 % of a uniform batch): no closed form,
+                // and in particular none of its 64-bit division
+                na = 1;
+                write_out(p, idx, rq, d0);
+                writer = true;
+                wcell = c;
+            } else {
+                const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
+                if (r == 0) {
+                    na = 1;
+                    write_out(p, idx, rq, d0);
+                    if (is_last || (f.regular && f.n_tot == 1)) {
+                        writer = true;
+                        wcell = c;
+                    } else if (!f.regular) {
+                        // irregular run (saturation, zero increment, immediate expiry):
+                        // walk the rest of the segment one request at a time
+                        if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // shard 0's spare word; the host's proof was wrong: must stay 0
+                        for (uint32_t j = k + 1; j < n; ++j) {
+                            const uint64_t nx = sorted[j];
+                            if ((uint32_t)(nx >> 32) != slot) break;
+                            const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
+                            na += dj.allowed;
+                            nd += !dj.allowed;
+                            write_out(p, (uint32_t)nx, rq, dj);
+                        }
+                        if (p.denied && nd) atomicAdd(&p.denied[slot], nd); // the whole run's denials sit in this lane
+                        walked = true;
+                        writer = true;
+                        wcell = c;
+                    }
+                } else if (f.regular) {
+                    const int64_t j = (int64_t)r < f.n_tot ? (int64_t)r : f.n_tot;
+                    Cell v;
+                    v.tat = f.new0 + (j - 1) * f.inc;
+                    v.expiry = UINT64_MAX;
+                    d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
+                    na = d.allowed;
+                    nd = !d.allowed;
+                    write_out(p, idx, rq, d);
+                    if (d.allowed && (is_last || (int64_t)r + 1 == f.n_tot)) {
+                        writer = true;
+                        wcell = v;
+                    }
+                }
+                // irregular && r > 0: the head lane produced this request's outputs
+            }
+        }
+    }
+    if (DIRECT) {
+        const uint32_t gw = k >> 6;
+        // (every lane's cell load has returned: the values were consumed above; pin that down)
+        asm volatile("" ::"v"((uint32_t)wcell.tat), "v"((uint32_t)na), "v"((uint32_t)nd) : "memory");
+        // announce "this wave has read its cells" if a later wave may have to wait for it
+        if (lane == 63 && valid && !is_last)
+            __hip_atomic_store(&loaded[gw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // at most one segment of this wave began in an earlier wave (the one holding lane 0)
+        const uint32_t wave_first = k - (uint32_t)lane;
+        const bool must_wait = writer && seg_start < wave_first;
+        const unsigned long long wm = __ballot(must_wait);
+        if (wm) {
+            const int wl = __builtin_ctzll(wm);
+            const uint32_t w0 = __shfl(seg_start, wl, 64) >> 6;
+            for (uint32_t base = w0; base < gw; base += 64) { // 64 earlier waves per round trip
+                const uint32_t w = base + (uint32_t)lane;
+                while (__ballot(w < gw && __hip_atomic_load(&loaded[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq))
+                    __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        if (writer) p.cells[slot] = wcell;
+    } else if (writer) {
+        if (seg_in_wave) {
+            p.cells[slot] = wcell;
+        } else {
+            const uint32_t at = atomicAdd(pend_count, 1u);
+            PendEntry pe;
+            pe.cell = wcell;
+            pe.slot = slot;
+            pe.pad[0] = pe.pad[1] = pe.pad[2] = 0;
+            pend[at] = pe;
+        }
+    }
+    wave_denied_add(p, slot, nd != 0 && !walked);
+    block_count3(na, nd, ne, p.counters);
+}
+
+// ---------------------------------------------------------------------------
+// K2g: general batches (per-request now / quantity / rate) over the sorted batch.
+// The update is not an associative scan (a denied request leaves the TAT, an
+// allowed one moves it), but a DENIED request never changes the state, so a wave
+// evaluates all requests of a segment piece against the piece's current state at
+// once: everything before the first allowed request is final (denied against that
+// state), the first allowed request is final and hands its new state to the lanes
+// after it, repeat.  Iterations per wave = allowed requests in its longest piece
+// + 1: a run of denials of a hot key costs one step per 64 requests, and a wave
+// of 64 unrelated keys costs one step.  A segment that continues into the next
+// wave hands (state, dirty) over through chain[]: the next wave (same or next
+// block, dispatched no later than its successor) waits for it with its own
+// request columns already loaded.  The last lane of a segment stores the cell.
+// ---------------------------------------------------------------------------
+struct __attribute__((aligned(32))) ChainRec {
+    unsigned long long tat, expiry; // state the wave's last piece leaves (valid once fin == batch sequence number)
+    uint32_t fin;                   // low half of the 8-byte flag word
+    uint32_t spec;                  // == sequence number: "my lanes are all denied if my segment still has its
+                                    // resident state when it reaches me" (published before the wave waits)
+    uint32_t dirty;
+    uint32_t pad;
+};
+
+template <bool FULL>
+__global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t* __restrict__ sorted,
+                                                        ChainRec* __restrict__ chain, uint32_t seq) {
+    const uint32_t n = p.n;
+    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const uint32_t gw = k >> 6; // global wave number
+    const bool valid = k < n;
+    const uint64_t me = valid ? sorted[k] : ~0ull;
+    const uint32_t slot = (uint32_t)(me >> 32);
+    const uint32_t idx = (uint32_t)me;
+    uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
+    if (lane == 0 && valid && k > 0) prev_slot = (uint32_t)(sorted[k - 1] >> 32);
+    if (lane == 63 && k + 1 < n) next_slot = (uint32_t)(sorted[k + 1] >> 32);
+    const bool head = valid && (k == 0 || prev_slot != slot);
+    const bool is_last = valid && (k + 1 == n || next_slot != slot);
+
+    Req r;
+    r.ei = r.dvt = r.q = r.now = r.limit = 0;
+    r.status = tc::ST_INTERNAL;
+    if (valid) r = make_req(p, idx, slot);
+    const bool ok = valid && r.status == tc::ST_OK;
+
+    // my piece = lanes [pstart, pend] of this wave that belong to my segment
+    const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+    const unsigned long long hb = __ballot(head) & upto;
+    const int pstart = hb ? 63 - __builtin_clzll(hb) : 0;
+    const bool continued = valid && hb == 0ull; // my segment began in an earlier wave
+    const unsigned long long lb = __ballot(is_last) >> lane;
+    const int pend = lb ? lane + __builtin_ctzll(lb) : 63;
+    const unsigned long long piece =
+        (pend == 63 ? ~0ull : ((2ull << pend) - 1ull)) & ~((1ull << pstart) - 1ull);
+
+    // State my piece starts from: the resident cell, or what the previous wave hands over.
+    // A hot key's segment crosses hundreds of waves; waiting wave by wave would serialise
+    // ~2 us hops (measured 3.5 ms for the Zipf head).  But a denied request leaves the state
+    // alone, and a saturated key is denied almost always, so every wave of a continued segment
+    // first checks its lanes against the segment's RESIDENT state c0 (every wave of the segment
+    // can load it: the cell is only rewritten by the segment's last lane, which needs all of
+    // them first).  "Nobody allowed under c0" is published at once (spec); a wave then looks
+    // back over 64 predecessors per round trip: spec, spec, ..., fin(v) with v == c0 proves that
+    // the state reaching it is c0.  Any mismatch falls back to the direct predecessor's record.
+    Cell c;
+    c.tat = 0;
+    c.expiry = 0;
+    bool dirty = false;
+    if (valid && slot < p.capacity) c = p.cells[slot]; // continued lanes: c0, the guess
+    if (__ballot(continued) != 0ull) { // wave-uniform: lane 0 is continued
+        bool spec_allow = false;
+        if (continued && ok) {
+            Cell t0 = c;
+            spec_allow = tc::gcra_step<false>(t0, r.ei, r.dvt, r.q, r.now).allowed;
+        }
+        const bool transparent = __ballot(spec_allow) == 0ull;
+        const bool through = __shfl((int)(continued && !is_last), 63, 64) != 0; // the segment runs through this whole wave
+        if (transparent && through && lane == 0)
+            __hip_atomic_store(&chain[gw].spec, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const long long c0_tat = __shfl((long long)c.tat, 0, 64);
+        const unsigned long long c0_exp = __shfl((unsigned long long)c.expiry, 0, 64);
+        long long in_tat = 0;
+        unsigned long long in_exp = 0;
+        uint32_t in_dirty = 0;
+        bool direct = false; // give up speculating: wait for the direct predecessor
+        uint32_t base = 0;   // records gw-1-base-lane are examined
+        while (true) {
+            const long long j = (long long)gw - 1 - (long long)base - lane;
+            unsigned long long fl = 0ull;
+            if (j >= 0 && (!direct || lane == 0))
+                fl = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&chain[j].fin), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+            const bool is_fin = (uint32_t)fl == seq, is_spec = (uint32_t)(fl >> 32) == seq;
+            const unsigned long long fm = __ballot(is_fin), sm = __ballot(is_spec);
+            int d = -1; // lane whose record ends the look-back
+            if (direct) {
+                if (fm & 1ull) d = 0;
+            } else if (fm) {
+                const int f = __builtin_ctzll(fm);
+                const unsigned long long below = f ? ((1ull << f) - 1ull) : 0ull;
+                if ((~sm & below) == 0ull) d = f; // everything nearer than the final record is transparent
+            } else if (~sm == 0ull) {
+                base += 64; // 64 transparent waves: look further back
+                continue;
+            }
+            if (d < 0) {
+                base = 0; // something in between is not ready: look again from the nearest record
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
+            long long vt = 0;
+            unsigned long long vx = 0;
+            uint32_t vd = 0;
+            if (lane == d) {
+                vt = (long long)__hip_atomic_load(&chain[j].tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vx = __hip_atomic_load(&chain[j].expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vd = __hip_atomic_load(&chain[j].dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            vt = __shfl(vt, d, 64);
+            vx = __shfl(vx, d, 64);
+            vd = __shfl(vd, d, 64);
+            if (d == 0 && base == 0) { // the direct predecessor: exact
+                in_tat = vt;
+                in_exp = vx;
+                in_dirty = vd;
+                break;
+            }
+            if (vt == c0_tat && vx == c0_exp) { // the transparent waves in between were right
+                in_tat = vt;
+                in_exp = vx;
+                in_dirty = vd;
+                break;
+            }
+            direct = true; // the state changed on the way: no shortcut
+            base = 0;
+        }
+        if (continued) {
+            c.tat = in_tat;
+            c.expiry = in_exp;
+            dirty = in_dirty != 0u;
+        }
+    }
+
+    uint32_t na = 0, nd = 0, ne = 0;
+    bool fin = !valid, was_allowed = false;
+    Cell mine; // state after my request, if it was allowed
+    mine.tat = 0;
+    mine.expiry = 0;
+    if (valid && !ok) { // errors leave the state alone (rate_limiter.rs:111-117)
+        Decision z;
+        z.allowed = false;
+        z.remaining = z.reset_after = z.retry_after = 0;
+        write_out(p, idx, r, z);
+        ne = 1;
+        fin = true;
+    }
+    while (true) {
+        Cell c2 = c;
+        bool allow = false;
+        if (!fin) allow = tc::gcra_step<false>(c2, r.ei, r.dvt, r.q, r.now).allowed;
+        const unsigned long long open = __ballot(!fin);
+        if (open == 0ull) break;
+        const unsigned long long ap = __ballot(allow) & piece;
+        const int first = ap ? __builtin_ctzll(ap) : 64;
+        if (!fin && lane <= first) {
+            // lanes before the first allowed request are denied against the current state,
+            // the first allowed request is allowed against it: both final
+            Decision d;
+            if (FULL) {
+                Cell tmp = c;
+                d = tc::gcra_step<true>(tmp, r.ei, r.dvt, r.q, r.now);
+            } else {
+                d.allowed = allow;
+                d.remaining = d.reset_after = d.retry_after = 0;
+            }
+            write_out(p, idx, r, d);
+            if (lane == first) {
+                na = 1;
+                was_allowed = true;
+                mine = c2;
+            } else {
+                nd = 1;
+            }
+            fin = true;
+        }
+        // the lanes after `first` in its piece continue from the state it leaves
+        const int src = first < 64 ? first : lane;
+        const long long nt = __shfl((long long)c2.tat, src, 64);
+        const unsigned long long nx = __shfl((unsigned long long)c2.expiry, src, 64);
+        if (first < 64 && lane > first) { // (lanes beyond pend are masked out by `piece` in `ap`: first is in MY piece)
+            c.tat = nt;
+            c.expiry = nx;
+            dirty = true;
+        }
+    }
+    // the last lane of the piece owns the state the piece leaves
+    if (valid && lane == pend) {
+        const Cell out = was_allowed ? mine : c;
+        const bool out_dirty = dirty || was_allowed;
+        if (is_last) {
+            if (out_dirty && slot < p.capacity) p.cells[slot] = out;
+        } else {
+            ChainRec* o = &chain[gw];
+            __hip_atomic_store(&o->tat, (unsigned long long)out.tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->expiry, (unsigned long long)out.expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->dirty, out_dirty ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // the record must be performed at agent scope before the flag that announces it
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __builtin_amdgcn_s_waitcnt(0);
+            __atomic_signal_fence(__ATOMIC_SEQ_CST);
+            __hip_atomic_store(&o->fin, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    wave_denied_add(p, slot, nd != 0);
+    block_count3(na, nd, ne, p.counters);
+}
+
+__global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restrict__ pend,
+                                                       uint32_t* __restrict__ pend_count, Cell* __restrict__ cells) {
+    // pend_count[0] = entries, pend_count[1] = blocks of this launch that are done
+    const uint32_t cnt = pend_count[0];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < cnt; i += gridDim.x * BLOCK) {
+        const PendEntry pe = pend[i];
+        cells[pe.slot] = pe.cell;
+    }
+    __syncthreads(); // every lane of this block has consumed `cnt`
+    if (threadIdx.x == 0) {
+        // the last block to finish re-arms the list for the next batch (no extra launch)
+        if (atomicAdd(&pend_count[1], 1u) == gridDim.x - 1) {
+            pend_count[0] = 0;
+            pend_count[1] = 0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(NSHARD) void k_fold_counters(unsigned long long* counters) {
+    __shared__ unsigned long long s[3][NSHARD / 64];
+    const unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + threadIdx.x * SHARD_WORDS;
+    unsigned long long v[3] = {shard[0], shard[1], shard[2]};
+    for (int off = 32; off > 0; off >>= 1)
+        for (int j = 0; j < 3; ++j) v[j] += __shfl_down(v[j], off, 64);
+    if ((threadIdx.x & 63) == 0)
+        for (int j = 0; j < 3; ++j) s[j][threadIdx.x >> 6] = v[j];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t[3] = {0, 0, 0};
+        for (int j = 0; j < 3; ++j)
+            for (int w = 0; w < NSHARD / 64; ++w) t[j] += s[j][w];
+        counters[TC_CNT_ALLOWED] = t[0];
+        counters[TC_CNT_DENIED] = t[1];
+        counters[TC_CNT_ERRORS] = t[2];
+        counters[TC_CNT_TOTAL] = t[0] + t[1] + t[2];
+    }
+}
+
+// allowed[] bytes -> bitmask (wavefront ballot, one u64 per wave)
+__global__ __launch_bounds__(BLOCK) void k_pack_bits(const uint8_t* __restrict__ allowed, uint32_t n,
+                                                     uint64_t* __restrict__ bits) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    const bool a = i < n && allowed[i];
+    const unsigned long long m = __ballot(a);
+    if ((threadIdx.x & 63) == 0 && i < n) bits[i >> 6] = m;
+}
+
+} // namespace ev

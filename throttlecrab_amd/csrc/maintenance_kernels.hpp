@@ -1,0 +1,242 @@
+// maintenance_kernels.hpp -- everything that is not a decision: expiry sweep (== AdaptiveStore::cleanup),
+// top-denied-key selection, rate-plan id fills, the single-key `trait Store` operations.
+// Included once, by tcgpu.hip.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/tcgpu.h"
+#include "eval_kernels.hpp"
+#include "gcra_math.hpp"
+#include "key_table.hpp"
+
+namespace mk {
+
+using ev::BLOCK;
+using tc::Cell;
+
+// ---------------------------------------------------------------------------
+// K4: expiry sweep == AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint64_t capacity, int64_t now,
+                                                 unsigned long long* counters, unsigned long long* removed_out) {
+    uint32_t removed = 0, live = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        Cell c = cells[i];
+        if (c.expiry != 0) {
+            if (!(c.expiry > (uint64_t)now)) { // retain(|exp| *exp > now)
+                c.tat = 0;
+                c.expiry = 0;
+                cells[i] = c;
+                removed++;
+            } else {
+                live++;
+            }
+        }
+    }
+    __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        removed += __shfl_down(removed, off, 64);
+        live += __shfl_down(live, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_r[threadIdx.x >> 6] = removed;
+        s_l[threadIdx.x >> 6] = live;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t r = 0, l = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            r += s_r[w];
+            l += s_l[w];
+        }
+        if (r) {
+            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)r);
+            atomicAdd(removed_out, (unsigned long long)r);
+        }
+        if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
+    }
+}
+
+// Key-mode sweep: same retain rule, and an expired (or never written) bound slot
+// also loses its key: tombstone in the hash table, slot back on the free stack.
+// Every block owns a contiguous range of slots, collects the slots it unbinds in
+// LDS and pushes them with ONE stack reservation per SWEEP_BUF slots (an atomic on
+// the stack top costs ~12 ns and serialises: one per 256 slots was most of the kernel).
+constexpr int SWEEP_BUF = 8192;
+__global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
+                                                      unsigned long long* counters, unsigned long long* removed_out,
+                                                      uint32_t* __restrict__ denied) {
+    __shared__ uint32_t s_buf[SWEEP_BUF];
+    __shared__ int s_base;
+    uint32_t removed = 0, live = 0, fill = 0; // fill is uniform over the block
+    const uint64_t per_block = (((uint64_t)t.capacity + gridDim.x - 1) / gridDim.x + BLOCK - 1) / BLOCK * BLOCK;
+    const uint64_t first = (uint64_t)blockIdx.x * per_block;
+    const uint64_t last = first + per_block < t.capacity ? first + per_block : t.capacity;
+    auto flush = [&]() {
+        if (threadIdx.x == 0) s_base = atomicAdd(t.free_top, (int)fill);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < fill; j += BLOCK) t.free_slots[s_base + (int)j] = s_buf[j];
+        __syncthreads();
+        fill = 0;
+    };
+    uint32_t unbound_total = 0;
+    for (uint64_t base = first; base < last; base += BLOCK) {
+        const uint64_t i = base + threadIdx.x;
+        bool unbind = false;
+        if (i < last && t.bound[i]) {
+            Cell c = cells[i];
+            if (!(c.expiry > (uint64_t)now)) {
+                if (c.expiry != 0) removed++; // the reference's map only ever held written entries
+                c.tat = 0;
+                c.expiry = 0;
+                cells[i] = c;
+                unbind = true;
+            } else {
+                live++;
+            }
+        }
+        uint32_t total = 0;
+        const uint32_t rank = kt::block_rank<BLOCK>(unbind, total); // one barrier
+        if (fill + total > (uint32_t)SWEEP_BUF) flush();
+        if (unbind) {
+            const uint32_t pos = t.rec[i].pos;
+            t.ktab[pos] = (t.ktab[pos] & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
+            t.bound[i] = 0;
+            if (denied) denied[i] = 0; // the slot will serve another key
+            s_buf[fill + rank] = (uint32_t)i;
+        }
+        fill += total;
+        unbound_total += total;
+        __syncthreads(); // block_rank's scratch is reused next round
+    }
+    if (fill) flush();
+    if (threadIdx.x == 0 && unbound_total) atomicAdd(t.tombs, unbound_total);
+    __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        removed += __shfl_down(removed, off, 64);
+        live += __shfl_down(live, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_r[threadIdx.x >> 6] = removed;
+        s_l[threadIdx.x >> 6] = live;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t r = 0, l = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            r += s_r[w];
+            l += s_l[w];
+        }
+        if (r) {
+            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)r);
+            atomicAdd(removed_out, (unsigned long long)r);
+        }
+        if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// top denied keys (metrics.rs:24-76 keeps a capped HashMap on the host; here the counts are
+// exact, one u32 per slot, and the top K are selected on demand: radix select of the K-th
+// largest count, 8 bits per pass, then one compaction pass)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_denied_hist(const uint32_t* __restrict__ denied, uint64_t capacity,
+                                                       uint32_t prefix, uint32_t prefix_mask, uint32_t shift,
+                                                       uint32_t* __restrict__ hist) {
+    __shared__ uint32_t s_h[256];
+    s_h[threadIdx.x] = 0; // BLOCK == 256
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t c = denied[i];
+        if (c != 0u && (c & prefix_mask) == prefix) atomicAdd(&s_h[(c >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+
+// entries with count > T go to list 0, entries with count == T to list 1 (each capped at `cap_out`)
+__global__ __launch_bounds__(BLOCK) void k_denied_collect(const uint32_t* __restrict__ denied, uint64_t capacity, uint32_t T,
+                                                          uint32_t* __restrict__ n_out /*[2]*/, uint32_t* __restrict__ lists,
+                                                          uint32_t cap_out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t c = denied[i];
+        if (c == 0u || c < T) continue;
+        const int which = c > T ? 0 : 1;
+        const uint32_t at = atomicAdd(&n_out[which], 1u);
+        if (at < cap_out) {
+            uint32_t* l = lists + (size_t)which * 2 * cap_out;
+            l[2 * at] = (uint32_t)i;
+            l[2 * at + 1] = c;
+        }
+    }
+}
+
+// key mode: copy the KeyRec of each listed slot into a dense array
+__global__ __launch_bounds__(BLOCK) void k_gather_keyrecs(kt::Table t, const uint32_t* __restrict__ slots, uint32_t n,
+                                                          kt::KeyRec* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = slots[i];
+    kt::KeyRec r;
+    r.hash = 0;
+    r.len = kt::NO_SLOT;
+    r.pos = 0;
+    if (s < t.capacity && t.bound[s]) r = t.rec[s];
+    out[i] = r;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_rate_id(uint16_t* __restrict__ rate_id, uint64_t capacity, uint16_t id) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK)
+        rate_id[i] = id;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_scatter_rate_id(uint16_t* __restrict__ rate_id, const uint32_t* __restrict__ slots,
+                                                           const uint16_t* __restrict__ src, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) rate_id[slots ? slots[i] : i] = src[i];
+}
+
+// `trait Store` shims on one resolved slot (store/mod.rs:85-133,
+// adaptive_cleanup.rs:221-279).  op: 0 get, 1 cas, 2 set_nx
+struct StoreOpResult {
+    int64_t value;
+    int32_t flag;
+    int32_t pad;
+};
+__global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
+                           StoreOpResult* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    Cell c = cells[slot];
+    const bool live = c.expiry > (uint64_t)now;
+    StoreOpResult r;
+    r.value = 0;
+    r.flag = 0;
+    r.pad = 0;
+    uint64_t e = (uint64_t)now + ttl;
+    if (e < ttl) e = UINT64_MAX;
+    if (op == 0) {
+        if (live) {
+            r.value = c.tat;
+            r.flag = 1;
+        }
+    } else if (op == 1) {
+        if (live && c.tat == a) {
+            c.tat = b;
+            c.expiry = e;
+            cells[slot] = c;
+            r.flag = 1;
+        }
+    } else {
+        if (!live) {
+            c.tat = a;
+            c.expiry = e;
+            cells[slot] = c;
+            r.flag = 1;
+        }
+    }
+    *out = r;
+}
+
+} // namespace mk
