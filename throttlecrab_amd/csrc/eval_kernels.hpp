@@ -166,7 +166,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
         Cell cell;
         cell.tat = 0;
         cell.expiry = 0;
-        if (slot < p.capacity) cell = p.cells[slot];
+        if (slot < p.capacity) cell = tc::load_cell(&p.cells[slot]);
         const Req r = make_req(p, i, slot);
         Decision d;
         d.allowed = false;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
         if (r.status == tc::ST_OK) {
             Cell c = cell;
             d = tc::gcra_step<FULL>(c, r.ei, r.dvt, r.q, r.now);
-            if (d.allowed) p.cells[slot] = c;
+            if (d.allowed) tc::store_cell(&p.cells[slot], c);
             na = d.allowed;
             nd = !d.allowed;
             if (p.denied && nd) atomicAdd(&p.denied[slot], 1u); // unique slots: no contention
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
         Cell cell;
         cell.tat = 0;
         cell.expiry = 0;
-        if (slot < p.capacity) cell = p.cells[slot];
+        if (slot < p.capacity) cell = tc::load_cell(&p.cells[slot]);
         const Req rq = make_req(p, idx, slot);
         Decision d;
         d.allowed = false;
@@ -361,10 +361,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                     __builtin_amdgcn_s_sleep(1);
             }
         }
-        if (writer) p.cells[slot] = wcell;
+        if (writer) tc::store_cell(&p.cells[slot], wcell);
     } else if (writer) {
         if (seg_in_wave) {
-            p.cells[slot] = wcell;
+            tc::store_cell(&p.cells[slot], wcell);
         } else {
             const uint32_t at = atomicAdd(pend_count, 1u);
             PendEntry pe;
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     c.tat = 0;
     c.expiry = 0;
     bool dirty = false;
-    if (valid && slot < p.capacity) c = p.cells[slot]; // continued lanes: c0, the guess
+    if (valid && slot < p.capacity) c = tc::load_cell(&p.cells[slot]); // continued lanes: c0, the guess
     if (__ballot(continued) != 0ull) { // wave-uniform: lane 0 is continued
         bool spec_allow = false;
         if (continued && ok) {
@@ -579,7 +579,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         const Cell out = was_allowed ? mine : c;
         const bool out_dirty = dirty || was_allowed;
         if (is_last) {
-            if (out_dirty && slot < p.capacity) p.cells[slot] = out;
+            if (out_dirty && slot < p.capacity) tc::store_cell(&p.cells[slot], out);
         } else {
             ChainRec* o = &chain[gw];
             __hip_atomic_store(&o->tat, (unsigned long long)out.tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -602,7 +602,7 @@ __global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restri
     const uint32_t cnt = pend_count[0];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < cnt; i += gridDim.x * BLOCK) {
         const PendEntry pe = pend[i];
-        cells[pe.slot] = pe.cell;
+        tc::store_cell(&cells[pe.slot], pe.cell);
     }
     __syncthreads(); // every lane of this block has consumed `cnt`
     if (threadIdx.x == 0) {

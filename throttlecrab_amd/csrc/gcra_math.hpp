@@ -67,6 +67,20 @@ struct __attribute__((aligned(16))) Rate {
     int64_t dvt;
 };
 
+// A cell is always read and written as ONE 16-byte access (global_load/store_dwordx4): the
+// evaluation kernels let a key's cell be rewritten while later requests of the same key may still
+// read it (k_eval_sorted, direct mode), which is only sound if nobody can see half a cell.
+__device__ __forceinline__ Cell load_cell(const Cell* p) {
+    const longlong2 v = *reinterpret_cast<const longlong2*>(p);
+    Cell c;
+    c.tat = v.x;
+    c.expiry = (uint64_t)v.y;
+    return c;
+}
+__device__ __forceinline__ void store_cell(Cell* p, const Cell& c) {
+    *reinterpret_cast<longlong2*>(p) = make_longlong2(c.tat, (long long)c.expiry);
+}
+
 // A registered rate plan: everything RateLimiter::rate_limit derives from
 // (max_burst, count_per_period, period) before it looks at the key
 // (rate_limiter.rs:119-123): emission interval, delay variation tolerance, and
