@@ -45,3 +45,30 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "__init__.py" and False, f"{f} mentions the oracle"
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/tcgpu.h must be usable from C (the boundary a Rust / Go / C host binds): compile a C11
+    translation unit that takes the address of every declared function and link it against
+    libtcgpu.so (link only -- nothing is called without a GPU)."""
+    import subprocess
+    names = _declared_symbols()
+    src = tmp_path / "abi_check.c"
+    body = "\n".join(f"    p[{i}] = (fn)&{n};" for i, n in enumerate(names))
+    src.write_text(f'''#include "tcgpu.h"
+#include <stddef.h>
+_Static_assert(sizeof(tc_config) == 40, "tc_config layout");
+_Static_assert(offsetof(tc_batch, result4) == 8 + 8 + 8 * 8 + 5 * 8 + 7 * 8, "tc_batch layout");
+_Static_assert(sizeof(tc_result) == 40, "tc_result layout");
+typedef void (*fn)(void);
+int main(void) {{
+    fn p[{len(names)}];
+{body}
+    return p[0] == 0;
+}}
+''')
+    exe = tmp_path / "abi_check"
+    subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+                           str(src), "-L" + os.path.join(ROOT, "throttlecrab_amd"), "-ltcgpu",
+                           "-Wl,-rpath," + os.path.join(ROOT, "throttlecrab_amd"), "-o", str(exe)])
+    assert exe.exists()
