@@ -1,0 +1,84 @@
+"""N > 1 path with the real engine: two processes (both on cuda:0 -- the GPU box has one device),
+each owning the keys that hash to it, each deciding only its own requests on its own engine; the
+counter blocks are all-gathered (gloo here, RCCL in bench.py).  The union of the shards must equal
+one sequential pass of the oracle over the whole stream."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    import throttlecrab_amd as t
+    from throttlecrab_amd import sharded, workload as W
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    n_keys, n, nb = 20000, 60000, 4
+    eng = t.Engine(n_keys, n)
+    eng.use_torch_stream()
+    local = sharded.LocalSlots()
+    allowed_global = np.zeros(nb * n, np.int64)
+    for b in range(nb):
+        gids = W.Zipf(n_keys).slots(n, start=b * n).astype(np.uint64) + np.uint64(10**9)
+        pos, mine = sharded.partition(gids, world, rank)
+        slots = local.resolve(mine)
+        d = torch.from_numpy(slots.astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        res = eng.rate_limit_batch_slots(d, max_burst=5, count_per_period=50, period=60, quantity=1,
+                                         now_ns=W.T0_NS + b * 10**8, want=("allowed",), inputs_ready=True)
+        torch.cuda.synchronize()
+        allowed_global[b * n + pos] = res.allowed.cpu().numpy()
+    c = eng.counters()
+    block = torch.tensor([c[k] for k in ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")],
+                         dtype=torch.int64)
+    per_rank, totals = sharded.all_gather_counters(block, dist, world)
+    tt = torch.from_numpy(allowed_global)
+    dist.all_reduce(tt)
+    if rank == 0:
+        q.put((totals, per_rank.tolist(), tt.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+    eng.close()
+
+
+def test_two_engines_two_processes_match_single_pass():
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    totals, per_rank, allowed = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n_keys, n, nb = 20000, 60000, 4
+    orc = O.DenseOracle(n_keys)
+    ref = []
+    for b in range(nb):
+        gids = W.Zipf(n_keys).slots(n, start=b * n)
+        ref.append(orc.batch_slots(gids, 5, 50, 60, 1, W.T0_NS + b * 10**8).allowed.astype(np.int64))
+    ref = np.concatenate(ref)
+    assert np.array_equal(allowed, ref)
+    assert totals["total"] == nb * n and totals["allowed"] == int(ref.sum())
+    assert per_rank[0][0] + per_rank[1][0] == nb * n and min(per_rank[0][0], per_rank[1][0]) > 0.2 * nb * n
