@@ -66,8 +66,8 @@ def pmc_traffic(stage):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="uniform", choices=["uniform", "zipf"])
     ap.add_argument("--keys", type=int, default=N_KEYS)
     ap.add_argument("--batch", type=int, default=BATCH)
