@@ -306,6 +306,12 @@ def main():
                              want=t.Engine.RECORD_FIELDS)
             also[f"{other}_stream_full_result_records"] = {"value": a.steps * a.batch / dt4, "unit": "decisions/s",
                                                           "note": "result4: one 32-byte RateLimitResult record per request"}
+            dec = t.BatchResult()
+            dt5, _ = run_gpu(eng2, ob, dec, W.T0_NS + 3 * 10**9 + 10**8, a.steps, 2, None, None, None,
+                             want=t.Engine.DECISION_FIELDS)
+            also[f"{other}_stream_full_result_decision_records"] = {
+                "value": a.steps * a.batch / dt5, "unit": "decisions/s",
+                "note": "tc_decision: remaining, reset_after, retry_after, allowed, status in one 32-byte record"}
             # general batches: every request carries its own timestamp (strictly increasing inside
             # the batch), so the closed form does not apply and k_eval_general runs
             nows = [torch.arange(a.batch, dtype=torch.int64, device=dev) + (W.T0_NS + 4 * 10**9 + b * 10**6)

@@ -91,6 +91,7 @@ typedef struct tc_config {
 /* One batch of requests = the argument list of RateLimiter::rate_limit
  * (rate_limiter.rs:102-110), columnar.  A NULL input column means "use the
  * scalar of the same name for every request". */
+struct tc_decision;
 typedef struct tc_batch {
     uint32_t struct_size; /* = sizeof(tc_batch) */
     uint32_t flags;       /* TC_B_* */
@@ -124,7 +125,20 @@ typedef struct tc_batch {
      * retry_after_ns}: a request's result then costs one scattered store instead of four
      * (use it instead of the four columns above when all fields are wanted). 16-byte aligned. */
     int64_t* result4;        /* [n][4] */
+    struct tc_decision* decisions; /* [n] 32-byte records (see tc_decision below); 16-byte aligned */
 } tc_batch;
+
+/* Everything rate_limit returns for one request except `limit` (== the request's max_burst, resp.
+ * the key's registered burst), as ONE 32-byte record: a full result then costs a single scattered
+ * store per request instead of three (result4 + allowed + status). */
+typedef struct tc_decision {
+    int64_t remaining;
+    int64_t reset_after_ns;
+    int64_t retry_after_ns;
+    uint8_t allowed; /* 0/1 */
+    uint8_t status;  /* TC_OK / TC_NEGATIVE_QUANTITY / ... */
+    uint8_t pad[6];  /* zero */
+} tc_decision;
 
 /* Single-request result (the tuple rate_limit returns). */
 typedef struct tc_result {

@@ -144,8 +144,8 @@ class RateLimiter {
         if (!n) return out;
         std::vector<uint8_t> arena;
         std::vector<uint32_t> off(n + 1, 0);
-        std::vector<int64_t> burst(n), count(n), period(n), qty(n), now(n), limit(n), remaining(n), reset(n), retry(n);
-        std::vector<uint8_t> allowed(n), status(n);
+        std::vector<int64_t> burst(n), count(n), period(n), qty(n), now(n);
+        std::vector<tc_decision> dec(n); // one 32-byte record per request; `limit` == the request's max_burst
         for (size_t i = 0; i < n; ++i) {
             arena.insert(arena.end(), reqs[i].key.begin(), reqs[i].key.end());
             off[i + 1] = (uint32_t)arena.size();
@@ -166,18 +166,14 @@ class RateLimiter {
         b.period = period.data();
         b.quantity = qty.data();
         b.now_ns = now.data();
-        b.allowed = allowed.data();
-        b.status = status.data();
-        b.limit = limit.data();
-        b.remaining = remaining.data();
-        b.reset_after_ns = reset.data();
-        b.retry_after_ns = retry.data();
+        b.decisions = dec.data();
         int rc = tc_rate_limit_batch_keys(store_.handle(), &b);
         for (size_t i = 0; i < n; ++i) {
             if (rc != TC_E_OK && rc != TC_E_TABLE_FULL)
                 out.push_back(CellError{CellError::Internal, 0, tc_last_error(store_.handle())});
             else
-                out.push_back(outcome(status[i], allowed[i], limit[i], remaining[i], reset[i], retry[i], qty[i]));
+                out.push_back(outcome(dec[i].status, dec[i].allowed, burst[i], dec[i].remaining, dec[i].reset_after_ns,
+                                      dec[i].retry_after_ns, qty[i]));
         }
         return out;
     }

@@ -288,8 +288,7 @@ class Pipeline {
     // Returns the engine's return code (TC_E_OK, or TC_E_TABLE_FULL: those keys answer with an error).
     int run(tc_engine* e, std::string& out) {
         const size_t n = throttles();
-        std::vector<int64_t> r4(4 * n);
-        std::vector<uint8_t> allowed(n), status(n);
+        std::vector<tc_decision> dec(n); // one 32-byte record per THROTTLE; `limit` is the command's max_burst
         int rc = TC_E_OK;
         if (n) {
             if (key_bytes.empty()) key_bytes.push_back(0);
@@ -304,9 +303,7 @@ class Pipeline {
             b.period = period.data();
             b.quantity = quantity.data();
             b.now_ns = now_ns.data();
-            b.allowed = allowed.data();
-            b.status = status.data();
-            b.result4 = r4.data();
+            b.decisions = dec.data();
             rc = tc_rate_limit_batch_keys(e, &b);
         }
         const bool usable = rc == TC_E_OK || rc == TC_E_TABLE_FULL;
@@ -318,17 +315,17 @@ class Pipeline {
             const size_t i = (size_t)c.throttle;
             if (!usable) {
                 put_error(out, std::string("ERR Rate limit check failed: internal error: ") + tc_last_error(e));
-            } else if (status[i] == TC_OK) {
+            } else if (dec[i].status == TC_OK) {
                 // [allowed, limit, remaining, reset_after s, retry_after s] (mod.rs:274-283, types.rs:87-96)
                 out += "*5\r\n";
-                put_integer(out, allowed[i] ? 1 : 0);
-                put_integer(out, r4[4 * i + 0]);
-                put_integer(out, r4[4 * i + 1]);
-                put_integer(out, r4[4 * i + 2] / 1000000000LL);
-                put_integer(out, r4[4 * i + 3] / 1000000000LL);
-            } else if (status[i] == TC_NEGATIVE_QUANTITY) { // CellError Display (core/mod.rs:58-66)
+                put_integer(out, dec[i].allowed ? 1 : 0);
+                put_integer(out, max_burst[i]);
+                put_integer(out, dec[i].remaining);
+                put_integer(out, dec[i].reset_after_ns / 1000000000LL);
+                put_integer(out, dec[i].retry_after_ns / 1000000000LL);
+            } else if (dec[i].status == TC_NEGATIVE_QUANTITY) { // CellError Display (core/mod.rs:58-66)
                 put_error(out, "ERR Rate limit check failed: negative quantity: " + std::to_string(quantity[i]));
-            } else if (status[i] == TC_INVALID_RATE_LIMIT) {
+            } else if (dec[i].status == TC_INVALID_RATE_LIMIT) {
                 put_error(out, "ERR Rate limit check failed: invalid rate limit parameters");
             } else {
                 put_error(out, "ERR Rate limit check failed: internal error: outside the validated domain");

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libtcgpu.so does not export {name}"
     assert set(_lib.SYMBOLS) == set(declared), set(_lib.SYMBOLS) ^ set(declared)
     assert lib.tc_abi_version() == 1
-    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 8 * 8  # incl. result4
+    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 9 * 8  # incl. result4, decisions
     assert ctypes.sizeof(_lib.tc_config) == 40
 
 
@@ -59,7 +59,9 @@ def test_header_is_plain_c_and_links(tmp_path):
 #include <stddef.h>
 _Static_assert(sizeof(tc_config) == 40, "tc_config layout");
 _Static_assert(offsetof(tc_batch, result4) == 8 + 8 + 8 * 8 + 5 * 8 + 7 * 8, "tc_batch layout");
+_Static_assert(offsetof(tc_batch, decisions) == 8 + 8 + 8 * 8 + 5 * 8 + 8 * 8, "tc_batch layout");
 _Static_assert(sizeof(tc_result) == 40, "tc_result layout");
+_Static_assert(sizeof(tc_decision) == 32 && offsetof(tc_decision, allowed) == 24 && offsetof(tc_decision, status) == 25, "tc_decision layout");
 typedef void (*fn)(void);
 int main(void) {{
     fn p[{len(names)}];

@@ -384,6 +384,45 @@ def test_pipelined_batches_inputs_ready(own_stream, mode):
 
 
 @pytest.mark.parametrize("uniform", [True, False])
+@pytest.mark.parametrize("dev", [False, True], ids=["host", "device"])
+def test_decision_records(uniform, dev):
+    """tc_decision: remaining / reset_after / retry_after / allowed / status in one 32-byte record."""
+    import torch
+    import throttlecrab_amd as t
+    cap, n = 800, 30000
+    rng = np.random.default_rng(32)
+    eng, orc = _engine(cap), _oracle(cap)
+    eng.use_torch_stream()
+    for rnd in range(3):
+        slots = rng.integers(0, cap + 3, n).astype(np.uint32)          # a few out-of-range slots: status Internal
+        if uniform:
+            q, now = 1, T0 + rnd * 10**9
+        else:
+            q, now = rng.choice(np.array([0, 1, 2, -1], dtype=np.int64), n), T0 + rnd * 10**9 + rng.integers(0, 10**9, n)
+        keep = slots < cap
+        from oracle import oracle as O
+        part = orc.batch_slots(slots[keep], 5, 10, 60, q if uniform else q[keep], now if uniform else now[keep])
+        ref = O.BatchOut(n)
+        ref.status[:] = 3
+        for f in FIELDS:
+            getattr(ref, f)[keep] = getattr(part, f)
+        if dev:
+            tt = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).cuda()
+            kw = dict(quantity=q if uniform else tt(q), now_ns=now if uniform else tt(now))
+            res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).cuda(), max_burst=5, count_per_period=10,
+                                             period=60, want=t.Engine.DECISION_FIELDS, **kw)
+            torch.cuda.synchronize()
+        else:
+            res = eng.rate_limit_batch_slots(slots, max_burst=5, count_per_period=10, period=60, quantity=q, now_ns=now,
+                                             want=t.Engine.DECISION_FIELDS)
+        got = t.Engine.unpack_decisions(res.decisions)
+        for f in ("allowed", "status", "remaining", "reset_after_ns", "retry_after_ns"):
+            bad = np.nonzero(got[f].astype(np.int64) != getattr(ref, f).astype(np.int64))[0]
+            assert bad.size == 0, f"round {rnd}: decisions.{f} differs at {bad[:8]}"
+    eng.close()
+
+
+@pytest.mark.parametrize("uniform", [True, False])
 def test_result_records_host_pointers(uniform):
     """RateLimitResult as one 32-byte record per request == the four columns."""
     import throttlecrab_amd as t

@@ -39,7 +39,7 @@ class tc_batch(C.Structure):
                 ("period_scalar", C.c_int64), ("quantity_scalar", C.c_int64), ("now_ns_scalar", C.c_int64),
                 ("allowed", C.c_void_p), ("allowed_bits", C.c_void_p), ("limit", C.c_void_p),
                 ("remaining", C.c_void_p), ("reset_after_ns", C.c_void_p), ("retry_after_ns", C.c_void_p),
-                ("status", C.c_void_p), ("result4", C.c_void_p)]
+                ("status", C.c_void_p), ("result4", C.c_void_p), ("decisions", C.c_void_p)]
 
 
 class tc_result(C.Structure):

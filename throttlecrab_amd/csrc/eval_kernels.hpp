@@ -44,6 +44,7 @@ struct Params {
     int64_t* retry;
     uint8_t* status;
     int64_t* result4;
+    tc_decision* decisions;
     Cell* cells;
     const uint16_t* rate_id;
     const RateClass* classes;
@@ -100,6 +101,12 @@ __device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req
         longlong2* r4 = reinterpret_cast<longlong2*>(p.result4 + (size_t)i * 4);
         r4[0] = make_longlong2(ok ? r.limit : 0, ok ? d.remaining : 0);
         r4[1] = make_longlong2(ok ? d.reset_after : 0, ok ? d.retry_after : 0);
+    }
+    if (p.decisions) {
+        longlong2* dr = reinterpret_cast<longlong2*>(p.decisions + i);
+        const long long flags = (long long)((ok && d.allowed) ? 1u : 0u) | ((long long)(uint8_t)r.status << 8);
+        dr[0] = make_longlong2(ok ? d.remaining : 0, ok ? d.reset_after : 0);
+        dr[1] = make_longlong2(ok ? d.retry_after : 0, flags); // allowed | status << 8, pad = 0 (little endian)
     }
 }
 

@@ -127,6 +127,7 @@ struct tc_engine {
         uint64_t* bits = nullptr;
         int64_t* out[4] = {nullptr, nullptr, nullptr, nullptr};
         int64_t* result4 = nullptr;
+        tc_decision* decisions = nullptr;
         uint8_t* status = nullptr;
         bool ready = false;
     } stage;
@@ -450,7 +451,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
-                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4};
+                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->key_stream) {
@@ -585,6 +586,7 @@ static int stage_ensure(tc_engine* e) {
     TC_HIP(e, hipMalloc(&e->stage.bits, ((mb + 63) / 64) * sizeof(uint64_t)));
     for (int j = 0; j < 4; ++j) TC_HIP(e, hipMalloc(&e->stage.out[j], mb * sizeof(int64_t)));
     TC_HIP(e, hipMalloc(&e->stage.result4, mb * 4 * sizeof(int64_t)));
+    TC_HIP(e, hipMalloc(&e->stage.decisions, mb * sizeof(tc_decision)));
     TC_HIP(e, hipMalloc(&e->stage.status, mb));
     e->stage.ready = true;
     return TC_E_OK;
@@ -678,6 +680,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     p.retry = b.retry_after_ns;
     p.status = b.status;
     p.result4 = b.result4;
+    p.decisions = b.decisions;
     p.cells = e->cells;
     p.rate_id = e->rate_id;
     p.classes = e->classes;
@@ -689,7 +692,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
         p.flags |= F_REGISTERED;
         if (e->uniform_id) p.flags |= F_UNIFORM_CLASS;
     }
-    const bool full = p.remaining || p.reset || p.retry || p.result4;
+    const bool full = p.remaining || p.reset || p.retry || p.result4 || p.decisions;
     const dim3 grid(nblocks(n)), block(BLOCK);
     hipStream_t s = cur_stream(e);
 
@@ -782,6 +785,7 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     d.retry_after_ns = b.retry_after_ns ? e->stage.out[3] : nullptr;
     d.status = b.status ? e->stage.status : nullptr;
     d.result4 = b.result4 ? e->stage.result4 : nullptr;
+    d.decisions = b.decisions ? e->stage.decisions : nullptr;
     e->batches++;
     int rc = run_slots_device(e, d);
     if (rc != TC_E_OK) return rc;
@@ -793,6 +797,7 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
         if (hout[j]) TC_HIP(e, hipMemcpyAsync(hout[j], e->stage.out[j], n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (b.status) TC_HIP(e, hipMemcpyAsync(b.status, e->stage.status, n, hipMemcpyDeviceToHost, s));
     if (b.result4) TC_HIP(e, hipMemcpyAsync(b.result4, e->stage.result4, n * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
+    if (b.decisions) TC_HIP(e, hipMemcpyAsync(b.decisions, e->stage.decisions, n * sizeof(tc_decision), hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
     return TC_E_OK;
 }

@@ -27,7 +27,7 @@ def _is_torch(x) -> bool:
 class BatchResult:
     """Columnar (bool, RateLimitResult) + status for one batch."""
     __slots__ = ("allowed", "allowed_bits", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status",
-                 "result4")
+                 "result4", "decisions")
 
     def __init__(self):
         for s in self.__slots__:
@@ -35,7 +35,8 @@ class BatchResult:
 
 
 _NP_DTYPES = {"allowed": np.uint8, "allowed_bits": np.uint64, "limit": np.int64, "remaining": np.int64,
-              "reset_after_ns": np.int64, "retry_after_ns": np.int64, "status": np.uint8, "result4": np.int64}
+              "reset_after_ns": np.int64, "retry_after_ns": np.int64, "status": np.uint8, "result4": np.int64,
+              "decisions": np.int64}
 
 
 class Engine:
@@ -43,6 +44,16 @@ class Engine:
     # the same information with RateLimitResult as one 32-byte record per request
     # (result4[i] = limit, remaining, reset_after_ns, retry_after_ns)
     RECORD_FIELDS = ("allowed", "status", "result4")
+    # tc_decision records: decisions[i] = remaining, reset_after_ns, retry_after_ns, allowed | status << 8
+    # (everything but `limit`, which the caller knows) -- ONE scattered store per request
+    DECISION_FIELDS = ("decisions",)
+
+    @staticmethod
+    def unpack_decisions(dec):
+        """[n*4] int64 decisions column -> dict of the five fields."""
+        d = (dec.cpu().numpy() if _is_torch(dec) else np.asarray(dec)).reshape(-1, 4)
+        return {"remaining": d[:, 0], "reset_after_ns": d[:, 1], "retry_after_ns": d[:, 2],
+                "allowed": (d[:, 3] & 0xFF).astype(np.uint8), "status": ((d[:, 3] >> 8) & 0xFF).astype(np.uint8)}
 
     def __init__(self, capacity: int, max_batch: int = 1 << 20, device: int = 0, key_mode: bool = False,
                  key_arena_bytes: int = 0, track_denied: bool = False):
@@ -166,7 +177,7 @@ class Engine:
         res = out or BatchResult()
         for name in want:
             cur = getattr(res, name)
-            ln = (n + 63) // 64 if name == "allowed_bits" else (4 * n if name == "result4" else n)
+            ln = (n + 63) // 64 if name == "allowed_bits" else (4 * n if name in ("result4", "decisions") else n)
             if cur is None:
                 if dev:
                     import torch
