@@ -12,6 +12,7 @@
 
 #include "../../include/tcgpu.h"
 #include "gcra_math.hpp"
+#include "key_table.hpp"
 
 namespace ev {
 
@@ -191,6 +192,55 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
         write_out(p, i, r, d);
     }
     block_count3(na, nd, ne, p.counters);
+}
+
+// ---------------------------------------------------------------------------
+// K0: ONE request (RateLimiter::rate_limit called singly, rate_limiter.rs:102-250): one thread resolves
+// the key, evaluates and stores; one launch and one 48-byte copy back instead of the batch pipeline.
+// ---------------------------------------------------------------------------
+struct InlineKey {
+    uint8_t bytes[64];
+    uint32_t len;
+    uint32_t is_inline;
+};
+struct OneResult {
+    tc_decision d;
+    int64_t limit;
+    uint32_t table_full;
+    uint32_t pad;
+};
+__global__ void k_rate_limit_one(Params p, kt::Table t, int key_mode, InlineKey ik, const uint8_t* __restrict__ long_key,
+                                 uint32_t slot_in, OneResult* __restrict__ out, unsigned long long* inserted) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t slot = slot_in;
+    bool full = false;
+    if (key_mode) slot = kt::find_or_bind_one(t, ik.is_inline ? ik.bytes : long_key, ik.len, true, &full, inserted);
+    Req r = make_req(p, 0, slot < p.capacity ? slot : (uint32_t)p.capacity); // unresolved key: Internal
+    Decision d;
+    d.allowed = false;
+    d.remaining = d.reset_after = d.retry_after = 0;
+    unsigned long long* shard = p.counters + (TC_CNT_COUNT + 1); // shard 0: allowed, denied, errors
+    if (r.status == tc::ST_OK) {
+        Cell c = tc::load_cell(&p.cells[slot]);
+        d = tc::gcra_step<true>(c, r.ei, r.dvt, r.q, r.now);
+        if (d.allowed) tc::store_cell(&p.cells[slot], c);
+        atomicAdd(&shard[d.allowed ? 0 : 1], 1ull);
+        if (p.denied && !d.allowed) atomicAdd(&p.denied[slot], 1u);
+    } else {
+        atomicAdd(&shard[2], 1ull);
+    }
+    const bool ok = r.status == tc::ST_OK;
+    OneResult o;
+    o.d.remaining = ok ? d.remaining : 0;
+    o.d.reset_after_ns = ok ? d.reset_after : 0;
+    o.d.retry_after_ns = ok ? d.retry_after : 0;
+    o.d.allowed = (ok && d.allowed) ? 1 : 0;
+    o.d.status = (uint8_t)r.status;
+    for (int i = 0; i < 6; ++i) o.d.pad[i] = 0;
+    o.limit = ok ? r.limit : 0;
+    o.table_full = full ? 1u : 0u;
+    o.pad = 0;
+    *out = o;
 }
 
 // block-wide inclusive max-scan (values are position+1, 0 = none)

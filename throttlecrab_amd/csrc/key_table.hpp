@@ -293,6 +293,59 @@ __global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uin
     }
 }
 
+// One key, one thread, no other key stage running: find the key's slot or (insert) bind a fresh one.
+// The single-request path (tc_rate_limit) uses this instead of the three-kernel batch protocol.
+// Returns NO_SLOT if the key is absent (lookup) or cannot be bound (*full = true).
+__device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32_t len, bool insert, bool* full,
+                                            unsigned long long* inserted_counter) {
+    const uint64_t h = hash_key(key, len);
+    const uint32_t tag = (uint32_t)(h >> 32);
+    uint64_t pos = h & t.nb_mask;
+    for (uint64_t probes = 0; probes <= t.nb_mask; ++probes, pos = (pos + 1) & t.nb_mask) {
+        const unsigned long long e = t.ktab[pos];
+        const uint32_t val = (uint32_t)e;
+        if (e == 0ull) {
+            if (!insert) return NO_SLOT;
+            unsigned long long ovf = 0;
+            if (len > INLINE_KEY) {
+                ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
+                if (ovf + len > t.overflow_bytes) break;
+            }
+            const int old = atomicSub(t.free_top, 1);
+            if (old <= 0) {
+                atomicAdd(t.free_top, 1);
+                break;
+            }
+            const uint32_t slot = t.free_slots[old - 1];
+            KeyRec& kr = t.rec[slot];
+            uint8_t* dst = kr.bytes;
+            if (len > INLINE_KEY) {
+                const uint64_t o64 = ovf;
+                __builtin_memcpy(kr.bytes, &o64, 8);
+                dst = t.overflow + ovf;
+            }
+            for (uint32_t b = 0; b < len; ++b) dst[b] = key[b];
+            kr.hash = h;
+            kr.len = len;
+            kr.pos = (uint32_t)pos;
+            t.bound[slot] = 1;
+            t.ktab[pos] = ((unsigned long long)tag << 32) | (unsigned long long)(slot + 2u);
+            atomicAdd(inserted_counter, 1ull);
+            return slot;
+        }
+        if (val == VAL_TOMB || (val & VAL_PENDING)) continue; // (no batch is in flight: no pending claims)
+        if ((uint32_t)(e >> 32) == tag) {
+            const uint32_t s = val - 2u;
+            if (t.rec[s].hash == h && t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len)) return s;
+        }
+    }
+    if (insert) {
+        *full = true;
+        atomicExch(t.error_flag, 1u);
+    }
+    return NO_SLOT;
+}
+
 // Rebuild (tombstones lengthen probe chains and are never reused): decided ON THE DEVICE so that
 // a sweep never waits for the host -- k_rebuild_decide latches "tombstones > 1/4 of the table" into
 // a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (three near-empty

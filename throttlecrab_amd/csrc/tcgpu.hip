@@ -118,6 +118,7 @@ struct tc_engine {
     uint32_t* pend_count = nullptr;
     uint8_t* allowed_tmp = nullptr;
     StoreOpResult* op_result = nullptr;
+    OneResult* one_result = nullptr; // tc_rate_limit: the single request's result
 
     // staging for host-pointer batches (lazy)
     struct Stage {
@@ -258,6 +259,7 @@ static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
     TC_HIP(e, hipMalloc(&e->op_result, sizeof(StoreOpResult)));
+    TC_HIP(e, hipMalloc(&e->one_result, sizeof(OneResult)));
     TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
     return TC_E_OK;
 }
@@ -449,7 +451,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
             if (p) (void)hipFree(p);
     }
     void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
-                    e->allowed_tmp, e->op_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
+                    e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions};
     for (void* p : ptrs)
@@ -881,45 +883,72 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
                              int64_t count_per_period, int64_t period, int64_t quantity, int64_t now_ns,
                              tc_result* out) {
     if (!e || !out || (!key && key_len)) return TC_E_INVALID_ARG;
+    if (key_len > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "key too long");
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
     uint32_t slot = 0;
-    uint32_t off[2] = {0u, (uint32_t)key_len};
-    uint8_t allowed = 0, status = 0;
-    int64_t limit = 0, remaining = 0, reset = 0, retry = 0;
-    tc_batch b;
-    memset(&b, 0, sizeof b);
-    b.struct_size = sizeof b;
-    b.n = 1;
-    b.max_burst_scalar = max_burst;
-    b.count_per_period_scalar = count_per_period;
-    b.period_scalar = period;
-    b.quantity_scalar = quantity;
-    b.now_ns_scalar = now_ns;
-    b.allowed = &allowed;
-    b.status = &status;
-    b.limit = &limit;
-    b.remaining = &remaining;
-    b.reset_after_ns = &reset;
-    b.retry_after_ns = &retry;
-    int rc;
+    InlineKey ik;
+    memset(&ik, 0, sizeof ik);
+    const uint8_t* d_long = nullptr;
     if (e->key_mode) {
-        static const uint8_t empty = 0;
-        b.key_bytes = key_len ? key : &empty;
-        b.key_off = off;
-        rc = tc_rate_limit_batch_keys(e, &b);
+        ik.len = (uint32_t)key_len;
+        ik.is_inline = key_len <= sizeof ik.bytes;
+        if (ik.is_inline) {
+            if (key_len) memcpy(ik.bytes, key, key_len);
+        } else { // long key: through the staging arena
+            const uint32_t off[2] = {0u, (uint32_t)key_len};
+            const uint32_t* d_off;
+            int rc = stage_keys(e, key, off, 1, &d_long, &d_off);
+            if (rc != TC_E_OK) return rc;
+        }
+        if (e->k_busy) { // key stages on the key stream come first
+            TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+            e->k_busy = false;
+        }
     } else {
         // slot-mode engines: the key is the 4-byte little-endian slot id
         if (key_len != 4) return fail(e, TC_E_INVALID_ARG, "slot-mode engine: key must be a 4-byte slot id");
         memcpy(&slot, key, 4);
-        b.slot = &slot;
-        rc = tc_rate_limit_batch_slots(e, &b);
     }
-    if (rc != TC_E_OK) return rc;
-    out->allowed = allowed;
-    out->status = status;
-    out->limit = limit;
-    out->remaining = remaining;
-    out->reset_after_ns = reset;
-    out->retry_after_ns = retry;
+    Params p;
+    memset(&p, 0, sizeof p);
+    p.n = 1;
+    p.burst_s = max_burst;
+    p.count_s = count_per_period;
+    p.period_s = period;
+    p.q_s = quantity;
+    p.now_s = now_ns;
+    p.cells = e->cells;
+    p.rate_id = e->rate_id;
+    p.classes = e->classes;
+    p.capacity = e->capacity;
+    p.counters = e->counters;
+    p.denied = e->denied;
+    prof_begin(e, TC_STAGE_EVAL, s);
+    hipLaunchKernelGGL(k_rate_limit_one, dim3(1), dim3(64), 0, s, p, e->kt, e->key_mode ? 1 : 0, ik, d_long, slot, e->one_result,
+                       e->counters + TC_CNT_KEYS_INSERTED);
+    prof_end(e, s);
+    TC_HIP(e, hipGetLastError());
+    if (e->key_mode) { // the key table may have changed: later key stages on the key stream wait for this
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
+    }
+    OneResult r;
+    TC_HIP(e, hipMemcpyAsync(&r, e->one_result, sizeof r, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    e->batches++;
+    if (r.table_full) {
+        uint32_t zero = 0;
+        TC_HIP(e, hipMemcpyAsync(e->kt.error_flag, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+        TC_HIP(e, hipStreamSynchronize(s));
+        return fail(e, TC_E_TABLE_FULL, "key table full: the key got status Internal (raise capacity or sweep)");
+    }
+    out->allowed = r.d.allowed;
+    out->status = r.d.status;
+    out->limit = r.limit;
+    out->remaining = r.d.remaining;
+    out->reset_after_ns = r.d.reset_after_ns;
+    out->retry_after_ns = r.d.retry_after_ns;
     return TC_E_OK;
 }
 
