@@ -142,6 +142,10 @@ class RateLimiter {
         std::vector<RateLimitOutcome> out;
         out.reserve(n);
         if (!n) return out;
+        if (n <= 4) { // a lightly loaded queue: single calls (one launch each, ~30 us) beat the batch pipeline (~200 us)
+            for (const Request& r : reqs) out.push_back(rate_limit(r.key, r.max_burst, r.count_per_period, r.period, r.quantity, r.now));
+            return out;
+        }
         std::vector<uint8_t> arena;
         std::vector<uint32_t> off(n + 1, 0);
         std::vector<int64_t> burst(n), count(n), period(n), qty(n), now(n);
