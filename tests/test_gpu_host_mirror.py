@@ -49,3 +49,15 @@ def test_cpp_metrics_text_program():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "all tests passed" in out.stdout
+
+
+def test_cpp_kernel_math_properties_on_host():
+    """gcra_math.hpp compiled for the host: closed form == sequence, the host-side proof behind the
+    direct-store evaluation, late readers harmless (tests/cpp/test_math_host.hip). No GPU needed."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_math_host")
+    src = os.path.join(ROOT, "tests", "cpp", "test_math_host.hip")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-ffp-contract=off", src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
