@@ -44,7 +44,12 @@ using namespace mk;
 
 namespace {
 
-constexpr int SORT_ITEMS = 8;  // items per thread of a sort tile (tile = 2048 requests; 512 tiles per 1 Mi batch)
+// Items per thread of a sort tile.  Alone on the chip, 2048-request tiles (512 blocks per 1 Mi batch) are
+// fastest (18.6 vs 21.1 us per pass).  Pipelined, the tiles of up to three sorts spin in their look-back
+// next to the evaluation kernel and every one of them holds 4 wave slots: 4096-request tiles halve that
+// (evaluation 63 -> 56 us under overlap, 13.9 -> 15.1 G decisions/s).
+constexpr int SORT_ITEMS = 8;        // batches that run in order on the engine's stream
+constexpr int SORT_ITEMS_PIPED = 16; // TC_B_INPUTS_READY batches (grouped on the auxiliary streams)
 constexpr int PIPE_DEPTH_MAX = 8;
 constexpr int AUX_MAX = 4;                  // auxiliary (grouping) streams
 // HIP multiplexes streams onto 4 hardware queues; two ACTIVE streams on one queue serialise each other
@@ -596,11 +601,12 @@ static int stage_ensure(tc_engine* e) {
 
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
 // returns the buffer holding the result
-static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n) {
+static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
+                                    bool piped) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
     const int passes = (bits + 7) / 8;
-    const uint32_t tile = rs::THREADS * SORT_ITEMS;
+    const uint32_t tile = rs::THREADS * (piped ? SORT_ITEMS_PIPED : SORT_ITEMS);
     const uint32_t tiles = (n + tile - 1) / tile;
     const rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
     ss.hist_parity ^= 1u;
@@ -613,12 +619,21 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
         prof_begin(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
-        if (p == 0)
-            hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                               (const uint64_t*)nullptr, out, n, cap, p, ws);
-        else
-            hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
-                               (const uint32_t*)nullptr, in, out, n, cap, p, ws);
+        if (p == 0) {
+            if (piped)
+                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
+                                   (const uint64_t*)nullptr, out, n, cap, p, ws);
+            else
+                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
+                                   (const uint64_t*)nullptr, out, n, cap, p, ws);
+        } else {
+            if (piped)
+                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
+                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws);
+            else
+                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
+                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws);
+        }
         prof_end(e, s);
         in = out;
     }
@@ -715,13 +730,13 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
             e->next_aux = (e->next_aux + 1) % e->n_aux;
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
             if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
-            sorted = sort_by_slot(e, ss, ax, b.slot, n);
+            sorted = sort_by_slot(e, ss, ax, b.slot, n, true);
             TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
         } else {
             // everything that used this set earlier is ordered before us on `s`: evaluations ran on `s`,
             // and every auxiliary sort was joined into `s` before its evaluation
-            sorted = sort_by_slot(e, ss, s, b.slot, n);
+            sorted = sort_by_slot(e, ss, s, b.slot, n, false);
         }
         const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!p.burst && !p.count && !p.period);
         const bool uniform = !p.q && !p.now && params_by_slot;
