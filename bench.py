@@ -28,14 +28,12 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-# HIP multiplexes streams onto 4 hardware queues by default.  The engine uses the main stream + 2
-# auxiliary grouping streams (+ 1 key stream); RCCL and torch add their own.  A main stream that
-# shares a hardware queue with a grouping stream serialises the pipeline (measured 12 -> 5.7 G/s),
-# so ask the runtime for 8 queues before HIP initialises.
+# HIP multiplexes streams onto 4 hardware queues by default.  The engine uses the main stream + 3
+# grouping streams (+ 1 key stream); RCCL and torch add their own.  A main stream that shares a
+# hardware queue with a grouping stream serialises the pipeline (measured 12 -> 5.7 G/s); the engine
+# probes its side streams against the main stream and keeps only those that run concurrently, and
+# asking the runtime for 8 queues before HIP initialises gives it more to choose from.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-if int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("TC_BENCH_FORCE_DIST") == "1":
-    # RCCL brings its own stream: leave it a hardware queue (main + 2 grouping streams + RCCL = 4)
-    os.environ.setdefault("TCGPU_AUX_STREAMS", "2")
 
 N_KEYS = 10_000_000
 BATCH = 1 << 20

@@ -239,4 +239,22 @@ __global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_
     *out = r;
 }
 
+// ---------------------------------------------------------------------------
+// Do two streams run concurrently?  HIP multiplexes streams onto a few hardware queues (round robin
+// at creation); two streams on one queue execute in order.  k_probe_spin (on stream A) waits for a
+// flag that only k_probe_set (on stream B) raises, or gives up after `timeout` ticks of the 100 MHz
+// wall clock: if it saw the flag, B ran while A was running.
+// ---------------------------------------------------------------------------
+__global__ void k_probe_spin(uint32_t* flag, uint32_t* saw, long long timeout) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    uint32_t v = 0;
+    while ((v = __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u && wall_clock64() - t0 < timeout)
+        __builtin_amdgcn_s_sleep(8);
+    *saw = v;
+}
+__global__ void k_probe_set(uint32_t* flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 } // namespace mk

@@ -111,6 +111,11 @@ struct tc_engine {
     hipStream_t aux[AUX_MAX] = {};       // set k groups on aux[k % n_aux]
     uint32_t n_aux = 0;
     uint32_t next_aux = 0;
+    uint32_t n_aux_want = 0;             // configured number of grouping streams
+    hipStream_t side_for = nullptr;      // main stream the side streams were probed against
+    bool side_ready = false;
+    int aux_priority = 0;
+    uint32_t* probe_ws = nullptr;        // {flag, saw}
     uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
     PendEntry* pend = nullptr;
@@ -244,8 +249,10 @@ static int engine_alloc(tc_engine* e) {
     const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
     // the evaluation kernel on the main stream is the critical path of the pipeline: grouping runs at
     // the lowest priority and fills what the evaluation leaves free (TCGPU_AUX_PRIORITY=1 flips it)
-    for (uint32_t ai = 0; ai < e->n_aux; ++ai)
-        TC_HIP(e, hipStreamCreateWithPriority(&e->aux[ai], hipStreamNonBlocking, aux_high ? prio_hi : prio_lo));
+    e->n_aux_want = e->n_aux;
+    e->aux_priority = aux_high ? prio_hi : prio_lo;
+    TC_HIP(e, hipMalloc(&e->probe_ws, 2 * sizeof(uint32_t)));
+    // (the grouping streams themselves are created by ensure_side_streams, against the actual main stream)
     for (uint32_t si = 0; si < e->depth; ++si) {
         tc_engine::SortSet& ss = e->sets[si];
         TC_HIP(e, hipMalloc(&ss.elem_a, mb * sizeof(uint64_t)));
@@ -309,7 +316,6 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->k_slot, mb * 4));
     for (uint32_t si = 0; si < e->depth; ++si) TC_HIP(e, hipMalloc(&e->sets[si].k_slot, mb * 4));
-    TC_HIP(e, hipStreamCreateWithFlags(&e->key_stream, hipStreamNonBlocking));
     TC_HIP(e, hipEventCreateWithFlags(&e->k_done, hipEventDisableTiming));
     TC_HIP(e, hipEventCreateWithFlags(&e->m_done, hipEventDisableTiming));
     TC_HIP(e, hipMalloc(&e->k_state, mb * 4));
@@ -319,6 +325,64 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
     e->key_mode = true;
     return TC_E_OK;
+}
+
+// true if work on `b` runs while work on `a` is running (different hardware queues)
+static int streams_concurrent(tc_engine* e, hipStream_t a, hipStream_t b, bool* out) {
+    uint32_t zero[2] = {0u, 0u}, saw = 0;
+    TC_HIP(e, hipMemcpyAsync(e->probe_ws, zero, sizeof zero, hipMemcpyHostToDevice, a));
+    TC_HIP(e, hipStreamSynchronize(a));
+    TC_HIP(e, hipStreamSynchronize(b));
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, e->probe_ws, e->probe_ws + 1, 30000LL); // <= 300 us
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(64), 0, b, e->probe_ws);
+    TC_HIP(e, hipGetLastError());
+    TC_HIP(e, hipStreamSynchronize(a));
+    TC_HIP(e, hipStreamSynchronize(b));
+    TC_HIP(e, hipMemcpy(&saw, e->probe_ws + 1, sizeof saw, hipMemcpyDeviceToHost));
+    *out = saw != 0u;
+    return TC_E_OK;
+}
+
+// The grouping streams (and the key stream) must not share a hardware queue with the main stream or
+// with each other: two active streams on one queue serialise, which costs the pipeline half its
+// throughput.  Which queue a new stream lands on depends on everything the
+// process created before (torch, RCCL, other engines), so candidates are created and PROBED against
+// the main stream in use; the ones that do not run concurrently are dropped.  ~0.5 ms, once per main stream.
+static int ensure_side_streams(tc_engine* e) {
+    hipStream_t m = cur_stream(e);
+    if (e->side_ready && e->side_for == m) return TC_E_OK;
+    TC_HIP(e, hipStreamSynchronize(m));
+    for (hipStream_t& a : e->aux)
+        if (a) {
+            TC_HIP(e, hipStreamSynchronize(a));
+            (void)hipStreamDestroy(a);
+            a = nullptr;
+        }
+    if (e->key_stream) {
+        TC_HIP(e, hipStreamSynchronize(e->key_stream));
+        (void)hipStreamDestroy(e->key_stream);
+        e->key_stream = nullptr;
+    }
+    const uint32_t want = e->n_aux_want + (e->key_mode ? 1u : 0u);
+    std::vector<hipStream_t> good, bad;
+    for (int c = 0; c < 16 && good.size() < want; ++c) {
+        hipStream_t s = nullptr;
+        TC_HIP(e, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, e->aux_priority));
+        bool ok = false;
+        int rc = streams_concurrent(e, m, s, &ok);
+        for (size_t g = 0; rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
+        if (rc != TC_E_OK) return rc;
+        (ok ? good : bad).push_back(s);
+    }
+    for (hipStream_t s : bad) (void)hipStreamDestroy(s);
+    size_t gi = 0;
+    if (e->key_mode && !good.empty()) e->key_stream = good[gi++];
+    e->n_aux = 0;
+    for (; gi < good.size() && e->n_aux < (uint32_t)AUX_MAX; ++gi) e->aux[e->n_aux++] = good[gi];
+    e->next_aux = 0;
+    e->side_for = m;
+    e->side_ready = true;
+    return TC_E_OK; // n_aux == 0: no free hardware queue, TC_B_INPUTS_READY batches run in order on the main stream
 }
 
 // keys (device arena) -> out_slot[0..n): found slot, freshly bound slot, or NO_SLOT.
@@ -455,7 +519,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
+    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions};
@@ -482,6 +546,7 @@ extern "C" int tc_engine_set_stream(tc_engine* e, void* hip_stream) {
     TC_HIP(e, hipSetDevice(e->device));
     if (e->user_stream || e->own_stream) TC_HIP(e, hipStreamSynchronize(cur_stream(e))); // drain the old one first
     e->user_stream = (hipStream_t)hip_stream;
+    e->side_ready = false; // the side streams are probed against the main stream in use
     return TC_E_OK;
 }
 
@@ -723,7 +788,12 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
         // (overlaps with the evaluation of earlier batches), else in order on `s`
         tc_engine::SortSet& ss = e->sets[e->next_set];
         e->next_set = (e->next_set + 1) % e->depth;
-        const bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        if (piped) {
+            int rc = ensure_side_streams(e);
+            if (rc != TC_E_OK) return rc;
+            piped = e->n_aux != 0; // no free hardware queue: in order on the main stream
+        }
         const uint64_t* sorted;
         if (piped) {
             hipStream_t ax = e->aux[e->next_aux];
@@ -873,11 +943,17 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     if (dev) {
         // the slots go into the scratch set the grouping stage is about to use
         tc_engine::SortSet& ss = e->sets[e->next_set];
-        const bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        if (piped) {
+            int rc = ensure_side_streams(e);
+            if (rc != TC_E_OK) return rc;
+            piped = e->key_stream != nullptr && e->n_aux != 0;
+        }
         if (piped && ss.in_use) TC_HIP(e, hipStreamWaitEvent(e->key_stream, ss.consumed, 0)); // ss.k_slot is free again
         int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, ss.k_slot, piped);
         if (rc != TC_E_OK) return rc;
         if (piped) e->wait_before_sort = e->k_done;
+        else s.flags &= ~TC_B_INPUTS_READY; // the slots were resolved on the main stream: group there too
         s.slot = ss.k_slot;
         e->batches++;
         return run_slots_device(e, s);
