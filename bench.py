@@ -54,7 +54,7 @@ def pmc_traffic(stage):
     if not files:
         return None
     ks = json.load(open(files[-1]))["kernels"]
-    want = {"eval": "k_eval_sorted<false>", "sort": "k_onesweep", "prep": "k_hist", "commit": "k_commit_list"}.get(stage)
+    want = {"eval": "k_eval_sorted<false", "sort": "k_onesweep", "prep": "k_hist", "commit": "k_commit_list"}.get(stage)
     for name, v in ks.items():
         if want and want in name:
             return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
