@@ -7,14 +7,17 @@
 // depend on the hash function (same as the reference with ahash).
 //
 // Layout (all in HBM):
-//   ktab[NB]        u64 open-addressing table, linear probing, NB = 2^k >= 2*capacity
-//                   entry = tag(32) << 32 | val(32);  val: 0 empty, 1 tombstone,
-//                   >= 2 bound to slot val-2, bit 31 set = "being inserted by
-//                   request (val & 0x7fffffff) of the current batch"
-//   rec[cap]        one 64-byte KeyRec per slot: full hash, key length, position of
-//                   the slot's ktab entry (for unbinding) and the key bytes inline
-//                   (<= 48 B; a longer key keeps an 8-byte offset into the overflow
-//                   arena).  Confirming a tag hit is ONE 64-byte access.
+//   ktab[NB]        open-addressing table of 32-byte Entry records, linear probing, NB = 2^k >= 2*capacity
+//                   w    = val(32) | tag(24) << 32 | len8 << 56;  val: 0 empty, 1 tombstone, >= 2 bound to
+//                          slot val-2, bit 31 set = "being inserted by request (val & 0x7fffffff) of the
+//                          current batch"; len8 = key length if <= 16, else 255
+//                   hash = full hash of the bound key
+//                   key  = the key itself, zero padded, when it is at most 16 bytes long
+//                   A key of up to 16 bytes ("user:123", "key_1234567") is therefore found and CONFIRMED
+//                   with one 32-byte access; longer keys are confirmed against their slot's KeyRec.
+//   rec[cap]        one 64-byte KeyRec per slot: full hash, key length, position of the slot's ktab entry
+//                   (for unbinding) and the key bytes inline (<= 48 B; a longer key keeps an 8-byte offset
+//                   into the overflow arena)
 //   bound[cap]      u8 1 = slot has a key (the compact column the expiry sweep scans:
 //                   walking the 64-byte records would read 4x the bytes)
 //   free_slots[cap] stack of unbound slots, free_top = number of free slots
@@ -37,7 +40,15 @@ constexpr int BIND_THREADS = 1024; // k_bind: one free-stack pop per block, so f
 constexpr uint32_t VAL_EMPTY = 0u, VAL_TOMB = 1u, VAL_PENDING = 0x80000000u;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 constexpr uint32_t ST_FOUND = 0u, ST_CLAIMANT = 1u, ST_FOLLOWER = 2u, ST_MISSING = 3u;
-constexpr uint32_t INLINE_KEY = 48u;
+constexpr uint32_t INLINE_KEY = 48u;  // KeyRec
+constexpr uint32_t ENTRY_KEY = 16u;   // Entry
+constexpr uint32_t LEN8_LONG = 255u;
+
+struct __attribute__((aligned(32))) Entry {
+    unsigned long long w;
+    uint64_t hash;
+    uint64_t key[2];
+};
 
 struct __attribute__((aligned(64))) KeyRec {
     uint64_t hash;
@@ -47,7 +58,7 @@ struct __attribute__((aligned(64))) KeyRec {
 };
 
 struct Table {
-    unsigned long long* ktab;
+    Entry* ktab;
     uint64_t nb_mask;
     KeyRec* rec;
     uint8_t* bound;
@@ -60,6 +71,13 @@ struct Table {
     uint32_t* error_flag;   // != 0: a key could not be bound (no slot / no overflow space)
     uint32_t capacity;
 };
+
+// upper half of Entry::w for a key: 24 tag bits of the hash + len8
+__device__ __forceinline__ unsigned long long entry_meta(uint64_t h, uint32_t len) {
+    const unsigned long long tag = (h >> 40) & 0xFFFFFFull;
+    const unsigned long long len8 = len <= ENTRY_KEY ? len : LEN8_LONG;
+    return (tag << 32) | (len8 << 56);
+}
 
 __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
@@ -124,6 +142,18 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, 
     return i == len || load_tail(a + i, len - i) == load_tail(b + i, len - i);
 }
 
+// a key of at most 16 bytes as two zero-padded little-endian words (what Entry::key holds)
+__device__ __forceinline__ void short_key_words(const uint8_t* __restrict__ p, uint32_t len, uint64_t& k0, uint64_t& k1) {
+    k0 = k1 = 0;
+    if (len >= 8) {
+        __builtin_memcpy(&k0, p, 8);
+        if (len == 16) __builtin_memcpy(&k1, p + 8, 8);
+        else if (len > 8) k1 = load_tail(p + 8, len - 8);
+    } else if (len) {
+        k0 = load_tail(p, len);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // probe: one lane per request.  INSERT: unseen keys claim an entry.
 // outputs: slot_out[i] (found), state[i], aux[i] (claimant: ktab position;
@@ -139,17 +169,20 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
     const uint32_t off = key_off[i], len = key_off[i + 1] - off;
     const uint8_t* key = key_bytes + off;
     const uint64_t h = hash_key(key, len);
-    const uint32_t tag = (uint32_t)(h >> 32);
+    const unsigned long long meta = entry_meta(h, len);
+    uint64_t k0 = 0, k1 = 0;
+    if (len <= ENTRY_KEY) short_key_words(key, len, k0, k1);
     hash_out[i] = h;
     uint64_t pos = h & t.nb_mask;
     uint32_t st = ST_MISSING, slot = NO_SLOT, ax = 0;
     for (uint64_t probes = 0; probes <= t.nb_mask; ++probes) {
-        unsigned long long e = __hip_atomic_load(&t.ktab[pos], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        Entry* en = &t.ktab[pos];
+        unsigned long long e = __hip_atomic_load(&en->w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (e == 0ull) {
             if (!INSERT) break;
-            const unsigned long long mine = ((unsigned long long)tag << 32) | (VAL_PENDING | i);
+            const unsigned long long mine = meta | (unsigned long long)(VAL_PENDING | i);
             unsigned long long expected = 0ull;
-            if (__hip_atomic_compare_exchange_strong(&t.ktab[pos], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+            if (__hip_atomic_compare_exchange_strong(&en->w, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
                                                      __HIP_MEMORY_SCOPE_AGENT)) {
                 st = ST_CLAIMANT;
                 ax = (uint32_t)pos;
@@ -157,11 +190,12 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
             }
             e = expected; // somebody else took this entry: examine what is there now
         }
-        const uint32_t val = (uint32_t)e, etag = (uint32_t)(e >> 32);
+        const uint32_t val = (uint32_t)e;
+        const bool meta_eq = (e & 0xFFFFFFFF00000000ull) == meta;
         if (val == VAL_TOMB) {
             // skip; tombstones are only reclaimed by a rebuild
         } else if (val & VAL_PENDING) {
-            if (etag == tag) {
+            if (meta_eq) {
                 const uint32_t j = val & ~VAL_PENDING; // request index of the claimant (this batch)
                 const uint32_t joff = key_off[j], jlen = key_off[j + 1] - joff;
                 if (jlen == len && bytes_equal(key_bytes + joff, key, len)) {
@@ -170,9 +204,13 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
                     break;
                 }
             }
-        } else if (etag == tag) {
+        } else if (meta_eq && en->hash == h) {
+            // bound in an earlier batch: hash / key / record are stable
             const uint32_t s = val - 2u;
-            if (t.rec[s].hash == h && t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len)) {
+            bool same;
+            if (len <= ENTRY_KEY) same = en->key[0] == k0 && en->key[1] == k1;
+            else same = t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len);
+            if (same) {
                 st = ST_FOUND;
                 slot = s;
                 break;
@@ -267,10 +305,16 @@ __global__ __launch_bounds__(BIND_THREADS) void k_bind(Table t, const uint8_t* _
             kr.len = len;
             kr.pos = pos;
             t.bound[slot] = 1;
-            t.ktab[pos] = ((unsigned long long)(uint32_t)(h >> 32) << 32) | (unsigned long long)(slot + 2u);
+            Entry* en = &t.ktab[pos];
+            uint64_t k0 = 0, k1 = 0;
+            if (len <= ENTRY_KEY) short_key_words(key, len, k0, k1);
+            en->hash = h;
+            en->key[0] = k0;
+            en->key[1] = k1;
+            en->w = entry_meta(h, len) | (unsigned long long)(slot + 2u);
             bound = true;
         } else {
-            t.ktab[pos] = ((unsigned long long)(uint32_t)(h >> 32) << 32) | VAL_TOMB;
+            t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
             atomicAdd(t.tombs, 1u);
             atomicExch(t.error_flag, 1u);
         }
@@ -299,10 +343,13 @@ __global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uin
 __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32_t len, bool insert, bool* full,
                                             unsigned long long* inserted_counter) {
     const uint64_t h = hash_key(key, len);
-    const uint32_t tag = (uint32_t)(h >> 32);
+    const unsigned long long meta = entry_meta(h, len);
+    uint64_t k0 = 0, k1 = 0;
+    if (len <= ENTRY_KEY) short_key_words(key, len, k0, k1);
     uint64_t pos = h & t.nb_mask;
     for (uint64_t probes = 0; probes <= t.nb_mask; ++probes, pos = (pos + 1) & t.nb_mask) {
-        const unsigned long long e = t.ktab[pos];
+        Entry* en = &t.ktab[pos];
+        const unsigned long long e = en->w;
         const uint32_t val = (uint32_t)e;
         if (e == 0ull) {
             if (!insert) return NO_SLOT;
@@ -329,14 +376,19 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
             kr.len = len;
             kr.pos = (uint32_t)pos;
             t.bound[slot] = 1;
-            t.ktab[pos] = ((unsigned long long)tag << 32) | (unsigned long long)(slot + 2u);
+            en->hash = h;
+            en->key[0] = k0;
+            en->key[1] = k1;
+            en->w = meta | (unsigned long long)(slot + 2u);
             atomicAdd(inserted_counter, 1ull);
             return slot;
         }
         if (val == VAL_TOMB || (val & VAL_PENDING)) continue; // (no batch is in flight: no pending claims)
-        if ((uint32_t)(e >> 32) == tag) {
+        if ((e & 0xFFFFFFFF00000000ull) == meta && en->hash == h) {
             const uint32_t s = val - 2u;
-            if (t.rec[s].hash == h && t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len)) return s;
+            const bool same = len <= ENTRY_KEY ? (en->key[0] == k0 && en->key[1] == k1)
+                                               : (t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len));
+            if (same) return s;
         }
     }
     if (insert) {
@@ -356,8 +408,11 @@ __global__ void k_rebuild_decide(Table t, uint32_t* __restrict__ flag) {
 
 __global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32_t* __restrict__ flag) {
     if (*flag == 0u) return;
-    for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i <= t.nb_mask; i += (uint64_t)gridDim.x * THREADS)
-        t.ktab[i] = 0ull;
+    // 32-byte entries as two 16-byte stores per thread
+    ulonglong2* raw = reinterpret_cast<ulonglong2*>(t.ktab);
+    const uint64_t n16 = (t.nb_mask + 1) * 2;
+    for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * THREADS)
+        raw[i] = make_ulonglong2(0ull, 0ull);
 }
 
 // re-enter every bound slot into the cleared table
@@ -367,12 +422,21 @@ __global__ __launch_bounds__(THREADS) void k_reinsert(Table t, const uint32_t* _
     for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
         if (!t.bound[s]) continue;
         const uint64_t h = t.rec[s].hash;
-        const unsigned long long mine = ((unsigned long long)(uint32_t)(h >> 32) << 32) | (unsigned long long)(s + 2u);
+        const uint32_t len = t.rec[s].len;
+        const unsigned long long meta = entry_meta(h, len);
         uint64_t pos = h & t.nb_mask;
         while (true) {
+            // claim with the pending pattern (nobody probes during a rebuild), fill, publish
             unsigned long long expected = 0ull;
-            if (__hip_atomic_compare_exchange_strong(&t.ktab[pos], &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)) {
+            if (__hip_atomic_compare_exchange_strong(&t.ktab[pos].w, &expected, meta | (unsigned long long)VAL_PENDING,
+                                                     __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                Entry* en = &t.ktab[pos];
+                uint64_t k0 = 0, k1 = 0;
+                if (len <= ENTRY_KEY) short_key_words(t.rec[s].bytes, len, k0, k1);
+                en->hash = h;
+                en->key[0] = k0;
+                en->key[1] = k1;
+                en->w = meta | (unsigned long long)(s + 2u);
                 t.rec[s].pos = (uint32_t)pos;
                 break;
             }

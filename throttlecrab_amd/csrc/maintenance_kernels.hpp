@@ -102,7 +102,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, 
         if (fill + total > (uint32_t)SWEEP_BUF) flush();
         if (unbind) {
             const uint32_t pos = t.rec[i].pos;
-            t.ktab[pos] = (t.ktab[pos] & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
+            t.ktab[pos].w = (t.ktab[pos].w & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
             t.bound[i] = 0;
             if (denied) denied[i] = 0; // the slot will serve another key
             s_buf[fill + rank] = (uint32_t)i;

@@ -291,14 +291,14 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
         off = align_up(off + bytes, 256);
         return at;
     };
-    const size_t o_ktab = take(nb * 8), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(overflow),
+    const size_t o_ktab = take(nb * sizeof(kt::Entry)), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(overflow),
                  o_free = take(cap * 4), o_misc = take(64);
     TC_HIP(e, hipMalloc(&e->kt_block, off));
     uint8_t* base = (uint8_t*)e->kt_block;
-    TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * 8, (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * sizeof(kt::Entry), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(base + o_misc, 0, 64, (hipStream_t)0));
     kt::Table& t = e->kt;
-    t.ktab = (unsigned long long*)(base + o_ktab);
+    t.ktab = (kt::Entry*)(base + o_ktab);
     t.nb_mask = nb - 1;
     t.rec = (kt::KeyRec*)(base + o_rec);
     t.bound = base + o_bound;
@@ -1384,7 +1384,7 @@ std::vector<Section> snapshot_sections(tc_engine* e) {
     if (e->denied) v.push_back({e->denied, e->capacity * sizeof(uint32_t)});
     if (e->key_mode) {
         const kt::Table& t = e->kt;
-        v.push_back({t.ktab, (t.nb_mask + 1) * 8});
+        v.push_back({t.ktab, (t.nb_mask + 1) * sizeof(kt::Entry)});
         v.push_back({t.rec, (size_t)t.capacity * sizeof(kt::KeyRec)});
         v.push_back({t.bound, (size_t)t.capacity});
         v.push_back({t.overflow, (size_t)t.overflow_bytes});
