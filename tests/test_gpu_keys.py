@@ -263,3 +263,43 @@ def test_pipelined_key_batches_inputs_ready():
     for k in keys[:300] + keys[-50:]:
         assert eng.get(k, t_end) == orc.get(k, t_end), k
     eng.close()
+
+
+@pytest.mark.parametrize("params", [(100, 1000, 3600), (5, 10, 60)], ids=["bench_params", "forces_denials"])
+def test_baseline_config0_1k_keys_100k_requests(params):
+    """BASELINE configs[0] / SURVEY section 8(d) cfg 1: 1 000 string keys key_<i>, 100 000 requests with
+    a uniform key index (seed 1), q = 1, request i stamped t0 + i * 10 us -- through the AdaptiveStore
+    port on the CPU and through the engine (per-request timestamps: the general path), bit-exact on
+    all five result fields + status; also in one pass, in 7 uneven batches and one request at a time
+    for the first 300."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    n_keys, n = 1000, 100_000
+    idx = rng.integers(0, n_keys, n)
+    keys = [b"key_%d" % i for i in range(n_keys)]
+    now = T0 + np.arange(n, dtype=np.int64) * 10_000
+    kb, ko = O.pack_keys([keys[i] for i in idx])
+    orc = O.AdaptiveOracle(capacity=n_keys, created_ns=T0)        # the reference's own cleanup heuristics on
+    ref = orc.batch_keys(kb, ko, *params, 1, now)
+    assert 0 < int(ref.allowed.sum()) <= n
+    # (a) one batch
+    eng = _engine(2048, n)
+    res = eng.rate_limit_batch_keys(kb, ko, max_burst=params[0], count_per_period=params[1], period=params[2], quantity=1, now_ns=now)
+    assert_same(res, ref, "one batch")
+    eng.close()
+    # (b) uneven batches, (c) the first requests one at a time through tc_rate_limit
+    eng = _engine(2048, n)
+    cuts = [0, 300, 301, 5000, 5064, 40000, 99999, n]
+    for i in range(300):
+        got = eng.rate_limit(keys[idx[i]], *params, 1, int(now[i]))
+        assert got == (int(ref.status[i]), bool(ref.allowed[i]), int(ref.limit[i]), int(ref.remaining[i]),
+                       int(ref.reset_after_ns[i]), int(ref.retry_after_ns[i])), i
+    for a, b in zip(cuts[1:-1], cuts[2:]):
+        part_kb, part_ko = O.pack_keys([keys[i] for i in idx[a:b]])
+        res = eng.rate_limit_batch_keys(part_kb, part_ko, max_burst=params[0], count_per_period=params[1], period=params[2],
+                                        quantity=1, now_ns=now[a:b])
+        for f in FIELDS:
+            got = getattr(res, f)
+            assert np.array_equal(got.astype(np.int64), getattr(ref, f)[a:b].astype(np.int64)), (f, a, b)
+    assert eng.counters()["total"] == n and eng.counters()["allowed"] == int(ref.allowed.sum())
+    eng.close()
