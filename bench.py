@@ -39,7 +39,7 @@ N_KEYS = 10_000_000
 BATCH = 1 << 20
 ALG_BYTES_PER_DECISION = 36.125  # SURVEY.md section 8(d), slot mode, decisions only
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
-METRICS_EVERY = 8                # N > 1: RCCL all-gather of the counter blocks every this many steps (+ the last)
+METRICS_EVERY = 32               # N > 1: RCCL all-gather of the counter blocks every this many steps (+ the last)
 
 
 KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep (one pass)", "eval": "k_eval_sorted",
