@@ -310,6 +310,24 @@ def main():
             also[f"{other}_stream_full_result_decision_records"] = {
                 "value": a.steps * a.batch / dt5, "unit": "decisions/s",
                 "note": "tc_decision: remaining, reset_after, retry_after, allowed, status in one 32-byte record"}
+            # grouped output (TC_B_GROUPED_OUTPUT): rows in evaluation order + the request index of each row
+            grp = t.BatchResult()
+            d_main = d_batches
+            for label, streams, want in ((f"{a.workload}_stream_grouped_output", d_main, ("allowed",)),
+                                         (f"{a.workload}_stream_grouped_decision_records", d_main, t.Engine.DECISION_FIELDS)):
+                for i in range(a.warmup):
+                    eng2.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=W.T0_NS + 5 * 10**9 + i,
+                                                want=want, out=grp, inputs_ready=True, grouped=True)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for i in range(a.steps):
+                    eng2.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1,
+                                                now_ns=W.T0_NS + 5 * 10**9 + 10**6 * (i + 1), want=want, out=grp, inputs_ready=True,
+                                                grouped=True)
+                torch.cuda.synchronize()
+                also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s",
+                               "note": "output rows in the engine's evaluation order + order[] (request index of each row)"}
+                grp = t.BatchResult()
             # general batches: every request carries its own timestamp (strictly increasing inside
             # the batch), so the closed form does not apply and k_eval_general runs
             nows = [torch.arange(a.batch, dtype=torch.int64, device=dev) + (W.T0_NS + 4 * 10**9 + b * 10**6)

@@ -88,6 +88,12 @@ typedef struct tc_config {
                                      * evaluated.  Evaluation order, results and visibility on the engine's stream are
                                      * unchanged; without the flag the whole batch runs in order on the engine's stream */
 
+#define TC_B_GROUPED_OUTPUT 0x10u    /* write every output ROW in the order the engine evaluates in (grouped by key,
+                                     * index order inside a key) and the request index of each row to `order`:
+                                     * output row k belongs to request order[k].  Saves the engine one scattered
+                                     * store per request; for consumers that walk all results anyway (a reply
+                                     * fan-out).  Without the flag row i belongs to request i, as everywhere else. */
+
 /* One batch of requests = the argument list of RateLimiter::rate_limit
  * (rate_limiter.rs:102-110), columnar.  A NULL input column means "use the
  * scalar of the same name for every request". */
@@ -126,6 +132,7 @@ typedef struct tc_batch {
      * (use it instead of the four columns above when all fields are wanted). 16-byte aligned. */
     int64_t* result4;        /* [n][4] */
     struct tc_decision* decisions; /* [n] 32-byte records (see tc_decision below); 16-byte aligned */
+    uint32_t* order;         /* [n] TC_B_GROUPED_OUTPUT: request index of each output row */
 } tc_batch;
 
 /* Everything rate_limit returns for one request except `limit` (== the request's max_burst, resp.

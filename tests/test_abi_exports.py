@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libtcgpu.so does not export {name}"
     assert set(_lib.SYMBOLS) == set(declared), set(_lib.SYMBOLS) ^ set(declared)
     assert lib.tc_abi_version() == 1
-    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 9 * 8  # incl. result4, decisions
+    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 10 * 8  # incl. result4, decisions, order
     assert ctypes.sizeof(_lib.tc_config) == 40
 
 

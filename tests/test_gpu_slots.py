@@ -513,3 +513,51 @@ def test_whole_batch_on_one_key(general):
         assert 0 < int(ref.allowed.sum()) < n
     assert_state_same(eng, orc, slots[:1])
     eng.close()
+
+
+@pytest.mark.parametrize("mode", ["uniform", "general", "unique"])
+@pytest.mark.parametrize("dev", [False, True], ids=["host", "device"])
+def test_grouped_output_rows(mode, dev):
+    """TC_B_GROUPED_OUTPUT: rows come in evaluation order, order[k] names the request of row k;
+    un-permuting them must give exactly the normal result (and `order` must be a permutation)."""
+    import torch
+    cap, n = 900, 40000
+    rng = np.random.default_rng(41)
+    eng, orc = _engine(cap, n), _oracle(cap)
+    eng.use_torch_stream()
+    for rnd in range(3):
+        if mode == "unique":
+            slots = rng.permutation(cap)[:700].astype(np.uint32)
+        else:
+            slots = ((rng.zipf(1.3, n) * 2654435761) % cap).astype(np.uint32)
+        m = slots.size
+        if mode == "uniform":
+            q, now = 1, T0 + rnd * 10**9
+        else:
+            q, now = rng.integers(0, 3, m), T0 + rnd * 10**9 + rng.integers(0, 10**9, m)
+        ref = orc.batch_slots(slots, 4, 10, 60, q, now)
+        want = FIELDS + ("decisions",)
+        if dev:
+            tt = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).cuda()
+            res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).cuda(), max_burst=4, count_per_period=10,
+                                             period=60, quantity=q if mode == "uniform" else tt(q),
+                                             now_ns=now if mode == "uniform" else tt(now), unique=(mode == "unique"),
+                                             want=want, grouped=True)
+            torch.cuda.synchronize()
+            order = res.order.cpu().numpy().astype(np.int64)
+        else:
+            res = eng.rate_limit_batch_slots(slots, max_burst=4, count_per_period=10, period=60, quantity=q, now_ns=now,
+                                             unique=(mode == "unique"), want=want, grouped=True)
+            order = res.order.astype(np.int64)
+        assert np.array_equal(np.sort(order), np.arange(m)), "order is a permutation of the requests"
+        if mode != "unique":   # rows are grouped by key, index order inside a key
+            s = slots[order].astype(np.int64)
+            assert np.all(np.diff(s) >= 0) and np.all((np.diff(s) > 0) | (np.diff(order) > 0))
+        for f in FIELDS:
+            rows = getattr(res, f)
+            rows = rows.cpu().numpy() if not isinstance(rows, np.ndarray) else rows
+            back = np.empty(m, np.int64)
+            back[order] = rows.astype(np.int64)
+            assert np.array_equal(back, getattr(ref, f).astype(np.int64)), (mode, f, rnd)
+    assert_state_same(eng, orc, np.arange(cap))
+    eng.close()

@@ -17,7 +17,7 @@ TC_OK, TC_NEGATIVE_QUANTITY, TC_INVALID_RATE_LIMIT, TC_INTERNAL = 0, 1, 2, 3
  TC_E_UNSUPPORTED) = (0, -1, -2, -3, -4, -5, -6, -7)
 TC_CFG_KEY_MODE = 0x1
 TC_CFG_TRACK_DENIED = 0x2
-TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY = 0x1, 0x2, 0x4, 0x8
+TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY, TC_B_GROUPED_OUTPUT = 0x1, 0x2, 0x4, 0x8, 0x10
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
 TC_CNT_COUNT = 8
 TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash")
@@ -39,7 +39,7 @@ class tc_batch(C.Structure):
                 ("period_scalar", C.c_int64), ("quantity_scalar", C.c_int64), ("now_ns_scalar", C.c_int64),
                 ("allowed", C.c_void_p), ("allowed_bits", C.c_void_p), ("limit", C.c_void_p),
                 ("remaining", C.c_void_p), ("reset_after_ns", C.c_void_p), ("retry_after_ns", C.c_void_p),
-                ("status", C.c_void_p), ("result4", C.c_void_p), ("decisions", C.c_void_p)]
+                ("status", C.c_void_p), ("result4", C.c_void_p), ("decisions", C.c_void_p), ("order", C.c_void_p)]
 
 
 class tc_result(C.Structure):

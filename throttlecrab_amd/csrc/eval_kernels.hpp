@@ -46,6 +46,7 @@ struct Params {
     uint8_t* status;
     int64_t* result4;
     tc_decision* decisions;
+    uint32_t* order; // TC_B_GROUPED_OUTPUT: output row k belongs to request order[k] (rows are in grouped order)
     Cell* cells;
     const uint16_t* rate_id;
     const RateClass* classes;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
             ne = 1;
         }
         write_out(p, i, r, d);
+        if (p.order) p.order[i] = i;
     }
     block_count3(na, nd, ne, p.counters);
 }
@@ -296,6 +298,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     const uint64_t me = valid ? sorted[k] : ~0ull;
     const uint32_t slot = (uint32_t)(me >> 32);
     const uint32_t idx = (uint32_t)me;
+    // output row: the request's own index, or (grouped output) its position in the sorted batch
+    const uint32_t orow = p.order ? k : idx;
+    if (p.order && valid) p.order[k] = idx;
     const int lane = threadIdx.x & 63;
     // neighbours' slots by wave shuffles; only the wave's edge lanes look at memory
     uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
@@ -340,26 +345,26 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
         d.remaining = d.reset_after = d.retry_after = 0;
         if (rq.status != tc::ST_OK) {
             ne = 1;
-            write_out(p, idx, rq, d);
+            write_out(p, orow, rq, d);
         } else {
             Cell c = cell;
             const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
             if (!d0.allowed) {
                 // request 0 denied => state untouched => every request of the run equals request 0
                 nd = 1;
-                write_out(p, idx, rq, d0);
+                write_out(p, orow, rq, d0);
             } else if (head && is_last) {
                 // a key requested once in this batch (95 % of a uniform batch): no closed form,
                 // and in particular none of its 64-bit division
                 na = 1;
-                write_out(p, idx, rq, d0);
+                write_out(p, orow, rq, d0);
                 writer = true;
                 wcell = c;
             } else {
                 const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
                 if (r == 0) {
                     na = 1;
-                    write_out(p, idx, rq, d0);
+                    write_out(p, orow, rq, d0);
                     if (is_last || (f.regular && f.n_tot == 1)) {
                         writer = true;
                         wcell = c;
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                             const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
                             na += dj.allowed;
                             nd += !dj.allowed;
-                            write_out(p, (uint32_t)nx, rq, dj);
+                            write_out(p, p.order ? j : (uint32_t)nx, rq, dj);
                         }
                         if (p.denied && nd) atomicAdd(&p.denied[slot], nd); // the whole run's denials sit in this lane
                         walked = true;
@@ -388,7 +393,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                     d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
                     na = d.allowed;
                     nd = !d.allowed;
-                    write_out(p, idx, rq, d);
+                    write_out(p, orow, rq, d);
                     if (d.allowed && (is_last || (int64_t)r + 1 == f.n_tot)) {
                         writer = true;
                         wcell = v;
@@ -469,6 +474,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     const uint64_t me = valid ? sorted[k] : ~0ull;
     const uint32_t slot = (uint32_t)(me >> 32);
     const uint32_t idx = (uint32_t)me;
+    const uint32_t orow = p.order ? k : idx;
+    if (p.order && valid) p.order[k] = idx;
     uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
     if (lane == 0 && valid && k > 0) prev_slot = (uint32_t)(sorted[k - 1] >> 32);
     if (lane == 63 && k + 1 < n) next_slot = (uint32_t)(sorted[k + 1] >> 32);
@@ -588,7 +595,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         Decision z;
         z.allowed = false;
         z.remaining = z.reset_after = z.retry_after = 0;
-        write_out(p, idx, r, z);
+        write_out(p, orow, r, z);
         ne = 1;
         fin = true;
     }
@@ -611,7 +618,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
                 d.allowed = allow;
                 d.remaining = d.reset_after = d.retry_after = 0;
             }
-            write_out(p, idx, r, d);
+            write_out(p, orow, r, d);
             if (lane == first) {
                 na = 1;
                 was_allowed = true;

@@ -139,6 +139,7 @@ struct tc_engine {
         int64_t* out[4] = {nullptr, nullptr, nullptr, nullptr};
         int64_t* result4 = nullptr;
         tc_decision* decisions = nullptr;
+        uint32_t* order = nullptr;
         uint8_t* status = nullptr;
         bool ready = false;
     } stage;
@@ -522,7 +523,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
-                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions};
+                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
     if (e->key_stream) {
@@ -659,6 +660,7 @@ static int stage_ensure(tc_engine* e) {
     for (int j = 0; j < 4; ++j) TC_HIP(e, hipMalloc(&e->stage.out[j], mb * sizeof(int64_t)));
     TC_HIP(e, hipMalloc(&e->stage.result4, mb * 4 * sizeof(int64_t)));
     TC_HIP(e, hipMalloc(&e->stage.decisions, mb * sizeof(tc_decision)));
+    TC_HIP(e, hipMalloc(&e->stage.order, mb * sizeof(uint32_t)));
     TC_HIP(e, hipMalloc(&e->stage.status, mb));
     e->stage.ready = true;
     return TC_E_OK;
@@ -763,6 +765,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     p.status = b.status;
     p.result4 = b.result4;
     p.decisions = b.decisions;
+    p.order = (b.flags & TC_B_GROUPED_OUTPUT) ? b.order : nullptr;
     p.cells = e->cells;
     p.rate_id = e->rate_id;
     p.classes = e->classes;
@@ -873,6 +876,7 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     d.status = b.status ? e->stage.status : nullptr;
     d.result4 = b.result4 ? e->stage.result4 : nullptr;
     d.decisions = b.decisions ? e->stage.decisions : nullptr;
+    d.order = b.order ? e->stage.order : nullptr;
     e->batches++;
     int rc = run_slots_device(e, d);
     if (rc != TC_E_OK) return rc;
@@ -885,6 +889,8 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     if (b.status) TC_HIP(e, hipMemcpyAsync(b.status, e->stage.status, n, hipMemcpyDeviceToHost, s));
     if (b.result4) TC_HIP(e, hipMemcpyAsync(b.result4, e->stage.result4, n * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
     if (b.decisions) TC_HIP(e, hipMemcpyAsync(b.decisions, e->stage.decisions, n * sizeof(tc_decision), hipMemcpyDeviceToHost, s));
+    if (b.order && (b.flags & TC_B_GROUPED_OUTPUT))
+        TC_HIP(e, hipMemcpyAsync(b.order, e->stage.order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
     return TC_E_OK;
 }
@@ -895,6 +901,7 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     if (b.n == 0) return TC_E_OK;
     if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
     if (!b.slot) return fail(e, TC_E_INVALID_ARG, "slot column is NULL");
+    if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
     if (e->key_mode) return fail(e, TC_E_INVALID_ARG, "key-mode engine: slots are assigned by the key table; use tc_rate_limit_batch_keys");
     TC_HIP(e, hipSetDevice(e->device));
     if (b.flags & TC_B_DEVICE_PTRS) {
@@ -927,6 +934,7 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     if (b.n == 0) return TC_E_OK;
     if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
     if (!b.key_bytes || !b.key_off) return fail(e, TC_E_INVALID_ARG, "key_bytes/key_off is NULL");
+    if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
     if (b.flags & (TC_B_REGISTERED_PARAMS | TC_B_UNIQUE_SLOTS))
         return fail(e, TC_E_INVALID_ARG, "registered params / unique-slot promise do not apply to string keys");
     TC_HIP(e, hipSetDevice(e->device));

@@ -27,7 +27,7 @@ def _is_torch(x) -> bool:
 class BatchResult:
     """Columnar (bool, RateLimitResult) + status for one batch."""
     __slots__ = ("allowed", "allowed_bits", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status",
-                 "result4", "decisions")
+                 "result4", "decisions", "order")
 
     def __init__(self):
         for s in self.__slots__:
@@ -146,7 +146,7 @@ class Engine:
         setattr(batch, name, arr.ctypes.data)
 
     def _prepare(self, n, dev, max_burst, count_per_period, period, quantity, now_ns, registered, unique,
-                 want, out: Optional[BatchResult], inputs_ready=False):
+                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False):
         keep = []
         b = L.tc_batch()
         b.struct_size = C.sizeof(L.tc_batch)
@@ -162,6 +162,8 @@ class Engine:
             if not dev:
                 raise ValueError("inputs_ready applies to device-pointer batches")
             flags |= L.TC_B_INPUTS_READY
+        if grouped:
+            flags |= L.TC_B_GROUPED_OUTPUT
         b.flags = flags
         b.quantity_scalar = 1
         if not registered:
@@ -175,6 +177,15 @@ class Engine:
             raise ValueError("now_ns is required")
         self._column(b, "now_ns", now_ns, n, dev, keep)
         res = out or BatchResult()
+        if grouped:  # output row k belongs to request res.order[k]
+            if res.order is None or (len(res.order) if not _is_torch(res.order) else res.order.numel()) != n:
+                if dev:
+                    import torch
+                    res.order = torch.empty(n, dtype=torch.int32, device=f"cuda:{self.device}")
+                else:
+                    res.order = np.zeros(n, dtype=np.uint32)
+            keep.append(res.order)
+            b.order = res.order.data_ptr() if _is_torch(res.order) else res.order.ctypes.data
         for name in want:
             cur = getattr(res, name)
             ln = (n + 63) // 64 if name == "allowed_bits" else (4 * n if name in ("result4", "decisions") else n)
@@ -192,8 +203,10 @@ class Engine:
 
     def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
                                now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
-                               out: Optional[BatchResult] = None, inputs_ready=False) -> BatchResult:
+                               out: Optional[BatchResult] = None, inputs_ready=False, grouped=False) -> BatchResult:
         """rate_limit_batch over pre-resolved slots (sequential semantics, index order).
+        grouped=True (TC_B_GROUPED_OUTPUT): output rows come in the engine's evaluation order and
+        res.order[k] is the request index of row k.
         inputs_ready=True (TC_B_INPUTS_READY): the CUDA `slots` tensor is already complete and
         stays untouched until the results are ready, so the engine may group this batch on its
         auxiliary stream while earlier batches are still being evaluated."""
@@ -210,7 +223,7 @@ class Engine:
             n = sl.size
             sp = sl.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
-                                   unique, want, out, inputs_ready)
+                                   unique, want, out, inputs_ready, grouped)
         b.slot = sp
         if n:
             self._check(self._lib.tc_rate_limit_batch_slots(self._h, C.byref(b)))

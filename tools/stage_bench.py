@@ -22,25 +22,29 @@ for kind in ("uniform", "zipf"):
     z = W.Zipf(keys) if kind == "zipf" else None
     hb = [(z.slots(batch, start=i * batch) if z else W.uniform_slots(keys, batch, start=i * batch)) for i in range(steps + 3)]
     db = [torch.from_numpy(b.astype(np.int32)).cuda() for b in hb]
-    for want in (("allowed",), t.Engine.ALL_FIELDS, t.Engine.RECORD_FIELDS, t.Engine.DECISION_FIELDS):
+    for want in (("allowed",), ("allowed", "grouped"), t.Engine.ALL_FIELDS, t.Engine.RECORD_FIELDS, t.Engine.DECISION_FIELDS,
+                 t.Engine.DECISION_FIELDS + ("grouped",)):
+        grouped = "grouped" in want
+        label = ('dec' if 'decisions' in want else ('rec' if 'result4' in want else ('full' if len(want) > 2 else 'bits'))) + ('+g' if grouped else '')
+        want = tuple(w for w in want if w != "grouped")
         eng = t.Engine(keys, batch)
         eng.use_torch_stream()
         eng.register_params_uniform(*W.REF_PARAMS)
         out = t.BatchResult()
         for i in range(3):
-            eng.rate_limit_batch_slots(db[i], registered=True, quantity=1, now_ns=W.T0_NS + i * 10**6, want=want, out=out, inputs_ready=piped)
+            eng.rate_limit_batch_slots(db[i], registered=True, quantity=1, now_ns=W.T0_NS + i * 10**6, want=want, out=out, inputs_ready=piped, grouped=grouped)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
-            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (3 + i) * 10**6, want=want, out=out, inputs_ready=piped)
+            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (3 + i) * 10**6, want=want, out=out, inputs_ready=piped, grouped=grouped)
         t_issue = time.perf_counter() - t0
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         eng.profile_enable(True)
         for i in range(steps):
-            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (30 + i) * 10**6, want=want, out=out, inputs_ready=piped)
+            eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (30 + i) * 10**6, want=want, out=out, inputs_ready=piped, grouped=grouped)
         prof = eng.profile_read()
         st = {k: round(1e3 * v[0] / max(1, v[1]), 1) for k, v in prof.items() if v[1]}
-        print(f"piped={int(piped)} {kind:8s} {'dec' if 'decisions' in want else ('rec' if 'result4' in want else ('full' if len(want) > 1 else 'bits')):5s} {steps * batch / dt / 1e9:7.2f} G/s  "
+        print(f"piped={int(piped)} {kind:8s} {label:6s} {steps * batch / dt / 1e9:7.2f} G/s  "
               f"{1e6 * dt / steps:7.1f} us/batch  host-issue {1e6 * t_issue / steps:6.1f} us/batch  stages(us)={st}", flush=True)
         eng.close()
