@@ -28,16 +28,19 @@ for kind in ("uniform", "zipf"):
         label = ('dec' if 'decisions' in want else ('rec' if 'result4' in want else ('full' if len(want) > 2 else 'bits'))) + ('+g' if grouped else '')
         want = tuple(w for w in want if w != "grouped")
         eng = t.Engine(keys, batch)
-        eng.use_torch_stream()
+        if os.environ.get("TC_OWN_STREAM") != "1":
+            eng.use_torch_stream()
         eng.register_params_uniform(*W.REF_PARAMS)
         out = t.BatchResult()
         for i in range(3):
             eng.rate_limit_batch_slots(db[i], registered=True, quantity=1, now_ns=W.T0_NS + i * 10**6, want=want, out=out, inputs_ready=piped, grouped=grouped)
+        eng.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
             eng.rate_limit_batch_slots(db[3 + i], registered=True, quantity=1, now_ns=W.T0_NS + (3 + i) * 10**6, want=want, out=out, inputs_ready=piped, grouped=grouped)
         t_issue = time.perf_counter() - t0
+        eng.synchronize()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         eng.profile_enable(True)
