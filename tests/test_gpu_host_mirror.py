@@ -51,6 +51,17 @@ def test_cpp_metrics_text_program():
     assert "all tests passed" in out.stdout
 
 
+def test_cpp_sweep_policy_program():
+    """Periodic / probabilistic / adaptive sweep schedulers == the reference stores' cleanup cadence
+    (periodic.rs:128-142, probabilistic.rs:110-125, adaptive_cleanup.rs:138-211): no GPU needed."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_sweep_policy")
+    src = os.path.join(ROOT, "tests", "cpp", "test_sweep_policy.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
+
+
 def test_cpp_kernel_math_properties_on_host():
     """gcra_math.hpp compiled for the host: closed form == sequence, the host-side proof behind the
     direct-store evaluation, late readers harmless (tests/cpp/test_math_host.hip). No GPU needed."""
