@@ -90,6 +90,31 @@ __device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t sl
     return r;
 }
 
+// make_req for the batches k_eval_sorted* see (one `now`, one `quantity`; parameters registered per slot or
+// scalar), with the slot's rate class already loaded by the caller.
+__device__ __forceinline__ Req make_req_rc(const Params& p, uint32_t slot, const RateClass& rc) {
+    Req r;
+    r.q = p.q_s;
+    r.now = p.now_s;
+    r.ei = r.dvt = r.limit = 0;
+    if (slot >= p.capacity) {
+        r.status = tc::ST_INTERNAL;
+        return r;
+    }
+    if (p.flags & F_REGISTERED) {
+        r.ei = rc.ei;
+        r.dvt = rc.dvt;
+        r.limit = rc.burst;
+        if (r.q < 0) r.status = tc::ST_NEGATIVE_QUANTITY;            // rate_limiter.rs:111
+        else if (r.limit <= 0) r.status = tc::ST_INVALID_RATE_LIMIT; // slot never registered
+        else r.status = tc::check_request(r.q, r.now, r.dvt);
+    } else {
+        r.limit = p.burst_s;
+        r.status = tc::derive_request(p.burst_s, p.count_s, p.period_s, r.q, r.now, r.ei, r.dvt);
+    }
+    return r;
+}
+
 __device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req& r, const Decision& d) {
     const bool ok = r.status == tc::ST_OK;
     if (p.allowed) p.allowed[i] = (ok && d.allowed) ? 1 : 0;
@@ -245,21 +270,6 @@ __global__ void k_rate_limit_one(Params p, kt::Table t, int key_mode, InlineKey 
     *out = o;
 }
 
-// block-wide inclusive max-scan (values are position+1, 0 = none)
-__device__ __forceinline__ uint32_t block_scan_max(uint32_t v) {
-    __shared__ uint32_t s_wmax[BLOCK / 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t o = __shfl_up(v, off, 64);
-        if (lane >= off) v = max(v, o);
-    }
-    if (lane == 63) s_wmax[wave] = v;
-    __syncthreads();
-    uint32_t carry = 0;
-    for (int w = 0; w < wave; ++w) carry = max(carry, s_wmax[w]);
-    return max(v, carry);
-}
-
 // Deferred cell store for a segment that spans waves (see k_eval_sorted).
 struct __attribute__((aligned(16))) PendEntry {
     Cell cell;
@@ -268,52 +278,119 @@ struct __attribute__((aligned(16))) PendEntry {
 };
 
 // ---------------------------------------------------------------------------
-// K2: evaluate over the (slot, index)-sorted batch; one lane per sorted position.
+// K2: evaluate over the (slot, index)-sorted batch, ITEMS sorted positions per lane.
 //   UNIFORM (one `now`, one `quantity`, per-slot or scalar params): every
 //     request of a slot's segment is identical, so lane r of the segment derives
 //     the cell left by its r predecessors in closed form (tc::run_form) and
 //     applies the ordinary step to it.  Exactly one lane per segment -- the one
 //     performing the last allowed step -- produces the new cell.  If the whole
-//     segment sits inside this wave the lane stores it directly (every lane of
-//     the segment loaded the old cell earlier in program order); otherwise the
+//     segment sits inside one row (64 consecutive positions = one wave's j-th items) the lane stores
+//     it directly (every lane of the segment loaded the old cell earlier in program order); otherwise the
 //     store is parked in pend[] and applied by k_commit_list after this kernel (folding it into
 //     the kernel's last block was measured slower: the hand-off needs every block to drain its stores),
 //     so no lane of another wave can read a half-updated cell.
 //   Batches with per-request now / quantity / rate go through k_eval_general.
-// ---------------------------------------------------------------------------
 //   DIRECT (the host proved every run of this batch regular, see all_runs_regular()): no store is
 //     parked and no commit launch follows.  The lane owning a segment's new cell stores it itself
-//     once every wave holding EARLIER requests of the segment has announced (loaded[wave] = seq)
-//     that it read the old cell -- earlier waves were dispatched earlier, so the wait cannot
-//     deadlock.  Requests AFTER the owner (rank >= n_tot: denied) may read either cell: against the
+//     once every row holding EARLIER requests of the segment has announced (loaded[row] = seq)
+//     that it read the old cell -- earlier blocks were dispatched earlier, and inside a block rows are
+//     announced and waited for in position order with no block barrier between announce and wait, so a
+//     row only ever waits for rows whose waves cannot be waiting for it: the wait cannot deadlock.
+//     Requests AFTER the owner (rank >= n_tot: denied) may read either cell: against the
 //     old one the closed form gives "denied against new0 + (n_tot-1) inc", against the new one the
 //     plain step gives the same, because the new cell IS that state.
-template <bool FULL, bool DIRECT>
+//   Loads: every load a lane will need is issued before anything waits -- the batch-wide rate class
+//     (scalar), ITEMS sorted elements + the row-edge neighbours, then plan ids (per-slot plans only) and
+//     ITEMS cells.  Block b covers positions [b*BLOCK*ITEMS, (b+1)*BLOCK*ITEMS); lane t's j-th position is
+//     b*BLOCK*ITEMS + j*BLOCK + t.  Measured (1 Mi requests, 10 M keys): the kernel's time does not depend
+//     on ITEMS for the decisions-only output (43 us: it is bound by the ~1.5 M fabric requests its random
+//     16-byte cells cost, not by latency), record outputs gain 15 % at ITEMS = 4 in order, the Zipf stream
+//     7 % at ITEMS = 2 when overlapped with the next batch's sort.
+// ---------------------------------------------------------------------------
+template <bool FULL, bool DIRECT, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
-                                                       PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
-                                                       uint32_t* __restrict__ loaded, uint32_t seq) {
+                                                             PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
+                                                             uint32_t* __restrict__ loaded, uint32_t seq) {
     const uint32_t n = p.n;
-    const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
-    const bool valid = k < n;
-    const uint64_t me = valid ? sorted[k] : ~0ull;
-    const uint32_t slot = (uint32_t)(me >> 32);
-    const uint32_t idx = (uint32_t)me;
-    // output row: the request's own index, or (grouped output) its position in the sorted batch
-    const uint32_t orow = p.order ? k : idx;
-    if (p.order && valid) p.order[k] = idx;
-    const int lane = threadIdx.x & 63;
-    // neighbours' slots by wave shuffles; only the wave's edge lanes look at memory
-    uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
-    if (lane == 0 && valid && k > 0) prev_slot = (uint32_t)(sorted[k - 1] >> 32);
-    if (lane == 63 && k + 1 < n) next_slot = (uint32_t)(sorted[k + 1] >> 32);
-    const bool head = valid && (k == 0 || prev_slot != slot);
-    uint32_t na = 0, nd = 0, ne = 0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t block_start = blockIdx.x * (BLOCK * ITEMS);
+    const bool class_by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS); // uniform over the grid
+    const RateClass rc_batch = p.classes[p.uniform_class];                                // (class 0 if there is none)
+    uint32_t kk[ITEMS];
+    uint64_t me[ITEMS];
+    uint32_t edge[ITEMS]; // lane 0: slot before my row; lane 63: slot after it
+    // every load is unconditional (indices clamped, results masked afterwards): a load under a branch
+    // makes the compiler drain the earlier ones first
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        kk[j] = block_start + j * BLOCK + threadIdx.x;
+        me[j] = sorted[min(kk[j], n - 1u)];
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        uint32_t ek = kk[j];
+        if (lane == 0 && ek > 0) ek -= 1;
+        if (lane == 63) ek += 1;
+        edge[j] = (uint32_t)(sorted[min(ek, n - 1u)] >> 32); // the other lanes re-read their own element (same lines)
+    }
+    // (vmcnt counts loads in issue order, so whatever the next load's address depends on goes first:
+    // plan ids before cells, the batch-wide class before everything)
+    Cell cell[ITEMS];
+    RateClass rc[ITEMS];
+    uint32_t rid[ITEMS];
+    bool has_cell[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if (kk[j] >= n) me[j] = ~0ull;
+        has_cell[j] = kk[j] < n && (uint32_t)(me[j] >> 32) < p.capacity;
+        rid[j] = 0;
+    }
+    if (class_by_slot) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) rid[j] = (uint32_t)p.rate_id[has_cell[j] ? (uint32_t)(me[j] >> 32) : 0u];
+    }
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        cell[j] = tc::load_cell(&p.cells[has_cell[j] ? (uint32_t)(me[j] >> 32) : 0u]);
+        if (!has_cell[j]) {
+            cell[j].tat = 0;
+            cell[j].expiry = 0;
+        }
+    }
+    if (class_by_slot) {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) rc[j] = p.classes[rid[j]]; // class 0 is all zero: burst 0 = never registered
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) rc[j] = rc_batch;
+    }
 
-    const bool is_last = valid && ((k + 1 == n) || next_slot != slot);
+    // run boundaries per row; start of my run by a max-scan of head positions over the block's range
+    __shared__ uint32_t s_rowmax[ITEMS][BLOCK / 64];
     __shared__ uint32_t s_start;
-    const uint32_t block_start = blockIdx.x * BLOCK;
-    if (threadIdx.x == 0 && valid && !head) {
-        // segment of sorted[block_start] began in an earlier block: lower_bound on the slot
+    bool head[ITEMS], is_last[ITEMS];
+    uint32_t hp[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t k = kk[j];
+        const bool valid = k < n;
+        const uint32_t slot = (uint32_t)(me[j] >> 32);
+        uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
+        if (lane == 0) prev_slot = edge[j];               // (k == 0: not looked at)
+        if (lane == 63) next_slot = edge[j];              // (k + 1 >= n: not looked at)
+        head[j] = valid && (k == 0 || prev_slot != slot);
+        is_last[j] = valid && ((k + 1 == n) || next_slot != slot);
+        uint32_t v = head[j] ? k + 1 : 0u;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(v, off, 64);
+            if (lane >= off) v = max(v, o);
+        }
+        hp[j] = v;
+        if (lane == 63) s_rowmax[j][wave] = v;
+    }
+    if (threadIdx.x == 0 && kk[0] < n && !head[0]) {
+        // the run of the block's first position began in an earlier block: lower_bound on the slot
+        const uint32_t slot = (uint32_t)(me[0] >> 32);
         uint32_t lo = 0, hi = block_start;
         while (lo < hi) {
             const uint32_t mid = lo + ((hi - lo) >> 1);
@@ -322,121 +399,144 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
         }
         s_start = lo;
     }
-    const uint32_t hp = block_scan_max(head ? k + 1 : 0u); // contains a __syncthreads()
-    const uint32_t seg_start = hp ? hp - 1 : s_start;
-    // does my whole segment live inside this wave?
-    const unsigned long long heads = __ballot(head), lasts = __ballot(is_last);
-    const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
-    const bool seg_in_wave = ((heads & upto) != 0ull) && ((lasts >> lane) != 0ull);
+    __syncthreads();
 
-    bool writer = false, walked = false;
-    Cell wcell;
-    wcell.tat = 0;
-    wcell.expiry = 0;
-    if (valid) {
-        const uint32_t r = k - seg_start;
-        Cell cell;
-        cell.tat = 0;
-        cell.expiry = 0;
-        if (slot < p.capacity) cell = tc::load_cell(&p.cells[slot]);
-        const Req rq = make_req(p, idx, slot);
+    uint32_t na = 0, nd = 0, ne = 0;
+    uint32_t seg_start[ITEMS];
+    bool writer[ITEMS], denied_here[ITEMS];
+    Cell wcell[ITEMS];
+    uint32_t carry = 0; // latest head position (+1) in the rows before mine
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            // rows before (j, wave) in position order: all of the earlier sub-tiles, and waves < mine of this one
+            if (w < wave) carry = max(carry, s_rowmax[j][w]);
+        }
+        const uint32_t h = max(hp[j], carry);
+        seg_start[j] = h ? h - 1 : s_start;
+        for (int w = wave; w < BLOCK / 64; ++w) carry = max(carry, s_rowmax[j][w]);
+
+        const uint32_t k = kk[j];
+        const bool valid = k < n;
+        const uint32_t slot = (uint32_t)(me[j] >> 32), idx = (uint32_t)me[j];
+        const uint32_t orow = p.order ? k : idx;
+        if (p.order && valid) p.order[k] = idx;
+        writer[j] = false;
+        denied_here[j] = false;
+        wcell[j].tat = 0;
+        wcell[j].expiry = 0;
+        if (!valid) continue;
+        const uint32_t r = k - seg_start[j];
+        const Req rq = make_req_rc(p, slot, rc[j]);
         Decision d;
         d.allowed = false;
         d.remaining = d.reset_after = d.retry_after = 0;
         if (rq.status != tc::ST_OK) {
-            ne = 1;
+            ne += 1;
             write_out(p, orow, rq, d);
+            continue;
+        }
+        Cell c = cell[j];
+        const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
+        if (!d0.allowed) {
+            // request 0 denied => state untouched => every request of the run equals request 0
+            nd += 1;
+            denied_here[j] = true;
+            write_out(p, orow, rq, d0);
+        } else if (head[j] && is_last[j]) {
+            na += 1; // a key requested once in this batch: no closed form, no 64-bit division
+            write_out(p, orow, rq, d0);
+            writer[j] = true;
+            wcell[j] = c;
         } else {
-            Cell c = cell;
-            const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
-            if (!d0.allowed) {
-                // request 0 denied => state untouched => every request of the run equals request 0
-                nd = 1;
+            const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
+            if (r == 0) {
+                na += 1;
                 write_out(p, orow, rq, d0);
-            } else if (head && is_last) {
-                // a key requested once in this batch (95 % of a uniform batch): no closed form,
-                // and in particular none of its 64-bit division
-                na = 1;
-                write_out(p, orow, rq, d0);
-                writer = true;
-                wcell = c;
-            } else {
-                const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
-                if (r == 0) {
-                    na = 1;
-                    write_out(p, orow, rq, d0);
-                    if (is_last || (f.regular && f.n_tot == 1)) {
-                        writer = true;
-                        wcell = c;
-                    } else if (!f.regular) {
-                        // irregular run (saturation, zero increment, immediate expiry):
-                        // walk the rest of the segment one request at a time
-                        if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // shard 0's spare word; the host's proof was wrong: must stay 0
-                        for (uint32_t j = k + 1; j < n; ++j) {
-                            const uint64_t nx = sorted[j];
-                            if ((uint32_t)(nx >> 32) != slot) break;
-                            const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
-                            na += dj.allowed;
-                            nd += !dj.allowed;
-                            write_out(p, p.order ? j : (uint32_t)nx, rq, dj);
-                        }
-                        if (p.denied && nd) atomicAdd(&p.denied[slot], nd); // the whole run's denials sit in this lane
-                        walked = true;
-                        writer = true;
-                        wcell = c;
+                if (is_last[j] || (f.regular && f.n_tot == 1)) {
+                    writer[j] = true;
+                    wcell[j] = c;
+                } else if (!f.regular) {
+                    // irregular run (saturation, zero increment, immediate expiry): walk the rest one by one
+                    if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // the host's proof was wrong: must stay 0
+                    uint32_t wd = 0;
+                    for (uint32_t q = k + 1; q < n; ++q) {
+                        const uint64_t nx = sorted[q];
+                        if ((uint32_t)(nx >> 32) != slot) break;
+                        const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
+                        na += dj.allowed;
+                        wd += !dj.allowed;
+                        write_out(p, p.order ? q : (uint32_t)nx, rq, dj);
                     }
-                } else if (f.regular) {
-                    const int64_t j = (int64_t)r < f.n_tot ? (int64_t)r : f.n_tot;
-                    Cell v;
-                    v.tat = f.new0 + (j - 1) * f.inc;
-                    v.expiry = UINT64_MAX;
-                    d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
-                    na = d.allowed;
-                    nd = !d.allowed;
-                    write_out(p, orow, rq, d);
-                    if (d.allowed && (is_last || (int64_t)r + 1 == f.n_tot)) {
-                        writer = true;
-                        wcell = v;
-                    }
+                    nd += wd;
+                    if (p.denied && wd) atomicAdd(&p.denied[slot], wd); // the whole run's denials sit in this lane
+                    writer[j] = true;
+                    wcell[j] = c;
                 }
-                // irregular && r > 0: the head lane produced this request's outputs
+            } else if (f.regular) {
+                const int64_t jj = (int64_t)r < f.n_tot ? (int64_t)r : f.n_tot;
+                Cell v;
+                v.tat = f.new0 + (jj - 1) * f.inc;
+                v.expiry = UINT64_MAX;
+                d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
+                na += d.allowed;
+                nd += !d.allowed;
+                denied_here[j] = !d.allowed;
+                write_out(p, orow, rq, d);
+                if (d.allowed && (is_last[j] || (int64_t)r + 1 == f.n_tot)) {
+                    writer[j] = true;
+                    wcell[j] = v;
+                }
             }
+            // irregular && r > 0: the head lane produced this request's outputs
         }
     }
-    if (DIRECT) {
-        const uint32_t gw = k >> 6;
-        // (every lane's cell load has returned: the values were consumed above; pin that down)
-        asm volatile("" ::"v"((uint32_t)wcell.tat), "v"((uint32_t)na), "v"((uint32_t)nd) : "memory");
-        // announce "this wave has read its cells" if a later wave may have to wait for it
-        if (lane == 63 && valid && !is_last)
-            __hip_atomic_store(&loaded[gw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // at most one segment of this wave began in an earlier wave (the one holding lane 0)
-        const uint32_t wave_first = k - (uint32_t)lane;
-        const bool must_wait = writer && seg_start < wave_first;
-        const unsigned long long wm = __ballot(must_wait);
-        if (wm) {
-            const int wl = __builtin_ctzll(wm);
-            const uint32_t w0 = __shfl(seg_start, wl, 64) >> 6;
-            for (uint32_t base = w0; base < gw; base += 64) { // 64 earlier waves per round trip
-                const uint32_t w = base + (uint32_t)lane;
-                while (__ballot(w < gw && __hip_atomic_load(&loaded[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq))
-                    __builtin_amdgcn_s_sleep(1);
+
+    // (every cell load of this lane has returned: the values were consumed above; pin that down)
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) asm volatile("" ::"v"((uint32_t)wcell[j].tat), "v"((uint32_t)writer[j]) : "memory");
+    asm volatile("" ::"v"(na), "v"(nd) : "memory");
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t k = kk[j];
+        const bool valid = k < n;
+        const uint32_t slot = (uint32_t)(me[j] >> 32);
+        if (DIRECT) {
+            const uint32_t gw = k >> 6; // row number
+            // announce "this row has read its cells" if a later row may have to wait for it
+            if (lane == 63 && valid && !is_last[j]) __hip_atomic_store(&loaded[gw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t row_first = k - (uint32_t)lane;
+            const bool must_wait = writer[j] && seg_start[j] < row_first; // at most one such run per row
+            const unsigned long long wm = __ballot(must_wait);
+            if (wm) {
+                const int wl = __builtin_ctzll(wm);
+                const uint32_t w0 = __shfl(seg_start[j], wl, 64) >> 6;
+                for (uint32_t base = w0; base < gw; base += 64) { // 64 earlier rows per round trip
+                    const uint32_t w = base + (uint32_t)lane;
+                    while (__ballot(w < gw && __hip_atomic_load(&loaded[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq))
+                        __builtin_amdgcn_s_sleep(1);
+                }
             }
-        }
-        if (writer) tc::store_cell(&p.cells[slot], wcell);
-    } else if (writer) {
-        if (seg_in_wave) {
-            tc::store_cell(&p.cells[slot], wcell);
+            if (writer[j]) tc::store_cell(&p.cells[slot], wcell[j]);
         } else {
-            const uint32_t at = atomicAdd(pend_count, 1u);
-            PendEntry pe;
-            pe.cell = wcell;
-            pe.slot = slot;
-            pe.pad[0] = pe.pad[1] = pe.pad[2] = 0;
-            pend[at] = pe;
+            // does my whole run live inside this row?  (ballots taken by the full wave)
+            const unsigned long long heads = __ballot(head[j]), lasts = __ballot(is_last[j]);
+            const unsigned long long upto = (lane == 63) ? ~0ull : ((2ull << lane) - 1ull);
+            const bool seg_in_row = ((heads & upto) != 0ull) && ((lasts >> lane) != 0ull);
+            if (!writer[j]) {
+            } else if (seg_in_row) {
+                tc::store_cell(&p.cells[slot], wcell[j]);
+            } else {
+                const uint32_t at = atomicAdd(pend_count, 1u);
+                PendEntry pe;
+                pe.cell = wcell[j];
+                pe.slot = slot;
+                pe.pad[0] = pe.pad[1] = pe.pad[2] = 0;
+                pend[at] = pe;
+            }
         }
+        wave_denied_add(p, slot, denied_here[j]);
     }
-    wave_denied_add(p, slot, nd != 0 && !walked);
     block_count3(na, nd, ne, p.counters);
 }
 

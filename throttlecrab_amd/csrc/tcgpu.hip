@@ -122,6 +122,7 @@ struct tc_engine {
     ChainRec* chain = nullptr; // k_eval_general: per-wave hand-over records
     uint32_t chain_seq = 0;
     uint32_t* loaded = nullptr; // k_eval_sorted<DIRECT>: per-wave "cells read" flags
+    int eval_items = 0;         // sorted positions per lane in k_eval_sorted (0: chosen per batch)
     uint32_t loaded_seq = 0;
     // bounds over the registered rate plans (for all_runs_regular)
     int64_t cls_min_ei = INT64_MAX, cls_max_ei = 0, cls_min_dvt = INT64_MAX, cls_max_dvt = 0;
@@ -246,6 +247,7 @@ static int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_PIPE_DEPTH")) e->depth = (uint32_t)std::min(std::max(atoi(d), 1), PIPE_DEPTH_MAX);
     int prio_lo = 0, prio_hi = 0;
     TC_HIP(e, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    if (const char* d = getenv("TCGPU_EVAL_ITEMS")) e->eval_items = atoi(d);
     const char* pe = getenv("TCGPU_AUX_PRIORITY");
     const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
     // the evaluation kernel on the main stream is the critical path of the pipeline: grouping runs at
@@ -741,6 +743,26 @@ static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params
 }
 
 // all pointers in `b` are device pointers here
+// k_eval_sorted<.., ITEMS>: 2 positions per lane when the batch overlaps with its neighbours' sorts,
+// 4 when it runs alone (measured; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
+template <int ITEMS>
+static void launch_eval_items(tc_engine* e, bool full, bool direct, uint32_t n, hipStream_t s, const Params& p, const uint64_t* sorted,
+                              uint32_t seq) {
+    const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
+    if (full && direct) hipLaunchKernelGGL((k_eval_sorted<true, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
+    else if (full) hipLaunchKernelGGL((k_eval_sorted<true, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
+    else if (direct) hipLaunchKernelGGL((k_eval_sorted<false, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
+    else hipLaunchKernelGGL((k_eval_sorted<false, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
+}
+static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped, uint32_t n, hipStream_t s, const Params& p,
+                               const uint64_t* sorted, uint32_t seq) {
+    switch (e->eval_items ? e->eval_items : (piped ? 2 : 4)) {
+    case 1: launch_eval_items<1>(e, full, direct, n, s, p, sorted, seq); return;
+    case 2: launch_eval_items<2>(e, full, direct, n, s, p, sorted, seq); return;
+    default: launch_eval_items<4>(e, full, direct, n, s, p, sorted, seq); return;
+    }
+}
+
 static int run_slots_device(tc_engine* e, const tc_batch& b) {
     const uint32_t n = (uint32_t)b.n;
     Params p;
@@ -815,16 +837,16 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
         const bool uniform = !p.q && !p.now && params_by_slot;
         prof_begin(e, TC_STAGE_EVAL, s);
         if (uniform) {
-            if (all_runs_regular(e, b, p)) {
-                // every run is regular whatever the cells hold: owners store directly, no commit launch
+            const bool direct = all_runs_regular(e, b, p);
+            // direct: every run is regular whatever the cells hold: owners store directly, no commit launch
+            uint32_t seq = 0u;
+            if (direct) {
                 if (++e->loaded_seq == 0u) e->loaded_seq = 1u;
-                if (full) hipLaunchKernelGGL((k_eval_sorted<true, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, e->loaded_seq);
-                else hipLaunchKernelGGL((k_eval_sorted<false, true>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, e->loaded_seq);
-                prof_end(e, s);
-            } else {
-                if (full) hipLaunchKernelGGL((k_eval_sorted<true, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, 0u);
-                else hipLaunchKernelGGL((k_eval_sorted<false, false>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, 0u);
-                prof_end(e, s);
+                seq = e->loaded_seq;
+            }
+            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq);
+            prof_end(e, s);
+            if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
                 hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells);
                 prof_end(e, s);

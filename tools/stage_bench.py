@@ -18,7 +18,10 @@ batch = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 20
 piped = (sys.argv[3] != '0') if len(sys.argv) > 3 else True
 keys = 10_000_000
 
-for kind in ("uniform", "zipf"):
+KINDS = os.environ.get("TC_STAGE_KINDS", "uniform,zipf").split(",")
+MODES = os.environ.get("TC_STAGE_MODES")  # e.g. "bits,dec": only these output modes
+
+for kind in KINDS:
     z = W.Zipf(keys) if kind == "zipf" else None
     hb = [(z.slots(batch, start=i * batch) if z else W.uniform_slots(keys, batch, start=i * batch)) for i in range(steps + 3)]
     db = [torch.from_numpy(b.astype(np.int32)).cuda() for b in hb]
@@ -27,6 +30,8 @@ for kind in ("uniform", "zipf"):
         grouped = "grouped" in want
         label = ('dec' if 'decisions' in want else ('rec' if 'result4' in want else ('full' if len(want) > 2 else 'bits'))) + ('+g' if grouped else '')
         want = tuple(w for w in want if w != "grouped")
+        if MODES and label not in MODES.split(","):
+            continue
         eng = t.Engine(keys, batch)
         if os.environ.get("TC_OWN_STREAM") != "1":
             eng.use_torch_stream()
