@@ -10,9 +10,11 @@
 // build: hipcc -O2 -std=c++17 tests/cpp/test_math_host.hip -o tests/cpp/test_math_host   (host code only)
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
 
 #include "../../throttlecrab_amd/csrc/gcra_math.hpp"
+#include "../../throttlecrab_amd/csrc/key_table.hpp"
 
 using tc::Cell;
 using tc::Decision;
@@ -118,6 +120,24 @@ int main() {
     CHECK(regular_runs > 20000 && irregular_runs > 2000 && direct_cases > 20000 && late_checks > 50000);
     std::printf("regular %llu irregular %llu direct-proof cases %llu late-reader checks %llu\n", (unsigned long long)regular_runs,
                 (unsigned long long)irregular_runs, (unsigned long long)direct_cases, (unsigned long long)late_checks);
+    // key_table.hpp: the hash of a short key computed from its two padded words == the byte-wise hash,
+    // for every length 0..16 (k_probe takes this path; the table and snapshots hold hash_key values)
+    {
+        unsigned long long short_keys = 0;
+        uint8_t buf[32];
+        for (int it = 0; it < 200000; ++it) {
+            const uint32_t len = (uint32_t)(rng() % 17);
+            for (uint8_t& b : buf) b = (uint8_t)rng();
+            uint64_t k0, k1, a, b;
+            kt::short_key_words(buf, len, k0, k1);
+            memcpy(&a, buf, 8);
+            memcpy(&b, buf + 8, 8);
+            CHECK(kt::keep_bytes(a, len) == k0 && (len > 8 ? kt::keep_bytes(b, len - 8) : 0ull) == k1);
+            CHECK(kt::hash_short(k0, k1, len) == kt::hash_key(buf, len));
+            ++short_keys;
+        }
+        CHECK(short_keys == 200000);
+    }
     std::puts("all tests passed");
     return 0;
 }

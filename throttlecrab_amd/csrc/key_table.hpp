@@ -79,7 +79,7 @@ __device__ __forceinline__ unsigned long long entry_meta(uint64_t h, uint32_t le
     return (tag << 32) | (len8 << 56);
 }
 
-__device__ __forceinline__ uint64_t mix64(uint64_t x) {
+__host__ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
     x ^= x >> 33;
     x *= 0xff51afd7ed558ccdull;
     x ^= x >> 33;
@@ -90,7 +90,7 @@ __device__ __forceinline__ uint64_t mix64(uint64_t x) {
 
 // 1..7 trailing bytes as a little-endian word, without reading past the key
 // (gfx950 runs with unaligned global access, so the 2/4/8-byte loads are single instructions)
-__device__ __forceinline__ uint64_t load_tail(const uint8_t* __restrict__ p, uint32_t r) {
+__host__ __device__ __forceinline__ uint64_t load_tail(const uint8_t* __restrict__ p, uint32_t r) {
     uint64_t w = 0;
     uint32_t sh = 0;
     if (r & 4u) {
@@ -111,7 +111,7 @@ __device__ __forceinline__ uint64_t load_tail(const uint8_t* __restrict__ p, uin
     return w;
 }
 
-__device__ __forceinline__ uint64_t hash_key(const uint8_t* __restrict__ p, uint32_t len) {
+__host__ __device__ __forceinline__ uint64_t hash_key(const uint8_t* __restrict__ p, uint32_t len) {
     uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)len;
     uint32_t i = 0;
     for (; i + 8 <= len; i += 8) {
@@ -143,7 +143,7 @@ __device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, 
 }
 
 // a key of at most 16 bytes as two zero-padded little-endian words (what Entry::key holds)
-__device__ __forceinline__ void short_key_words(const uint8_t* __restrict__ p, uint32_t len, uint64_t& k0, uint64_t& k1) {
+__host__ __device__ __forceinline__ void short_key_words(const uint8_t* __restrict__ p, uint32_t len, uint64_t& k0, uint64_t& k1) {
     k0 = k1 = 0;
     if (len >= 8) {
         __builtin_memcpy(&k0, p, 8);
@@ -152,6 +152,45 @@ __device__ __forceinline__ void short_key_words(const uint8_t* __restrict__ p, u
     } else if (len) {
         k0 = load_tail(p, len);
     }
+}
+
+// hash_key() of a key of at most 16 bytes, from its two zero-padded words (no further loads)
+__host__ __device__ __forceinline__ uint64_t hash_short(uint64_t k0, uint64_t k1, uint32_t len) {
+    const uint64_t C = 0x9e3779b97f4a7c15ull;
+    uint64_t h = C ^ (uint64_t)len;
+    if (len >= 8) {
+        h = mix64(h ^ k0) + C;
+        if (len == 16) h = mix64(h ^ k1) + C;
+        else if (len > 8) h = mix64(h ^ k1 ^ ((uint64_t)(len - 8) << 56));
+    } else if (len) {
+        h = mix64(h ^ k0 ^ ((uint64_t)len << 56));
+    }
+    return mix64(h);
+}
+
+// the low `nbytes` (0..8) bytes of w
+__host__ __device__ __forceinline__ uint64_t keep_bytes(uint64_t w, uint32_t nbytes) {
+    return nbytes >= 8 ? w : (nbytes ? (w & ((1ull << (8 * nbytes)) - 1ull)) : 0ull);
+}
+
+// A request's key as (hash, k0, k1).  Keys of at most 16 bytes that do not end within 16 bytes of the
+// arena's end are read with two unconditional 8-byte loads and masked -- one round trip instead of the
+// branchy 8/4/2/1-byte tail loads -- and hashed from the words.
+__device__ __forceinline__ uint64_t load_and_hash(const uint8_t* __restrict__ key_bytes, uint32_t off, uint32_t len, uint32_t arena,
+                                                  uint64_t& k0, uint64_t& k1) {
+    const uint8_t* key = key_bytes + off;
+    k0 = k1 = 0;
+    if (len > ENTRY_KEY) return hash_key(key, len);
+    if ((uint64_t)off + 16u <= arena) {
+        uint64_t a, b;
+        __builtin_memcpy(&a, key, 8);
+        __builtin_memcpy(&b, key + 8, 8);
+        k0 = keep_bytes(a, len);
+        k1 = len > 8 ? keep_bytes(b, len - 8) : 0ull;
+    } else {
+        short_key_words(key, len, k0, k1);
+    }
+    return hash_short(k0, k1, len);
 }
 
 // ---------------------------------------------------------------------------
@@ -166,18 +205,22 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
                                                    uint32_t* __restrict__ aux, uint64_t* __restrict__ hash_out) {
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     if (i >= n) return;
-    const uint32_t off = key_off[i], len = key_off[i + 1] - off;
+    const uint32_t off = key_off[i], len = key_off[i + 1] - off, arena = key_off[n];
     const uint8_t* key = key_bytes + off;
-    const uint64_t h = hash_key(key, len);
+    uint64_t k0, k1;
+    const uint64_t h = load_and_hash(key_bytes, off, len, arena, k0, k1);
     const unsigned long long meta = entry_meta(h, len);
-    uint64_t k0 = 0, k1 = 0;
-    if (len <= ENTRY_KEY) short_key_words(key, len, k0, k1);
     hash_out[i] = h;
     uint64_t pos = h & t.nb_mask;
     uint32_t st = ST_MISSING, slot = NO_SLOT, ax = 0;
     for (uint64_t probes = 0; probes <= t.nb_mask; ++probes) {
         Entry* en = &t.ktab[pos];
-        unsigned long long e = __hip_atomic_load(&en->w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // The whole 32-byte entry in one round trip, with plain loads: what they can show is either final
+        // for this kernel (bound entries and tombstones only change in other kernels; a pending entry keeps
+        // its claimant until k_bind) or "empty", which the compare-and-swap below settles.
+        const ulonglong2 lo = *reinterpret_cast<const ulonglong2*>(en);      // w, hash
+        const ulonglong2 hi = *(reinterpret_cast<const ulonglong2*>(en) + 1); // key[0], key[1]
+        unsigned long long e = lo.x;
         if (e == 0ull) {
             if (!INSERT) break;
             const unsigned long long mine = meta | (unsigned long long)(VAL_PENDING | i);
@@ -188,7 +231,7 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
                 ax = (uint32_t)pos;
                 break;
             }
-            e = expected; // somebody else took this entry: examine what is there now
+            e = expected; // somebody else claimed this entry in the meantime (it was empty: the claim is all there is)
         }
         const uint32_t val = (uint32_t)e;
         const bool meta_eq = (e & 0xFFFFFFFF00000000ull) == meta;
@@ -204,11 +247,11 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
                     break;
                 }
             }
-        } else if (meta_eq && en->hash == h) {
+        } else if (meta_eq && lo.y == h) {
             // bound in an earlier batch: hash / key / record are stable
             const uint32_t s = val - 2u;
             bool same;
-            if (len <= ENTRY_KEY) same = en->key[0] == k0 && en->key[1] == k1;
+            if (len <= ENTRY_KEY) same = hi.x == k0 && hi.y == k1;
             else same = t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len);
             if (same) {
                 st = ST_FOUND;

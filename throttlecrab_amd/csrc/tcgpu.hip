@@ -370,11 +370,17 @@ static int ensure_side_streams(tc_engine* e) {
     std::vector<hipStream_t> good, bad;
     for (int c = 0; c < 16 && good.size() < want; ++c) {
         hipStream_t s = nullptr;
-        TC_HIP(e, hipStreamCreateWithPriority(&s, hipStreamNonBlocking, e->aux_priority));
+        int rc = TC_E_OK;
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, e->aux_priority) != hipSuccess) rc = fail(e, TC_E_HIP, "hipStreamCreateWithPriority failed");
         bool ok = false;
-        int rc = streams_concurrent(e, m, s, &ok);
+        if (rc == TC_E_OK) rc = streams_concurrent(e, m, s, &ok);
         for (size_t g = 0; rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
-        if (rc != TC_E_OK) return rc;
+        if (rc != TC_E_OK) {
+            if (s) (void)hipStreamDestroy(s);
+            for (hipStream_t x : good) (void)hipStreamDestroy(x);
+            for (hipStream_t x : bad) (void)hipStreamDestroy(x);
+            return rc;
+        }
         (ok ? good : bad).push_back(s);
     }
     for (hipStream_t s : bad) (void)hipStreamDestroy(s);
@@ -636,17 +642,21 @@ extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slot
         int rc = upload_classes(e);
         if (rc != TC_E_OK) return rc;
     }
-    uint16_t* d_id = nullptr;
-    uint32_t* d_s = nullptr;
-    TC_HIP(e, hipMalloc(&d_id, n * sizeof(uint16_t)));
-    if (slots) TC_HIP(e, hipMalloc(&d_s, n * sizeof(uint32_t)));
-    TC_HIP(e, hipMemcpyAsync(d_id, ids.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice, cur_stream(e)));
-    if (slots) TC_HIP(e, hipMemcpyAsync(d_s, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
-    hipLaunchKernelGGL(k_scatter_rate_id, dim3(nblocks(n)), dim3(BLOCK), 0, cur_stream(e), e->rate_id, d_s, d_id, n);
+    struct Tmp { // upload buffers, released on every exit
+        uint16_t* id = nullptr;
+        uint32_t* slot = nullptr;
+        ~Tmp() {
+            if (id) (void)hipFree(id);
+            if (slot) (void)hipFree(slot);
+        }
+    } d;
+    TC_HIP(e, hipMalloc(&d.id, n * sizeof(uint16_t)));
+    if (slots) TC_HIP(e, hipMalloc(&d.slot, n * sizeof(uint32_t)));
+    TC_HIP(e, hipMemcpyAsync(d.id, ids.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice, cur_stream(e)));
+    if (slots) TC_HIP(e, hipMemcpyAsync(d.slot, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+    hipLaunchKernelGGL(k_scatter_rate_id, dim3(nblocks(n)), dim3(BLOCK), 0, cur_stream(e), e->rate_id, d.slot, d.id, n);
     TC_HIP(e, hipGetLastError());
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
-    (void)hipFree(d_id);
-    if (d_s) (void)hipFree(d_s);
     e->uniform_id = 0; // per-slot plans from now on: evaluation reads rate_id[]
     return TC_E_OK;
 }
@@ -742,7 +752,6 @@ static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params
     return true;
 }
 
-// all pointers in `b` are device pointers here
 // k_eval_sorted<.., ITEMS>: 2 positions per lane when the batch overlaps with its neighbours' sorts,
 // 4 when it runs alone (measured; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
 template <int ITEMS>
@@ -763,6 +772,7 @@ static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped,
     }
 }
 
+// all pointers in `b` are device pointers here
 static int run_slots_device(tc_engine* e, const tc_batch& b) {
     const uint32_t n = (uint32_t)b.n;
     Params p;
@@ -1246,7 +1256,7 @@ extern "C" int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* 
 }
 
 extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* tat, uint64_t* expiry) {
-    if (!e || first + n > e->capacity) return TC_E_INVALID_ARG;
+    if (!e || n > e->capacity || first > e->capacity - n) return TC_E_INVALID_ARG;
     if (n == 0) return TC_E_OK;
     TC_HIP(e, hipSetDevice(e->device));
     std::vector<Cell> h(n);
@@ -1359,17 +1369,21 @@ extern "C" int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uin
         TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
         e->k_busy = false;
     }
-    uint32_t* d_slots = nullptr;
-    kt::KeyRec* d_rec = nullptr;
-    TC_HIP(e, hipMalloc(&d_slots, n * sizeof(uint32_t)));
-    TC_HIP(e, hipMalloc(&d_rec, n * sizeof(kt::KeyRec)));
-    TC_HIP(e, hipMemcpyAsync(d_slots, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(k_gather_keyrecs, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->kt, d_slots, n, d_rec);
+    struct Tmp { // scratch, released on every exit
+        uint32_t* slots = nullptr;
+        kt::KeyRec* rec = nullptr;
+        ~Tmp() {
+            if (slots) (void)hipFree(slots);
+            if (rec) (void)hipFree(rec);
+        }
+    } d;
+    TC_HIP(e, hipMalloc(&d.slots, n * sizeof(uint32_t)));
+    TC_HIP(e, hipMalloc(&d.rec, n * sizeof(kt::KeyRec)));
+    TC_HIP(e, hipMemcpyAsync(d.slots, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_keyrecs, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->kt, d.slots, n, d.rec);
     std::vector<kt::KeyRec> h(n);
-    TC_HIP(e, hipMemcpyAsync(h.data(), d_rec, n * sizeof(kt::KeyRec), hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipMemcpyAsync(h.data(), d.rec, n * sizeof(kt::KeyRec), hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
-    (void)hipFree(d_slots);
-    (void)hipFree(d_rec);
     size_t at = 0;
     int rc = TC_E_OK;
     key_off[0] = 0;
@@ -1498,6 +1512,8 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     if (ok) { // rebuild the plan dictionary in id order
         e->host_classes.assign(1, RateClass{0, 0, 0, 0});
         e->class_of.clear();
+        e->cls_min_ei = e->cls_min_dvt = INT64_MAX;
+        e->cls_max_ei = e->cls_max_dvt = 0;
         for (uint64_t id = 1; id < h.n_classes && ok; ++id) {
             bool grew = false;
             ok = intern_class(e, plans[3 * id], plans[3 * id + 1], plans[3 * id + 2], &grew) == (int)id;

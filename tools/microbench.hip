@@ -44,15 +44,19 @@ __global__ __launch_bounds__(256) void k_pat16(const uint64_t* __restrict__ sort
     const uint64_t e = sorted[k];
     const uint32_t slot = (uint32_t)(e >> 32), idx = (uint32_t)e;
     long long v = slot;
+    typedef long long v2ll __attribute__((ext_vector_type(2)));
+    v2ll* cell = reinterpret_cast<v2ll*>(table + slot);
     if (MODE & 1) {
-        const Rec16 r = table[slot];
-        v = r.a + r.b;
+        const v2ll r = (MODE & 32) ? __builtin_nontemporal_load(cell) : *cell;
+        v = r.x + r.y;
     }
     if (MODE & 2) {
-        Rec16 w;
-        w.a = v + 1;
-        w.b = v + 2;
-        table[slot] = w;
+        v2ll w;
+        w.x = v + 1;
+        w.y = v + 2;
+        if (MODE & 64) *reinterpret_cast<long long*>(cell) = w.x; // 8 of the 16 bytes
+        else if (MODE & 16) __builtin_nontemporal_store(w, cell);
+        else *cell = w;
     }
     if (MODE & 4) out[idx] = (uint8_t)(v & 1);
     if (MODE & 8) out[k] = (uint8_t)(v & 1);
@@ -124,5 +128,10 @@ int main(int argc, char** argv) {
     ROW16(1 | 8, "gather 16B + coalesced byte store");
     ROW16(1 | 2 | 8, "gather 16B + store 16B + coalesced byte store");
     ROW16(1 | 2 | 4, "gather 16B + store 16B + scattered byte store");
+    ROW16(2 | 8, "store 16B only (no gather) + coalesced byte store");
+    ROW16(1 | 2 | 8 | 16, "gather 16B + NT store 16B + coalesced byte store");
+    ROW16(1 | 2 | 8 | 32, "NT gather 16B + store 16B + coalesced byte store");
+    ROW16(1 | 2 | 8 | 16 | 32, "NT gather 16B + NT store 16B + coalesced byte store");
+    ROW16(1 | 2 | 8 | 64, "gather 16B + store 8B + coalesced byte store");
     return 0;
 }
