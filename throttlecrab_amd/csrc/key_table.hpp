@@ -36,10 +36,9 @@
 namespace kt {
 
 constexpr int THREADS = 256;
-constexpr int BIND_THREADS = 1024; // k_bind: one free-stack pop per block, so few, fat blocks
 constexpr uint32_t VAL_EMPTY = 0u, VAL_TOMB = 1u, VAL_PENDING = 0x80000000u;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
-constexpr uint32_t ST_FOUND = 0u, ST_CLAIMANT = 1u, ST_FOLLOWER = 2u, ST_MISSING = 3u;
+constexpr uint32_t ST_FOUND = 0u, ST_CLAIMANT = 1u, ST_FOLLOWER = 2u, ST_MISSING = 3u, ST_NOSPACE = 4u; // NOSPACE: claimed an entry, but the overflow arena is full
 constexpr uint32_t INLINE_KEY = 48u;  // KeyRec
 constexpr uint32_t ENTRY_KEY = 16u;   // Entry
 constexpr uint32_t LEN8_LONG = 255u;
@@ -202,9 +201,11 @@ template <bool INSERT>
 __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __restrict__ key_bytes,
                                                    const uint32_t* __restrict__ key_off, uint32_t n,
                                                    uint32_t* __restrict__ slot_out, uint32_t* __restrict__ state,
-                                                   uint32_t* __restrict__ aux, uint64_t* __restrict__ hash_out) {
+                                                   uint32_t* __restrict__ aux, uint64_t* __restrict__ hash_out,
+                                                   uint32_t* __restrict__ claim_cnt) {
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
-    if (i >= n) return;
+    uint32_t st = ST_MISSING;
+    if (i < n) {
     const uint32_t off = key_off[i], len = key_off[i + 1] - off, arena = key_off[n];
     const uint8_t* key = key_bytes + off;
     uint64_t k0, k1;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
     const unsigned long long meta = entry_meta(h, len);
     hash_out[i] = h;
     uint64_t pos = h & t.nb_mask;
-    uint32_t st = ST_MISSING, slot = NO_SLOT, ax = 0;
+    uint32_t slot = NO_SLOT, ax = 0;
     for (uint64_t probes = 0; probes <= t.nb_mask; ++probes) {
         Entry* en = &t.ktab[pos];
         // The whole 32-byte entry in one round trip, with plain loads: what they can show is either final
@@ -261,9 +262,28 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
         }
         pos = (pos + 1) & t.nb_mask;
     }
+    if (INSERT && st == ST_CLAIMANT && len > INLINE_KEY) {
+        // long key: reserve its overflow bytes now, so that k_bind knows who takes a slot (offset / 16 rides in slot_out)
+        const unsigned long long ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
+        if (ovf + len > t.overflow_bytes) st = ST_NOSPACE;
+        else slot = (uint32_t)(ovf >> 4);
+    }
     slot_out[i] = slot;
     state[i] = st;
     aux[i] = ax;
+    }
+    if (INSERT) {
+        // claimants of this block, for k_bind's slot assignment (no atomics on the free stack)
+        __shared__ uint32_t s_claims[THREADS / 64];
+        const unsigned long long m = __ballot(i < n && st == ST_CLAIMANT);
+        if ((threadIdx.x & 63) == 0) s_claims[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t c = 0;
+            for (int w = 0; w < THREADS / 64; ++w) c += s_claims[w];
+            claim_cnt[blockIdx.x] = c;
+        }
+    }
 }
 
 // rank of each flagged lane inside its block + the block total (one barrier)
@@ -283,59 +303,43 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t& total) {
     return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
-// claimants: take a slot, store the key, publish the binding.  Slots are popped
-// from the free stack once per BLOCK and the insert counter is bumped once per
-// block: an atomic on one address costs ~12 ns and serialises (a per-wave add was
-// 197 us of a 225 us kernel), hence blocks of 1024.
-__global__ __launch_bounds__(BIND_THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
+// claimants: take a slot, store the key, publish the binding.  Claimant number R of the batch (in request
+// order: k_probe left the number of claimants per block in claim_cnt[]) takes free_slots[top - 1 - R]; the
+// stack pointer itself moves once, in k_follow.  No atomics: one on a single address costs ~12 ns and
+// serialises (a per-wave pop was 197 us of a 225 us kernel, a per-1024-block pop still 12 us).
+__global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
                                                   const uint32_t* __restrict__ key_off, uint32_t n,
                                                   uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ state,
                                                   const uint32_t* __restrict__ aux, const uint64_t* __restrict__ hash_in,
-                                                  unsigned long long* inserted_counter) {
-    __shared__ int s_old_top;
-    const uint32_t i = blockIdx.x * BIND_THREADS + threadIdx.x;
-    const bool claimant = i < n && state[i] == ST_CLAIMANT;
-    uint32_t off = 0, len = 0;
-    unsigned long long ovf = 0;
-    bool want = claimant;
-    if (claimant) {
-        off = key_off[i];
-        len = key_off[i + 1] - off;
-        if (len > INLINE_KEY) { // long key: reserve overflow bytes first
-            ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
-            if (ovf + len > t.overflow_bytes) want = false;
-        }
-    }
+                                                  const uint32_t* __restrict__ claim_cnt) {
+    __shared__ uint32_t s_part[THREADS / 64];
+    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    const uint32_t st = i < n ? state[i] : ST_FOUND;
+    const bool want = st == ST_CLAIMANT;
+    // claimants in the blocks before mine
+    uint32_t part = 0;
+    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += THREADS) part += claim_cnt[j];
+    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
     uint32_t total = 0;
-    const uint32_t rank = block_rank<BIND_THREADS>(want, total);
-    if (threadIdx.x == 0) {
-        int old = 0;
-        if (total) {
-            old = atomicSub(t.free_top, (int)total);
-            const int got = old < 0 ? 0 : (old < (int)total ? old : (int)total);
-            if (got < (int)total) atomicAdd(t.free_top, (int)total - got); // stack ran dry: undo the excess
-            if (got > 0) atomicAdd(inserted_counter, (unsigned long long)got);
-        }
-        s_old_top = old;
-    }
-    __syncthreads();
-    bool bound = false;
-    if (claimant) {
+    const uint32_t rank = block_rank<THREADS>(want, total); // (its barrier also publishes s_part)
+    if (want) {
+        uint32_t before = 0;
+        for (int w = 0; w < THREADS / 64; ++w) before += s_part[w];
+        const int top = *t.free_top; // moves in k_follow, not here
+        const int idx = top - 1 - (int)(before + rank);
+        const uint32_t off = key_off[i], len = key_off[i + 1] - off;
         const uint8_t* key = key_bytes + off;
         const uint32_t pos = aux[i];
         const uint64_t h = hash_in[i];
-        uint32_t slot = NO_SLOT;
-        if (want) {
-            const int idx = s_old_top - 1 - (int)rank;
-            if (idx >= 0) slot = t.free_slots[idx];
-        }
+        const uint32_t slot = idx >= 0 ? t.free_slots[idx] : NO_SLOT;
         if (slot != NO_SLOT) {
             KeyRec& kr = t.rec[slot];
             uint8_t* dst = kr.bytes;
             if (len > INLINE_KEY) {
-                const uint64_t o64 = ovf;
+                const uint64_t o64 = (uint64_t)slot_out[i] << 4; // reserved by k_probe
                 __builtin_memcpy(kr.bytes, &o64, 8);
-                dst = t.overflow + ovf; // reservations are 16-byte multiples: dst is 16-byte aligned
+                dst = t.overflow + o64; // reservations are 16-byte multiples: dst is 16-byte aligned
             }
             uint32_t b = 0;
             for (; b + 8 <= len; b += 8) {
@@ -355,22 +359,45 @@ __global__ __launch_bounds__(BIND_THREADS) void k_bind(Table t, const uint8_t* _
             en->key[0] = k0;
             en->key[1] = k1;
             en->w = entry_meta(h, len) | (unsigned long long)(slot + 2u);
-            bound = true;
-        } else {
+        } else { // the free stack ran dry
             t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
             atomicAdd(t.tombs, 1u);
             atomicExch(t.error_flag, 1u);
         }
         slot_out[i] = slot;
+    } else if (st == ST_NOSPACE) { // no room for a long key: give the claimed entry back as a tombstone
+        const uint32_t off = key_off[i], len = key_off[i + 1] - off;
+        t.ktab[aux[i]].w = entry_meta(hash_in[i], len) | VAL_TOMB;
+        atomicAdd(t.tombs, 1u);
+        atomicExch(t.error_flag, 1u);
+        slot_out[i] = NO_SLOT;
     }
-    (void)bound;
 }
 
-// duplicates of a key first seen in this batch take the claimant's slot
+// duplicates of a key first seen in this batch take the claimant's slot; block 0 also moves the free
+// stack's pointer past the slots k_bind handed out and counts the insertions
 __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __restrict__ slot_out,
-                                                    const uint32_t* __restrict__ state, const uint32_t* __restrict__ aux) {
+                                                    const uint32_t* __restrict__ state, const uint32_t* __restrict__ aux, Table t,
+                                                    const uint32_t* __restrict__ claim_cnt, uint32_t n_blocks,
+                                                    unsigned long long* inserted_counter) {
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     if (i < n && state[i] == ST_FOLLOWER) slot_out[i] = slot_out[aux[i]];
+    if (blockIdx.x == 0) {
+        __shared__ uint32_t s_tot[THREADS / 64];
+        uint32_t part = 0;
+        for (uint32_t j = threadIdx.x; j < n_blocks; j += THREADS) part += claim_cnt[j];
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
+        if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = part;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t total = 0;
+            for (int w = 0; w < THREADS / 64; ++w) total += s_tot[w];
+            const int top = *t.free_top;
+            const int got = top < 0 ? 0 : (top < (int)total ? top : (int)total);
+            *t.free_top = top - got;
+            if (got) atomicAdd(inserted_counter, (unsigned long long)got);
+        }
+    }
 }
 
 __global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint8_t* bound, uint32_t capacity) {

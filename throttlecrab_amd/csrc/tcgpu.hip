@@ -152,6 +152,7 @@ struct tc_engine {
     kt::Table kt;
     void* kt_block = nullptr;        // one allocation backing every kt.* array
     uint32_t *k_slot = nullptr, *k_state = nullptr, *k_aux = nullptr; // max_batch each
+    uint32_t* k_claim = nullptr;     // keys first seen in the batch, per k_probe block
     uint64_t* k_hash = nullptr;
     // Key stages mutate the key table and share the scratch above, so they run one after another in
     // call order: on the key stream for TC_B_INPUTS_READY device batches (overlapping the grouping and
@@ -323,6 +324,7 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     TC_HIP(e, hipEventCreateWithFlags(&e->m_done, hipEventDisableTiming));
     TC_HIP(e, hipMalloc(&e->k_state, mb * 4));
     TC_HIP(e, hipMalloc(&e->k_aux, mb * 4));
+    TC_HIP(e, hipMalloc(&e->k_claim, ((size_t)nblocks(mb) + 1) * 4));
     TC_HIP(e, hipMalloc(&e->k_hash, mb * 8));
     TC_HIP(e, hipMalloc(&e->k_stage_off, (mb + 1) * 4));
     TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
@@ -408,14 +410,14 @@ static int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint3
     prof_begin(e, TC_STAGE_HASH, s);
     if (insert) {
         hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux,
-                           e->k_hash);
-        hipLaunchKernelGGL(kt::k_bind, dim3((n + kt::BIND_THREADS - 1) / kt::BIND_THREADS), dim3(kt::BIND_THREADS), 0, s,
-                           e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_hash,
+                           e->k_hash, e->k_claim);
+        hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_hash,
+                           e->k_claim);
+        hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, out_slot, e->k_state, e->k_aux, e->kt, e->k_claim, grid.x,
                            e->counters + TC_CNT_KEYS_INSERTED);
-        hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, out_slot, e->k_state, e->k_aux);
     } else {
         hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state,
-                           e->k_aux, e->k_hash);
+                           e->k_aux, e->k_hash, (uint32_t*)nullptr);
     }
     prof_end(e, s);
     TC_HIP(e, hipGetLastError());
@@ -542,7 +544,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
         if (ss.k_slot) (void)hipFree(ss.k_slot);
-    void* kptrs[] = {e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_hash, e->k_stage_bytes, e->k_stage_off};
+    void* kptrs[] = {e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_hash, e->k_stage_bytes, e->k_stage_off};
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
