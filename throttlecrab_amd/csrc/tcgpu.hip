@@ -755,7 +755,7 @@ static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params
 }
 
 // k_eval_sorted<.., ITEMS>: 2 positions per lane when the batch overlaps with its neighbours' sorts,
-// 4 when it runs alone (measured; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
+// 4 when it runs alone (measured; 8 is slower everywhere; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
 template <int ITEMS>
 static void launch_eval_items(tc_engine* e, bool full, bool direct, uint32_t n, hipStream_t s, const Params& p, const uint64_t* sorted,
                               uint32_t seq) {
