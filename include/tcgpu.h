@@ -98,6 +98,15 @@ typedef struct tc_config {
  * (rate_limiter.rs:102-110), columnar.  A NULL input column means "use the
  * scalar of the same name for every request". */
 struct tc_decision;
+#define TC_B_ASYNC 0x20u             /* HOST-pointer slot batch that only enqueues: the inputs are copied to the device,
+                                     * evaluated and the outputs copied back asynchronously, overlapping the PCIe
+                                     * transfers of one batch with the evaluation of others.  Input and output
+                                     * arrays must stay untouched / are not valid until tc_wait_batches() says the
+                                     * batch is done (or tc_synchronize()).  For the copies to be asynchronous the
+                                     * arrays must be pinned (tc_host_alloc); with pageable memory the call is
+                                     * correct but waits for its transfers.  Results are those of the in-order
+                                     * sequence of calls, as always. */
+
 typedef struct tc_batch {
     uint32_t struct_size; /* = sizeof(tc_batch) */
     uint32_t flags;       /* TC_B_* */
@@ -199,6 +208,16 @@ int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64_t count_pe
  * TC_B_DEVICE_PTRS batches are asynchronous on the engine's stream. */
 int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* b);
 int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* b);
+
+/* TC_B_ASYNC batches: block until at most `max_in_flight` of them are still incomplete (0 = all done).
+ * A caller that cycles through K sets of pinned buffers calls tc_wait_batches(e, K - 1) before it
+ * refills the oldest set.  (The reference's actor answers one request per loop turn,
+ * throttlecrab-server/src/actor.rs:217-236; this is what lets a batch-draining actor fill the next
+ * batch while the previous ones are in flight.) */
+int tc_wait_batches(tc_engine* e, uint32_t max_in_flight);
+/* Pinned host memory for TC_B_ASYNC batches (hipHostMalloc / hipHostFree behind a C signature). */
+void* tc_host_alloc(size_t bytes);
+void tc_host_free(void* p);
 
 /* RateLimiter::rate_limit (rate_limiter.rs:102-250), one request, string key.
  * Returns 0 and fills *out (out->status carries the CellError). */

@@ -561,3 +561,69 @@ def test_grouped_output_rows(mode, dev):
             assert np.array_equal(back, getattr(ref, f).astype(np.int64)), (mode, f, rnd)
     assert_state_same(eng, orc, np.arange(cap))
     eng.close()
+
+
+@pytest.mark.parametrize("pinned", [True, False], ids=["pinned", "pageable"])
+@pytest.mark.parametrize("mode", ["uniform", "general", "mixed", "unique"])
+def test_async_host_batches(mode, pinned):
+    """TC_B_ASYNC: host-array batches that only enqueue (inputs staged on the grouping stream, outputs
+    copied back behind the evaluation).  A ring of 3 buffer sets is cycled 4 times with
+    tc_wait_batches(2) before each refill; results and state must equal the sequential oracle,
+    also when ordinary synchronous calls are mixed in."""
+    import throttlecrab_amd as t
+    cap, n, nb, K = (3000, 40000, 12, 3) if mode != "unique" else (50000, 40000, 12, 3)
+    rng = np.random.default_rng(91)
+    eng, orc = _engine(cap, n), _oracle(cap)
+
+    def buf(count, dtype):
+        return eng.host_alloc(count, dtype) if pinned else np.zeros(count, dtype)
+    sets = [dict(slots=buf(n, np.uint32), q=buf(n, np.int64), now=buf(n, np.int64),
+                 out=t.BatchResult(**{f: buf(n, np.uint8 if f in ("allowed", "status") else np.int64) for f in FIELDS}))
+            for _ in range(K)]
+    refs, got = [], []
+    for bidx in range(nb):
+        s = sets[bidx % K]
+        if bidx >= K:
+            eng.wait_batches(K - 1)            # the batch that used this set is done: keep its results, refill
+            got.append({f: getattr(s["out"], f).copy() for f in FIELDS})
+        if mode == "unique":
+            s["slots"][:] = rng.permutation(cap)[:n].astype(np.uint32)      # no slot twice (n <= cap here)
+        else:
+            s["slots"][:] = ((rng.zipf(1.2, n) * 2654435761) % cap).astype(np.uint32)
+        general = mode == "general" or (mode == "mixed" and bidx % 2 == 1)
+        sync_call = mode == "mixed" and bidx % 3 == 2
+        if general:
+            s["now"][:] = T0 + bidx * 10**8 + rng.integers(0, 10**8, n)
+            s["q"][:] = rng.integers(0, 3, n)
+            refs.append(orc.batch_slots(s["slots"], 5, 10, 60, s["q"], s["now"]))
+            eng.rate_limit_batch_slots(s["slots"], max_burst=5, count_per_period=10, period=60, quantity=s["q"], now_ns=s["now"],
+                                       want=FIELDS, out=s["out"], async_=not sync_call)
+        else:
+            now = T0 + bidx * 10**8
+            refs.append(orc.batch_slots(s["slots"], 5, 10, 60, 1, now))
+            eng.rate_limit_batch_slots(s["slots"], max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=now,
+                                       want=FIELDS, out=s["out"], async_=not sync_call, unique=(mode == "unique"))
+        if sync_call:
+            eng.wait_batches(0)                # (a synchronous call drains everything before it anyway)
+    eng.wait_batches(0)
+    for bidx in range(nb - K, nb):
+        got.append({f: getattr(sets[bidx % K]["out"], f).copy() for f in FIELDS})
+    assert len(got) == nb
+    for bidx in range(nb):
+        assert_same(t.BatchResult(**got[bidx]), refs[bidx], f"async {mode} batch {bidx}")
+    assert_state_same(eng, orc, np.arange(cap))
+    eng.close()
+
+
+def test_async_flag_misuse():
+    import torch
+    import throttlecrab_amd as t
+    eng = _engine(100, 1000)
+    ds = torch.zeros(10, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        eng.rate_limit_batch_slots(ds, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0, async_=True)
+    with pytest.raises(ValueError):   # a hidden dtype conversion would hand the engine a temporary
+        eng.rate_limit_batch_slots(np.zeros(10, np.int64), max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0,
+                                   async_=True)
+    eng.wait_batches(0)
+    eng.close()

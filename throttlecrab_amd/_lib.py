@@ -18,6 +18,7 @@ TC_OK, TC_NEGATIVE_QUANTITY, TC_INVALID_RATE_LIMIT, TC_INTERNAL = 0, 1, 2, 3
 TC_CFG_KEY_MODE = 0x1
 TC_CFG_TRACK_DENIED = 0x2
 TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY, TC_B_GROUPED_OUTPUT = 0x1, 0x2, 0x4, 0x8, 0x10
+TC_B_ASYNC = 0x20
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
 TC_CNT_COUNT = 8
 TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash")
@@ -59,6 +60,9 @@ SYMBOLS = {
     "tc_register_params_uniform": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64]),
     "tc_rate_limit_batch_slots": (C.c_int, [C.c_void_p, C.POINTER(tc_batch)]),
     "tc_rate_limit_batch_keys": (C.c_int, [C.c_void_p, C.POINTER(tc_batch)]),
+    "tc_wait_batches": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "tc_host_alloc": (C.c_void_p, [C.c_size_t]),
+    "tc_host_free": (None, [C.c_void_p]),
     "tc_rate_limit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_int64, C.POINTER(tc_result)]),
     "tc_sweep_expired": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]),

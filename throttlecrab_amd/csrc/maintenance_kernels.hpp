@@ -257,4 +257,30 @@ __global__ void k_probe_set(uint32_t* flag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------
+// Plain copy, used for device memory -> PINNED host memory (which the GPU addresses directly): the result
+// transfers of TC_B_ASYNC batches are ordinary kernels on the engine's stream (see copy_back_async).
+// 16 bytes per lane per step when both ends and the size allow, else bytes.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, const void* __restrict__ src, size_t bytes) {
+    const size_t tid = (size_t)blockIdx.x * BLOCK + threadIdx.x, nthreads = (size_t)gridDim.x * BLOCK;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+        const size_t n16 = bytes / 16;
+        const uint4* s = static_cast<const uint4*>(src);
+        uint4* d = static_cast<uint4*>(dst);
+        size_t i = tid;
+        for (; i + 3 * nthreads < n16; i += 4 * nthreads) { // four loads in flight per lane: PCIe latency, few waves
+            const uint4 a = s[i], b = s[i + nthreads], c = s[i + 2 * nthreads], e = s[i + 3 * nthreads];
+            d[i] = a;
+            d[i + nthreads] = b;
+            d[i + 2 * nthreads] = c;
+            d[i + 3 * nthreads] = e;
+        }
+        for (; i < n16; i += nthreads) d[i] = s[i];
+        for (i = n16 * 16 + tid; i < bytes; i += nthreads) static_cast<uint8_t*>(dst)[i] = static_cast<const uint8_t*>(src)[i];
+    } else {
+        for (size_t i = tid; i < bytes; i += nthreads) static_cast<uint8_t*>(dst)[i] = static_cast<const uint8_t*>(src)[i];
+    }
+}
+
 } // namespace mk

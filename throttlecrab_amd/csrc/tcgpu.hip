@@ -26,6 +26,7 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <deque>
 #include <vector>
 
 #include "../../include/tcgpu.h"
@@ -102,6 +103,8 @@ struct tc_engine {
         uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
         uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
         uint32_t* k_slot = nullptr;                    // key mode: slots resolved for the batch using this set
+        uint32_t* h_slot = nullptr;                    // TC_B_ASYNC: the host batch's slot column, staged (lazy)
+        int64_t* h_in[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // ... and its request columns (lazy)
         uint32_t hist_parity = 0;
         hipEvent_t sorted = nullptr;   // recorded on the auxiliary stream after the last pass
         hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
@@ -142,8 +145,11 @@ struct tc_engine {
         tc_decision* decisions = nullptr;
         uint32_t* order = nullptr;
         uint8_t* status = nullptr;
-        bool ready = false;
     } stage;
+
+    // TC_B_ASYNC host batches still in flight, oldest first: one event per batch, recorded behind its last copy
+    std::deque<hipEvent_t> async_done;
+    std::vector<hipEvent_t> async_pool;
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
 
@@ -526,7 +532,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.elem_a, ss.elem_b, ss.ws};
+        void* sp[] = {ss.elem_a, ss.elem_b, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4]};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
@@ -548,6 +554,8 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->async_done) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->async_pool) (void)hipEventDestroy(ev);
     if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
     delete e;
 }
@@ -565,6 +573,11 @@ extern "C" int tc_synchronize(tc_engine* e) {
     if (!e) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    // every TC_B_ASYNC batch recorded its completion on this stream
+    while (!e->async_done.empty()) {
+        e->async_pool.push_back(e->async_done.front());
+        e->async_done.pop_front();
+    }
     return TC_E_OK;
 }
 
@@ -664,19 +677,93 @@ extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slot
 }
 
 // ---- batch over slots -------------------------------------------------------
-static int stage_ensure(tc_engine* e) {
-    if (e->stage.ready) return TC_E_OK;
+// The device-side address of a pinned host array (tc_host_alloc / hipHostMalloc / hipHostRegister), or
+// nullptr for pageable memory.
+static void* device_view_of_host(const void* host) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) {
+        (void)hipGetLastError(); // pageable memory: not an error for us
+        return nullptr;
+    }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
+// Results of a TC_B_ASYNC batch -> the caller's host array, on stream `st`: a copy kernel when the array is
+// pinned, hipMemcpyAsync otherwise (correct, but the call may wait for the transfer).  hipMemcpyAsync of
+// device -> pinned host memory behind kernels stalled the submitting thread for 7-13 ms every few dozen
+// batches (host -> device through the SDMA engines does not, and unlike a copy kernel reading over PCIe it
+// does not slow the kernels running beside it: 41 vs 100 us for the evaluation).
+static int copy_back_async(tc_engine* e, void* host, const void* dev, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return TC_E_OK;
+    void* hv = device_view_of_host(host);
+    if (!hv) {
+        TC_HIP(e, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+        return TC_E_OK;
+    }
+    // few blocks: the transfer is bound by the PCIe link, and a grid that fills the chip with waves waiting on
+    // the link starves the kernels running beside it
+    const uint32_t blocks = (uint32_t)std::min<size_t>((bytes / 16 + BLOCK - 1) / BLOCK + 1, 48);
+    hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(BLOCK), 0, st, hv, dev, bytes);
+    return TC_E_OK;
+}
+
+// device staging for host-pointer batches, allocated per array on first use
+template <class T>
+static int stage_need(tc_engine* e, T*& p, size_t count) {
+    if (!p) TC_HIP(e, hipMalloc(&p, count * sizeof(T)));
+    return TC_E_OK;
+}
+#define TC_TRY(call)                  \
+    do {                              \
+        int _trc = (call);            \
+        if (_trc != TC_E_OK) return _trc; \
+    } while (0)
+
+// output staging for the arrays `b` asks for; `d` gets the device pointers
+static int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d) {
     const uint64_t mb = e->max_batch;
-    TC_HIP(e, hipMalloc(&e->stage.slot, mb * sizeof(uint32_t)));
-    for (int j = 0; j < 5; ++j) TC_HIP(e, hipMalloc(&e->stage.in[j], mb * sizeof(int64_t)));
-    TC_HIP(e, hipMalloc(&e->stage.allowed, mb));
-    TC_HIP(e, hipMalloc(&e->stage.bits, ((mb + 63) / 64) * sizeof(uint64_t)));
-    for (int j = 0; j < 4; ++j) TC_HIP(e, hipMalloc(&e->stage.out[j], mb * sizeof(int64_t)));
-    TC_HIP(e, hipMalloc(&e->stage.result4, mb * 4 * sizeof(int64_t)));
-    TC_HIP(e, hipMalloc(&e->stage.decisions, mb * sizeof(tc_decision)));
-    TC_HIP(e, hipMalloc(&e->stage.order, mb * sizeof(uint32_t)));
-    TC_HIP(e, hipMalloc(&e->stage.status, mb));
-    e->stage.ready = true;
+    tc_engine::Stage& st = e->stage;
+    if (b.allowed) TC_TRY(stage_need(e, st.allowed, mb));
+    if (b.allowed_bits) TC_TRY(stage_need(e, st.bits, (mb + 63) / 64));
+    int64_t* const want[4] = {b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns};
+    for (int j = 0; j < 4; ++j)
+        if (want[j]) TC_TRY(stage_need(e, st.out[j], mb));
+    if (b.status) TC_TRY(stage_need(e, st.status, mb));
+    if (b.result4) TC_TRY(stage_need(e, st.result4, mb * 4));
+    if (b.decisions) TC_TRY(stage_need(e, st.decisions, mb));
+    if (b.order) TC_TRY(stage_need(e, st.order, mb));
+    d.allowed = b.allowed ? st.allowed : nullptr;
+    d.allowed_bits = b.allowed_bits ? st.bits : nullptr;
+    d.limit = b.limit ? st.out[0] : nullptr;
+    d.remaining = b.remaining ? st.out[1] : nullptr;
+    d.reset_after_ns = b.reset_after_ns ? st.out[2] : nullptr;
+    d.retry_after_ns = b.retry_after_ns ? st.out[3] : nullptr;
+    d.status = b.status ? st.status : nullptr;
+    d.result4 = b.result4 ? st.result4 : nullptr;
+    d.decisions = b.decisions ? st.decisions : nullptr;
+    d.order = b.order ? st.order : nullptr;
+    return TC_E_OK;
+}
+
+// staged outputs -> the caller's host arrays, enqueued on `s` (by_kernel: TC_B_ASYNC, see copy_back_async)
+static int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_kernel = false) {
+    const uint64_t n = b.n;
+    const tc_engine::Stage& st = e->stage;
+    auto back = [&](void* host, const void* dev, size_t bytes) -> int {
+        if (by_kernel) return copy_back_async(e, host, dev, bytes, s);
+        TC_HIP(e, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+        return TC_E_OK;
+    };
+    if (b.allowed) TC_TRY(back(b.allowed, st.allowed, n));
+    if (b.allowed_bits) TC_TRY(back(b.allowed_bits, st.bits, ((n + 63) / 64) * sizeof(uint64_t)));
+    int64_t* hout[4] = {b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns};
+    for (int j = 0; j < 4; ++j)
+        if (hout[j]) TC_TRY(back(hout[j], st.out[j], n * sizeof(int64_t)));
+    if (b.status) TC_TRY(back(b.status, st.status, n));
+    if (b.result4) TC_TRY(back(b.result4, st.result4, n * 4 * sizeof(int64_t)));
+    if (b.decisions) TC_TRY(back(b.decisions, st.decisions, n * sizeof(tc_decision)));
+    if (b.order && (b.flags & TC_B_GROUPED_OUTPUT)) TC_TRY(back(b.order, st.order, n * sizeof(uint32_t)));
     return TC_E_OK;
 }
 
@@ -774,8 +861,32 @@ static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped,
     }
 }
 
-// all pointers in `b` are device pointers here
-static int run_slots_device(tc_engine* e, const tc_batch& b) {
+// input arrays of a TC_B_ASYNC host batch, staged inside run_slots_device on the stream that groups the batch
+struct HostIn {
+    const uint32_t* slot = nullptr;
+    const int64_t* col[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // burst, count, period, quantity, now
+};
+
+// host arrays -> the scratch set's staging columns, enqueued on `st`; `p` gets the device pointers
+static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn& hin, uint32_t n, hipStream_t st, Params& p,
+                             const uint32_t** d_slot) {
+    const uint64_t mb = e->max_batch;
+    if (!ss.h_slot) TC_HIP(e, hipMalloc(&ss.h_slot, mb * sizeof(uint32_t)));
+    TC_HIP(e, hipMemcpyAsync(ss.h_slot, hin.slot, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st)); // SDMA when pinned
+    *d_slot = ss.h_slot;
+    p.slot = ss.h_slot;
+    const int64_t** dst[5] = {&p.burst, &p.count, &p.period, &p.q, &p.now};
+    for (int j = 0; j < 5; ++j) {
+        if (!hin.col[j]) continue;
+        if (!ss.h_in[j]) TC_HIP(e, hipMalloc(&ss.h_in[j], mb * sizeof(int64_t)));
+        TC_HIP(e, hipMemcpyAsync(ss.h_in[j], hin.col[j], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        *dst[j] = ss.h_in[j];
+    }
+    return TC_E_OK;
+}
+
+// all pointers in `b` are device pointers here (hin: the inputs are host arrays still to be staged)
+static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin = nullptr) {
     const uint32_t n = (uint32_t)b.n;
     Params p;
     p.n = n;
@@ -816,10 +927,23 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
     hipStream_t s = cur_stream(e);
 
     if (b.flags & TC_B_UNIQUE_SLOTS) {
+        if (hin) {
+            // (a set's staging columns are only read by work that this stream has already been ordered behind)
+            tc_engine::SortSet& ss = e->sets[e->next_set];
+            e->next_set = (e->next_set + 1) % e->depth;
+            if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(s, ss.consumed, 0));
+            const uint32_t* d_slot = nullptr;
+            TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
+        }
         prof_begin(e, TC_STAGE_EVAL, s);
         if (full) hipLaunchKernelGGL(k_eval_unique<true>, grid, block, 0, s, p);
         else hipLaunchKernelGGL(k_eval_unique<false>, grid, block, 0, s, p);
         prof_end(e, s);
+        if (hin) {
+            tc_engine::SortSet& ss = e->sets[(e->next_set + e->depth - 1) % e->depth];
+            TC_HIP(e, hipEventRecord(ss.consumed, s));
+            ss.in_use = true;
+        }
     } else {
         // grouping: on the set's auxiliary stream when the caller vouches for the inputs
         // (overlaps with the evaluation of earlier batches), else in order on `s`
@@ -832,18 +956,21 @@ static int run_slots_device(tc_engine* e, const tc_batch& b) {
             piped = e->n_aux != 0; // no free hardware queue: in order on the main stream
         }
         const uint64_t* sorted;
+        const uint32_t* d_slot = b.slot;
         if (piped) {
             hipStream_t ax = e->aux[e->next_aux];
             e->next_aux = (e->next_aux + 1) % e->n_aux;
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
             if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
-            sorted = sort_by_slot(e, ss, ax, b.slot, n, true);
+            if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true);
             TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
         } else {
             // everything that used this set earlier is ordered before us on `s`: evaluations ran on `s`,
             // and every auxiliary sort was joined into `s` before its evaluation
-            sorted = sort_by_slot(e, ss, s, b.slot, n, false);
+            if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
+            sorted = sort_by_slot(e, ss, s, d_slot, n, false);
         }
         const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!p.burst && !p.count && !p.period);
         const bool uniform = !p.q && !p.now && params_by_slot;
@@ -890,6 +1017,7 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     hipStream_t s = cur_stream(e);
     tc_batch d = b;
     d.flags |= TC_B_DEVICE_PTRS;
+    d.flags &= ~(TC_B_INPUTS_READY | TC_B_ASYNC);
     d.slot = e->stage.slot;
     d.key_bytes = nullptr;
     d.key_off = nullptr;
@@ -897,35 +1025,46 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     const int64_t** din[5] = {&d.max_burst, &d.count_per_period, &d.period, &d.quantity, &d.now_ns};
     for (int j = 0; j < 5; ++j) {
         if (hin[j]) {
+            TC_TRY(stage_need(e, e->stage.in[j], e->max_batch));
             TC_HIP(e, hipMemcpyAsync(e->stage.in[j], hin[j], n * sizeof(int64_t), hipMemcpyHostToDevice, s));
             *din[j] = e->stage.in[j];
         }
     }
-    d.allowed = b.allowed ? e->stage.allowed : nullptr;
-    d.allowed_bits = b.allowed_bits ? e->stage.bits : nullptr;
-    d.limit = b.limit ? e->stage.out[0] : nullptr;
-    d.remaining = b.remaining ? e->stage.out[1] : nullptr;
-    d.reset_after_ns = b.reset_after_ns ? e->stage.out[2] : nullptr;
-    d.retry_after_ns = b.retry_after_ns ? e->stage.out[3] : nullptr;
-    d.status = b.status ? e->stage.status : nullptr;
-    d.result4 = b.result4 ? e->stage.result4 : nullptr;
-    d.decisions = b.decisions ? e->stage.decisions : nullptr;
-    d.order = b.order ? e->stage.order : nullptr;
+    TC_TRY(stage_outputs(e, b, d));
     e->batches++;
-    int rc = run_slots_device(e, d);
-    if (rc != TC_E_OK) return rc;
-    if (b.allowed) TC_HIP(e, hipMemcpyAsync(b.allowed, e->stage.allowed, n, hipMemcpyDeviceToHost, s));
-    if (b.allowed_bits)
-        TC_HIP(e, hipMemcpyAsync(b.allowed_bits, e->stage.bits, ((n + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    int64_t* hout[4] = {b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns};
-    for (int j = 0; j < 4; ++j)
-        if (hout[j]) TC_HIP(e, hipMemcpyAsync(hout[j], e->stage.out[j], n * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    if (b.status) TC_HIP(e, hipMemcpyAsync(b.status, e->stage.status, n, hipMemcpyDeviceToHost, s));
-    if (b.result4) TC_HIP(e, hipMemcpyAsync(b.result4, e->stage.result4, n * 4 * sizeof(int64_t), hipMemcpyDeviceToHost, s));
-    if (b.decisions) TC_HIP(e, hipMemcpyAsync(b.decisions, e->stage.decisions, n * sizeof(tc_decision), hipMemcpyDeviceToHost, s));
-    if (b.order && (b.flags & TC_B_GROUPED_OUTPUT))
-        TC_HIP(e, hipMemcpyAsync(b.order, e->stage.order, n * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    TC_TRY(run_slots_device(e, d));
+    TC_TRY(copy_outputs_back(e, b, s));
     TC_HIP(e, hipStreamSynchronize(s));
+    return TC_E_OK;
+}
+
+// TC_B_ASYNC: the host batch's inputs are staged on the stream that groups it (overlapping the evaluation
+// of earlier batches), the outputs are copied back behind its evaluation, nothing waits.
+static int run_slots_host_async(tc_engine* e, const tc_batch& b) {
+    tc_batch d = b;
+    d.flags |= TC_B_DEVICE_PTRS | TC_B_INPUTS_READY; // the host arrays are complete at call time by contract
+    d.flags &= ~TC_B_ASYNC;
+    d.slot = nullptr;
+    d.max_burst = d.count_per_period = d.period = d.quantity = d.now_ns = nullptr;
+    d.key_bytes = nullptr;
+    d.key_off = nullptr;
+    HostIn hin;
+    hin.slot = b.slot;
+    hin.col[0] = b.max_burst, hin.col[1] = b.count_per_period, hin.col[2] = b.period, hin.col[3] = b.quantity, hin.col[4] = b.now_ns;
+    TC_TRY(stage_outputs(e, b, d));
+    e->batches++;
+    TC_TRY(run_slots_device(e, d, &hin));
+    hipStream_t s = cur_stream(e);
+    TC_TRY(copy_outputs_back(e, b, s, true));
+    hipEvent_t ev = nullptr;
+    if (!e->async_pool.empty()) {
+        ev = e->async_pool.back();
+        e->async_pool.pop_back();
+    } else {
+        TC_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    e->async_done.push_back(ev);
+    TC_HIP(e, hipEventRecord(ev, s));
     return TC_E_OK;
 }
 
@@ -939,14 +1078,37 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     if (e->key_mode) return fail(e, TC_E_INVALID_ARG, "key-mode engine: slots are assigned by the key table; use tc_rate_limit_batch_keys");
     TC_HIP(e, hipSetDevice(e->device));
     if (b.flags & TC_B_DEVICE_PTRS) {
+        if (b.flags & TC_B_ASYNC) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
         e->batches++;
         return run_slots_device(e, b);
     }
+    if (b.flags & TC_B_ASYNC) return run_slots_host_async(e, b);
     // host pointers: stage in, run, stage out, synchronise
-    int rc = stage_ensure(e);
-    if (rc != TC_E_OK) return rc;
+    TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
     TC_HIP(e, hipMemcpyAsync(e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
     return run_slots_host_staged(e, b);
+}
+
+extern "C" int tc_wait_batches(tc_engine* e, uint32_t max_in_flight) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    while (e->async_done.size() > max_in_flight) {
+        hipEvent_t ev = e->async_done.front();
+        TC_HIP(e, hipEventSynchronize(ev));
+        e->async_done.pop_front();
+        e->async_pool.push_back(ev);
+    }
+    return TC_E_OK;
+}
+
+extern "C" void* tc_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void tc_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 // did any key of the batches since the last check fail to get a slot?
@@ -971,6 +1133,7 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
     if (b.flags & (TC_B_REGISTERED_PARAMS | TC_B_UNIQUE_SLOTS))
         return fail(e, TC_E_INVALID_ARG, "registered params / unique-slot promise do not apply to string keys");
+    if (b.flags & TC_B_ASYNC) return fail(e, TC_E_UNSUPPORTED, "TC_B_ASYNC: slot batches only");
     TC_HIP(e, hipSetDevice(e->device));
     const uint8_t* d_bytes = b.key_bytes;
     const uint32_t* d_off = b.key_off;
@@ -1004,8 +1167,7 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     if (rc != TC_E_OK) return rc;
     // host pointers for everything else: reuse the slot path's staging, with the
     // slot column already on the device
-    rc = stage_ensure(e);
-    if (rc != TC_E_OK) return rc;
+    TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
     TC_HIP(e, hipMemcpyAsync(e->stage.slot, e->k_slot, b.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, cur_stream(e)));
     rc = run_slots_host_staged(e, b);
     if (rc != TC_E_OK) return rc;

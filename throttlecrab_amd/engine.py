@@ -6,6 +6,7 @@ the engine's stream, results written into CUDA tensors).
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 from typing import Optional
 
@@ -29,14 +30,30 @@ class BatchResult:
     __slots__ = ("allowed", "allowed_bits", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status",
                  "result4", "decisions", "order")
 
-    def __init__(self):
+    def __init__(self, **arrays):
         for s in self.__slots__:
-            setattr(self, s, None)
+            setattr(self, s, arrays.pop(s, None))
+        if arrays:
+            raise TypeError(f"unknown result fields: {sorted(arrays)}")
 
 
 _NP_DTYPES = {"allowed": np.uint8, "allowed_bits": np.uint64, "limit": np.int64, "remaining": np.int64,
               "reset_after_ns": np.int64, "retry_after_ns": np.int64, "status": np.uint8, "result4": np.int64,
               "decisions": np.int64}
+
+
+class _PinnedBlock:
+    """Frees one tc_host_alloc block when the last numpy view of it is gone (it hangs off the ctypes
+    array that is the views' base)."""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self._lib.tc_host_free(C.c_void_p(self._ptr))
+        except Exception:
+            pass
 
 
 class Engine:
@@ -66,6 +83,7 @@ class Engine:
         cfg.max_batch = max_batch
         cfg.key_arena_bytes = key_arena_bytes
         err = C.c_int(0)
+        self._async_keep = collections.deque()
         self._h = self._lib.tc_engine_create(C.byref(cfg), C.byref(err))
         if not self._h:
             raise TcError(err.value, "tc_engine_create failed (is an MI355X visible and libtcgpu.so built for gfx950?)")
@@ -146,7 +164,7 @@ class Engine:
         setattr(batch, name, arr.ctypes.data)
 
     def _prepare(self, n, dev, max_burst, count_per_period, period, quantity, now_ns, registered, unique,
-                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False):
+                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False, async_=False):
         keep = []
         b = L.tc_batch()
         b.struct_size = C.sizeof(L.tc_batch)
@@ -164,6 +182,10 @@ class Engine:
             flags |= L.TC_B_INPUTS_READY
         if grouped:
             flags |= L.TC_B_GROUPED_OUTPUT
+        if async_:
+            if dev:
+                raise ValueError("async_ applies to host-array batches (CUDA-tensor batches are asynchronous anyway)")
+            flags |= L.TC_B_ASYNC
         b.flags = flags
         b.quantity_scalar = 1
         if not registered:
@@ -203,8 +225,12 @@ class Engine:
 
     def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
                                now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
-                               out: Optional[BatchResult] = None, inputs_ready=False, grouped=False) -> BatchResult:
+                               out: Optional[BatchResult] = None, inputs_ready=False, grouped=False,
+                               async_=False) -> BatchResult:
         """rate_limit_batch over pre-resolved slots (sequential semantics, index order).
+        async_=True (TC_B_ASYNC, host arrays): only enqueue -- transfers and evaluation overlap with
+        other batches; `slots`, per-request columns and the arrays of `out` must be uint32 / int64 /
+        uint8 numpy arrays (pinned: host_alloc) that stay untouched until wait_batches() says so.
         grouped=True (TC_B_GROUPED_OUTPUT): output rows come in the engine's evaluation order and
         res.order[k] is the request index of row k.
         inputs_ready=True (TC_B_INPUTS_READY): the CUDA `slots` tensor is already complete and
@@ -218,16 +244,37 @@ class Engine:
             n = slots.numel()
             sp = slots.data_ptr()
         else:
+            if async_ and not (isinstance(slots, np.ndarray) and slots.dtype == np.uint32 and slots.flags.c_contiguous):
+                raise ValueError("async_: slots must be a C-contiguous uint32 numpy array (no hidden copy may be made)")
             sl = np.ascontiguousarray(slots, dtype=np.uint32)
             keep.append(sl)
             n = sl.size
             sp = sl.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
-                                   unique, want, out, inputs_ready, grouped)
+                                   unique, want, out, inputs_ready, grouped, async_)
         b.slot = sp
         if n:
             self._check(self._lib.tc_rate_limit_batch_slots(self._h, C.byref(b)))
+            if async_:
+                self._async_keep.append((keep, k2))  # arrays stay referenced while the batch is in flight
         return res
+
+    def wait_batches(self, max_in_flight: int = 0) -> None:
+        """Block until at most `max_in_flight` async_ batches are still incomplete (tc_wait_batches)."""
+        self._check(self._lib.tc_wait_batches(self._h, max_in_flight))
+        while len(self._async_keep) > max_in_flight:
+            self._async_keep.popleft()
+
+    def host_alloc(self, n: int, dtype) -> np.ndarray:
+        """Pinned host array for async_ batches (tc_host_alloc); freed when the array is garbage-collected."""
+        dt = np.dtype(dtype)
+        nbytes = max(1, int(n) * dt.itemsize)
+        ptr = self._lib.tc_host_alloc(nbytes)
+        if not ptr:
+            raise MemoryError(f"tc_host_alloc({nbytes}) failed")
+        buf = (C.c_uint8 * nbytes).from_address(ptr)
+        buf._owner = _PinnedBlock(self._lib, ptr)
+        return np.frombuffer(buf, dtype=dt, count=int(n))
 
     def rate_limit_batch_keys(self, key_bytes, key_off, *, max_burst=None, count_per_period=None, period=None,
                               quantity=None, now_ns=None, want=ALL_FIELDS,
