@@ -176,9 +176,39 @@ def keys_bench(a, dev):
     c = eng.counters()
     eng.close()
     swept = c["swept"] - swept0
-    return {"value": steps * B / dt, "unit": "decisions/s", "steps": steps, "keys_inserted": c["keys_inserted"],
-            "swept": swept, "allowed_fraction": c["allowed"] / max(1, c["total"]),
-            "workload": f"string keys key_<id>, {B} requests/batch, 20% new keys, sweep every 4 batches"}
+    res = {"value": steps * B / dt, "unit": "decisions/s", "steps": steps, "keys_inserted": c["keys_inserted"],
+           "swept": swept, "allowed_fraction": c["allowed"] / max(1, c["total"]),
+           "workload": f"string keys key_<id>, {B} requests/batch, 20% new keys, sweep every 4 batches"}
+    # the same stream handed over as HOST arrays (PCIe-inclusive): TC_B_ASYNC batches from pinned memory, at most
+    # 3 in flight; key arena + offsets go in, one decision byte per request comes back
+    eng = t.Engine(cap, B, device=dev.index or 0, key_mode=True)
+    eng.use_torch_stream()
+    pinned = []
+    for kb_d, ko_d in batches:
+        kb, ko = eng.host_alloc(kb_d.numel(), np.uint8), eng.host_alloc(ko_d.numel(), np.uint32)
+        kb[:] = kb_d.cpu().numpy()
+        ko[:] = ko_d.cpu().numpy().astype(np.uint32)
+        pinned.append((kb, ko))
+    outs = [t.BatchResult(allowed=eng.host_alloc(B, np.uint8)) for _ in range(3)]
+
+    def one_host(s, async_):
+        kb, ko = pinned[s]
+        if async_ and s >= pre + 3:
+            eng.wait_batches(2)
+        eng.rate_limit_batch_keys(kb, ko, max_burst=10, count_per_period=100, period=60, quantity=1,
+                                  now_ns=W.T0_NS + s * 10**9, want=("allowed",), out=outs[s % 3], async_=async_)
+    for s in range(pre):
+        one_host(s, False)
+    t0 = time.perf_counter()
+    for s in range(pre, pre + steps):
+        one_host(s, True)
+        if (s - pre) % 4 == 3:
+            eng.sweep_expired_async(W.T0_NS + s * 10**9)
+    eng.wait_batches(0)
+    eng.synchronize()
+    res["host_buffers_pinned_async_pcie_inclusive"] = {"value": steps * B / (time.perf_counter() - t0), "unit": "decisions/s"}
+    eng.close()
+    return res
 
 
 def cpu_baseline(kind, n_keys, batch, n_batches):

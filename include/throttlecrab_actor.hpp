@@ -177,44 +177,76 @@ class RateLimiterActor {
     }
 
   private:
-    // actor.rs:217-236, draining the queue instead of taking one message
+    // actor.rs:217-236, draining the queue instead of taking one message -- and pipelined: a drained batch
+    // is only SUBMITTED (RateLimiter::submit_batch: marshalled into pinned buffers, transfers and evaluation
+    // enqueued); while the GPU works on it the loop drains and marshals the next one, and the replies of
+    // the oldest batch in flight go out when the pipeline is full or the queue has nothing to add.
+    // Evaluation order == queue order, as with one batch at a time.
     static void run_actor(detail::Channel& ch, RateLimiter& limiter, size_t max_batch, std::chrono::microseconds linger,
                           size_t min_batch) {
-        std::vector<RateLimiterMessage> msgs;
+        std::deque<std::vector<RateLimiterMessage>> flying; // submitted batches, oldest first
         while (true) {
-            msgs.clear();
+            std::vector<RateLimiterMessage> msgs;
             {
                 std::unique_lock<std::mutex> lk(ch.mu);
-                ch.not_empty.wait(lk, [&] { return ch.closed || !ch.queue.empty(); });
-                if (ch.queue.empty()) break; // closed and drained
-                if (linger.count() > 0 && ch.queue.size() < min_batch && !ch.closed)
-                    ch.not_empty.wait_for(lk, linger, [&] { return ch.closed || ch.queue.size() >= min_batch; });
+                if (flying.empty()) { // nothing to answer meanwhile: wait for work
+                    ch.not_empty.wait(lk, [&] { return ch.closed || !ch.queue.empty(); });
+                    if (ch.queue.empty()) break; // closed and drained
+                    if (linger.count() > 0 && ch.queue.size() < min_batch && !ch.closed)
+                        ch.not_empty.wait_for(lk, linger, [&] { return ch.closed || ch.queue.size() >= min_batch; });
+                }
                 const size_t take = ch.queue.size() < max_batch ? ch.queue.size() : max_batch;
                 msgs.reserve(take);
                 for (size_t i = 0; i < take; ++i) {
                     msgs.push_back(std::move(ch.queue.front()));
                     ch.queue.pop_front();
                 }
-                ch.batches += 1;
-                ch.requests += take;
-                if (take > ch.largest_batch) ch.largest_batch = take;
+                if (take) {
+                    ch.batches += 1;
+                    ch.requests += take;
+                    if (take > ch.largest_batch) ch.largest_batch = take;
+                }
             }
-            ch.not_full.notify_all();
-            handle_throttle_batch(limiter, msgs);
+            const bool took = !msgs.empty();
+            if (took) {
+                ch.not_full.notify_all();
+                if (submit_throttle_batch(limiter, msgs)) flying.push_back(std::move(msgs));
+            }
+            // answer the oldest batch when the pipeline is full or the queue had nothing to add
+            if (!flying.empty() && (flying.size() >= RateLimiter::FLIGHTS || !took)) {
+                answer_throttle_batch(limiter, flying.front());
+                flying.pop_front();
+            }
         }
     }
 
-    // actor.rs:238-255 for a whole batch; send errors are ignored like in the reference
-    // (the receiver may have given up, actor.rs:229-230)
-    static void handle_throttle_batch(RateLimiter& limiter, std::vector<RateLimiterMessage>& msgs) {
+    static std::vector<Request> requests_of(const std::vector<RateLimiterMessage>& msgs) {
         std::vector<Request> reqs;
         reqs.reserve(msgs.size());
         for (const RateLimiterMessage& m : msgs)
             reqs.push_back(Request{m.request.key, m.request.max_burst, m.request.count_per_period, m.request.period,
                                    m.request.quantity, m.request.timestamp});
+        return reqs;
+    }
+
+    // actor.rs:238-255 for a whole batch, first half: hand the batch to the limiter.  false: it could not be
+    // submitted and every request has been answered with the error.
+    static bool submit_throttle_batch(RateLimiter& limiter, std::vector<RateLimiterMessage>& msgs) {
+        try {
+            limiter.submit_batch(requests_of(msgs));
+            return true;
+        } catch (const std::exception& ex) {
+            for (RateLimiterMessage& m : msgs) m.response_tx.set_value(std::string("Rate limit check failed: internal error: ") + ex.what());
+            return false;
+        }
+    }
+
+    // second half: the replies; send errors are ignored like in the reference (the receiver may have given
+    // up, actor.rs:229-230)
+    static void answer_throttle_batch(RateLimiter& limiter, std::vector<RateLimiterMessage>& msgs) {
         std::vector<RateLimitOutcome> out;
         try {
-            out = limiter.rate_limit_batch(reqs);
+            out = limiter.collect_batch();
         } catch (const std::exception& ex) {
             for (RateLimiterMessage& m : msgs) m.response_tx.set_value(std::string("Rate limit check failed: internal error: ") + ex.what());
             return;

@@ -13,6 +13,8 @@
 
 #include <chrono>
 #include <cstdint>
+#include <cstring>
+#include <deque>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -82,10 +84,11 @@ class GpuStore {
         int err = 0;
         e_ = tc_engine_create(&cfg, &err);
         if (!e_) throw std::runtime_error("tc_engine_create failed: " + std::to_string(err));
+        max_batch_ = max_batch;
     }
     GpuStore(const GpuStore&) = delete;
     GpuStore& operator=(const GpuStore&) = delete;
-    GpuStore(GpuStore&& o) noexcept : e_(o.e_) { o.e_ = nullptr; }
+    GpuStore(GpuStore&& o) noexcept : e_(o.e_), max_batch_(o.max_batch_) { o.e_ = nullptr; }
     ~GpuStore() { tc_engine_destroy(e_); }
 
     // trait Store (store/mod.rs:85-133); Err(String) -> exception
@@ -112,6 +115,7 @@ class GpuStore {
         return removed;
     }
     tc_engine* handle() { return e_; }
+    uint64_t max_batch() const { return max_batch_; }
 
   private:
     static const uint8_t* bytes(std::string_view k) { return reinterpret_cast<const uint8_t*>(k.data()); }
@@ -119,6 +123,7 @@ class GpuStore {
         if (rc != TC_E_OK) throw std::runtime_error(std::string("tcgpu: ") + tc_last_error(e_));
     }
     tc_engine* e_;
+    uint64_t max_batch_ = 0;
 };
 
 // RateLimiter<GpuStore> (rate_limiter.rs:42-58)
@@ -182,9 +187,148 @@ class RateLimiter {
         return out;
     }
 
+    // ---- the same, pipelined -------------------------------------------------------------------
+    // submit_batch() marshals the requests into one of FLIGHTS sets of pinned buffers and only enqueues
+    // them (TC_B_ASYNC: the PCIe transfers and the evaluation overlap with the caller marshalling the
+    // next batch); collect_batch() waits for the OLDEST submitted batch and returns its outcomes.  The
+    // outcomes are those of rate_limit_batch called once per submission, in submission order.  At most
+    // FLIGHTS batches may be in flight (collect before submitting a fourth).
+    static constexpr size_t FLIGHTS = 3;
+    size_t in_flight() const { return order_.size(); }
+    void submit_batch(const std::vector<Request>& reqs) {
+        if (order_.size() >= FLIGHTS) throw std::logic_error("submit_batch: collect_batch() first");
+        const size_t n = reqs.size();
+        if (n > store_.max_batch()) throw std::invalid_argument("submit_batch: more requests than the store's max_batch");
+        size_t fi = 0;
+        while (flights_[fi].busy) ++fi;
+        Flight& f = flights_[fi];
+        if (n > 4) { // (may throw: nothing has changed yet)
+            size_t bytes = 0;
+            for (const Request& r : reqs) bytes += r.key.size();
+            f.reserve(store_.max_batch(), bytes + 1);
+        }
+        f.n = n;
+        f.ready.clear();
+        f.rc = TC_E_OK;
+        f.async = false;
+        f.busy = true;
+        order_.push_back(fi);
+        if (n <= 4) { // lightly loaded: single calls (they run behind the batches in flight, in stream order)
+            for (const Request& r : reqs) f.ready.push_back(rate_limit(r.key, r.max_burst, r.count_per_period, r.period, r.quantity, r.now));
+            return;
+        }
+        uint32_t at = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const Request& r = reqs[i];
+            if (!r.key.empty()) std::memcpy(f.arena + at, r.key.data(), r.key.size());
+            at += (uint32_t)r.key.size();
+            f.off[i + 1] = at;
+            f.col[0][i] = r.max_burst;
+            f.col[1][i] = r.count_per_period;
+            f.col[2][i] = r.period;
+            f.col[3][i] = r.quantity;
+            f.col[4][i] = to_ns(r.now);
+        }
+        tc_batch b{};
+        b.struct_size = sizeof b;
+        b.flags = TC_B_ASYNC;
+        b.n = n;
+        b.key_bytes = f.arena;
+        b.key_off = f.off;
+        b.max_burst = f.col[0];
+        b.count_per_period = f.col[1];
+        b.period = f.col[2];
+        b.quantity = f.col[3];
+        b.now_ns = f.col[4];
+        b.decisions = f.dec;
+        f.rc = tc_rate_limit_batch_keys(store_.handle(), &b);
+        f.async = f.rc == TC_E_OK;
+        if (!f.async) f.err = tc_last_error(store_.handle());
+    }
+    std::vector<RateLimitOutcome> collect_batch() {
+        if (order_.empty()) throw std::logic_error("collect_batch: nothing in flight");
+        Flight& f = flights_[order_.front()];
+        order_.pop_front();
+        std::vector<RateLimitOutcome> out;
+        out.reserve(f.n);
+        if (f.async) {
+            // batches complete in submission order: everything but the younger asynchronous ones must be done
+            uint32_t younger = 0;
+            for (size_t fi : order_) younger += flights_[fi].async ? 1u : 0u;
+            const int rc = tc_wait_batches(store_.handle(), younger);
+            for (size_t i = 0; i < f.n; ++i) {
+                if (rc != TC_E_OK) out.push_back(CellError{CellError::Internal, 0, tc_last_error(store_.handle())});
+                else
+                    out.push_back(outcome(f.dec[i].status, f.dec[i].allowed, f.col[0][i], f.dec[i].remaining, f.dec[i].reset_after_ns,
+                                          f.dec[i].retry_after_ns, f.col[3][i]));
+            }
+        } else if (f.rc != TC_E_OK) {
+            for (size_t i = 0; i < f.n; ++i) out.push_back(CellError{CellError::Internal, 0, f.err});
+        } else {
+            out = std::move(f.ready);
+        }
+        f.busy = false;
+        return out;
+    }
+
     GpuStore& store() { return store_; }
 
   private:
+    // one set of pinned staging buffers (tc_host_alloc), grown on demand while the set is idle
+    struct Flight {
+        uint8_t* arena = nullptr;
+        size_t arena_cap = 0;
+        uint32_t* off = nullptr;
+        int64_t* col[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        tc_decision* dec = nullptr;
+        size_t rows = 0, n = 0;
+        std::vector<RateLimitOutcome> ready; // small batches answered by single calls
+        std::string err;
+        int rc = TC_E_OK;
+        bool async = false, busy = false;
+        Flight() = default;
+        Flight(const Flight&) = delete;
+        Flight& operator=(const Flight&) = delete;
+        Flight(Flight&& o) noexcept { *this = std::move(o); }
+        Flight& operator=(Flight&& o) noexcept {
+            std::swap(arena, o.arena), std::swap(arena_cap, o.arena_cap), std::swap(off, o.off), std::swap(dec, o.dec);
+            for (int j = 0; j < 5; ++j) std::swap(col[j], o.col[j]);
+            std::swap(rows, o.rows), std::swap(n, o.n), std::swap(ready, o.ready), std::swap(err, o.err);
+            std::swap(rc, o.rc), std::swap(async, o.async), std::swap(busy, o.busy);
+            return *this;
+        }
+        ~Flight() {
+            tc_host_free(arena), tc_host_free(off), tc_host_free(dec);
+            for (int64_t* c : col) tc_host_free(c);
+        }
+        template <class T>
+        static T* pinned(size_t count) {
+            T* p = static_cast<T*>(tc_host_alloc(count * sizeof(T)));
+            if (!p) throw std::bad_alloc();
+            return p;
+        }
+        void reserve(size_t max_rows, size_t arena_bytes) {
+            if (rows < max_rows) {
+                tc_host_free(off), tc_host_free(dec);
+                for (int64_t*& c : col) tc_host_free(c), c = nullptr;
+                off = pinned<uint32_t>(max_rows + 1);
+                dec = pinned<tc_decision>(max_rows);
+                for (int64_t*& c : col) c = pinned<int64_t>(max_rows);
+                rows = max_rows;
+            }
+            off[0] = 0;
+            if (arena_cap < arena_bytes) {
+                tc_host_free(arena);
+                arena = nullptr;
+                arena_cap = 0;
+                arena = pinned<uint8_t>(arena_bytes * 2);
+                arena_cap = arena_bytes * 2;
+            }
+        }
+    };
+    Flight flights_[FLIGHTS];
+    std::deque<size_t> order_; // flights in submission order
+
     static RateLimitOutcome outcome(uint8_t status, uint8_t allowed, int64_t limit, int64_t remaining, int64_t reset_ns,
                                     int64_t retry_ns, int64_t quantity) {
         switch (status) {

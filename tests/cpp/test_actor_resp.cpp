@@ -182,7 +182,56 @@ static void test_metrics_from_engine() {
     CHECK(prom.find("user:789") == std::string::npos); // never denied
 }
 
+// RateLimiter::submit_batch / collect_batch (TC_B_ASYNC behind them) == rate_limit_batch on a second limiter:
+// same stream of batches (new keys, hot keys, long keys, errors, tiny batches answered by single calls),
+// up to FLIGHTS batches in flight.
+static void test_pipelined_submit_collect() {
+    RateLimiter seq(GpuStore(20000, 4096)), pip(GpuStore(20000, 4096));
+    uint64_t x = 88172645463325252ULL;
+    auto rnd = [&]() { x ^= x << 13, x ^= x >> 7, x ^= x << 17; return x; };
+    std::vector<std::vector<std::string>> keys;     // the requests' keys must outlive the submission
+    std::vector<std::vector<Request>> batches;
+    const size_t sizes[] = {700, 3, 4096, 1, 2500, 5, 64, 4000, 2, 900, 3100, 4};
+    for (size_t bi = 0; bi < sizeof sizes / sizeof sizes[0]; ++bi) {
+        keys.emplace_back();
+        for (size_t i = 0; i < sizes[bi]; ++i) {
+            const uint64_t r = rnd();
+            std::string k = (r % 7 == 0) ? "hot" : "user:" + std::to_string(r % (500 + 300 * bi));
+            if (r % 97 == 0) k = std::string(70, 'L') + std::to_string(r % 5); // beyond the inline 48 bytes
+            keys.back().push_back(std::move(k));
+        }
+        batches.emplace_back();
+        for (size_t i = 0; i < sizes[bi]; ++i) {
+            const uint64_t r = rnd();
+            batches.back().push_back(Request{keys.back()[i], 5, 10, 60, r % 53 == 0 ? -1 : (int64_t)(r % 3),
+                                             now0() + std::chrono::milliseconds(100 * bi) + std::chrono::microseconds(r % 50000)});
+        }
+    }
+    std::vector<std::vector<RateLimitOutcome>> want, got;
+    for (const auto& b : batches) want.push_back(seq.rate_limit_batch(b));
+    for (const auto& b : batches) {
+        if (pip.in_flight() == RateLimiter::FLIGHTS) got.push_back(pip.collect_batch());
+        pip.submit_batch(b);
+    }
+    while (pip.in_flight()) got.push_back(pip.collect_batch());
+    CHECK(got.size() == want.size());
+    for (size_t bi = 0; bi < want.size(); ++bi) {
+        CHECK(got[bi].size() == want[bi].size());
+        for (size_t i = 0; i < want[bi].size(); ++i) {
+            CHECK(got[bi][i].index() == want[bi][i].index());
+            if (is_ok(want[bi][i])) {
+                const auto &a = std::get<0>(got[bi][i]), &b = std::get<0>(want[bi][i]);
+                CHECK(a.first == b.first && a.second.limit == b.second.limit && a.second.remaining == b.second.remaining &&
+                      a.second.reset_after == b.second.reset_after && a.second.retry_after == b.second.retry_after);
+            } else {
+                CHECK(std::get<1>(got[bi][i]).to_string() == std::get<1>(want[bi][i]).to_string());
+            }
+        }
+    }
+}
+
 int main() {
+    test_pipelined_submit_collect();
     test_basic_rate_limiting();
     test_concurrent_requests();
     test_errors_and_truncation();

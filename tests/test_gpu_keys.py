@@ -303,3 +303,58 @@ def test_baseline_config0_1k_keys_100k_requests(params):
             assert np.array_equal(got.astype(np.int64), getattr(ref, f)[a:b].astype(np.int64)), (f, a, b)
     assert eng.counters()["total"] == n and eng.counters()["allowed"] == int(ref.allowed.sum())
     eng.close()
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["one_now", "per_request_now"])
+def test_async_host_key_batches(general):
+    """TC_B_ASYNC key batches from a ring of 3 pinned buffer sets: key arena and offsets are staged on the key
+    stream, resolved there, grouped and evaluated as usual, results copied back behind the evaluation.  New
+    keys keep appearing, hot keys recur, a synchronous batch, a single-key operation and a sweep are mixed in."""
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    keys = [b"ak_%d" % i for i in range(30000)] + [b"long-key-" + b"z" * 60 + b"%d" % i for i in range(300)]
+    eng, orc = _engine(50000, 40000), _oracle(50000)
+    n, nb, K = 30000, 10, 3
+    F = ("allowed", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+    ring = [dict(kb=eng.host_alloc(n * 80, np.uint8), ko=eng.host_alloc(n + 1, np.uint32), now=eng.host_alloc(n, np.int64),
+                 out=t.BatchResult(**{f: eng.host_alloc(n, np.uint8 if f in ("allowed", "status") else np.int64) for f in F}))
+            for _ in range(K)]
+    refs, got = [], []
+    for bidx in range(nb):
+        r = ring[bidx % K]
+        if bidx >= K:
+            eng.wait_batches(K - 1)
+            got.append({f: getattr(r["out"], f).copy() for f in F})
+        hi = 3000 + 3000 * bidx
+        idx = np.where(rng.random(n) < 0.3, np.minimum(rng.zipf(1.3, n) - 1, hi - 1), rng.integers(0, hi, n))
+        idx[:40] = len(keys) - 1 - rng.integers(0, 300, 40)   # a few keys beyond the inline 48 bytes
+        kb, ko = O.pack_keys([keys[i] for i in idx])
+        r["kb"][:kb.size] = kb
+        r["ko"][:] = ko
+        base = T0 + bidx * 2 * 10**9
+        sync_call = bidx == 4
+        if general:
+            r["now"][:] = base + rng.integers(0, 10**9, n)
+            refs.append(orc.batch_keys(kb, ko, 5, 10, 60, 1, r["now"]))
+            eng.rate_limit_batch_keys(r["kb"], r["ko"], max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=r["now"],
+                                      want=F, out=r["out"], async_=not sync_call)
+        else:
+            refs.append(orc.batch_keys(kb, ko, 5, 10, 60, 1, base))
+            eng.rate_limit_batch_keys(r["kb"], r["ko"], max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=base,
+                                      want=F, out=r["out"], async_=not sync_call)
+        if bidx == 6:       # single-key operation and a sweep between asynchronous batches
+            now = base + 10**9
+            assert eng.get(b"ak_0", now) == orc.get(b"ak_0", now)
+            orc.force_cleanup(now)
+            eng.sweep_expired(now)
+            assert eng.counters()["live_slots"] == len(orc)
+    eng.wait_batches(0)
+    for bidx in range(nb - K, nb):
+        got.append({f: getattr(ring[bidx % K]["out"], f).copy() for f in F})
+    for bidx in range(nb):
+        assert_same(t.BatchResult(**got[bidx]), refs[bidx], f"async key batch {bidx}")
+    t_end = T0 + nb * 2 * 10**9
+    for k in keys[:300] + keys[-50:]:
+        assert eng.get(k, t_end) == orc.get(k, t_end), k
+    eng.close()

@@ -278,9 +278,10 @@ class Engine:
 
     def rate_limit_batch_keys(self, key_bytes, key_off, *, max_burst=None, count_per_period=None, period=None,
                               quantity=None, now_ns=None, want=ALL_FIELDS,
-                              out: Optional[BatchResult] = None, inputs_ready=False) -> BatchResult:
+                              out: Optional[BatchResult] = None, inputs_ready=False, async_=False) -> BatchResult:
         """rate_limit_batch over string keys (arena bytes + offsets[n+1]).  inputs_ready: see
-        rate_limit_batch_slots (here it covers the key arena and the offsets)."""
+        rate_limit_batch_slots (here it covers the key arena and the offsets).  async_: see
+        rate_limit_batch_slots (key_bytes: uint8, key_off: uint32 numpy arrays, no hidden copies)."""
         dev = _is_torch(key_bytes)
         keep = []
         if dev:
@@ -288,17 +289,23 @@ class Engine:
             n = key_off.numel() - 1
             kb, ko = key_bytes.data_ptr(), key_off.data_ptr()
         else:
+            if async_:
+                for a, dt in ((key_bytes, np.uint8), (key_off, np.uint32)):
+                    if not (isinstance(a, np.ndarray) and a.dtype == dt and a.flags.c_contiguous):
+                        raise ValueError("async_: key_bytes / key_off must be C-contiguous uint8 / uint32 numpy arrays")
             kbytes = np.ascontiguousarray(key_bytes, dtype=np.uint8)
             koff = np.ascontiguousarray(key_off, dtype=np.uint32)
             keep += [kbytes, koff]
             n = koff.size - 1
             kb, ko = kbytes.ctypes.data, koff.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, False, False,
-                                   want, out, inputs_ready)
+                                   want, out, inputs_ready, False, async_)
         b.key_bytes = kb
         b.key_off = ko
         if n:
             self._check(self._lib.tc_rate_limit_batch_keys(self._h, C.byref(b)))
+            if async_:
+                self._async_keep.append((keep, k2))
         return res
 
     def rate_limit(self, key: bytes, max_burst: int, count_per_period: int, period: int, quantity: int, now_ns: int):
