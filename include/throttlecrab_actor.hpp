@@ -12,8 +12,9 @@
 // What changes against the reference: its actor takes ONE message per loop turn
 // (`while let Some(msg) = rx.recv().await`, actor.rs:222) and calls rate_limit once; this one
 // takes EVERYTHING that is queued (tokio's `recv_many`), in queue order, and hands it to
-// RateLimiter::rate_limit_batch, whose result is by construction the result of the
-// one-by-one loop.  Requests keep the timestamp their transport stamped (types.rs:46), so a
+// RateLimiter::submit_batch / collect_batch (the pipelined form of rate_limit_batch: up to three
+// batches in flight while the next one is drained and marshalled), whose result is by
+// construction the result of the one-by-one loop.  Requests keep the timestamp their transport stamped (types.rs:46), so a
 // batch carries per-request, possibly non-monotone `now` values, like the reference's queue.
 //
 // Channel semantics follow tokio's bounded mpsc: `throttle` blocks while the buffer is full
