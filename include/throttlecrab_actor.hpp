@@ -69,10 +69,15 @@ struct ThrottleResponse {
     }
 };
 
-// actor.rs:35-45
+// actor.rs:35-45.  A message carries one request and its oneshot (the reference's Throttle variant) or --
+// `many` non-empty -- a connection's whole pipelined buffer with one oneshot for all replies, so that a
+// transport pays for the channel once per buffer instead of once per request.
 struct RateLimiterMessage {
     ThrottleRequest request;
     std::promise<Result<ThrottleResponse>> response_tx;
+    std::vector<ThrottleRequest> many;
+    std::promise<std::vector<Result<ThrottleResponse>>> many_tx;
+    size_t size() const { return many.empty() ? 1 : many.size(); }
 };
 
 namespace detail {
@@ -81,6 +86,7 @@ struct Channel {
     std::mutex mu;
     std::condition_variable not_empty, not_full;
     std::deque<RateLimiterMessage> queue;
+    size_t queued_requests = 0; // requests in `queue` (a message may carry many)
     size_t buffer_size = 1;
     size_t senders = 0;
     bool closed = false;
@@ -108,22 +114,29 @@ class RateLimiterHandle {
 
     // the two halves separately: a transport thread can queue many requests before it waits
     std::future<Result<ThrottleResponse>> throttle_async(ThrottleRequest request) {
-        RateLimiterMessage msg{std::move(request), {}};
+        RateLimiterMessage msg;
+        msg.request = std::move(request);
         std::future<Result<ThrottleResponse>> rx = msg.response_tx.get_future();
-        if (!ch_) {
-            msg.response_tx.set_value(std::string("Rate limiter actor has shut down"));
-            return rx;
-        }
-        std::unique_lock<std::mutex> lk(ch_->mu);
-        ch_->not_full.wait(lk, [&] { return ch_->closed || ch_->queue.size() < ch_->buffer_size; });
-        if (ch_->closed) {
-            msg.response_tx.set_value(std::string("Rate limiter actor has shut down"));
-            return rx;
-        }
-        ch_->queue.push_back(std::move(msg));
-        lk.unlock();
-        ch_->not_empty.notify_one();
+        if (!send(msg)) msg.response_tx.set_value(std::string("Rate limiter actor has shut down"));
         return rx;
+    }
+
+    // A whole buffer of requests (a connection's pipelined commands) as ONE message: evaluated in order,
+    // answered together.  Empty input -> empty output.
+    std::future<std::vector<Result<ThrottleResponse>>> throttle_many_async(std::vector<ThrottleRequest> requests) {
+        RateLimiterMessage msg;
+        std::future<std::vector<Result<ThrottleResponse>>> rx = msg.many_tx.get_future();
+        const size_t n = requests.size();
+        if (n == 0) {
+            msg.many_tx.set_value({});
+            return rx;
+        }
+        msg.many = std::move(requests);
+        if (!send(msg)) msg.many_tx.set_value(std::vector<Result<ThrottleResponse>>(n, std::string("Rate limiter actor has shut down")));
+        return rx;
+    }
+    std::vector<Result<ThrottleResponse>> throttle_many(std::vector<ThrottleRequest> requests) {
+        return throttle_many_async(std::move(requests)).get();
     }
 
     // (batches drained, requests served, largest batch) so far
@@ -135,6 +148,21 @@ class RateLimiterHandle {
   private:
     friend class RateLimiterActor;
     explicit RateLimiterHandle(std::shared_ptr<detail::Channel> ch) : ch_(std::move(ch)) { retain(); }
+    // false: the actor has shut down (msg is untouched).  Blocks while the buffer is full (a message
+    // larger than the whole buffer is let in when the buffer is empty).
+    bool send(RateLimiterMessage& msg) {
+        if (!ch_) return false;
+        const size_t n = msg.size();
+        std::unique_lock<std::mutex> lk(ch_->mu);
+        ch_->not_full.wait(lk, [&] { return ch_->closed || ch_->queued_requests == 0 || ch_->queued_requests + n <= ch_->buffer_size; });
+        if (ch_->closed) return false;
+        const bool was_empty = ch_->queue.empty();
+        ch_->queue.push_back(std::move(msg));
+        ch_->queued_requests += n;
+        lk.unlock();
+        if (was_empty) ch_->not_empty.notify_one(); // (the actor only ever sleeps on an empty queue)
+        return true;
+    }
     void retain() {
         if (!ch_) return;
         std::lock_guard<std::mutex> lk(ch_->mu);
@@ -193,15 +221,20 @@ class RateLimiterActor {
                 if (flying.empty()) { // nothing to answer meanwhile: wait for work
                     ch.not_empty.wait(lk, [&] { return ch.closed || !ch.queue.empty(); });
                     if (ch.queue.empty()) break; // closed and drained
-                    if (linger.count() > 0 && ch.queue.size() < min_batch && !ch.closed)
-                        ch.not_empty.wait_for(lk, linger, [&] { return ch.closed || ch.queue.size() >= min_batch; });
+                    if (linger.count() > 0 && ch.queued_requests < min_batch && !ch.closed) {
+                        // (senders only signal an empty queue: poll in slices of the linger time)
+                        const auto until = std::chrono::steady_clock::now() + linger;
+                        while (!ch.closed && ch.queued_requests < min_batch && std::chrono::steady_clock::now() < until)
+                            ch.not_empty.wait_for(lk, linger / 8 + std::chrono::microseconds(1));
+                    }
                 }
-                const size_t take = ch.queue.size() < max_batch ? ch.queue.size() : max_batch;
-                msgs.reserve(take);
-                for (size_t i = 0; i < take; ++i) {
+                size_t take = 0; // requests
+                while (!ch.queue.empty() && (take == 0 || take + ch.queue.front().size() <= max_batch)) {
+                    take += ch.queue.front().size();
                     msgs.push_back(std::move(ch.queue.front()));
                     ch.queue.pop_front();
                 }
+                ch.queued_requests -= take;
                 if (take) {
                     ch.batches += 1;
                     ch.requests += take;
@@ -222,12 +255,26 @@ class RateLimiterActor {
     }
 
     static std::vector<Request> requests_of(const std::vector<RateLimiterMessage>& msgs) {
+        size_t n = 0;
+        for (const RateLimiterMessage& m : msgs) n += m.size();
         std::vector<Request> reqs;
-        reqs.reserve(msgs.size());
-        for (const RateLimiterMessage& m : msgs)
-            reqs.push_back(Request{m.request.key, m.request.max_burst, m.request.count_per_period, m.request.period,
-                                   m.request.quantity, m.request.timestamp});
+        reqs.reserve(n);
+        auto add = [&](const ThrottleRequest& r) {
+            reqs.push_back(Request{r.key, r.max_burst, r.count_per_period, r.period, r.quantity, r.timestamp});
+        };
+        for (const RateLimiterMessage& m : msgs) {
+            if (m.many.empty()) add(m.request);
+            else
+                for (const ThrottleRequest& r : m.many) add(r);
+        }
         return reqs;
+    }
+    // the same reply to every request of a batch (errors)
+    static void answer_all(std::vector<RateLimiterMessage>& msgs, const std::string& err) {
+        for (RateLimiterMessage& m : msgs) {
+            if (m.many.empty()) m.response_tx.set_value(err);
+            else m.many_tx.set_value(std::vector<Result<ThrottleResponse>>(m.many.size(), err));
+        }
     }
 
     // actor.rs:238-255 for a whole batch, first half: hand the batch to the limiter.  false: it could not be
@@ -237,7 +284,7 @@ class RateLimiterActor {
             limiter.submit_batch(requests_of(msgs));
             return true;
         } catch (const std::exception& ex) {
-            for (RateLimiterMessage& m : msgs) m.response_tx.set_value(std::string("Rate limit check failed: internal error: ") + ex.what());
+            answer_all(msgs, std::string("Rate limit check failed: internal error: ") + ex.what());
             return false;
         }
     }
@@ -249,15 +296,25 @@ class RateLimiterActor {
         try {
             out = limiter.collect_batch();
         } catch (const std::exception& ex) {
-            for (RateLimiterMessage& m : msgs) m.response_tx.set_value(std::string("Rate limit check failed: internal error: ") + ex.what());
+            answer_all(msgs, std::string("Rate limit check failed: internal error: ") + ex.what());
             return;
         }
-        for (size_t i = 0; i < msgs.size(); ++i) {
-            if (throttlecrab::is_ok(out[i])) {
-                const auto& ok = std::get<0>(out[i]);
-                msgs[i].response_tx.set_value(ThrottleResponse::from(ok.first, ok.second));
+        auto reply = [](const RateLimitOutcome& o) -> Result<ThrottleResponse> {
+            if (throttlecrab::is_ok(o)) {
+                const auto& ok = std::get<0>(o);
+                return ThrottleResponse::from(ok.first, ok.second);
+            }
+            return "Rate limit check failed: " + std::get<1>(o).to_string();
+        };
+        size_t at = 0;
+        for (RateLimiterMessage& m : msgs) {
+            if (m.many.empty()) {
+                m.response_tx.set_value(reply(out[at++]));
             } else {
-                msgs[i].response_tx.set_value("Rate limit check failed: " + std::get<1>(out[i]).to_string());
+                std::vector<Result<ThrottleResponse>> rs;
+                rs.reserve(m.many.size());
+                for (size_t i = 0; i < m.many.size(); ++i) rs.push_back(reply(out[at++]));
+                m.many_tx.set_value(std::move(rs));
             }
         }
     }

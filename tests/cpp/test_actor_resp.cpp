@@ -230,8 +230,53 @@ static void test_pipelined_submit_collect() {
     }
 }
 
+// a connection's pipelined buffer as one message: evaluated in order between the other senders' requests,
+// answered together; same replies as the requests sent one by one
+static void test_throttle_many() {
+    RateLimiterHandle one = RateLimiterActor::spawn_gpu(1000, GpuStore(1000));
+    RateLimiterHandle many = RateLimiterActor::spawn_gpu(1000, GpuStore(1000));
+    std::vector<ThrottleRequest> reqs;
+    for (int i = 0; i < 300; ++i)
+        reqs.push_back(ThrottleRequest{"conn:" + std::to_string(i % 7), 5, 10, 60, i % 31 == 0 ? -1 : 1, now0() + std::chrono::milliseconds(i)});
+    auto got = many.throttle_many(reqs);
+    CHECK(got.size() == reqs.size());
+    for (size_t i = 0; i < reqs.size(); ++i) {
+        auto want = one.throttle(reqs[i]);
+        CHECK(want.index() == got[i].index());
+        if (is_ok(want)) {
+            const ThrottleResponse &a = std::get<0>(want), &b = std::get<0>(got[i]);
+            CHECK(a.allowed == b.allowed && a.limit == b.limit && a.remaining == b.remaining && a.reset_after == b.reset_after &&
+                  a.retry_after == b.retry_after);
+        } else {
+            CHECK(std::get<1>(want) == std::get<1>(got[i]));
+        }
+    }
+    CHECK(many.throttle_many({}).empty());
+    // groups from several threads, mixed with single requests: every key still gets exactly `burst` grants
+    std::atomic<int> allowed{0};
+    std::vector<std::thread> th;
+    for (int p = 0; p < 8; ++p)
+        th.emplace_back([&, p] {
+            RateLimiterHandle h = many;
+            for (int round = 0; round < 20; ++round) {
+                std::vector<ThrottleRequest> g;
+                for (int i = 0; i < 50; ++i) g.push_back(ThrottleRequest{"shared:" + std::to_string(i % 10), 20, 10, 3600, 1, now0()});
+                for (auto& r : h.throttle_many(std::move(g))) {
+                    CHECK(is_ok(r));
+                    allowed += std::get<0>(r).allowed;
+                }
+                auto r = h.throttle(ThrottleRequest{"shared:" + std::to_string(p % 10), 20, 10, 3600, 1, now0()});
+                CHECK(is_ok(r));
+                allowed += std::get<0>(r).allowed;
+            }
+        });
+    for (auto& t : th) t.join();
+    CHECK(allowed.load() == 10 * 20);
+}
+
 int main() {
     test_pipelined_submit_collect();
+    test_throttle_many();
     test_basic_rate_limiting();
     test_concurrent_requests();
     test_errors_and_truncation();

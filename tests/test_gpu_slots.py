@@ -627,3 +627,40 @@ def test_async_flag_misuse():
                                    async_=True)
     eng.wait_batches(0)
     eng.close()
+
+
+def test_async_host_batches_record_and_bit_outputs():
+    """TC_B_ASYNC with the other output forms: decision records, result records, packed bits, grouped rows."""
+    import throttlecrab_amd as t
+    cap, n = 2000, 10000
+    rng = np.random.default_rng(5)
+    eng, orc = _engine(cap, n), _oracle(cap)
+    outs, refs, slots_all = [], [], []
+    for bidx in range(4):
+        slots = eng.host_alloc(n, np.uint32)
+        slots[:] = ((rng.zipf(1.3, n) * 2654435761) % cap).astype(np.uint32)
+        now = T0 + bidx * 10**8
+        refs.append(orc.batch_slots(slots, 5, 10, 60, 1, now))
+        out = t.BatchResult(decisions=eng.host_alloc(4 * n, np.int64), result4=eng.host_alloc(4 * n, np.int64),
+                            allowed_bits=eng.host_alloc((n + 63) // 64, np.uint64), allowed=eng.host_alloc(n, np.uint8),
+                            order=eng.host_alloc(n, np.uint32) if bidx % 2 else None)
+        eng.rate_limit_batch_slots(slots, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=now,
+                                   want=("decisions", "result4", "allowed_bits", "allowed"), out=out, async_=True, grouped=bool(bidx % 2))
+        outs.append(out)
+        slots_all.append(slots)
+    eng.wait_batches(0)
+    for bidx, (out, ref) in enumerate(zip(outs, refs)):
+        order = out.order.astype(np.int64) if bidx % 2 else np.arange(n)
+        dec = t.Engine.unpack_decisions(out.decisions)
+        r4 = out.result4.reshape(-1, 4)
+        inv = np.empty(n, np.int64)
+        inv[order] = np.arange(n)           # row of request i
+        assert np.array_equal(out.allowed[inv], ref.allowed.astype(np.uint8)), f"batch {bidx} allowed"
+        for col, f in enumerate(("limit", "remaining", "reset_after_ns", "retry_after_ns")):
+            assert np.array_equal(r4[inv, col], getattr(ref, f).astype(np.int64)), f"batch {bidx} result4.{f}"
+        bits = np.unpackbits(out.allowed_bits.view(np.uint8), bitorder="little")[:n]
+        assert np.array_equal(bits, out.allowed), f"batch {bidx} bits vs bytes (both in row order)"
+        assert np.array_equal(dec["remaining"][inv], ref.remaining.astype(np.int64))
+        assert np.array_equal(dec["allowed"][inv].astype(np.uint8), ref.allowed.astype(np.uint8))
+    assert_state_same(eng, orc, np.arange(cap))
+    eng.close()
