@@ -100,6 +100,7 @@ struct Channel {
 // actor.rs:52-82.  Copyable; the actor shuts down when the last copy is destroyed.
 class RateLimiterHandle {
   public:
+    using request_type = ThrottleRequest;
     RateLimiterHandle() = default;
     RateLimiterHandle(const RateLimiterHandle& o) : ch_(o.ch_) { retain(); }
     RateLimiterHandle(RateLimiterHandle&& o) noexcept : ch_(std::move(o.ch_)) {}

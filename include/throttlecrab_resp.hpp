@@ -15,11 +15,13 @@
 // engine applies a batch in index order.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <functional>
 #include <string>
 #include <string_view>
+#include <variant>
 #include <vector>
 
 #include "tcgpu.h"
@@ -332,6 +334,46 @@ class Pipeline {
             }
         }
         return rc;
+    }
+
+    // The same through the batch-draining actor (throttlecrab_actor.hpp: `Handle` = RateLimiterHandle): the
+    // buffer's THROTTLEs travel as ONE throttle_many message, so the buffers of many connections end up in
+    // one engine batch -- what redis/mod.rs:264-287 does per command with handle.throttle(req).await.
+    template <class Handle>
+    void run_via_actor(Handle& handle, std::string& out) {
+        using Req = typename Handle::request_type;
+        const size_t n = throttles();
+        std::vector<Req> reqs;
+        reqs.reserve(n);
+        for (size_t i = 0; i < n; ++i) {
+            Req r;
+            r.key.assign((const char*)key_bytes.data() + key_off[i], key_off[i + 1] - key_off[i]);
+            r.max_burst = max_burst[i];
+            r.count_per_period = count_per_period[i];
+            r.period = period[i];
+            r.quantity = quantity[i];
+            r.timestamp = decltype(r.timestamp)(std::chrono::nanoseconds(now_ns[i]));
+            reqs.push_back(std::move(r));
+        }
+        auto replies = handle.throttle_many(std::move(reqs));
+        for (const Cmd& c : cmds_) {
+            if (c.throttle < 0) {
+                out += c.reply;
+                continue;
+            }
+            const auto& r = replies[(size_t)c.throttle];
+            if (r.index() == 0) { // [allowed, limit, remaining, reset_after s, retry_after s] (mod.rs:274-283)
+                const auto& ok = std::get<0>(r);
+                out += "*5\r\n";
+                put_integer(out, ok.allowed ? 1 : 0);
+                put_integer(out, ok.limit);
+                put_integer(out, ok.remaining);
+                put_integer(out, ok.reset_after);
+                put_integer(out, ok.retry_after);
+            } else {
+                put_error(out, "ERR " + std::get<1>(r)); // mod.rs:285 `ERR {e}`
+            }
+        }
     }
 
     // replies of the commands that never reach the engine (for parser-only use)

@@ -152,6 +152,12 @@ static void test_resp_pipeline() {
         "+OK\r\n";
     if (out != expect) std::fprintf(stderr, "got:\n%s\nwant:\n%s\n", out.c_str(), expect.c_str());
     CHECK(out == expect);
+    // the same buffer through the actor (one throttle_many message) against a fresh store: same bytes
+    RateLimiterHandle handle = RateLimiterActor::spawn_gpu(1000, GpuStore(1000, 4096), 4096);
+    std::string via;
+    p.run_via_actor(handle, via);
+    if (via != expect) std::fprintf(stderr, "via actor got:\n%s\nwant:\n%s\n", via.c_str(), expect.c_str());
+    CHECK(via == expect);
 }
 
 // tests/metrics_test.rs + denied_keys_test.rs:37-67 with the decisions counted on the device
