@@ -64,7 +64,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint6
 // Every block owns a contiguous range of slots, collects the slots it unbinds in
 // LDS and pushes them with ONE stack reservation per SWEEP_BUF slots (an atomic on
 // the stack top costs ~12 ns and serialises: one per 256 slots was most of the kernel).
-constexpr int SWEEP_BUF = 8192;
+constexpr int SWEEP_BUF = 4096;
 __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
                                                       unsigned long long* counters, unsigned long long* removed_out,
                                                       uint32_t* __restrict__ denied) {

@@ -1313,7 +1313,7 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s));
     TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), s));
     if (e->key_mode)
-        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 1024)), dim3(BLOCK), 0, s,
+        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
                            e->cells, e->kt, now_ns, e->counters, scratch, e->denied);
     else
         hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
