@@ -74,3 +74,24 @@ int main(void) {{
                            str(src), "-L" + os.path.join(ROOT, "throttlecrab_amd"), "-ltcgpu",
                            "-Wl,-rpath," + os.path.join(ROOT, "throttlecrab_amd"), "-o", str(exe)])
     assert exe.exists()
+
+
+def test_python_constants_match_the_header():
+    """The ctypes wrapper restates the header's #defines, struct sizes and field order; they must agree."""
+    import ctypes as C
+    import re
+    from throttlecrab_amd import _lib as L
+    text = open(os.path.join(ROOT, "include", "tcgpu.h")).read()
+    defines = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"#define\s+(TC_(?:B|CFG)_[A-Z_]+)\s+(0x[0-9a-fA-F]+|\d+)u?\b", text)}
+    assert len(defines) >= 8, defines
+    for name, value in defines.items():
+        assert getattr(L, name) == value, (name, value)
+    errors = {m.group(1): int(m.group(2)) for m in re.finditer(r"\b(TC_E_[A-Z_]+)\s*=\s*(-?\d+)", text)}
+    for name, value in errors.items():
+        assert getattr(L, name) == value, (name, value)
+    # struct layouts as the C compiler sees them (same numbers as the _Static_asserts above)
+    assert C.sizeof(L.tc_config) == 40 and C.sizeof(L.tc_result) == 40
+    assert L.tc_batch.result4.offset == 8 + 8 + 8 * 8 + 5 * 8 + 7 * 8
+    assert L.tc_batch.decisions.offset == L.tc_batch.result4.offset + 8
+    assert L.tc_batch.order.offset == L.tc_batch.decisions.offset + 8
+    assert C.sizeof(L.tc_batch) == L.tc_batch.order.offset + 8
