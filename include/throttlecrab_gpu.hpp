@@ -147,10 +147,12 @@ class RateLimiter {
         std::vector<RateLimitOutcome> out;
         out.reserve(n);
         if (!n) return out;
-        if (n <= 4) { // a lightly loaded queue: single calls (one launch each, ~30 us) beat the batch pipeline (~200 us)
-            for (const Request& r : reqs) out.push_back(rate_limit(r.key, r.max_burst, r.count_per_period, r.period, r.quantity, r.now));
+        if (n == 1) { // one launch either way; the single call skips the marshalling
+            const Request& r = reqs[0];
+            out.push_back(rate_limit(r.key, r.max_burst, r.count_per_period, r.period, r.quantity, r.now));
             return out;
         }
+        // (up to 1024 requests the engine answers with one launch, ~35-45 us; beyond that with its pipeline)
         std::vector<uint8_t> arena;
         std::vector<uint32_t> off(n + 1, 0);
         std::vector<int64_t> burst(n), count(n), period(n), qty(n), now(n);
@@ -194,6 +196,7 @@ class RateLimiter {
     // outcomes are those of rate_limit_batch called once per submission, in submission order.  At most
     // FLIGHTS batches may be in flight (collect before submitting a fourth).
     static constexpr size_t FLIGHTS = 3;
+    static constexpr size_t SMALL_BATCH = 1024; // what the engine serves with one launch (k_small_batch)
     size_t in_flight() const { return order_.size(); }
     void submit_batch(const std::vector<Request>& reqs) {
         if (order_.size() >= FLIGHTS) throw std::logic_error("submit_batch: collect_batch() first");
@@ -202,7 +205,7 @@ class RateLimiter {
         size_t fi = 0;
         while (flights_[fi].busy) ++fi;
         Flight& f = flights_[fi];
-        if (n > 4) { // (may throw: nothing has changed yet)
+        if (n > SMALL_BATCH) { // (may throw: nothing has changed yet)
             size_t bytes = 0;
             for (const Request& r : reqs) bytes += r.key.size();
             f.reserve(store_.max_batch(), bytes + 1);
@@ -213,8 +216,8 @@ class RateLimiter {
         f.async = false;
         f.busy = true;
         order_.push_back(fi);
-        if (n <= 4) { // lightly loaded: single calls (they run behind the batches in flight, in stream order)
-            for (const Request& r : reqs) f.ready.push_back(rate_limit(r.key, r.max_burst, r.count_per_period, r.period, r.quantity, r.now));
+        if (n <= SMALL_BATCH) { // lightly loaded: the engine's one-launch path, answered at once (it runs behind
+            f.ready = rate_limit_batch(reqs); // the batches in flight, in stream order)
             return;
         }
         uint32_t at = 0;

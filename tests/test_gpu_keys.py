@@ -358,3 +358,45 @@ def test_async_host_key_batches(general):
     for k in keys[:300] + keys[-50:]:
         assert eng.get(k, t_end) == orc.get(k, t_end), k
     eng.close()
+
+
+def test_small_host_key_batches_single_launch():
+    """String-key batches of at most 1024 requests in one launch: new keys (also twice in one batch), known
+    keys, long keys, the empty key, per-request timestamps and rates; mixed with big batches, single calls and
+    a sweep; finally a table that runs full."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(29)
+    keys = [b"sk_%d" % i for i in range(3000)] + [b"long-key-" + b"q" * 70 + b"%d" % i for i in range(40)] + [b""]
+    eng, orc = _engine(6000, 4000), _oracle(6000)
+    sizes = [1, 2, 5, 64, 65, 300, 1024, 1025, 2500, 17, 1000, 3, 700]
+    for bidx, n in enumerate(sizes):
+        hi = 50 + 230 * bidx
+        idx = np.where(rng.random(n) < 0.4, rng.integers(0, 8, n), rng.integers(0, hi, n))
+        idx[: max(1, n // 20)] = len(keys) - 1 - rng.integers(0, 41, max(1, n // 20))   # long keys and the empty key
+        kb, ko = O.pack_keys([keys[i] for i in idx])
+        now = T0 + bidx * 3 * 10**9 + rng.integers(0, 10**9, n)
+        b, c, p_, q = rng.integers(0, 6, n), rng.integers(1, 30, n), rng.integers(1, 70, n), rng.integers(-1, 3, n)
+        ref = orc.batch_keys(kb, ko, b, c, p_, q, now)
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=b, count_per_period=c, period=p_, quantity=q, now_ns=now)
+        assert_same(res, ref, f"small key batch {bidx} (n={n})")
+        if bidx == 6:
+            t_sweep = T0 + bidx * 3 * 10**9 + 2 * 10**9
+            orc.force_cleanup(t_sweep)
+            eng.sweep_expired(t_sweep)
+            assert eng.counters()["live_slots"] == len(orc)
+            assert eng.rate_limit(b"sk_1", 5, 10, 60, 1, t_sweep)[:2] == orc.rate_limit(b"sk_1", 5, 10, 60, 1, t_sweep)[:2]
+    t_end = T0 + len(sizes) * 3 * 10**9
+    for k in keys[:200] + keys[-41:]:
+        assert eng.get(k, t_end) == orc.get(k, t_end), k
+    eng.close()
+    # a table that runs full inside a small batch: the keys that fit are served, the others get Internal
+    import throttlecrab_amd as t
+    eng = _engine(16, 64)
+    kb, ko = O.pack_keys([b"full_%d" % i for i in range(40)])
+    with pytest.raises(t.TcError):
+        eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0)
+    kb, ko = O.pack_keys([b"full_%d" % i for i in range(8)])
+    res = eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 1)
+    assert (res.status == 0).all()      # bound by the first call (in request order: the first 16 keys got the slots)
+    eng.check_on_close = False
+    eng.close()

@@ -664,3 +664,45 @@ def test_async_host_batches_record_and_bit_outputs():
         assert np.array_equal(dec["allowed"][inv].astype(np.uint8), ref.allowed.astype(np.uint8))
     assert_state_same(eng, orc, np.arange(cap))
     eng.close()
+
+
+@pytest.mark.parametrize("registered", [False, True])
+def test_small_host_batches_single_launch(registered):
+    """Host-pointer batches of at most 1024 requests take k_small_batch (keys resolved, sorted and walked by one
+    block, inputs and results in pinned host memory): every size class, heavy duplicates, per-request
+    timestamps / quantities / rates, errors, all output columns and both record forms -- against the oracle,
+    interleaved with big-pipeline batches on the same engine."""
+    import throttlecrab_amd as t
+    cap = 700
+    rng = np.random.default_rng(23)
+    eng, orc = _engine(cap, 5000), _oracle(cap)
+    if registered:
+        bursts, counts, periods = rng.integers(1, 8, cap), rng.integers(1, 50, cap), rng.integers(1, 90, cap)
+        eng.register_params(bursts, counts, periods)
+    sizes = [1, 2, 3, 5, 63, 64, 65, 100, 511, 512, 513, 1000, 1023, 1024, 1025, 3000, 7, 900]
+    for bidx, n in enumerate(sizes):
+        slots = np.where(rng.random(n) < 0.5, rng.integers(0, 12, n), rng.integers(0, cap, n)).astype(np.uint32)
+        now = T0 + bidx * 10**9 + rng.integers(0, 10**9, n)
+        q = rng.integers(-1, 4, n)
+        if registered:
+            b, c, p_ = bursts[slots], counts[slots], periods[slots]   # (the oracle has no registration: hand it the plans)
+            ref = orc.batch_slots(slots, b, c, p_, q, now)
+            res = eng.rate_limit_batch_slots(slots, registered=True, quantity=q, now_ns=now,
+                                             want=FIELDS + ("result4", "decisions"))
+        else:
+            b = rng.integers(0, 8, n)           # burst 0: InvalidRateLimit
+            c, p_ = rng.integers(1, 50, n), rng.integers(1, 90, n)
+            ref = orc.batch_slots(slots, b, c, p_, q, now)
+            res = eng.rate_limit_batch_slots(slots, max_burst=b, count_per_period=c, period=p_, quantity=q, now_ns=now,
+                                             want=FIELDS + ("result4", "decisions"))
+        assert_same(res, ref, f"small batch {bidx} (n={n})")
+        ok = ref.status == 0
+        r4 = res.result4.reshape(-1, 4)
+        for col, f in enumerate(("limit", "remaining", "reset_after_ns", "retry_after_ns")):
+            assert np.array_equal(r4[:, col], getattr(ref, f).astype(np.int64)), f"batch {bidx} result4.{f}"
+        dec = t.Engine.unpack_decisions(res.decisions)
+        assert np.array_equal(dec["status"], ref.status.astype(np.uint8)) and np.array_equal(dec["remaining"][ok], ref.remaining[ok])
+    assert_state_same(eng, orc, np.arange(cap))
+    c = eng.counters()
+    assert c["total"] == sum(sizes)
+    eng.close()

@@ -194,31 +194,28 @@ __device__ __forceinline__ uint64_t load_and_hash(const uint8_t* __restrict__ ke
 
 // ---------------------------------------------------------------------------
 // probe: one lane per request.  INSERT: unseen keys claim an entry.
-// outputs: slot_out[i] (found), state[i], aux[i] (claimant: ktab position;
-// follower: request index of the claimant), hash_out[i]
+// Request i of a batch of n: returns its state; `slot` (found: the slot; claimant of a long key: the
+// reserved overflow offset / 16), `ax` (claimant: ktab position; follower: request index of the claimant)
+// and `h` (the key's hash).
 // ---------------------------------------------------------------------------
 template <bool INSERT>
-__global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __restrict__ key_bytes,
-                                                   const uint32_t* __restrict__ key_off, uint32_t n,
-                                                   uint32_t* __restrict__ slot_out, uint32_t* __restrict__ state,
-                                                   uint32_t* __restrict__ aux, uint64_t* __restrict__ hash_out,
-                                                   uint32_t* __restrict__ claim_cnt) {
-    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+__device__ __forceinline__ uint32_t probe_request(const Table& t, const uint8_t* __restrict__ key_bytes,
+                                                  const uint32_t* __restrict__ key_off, uint32_t n, uint32_t i, uint32_t& slot,
+                                                  uint32_t& ax, uint64_t& h) {
     uint32_t st = ST_MISSING;
-    if (i < n) {
     const uint32_t off = key_off[i], len = key_off[i + 1] - off, arena = key_off[n];
     const uint8_t* key = key_bytes + off;
     uint64_t k0, k1;
-    const uint64_t h = load_and_hash(key_bytes, off, len, arena, k0, k1);
+    h = load_and_hash(key_bytes, off, len, arena, k0, k1);
     const unsigned long long meta = entry_meta(h, len);
-    hash_out[i] = h;
     uint64_t pos = h & t.nb_mask;
-    uint32_t slot = NO_SLOT, ax = 0;
+    slot = NO_SLOT;
+    ax = 0;
     for (uint64_t probes = 0; probes <= t.nb_mask; ++probes) {
         Entry* en = &t.ktab[pos];
         // The whole 32-byte entry in one round trip, with plain loads: what they can show is either final
         // for this kernel (bound entries and tombstones only change in other kernels; a pending entry keeps
-        // its claimant until k_bind) or "empty", which the compare-and-swap below settles.
+        // its claimant until it is bound) or "empty", which the compare-and-swap below settles.
         const ulonglong2 lo = *reinterpret_cast<const ulonglong2*>(en);      // w, hash
         const ulonglong2 hi = *(reinterpret_cast<const ulonglong2*>(en) + 1); // key[0], key[1]
         unsigned long long e = lo.x;
@@ -263,14 +260,31 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
         pos = (pos + 1) & t.nb_mask;
     }
     if (INSERT && st == ST_CLAIMANT && len > INLINE_KEY) {
-        // long key: reserve its overflow bytes now, so that k_bind knows who takes a slot (offset / 16 rides in slot_out)
+        // long key: reserve its overflow bytes now, so that binding knows who takes a slot (offset / 16 rides in `slot`)
         const unsigned long long ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
         if (ovf + len > t.overflow_bytes) st = ST_NOSPACE;
         else slot = (uint32_t)(ovf >> 4);
     }
-    slot_out[i] = slot;
-    state[i] = st;
-    aux[i] = ax;
+    return st;
+}
+
+// outputs: slot_out[i], state[i], aux[i], hash_out[i] as probe_request leaves them; claim_cnt[block]
+template <bool INSERT>
+__global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __restrict__ key_bytes,
+                                                   const uint32_t* __restrict__ key_off, uint32_t n,
+                                                   uint32_t* __restrict__ slot_out, uint32_t* __restrict__ state,
+                                                   uint32_t* __restrict__ aux, uint64_t* __restrict__ hash_out,
+                                                   uint32_t* __restrict__ claim_cnt) {
+    const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
+    uint32_t st = ST_MISSING;
+    if (i < n) {
+        uint32_t slot, ax;
+        uint64_t h;
+        st = probe_request<INSERT>(t, key_bytes, key_off, n, i, slot, ax, h);
+        hash_out[i] = h;
+        slot_out[i] = slot;
+        state[i] = st;
+        aux[i] = ax;
     }
     if (INSERT) {
         // claimants of this block, for k_bind's slot assignment (no atomics on the free stack)
@@ -303,6 +317,56 @@ __device__ __forceinline__ uint32_t block_rank(bool flag, uint32_t& total) {
     return before + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
 }
 
+// Claimant i (its entry is ktab[pos], hash h, long keys: overflow offset / 16 in ovf16) takes
+// free_slots[stack_idx] (stack_idx < 0: the stack ran dry), stores the key and publishes the binding.
+// Returns the slot or NO_SLOT.
+__device__ __forceinline__ uint32_t bind_claimant(const Table& t, const uint8_t* __restrict__ key_bytes,
+                                                  const uint32_t* __restrict__ key_off, uint32_t i, uint32_t pos, uint64_t h,
+                                                  uint32_t ovf16, int stack_idx) {
+    const uint32_t off = key_off[i], len = key_off[i + 1] - off;
+    const uint8_t* key = key_bytes + off;
+    const uint32_t slot = stack_idx >= 0 ? t.free_slots[stack_idx] : NO_SLOT;
+    if (slot != NO_SLOT) {
+        KeyRec& kr = t.rec[slot];
+        uint8_t* dst = kr.bytes;
+        if (len > INLINE_KEY) {
+            const uint64_t o64 = (uint64_t)ovf16 << 4; // reserved by the probe
+            __builtin_memcpy(kr.bytes, &o64, 8);
+            dst = t.overflow + o64; // reservations are 16-byte multiples: dst is 16-byte aligned
+        }
+        uint32_t b = 0;
+        for (; b + 8 <= len; b += 8) {
+            uint64_t w;
+            __builtin_memcpy(&w, key + b, 8);
+            __builtin_memcpy(dst + b, &w, 8);
+        }
+        for (; b < len; ++b) dst[b] = key[b];
+        kr.hash = h;
+        kr.len = len;
+        kr.pos = pos;
+        t.bound[slot] = 1;
+        Entry* en = &t.ktab[pos];
+        uint64_t k0 = 0, k1 = 0;
+        if (len <= ENTRY_KEY) short_key_words(key, len, k0, k1);
+        en->hash = h;
+        en->key[0] = k0;
+        en->key[1] = k1;
+        en->w = entry_meta(h, len) | (unsigned long long)(slot + 2u);
+    } else { // the free stack ran dry
+        t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
+        atomicAdd(t.tombs, 1u);
+        atomicExch(t.error_flag, 1u);
+    }
+    return slot;
+}
+// a claimant without room for its long key gives the claimed entry back as a tombstone
+__device__ __forceinline__ void release_claim(const Table& t, const uint32_t* __restrict__ key_off, uint32_t i, uint32_t pos, uint64_t h) {
+    const uint32_t len = key_off[i + 1] - key_off[i];
+    t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
+    atomicAdd(t.tombs, 1u);
+    atomicExch(t.error_flag, 1u);
+}
+
 // claimants: take a slot, store the key, publish the binding.  Claimant number R of the batch (in request
 // order: k_probe left the number of claimants per block in claim_cnt[]) takes free_slots[top - 1 - R]; the
 // stack pointer itself moves once, in k_follow.  No atomics: one on a single address costs ~12 ns and
@@ -327,49 +391,9 @@ __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __rest
         uint32_t before = 0;
         for (int w = 0; w < THREADS / 64; ++w) before += s_part[w];
         const int top = *t.free_top; // moves in k_follow, not here
-        const int idx = top - 1 - (int)(before + rank);
-        const uint32_t off = key_off[i], len = key_off[i + 1] - off;
-        const uint8_t* key = key_bytes + off;
-        const uint32_t pos = aux[i];
-        const uint64_t h = hash_in[i];
-        const uint32_t slot = idx >= 0 ? t.free_slots[idx] : NO_SLOT;
-        if (slot != NO_SLOT) {
-            KeyRec& kr = t.rec[slot];
-            uint8_t* dst = kr.bytes;
-            if (len > INLINE_KEY) {
-                const uint64_t o64 = (uint64_t)slot_out[i] << 4; // reserved by k_probe
-                __builtin_memcpy(kr.bytes, &o64, 8);
-                dst = t.overflow + o64; // reservations are 16-byte multiples: dst is 16-byte aligned
-            }
-            uint32_t b = 0;
-            for (; b + 8 <= len; b += 8) {
-                uint64_t w;
-                __builtin_memcpy(&w, key + b, 8);
-                __builtin_memcpy(dst + b, &w, 8);
-            }
-            for (; b < len; ++b) dst[b] = key[b];
-            kr.hash = h;
-            kr.len = len;
-            kr.pos = pos;
-            t.bound[slot] = 1;
-            Entry* en = &t.ktab[pos];
-            uint64_t k0 = 0, k1 = 0;
-            if (len <= ENTRY_KEY) short_key_words(key, len, k0, k1);
-            en->hash = h;
-            en->key[0] = k0;
-            en->key[1] = k1;
-            en->w = entry_meta(h, len) | (unsigned long long)(slot + 2u);
-        } else { // the free stack ran dry
-            t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
-            atomicAdd(t.tombs, 1u);
-            atomicExch(t.error_flag, 1u);
-        }
-        slot_out[i] = slot;
-    } else if (st == ST_NOSPACE) { // no room for a long key: give the claimed entry back as a tombstone
-        const uint32_t off = key_off[i], len = key_off[i + 1] - off;
-        t.ktab[aux[i]].w = entry_meta(hash_in[i], len) | VAL_TOMB;
-        atomicAdd(t.tombs, 1u);
-        atomicExch(t.error_flag, 1u);
+        slot_out[i] = bind_claimant(t, key_bytes, key_off, i, aux[i], hash_in[i], slot_out[i], top - 1 - (int)(before + rank));
+    } else if (st == ST_NOSPACE) {
+        release_claim(t, key_off, i, aux[i], hash_in[i]);
         slot_out[i] = NO_SLOT;
     }
 }

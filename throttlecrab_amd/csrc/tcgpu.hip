@@ -150,6 +150,13 @@ struct tc_engine {
         uint8_t* status = nullptr;
     } stage;
 
+    // small host-pointer batches (k_small_batch): one pinned block the kernel reads its inputs from and writes
+    // its results to (the caller's arrays are copied in and out by the host)
+    uint8_t* small_io = nullptr;  // host address
+    uint8_t* small_io_dev = nullptr; // the same block as the device addresses it
+    size_t small_io_bytes = 0;
+    bool small_off = false;       // TCGPU_NO_SMALL_BATCH=1: always take the big pipeline
+
     // TC_B_ASYNC host batches still in flight, oldest first: one event per batch, recorded behind its last copy
     std::deque<hipEvent_t> async_done;
     std::vector<hipEvent_t> async_pool;
@@ -258,6 +265,7 @@ static int engine_alloc(tc_engine* e) {
     int prio_lo = 0, prio_hi = 0;
     TC_HIP(e, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     if (const char* d = getenv("TCGPU_EVAL_ITEMS")) e->eval_items = atoi(d);
+    if (const char* d = getenv("TCGPU_NO_SMALL_BATCH")) e->small_off = atoi(d) != 0;
     const char* pe = getenv("TCGPU_AUX_PRIORITY");
     const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
     // the evaluation kernel on the main stream is the critical path of the pipeline: grouping runs at
@@ -556,6 +564,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     void* kptrs[] = {e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_hash, e->k_stage_bytes, e->k_stage_off};
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
+    if (e->small_io) (void)hipHostFree(e->small_io);
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->async_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->async_pool) (void)hipEventDestroy(ev);
@@ -1078,6 +1087,125 @@ static int run_slots_host_async(tc_engine* e, const tc_batch& b) {
     return finish_async(e, b);
 }
 
+// ---- small host-pointer batches: one launch (k_small_batch) ----------------------------------------
+constexpr size_t SMALL_KEY_BYTES = 128 * 1024; // string mode: batches with a larger key arena take the big pipeline
+
+static bool small_batch_applies(const tc_engine* e, const tc_batch& b) {
+    if (e->small_off || b.n > (uint64_t)SMALL_MAX) return false;
+    if (b.flags & (TC_B_DEVICE_PTRS | TC_B_ASYNC | TC_B_GROUPED_OUTPUT)) return false;
+    if (b.allowed_bits) return false; // (packed bits come out of the big pipeline only)
+    if (e->key_mode && b.key_off[b.n] > SMALL_KEY_BYTES) return false;
+    return true;
+}
+
+// Host-pointer batch of at most SMALL_MAX requests, slot or string mode.  Same results as the big pipeline
+// (the run walker is the plain sequence); ordering against key stages on the key stream as tc_rate_limit.
+static int run_small_batch(tc_engine* e, const tc_batch& b) {
+    const size_t n = b.n;
+    if (!e->small_io) {
+        const size_t bytes = 64 + SMALL_KEY_BYTES + (size_t)SMALL_MAX * (4 + 4 + 5 * 8 + 1 + 1 + 4 * 8 + 32 + 32) + 16 * 16;
+        TC_HIP(e, hipHostMalloc((void**)&e->small_io, bytes, hipHostMallocDefault));
+        void* dv = nullptr;
+        TC_HIP(e, hipHostGetDevicePointer(&dv, e->small_io, 0));
+        e->small_io_dev = (uint8_t*)dv;
+        e->small_io_bytes = bytes;
+    }
+    size_t off = 64; // [0, 64): header: word 0 = "a key could not be bound"
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = (off + bytes + 15) & ~(size_t)15;
+        return at;
+    };
+    uint8_t* h = e->small_io;
+    uint8_t* d = e->small_io_dev;
+    std::memset(h, 0, 64);
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.n = (uint32_t)n;
+    const uint8_t* d_key_bytes = nullptr;
+    const uint32_t* d_key_off = nullptr;
+    if (e->key_mode) {
+        const size_t total = b.key_off[n];
+        const size_t o_off = take((n + 1) * 4), o_bytes = take(total + 16);
+        std::memcpy(h + o_off, b.key_off, (n + 1) * 4);
+        if (total) std::memcpy(h + o_bytes, b.key_bytes, total);
+        d_key_off = (const uint32_t*)(d + o_off);
+        d_key_bytes = d + o_bytes;
+    } else {
+        const size_t o = take(n * 4);
+        std::memcpy(h + o, b.slot, n * 4);
+        p.slot = (const uint32_t*)(d + o);
+    }
+    const int64_t* hin[5] = {b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns};
+    const int64_t** din[5] = {&p.burst, &p.count, &p.period, &p.q, &p.now};
+    for (int j = 0; j < 5; ++j) {
+        if (!hin[j]) continue;
+        const size_t o = take(n * 8);
+        std::memcpy(h + o, hin[j], n * 8);
+        *din[j] = (const int64_t*)(d + o);
+    }
+    p.burst_s = b.max_burst_scalar;
+    p.count_s = b.count_per_period_scalar;
+    p.period_s = b.period_scalar;
+    p.q_s = b.quantity_scalar;
+    p.now_s = b.now_ns_scalar;
+    struct Out {
+        void* host;
+        size_t at, bytes;
+    } outs[9];
+    int n_out = 0;
+    auto out_col = [&](void* host, size_t bytes) -> uint8_t* {
+        if (!host) return nullptr;
+        const size_t o = take(bytes);
+        outs[n_out++] = Out{host, o, bytes};
+        return d + o;
+    };
+    p.allowed = out_col(b.allowed, n);
+    p.status = out_col(b.status, n);
+    p.limit = (int64_t*)out_col(b.limit, n * 8);
+    p.remaining = (int64_t*)out_col(b.remaining, n * 8);
+    p.reset = (int64_t*)out_col(b.reset_after_ns, n * 8);
+    p.retry = (int64_t*)out_col(b.retry_after_ns, n * 8);
+    p.result4 = (int64_t*)out_col(b.result4, n * 32);
+    p.decisions = (tc_decision*)out_col(b.decisions, n * sizeof(tc_decision));
+    if (off > e->small_io_bytes) return fail(e, TC_E_INVALID_ARG, "small batch does not fit its staging block");
+    p.cells = e->cells;
+    p.rate_id = e->rate_id;
+    p.classes = e->classes;
+    p.uniform_class = e->uniform_id;
+    p.denied = e->denied;
+    p.capacity = e->capacity;
+    p.counters = e->counters;
+    if (b.flags & TC_B_REGISTERED_PARAMS) {
+        p.flags |= F_REGISTERED;
+        if (e->uniform_id) p.flags |= F_UNIFORM_CLASS;
+    }
+    hipStream_t s = cur_stream(e);
+    if (e->key_mode && e->k_busy) { // key stages on the key stream come first
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        e->k_busy = false;
+    }
+    prof_begin(e, TC_STAGE_EVAL, s);
+    hipLaunchKernelGGL(k_small_batch, dim3(1), dim3(SMALL_MAX), 0, s, p, e->kt, e->key_mode ? 1 : 0, d_key_bytes, d_key_off,
+                       (uint32_t*)d, e->counters + TC_CNT_KEYS_INSERTED);
+    prof_end(e, s);
+    TC_HIP(e, hipGetLastError());
+    if (e->key_mode) { // the key table may have changed: later key stages on the key stream wait for this
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
+    }
+    TC_HIP(e, hipStreamSynchronize(s));
+    e->batches++;
+    for (int j = 0; j < n_out; ++j) std::memcpy(outs[j].host, h + outs[j].at, outs[j].bytes);
+    uint32_t full = 0;
+    std::memcpy(&full, h, 4);
+    if (full) {
+        TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof(uint32_t), s));
+        return fail(e, TC_E_TABLE_FULL, "key table full: some keys got status Internal (raise capacity or sweep)");
+    }
+    return TC_E_OK;
+}
+
 extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
     const tc_batch& b = *bp;
@@ -1093,6 +1221,7 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
         return run_slots_device(e, b);
     }
     if (b.flags & TC_B_ASYNC) return run_slots_host_async(e, b);
+    if (small_batch_applies(e, b)) return run_small_batch(e, b);
     // host pointers: stage in, run, stage out, synchronise
     TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
     TC_HIP(e, hipMemcpyAsync(e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
@@ -1192,6 +1321,7 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     const uint8_t* d_bytes = b.key_bytes;
     const uint32_t* d_off = b.key_off;
     const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
+    if (!dev && small_batch_applies(e, b)) return run_small_batch(e, b);
     if (!dev) {
         int rc = stage_keys(e, b.key_bytes, b.key_off, b.n, &d_bytes, &d_off);
         if (rc != TC_E_OK) return rc;
