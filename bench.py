@@ -50,10 +50,15 @@ def pmc_traffic(stage):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
     (profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")))
+    import re
+    files = glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))
     if not files:
         return None
-    ks = json.load(open(files[-1]))["kernels"]
+
+    def visit(path):  # r<round>_v<visit>_...: newest visit of the newest round ("v10" sorts after "v9")
+        m = re.match(r"r(\d+)_v(\d+)_", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+    ks = json.load(open(max(files, key=visit)))["kernels"]
     want = {"eval": "k_eval_sorted<false", "sort": "k_onesweep", "prep": "k_hist", "commit": "k_commit_list"}.get(stage)
     for name, v in ks.items():
         if want and want in name:
