@@ -204,8 +204,9 @@ int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slots, const in
 int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64_t count_per_period, int64_t period);
 
 /* rate_limit_batch over pre-resolved slots / over string keys.
- * Host-pointer batches return after the results are in the output arrays;
- * TC_B_DEVICE_PTRS batches are asynchronous on the engine's stream. */
+ * Host-pointer batches return after the results are in the output arrays (up to 1024 requests are served by
+ * one kernel launch, ~30-40 us per call; larger ones by the grouping + evaluation pipeline), unless flagged
+ * TC_B_ASYNC; TC_B_DEVICE_PTRS batches are asynchronous on the engine's stream. */
 int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* b);
 int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* b);
 
