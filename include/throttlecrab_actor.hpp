@@ -147,7 +147,8 @@ class RateLimiterHandle {
     }
 
   private:
-    friend class RateLimiterActor;
+    template <class L>
+    friend class BasicRateLimiterActor;
     explicit RateLimiterHandle(std::shared_ptr<detail::Channel> ch) : ch_(std::move(ch)) { retain(); }
     // false: the actor has shut down (msg is untouched).  Blocks while the buffer is full (a message
     // larger than the whole buffer is let in when the buffer is empty).
@@ -189,19 +190,21 @@ class RateLimiterHandle {
 
 // actor.rs:88-168 (spawn_periodic / spawn_probabilistic / spawn_adaptive differ only in the
 // store's cleanup cadence, which never changes a decision; there is one GPU store)
-class RateLimiterActor {
+// The loop is written against what it needs from the limiter -- `FLIGHTS`, `submit_batch(std::vector<Request>)`,
+// `collect_batch()` -- so that the channel and pipelining logic can be tested without a GPU
+// (tests/cpp/test_actor_logic.cpp runs it over a stand-in limiter); RateLimiterActor below is the real one.
+template <class Limiter>
+class BasicRateLimiterActor {
   public:
-    // buffer_size: channel capacity (the server's --buffer-size, config.rs:311, default 100 000)
-    // max_batch:   most messages taken per loop turn (<= the store's max_batch)
+    // buffer_size: channel capacity in requests (the server's --buffer-size, config.rs:311, default 100 000)
+    // max_batch:   most requests taken per loop turn (<= the store's max_batch)
     // linger:      after the first message, wait up to this long for the queue to reach
     //              min_batch before draining (0 = drain whatever is there: lowest latency)
-    static RateLimiterHandle spawn_gpu(size_t buffer_size, GpuStore store, size_t max_batch = 1 << 16,
-                                       std::chrono::microseconds linger = std::chrono::microseconds(0),
-                                       size_t min_batch = 1) {
+    static RateLimiterHandle spawn(size_t buffer_size, std::shared_ptr<Limiter> limiter, size_t max_batch = 1 << 16,
+                                   std::chrono::microseconds linger = std::chrono::microseconds(0), size_t min_batch = 1) {
         auto ch = std::make_shared<detail::Channel>();
         ch->buffer_size = buffer_size ? buffer_size : 1;
         detail::Channel* raw = ch.get();
-        auto limiter = std::make_shared<RateLimiter>(std::move(store));
         ch->actor = std::thread([raw, limiter, max_batch, linger, min_batch] { run_actor(*raw, *limiter, max_batch, linger, min_batch); });
         return RateLimiterHandle(std::move(ch));
     }
@@ -212,7 +215,7 @@ class RateLimiterActor {
     // enqueued); while the GPU works on it the loop drains and marshals the next one, and the replies of
     // the oldest batch in flight go out when the pipeline is full or the queue has nothing to add.
     // Evaluation order == queue order, as with one batch at a time.
-    static void run_actor(detail::Channel& ch, RateLimiter& limiter, size_t max_batch, std::chrono::microseconds linger,
+    static void run_actor(detail::Channel& ch, Limiter& limiter, size_t max_batch, std::chrono::microseconds linger,
                           size_t min_batch) {
         std::deque<std::vector<RateLimiterMessage>> flying; // submitted batches, oldest first
         while (true) {
@@ -248,7 +251,7 @@ class RateLimiterActor {
                 if (submit_throttle_batch(limiter, msgs)) flying.push_back(std::move(msgs));
             }
             // answer the oldest batch when the pipeline is full or the queue had nothing to add
-            if (!flying.empty() && (flying.size() >= RateLimiter::FLIGHTS || !took)) {
+            if (!flying.empty() && (flying.size() >= Limiter::FLIGHTS || !took)) {
                 answer_throttle_batch(limiter, flying.front());
                 flying.pop_front();
             }
@@ -280,7 +283,7 @@ class RateLimiterActor {
 
     // actor.rs:238-255 for a whole batch, first half: hand the batch to the limiter.  false: it could not be
     // submitted and every request has been answered with the error.
-    static bool submit_throttle_batch(RateLimiter& limiter, std::vector<RateLimiterMessage>& msgs) {
+    static bool submit_throttle_batch(Limiter& limiter, std::vector<RateLimiterMessage>& msgs) {
         try {
             limiter.submit_batch(requests_of(msgs));
             return true;
@@ -292,7 +295,7 @@ class RateLimiterActor {
 
     // second half: the replies; send errors are ignored like in the reference (the receiver may have given
     // up, actor.rs:229-230)
-    static void answer_throttle_batch(RateLimiter& limiter, std::vector<RateLimiterMessage>& msgs) {
+    static void answer_throttle_batch(Limiter& limiter, std::vector<RateLimiterMessage>& msgs) {
         std::vector<RateLimitOutcome> out;
         try {
             out = limiter.collect_batch();
@@ -318,6 +321,15 @@ class RateLimiterActor {
                 m.many_tx.set_value(std::move(rs));
             }
         }
+    }
+};
+
+// actor.rs:88-168 with the GPU store
+class RateLimiterActor : public BasicRateLimiterActor<RateLimiter> {
+  public:
+    static RateLimiterHandle spawn_gpu(size_t buffer_size, GpuStore store, size_t max_batch = 1 << 16,
+                                       std::chrono::microseconds linger = std::chrono::microseconds(0), size_t min_batch = 1) {
+        return spawn(buffer_size, std::make_shared<RateLimiter>(std::move(store)), max_batch, linger, min_batch);
     }
 };
 

@@ -51,6 +51,17 @@ def test_cpp_metrics_text_program():
     assert "all tests passed" in out.stdout
 
 
+def test_cpp_actor_logic_program():
+    """The actor's channel / batching / pipelining logic over a stand-in limiter (queue order == evaluation
+    order, replies matched, at most FLIGHTS batches in flight, back-pressure, errors, shutdown): no GPU needed."""
+    exe = os.path.join(ROOT, "tests", "cpp", "test_actor_logic")
+    src = os.path.join(ROOT, "tests", "cpp", "test_actor_logic.cpp")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all tests passed" in out.stdout
+
+
 def test_cpp_sweep_policy_program():
     """Periodic / probabilistic / adaptive sweep schedulers == the reference stores' cleanup cadence
     (periodic.rs:128-142, probabilistic.rs:110-125, adaptive_cleanup.rs:138-211): no GPU needed."""
