@@ -75,9 +75,14 @@ struct ThrottleResponse {
 struct RateLimiterMessage {
     ThrottleRequest request;
     std::promise<Result<ThrottleResponse>> response_tx;
-    std::vector<ThrottleRequest> many;
-    std::promise<std::vector<Result<ThrottleResponse>>> many_tx;
-    size_t size() const { return many.empty() ? 1 : many.size(); }
+    // the group form lives behind one pointer: a std::promise allocates its shared state when it is constructed,
+    // and single requests should not pay for a second one
+    struct Many {
+        std::vector<ThrottleRequest> requests;
+        std::promise<std::vector<Result<ThrottleResponse>>> tx;
+    };
+    std::unique_ptr<Many> many;
+    size_t size() const { return many ? many->requests.size() : 1; }
 };
 
 namespace detail {
@@ -126,14 +131,15 @@ class RateLimiterHandle {
     // answered together.  Empty input -> empty output.
     std::future<std::vector<Result<ThrottleResponse>>> throttle_many_async(std::vector<ThrottleRequest> requests) {
         RateLimiterMessage msg;
-        std::future<std::vector<Result<ThrottleResponse>>> rx = msg.many_tx.get_future();
+        msg.many = std::make_unique<RateLimiterMessage::Many>();
+        std::future<std::vector<Result<ThrottleResponse>>> rx = msg.many->tx.get_future();
         const size_t n = requests.size();
         if (n == 0) {
-            msg.many_tx.set_value({});
+            msg.many->tx.set_value({});
             return rx;
         }
-        msg.many = std::move(requests);
-        if (!send(msg)) msg.many_tx.set_value(std::vector<Result<ThrottleResponse>>(n, std::string("Rate limiter actor has shut down")));
+        msg.many->requests = std::move(requests);
+        if (!send(msg)) msg.many->tx.set_value(std::vector<Result<ThrottleResponse>>(n, std::string("Rate limiter actor has shut down")));
         return rx;
     }
     std::vector<Result<ThrottleResponse>> throttle_many(std::vector<ThrottleRequest> requests) {
@@ -217,9 +223,9 @@ class BasicRateLimiterActor {
     // Evaluation order == queue order, as with one batch at a time.
     static void run_actor(detail::Channel& ch, Limiter& limiter, size_t max_batch, std::chrono::microseconds linger,
                           size_t min_batch) {
-        std::deque<std::vector<RateLimiterMessage>> flying; // submitted batches, oldest first
+        std::deque<std::deque<RateLimiterMessage>> flying; // submitted batches, oldest first
         while (true) {
-            std::vector<RateLimiterMessage> msgs;
+            std::deque<RateLimiterMessage> msgs;
             {
                 std::unique_lock<std::mutex> lk(ch.mu);
                 if (flying.empty()) { // nothing to answer meanwhile: wait for work
@@ -233,10 +239,15 @@ class BasicRateLimiterActor {
                     }
                 }
                 size_t take = 0; // requests
-                while (!ch.queue.empty() && (take == 0 || take + ch.queue.front().size() <= max_batch)) {
-                    take += ch.queue.front().size();
-                    msgs.push_back(std::move(ch.queue.front()));
-                    ch.queue.pop_front();
+                if (ch.queued_requests <= max_batch) { // the whole queue: O(1) under the lock the senders need
+                    take = ch.queued_requests;
+                    msgs.swap(ch.queue);
+                } else {
+                    while (!ch.queue.empty() && (take == 0 || take + ch.queue.front().size() <= max_batch)) {
+                        take += ch.queue.front().size();
+                        msgs.push_back(std::move(ch.queue.front()));
+                        ch.queue.pop_front();
+                    }
                 }
                 ch.queued_requests -= take;
                 if (take) {
@@ -258,7 +269,7 @@ class BasicRateLimiterActor {
         }
     }
 
-    static std::vector<Request> requests_of(const std::vector<RateLimiterMessage>& msgs) {
+    static std::vector<Request> requests_of(const std::deque<RateLimiterMessage>& msgs) {
         size_t n = 0;
         for (const RateLimiterMessage& m : msgs) n += m.size();
         std::vector<Request> reqs;
@@ -267,23 +278,23 @@ class BasicRateLimiterActor {
             reqs.push_back(Request{r.key, r.max_burst, r.count_per_period, r.period, r.quantity, r.timestamp});
         };
         for (const RateLimiterMessage& m : msgs) {
-            if (m.many.empty()) add(m.request);
+            if (!m.many) add(m.request);
             else
-                for (const ThrottleRequest& r : m.many) add(r);
+                for (const ThrottleRequest& r : m.many->requests) add(r);
         }
         return reqs;
     }
     // the same reply to every request of a batch (errors)
-    static void answer_all(std::vector<RateLimiterMessage>& msgs, const std::string& err) {
+    static void answer_all(std::deque<RateLimiterMessage>& msgs, const std::string& err) {
         for (RateLimiterMessage& m : msgs) {
-            if (m.many.empty()) m.response_tx.set_value(err);
-            else m.many_tx.set_value(std::vector<Result<ThrottleResponse>>(m.many.size(), err));
+            if (!m.many) m.response_tx.set_value(err);
+            else m.many->tx.set_value(std::vector<Result<ThrottleResponse>>(m.many->requests.size(), err));
         }
     }
 
     // actor.rs:238-255 for a whole batch, first half: hand the batch to the limiter.  false: it could not be
     // submitted and every request has been answered with the error.
-    static bool submit_throttle_batch(Limiter& limiter, std::vector<RateLimiterMessage>& msgs) {
+    static bool submit_throttle_batch(Limiter& limiter, std::deque<RateLimiterMessage>& msgs) {
         try {
             limiter.submit_batch(requests_of(msgs));
             return true;
@@ -295,7 +306,7 @@ class BasicRateLimiterActor {
 
     // second half: the replies; send errors are ignored like in the reference (the receiver may have given
     // up, actor.rs:229-230)
-    static void answer_throttle_batch(Limiter& limiter, std::vector<RateLimiterMessage>& msgs) {
+    static void answer_throttle_batch(Limiter& limiter, std::deque<RateLimiterMessage>& msgs) {
         std::vector<RateLimitOutcome> out;
         try {
             out = limiter.collect_batch();
@@ -312,13 +323,14 @@ class BasicRateLimiterActor {
         };
         size_t at = 0;
         for (RateLimiterMessage& m : msgs) {
-            if (m.many.empty()) {
+            if (!m.many) {
                 m.response_tx.set_value(reply(out[at++]));
             } else {
+                const size_t k = m.many->requests.size();
                 std::vector<Result<ThrottleResponse>> rs;
-                rs.reserve(m.many.size());
-                for (size_t i = 0; i < m.many.size(); ++i) rs.push_back(reply(out[at++]));
-                m.many_tx.set_value(std::move(rs));
+                rs.reserve(k);
+                for (size_t i = 0; i < k; ++i) rs.push_back(reply(out[at++]));
+                m.many->tx.set_value(std::move(rs));
             }
         }
     }
