@@ -400,3 +400,27 @@ def test_small_host_key_batches_single_launch():
     assert (res.status == 0).all()      # bound by the first call (in request order: the first 16 keys got the slots)
     eng.check_on_close = False
     eng.close()
+
+
+def test_async_key_batch_table_full_is_reported_later():
+    """A TC_B_ASYNC batch cannot return TC_E_TABLE_FULL itself: the requests that found no slot carry status
+    Internal, and the next synchronous key call delivers the return code once."""
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    eng = _engine(16, 64)
+    kb, ko = O.pack_keys([b"af_%d" % i for i in range(40)])
+    pk, po = eng.host_alloc(kb.size, np.uint8), eng.host_alloc(ko.size, np.uint32)
+    pk[:], po[:] = kb, ko
+    out = t.BatchResult(status=eng.host_alloc(40, np.uint8), allowed=eng.host_alloc(40, np.uint8))
+    eng.rate_limit_batch_keys(pk, po, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0, want=("status", "allowed"),
+                              out=out, async_=True)
+    eng.wait_batches(0)
+    assert (out.status == 0).sum() == 16 and (out.status == 3).sum() == 24 and out.allowed[out.status == 0].all()
+    served = [b"af_%d" % i for i in np.nonzero(out.status == 0)[0][:5]]
+    kb2, ko2 = O.pack_keys(served)
+    with pytest.raises(t.TcError):     # the earlier batch's TC_E_TABLE_FULL; this call's own requests were applied
+        eng.rate_limit_batch_keys(kb2, ko2, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 1)
+    res = eng.rate_limit_batch_keys(kb2, ko2, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 2)
+    assert (res.status == 0).all() and (res.remaining == 2).all()      # third request on each of these keys
+    eng.check_on_close = False
+    eng.close()

@@ -290,6 +290,8 @@ __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t
     const uint32_t i = threadIdx.x, n = p.n;
     uint32_t slot = kt::NO_SLOT;
     if (key_mode) {
+        // a TC_B_ASYNC batch before this one may have run into a full table: its return code is delivered here
+        if (i == 0 && atomicExch(t.error_flag, 0u) != 0u) table_full[1] = 1u;
         uint32_t st = kt::ST_FOUND, ax = 0;
         uint64_t h = 0;
         if (i < n) st = kt::probe_request<true>(t, key_bytes, key_off, n, i, slot, ax, h);

@@ -1197,12 +1197,12 @@ static int run_small_batch(tc_engine* e, const tc_batch& b) {
     TC_HIP(e, hipStreamSynchronize(s));
     e->batches++;
     for (int j = 0; j < n_out; ++j) std::memcpy(outs[j].host, h + outs[j].at, outs[j].bytes);
-    uint32_t full = 0;
-    std::memcpy(&full, h, 4);
-    if (full) {
-        TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof(uint32_t), s));
-        return fail(e, TC_E_TABLE_FULL, "key table full: some keys got status Internal (raise capacity or sweep)");
-    }
+    uint32_t full[2] = {0, 0}; // [0]: in this batch; [1]: in an asynchronous batch before it
+    std::memcpy(full, h, sizeof full);
+    if (full[0]) TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof(uint32_t), s));
+    if (full[0] || full[1])
+        return fail(e, TC_E_TABLE_FULL, full[0] ? "key table full: some keys got status Internal (raise capacity or sweep)"
+                                                : "key table full in an earlier TC_B_ASYNC batch: some of its keys got status Internal");
     return TC_E_OK;
 }
 
