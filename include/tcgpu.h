@@ -24,7 +24,8 @@
  *
  * Ownership / threading: the handle is owned by the caller and is NOT
  * thread-safe (same contract as `&mut RateLimiter`, store/mod.rs:40-43): one
- * caller at a time, work is issued on one HIP stream per engine.
+ * caller at a time; results are ordered on one HIP stream per engine (the
+ * engine may group and stage batches on internal streams of its own).
  * Plain pointers and sizes only; no C++/torch types cross this boundary.
  */
 #ifndef TCGPU_H
@@ -50,7 +51,9 @@ enum {
 };
 
 /* Call-level return codes (0 = success).  A negative return means the whole
- * call failed and NO request of the batch was applied. */
+ * call failed and NO request of the batch was applied -- except TC_E_TABLE_FULL:
+ * the requests whose keys had or got a slot were applied, the others carry
+ * status TC_INTERNAL. */
 enum {
     TC_E_OK = 0,
     TC_E_INVALID_ARG = -1,
