@@ -51,7 +51,7 @@ def pmc_traffic(stage):
     (profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is)."""
     import glob
     import re
-    files = glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json"))
+    files = glob.glob(os.path.join(ROOT, "profiles", "*_uniform_1M*_pmc.json"))  # the PMC passes over THIS command
     if not files:
         return None
 
