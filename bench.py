@@ -43,7 +43,9 @@ METRICS_EVERY = 32               # N > 1: RCCL all-gather of the counter blocks 
 
 
 KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep (one pass)", "eval": "k_eval_sorted",
-                   "commit": "k_commit_list", "pack": "k_pack_bits", "hash": "kt::k_probe+k_bind+k_follow"}
+                   "commit": "k_commit_list", "pack": "k_pack_bits", "hash": "kt::k_probe+k_bind+k_follow",
+                   "bucket_hist": "bp::k_tile_hist", "bucket_scan": "bp::k_bucket_scan", "bucket_scatter": "bp::k_scatter",
+                   "bucket_eval": "bp::k_bucket_eval"}
 
 
 def pmc_traffic(stage):
@@ -59,7 +61,9 @@ def pmc_traffic(stage):
         m = re.match(r"r(\d+)_v(\d+)_", os.path.basename(path))
         return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
     ks = json.load(open(max(files, key=visit)))["kernels"]
-    want = {"eval": "k_eval_sorted<false", "sort": "k_onesweep", "prep": "k_hist", "commit": "k_commit_list"}.get(stage)
+    want = {"eval": "k_eval_sorted<false", "sort": "k_onesweep", "prep": "k_hist", "commit": "k_commit_list",
+            "bucket_eval": "k_bucket_eval<false", "bucket_scatter": "k_scatter", "bucket_hist": "k_tile_hist",
+            "bucket_scan": "k_bucket_scan"}.get(stage)
     for name, v in ks.items():
         if want and want in name:
             return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0

@@ -250,7 +250,12 @@ enum {
     TC_STAGE_COMMIT = 3, /* deferred cell stores */
     TC_STAGE_PACK = 4,   /* decision bit packing */
     TC_STAGE_HASH = 5,   /* string mode: key -> slot resolution */
-    TC_STAGE_COUNT = 6
+    /* uniform batches are grouped WITHOUT a sort when their keys are spread evenly (bucket path): */
+    TC_STAGE_BUCKET_HIST = 6,    /* requests per key-range bucket, per 4096-request tile (bp::k_tile_hist) */
+    TC_STAGE_BUCKET_SCAN = 7,    /* prefix of those counts over the tiles (bp::k_bucket_scan) */
+    TC_STAGE_BUCKET_SCATTER = 8, /* stable partition of the batch by bucket (bp::k_scatter) */
+    TC_STAGE_BUCKET_EVAL = 9,    /* rank + GCRA decide + advance, one wave per bucket (bp::k_bucket_eval) */
+    TC_STAGE_COUNT = 10
 };
 int tc_profile_enable(tc_engine* e, int on);
 /* Accumulated milliseconds and launches per stage since tc_profile_enable. */

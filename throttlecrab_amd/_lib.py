@@ -21,8 +21,9 @@ TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY, 
 TC_B_ASYNC = 0x20
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
 TC_CNT_COUNT = 8
-TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash")
-TC_STAGE_COUNT = 6
+TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash", "bucket_hist", "bucket_scan", "bucket_scatter",
+                  "bucket_eval")
+TC_STAGE_COUNT = 10
 
 
 class tc_config(C.Structure):

@@ -22,6 +22,7 @@ using tc::RateClass;
 constexpr int BLOCK = 256;
 constexpr uint32_t F_REGISTERED = 1u;    // Params.flags: per-slot registered rate plan
 constexpr uint32_t F_UNIFORM_CLASS = 2u; // every slot carries plan `uniform_class`: skip the rate_id[] read
+constexpr uint32_t F_FIXED = 4u;         // TC_CFG_FIXED_PARAMS engine: 8-byte TAT column (tat8), timestamps < 2^62
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
 constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
 
@@ -48,6 +49,7 @@ struct Params {
     tc_decision* decisions;
     uint32_t* order; // TC_B_GROUPED_OUTPUT: output row k belongs to request order[k] (rows are in grouped order)
     Cell* cells;
+    int64_t* tat8; // TC_CFG_FIXED_PARAMS: the resident state as one TAT per key (cells == nullptr then)
     const uint16_t* rate_id;
     const RateClass* classes;
     uint32_t uniform_class;
@@ -80,6 +82,7 @@ __device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t sl
         if (r.q < 0) r.status = tc::ST_NEGATIVE_QUANTITY;            // rate_limiter.rs:111
         else if (r.limit <= 0) r.status = tc::ST_INVALID_RATE_LIMIT; // slot never registered
         else r.status = tc::check_request(r.q, r.now, r.dvt);
+        if ((p.flags & F_FIXED) && r.status == tc::ST_OK && r.now >= ((int64_t)1 << 62)) r.status = tc::ST_INTERNAL;
     } else {
         const int64_t burst = p.burst ? p.burst[i] : p.burst_s;
         const int64_t count = p.count ? p.count[i] : p.count_s;
@@ -108,6 +111,7 @@ __device__ __forceinline__ Req make_req_rc(const Params& p, uint32_t slot, const
         if (r.q < 0) r.status = tc::ST_NEGATIVE_QUANTITY;            // rate_limiter.rs:111
         else if (r.limit <= 0) r.status = tc::ST_INVALID_RATE_LIMIT; // slot never registered
         else r.status = tc::check_request(r.q, r.now, r.dvt);
+        if ((p.flags & F_FIXED) && r.status == tc::ST_OK && r.now >= ((int64_t)1 << 62)) r.status = tc::ST_INTERNAL;
     } else {
         r.limit = p.burst_s;
         r.status = tc::derive_request(p.burst_s, p.count_s, p.period_s, r.q, r.now, r.ei, r.dvt);
@@ -414,7 +418,9 @@ struct __attribute__((aligned(16))) PendEntry {
 template <bool FULL, bool DIRECT, int ITEMS>
 __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
                                                              PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
-                                                             uint32_t* __restrict__ loaded, uint32_t seq) {
+                                                             uint32_t* __restrict__ loaded, uint32_t seq,
+                                                             const uint32_t* __restrict__ gate, uint32_t gate_min) {
+    if (gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min) return; // this batch took the bucket path (bucket_path.hpp)
     const uint32_t n = p.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t block_start = blockIdx.x * (BLOCK * ITEMS);

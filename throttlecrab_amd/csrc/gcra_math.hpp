@@ -81,6 +81,25 @@ __device__ __forceinline__ void store_cell(Cell* p, const Cell& c) {
     *reinterpret_cast<longlong2*>(p) = make_longlong2(c.tat, (long long)c.expiry);
 }
 
+// TC_CFG_FIXED_PARAMS layout: 8 bytes per key, the stored TAT alone ("fixed-params
+// shortcut").  While a key's (burst, count, period) never change, every write leaves
+// expiry == tat + dvt (rate_limiter.rs:179-183 with adaptive_cleanup.rs:237: now + ((new_tat - now) + dvt)),
+// so the expiry column is redundant; a key that holds nothing is TAT_VACANT.  The engine only accepts
+// plans for this layout under which that identity is exact (fixed_plan_ok) and timestamps below 2^62.
+constexpr int64_t TAT_VACANT = INT64_MIN;
+TC_HD Cell fixed_cell(int64_t tat, int64_t dvt) {
+    Cell c;
+    c.tat = tat == TAT_VACANT ? 0 : tat;
+    c.expiry = tat == TAT_VACANT ? 0ull : (uint64_t)(tat + dvt);
+    return c;
+}
+// ei > 0 keeps TATs moving, dvt >= ei (burst >= 2 after the u32 truncation) keeps every ttl >= 0 (quantity 0
+// on a fresh key included), the 2^60 bounds keep tat + dvt inside i64 for every timestamp below 2^62.
+TC_HD bool fixed_plan_ok(int64_t ei, int64_t dvt) {
+    const int64_t LIM = (int64_t)1 << 60;
+    return ei > 0 && dvt >= ei && ei < LIM && dvt < LIM;
+}
+
 // A registered rate plan: everything RateLimiter::rate_limit derives from
 // (max_burst, count_per_period, period) before it looks at the key
 // (rate_limiter.rs:119-123): emission interval, delay variation tolerance, and
@@ -209,6 +228,51 @@ TC_HD RunForm run_form(const Cell& after0, int64_t ei, int64_t dvt, int64_t q, i
     f.n_tot = 1 + (lim - f.new0) / inc;
     f.regular = true;
     return f;
+}
+
+// The same run without the 64-bit division, for decisions-only batches: in a regular run the request of
+// rank r >= 1 is allowed  <=>  r < n_tot = 1 + (lim - new0) / inc  <=>  r * inc <= lim - new0.
+struct RunLite {
+    int64_t new0, inc;
+    uint64_t room; // lim - new0 >= 0
+    bool regular;
+};
+TC_HD RunLite run_lite(const Cell& after0, int64_t ei, int64_t dvt, int64_t q, int64_t now) {
+    RunLite f;
+    f.new0 = after0.tat;
+    f.inc = 0;
+    f.room = 0;
+    f.regular = false;
+    int64_t inc;
+    const int64_t LIM = (int64_t)1 << 62;
+    if (ei <= 0 || dvt < 0 || q <= 0 || __builtin_mul_overflow(ei, q, &inc)) return f;
+    f.inc = inc;
+    const int64_t lim = now + dvt;
+    if (inc >= LIM || lim >= LIM || f.new0 <= -LIM || f.new0 > lim) return f;
+    if (!(after0.expiry > (uint64_t)now)) return f;
+    if (f.new0 < now - dvt) return f;
+    f.room = (uint64_t)(lim - f.new0);
+    f.regular = true;
+    return f;
+}
+// r * inc <= room, exactly (r < 2^32, inc < 2^62: the product needs up to 94 bits)
+TC_HD bool rank_allowed(const RunLite& f, uint32_t r) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t hi = __umul64hi((uint64_t)r, (uint64_t)f.inc);
+#else
+    const uint64_t hi = (uint64_t)(((unsigned __int128)r * (unsigned __int128)(uint64_t)f.inc) >> 64);
+#endif
+    return hi == 0 && (uint64_t)r * (uint64_t)f.inc <= f.room;
+}
+// the cell an allowed request leaves: new_tat with the expiry of rate_limiter.rs:179-183 / adaptive_cleanup.rs:237
+TC_HD Cell cell_after(int64_t new_tat, int64_t dvt, int64_t now) {
+    Cell c;
+    const uint64_t ttl = (uint64_t)sat_add(sat_sub(new_tat, now), dvt);
+    uint64_t e = (uint64_t)now + ttl;
+    if (e < ttl) e = UINT64_MAX;
+    c.tat = new_tat;
+    c.expiry = e;
+    return c;
 }
 
 } // namespace tc

@@ -86,9 +86,23 @@ __device__ __forceinline__ uint32_t clamp_slot(uint32_t s, uint32_t cap) { retur
 // histogram of every pass's digit in one read of the slot column; also clears
 // the look-back state of this sort (so no separate memset launches)
 // ---------------------------------------------------------------------------
+// `gate`: a batch that is enqueued on BOTH grouping paths (bucket_path.hpp) is sorted only if the partition
+// found a bucket longer than `gate_min` requests (*gate, published by bp::k_bucket_scan earlier on the same
+// stream); otherwise every block leaves at once -- block 0 after clearing the other parity's histograms,
+// which is the one duty the host's parity flip relies on.
+__device__ __forceinline__ bool gated_off(const uint32_t* __restrict__ gate, uint32_t gate_min) {
+    return gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min;
+}
+
 __global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
-                                                  int passes, Workspace ws, uint32_t tiles) {
+                                                  int passes, Workspace ws, uint32_t tiles, const uint32_t* __restrict__ gate,
+                                                  uint32_t gate_min) {
     __shared__ uint32_t s_h[MAX_PASSES][RADIX];
+    if (gated_off(gate, gate_min)) {
+        if (blockIdx.x == 0)
+            for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += HIST_THREADS) ws.hist_next[i] = 0;
+        return;
+    }
     for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += HIST_THREADS) (&s_h[0][0])[i] = 0;
     // clear the look-back words this sort will use (every pass: part | gacc | gincl) + tickets
     {
@@ -144,8 +158,9 @@ template <int ITEMS, bool FIRST>
 __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict__ slot_in,
                                                       const uint64_t* __restrict__ elem_in,
                                                       uint64_t* __restrict__ elem_out, uint32_t n, uint32_t cap,
-                                                      int pass, Workspace ws) {
+                                                      int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min) {
     constexpr int TILE = THREADS * ITEMS;
+    if (gated_off(gate, gate_min)) return; // (the whole grid: nobody is left waiting in a look-back)
     __shared__ uint32_t s_base[RADIX];          // global exclusive start of each digit
     __shared__ uint32_t s_wave[WAVES][RADIX];   // per-wave digit counts -> exclusive prefix over waves
     __shared__ uint32_t s_off[RADIX];           // where this tile's run of each digit starts

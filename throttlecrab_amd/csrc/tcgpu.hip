@@ -35,6 +35,7 @@
 #include "radix_sort.hpp"
 
 #include "eval_kernels.hpp"
+#include "bucket_path.hpp"
 #include "maintenance_kernels.hpp"
 
 using tc::Cell;
@@ -109,6 +110,8 @@ struct tc_engine {
         size_t h_key_cap = 0;
         uint32_t* h_key_off = nullptr;
         uint32_t hist_parity = 0;
+        void* bp_scratch = nullptr;    // bucket path: tile histograms, offsets, partitioned elements, gate
+        bp::Work bpw;
         hipEvent_t sorted = nullptr;   // recorded on the auxiliary stream after the last pass
         hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
         bool in_use = false;
@@ -162,6 +165,18 @@ struct tc_engine {
     std::vector<hipEvent_t> async_pool;
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
+
+    // bucket path (bucket_path.hpp): uniform batches are partitioned by key range and ranked per bucket instead of
+    // sorted.  Such a batch is enqueued on BOTH paths; the partition's largest bucket (a word in device memory,
+    // the gate) decides on the device which of the two runs, so a skewed batch never waits for the host.
+    bool bp_ok = false;      // the key space fits the path (<= bp::MAX_BUCKETS buckets)
+    int bp_lb = 0;           // log2(slots per bucket)
+    uint32_t bp_nbk = 0;
+    uint32_t bp_max_n = 0;   // largest batch the scratch is sized for (<= bp::MAX_N)
+    uint32_t bp_min_n = 0;   // smaller batches are sorted (TCGPU_BUCKET_MIN_N)
+    uint32_t bp_skew = 1024; // longest bucket the path takes on (TCGPU_BUCKET_SKEW)
+    bool bp_piped = false;   // also for TC_B_INPUTS_READY batches (TCGPU_BUCKET_PIPED=1; measured slower)
+    PendEntry* bp_park = nullptr; // parked cell stores of long buckets, one entry per request
 
     // string-key mode (TC_CFG_KEY_MODE): device hash table + per-batch resolution scratch
     bool key_mode = false;
@@ -282,6 +297,27 @@ static int engine_alloc(tc_engine* e) {
         TC_HIP(e, hipMemsetAsync(ss.ws, 0, words * sizeof(uint32_t), (hipStream_t)0));
         TC_HIP(e, hipEventCreateWithFlags(&ss.sorted, hipEventDisableTiming));
         TC_HIP(e, hipEventCreateWithFlags(&ss.consumed, hipEventDisableTiming));
+    }
+    {
+        e->bp_max_n = (uint32_t)std::min<uint64_t>(mb, bp::MAX_N);
+        e->bp_lb = bp::pick_lb(cap, e->bp_max_n);
+        const char* off = getenv("TCGPU_BUCKET");
+        e->bp_ok = e->bp_lb >= 0 && !(off && atoi(off) == 0);
+        e->bp_min_n = 16384;
+        if (const char* d = getenv("TCGPU_BUCKET_PIPED")) e->bp_piped = atoi(d) != 0;
+        if (const char* d = getenv("TCGPU_BUCKET_MIN_N")) e->bp_min_n = (uint32_t)std::max(atoi(d), 1);
+        if (const char* d = getenv("TCGPU_BUCKET_SKEW")) e->bp_skew = (uint32_t)std::min<long long>(std::max(atoll(d), 1ll), bp::MAX_SKEW);
+        if (e->bp_ok) {
+            e->bp_nbk = bp::buckets_of(cap, e->bp_lb);
+            const size_t bytes = bp::work_bytes(e->bp_max_n, e->bp_nbk);
+            for (uint32_t si = 0; si < e->depth; ++si) {
+                tc_engine::SortSet& ss = e->sets[si];
+                TC_HIP(e, hipMalloc(&ss.bp_scratch, bytes));
+                ss.bpw = bp::carve(ss.bp_scratch, e->bp_max_n, e->bp_nbk, e->bp_lb);
+                ss.bpw.skew = e->bp_skew;
+            }
+            TC_HIP(e, hipMalloc(&e->bp_park, (size_t)e->bp_max_n * sizeof(PendEntry)));
+        }
     }
     TC_HIP(e, hipMalloc(&e->pend, (mb / 32 + 1024) * sizeof(PendEntry)));
     TC_HIP(e, hipMalloc(&e->chain, (mb / 64 + 2) * sizeof(ChainRec)));
@@ -543,11 +579,11 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.elem_a, ss.elem_b, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
+    void* ptrs[] = {e->bp_park, e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};
@@ -782,7 +818,7 @@ static int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, boo
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
 // returns the buffer holding the result
 static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
-                                    bool piped) {
+                                    bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
     const int passes = (bits + 7) / 8;
@@ -792,7 +828,7 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     ss.hist_parity ^= 1u;
     prof_begin(e, TC_STAGE_PREP, s);
     hipLaunchKernelGGL(rs::k_hist, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap,
-                       passes, ws, tiles);
+                       passes, ws, tiles, gate, gate_min);
     prof_end(e, s);
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
     const uint64_t* in = nullptr;
@@ -802,17 +838,17 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
         if (p == 0) {
             if (piped)
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                                   (const uint64_t*)nullptr, out, n, cap, p, ws);
+                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min);
             else
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                                   (const uint64_t*)nullptr, out, n, cap, p, ws);
+                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min);
         } else {
             if (piped)
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
-                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws);
+                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min);
             else
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
-                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws);
+                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min);
         }
         prof_end(e, s);
         in = out;
@@ -857,20 +893,59 @@ static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params
 // 4 when it runs alone (measured; 8 is slower everywhere; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
 template <int ITEMS>
 static void launch_eval_items(tc_engine* e, bool full, bool direct, uint32_t n, hipStream_t s, const Params& p, const uint64_t* sorted,
-                              uint32_t seq) {
+                              uint32_t seq, const uint32_t* gate, uint32_t gate_min) {
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
-    if (full && direct) hipLaunchKernelGGL((k_eval_sorted<true, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
-    else if (full) hipLaunchKernelGGL((k_eval_sorted<true, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
-    else if (direct) hipLaunchKernelGGL((k_eval_sorted<false, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
-    else hipLaunchKernelGGL((k_eval_sorted<false, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq);
+    if (full && direct) hipLaunchKernelGGL((k_eval_sorted<true, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (full) hipLaunchKernelGGL((k_eval_sorted<true, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (direct) hipLaunchKernelGGL((k_eval_sorted<false, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else hipLaunchKernelGGL((k_eval_sorted<false, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
 }
 static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped, uint32_t n, hipStream_t s, const Params& p,
-                               const uint64_t* sorted, uint32_t seq) {
+                               const uint64_t* sorted, uint32_t seq, const uint32_t* gate = nullptr, uint32_t gate_min = 0) {
     switch (e->eval_items ? e->eval_items : (piped ? 2 : 4)) {
-    case 1: launch_eval_items<1>(e, full, direct, n, s, p, sorted, seq); return;
-    case 2: launch_eval_items<2>(e, full, direct, n, s, p, sorted, seq); return;
-    default: launch_eval_items<4>(e, full, direct, n, s, p, sorted, seq); return;
+    case 1: launch_eval_items<1>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+    case 2: launch_eval_items<2>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+    default: launch_eval_items<4>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
     }
+}
+
+// ---- bucket path (bucket_path.hpp) -------------------------------------------------------------------
+// partition of the batch by key range, on stream `s` (k_tile_hist, k_bucket_scan, k_scatter)
+static void bucket_partition(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n) {
+    const bp::Work& w = ss.bpw;
+    const uint32_t tiles = bp::tiles_of(n), cap = (uint32_t)e->capacity;
+    prof_begin(e, TC_STAGE_BUCKET_HIST, s);
+    hipLaunchKernelGGL(bp::k_tile_hist, dim3(tiles), dim3(bp::TILE_THREADS), w.nbk * sizeof(uint32_t), s, d_slot, n, cap, w);
+    prof_end(e, s);
+    prof_begin(e, TC_STAGE_BUCKET_SCAN, s);
+    hipLaunchKernelGGL(bp::k_bucket_scan, dim3(bp::scan_blocks(w.nbk)), dim3(bp::SCAN_THREADS), 0, s, w, tiles);
+    prof_end(e, s);
+    prof_begin(e, TC_STAGE_BUCKET_SCATTER, s);
+    hipLaunchKernelGGL(bp::k_scatter, dim3(tiles), dim3(bp::TILE_THREADS), bp::scatter_lds_bytes(w.nbk), s, d_slot, n, cap, w);
+    prof_end(e, s);
+}
+// evaluation of the partitioned batch: one wave per bucket (k_bucket_eval)
+static void bucket_eval(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const Params& p, bool full) {
+    const bp::Work& w = ss.bpw;
+    const bool by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS);
+    const bool fixed = (p.flags & F_FIXED) != 0;
+    const dim3 grid(w.nbk), block(64);
+    const size_t lds = bp::eval_lds_bytes(w.lb);
+    prof_begin(e, TC_STAGE_BUCKET_EVAL, s);
+#define TC_BEV(FU, FI, BS) \
+    hipLaunchKernelGGL((bp::k_bucket_eval<FU, FI, BS>), grid, block, lds, s, p, w, e->bp_park)
+    switch ((full ? 4 : 0) | (fixed ? 2 : 0) | (by_slot ? 1 : 0)) {
+    case 0: TC_BEV(false, false, false); break;
+    case 1: TC_BEV(false, false, true); break;
+    case 2: TC_BEV(false, true, false); break;
+    case 3: TC_BEV(false, true, true); break;
+    case 4: TC_BEV(true, false, false); break;
+    case 5: TC_BEV(true, false, true); break;
+    case 6: TC_BEV(true, true, false); break;
+    default: TC_BEV(true, true, true); break;
+    }
+#undef TC_BEV
+    prof_end(e, s);
 }
 
 // input arrays of a TC_B_ASYNC host batch, staged inside run_slots_device on the stream that groups the batch
@@ -926,6 +1001,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
     p.decisions = b.decisions;
     p.order = (b.flags & TC_B_GROUPED_OUTPUT) ? b.order : nullptr;
     p.cells = e->cells;
+    p.tat8 = nullptr;
     p.rate_id = e->rate_id;
     p.classes = e->classes;
     p.uniform_class = e->uniform_id;
@@ -969,6 +1045,22 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             if (rc != TC_E_OK) return rc;
             piped = e->n_aux != 0; // no free hardware queue: in order on the main stream
         }
+        // (the per-request columns of a TC_B_ASYNC host batch are still to be staged: they are in `hin`)
+        auto column = [&](const int64_t* dev, int j) { return dev != nullptr || (hin && hin->col[j] != nullptr); };
+        const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!column(p.burst, 0) && !column(p.count, 1) && !column(p.period, 2));
+        const bool uniform = !column(p.q, 3) && !column(p.now, 4) && params_by_slot;
+        // direct: every run is regular whatever the cells hold: owners store directly, no commit launch
+        const bool direct = uniform && all_runs_regular(e, b, p);
+        // Uniform batches whose runs are all regular, running IN ORDER on the engine's stream, are enqueued on
+        // BOTH grouping paths: the partition by key range (bucket_path.hpp) and, gated behind it, the sort.  The
+        // partition publishes its largest bucket; if that is longer than bp_skew (a skewed stream) the bucket
+        // kernels leave at once and the sort path runs, otherwise the other way round -- decided on the
+        // device, batch by batch (the host may be hundreds of batches ahead).  Pipelined batches are sorted:
+        // beside the evaluation of earlier batches the partition's scattered 4-byte writes cost more than
+        // the sort's three coalesced passes (69-86 vs 66 us per 1 Mi batch).
+        // (TC_B_GROUPED_OUTPUT promises rows grouped by key: that is the sorted order)
+        const bool bucketed = direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
+        const uint32_t* gate = bucketed ? ss.bpw.maxb : nullptr;
         const uint64_t* sorted;
         const uint32_t* d_slot = b.slot;
         if (piped) {
@@ -977,27 +1069,26 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
             if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
-            sorted = sort_by_slot(e, ss, ax, d_slot, n, true);
+            if (bucketed) bucket_partition(e, ss, ax, d_slot, n);
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew);
             TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
         } else {
             // everything that used this set earlier is ordered before us on `s`: evaluations ran on `s`,
             // and every auxiliary sort was joined into `s` before its evaluation
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
-            sorted = sort_by_slot(e, ss, s, d_slot, n, false);
+            if (bucketed) bucket_partition(e, ss, s, d_slot, n);
+            sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
         }
-        const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!p.burst && !p.count && !p.period);
-        const bool uniform = !p.q && !p.now && params_by_slot;
+        if (bucketed) bucket_eval(e, ss, s, p, full);
         prof_begin(e, TC_STAGE_EVAL, s);
         if (uniform) {
-            const bool direct = all_runs_regular(e, b, p);
-            // direct: every run is regular whatever the cells hold: owners store directly, no commit launch
             uint32_t seq = 0u;
             if (direct) {
                 if (++e->loaded_seq == 0u) e->loaded_seq = 1u;
                 seq = e->loaded_seq;
             }
-            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq);
+            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew);
             prof_end(e, s);
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
