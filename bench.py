@@ -42,32 +42,47 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRICS_EVERY = 32               # N > 1: RCCL all-gather of the counter blocks every this many steps (+ the last)
 
 
-KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep (one pass)", "eval": "k_eval_sorted",
-                   "commit": "k_commit_list", "pack": "k_pack_bits", "hash": "kt::k_probe+k_bind+k_follow",
-                   "bucket_hist": "bp::k_tile_hist", "bucket_scan": "bp::k_bucket_scan", "bucket_scatter": "bp::k_scatter",
-                   "bucket_eval": "bp::k_bucket_eval"}
+KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep", "eval": "ev::k_eval_sorted", "commit": "ev::k_commit_list",
+                   "pack": "ev::k_pack_bits", "hash": "kt::k_probe + k_bind + k_follow", "bucket_hist": "bp::k_tile_hist",
+                   "bucket_scan": "bp::k_bucket_scan", "bucket_scatter": "bp::k_scatter", "bucket_eval": "bp::k_bucket_eval"}
+# kernel name fragments in the rocprofv3 summaries under profiles/
+PROFILE_NAME_OF_STAGE = {"prep": "rs::k_hist", "sort": "k_onesweep", "eval": "k_eval_sorted", "commit": "k_commit_list",
+                         "bucket_hist": "k_tile_hist", "bucket_scan": "k_bucket_scan", "bucket_scatter": "k_scatter",
+                         "bucket_eval": "k_bucket_eval", "hash": "kt::k_probe"}
+COPY_CEILING_GBS = 6290.0        # MI355X_MICROARCH.md: measured copy ceiling (what line-granular traffic can reach)
 
 
-def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
-    (profiles/*_pmc.json; FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is)."""
+def pmc_traffic(stage, stream, layout, launches_per_batch):
+    """HBM bytes per BATCH of the stage's kernels from the newest committed rocprofv3 PMC summary of this
+    command (profiles/r<round>_v<visit>_<stream>_<layout>*_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE
+    passes; FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md, WRITE_SIZE as is).
+    -> (bytes or None, source dict or None).  The numbers are NOT measured by this run: `source` says which
+    file (and which commit it was taken at) so that a stale profile cannot pass for a fresh one."""
     import glob
     import re
-    files = glob.glob(os.path.join(ROOT, "profiles", "*_uniform_1M*_pmc.json"))  # the PMC passes over THIS command
-    if not files:
-        return None
+    files = glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_{layout}*_pmc.json"))
+    if layout == "wide":  # (round-1 summaries carry no layout tag: they are the 16-byte layout)
+        files += [f for f in glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_1M*_pmc.json"))]
+    want = PROFILE_NAME_OF_STAGE.get(stage)
+    if not files or not want:
+        return None, None
 
-    def visit(path):  # r<round>_v<visit>_...: newest visit of the newest round ("v10" sorts after "v9")
+    def visit(path):  # newest visit of the newest round ("v10" sorts after "v9")
         m = re.match(r"r(\d+)_v(\d+)_", os.path.basename(path))
         return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
-    ks = json.load(open(max(files, key=visit)))["kernels"]
-    want = {"eval": "k_eval_sorted<false", "sort": "k_onesweep", "prep": "k_hist", "commit": "k_commit_list",
-            "bucket_eval": "k_bucket_eval<false", "bucket_scatter": "k_scatter", "bucket_hist": "k_tile_hist",
-            "bucket_scan": "k_bucket_scan"}.get(stage)
-    for name, v in ks.items():
-        if want and want in name:
-            return (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0
-    return None
+    for path in sorted(files, key=visit, reverse=True):
+        doc = json.load(open(path))
+        total, names = 0.0, []
+        for name, v in doc["kernels"].items():
+            if want in name and v.get("launches", 0) >= 3:
+                # several variants of one stage (first / later radix pass): weigh by launches
+                total += (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * v["launches"]
+                names.append((name, v["launches"]))
+        if names:
+            n_launch = sum(n for _, n in names)
+            return total / n_launch * launches_per_batch, {"file": os.path.relpath(path, ROOT), "git_sha": doc.get("git_sha"),
+                                                           "command": doc.get("command"), "kernels": [n for n, _ in names]}
+    return None, None
 
 
 def parse():
@@ -81,6 +96,10 @@ def parse():
     ap.add_argument("--cpu-sample-batches", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--profile-run", action="store_true",
+                    help="warmup + timed region only (what rocprofv3 is pointed at: no per-kernel events, no secondary runs)")
+    ap.add_argument("--layout", default="wide", choices=["wide", "fixed"],
+                    help="resident state: 16-byte {tat, expiry} cells, or TC_CFG_FIXED_PARAMS (8-byte TAT column)")
     return ap.parse_args()
 
 
@@ -126,9 +145,10 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
 
 
 def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True):
-    """Same steps again with a HIP event pair around each of the engine's kernels (recorded on
-    the stream the kernel runs on).  piped=True: as in the timed region, the sort of later batches
-    overlaps the evaluation of earlier ones, so the durations include that contention."""
+    """`steps` more batches with a HIP event pair around each of the engine's kernels (recorded on the stream the
+    kernel runs on).  piped=True: issued exactly like the timed region (the grouping of later batches overlaps
+    the evaluation of earlier ones), so the durations include that contention.
+    -> {stage: {"kernel", "launches_per_batch", "avg_ms", "per_batch_ms"}}"""
     import torch
     eng.profile_enable(True)
     for i in range(steps):
@@ -137,7 +157,72 @@ def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True):
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile_enable(False)
-    return prof
+    return {k: {"kernel": KERNEL_OF_STAGE[k], "launches_per_batch": calls / steps, "avg_ms": ms / calls, "per_batch_ms": ms / steps}
+            for k, (ms, calls) in prof.items() if calls}
+
+
+def roofline_block(a, stream, dt, piped, inorder):
+    """achieved = algorithmic bytes (36.125 B per decision x the batch) / duration, against the
+    8 TB/s HBM peak.  The headline entry is the stage with the largest PER-BATCH total in the configuration that
+    was timed (pipelined: `value` comes from there); `stages` has every stage, in that configuration and with
+    the batches strictly in order on one stream (what rocprofv3 --kernel-trace shows: the tracer serialises)."""
+    alg = ALG_BYTES_PER_DECISION * a.batch
+
+    def fill(st, k):
+        s = dict(st)
+        s["achieved_GBs"] = alg / (s["per_batch_ms"] * 1e-3) / 1e9
+        s["frac"] = s["achieved_GBs"] / HBM_PEAK_GBS
+        tr, src = pmc_traffic(k, stream, a.layout, s["launches_per_batch"])
+        s["traffic_bytes_per_batch"] = tr
+        if tr:
+            s["traffic_floor_ms"] = tr / (COPY_CEILING_GBS * 1e9) * 1e3  # what this traffic costs at the copy ceiling
+            s["traffic_source"] = src
+        return s
+    p_st = {k: fill(v, k) for k, v in piped.items()}
+    i_st = {k: fill(v, k) for k, v in inorder.items()}
+    dom = max(p_st, key=lambda k: p_st[k]["per_batch_ms"])
+    d = p_st[dom]
+    # the kernel that touches the resident state (what the algorithmic bytes describe), in both configurations
+    ev_p = p_st.get("eval") or p_st.get("bucket_eval")
+    ev_i = max((i_st[k] for k in ("eval", "bucket_eval") if k in i_st), key=lambda s: s["per_batch_ms"])
+    block = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_batch": alg,
+             "stage": dom, "kernel": d["kernel"], "launches_per_batch": d["launches_per_batch"], "avg_ms": d["avg_ms"],
+             "per_batch_ms": d["per_batch_ms"], "achieved": d["achieved_GBs"], "frac": d["frac"],
+             "traffic": d["traffic_bytes_per_batch"], "traffic_source": d.get("traffic_source"),
+             "measured_in": "the configuration of the timed region (batches pipelined with TC_B_INPUTS_READY; HIP events on the "
+                            "stream each kernel runs on, same process, right after the timed region)",
+             "whole_step_frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
+             "whole_step_GBs": alg / (dt / a.steps) / 1e9,
+             "evaluation_kernel": {"pipelined": ev_p, "in_order": ev_i},
+             "stages": {"pipelined": p_st, "in_order": i_st},
+             "in_order_sum_ms": sum(s["per_batch_ms"] for s in i_st.values())}
+    return block
+
+
+def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world):
+    """One engine, one request stream: warmup + timed region (pipelined), then the per-kernel profile."""
+    import torch
+    eng = t.Engine(a.keys, a.batch, device=local, fixed_params=(a.layout == "fixed"))
+    eng.use_torch_stream()
+    eng.register_params_uniform(*W.REF_PARAMS)
+    nb = a.steps + a.warmup
+    host_batches = make_batches(stream, a.keys, a.batch, min(nb, 64), seed_shift=seed_shift)
+    d_batches = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in host_batches]
+    out = t.BatchResult()
+    cnt_view = gathered = None
+    if dist is not None:
+        from throttlecrab_amd.sharded import device_counter_view
+        cnt_view = device_counter_view(eng)
+        gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
+    dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered)
+    c = eng.counters()
+    res = {"value": a.steps * a.batch * world / dt, "unit": "decisions/s", "ms_per_step": 1e3 * dt / a.steps,
+           "allowed_fraction": c["allowed"] / max(1, c["total"])}
+    if rank == 0 and not a.profile_run:
+        piped = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True)
+        inorder = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False)
+        res["roofline"] = roofline_block(a, stream, dt, piped, inorder)
+    return res, eng, d_batches, dt
 
 
 def keys_bench(a, dev):
@@ -244,6 +329,102 @@ def cpu_baseline(kind, n_keys, batch, n_batches):
                           "note": "keys hash-sharded over one AdaptiveStore port per thread"}}
 
 
+def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
+    """Other output forms and batch shapes on the second engine (its stream `ob` is the `other` one)."""
+    import torch
+    also = {}
+    out = t.BatchResult()
+    nb = a.steps + a.warmup
+    full = t.BatchResult()
+    dt3, _ = run_gpu(eng2, ob, full, W.T0_NS + 10**9, a.steps, 2, None, None, None,
+                     want=t.Engine.ALL_FIELDS)
+    also[f"{other}_stream_full_result"] = {"value": a.steps * a.batch / dt3, "unit": "decisions/s"}
+    rec = t.BatchResult()
+    dt4, _ = run_gpu(eng2, ob, rec, W.T0_NS + 3 * 10**9, a.steps, 2, None, None, None,
+                     want=t.Engine.RECORD_FIELDS)
+    also[f"{other}_stream_full_result_records"] = {"value": a.steps * a.batch / dt4, "unit": "decisions/s",
+                                                  "note": "result4: one 32-byte RateLimitResult record per request"}
+    dec = t.BatchResult()
+    dt5, _ = run_gpu(eng2, ob, dec, W.T0_NS + 3 * 10**9 + 10**8, a.steps, 2, None, None, None,
+                     want=t.Engine.DECISION_FIELDS)
+    also[f"{other}_stream_full_result_decision_records"] = {
+        "value": a.steps * a.batch / dt5, "unit": "decisions/s",
+        "note": "tc_decision: remaining, reset_after, retry_after, allowed, status in one 32-byte record"}
+    # grouped output (TC_B_GROUPED_OUTPUT): rows in evaluation order + the request index of each row
+    grp = t.BatchResult()
+    d_main = d_batches
+    for label, streams, want in ((f"{a.workload}_stream_grouped_output", d_main, ("allowed",)),
+                                 (f"{a.workload}_stream_grouped_decision_records", d_main, t.Engine.DECISION_FIELDS)):
+        for i in range(a.warmup):
+            eng2.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=W.T0_NS + 5 * 10**9 + i,
+                                        want=want, out=grp, inputs_ready=True, grouped=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.steps):
+            eng2.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1,
+                                        now_ns=W.T0_NS + 5 * 10**9 + 10**6 * (i + 1), want=want, out=grp, inputs_ready=True,
+                                        grouped=True)
+        torch.cuda.synchronize()
+        also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s",
+                       "note": "output rows in the engine's evaluation order + order[] (request index of each row)"}
+        grp = t.BatchResult()
+    # general batches: every request carries its own timestamp (strictly increasing inside
+    # the batch), so the closed form does not apply and k_eval_general runs
+    nows = [torch.arange(a.batch, dtype=torch.int64, device=dev) + (W.T0_NS + 4 * 10**9 + b * 10**6)
+            for b in range(a.warmup + a.steps)]
+    gout = t.BatchResult()
+    for label, streams in ((f"{other}_stream_per_request_timestamps", ob), (f"{a.workload}_stream_per_request_timestamps", d_batches)):
+        eng3 = t.Engine(a.keys, a.batch, device=local, fixed_params=(a.layout == "fixed"))
+        eng3.use_torch_stream()
+        eng3.register_params_uniform(*W.REF_PARAMS)
+        for i in range(a.warmup):
+            eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
+                                        want=("allowed",), out=gout, inputs_ready=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(a.warmup, a.warmup + a.steps):
+            eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
+                                        want=("allowed",), out=gout, inputs_ready=True)
+        torch.cuda.synchronize()
+        also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s"}
+        eng3.close()
+    # PCIe-inclusive rate: the same stream handed over as HOST buffers (never `value`)
+    hb = make_batches(other, a.keys, a.batch, 8)
+    hout = t.BatchResult()
+    for i in range(2):
+        eng2.rate_limit_batch_slots(hb[i], registered=True, quantity=1, now_ns=W.T0_NS + 2 * 10**9, want=("allowed",), out=hout)
+    t0 = time.perf_counter()
+    for i in range(8):
+        eng2.rate_limit_batch_slots(hb[i], registered=True, quantity=1, now_ns=W.T0_NS + 2 * 10**9 + i, want=("allowed",), out=hout)
+    also[f"{other}_stream_host_buffers_pcie_inclusive"] = {"value": 8 * a.batch / (time.perf_counter() - t0),
+                                                          "unit": "decisions/s"}
+    # the same, as a server would feed it: TC_B_ASYNC batches from a ring of pinned buffers, so the PCIe
+    # transfers of one batch overlap the evaluation of others (never `value` either)
+    K, NA = 4, 48
+    ring = [(eng2.host_alloc(a.batch, np.uint32), t.BatchResult(allowed=eng2.host_alloc(a.batch, np.uint8))) for _ in range(K)]
+
+    def feed(i):
+        if i >= K:
+            eng2.wait_batches(K - 1)   # the oldest set's results are in: a server would answer them here
+        sl, ob = ring[i % K]
+        eng2.rate_limit_batch_slots(sl, registered=True, quantity=1, now_ns=W.T0_NS + 3 * 10**9 + i, want=("allowed",),
+                                    out=ob, async_=True)
+    for i in range(K):
+        ring[i][0][:] = hb[i % len(hb)]  # (producing the requests is the server's work, not the engine's)
+    for i in range(K):
+        feed(i)
+    eng2.wait_batches(0)
+    t0 = time.perf_counter()
+    for i in range(NA):
+        feed(i)
+    eng2.wait_batches(0)
+    also[f"{other}_stream_host_buffers_pinned_async_pcie_inclusive"] = {
+        "value": NA * a.batch / (time.perf_counter() - t0), "unit": "decisions/s",
+        "note": f"TC_B_ASYNC, ring of {K} pinned buffer sets (slots in, decisions out over PCIe every batch)"}
+    del ring
+    return also
+
+
 def main():
     a = parse()
     import torch
@@ -267,164 +448,45 @@ def main():
         local = 0
     dev = torch.device(f"cuda:{local}")
 
-    eng = t.Engine(a.keys, a.batch, device=local)
-    eng.use_torch_stream()
-    eng.register_params_uniform(*W.REF_PARAMS)
-
     # per-rank request stream over this rank's shard of the key space (slots are shard-local ids)
-    nb = a.steps + a.warmup
-    host_batches = make_batches(a.workload, a.keys, a.batch, min(nb, 64), seed_shift=100 * rank)
-    d_batches = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in host_batches]
-    out = t.BatchResult()
-
-    cnt_view = gathered = None
-    if dist is not None:
-        from throttlecrab_amd.sharded import device_counter_view
-        cnt_view = device_counter_view(eng)
-        gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
-
-    dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered)
-    decisions = a.steps * a.batch * world
-    value = decisions / dt
-    counters = eng.counters()
-
+    main_res, eng, d_batches, dt = measure_stream(a, t, W, a.workload, dev, local, rank, 100 * rank, dist, world)
     result = {
-        "metric": "GCRA decisions/sec, 10M keys", "value": value, "unit": "decisions/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * dt / a.steps,
+        "metric": "GCRA decisions/sec, 10M keys", "value": main_res["value"], "unit": "decisions/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
         "data": "synthetic",
         "config": {"workload": f"configs[{1 if a.workload == 'uniform' else 2}]: {a.keys} pre-hashed keys SoA per GPU, "
                                f"{a.workload} request stream, batch={a.batch}, params (100,1000/3600s), q=1",
                    "keys_per_gpu": a.keys, "batch": a.batch, "stream": a.workload,
+                   "resident_state": ("TC_CFG_FIXED_PARAMS: TAT column, 8 B per key + the plan dictionary (emission interval, "
+                                      "tolerance, burst capacity per plan)" if a.layout == "fixed" else
+                                      "{tat, expiry} cell, 16 B per key + plan id column + the plan dictionary"),
                    "parallelism": f"hash-shard x{world}", "outputs": "allowed u8 (decisions only)",
                    "pipelining": "TC_B_INPUTS_READY: batch k+1.. grouped on auxiliary streams while batch k is evaluated",
                    "metrics_allgather_every": METRICS_EVERY if world > 1 else None},
-        "allowed_fraction": counters["allowed"] / max(1, counters["total"]),
+        "allowed_fraction": main_res["allowed_fraction"],
     }
+    if "roofline" in main_res:
+        result["roofline"] = main_res["roofline"]
 
     if rank == 0:
-        # Roofline of the dominant kernel: a HIP event pair around every launch, on the stream it
-        # runs on.  `roofline` is the kernel's duration with the batches issued strictly in order on
-        # one stream -- the duration rocprofv3 --kernel-trace reports for it (the tracer serialises
-        # dispatches; profiles/).  `pipelined` is the same measurement over steps issued exactly like
-        # the timed region (grouping of later batches overlaps the evaluation of earlier ones on the
-        # auxiliary streams), i.e. including the contention the overlap causes.
-        piped = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True)
-        piped_stages = {k: v[0] / max(1, v[1]) for k, v in piped.items() if v[1]}
-        prof = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False)
-        stages = {k: v[0] / max(1, v[1]) for k, v in prof.items() if v[1]}
-        dom = max(stages, key=stages.get)
-        alg_bytes = ALG_BYTES_PER_DECISION * a.batch
-        ach = alg_bytes / (stages[dom] * 1e-3) / 1e9
-        ach_p = alg_bytes / (piped_stages[dom] * 1e-3) / 1e9
-        result["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": ach / HBM_PEAK_GBS, "traffic": pmc_traffic(dom), "kernel": KERNEL_OF_STAGE[dom],
-                              "avg_ms": stages[dom], "stage_ms": stages,
-                              "pipelined": {"avg_ms": piped_stages[dom], "achieved": ach_p,
-                                            "frac": ach_p / HBM_PEAK_GBS, "stage_ms": piped_stages},
-                              "whole_batch_GBs": alg_bytes * a.steps / dt / 1e9}
-        if not a.no_also and world == 1:
-            also = {}
+        if not a.no_also and world == 1 and not a.profile_run:
             other = "zipf" if a.workload == "uniform" else "uniform"
-            ob = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in make_batches(other, a.keys, a.batch, min(nb, 32))]
-            eng2 = t.Engine(a.keys, a.batch, device=local)
-            eng2.use_torch_stream()
-            eng2.register_params_uniform(*W.REF_PARAMS)
-            dt2, _ = run_gpu(eng2, ob, out, W.T0_NS, a.steps, a.warmup, None, None, None)
-            c2 = eng2.counters()
-            also[f"{other}_stream"] = {"value": a.steps * a.batch / dt2, "unit": "decisions/s",
-                                       "allowed_fraction": c2["allowed"] / max(1, c2["total"])}
-            full = t.BatchResult()
-            dt3, _ = run_gpu(eng2, ob, full, W.T0_NS + 10**9, a.steps, 2, None, None, None,
-                             want=t.Engine.ALL_FIELDS)
-            also[f"{other}_stream_full_result"] = {"value": a.steps * a.batch / dt3, "unit": "decisions/s"}
-            rec = t.BatchResult()
-            dt4, _ = run_gpu(eng2, ob, rec, W.T0_NS + 3 * 10**9, a.steps, 2, None, None, None,
-                             want=t.Engine.RECORD_FIELDS)
-            also[f"{other}_stream_full_result_records"] = {"value": a.steps * a.batch / dt4, "unit": "decisions/s",
-                                                          "note": "result4: one 32-byte RateLimitResult record per request"}
-            dec = t.BatchResult()
-            dt5, _ = run_gpu(eng2, ob, dec, W.T0_NS + 3 * 10**9 + 10**8, a.steps, 2, None, None, None,
-                             want=t.Engine.DECISION_FIELDS)
-            also[f"{other}_stream_full_result_decision_records"] = {
-                "value": a.steps * a.batch / dt5, "unit": "decisions/s",
-                "note": "tc_decision: remaining, reset_after, retry_after, allowed, status in one 32-byte record"}
-            # grouped output (TC_B_GROUPED_OUTPUT): rows in evaluation order + the request index of each row
-            grp = t.BatchResult()
-            d_main = d_batches
-            for label, streams, want in ((f"{a.workload}_stream_grouped_output", d_main, ("allowed",)),
-                                         (f"{a.workload}_stream_grouped_decision_records", d_main, t.Engine.DECISION_FIELDS)):
-                for i in range(a.warmup):
-                    eng2.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=W.T0_NS + 5 * 10**9 + i,
-                                                want=want, out=grp, inputs_ready=True, grouped=True)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(a.steps):
-                    eng2.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1,
-                                                now_ns=W.T0_NS + 5 * 10**9 + 10**6 * (i + 1), want=want, out=grp, inputs_ready=True,
-                                                grouped=True)
-                torch.cuda.synchronize()
-                also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s",
-                               "note": "output rows in the engine's evaluation order + order[] (request index of each row)"}
-                grp = t.BatchResult()
-            # general batches: every request carries its own timestamp (strictly increasing inside
-            # the batch), so the closed form does not apply and k_eval_general runs
-            nows = [torch.arange(a.batch, dtype=torch.int64, device=dev) + (W.T0_NS + 4 * 10**9 + b * 10**6)
-                    for b in range(a.warmup + a.steps)]
-            gout = t.BatchResult()
-            for label, streams in ((f"{other}_stream_per_request_timestamps", ob), (f"{a.workload}_stream_per_request_timestamps", d_batches)):
-                eng3 = t.Engine(a.keys, a.batch, device=local)
-                eng3.use_torch_stream()
-                eng3.register_params_uniform(*W.REF_PARAMS)
-                for i in range(a.warmup):
-                    eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
-                                                want=("allowed",), out=gout, inputs_ready=True)
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for i in range(a.warmup, a.warmup + a.steps):
-                    eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
-                                                want=("allowed",), out=gout, inputs_ready=True)
-                torch.cuda.synchronize()
-                also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s"}
-                eng3.close()
-            # PCIe-inclusive rate: the same stream handed over as HOST buffers (never `value`)
-            hb = make_batches(other, a.keys, a.batch, 8)
-            hout = t.BatchResult()
-            for i in range(2):
-                eng2.rate_limit_batch_slots(hb[i], registered=True, quantity=1, now_ns=W.T0_NS + 2 * 10**9, want=("allowed",), out=hout)
-            t0 = time.perf_counter()
-            for i in range(8):
-                eng2.rate_limit_batch_slots(hb[i], registered=True, quantity=1, now_ns=W.T0_NS + 2 * 10**9 + i, want=("allowed",), out=hout)
-            also[f"{other}_stream_host_buffers_pcie_inclusive"] = {"value": 8 * a.batch / (time.perf_counter() - t0),
-                                                                  "unit": "decisions/s"}
-            # the same, as a server would feed it: TC_B_ASYNC batches from a ring of pinned buffers, so the PCIe
-            # transfers of one batch overlap the evaluation of others (never `value` either)
-            K, NA = 4, 48
-            ring = [(eng2.host_alloc(a.batch, np.uint32), t.BatchResult(allowed=eng2.host_alloc(a.batch, np.uint8))) for _ in range(K)]
-
-            def feed(i):
-                if i >= K:
-                    eng2.wait_batches(K - 1)   # the oldest set's results are in: a server would answer them here
-                sl, ob = ring[i % K]
-                eng2.rate_limit_batch_slots(sl, registered=True, quantity=1, now_ns=W.T0_NS + 3 * 10**9 + i, want=("allowed",),
-                                            out=ob, async_=True)
-            for i in range(K):
-                ring[i][0][:] = hb[i % len(hb)]  # (producing the requests is the server's work, not the engine's)
-            for i in range(K):
-                feed(i)
-            eng2.wait_batches(0)
-            t0 = time.perf_counter()
-            for i in range(NA):
-                feed(i)
-            eng2.wait_batches(0)
-            also[f"{other}_stream_host_buffers_pinned_async_pcie_inclusive"] = {
-                "value": NA * a.batch / (time.perf_counter() - t0), "unit": "decisions/s",
-                "note": f"TC_B_ASYNC, ring of {K} pinned buffer sets (slots in, decisions out over PCIe every batch)"}
-            del ring
+            # the other BASELINE stream (configs[2]: Zipf s = 1.1, north_star's target stream), measured the same way
+            o_res, eng2, ob, _ = measure_stream(a, t, W, other, dev, local, 0, 0, None, 1)
+            o_res["config"] = f"configs[{2 if other == 'zipf' else 1}]: same engine shape, {other} request stream"
+            result[f"{other}_stream"] = o_res
+            # the headline stream on the other resident-state layout
+            a2 = argparse.Namespace(**vars(a))
+            a2.layout = "fixed" if a.layout == "wide" else "wide"
+            l_res, eng_l, _, _ = measure_stream(a2, t, W, a.workload, dev, local, 0, 0, None, 1)
+            eng_l.close()
+            l_res.pop("roofline", None)
+            result[f"{a.workload}_stream_{a2.layout}_layout"] = l_res
+            result["also"] = secondary(a, t, W, eng2, ob, d_batches, dev, local, other)
             eng2.close()
-            also["string_keys_config4"] = keys_bench(a, dev)
-            result["also"] = also
-        if not a.no_cpu:
+            result["also"]["string_keys_config4"] = keys_bench(a, dev)
+        if not a.no_cpu and not a.profile_run:
             result["cpu_baseline"] = cpu_baseline(a.workload, a.keys, a.batch, a.cpu_sample_batches)
         print(json.dumps(result))
     if dist is not None:

@@ -70,6 +70,19 @@ enum {
 #define TC_CFG_TRACK_DENIED 0x2u /* keep a denial counter per key (4 B/slot) for tc_top_denied: the device-side
                                   * TopDeniedKeys of throttlecrab-server/src/metrics.rs:24-76 */
 
+#define TC_CFG_FIXED_PARAMS 0x4u /* 8-byte resident state: one TAT per key instead of the 16-byte {tat, expiry} cell (half the
+                                  * table, twice the keys per memory line).  Sound while a key's (burst, count, period)
+                                  * never change -- then every write leaves expiry == tat + dvt (rate_limiter.rs:179-183,
+                                  * adaptive_cleanup.rs:237) and the expiry column is redundant.  Hence, in this mode:
+                                  *  - plans are registered BEFORE the first request (tc_register_params*; later calls
+                                  *    return TC_E_UNSUPPORTED) and every batch carries TC_B_REGISTERED_PARAMS;
+                                  *  - a plan needs burst >= 2 after the reference's `as u32` truncation and an emission
+                                  *    interval / tolerance below 2^60 ns (else TC_E_UNSUPPORTED at registration);
+                                  *  - timestamps >= 2^62 ns (year 2116) get TC_INTERNAL;
+                                  *  - tc_rate_limit, the tc_store_* operations (free ttl) and TC_CFG_KEY_MODE (string
+                                  *    keys carry their rate with every request) return TC_E_UNSUPPORTED.
+                                  * Results and tc_read_state are bit-identical to the 16-byte layout otherwise. */
+
 typedef struct tc_config {
     uint32_t struct_size;     /* = sizeof(tc_config) */
     uint32_t flags;           /* TC_CFG_* */

@@ -326,18 +326,6 @@ __device__ __forceinline__ void wave_count3(uint32_t a, uint32_t b, uint32_t c, 
     }
 }
 
-// resident state of a slot as loaded, in either layout (FIXED: 8-byte TAT column, see tc::fixed_cell)
-template <bool FIXED>
-__device__ __forceinline__ Cell load_raw(const Params& p, uint32_t slot) {
-    if (FIXED) {
-        Cell c;
-        c.tat = p.tat8[slot];
-        c.expiry = 0;
-        return c;
-    }
-    return tc::load_cell(&p.cells[slot]);
-}
-
 struct Tally {
     uint32_t na, nd, ne;
 };
@@ -450,8 +438,7 @@ __device__ __forceinline__ void eval_step(const Params& p, const Req& rq0, uint3
         }
         parked += (uint32_t)__popcll(wm);
     } else if (writer) {
-        if (FIXED) p.tat8[slot] = wcell.tat;
-        else tc::store_cell(&p.cells[slot], wcell);
+        ev::store_state<FIXED>(p, slot, wcell);
     }
 }
 
@@ -485,7 +472,7 @@ __device__ __forceinline__ void bucket_in_registers(const Params& p, const Req& 
         const uint32_t slot = (bucket << lb) | (e[j] >> IDX_BITS);
         raw[j].tat = 0;
         raw[j].expiry = 0;
-        if (valid[j] && slot < p.capacity) raw[j] = load_raw<FIXED>(p, slot);
+        if (valid[j] && slot < p.capacity) raw[j] = ev::load_raw<FIXED>(p, slot);
     }
     // pass A: requests per slot (order does not matter: LDS atomics, nothing waits)
 #pragma unroll
@@ -579,7 +566,7 @@ __global__ __launch_bounds__(64) void k_bucket_eval(Params p, Work w, PendEntry*
                 raw[j].expiry = 0;
                 if (BYSLOT) rc[BYSLOT ? j : 0] = rc_batch;
                 if (valid[j] && slot < p.capacity) {
-                    raw[j] = load_raw<FIXED>(p, slot);
+                    raw[j] = ev::load_raw<FIXED>(p, slot);
                     if (BYSLOT) rc[BYSLOT ? j : 0] = p.classes[p.rate_id[slot]];
                 }
             }
@@ -594,8 +581,7 @@ __global__ __launch_bounds__(64) void k_bucket_eval(Params p, Work w, PendEntry*
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         for (uint32_t i = lane; i < parked; i += 64) {
             const PendEntry pe = mine[i];
-            if (FIXED) p.tat8[pe.slot] = pe.cell.tat;
-            else tc::store_cell(&p.cells[pe.slot], pe.cell);
+            ev::store_state<FIXED>(p, pe.slot, pe.cell);
         }
     }
     wave_count3(t.na, t.nd, t.ne, p.counters);

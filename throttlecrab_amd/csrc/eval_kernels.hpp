@@ -141,6 +141,34 @@ __device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req
     }
 }
 
+// The resident state of `slot` under either layout.  TC_CFG_FIXED_PARAMS engines keep one TAT per key
+// (p.tat8, p.cells == nullptr; tc::fixed_cell rebuilds the expiry from the key's dvt); the raw load does
+// not need the rate yet, so it can be issued before the plan is known.
+template <bool FIXED>
+__device__ __forceinline__ Cell load_raw(const Params& p, uint32_t slot) {
+    if (FIXED) {
+        Cell c;
+        c.tat = p.tat8[slot];
+        c.expiry = 0;
+        return c;
+    }
+    return tc::load_cell(&p.cells[slot]);
+}
+template <bool FIXED>
+__device__ __forceinline__ void store_state(const Params& p, uint32_t slot, const Cell& c) {
+    if (FIXED) p.tat8[slot] = c.tat;
+    else tc::store_cell(&p.cells[slot], c);
+}
+// the same with the layout looked up at run time (wave-uniform branch): the kernels that are not hot
+__device__ __forceinline__ Cell load_state_rt(const Params& p, uint32_t slot, int64_t dvt) {
+    if (p.tat8) return tc::fixed_cell(p.tat8[slot], dvt);
+    return tc::load_cell(&p.cells[slot]);
+}
+__device__ __forceinline__ void store_state_rt(const Params& p, uint32_t slot, const Cell& c) {
+    if (p.tat8) p.tat8[slot] = c.tat;
+    else tc::store_cell(&p.cells[slot], c);
+}
+
 // Decision counters are accumulated in NSHARD shards (block b -> shard b % NSHARD):
 // a device-scope atomic on ONE address costs ~12 ns and serialises, so 4096
 // blocks hitting one counter would add ~50 us to a 1 Mi-request batch.
@@ -202,18 +230,14 @@ __global__ __launch_bounds__(BLOCK) void k_eval_unique(Params p) {
     uint32_t na = 0, nd = 0, ne = 0;
     if (i < p.n) {
         const uint32_t slot = p.slot[i];
-        Cell cell;
-        cell.tat = 0;
-        cell.expiry = 0;
-        if (slot < p.capacity) cell = tc::load_cell(&p.cells[slot]);
         const Req r = make_req(p, i, slot);
         Decision d;
         d.allowed = false;
         d.remaining = d.reset_after = d.retry_after = 0;
         if (r.status == tc::ST_OK) {
-            Cell c = cell;
+            Cell c = load_state_rt(p, slot, r.dvt);
             d = tc::gcra_step<FULL>(c, r.ei, r.dvt, r.q, r.now);
-            if (d.allowed) tc::store_cell(&p.cells[slot], c);
+            if (d.allowed) store_state_rt(p, slot, c);
             na = d.allowed;
             nd = !d.allowed;
             if (p.denied && nd) atomicAdd(&p.denied[slot], 1u); // unique slots: no contention
@@ -349,7 +373,8 @@ __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t
             c.tat = 0;
             c.expiry = 0;
             const bool has_cell = my_slot < p.capacity;
-            if (has_cell) c = tc::load_cell(&p.cells[my_slot]);
+            // (the 8-byte layout only takes registered plans: every request of the key has the first one's dvt)
+            if (has_cell) c = load_state_rt(p, my_slot, make_req(p, (uint32_t)me, my_slot).dvt);
             bool dirty = false;
             uint32_t run_denied = 0;
             for (uint32_t k = i; k < n; ++k) {
@@ -371,7 +396,7 @@ __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t
                 }
                 write_out(p, idx, rq, d);
             }
-            if (dirty) tc::store_cell(&p.cells[my_slot], c);
+            if (dirty) store_state_rt(p, my_slot, c);
             if (p.denied && run_denied) atomicAdd(&p.denied[my_slot], run_denied);
         }
     }
@@ -415,7 +440,7 @@ struct __attribute__((aligned(16))) PendEntry {
 //     16-byte cells cost, not by latency), record outputs gain 15 % at ITEMS = 4 in order, the Zipf stream
 //     7 % at ITEMS = 2 when overlapped with the next batch's sort.
 // ---------------------------------------------------------------------------
-template <bool FULL, bool DIRECT, int ITEMS>
+template <bool FULL, bool DIRECT, int ITEMS, bool FIXED>
 __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
                                                              PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
                                                              uint32_t* __restrict__ loaded, uint32_t seq,
@@ -461,9 +486,9 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
     }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        cell[j] = tc::load_cell(&p.cells[has_cell[j] ? (uint32_t)(me[j] >> 32) : 0u]);
+        cell[j] = load_raw<FIXED>(p, has_cell[j] ? (uint32_t)(me[j] >> 32) : 0u);
         if (!has_cell[j]) {
-            cell[j].tat = 0;
+            cell[j].tat = FIXED ? tc::TAT_VACANT : 0;
             cell[j].expiry = 0;
         }
     }
@@ -546,7 +571,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
             write_out(p, orow, rq, d);
             continue;
         }
-        Cell c = cell[j];
+        Cell c = FIXED ? tc::fixed_cell(cell[j].tat, rq.dvt) : cell[j];
         const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
         if (!d0.allowed) {
             // request 0 denied => state untouched => every request of the run equals request 0
@@ -627,7 +652,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                         __builtin_amdgcn_s_sleep(1);
                 }
             }
-            if (writer[j]) tc::store_cell(&p.cells[slot], wcell[j]);
+            if (writer[j]) store_state<FIXED>(p, slot, wcell[j]);
         } else {
             // does my whole run live inside this row?  (ballots taken by the full wave)
             const unsigned long long heads = __ballot(head[j]), lasts = __ballot(is_last[j]);
@@ -635,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
             const bool seg_in_row = ((heads & upto) != 0ull) && ((lasts >> lane) != 0ull);
             if (!writer[j]) {
             } else if (seg_in_row) {
-                tc::store_cell(&p.cells[slot], wcell[j]);
+                store_state<FIXED>(p, slot, wcell[j]);
             } else {
                 const uint32_t at = atomicAdd(pend_count, 1u);
                 PendEntry pe;
@@ -721,7 +746,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     c.tat = 0;
     c.expiry = 0;
     bool dirty = false;
-    if (valid && slot < p.capacity) c = tc::load_cell(&p.cells[slot]); // continued lanes: c0, the guess
+    if (valid && slot < p.capacity) c = load_state_rt(p, slot, r.dvt); // continued lanes: c0, the guess
     if (__ballot(continued) != 0ull) { // wave-uniform: lane 0 is continued
         bool spec_allow = false;
         if (continued && ok) {
@@ -853,7 +878,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         const Cell out = was_allowed ? mine : c;
         const bool out_dirty = dirty || was_allowed;
         if (is_last) {
-            if (out_dirty && slot < p.capacity) tc::store_cell(&p.cells[slot], out);
+            if (out_dirty && slot < p.capacity) store_state_rt(p, slot, out);
         } else {
             ChainRec* o = &chain[gw];
             __hip_atomic_store(&o->tat, (unsigned long long)out.tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -871,12 +896,14 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
 }
 
 __global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restrict__ pend,
-                                                       uint32_t* __restrict__ pend_count, Cell* __restrict__ cells) {
+                                                       uint32_t* __restrict__ pend_count, Cell* __restrict__ cells,
+                                                       int64_t* __restrict__ tat8) {
     // pend_count[0] = entries, pend_count[1] = blocks of this launch that are done
     const uint32_t cnt = pend_count[0];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < cnt; i += gridDim.x * BLOCK) {
         const PendEntry pe = pend[i];
-        tc::store_cell(&cells[pe.slot], pe.cell);
+        if (tat8) tat8[pe.slot] = pe.cell.tat;
+        else tc::store_cell(&cells[pe.slot], pe.cell);
     }
     __syncthreads(); // every lane of this block has consumed `cnt`
     if (threadIdx.x == 0) {

@@ -59,6 +59,48 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint6
     }
 }
 
+// TC_CFG_FIXED_PARAMS layout: expiry == tat + dvt of the key's plan (tc::fixed_cell); vacant == TAT_VACANT
+__global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restrict__ tat8, const uint16_t* __restrict__ rate_id,
+                                                       const tc::RateClass* __restrict__ classes, uint32_t uniform_class, uint64_t capacity,
+                                                       int64_t now, unsigned long long* counters, unsigned long long* removed_out) {
+    uint32_t removed = 0, live = 0;
+    const int64_t dvt_all = classes[uniform_class].dvt;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
+        const int64_t t = tat8[i];
+        if (t != tc::TAT_VACANT) {
+            const int64_t dvt = uniform_class ? dvt_all : classes[rate_id[i]].dvt;
+            if (!(tc::fixed_cell(t, dvt).expiry > (uint64_t)now)) { // retain(|exp| *exp > now)
+                tat8[i] = tc::TAT_VACANT;
+                removed++;
+            } else {
+                live++;
+            }
+        }
+    }
+    __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
+    for (int off = 32; off > 0; off >>= 1) {
+        removed += __shfl_down(removed, off, 64);
+        live += __shfl_down(live, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_r[threadIdx.x >> 6] = removed;
+        s_l[threadIdx.x >> 6] = live;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t r = 0, l = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            r += s_r[w];
+            l += s_l[w];
+        }
+        if (r) {
+            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)r);
+            atomicAdd(removed_out, (unsigned long long)r);
+        }
+        if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
+    }
+}
+
 // Key-mode sweep: same retain rule, and an expired (or never written) bound slot
 // also loses its key: tombstone in the hash table, slot back on the free stack.
 // Every block owns a contiguous range of slots, collects the slots it unbinds in
@@ -185,6 +227,10 @@ __global__ __launch_bounds__(BLOCK) void k_gather_keyrecs(kt::Table t, const uin
     r.pos = 0;
     if (s < t.capacity && t.bound[s]) r = t.rec[s];
     out[i] = r;
+}
+
+__global__ __launch_bounds__(BLOCK) void k_fill_i64(int64_t* __restrict__ a, uint64_t n, int64_t v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) a[i] = v;
 }
 
 __global__ __launch_bounds__(BLOCK) void k_fill_rate_id(uint16_t* __restrict__ rate_id, uint64_t capacity, uint16_t id) {

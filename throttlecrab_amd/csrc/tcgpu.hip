@@ -88,6 +88,9 @@ struct tc_engine {
     uint32_t cfg_flags = 0;
 
     Cell* cells = nullptr;
+    int64_t* tat8 = nullptr;                 // TC_CFG_FIXED_PARAMS: one TAT per key instead of cells (gcra_math.hpp)
+    bool fixed = false;
+    bool sealed = false;                     // fixed layout: a request has been decided, the plans can no longer change
     uint16_t* rate_id = nullptr;
     RateClass* classes = nullptr;            // device, MAX_CLASSES entries, [0] = all zero
     std::vector<RateClass> host_classes;     // host mirror, index = class id
@@ -256,7 +259,9 @@ static size_t sort_ws_words(uint32_t max_tiles) { return rs::workspace_words(max
 static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipSetDevice(e->device));
     const uint64_t cap = e->capacity, mb = e->max_batch;
-    TC_HIP(e, hipMalloc(&e->cells, cap * sizeof(Cell)));
+    e->fixed = (e->cfg_flags & TC_CFG_FIXED_PARAMS) != 0;
+    if (e->fixed) TC_HIP(e, hipMalloc(&e->tat8, cap * sizeof(int64_t)));
+    else TC_HIP(e, hipMalloc(&e->cells, cap * sizeof(Cell)));
     TC_HIP(e, hipMalloc(&e->rate_id, cap * sizeof(uint16_t)));
     TC_HIP(e, hipMalloc(&e->classes, (size_t)MAX_CLASSES * sizeof(RateClass)));
     e->host_classes.assign(1, RateClass{0, 0, 0, 0});
@@ -267,7 +272,8 @@ static int engine_alloc(tc_engine* e) {
     }
     const size_t cnt_words = (TC_CNT_COUNT + 1) + (size_t)NSHARD * SHARD_WORDS;
     TC_HIP(e, hipMalloc(&e->counters, cnt_words * sizeof(unsigned long long)));
-    TC_HIP(e, hipMemsetAsync(e->cells, 0, cap * sizeof(Cell), (hipStream_t)0));
+    if (e->fixed) hipLaunchKernelGGL(k_fill_i64, dim3(std::min<uint64_t>(nblocks(cap), 4096)), dim3(BLOCK), 0, (hipStream_t)0, e->tat8, cap, tc::TAT_VACANT);
+    else TC_HIP(e, hipMemsetAsync(e->cells, 0, cap * sizeof(Cell), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(e->rate_id, 0, cap * sizeof(uint16_t), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(e->classes, 0, (size_t)MAX_CLASSES * sizeof(RateClass), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), (hipStream_t)0));
@@ -546,6 +552,10 @@ extern "C" tc_engine* tc_engine_create(const tc_config* cfg, int* err) {
         *err = TC_E_NO_DEVICE;
         return nullptr;
     }
+    if ((cfg->flags & TC_CFG_FIXED_PARAMS) && (cfg->flags & TC_CFG_KEY_MODE)) {
+        *err = TC_E_UNSUPPORTED; // string keys carry their rate with every request: nothing is fixed
+        return nullptr;
+    }
     tc_engine* e = new (std::nothrow) tc_engine();
     if (!e) {
         *err = TC_E_NOMEM;
@@ -583,7 +593,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->bp_park, e->cells, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
+    void* ptrs[] = {e->bp_park, e->cells, e->tat8, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};
@@ -663,6 +673,11 @@ extern "C" int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64
     const int id = intern_class(e, max_burst, count_per_period, period, &grew);
     if (id == 0) return fail(e, TC_E_INVALID_ARG, "tc_register_params_uniform: invalid (burst,count,period)");
     if (id < 0) return fail(e, TC_E_UNSUPPORTED, "more than 65535 distinct rate plans registered");
+    if (e->fixed) {
+        if (e->sealed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: plans cannot change once a request has been decided");
+        const RateClass& rc = e->host_classes[id];
+        if (!tc::fixed_plan_ok(rc.ei, rc.dvt)) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: the plan needs burst >= 2 and an emission interval / tolerance below 2^60 ns");
+    }
     TC_HIP(e, hipSetDevice(e->device));
     if (grew) {
         int rc = upload_classes(e);
@@ -682,11 +697,14 @@ extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slot
     if (n == 0) return TC_E_OK;
     if (!slots && n > e->capacity) return fail(e, TC_E_INVALID_ARG, "tc_register_params: n > capacity");
     // validate everything before touching the dictionary or the device
+    if (e->fixed && e->sealed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: plans cannot change once a request has been decided");
     for (uint64_t i = 0; i < n; ++i) {
         if (slots && slots[i] >= e->capacity) return fail(e, TC_E_INVALID_ARG, "tc_register_params: slot out of range");
         int64_t ei, dvt;
         if (tc::derive_rate(max_burst[i], count_per_period[i], period[i], ei, dvt) != tc::ST_OK)
             return fail(e, TC_E_INVALID_ARG, "tc_register_params: invalid (burst,count,period)");
+        if (e->fixed && !tc::fixed_plan_ok(ei, dvt))
+            return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: every plan needs burst >= 2 and an emission interval / tolerance below 2^60 ns");
     }
     std::vector<uint16_t> ids(n);
     bool grew = false;
@@ -891,21 +909,29 @@ static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params
 
 // k_eval_sorted<.., ITEMS>: 2 positions per lane when the batch overlaps with its neighbours' sorts,
 // 4 when it runs alone (measured; 8 is slower everywhere; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
-template <int ITEMS>
+template <int ITEMS, bool FIXED>
 static void launch_eval_items(tc_engine* e, bool full, bool direct, uint32_t n, hipStream_t s, const Params& p, const uint64_t* sorted,
                               uint32_t seq, const uint32_t* gate, uint32_t gate_min) {
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
-    if (full && direct) hipLaunchKernelGGL((k_eval_sorted<true, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else if (full) hipLaunchKernelGGL((k_eval_sorted<true, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else if (direct) hipLaunchKernelGGL((k_eval_sorted<false, true, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else hipLaunchKernelGGL((k_eval_sorted<false, false, ITEMS>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    if (full && direct) hipLaunchKernelGGL((k_eval_sorted<true, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (full) hipLaunchKernelGGL((k_eval_sorted<true, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (direct) hipLaunchKernelGGL((k_eval_sorted<false, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else hipLaunchKernelGGL((k_eval_sorted<false, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
 }
 static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped, uint32_t n, hipStream_t s, const Params& p,
                                const uint64_t* sorted, uint32_t seq, const uint32_t* gate = nullptr, uint32_t gate_min = 0) {
-    switch (e->eval_items ? e->eval_items : (piped ? 2 : 4)) {
-    case 1: launch_eval_items<1>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
-    case 2: launch_eval_items<2>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
-    default: launch_eval_items<4>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+    const int items = e->eval_items ? e->eval_items : (piped ? 2 : 4);
+    if (e->fixed) {
+        switch (items) {
+        case 1: launch_eval_items<1, true>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+        case 2: launch_eval_items<2, true>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+        default: launch_eval_items<4, true>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+        }
+    }
+    switch (items) {
+    case 1: launch_eval_items<1, false>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+    case 2: launch_eval_items<2, false>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+    default: launch_eval_items<4, false>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
     }
 }
 
@@ -1001,7 +1027,8 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
     p.decisions = b.decisions;
     p.order = (b.flags & TC_B_GROUPED_OUTPUT) ? b.order : nullptr;
     p.cells = e->cells;
-    p.tat8 = nullptr;
+    p.tat8 = e->tat8;
+    if (e->fixed) p.flags |= F_FIXED;
     p.rate_id = e->rate_id;
     p.classes = e->classes;
     p.uniform_class = e->uniform_id;
@@ -1092,7 +1119,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             prof_end(e, s);
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
-                hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells);
+                hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells, e->tat8);
                 prof_end(e, s);
             }
         } else {
@@ -1261,6 +1288,8 @@ static int run_small_batch(tc_engine* e, const tc_batch& b) {
     p.decisions = (tc_decision*)out_col(b.decisions, n * sizeof(tc_decision));
     if (off > e->small_io_bytes) return fail(e, TC_E_INVALID_ARG, "small batch does not fit its staging block");
     p.cells = e->cells;
+    p.tat8 = e->tat8;
+    if (e->fixed) p.flags |= F_FIXED;
     p.rate_id = e->rate_id;
     p.classes = e->classes;
     p.uniform_class = e->uniform_id;
@@ -1305,6 +1334,11 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     if (!b.slot) return fail(e, TC_E_INVALID_ARG, "slot column is NULL");
     if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
     if (e->key_mode) return fail(e, TC_E_INVALID_ARG, "key-mode engine: slots are assigned by the key table; use tc_rate_limit_batch_keys");
+    if (e->fixed) {
+        if (!(b.flags & TC_B_REGISTERED_PARAMS))
+            return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: batches use the registered plans (TC_B_REGISTERED_PARAMS)");
+        e->sealed = true;
+    }
     TC_HIP(e, hipSetDevice(e->device));
     if (b.flags & TC_B_DEVICE_PTRS) {
         if (b.flags & TC_B_ASYNC) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
@@ -1454,6 +1488,7 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
                              tc_result* out) {
     if (!e || !out || (!key && key_len)) return TC_E_INVALID_ARG;
     if (key_len > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "key too long");
+    if (e->fixed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: single calls carry their own rate; use a registered batch");
     TC_HIP(e, hipSetDevice(e->device));
     hipStream_t s = cur_stream(e);
     uint32_t slot = 0;
@@ -1536,6 +1571,9 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     if (e->key_mode)
         hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
                            e->cells, e->kt, now_ns, e->counters, scratch, e->denied);
+    else if (e->fixed)
+        hipLaunchKernelGGL(k_sweep_fixed, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s, e->tat8, e->rate_id,
+                           e->classes, (uint32_t)e->uniform_id, e->capacity, now_ns, e->counters, scratch);
     else
         hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
                            e->cells, e->capacity, now_ns, e->counters, scratch);
@@ -1637,6 +1675,7 @@ static int store_slot_of(tc_engine* e, const uint8_t* key, size_t key_len, bool 
 
 static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
                     StoreOpResult* r) {
+    if (e->fixed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: the 8-byte layout cannot hold a free ttl (Store operations need the 16-byte cell)");
     if (now < 0) return fail(e, TC_E_INVALID_ARG, "now_ns < 0");
     TC_HIP(e, hipSetDevice(e->device));
     hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, cur_stream(e), e->cells, slot, op, a, b, ttl, now, e->op_result);
@@ -1698,6 +1737,20 @@ extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* 
     if (!e || n > e->capacity || first > e->capacity - n) return TC_E_INVALID_ARG;
     if (n == 0) return TC_E_OK;
     TC_HIP(e, hipSetDevice(e->device));
+    if (e->fixed) { // expiry == tat + dvt of the key's plan (gcra_math.hpp: fixed_cell)
+        std::vector<int64_t> t(n);
+        std::vector<uint16_t> id(n);
+        TC_HIP(e, hipMemcpyAsync(t.data(), e->tat8 + first, n * sizeof(int64_t), hipMemcpyDeviceToHost, cur_stream(e)));
+        TC_HIP(e, hipMemcpyAsync(id.data(), e->rate_id + first, n * sizeof(uint16_t), hipMemcpyDeviceToHost, cur_stream(e)));
+        TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+        for (uint64_t i = 0; i < n; ++i) {
+            const int64_t dvt = id[i] < e->host_classes.size() ? e->host_classes[id[i]].dvt : 0;
+            const Cell c = tc::fixed_cell(t[i], dvt);
+            if (tat) tat[i] = c.tat;
+            if (expiry) expiry[i] = c.expiry;
+        }
+        return TC_E_OK;
+    }
     std::vector<Cell> h(n);
     TC_HIP(e, hipMemcpyAsync(h.data(), e->cells + first, n * sizeof(Cell), hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
@@ -1862,7 +1915,8 @@ struct Section {
 };
 std::vector<Section> snapshot_sections(tc_engine* e) {
     std::vector<Section> v;
-    v.push_back({e->cells, e->capacity * sizeof(Cell)});
+    if (e->fixed) v.push_back({e->tat8, e->capacity * sizeof(int64_t)});
+    else v.push_back({e->cells, e->capacity * sizeof(Cell)});
     v.push_back({e->rate_id, e->capacity * sizeof(uint16_t)});
     if (e->denied) v.push_back({e->denied, e->capacity * sizeof(uint32_t)});
     if (e->key_mode) {
@@ -1906,6 +1960,7 @@ extern "C" int tc_snapshot_save(tc_engine* e, const char* path) {
     h.n_classes = e->host_classes.size();
     h.batches = e->batches;
     h.key_mode |= e->denied ? 2u : 0u;
+    h.key_mode |= e->fixed ? 4u : 0u;
     if (hipMemcpy(h.counters, e->counters, sizeof h.counters, hipMemcpyDeviceToHost) != hipSuccess) {
         fclose(f);
         return fail(e, TC_E_HIP, "tc_snapshot_save: counter copy failed");
@@ -1937,7 +1992,7 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     if (!f) return fail(e, TC_E_INVALID_ARG, "tc_snapshot_load: cannot open file");
     SnapHeader h;
     bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "TCGPUSN1", 8) == 0 && h.version == 1;
-    const uint32_t mode = (e->key_mode ? 1u : 0u) | (e->denied ? 2u : 0u);
+    const uint32_t mode = (e->key_mode ? 1u : 0u) | (e->denied ? 2u : 0u) | (e->fixed ? 4u : 0u);
     if (!ok || h.key_mode != mode || h.capacity != e->capacity || (e->key_mode && (h.nb != e->kt.nb_mask + 1 ||
                                                                                   h.overflow_bytes != e->kt.overflow_bytes)) ||
         h.n_classes == 0 || h.n_classes > MAX_CLASSES) {
@@ -1981,6 +2036,7 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     c[(TC_CNT_COUNT + 1) + 2] = h.counters[TC_CNT_ERRORS];
     TC_HIP(e, hipMemcpy(e->counters, c.data(), cnt_words * sizeof(unsigned long long), hipMemcpyHostToDevice));
     e->batches = h.batches;
+    e->sealed = true; // (fixed layout: the loaded state was written under the loaded plans)
     return TC_E_OK;
 }
 

@@ -73,11 +73,12 @@ class Engine:
                 "allowed": (d[:, 3] & 0xFF).astype(np.uint8), "status": ((d[:, 3] >> 8) & 0xFF).astype(np.uint8)}
 
     def __init__(self, capacity: int, max_batch: int = 1 << 20, device: int = 0, key_mode: bool = False,
-                 key_arena_bytes: int = 0, track_denied: bool = False):
+                 key_arena_bytes: int = 0, track_denied: bool = False, fixed_params: bool = False):
         self._lib = L.load()
         cfg = L.tc_config()
         cfg.struct_size = C.sizeof(L.tc_config)
-        cfg.flags = (L.TC_CFG_KEY_MODE if key_mode else 0) | (L.TC_CFG_TRACK_DENIED if track_denied else 0)
+        cfg.flags = ((L.TC_CFG_KEY_MODE if key_mode else 0) | (L.TC_CFG_TRACK_DENIED if track_denied else 0) |
+                     (L.TC_CFG_FIXED_PARAMS if fixed_params else 0))
         cfg.device_id = device
         cfg.capacity = capacity
         cfg.max_batch = max_batch

@@ -2,7 +2,7 @@
 """Condense rocprofv3 output (rocpd .db files under gpurun_out/<dir>) into small text /
 json summaries under profiles/.
 
-usage: summarize_prof.py <tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir>]
+usage: summarize_prof.py <tag> <stats_dir> [<pmc_fetch_dir> <pmc_write_dir> [<command profiled>]]
 
 <stats_dir> comes from `rocprofv3 --kernel-trace --stats`, the PMC dirs from separate
 `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of the same command."""
@@ -70,7 +70,12 @@ def main():
             fa, wa = sum(fs) / len(fs), sum(ws) / len(ws)
             out.append(f"{short(k):96s} {len(fs):5d} {fa:12.1f} {wa:12.1f} {(2*fa+wa)/1024:13.2f}")
             pm[short(k)] = {"FETCH_SIZE_KB": fa, "WRITE_SIZE_KB": wa, "launches": len(fs)}
-        json.dump({"tag": tag, "note": "raw rocprofv3 PMC values per dispatch; gfx950 FETCH_SIZE tallies a 128-B "
+        import subprocess
+        try:
+            sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+        except OSError:
+            sha = None
+        json.dump({"tag": tag, "git_sha": sha, "command": sys.argv[5] if len(sys.argv) > 5 else None, "note": "raw rocprofv3 PMC values per dispatch; gfx950 FETCH_SIZE tallies a 128-B "
                                        "request as 64 B (MI355X_MICROARCH.md HBM section): hbm_read = 2 x FETCH_SIZE",
                    "kernels": pm, "kernel_stats": stats},
                   open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
