@@ -61,9 +61,10 @@ struct Table {
     uint64_t nb_mask;
     KeyRec* rec;
     uint8_t* bound;
-    uint8_t* overflow;
-    uint64_t overflow_bytes;
-    unsigned long long* overflow_used;
+    uint8_t* overflow;                 // two halves of overflow_bytes each: keys live in half *overflow_half,
+    uint64_t overflow_bytes;           // the sweep compacts them into the other one when the arena runs full
+    unsigned long long* overflow_used; // bytes handed out in the current half
+    uint32_t* overflow_half;           // 0 / 1
     uint32_t* free_slots;
     int* free_top;
     uint32_t* tombs;        // tombstones currently in ktab
@@ -127,7 +128,7 @@ __device__ __forceinline__ const uint8_t* stored_key(const Table& t, uint32_t sl
     if (len <= INLINE_KEY) return in;
     uint64_t off;
     __builtin_memcpy(&off, in, 8);
-    return t.overflow + off;
+    return t.overflow + (uint64_t)*t.overflow_half * t.overflow_bytes + off;
 }
 
 __device__ __forceinline__ bool bytes_equal(const uint8_t* a, const uint8_t* b, uint32_t len) {
@@ -208,57 +209,79 @@ __device__ __forceinline__ uint32_t probe_request(const Table& t, const uint8_t*
     uint64_t k0, k1;
     h = load_and_hash(key_bytes, off, len, arena, k0, k1);
     const unsigned long long meta = entry_meta(h, len);
-    uint64_t pos = h & t.nb_mask;
     slot = NO_SLOT;
     ax = 0;
-    for (uint64_t probes = 0; probes <= t.nb_mask; ++probes) {
-        Entry* en = &t.ktab[pos];
-        // The whole 32-byte entry in one round trip, with plain loads: what they can show is either final
-        // for this kernel (bound entries and tombstones only change in other kernels; a pending entry keeps
-        // its claimant until it is bound) or "empty", which the compare-and-swap below settles.
-        const ulonglong2 lo = *reinterpret_cast<const ulonglong2*>(en);      // w, hash
-        const ulonglong2 hi = *(reinterpret_cast<const ulonglong2*>(en) + 1); // key[0], key[1]
-        unsigned long long e = lo.x;
-        if (e == 0ull) {
-            if (!INSERT) break;
-            const unsigned long long mine = meta | (unsigned long long)(VAL_PENDING | i);
-            unsigned long long expected = 0ull;
-            if (__hip_atomic_compare_exchange_strong(&en->w, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)) {
-                st = ST_CLAIMANT;
-                ax = (uint32_t)pos;
+    // An unseen key claims the FIRST TOMBSTONE of its probe chain if there is one, else the empty entry that
+    // ends the chain (tombstones are recycled by inserts: a table that once ran full does not keep its probe
+    // chains long until the next rebuild).  Every request of a key walks the same chain, so all of them aim at
+    // the same entry; whoever loses the compare-and-swap walks again and finds the winner's claim.
+    for (uint32_t attempt = 0; attempt <= n && st == ST_MISSING; ++attempt) { // (a lost compare-and-swap is somebody else's progress: <= n turns)
+        uint64_t pos = h & t.nb_mask;
+        uint64_t tomb_pos = ~0ull;
+        unsigned long long tomb_word = 0ull;
+        bool absent = false;
+        for (uint64_t probes = 0; probes <= t.nb_mask; ++probes) {
+            Entry* en = &t.ktab[pos];
+            // The whole 32-byte entry in one round trip, with plain loads: what they can show is either final
+            // for this kernel (bound entries only change in other kernels; a pending entry keeps its claimant
+            // until it is bound), a tombstone (which may turn into a claim: settled by the compare-and-swap
+            // below), or "empty", which ends the chain.
+            const ulonglong2 lo = *reinterpret_cast<const ulonglong2*>(en);      // w, hash
+            const ulonglong2 hi = *(reinterpret_cast<const ulonglong2*>(en) + 1); // key[0], key[1]
+            const unsigned long long e = lo.x;
+            if (e == 0ull) {
+                absent = true;
                 break;
             }
-            e = expected; // somebody else claimed this entry in the meantime (it was empty: the claim is all there is)
-        }
-        const uint32_t val = (uint32_t)e;
-        const bool meta_eq = (e & 0xFFFFFFFF00000000ull) == meta;
-        if (val == VAL_TOMB) {
-            // skip; tombstones are only reclaimed by a rebuild
-        } else if (val & VAL_PENDING) {
-            if (meta_eq) {
-                const uint32_t j = val & ~VAL_PENDING; // request index of the claimant (this batch)
-                const uint32_t joff = key_off[j], jlen = key_off[j + 1] - joff;
-                if (jlen == len && bytes_equal(key_bytes + joff, key, len)) {
-                    st = ST_FOLLOWER;
-                    ax = j;
+            const uint32_t val = (uint32_t)e;
+            const bool meta_eq = (e & 0xFFFFFFFF00000000ull) == meta;
+            if (val == VAL_TOMB) {
+                if (INSERT && tomb_pos == ~0ull) {
+                    tomb_pos = pos;
+                    tomb_word = e;
+                }
+            } else if (val & VAL_PENDING) {
+                if (meta_eq) {
+                    const uint32_t j = val & ~VAL_PENDING; // request index of the claimant (this batch)
+                    const uint32_t joff = key_off[j], jlen = key_off[j + 1] - joff;
+                    if (jlen == len && bytes_equal(key_bytes + joff, key, len)) {
+                        st = ST_FOLLOWER;
+                        ax = j;
+                        break;
+                    }
+                }
+            } else if (meta_eq && lo.y == h) {
+                // bound in an earlier batch: hash / key / record are stable
+                const uint32_t s = val - 2u;
+                bool same;
+                if (len <= ENTRY_KEY) same = hi.x == k0 && hi.y == k1;
+                else same = t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len);
+                if (same) {
+                    st = ST_FOUND;
+                    slot = s;
                     break;
                 }
             }
-        } else if (meta_eq && lo.y == h) {
-            // bound in an earlier batch: hash / key / record are stable
-            const uint32_t s = val - 2u;
-            bool same;
-            if (len <= ENTRY_KEY) same = hi.x == k0 && hi.y == k1;
-            else same = t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len);
-            if (same) {
-                st = ST_FOUND;
-                slot = s;
-                break;
-            }
+            pos = (pos + 1) & t.nb_mask;
         }
-        pos = (pos + 1) & t.nb_mask;
+        if (st != ST_MISSING || !INSERT) break;
+        if (!absent && tomb_pos == ~0ull) break; // the table has neither an empty entry nor a tombstone left on this chain
+        // No free slot when the batch began: do not claim (a claim that cannot be bound ends as a tombstone, and a
+        // flood of unseen keys against a full table would turn every empty entry into one).  free_top only moves
+        // after the probe, so a batch can still over-claim by its own new keys: bounded, and recycled later.
+        if (*t.free_top <= 0) break;
+        const unsigned long long mine = meta | (unsigned long long)(VAL_PENDING | i);
+        const uint64_t target = tomb_pos != ~0ull ? tomb_pos : pos;
+        unsigned long long expected = tomb_pos != ~0ull ? tomb_word : 0ull;
+        if (__hip_atomic_compare_exchange_strong(&t.ktab[target].w, &expected, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT)) {
+            st = ST_CLAIMANT;
+            ax = (uint32_t)target;
+            if (tomb_pos != ~0ull) atomicSub(t.tombs, 1u);
+        }
+        // else: somebody claimed that entry in the meantime -- walk again (it now shows as a pending claim)
     }
+    if (INSERT && st == ST_MISSING) atomicExch(t.error_flag, 1u); // no room on this key's chain: TC_E_TABLE_FULL
     if (INSERT && st == ST_CLAIMANT && len > INLINE_KEY) {
         // long key: reserve its overflow bytes now, so that binding knows who takes a slot (offset / 16 rides in `slot`)
         const unsigned long long ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
@@ -332,7 +355,7 @@ __device__ __forceinline__ uint32_t bind_claimant(const Table& t, const uint8_t*
         if (len > INLINE_KEY) {
             const uint64_t o64 = (uint64_t)ovf16 << 4; // reserved by the probe
             __builtin_memcpy(kr.bytes, &o64, 8);
-            dst = t.overflow + o64; // reservations are 16-byte multiples: dst is 16-byte aligned
+            dst = t.overflow + (uint64_t)*t.overflow_half * t.overflow_bytes + o64; // reservations are 16-byte multiples: dst is 16-byte aligned
         }
         uint32_t b = 0;
         for (; b + 8 <= len; b += 8) {
@@ -367,8 +390,36 @@ __device__ __forceinline__ void release_claim(const Table& t, const uint32_t* __
     atomicExch(t.error_flag, 1u);
 }
 
+// claim_cnt[b] (claimants of k_probe's block b) -> claimants in the blocks before b; claim_cnt[n_blocks] = all of them.
+// One block: a batch has at most a few thousand probe blocks.
+__global__ __launch_bounds__(1024) void k_claim_scan(uint32_t* __restrict__ claim_cnt, uint32_t n_blocks) {
+    __shared__ uint32_t s_w[16];
+    __shared__ uint32_t s_carry;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024) {
+        const uint32_t j = base + threadIdx.x;
+        const uint32_t c = j < n_blocks ? claim_cnt[j] : 0u;
+        uint32_t v = c;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(v, off, 64);
+            if (lane >= off) v += o;
+        }
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int k = 0; k < wave; ++k) before += s_w[k];
+        if (j < n_blocks) claim_cnt[j] = before + v - c;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) claim_cnt[n_blocks] = s_carry;
+}
+
 // claimants: take a slot, store the key, publish the binding.  Claimant number R of the batch (in request
-// order: k_probe left the number of claimants per block in claim_cnt[]) takes free_slots[top - 1 - R]; the
+// order: k_probe left the number of claimants per block in claim_cnt[], k_claim_scan made them offsets) takes free_slots[top - 1 - R]; the
 // stack pointer itself moves once, in k_follow.  No atomics: one on a single address costs ~12 ns and
 // serialises (a per-wave pop was 197 us of a 225 us kernel, a per-1024-block pop still 12 us).
 __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
@@ -376,20 +427,13 @@ __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __rest
                                                   uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ state,
                                                   const uint32_t* __restrict__ aux, const uint64_t* __restrict__ hash_in,
                                                   const uint32_t* __restrict__ claim_cnt) {
-    __shared__ uint32_t s_part[THREADS / 64];
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     const uint32_t st = i < n ? state[i] : ST_FOUND;
     const bool want = st == ST_CLAIMANT;
-    // claimants in the blocks before mine
-    uint32_t part = 0;
-    for (uint32_t j = threadIdx.x; j < blockIdx.x; j += THREADS) part += claim_cnt[j];
-    for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
     uint32_t total = 0;
-    const uint32_t rank = block_rank<THREADS>(want, total); // (its barrier also publishes s_part)
+    const uint32_t rank = block_rank<THREADS>(want, total);
     if (want) {
-        uint32_t before = 0;
-        for (int w = 0; w < THREADS / 64; ++w) before += s_part[w];
+        const uint32_t before = claim_cnt[blockIdx.x]; // claimants in the blocks before mine (k_claim_scan)
         const int top = *t.free_top; // moves in k_follow, not here
         slot_out[i] = bind_claimant(t, key_bytes, key_off, i, aux[i], hash_in[i], slot_out[i], top - 1 - (int)(before + rank));
     } else if (st == ST_NOSPACE) {
@@ -407,15 +451,8 @@ __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __rest
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     if (i < n && state[i] == ST_FOLLOWER) slot_out[i] = slot_out[aux[i]];
     if (blockIdx.x == 0) {
-        __shared__ uint32_t s_tot[THREADS / 64];
-        uint32_t part = 0;
-        for (uint32_t j = threadIdx.x; j < n_blocks; j += THREADS) part += claim_cnt[j];
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_down(part, o, 64);
-        if ((threadIdx.x & 63) == 0) s_tot[threadIdx.x >> 6] = part;
-        __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t total = 0;
-            for (int w = 0; w < THREADS / 64; ++w) total += s_tot[w];
+            const uint32_t total = claim_cnt[n_blocks]; // (k_claim_scan)
             const int top = *t.free_top;
             const int got = top < 0 ? 0 : (top < (int)total ? top : (int)total);
             *t.free_top = top - got;
@@ -440,13 +477,31 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
     const unsigned long long meta = entry_meta(h, len);
     uint64_t k0 = 0, k1 = 0;
     if (len <= ENTRY_KEY) short_key_words(key, len, k0, k1);
-    uint64_t pos = h & t.nb_mask;
+    uint64_t pos = h & t.nb_mask, tomb_pos = ~0ull, empty_pos = ~0ull;
     for (uint64_t probes = 0; probes <= t.nb_mask; ++probes, pos = (pos + 1) & t.nb_mask) {
-        Entry* en = &t.ktab[pos];
+        const Entry* en = &t.ktab[pos];
         const unsigned long long e = en->w;
         const uint32_t val = (uint32_t)e;
         if (e == 0ull) {
-            if (!insert) return NO_SLOT;
+            empty_pos = pos;
+            break;
+        }
+        if (val == VAL_TOMB) {
+            if (tomb_pos == ~0ull) tomb_pos = pos;
+            continue;
+        }
+        if (val & VAL_PENDING) continue; // (no batch is in flight: no pending claims)
+        if ((e & 0xFFFFFFFF00000000ull) == meta && en->hash == h) {
+            const uint32_t s = val - 2u;
+            const bool same = len <= ENTRY_KEY ? (en->key[0] == k0 && en->key[1] == k1)
+                                               : (t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len));
+            if (same) return s;
+        }
+    }
+    if (!insert) return NO_SLOT;
+    const uint64_t target = tomb_pos != ~0ull ? tomb_pos : empty_pos; // the chain's first tombstone is recycled
+    if (target != ~0ull) {
+        do {
             unsigned long long ovf = 0;
             if (len > INLINE_KEY) {
                 ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
@@ -463,27 +518,22 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
             if (len > INLINE_KEY) {
                 const uint64_t o64 = ovf;
                 __builtin_memcpy(kr.bytes, &o64, 8);
-                dst = t.overflow + ovf;
+                dst = t.overflow + (uint64_t)*t.overflow_half * t.overflow_bytes + ovf;
             }
             for (uint32_t b = 0; b < len; ++b) dst[b] = key[b];
             kr.hash = h;
             kr.len = len;
-            kr.pos = (uint32_t)pos;
+            kr.pos = (uint32_t)target;
             t.bound[slot] = 1;
+            Entry* en = &t.ktab[target];
             en->hash = h;
             en->key[0] = k0;
             en->key[1] = k1;
             en->w = meta | (unsigned long long)(slot + 2u);
+            if (target == tomb_pos) atomicSub(t.tombs, 1u);
             atomicAdd(inserted_counter, 1ull);
             return slot;
-        }
-        if (val == VAL_TOMB || (val & VAL_PENDING)) continue; // (no batch is in flight: no pending claims)
-        if ((e & 0xFFFFFFFF00000000ull) == meta && en->hash == h) {
-            const uint32_t s = val - 2u;
-            const bool same = len <= ENTRY_KEY ? (en->key[0] == k0 && en->key[1] == k1)
-                                               : (t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len));
-            if (same) return s;
-        }
+        } while (false);
     }
     if (insert) {
         *full = true;
@@ -492,7 +542,47 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
     return NO_SLOT;
 }
 
-// Rebuild (tombstones lengthen probe chains and are never reused): decided ON THE DEVICE so that
+// Overflow arena (keys longer than 48 bytes).  Space is handed out by a bump pointer and a swept key's bytes
+// are not given back one by one; instead the sweep compacts: once more than half of the current half is
+// handed out, every bound long key is copied into the other half (fresh bump pointer) and the halves swap.
+// Decided and done ON THE DEVICE (the asynchronous sweep never waits for the host); three near-empty
+// launches when nothing is due.  flag[0] = compact now, flag[1] = bytes handed out in the new half.
+__global__ void k_overflow_decide(Table t, unsigned long long* __restrict__ flag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        flag[0] = *t.overflow_used > t.overflow_bytes / 2 ? 1ull : 0ull;
+        flag[1] = 0ull;
+    }
+}
+__global__ __launch_bounds__(THREADS) void k_overflow_compact(Table t, unsigned long long* __restrict__ flag) {
+    if (flag[0] == 0ull) return;
+    const uint64_t from = (uint64_t)*t.overflow_half * t.overflow_bytes, to = (uint64_t)(*t.overflow_half ^ 1u) * t.overflow_bytes;
+    for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
+        if (!t.bound[s]) continue;
+        const uint32_t len = t.rec[s].len;
+        if (len <= INLINE_KEY || len == NO_SLOT) continue;
+        uint64_t off;
+        __builtin_memcpy(&off, t.rec[s].bytes, 8);
+        const uint64_t at = atomicAdd(&flag[1], (unsigned long long)((len + 15u) & ~15u));
+        const uint8_t* src = t.overflow + from + off;
+        uint8_t* dst = t.overflow + to + at;
+        uint32_t b = 0;
+        for (; b + 8 <= len; b += 8) {
+            uint64_t w;
+            __builtin_memcpy(&w, src + b, 8);
+            __builtin_memcpy(dst + b, &w, 8);
+        }
+        for (; b < len; ++b) dst[b] = src[b];
+        __builtin_memcpy(t.rec[s].bytes, &at, 8);
+    }
+}
+__global__ void k_overflow_swap(Table t, const unsigned long long* __restrict__ flag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && flag[0] != 0ull) {
+        *t.overflow_used = flag[1];
+        *t.overflow_half ^= 1u;
+    }
+}
+
+// Rebuild (tombstones lengthen probe chains; inserts recycle the ones on their own chain, the rest stays): decided ON THE DEVICE so that
 // a sweep never waits for the host -- k_rebuild_decide latches "tombstones > 1/4 of the table" into
 // a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (three near-empty
 // launches, ~10 us, when no rebuild is due).

@@ -354,7 +354,7 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
         off = align_up(off + bytes, 256);
         return at;
     };
-    const size_t o_ktab = take(nb * sizeof(kt::Entry)), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(overflow),
+    const size_t o_ktab = take(nb * sizeof(kt::Entry)), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(2 * overflow),
                  o_free = take(cap * 4), o_misc = take(64);
     TC_HIP(e, hipMalloc(&e->kt_block, off));
     uint8_t* base = (uint8_t*)e->kt_block;
@@ -370,7 +370,9 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     t.overflow_used = (unsigned long long*)(base + o_misc);
     t.free_top = (int*)(base + o_misc + 8);
     t.tombs = (uint32_t*)(base + o_misc + 12);
-    t.error_flag = (uint32_t*)(base + o_misc + 16);
+    t.error_flag = (uint32_t*)(base + o_misc + 16); // (+20: the rebuild's flag word)
+    t.overflow_half = (uint32_t*)(base + o_misc + 24);
+    // (+32, +40: the overflow compaction's flag words)
     t.free_slots = (uint32_t*)(base + o_free);
     t.capacity = (uint32_t)cap;
     hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, (hipStream_t)0,
@@ -470,6 +472,7 @@ static int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint3
     if (insert) {
         hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux,
                            e->k_hash, e->k_claim);
+        hipLaunchKernelGGL(kt::k_claim_scan, dim3(1), dim3(1024), 0, s, e->k_claim, grid.x);
         hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_hash,
                            e->k_claim);
         hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, out_slot, e->k_state, e->k_aux, e->kt, e->k_claim, grid.x,
@@ -534,6 +537,11 @@ static int rebuild_key_table_if_due(tc_engine* e) {
     hipLaunchKernelGGL(kt::k_rebuild_decide, dim3(1), dim3(64), 0, s, t, flag);
     hipLaunchKernelGGL(kt::k_rebuild_clear, grid, block, 0, s, t, flag);
     hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, flag);
+    // ... and compact the overflow arena (keys longer than 48 bytes) once more than half of it is handed out
+    unsigned long long* oflag = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 32);
+    hipLaunchKernelGGL(kt::k_overflow_decide, dim3(1), dim3(64), 0, s, t, oflag);
+    hipLaunchKernelGGL(kt::k_overflow_compact, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, oflag);
+    hipLaunchKernelGGL(kt::k_overflow_swap, dim3(1), dim3(64), 0, s, t, oflag);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
@@ -1655,6 +1663,7 @@ extern "C" int tc_counters_device_ptr(tc_engine* e, void** dptr) {
 
 // *slot = NO_SLOT when a key-mode lookup (insert == false) does not find the key
 static int store_slot_of(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint64_t* slot) {
+    TC_HIP(e, hipSetDevice(e->device)); // (the key is resolved on the engine's device whatever the caller's current one is)
     if (e->key_mode) {
         if (!key && key_len) return TC_E_INVALID_ARG;
         static const uint8_t empty = 0;
@@ -1887,7 +1896,9 @@ extern "C" int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uin
             } else {
                 uint64_t off;
                 memcpy(&off, h[i].bytes, 8);
-                TC_HIP(e, hipMemcpy(key_bytes + at, e->kt.overflow + off, len, hipMemcpyDeviceToHost));
+                uint32_t half = 0;
+                TC_HIP(e, hipMemcpy(&half, e->kt.overflow_half, sizeof half, hipMemcpyDeviceToHost));
+                TC_HIP(e, hipMemcpy(key_bytes + at, e->kt.overflow + (size_t)half * e->kt.overflow_bytes + off, len, hipMemcpyDeviceToHost));
             }
             at += len;
         } else {
@@ -1924,7 +1935,7 @@ std::vector<Section> snapshot_sections(tc_engine* e) {
         v.push_back({t.ktab, (t.nb_mask + 1) * sizeof(kt::Entry)});
         v.push_back({t.rec, (size_t)t.capacity * sizeof(kt::KeyRec)});
         v.push_back({t.bound, (size_t)t.capacity});
-        v.push_back({t.overflow, (size_t)t.overflow_bytes});
+        v.push_back({t.overflow, (size_t)t.overflow_bytes * 2});
         v.push_back({t.free_slots, (size_t)t.capacity * 4});
         v.push_back({t.overflow_used, 64}); // overflow_used | free_top | tombs | error_flag
     }

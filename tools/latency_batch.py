@@ -9,7 +9,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import throttlecrab_amd as t  # noqa: E402
-from oracle import oracle as O  # noqa: E402  (pack_keys only: builds the key arena)
+from throttlecrab_amd import workload as O  # noqa: E402  (pack_keys: builds the key arena)
 from throttlecrab_amd import workload as W  # noqa: E402
 
 rng = np.random.default_rng(3)
