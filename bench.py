@@ -226,107 +226,120 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world):
 
 
 def keys_bench(a, dev):
-    """BASELINE configs[4]: string keys "key_<id>" through the on-device key table;
-    per 1 Mi batch 80 % of the requests hit keys seen before (some of them already
-    expired), 20 % bring new keys; params (10,100,60) so TTLs are <= 11 s; `now`
-    advances 1 s per batch; expiry sweep every 4 batches (inside the timed region)."""
+    """BASELINE configs[4] at its stated configuration (SURVEY.md section 8(d) cfg 5; workload.Config4Stream, the
+    stream tests/test_gpu_keys_spec.py checks against the oracle): 10 batches of new keys (10.5 M keys, untimed),
+    then mixed batches of 1 Mi requests -- 70 % hits of live keys (a fifth of them on 1000 hot keys), 20 % new keys,
+    10 % re-hits of expired keys --, rate (10, 100 / 60 s), one second per batch, an expiry sweep every 4 batches
+    INSIDE the timed region (the first one unbinds ~9 M keys: table rebuild, overflow compaction).  Both key
+    sets: `key_%d` (5-12 B, confirmed inside the 32-byte table entry) and 32..64 B random ASCII (64-byte key
+    records; over 48 bytes: the overflow arena).  Key arenas resident in HBM, batches pipelined."""
     import torch
 
     import throttlecrab_amd as t
     from throttlecrab_amd import workload as W
-    B, steps, pre = a.batch, min(a.steps, 24), 5
-    cap = a.keys + (steps + pre) * B // 5 + B
-    eng = t.Engine(cap, B, device=dev.index or 0, key_mode=True)
-    eng.use_torch_stream()
-    rng = np.random.default_rng(5)
-    seen, batches = 0, []
-    for s in range(pre + steps):
-        n_new = B if s < pre else B // 5
-        new = np.arange(seen, seen + n_new, dtype=np.int64)
-        old = rng.integers(0, max(seen, 1), B - n_new)
-        ids = np.concatenate([old, new])
-        rng.shuffle(ids)
-        seen += n_new
-        kb, ko = W.string_keys(ids)
-        batches.append((torch.from_numpy(kb).to(dev), torch.from_numpy(ko.astype(np.int32)).to(dev)))
-    out = t.BatchResult()
+    B, n_prefill = a.batch, 10
+    steps = max(4, min(a.steps, 16) // 4 * 4)
+    out = {}
+    for label, long in (("key_%d", False), ("ascii_32_64", True)):
+        st = W.Config4Stream(B, n_prefill=n_prefill, long=long, sweep_every=4)
+        cap = B * n_prefill + B
+        eng = t.Engine(cap, B, device=dev.index or 0, key_mode=True, key_arena_bytes=(448 << 20) if long else 0)
+        eng.use_torch_stream()
+        res = t.BatchResult()
+        b, c, p = W.Config4Stream.PARAMS
 
-    def one(s):
-        kb, ko = batches[s]
-        eng.rate_limit_batch_keys(kb, ko, max_burst=10, count_per_period=100, period=60, quantity=1,
-                                  now_ns=W.T0_NS + s * 10**9, want=("allowed",), out=out, inputs_ready=True)
-
-    for s in range(pre):
-        one(s)
-    torch.cuda.synchronize()
-    swept0 = eng.counters()["swept"]
-    t0 = time.perf_counter()
-    for s in range(pre, pre + steps):
-        one(s)
-        if (s - pre) % 4 == 3:
-            eng.sweep_expired_async(W.T0_NS + s * 10**9)  # enqueued behind the batch, no host wait
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    c = eng.counters()
-    eng.close()
-    swept = c["swept"] - swept0
-    res = {"value": steps * B / dt, "unit": "decisions/s", "steps": steps, "keys_inserted": c["keys_inserted"],
-           "swept": swept, "allowed_fraction": c["allowed"] / max(1, c["total"]),
-           "workload": f"string keys key_<id>, {B} requests/batch, 20% new keys, sweep every 4 batches"}
-    # the same stream handed over as HOST arrays (PCIe-inclusive): TC_B_ASYNC batches from pinned memory, at most
-    # 3 in flight; key arena + offsets go in, one decision byte per request comes back
-    eng = t.Engine(cap, B, device=dev.index or 0, key_mode=True)
-    eng.use_torch_stream()
-    pinned = []
-    for kb_d, ko_d in batches:
-        kb, ko = eng.host_alloc(kb_d.numel(), np.uint8), eng.host_alloc(ko_d.numel(), np.uint32)
-        kb[:] = kb_d.cpu().numpy()
-        ko[:] = ko_d.cpu().numpy().astype(np.uint32)
-        pinned.append((kb, ko))
-    outs = [t.BatchResult(allowed=eng.host_alloc(B, np.uint8)) for _ in range(3)]
-
-    def one_host(s, async_):
-        kb, ko = pinned[s]
-        if async_ and s >= pre + 3:
-            eng.wait_batches(2)
-        eng.rate_limit_batch_keys(kb, ko, max_burst=10, count_per_period=100, period=60, quantity=1,
-                                  now_ns=W.T0_NS + s * 10**9, want=("allowed",), out=outs[s % 3], async_=async_)
-    for s in range(pre):
-        one_host(s, False)
-    t0 = time.perf_counter()
-    for s in range(pre, pre + steps):
-        one_host(s, True)
-        if (s - pre) % 4 == 3:
-            eng.sweep_expired_async(W.T0_NS + s * 10**9)
-    eng.wait_batches(0)
-    eng.synchronize()
-    res["host_buffers_pinned_async_pcie_inclusive"] = {"value": steps * B / (time.perf_counter() - t0), "unit": "decisions/s"}
-    eng.close()
-    return res
+        def one(arena, now, piped=True):
+            eng.rate_limit_batch_keys(arena[0], arena[1], max_burst=b, count_per_period=c, period=p, quantity=1, now_ns=now,
+                                      want=("allowed",), out=res, inputs_ready=piped)
+        for k in range(n_prefill):
+            ids, now = st.prefill(k)
+            arena = st.keys(ids, device=dev)
+            one(arena, now)
+            torch.cuda.synchronize()
+            del arena
+        mixed = []
+        key_bytes = 0
+        for s_ in range(2 * steps):  # timed steps + the same number for the per-kernel profile
+            ids, now = st.mixed(s_)
+            arena = st.keys(ids, device=dev)
+            key_bytes += int(arena[0].numel())
+            mixed.append((arena, now))
+        torch.cuda.synchronize()
+        c0 = eng.counters()
+        t0 = time.perf_counter()
+        for s_ in range(steps):
+            one(*mixed[s_])
+            if st.sweep_due(s_):
+                eng.sweep_expired_async(mixed[s_][1])  # enqueued behind the batch, no host wait
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        c1 = eng.counters()
+        mean_len = key_bytes / (2 * steps * B)
+        alg = (ALG_BYTES_PER_DECISION + 12 + 2 * mean_len) * B  # SURVEY.md 8(d): + offset 4, table probe 8, key bytes read twice
+        r = {"value": steps * B / dt, "unit": "decisions/s", "steps": steps, "ms_per_step": 1e3 * dt / steps,
+             "mean_key_bytes": mean_len, "keys_inserted_before": c0["keys_inserted"], "keys_inserted": c1["keys_inserted"] - c0["keys_inserted"],
+             "swept": c1["swept"] - c0["swept"], "sweeps": steps // 4,
+             "allowed_fraction": (c1["allowed"] - c0["allowed"]) / max(1, c1["total"] - c0["total"])}
+        # per-kernel times of the same stream, pipelined as in the timed region (sweeps left out: not a per-batch stage)
+        eng.profile_enable(True)
+        for s_ in range(steps, 2 * steps):
+            one(*mixed[s_])
+        torch.cuda.synchronize()
+        prof = eng.profile_read()
+        eng.profile_enable(False)
+        stages = {k: {"kernel": KERNEL_OF_STAGE[k], "launches_per_batch": calls / steps, "avg_ms": ms / calls, "per_batch_ms": ms / steps}
+                  for k, (ms, calls) in prof.items() if calls}
+        dom = max(stages, key=lambda k: stages[k]["per_batch_ms"])
+        d = stages[dom]
+        tr, src = pmc_traffic(dom, "string_keys" + ("_long" if long else ""), "wide", d["launches_per_batch"])
+        ach = alg / (d["per_batch_ms"] * 1e-3) / 1e9
+        r["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_batch": alg,
+                         "algorithmic_bytes_per_decision": alg / B, "stage": dom, "kernel": d["kernel"],
+                         "launches_per_batch": d["launches_per_batch"], "avg_ms": d["avg_ms"], "per_batch_ms": d["per_batch_ms"],
+                         "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
+                         "whole_step_frac": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, "stages": {"pipelined": stages},
+                         "note": "the timed region also holds the sweeps (" + str(steps // 4) + "), the profile steps do not"}
+        out[label] = r
+        eng.close()
+        del mixed
+        torch.cuda.empty_cache()
+    out["workload"] = ("10 x 1 Mi new keys, then 1 Mi-request batches: 70 % hits (1/5 of them on 1000 hot keys), 20 % new keys, "
+                       "10 % re-hits of expired keys; rate (10,100/60 s); 1 s per batch; sweep every 4 batches")
+    return out
 
 
 def cpu_baseline(kind, n_keys, batch, n_batches):
-    """The oracle (a port of RateLimiter<AdaptiveStore>, string keys "key_<slot>")
-    timed on this box's host cores over the first n_batches of the same stream."""
+    """The oracle (a port of RateLimiter<AdaptiveStore>, string keys "key_<slot>") timed on this box's host cores:
+    (i) one thread over the first n_batches of the same stream == the reference's one actor task
+    (throttlecrab-server/src/actor.rs:217-236); (ii) every core, one store per thread, keys routed by hash
+    (what README.md:247-249 recommends); (iii) the reference's OWN benchmark loop (store_comparison.rs: 2 000 keys,
+    400 000 calls, key formatting and clock read inside), next to the number the reference publishes for it."""
     from oracle import oracle as O
     from throttlecrab_amd import workload as W
     slots = np.concatenate(make_batches(kind, n_keys, batch, n_batches))
     kb, ko = O.format_keys(slots)
     now = (W.T0_NS + (np.arange(slots.size, dtype=np.int64) // batch) * 1_000_000)
     b, c, p = W.REF_PARAMS
-    # single thread == the reference's one actor task (throttlecrab-server/src/actor.rs:217-236);
     # store sized like the server would for this key count, server-default max_operations (config.rs:301)
     st = O.AdaptiveOracle(capacity=n_keys, created_ns=W.T0_NS, max_operations=1_000_000)
     t0 = time.perf_counter()
     st.batch_keys(kb, ko, b, c, p, 1, now)
     t1 = time.perf_counter() - t0
+    del st
     ncores = min(os.cpu_count() or 1, 64)
     tm, _ = O.batch_keys_mt(ncores, max(1000, n_keys // ncores), W.T0_NS, kb, ko, b, c, p, 1, now)
+    O.reference_shape(2000, 50_000)  # warm
+    ts, allowed, blocked = min(O.reference_shape(2000, 400_000) for _ in range(3))
     return {"value": slots.size / t1, "unit": "decisions/s", "cores": 1, "kind": "port",
             "sample": f"first {n_batches} batches ({slots.size} requests) of the same {kind} stream, "
                       f"string keys key_<slot>, AdaptiveStore port, 1 thread",
-            "all_cores": {"value": slots.size / tm, "cores": ncores,
-                          "note": "keys hash-sharded over one AdaptiveStore port per thread"}}
+            "all_cores": {"value": slots.size / tm, "cores": ncores, "speedup_over_one_thread": t1 / tm,
+                          "note": "one AdaptiveStore port per thread, keys routed by hash (routing inside the timing)"},
+            "reference_shape": {"value": 400_000 / ts, "unit": "decisions/s", "cores": 1, "allowed": allowed, "blocked": blocked,
+                                "sample": "throttlecrab-server/examples/store_comparison.rs: 400 000 rate_limit calls over 2 000 keys key_<i>, "
+                                          "(100, 1000 / 3600 s), key formatting and clock read inside the loop, best of 3",
+                                "published_by_reference": {"value": 12_500_000, "unit": "req/s", "hardware": "Apple M3 Max",
+                                                           "source": "docs/benchmark-results.md:26-30 (AdaptiveStore)"}}}
 
 
 def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):

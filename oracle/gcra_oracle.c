@@ -20,6 +20,7 @@
 
 #include <pthread.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include <time.h>
 
@@ -532,38 +533,60 @@ void tco_batch_slots(tco_store* st, const uint32_t* slot, const tco_batch_io* io
     }
 }
 
-/* ---- hash-sharded multi-thread baseline ----------------------------------- */
+/* ---- hash-sharded multi-thread baseline -----------------------------------
+ * What the reference's README recommends beyond one core ("client-side sharding by key", README.md:247-249):
+ * one AdaptiveStore per thread, keys routed by hash.  Three parallel phases, all inside the timing:
+ *   1. every thread routes a contiguous chunk of the stream: owner of each key + how many it sends to every shard
+ *   2. every thread writes the indices of its chunk's requests into the shards' lists (offsets from phase 1:
+ *      a shard's list is in stream order)
+ *   3. every thread serves its own list from its own store
+ * (A worker that walks the WHOLE stream looking for its own requests spends most of its time skipping:
+ * 64 threads gave 3.7x that way.) */
 typedef struct {
     int tid, threads;
     size_t cap;
+    uint64_t max_operations;
     int64_t created;
     const uint8_t* key_bytes;
     const uint32_t* key_off;
     const tco_batch_io* io;
     uint16_t* owner;
+    size_t* counts;  /* [threads (router)][threads (shard)] -> start of the router's part of the shard's list */
+    uint32_t* lists; /* [n] request indices, grouped by shard */
+    size_t* shard_begin; /* [threads + 1] */
 } mt_arg;
 
-/* phase 1: every thread routes a contiguous chunk of the stream (owner[i] = shard of key i);
- * phase 2: every thread serves its own keys, in stream order, from its own AdaptiveStore. */
 static void* mt_route(void* p) {
     mt_arg* a = (mt_arg*)p;
-    const size_t n = a->io->n, lo = n * (size_t)a->tid / (size_t)a->threads, hi = n * (size_t)(a->tid + 1) / (size_t)a->threads;
+    const size_t n = a->io->n, T = (size_t)a->threads;
+    const size_t lo = n * (size_t)a->tid / T, hi = n * (size_t)(a->tid + 1) / T;
+    size_t* mine = a->counts + (size_t)a->tid * T;
     for (size_t i = lo; i < hi; i++) {
         const uint8_t* k = a->key_bytes + a->key_off[i];
         size_t kl = a->key_off[i + 1] - a->key_off[i];
         /* shard by a hash decorrelated from the in-store placement hash */
-        a->owner[i] = (uint16_t)(mix64(tco_hash_bytes(k, kl) ^ 0xa5a5a5a5a5a5a5a5ull) % (uint64_t)a->threads);
+        const uint16_t o = (uint16_t)(mix64(tco_hash_bytes(k, kl) ^ 0xa5a5a5a5a5a5a5a5ull) % (uint64_t)T);
+        a->owner[i] = o;
+        mine[o]++;
     }
+    return NULL;
+}
+static void* mt_fill(void* p) {
+    mt_arg* a = (mt_arg*)p;
+    const size_t n = a->io->n, T = (size_t)a->threads;
+    const size_t lo = n * (size_t)a->tid / T, hi = n * (size_t)(a->tid + 1) / T;
+    size_t* at = a->counts + (size_t)a->tid * T; /* (now offsets) */
+    for (size_t i = lo; i < hi; i++) a->lists[at[a->owner[i]]++] = (uint32_t)i;
     return NULL;
 }
 static void* mt_worker(void* p) {
     mt_arg* a = (mt_arg*)p;
-    tco_adaptive* s = tco_adaptive_with_capacity(a->cap, a->created);
+    /* the server's store: cleanup interval 1 s .. 300 s, max_operations as configured (config.rs:301 default 1e6) */
+    tco_adaptive* s = tco_adaptive_new(a->cap, 1000000000ull, 300ull * 1000000000ull, a->max_operations, a->created);
     tco_store st = tco_adaptive_as_store(s);
     const tco_batch_io* io = a->io;
-    const uint16_t me = (uint16_t)a->tid;
-    for (size_t i = 0; i < io->n; i++) {
-        if (a->owner[i] != me) continue;
+    for (size_t j = a->shard_begin[a->tid]; j < a->shard_begin[a->tid + 1]; j++) {
+        const size_t i = a->lists[j];
         const uint8_t* k = a->key_bytes + a->key_off[i];
         size_t kl = a->key_off[i + 1] - a->key_off[i];
         tco_result r;
@@ -574,29 +597,78 @@ static void* mt_worker(void* p) {
     return NULL;
 }
 
-double tco_batch_keys_mt(int threads, size_t capacity_per_thread, int64_t created_ns,
+double tco_batch_keys_mt(int threads, size_t capacity_per_thread, uint64_t max_operations, int64_t created_ns,
                          const uint8_t* key_bytes, const uint32_t* key_off,
                          const tco_batch_io* io) {
     if (threads < 1) threads = 1;
     if (threads > 60000) threads = 60000;
-    pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof *th);
-    mt_arg* args = (mt_arg*)calloc((size_t)threads, sizeof *args);
-    uint16_t* owner = (uint16_t*)malloc((io->n ? io->n : 1) * sizeof *owner);
+    const size_t T = (size_t)threads, n = io->n;
+    pthread_t* th = (pthread_t*)calloc(T, sizeof *th);
+    mt_arg* args = (mt_arg*)calloc(T, sizeof *args);
+    uint16_t* owner = (uint16_t*)malloc((n ? n : 1) * sizeof *owner);
+    uint32_t* lists = (uint32_t*)malloc((n ? n : 1) * sizeof *lists);
+    size_t* counts = (size_t*)calloc(T * T, sizeof *counts);
+    size_t* shard_begin = (size_t*)calloc(T + 1, sizeof *shard_begin);
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
-    for (int t = 0; t < threads; t++) {
-        args[t].tid = t; args[t].threads = threads; args[t].cap = capacity_per_thread;
-        args[t].created = created_ns; args[t].key_bytes = key_bytes; args[t].key_off = key_off;
-        args[t].io = io; args[t].owner = owner;
+    for (size_t t = 0; t < T; t++) {
+        args[t].tid = (int)t; args[t].threads = threads; args[t].cap = capacity_per_thread;
+        args[t].max_operations = max_operations; args[t].created = created_ns; args[t].key_bytes = key_bytes; args[t].key_off = key_off;
+        args[t].io = io; args[t].owner = owner; args[t].counts = counts; args[t].lists = lists;
+        args[t].shard_begin = shard_begin;
         pthread_create(&th[t], NULL, mt_route, &args[t]);
     }
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
-    for (int t = 0; t < threads; t++) pthread_create(&th[t], NULL, mt_worker, &args[t]);
-    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
+    for (size_t t = 0; t < T; t++) pthread_join(th[t], NULL);
+    /* counts[router][shard] -> where the router's requests start in the shard's list (T*T words: negligible) */
+    size_t run = 0;
+    for (size_t o = 0; o < T; o++) {
+        shard_begin[o] = run;
+        for (size_t r = 0; r < T; r++) {
+            const size_t c = counts[r * T + o];
+            counts[r * T + o] = run;
+            run += c;
+        }
+    }
+    shard_begin[T] = run;
+    for (size_t t = 0; t < T; t++) pthread_create(&th[t], NULL, mt_fill, &args[t]);
+    for (size_t t = 0; t < T; t++) pthread_join(th[t], NULL);
+    for (size_t t = 0; t < T; t++) pthread_create(&th[t], NULL, mt_worker, &args[t]);
+    for (size_t t = 0; t < T; t++) pthread_join(th[t], NULL);
     clock_gettime(CLOCK_MONOTONIC, &t1);
     free(th);
     free(args);
     free(owner);
+    free(lists);
+    free(counts);
+    free(shard_begin);
+    return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+}
+
+/* The reference's own library benchmark, shape for shape (throttlecrab-server/examples/store_comparison.rs:4-34,
+ * the run behind "AdaptiveStore 12.5M req/s" in docs/benchmark-results.md:26-30): `iterations` calls of
+ * rate_limit(&format!("key_{}", i % num_keys), 100, 1000, 3600, 1, SystemTime::now()) on
+ * RateLimiter::new(AdaptiveStore::with_capacity(num_keys)), one thread, key formatting and the clock read
+ * inside the loop.  Returns seconds; *allowed / *blocked as the example counts them. */
+double tco_reference_shape(size_t num_keys, size_t iterations, uint64_t* allowed, uint64_t* blocked) {
+    struct timespec t0, t1, now;
+    clock_gettime(CLOCK_REALTIME, &now);
+    tco_adaptive* s = tco_adaptive_with_capacity(num_keys, (int64_t)now.tv_sec * 1000000000ll + now.tv_nsec);
+    tco_store st = tco_adaptive_as_store(s);
+    uint64_t na = 0, nb = 0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (size_t i = 0; i < iterations; i++) {
+        char key[32];
+        const int kl = snprintf(key, sizeof key, "key_%zu", i % num_keys);
+        clock_gettime(CLOCK_REALTIME, &now);
+        tco_result r;
+        tco_rate_limit(&st, (const uint8_t*)key, (size_t)kl, 100, 1000, 3600, 1, (int64_t)now.tv_sec * 1000000000ll + now.tv_nsec, &r);
+        if (r.allowed) na++;
+        else nb++;
+    }
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    tco_adaptive_free(s);
+    if (allowed) *allowed = na;
+    if (blocked) *blocked = nb;
     return (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
 }
 

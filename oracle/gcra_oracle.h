@@ -138,7 +138,7 @@ void tco_batch_slots(tco_store* st, const uint32_t* slot, const tco_batch_io* io
 /* Hash-sharded multi-thread CPU baseline: T AdaptiveStores, key i handled by
  * thread (hash(key) % T); each thread walks the whole stream in index order
  * and serves its own keys.  Returns elapsed seconds (steady clock). */
-double tco_batch_keys_mt(int threads, size_t capacity_per_thread, int64_t created_ns,
+double tco_batch_keys_mt(int threads, size_t capacity_per_thread, uint64_t max_operations, int64_t created_ns,
                          const uint8_t* key_bytes, const uint32_t* key_off,
                          const tco_batch_io* io);
 
@@ -149,6 +149,8 @@ size_t tco_format_keys(const char* prefix, const uint32_t* ids, size_t n, uint8_
 
 /* 64-bit key hash used only to place keys (results are hash independent). */
 uint64_t tco_hash_bytes(const uint8_t* p, size_t n);
+/* the reference's own store_comparison.rs loop (see gcra_oracle.c); returns seconds */
+double tco_reference_shape(size_t num_keys, size_t iterations, uint64_t* allowed, uint64_t* blocked);
 
 #ifdef __cplusplus
 }

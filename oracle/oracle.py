@@ -91,7 +91,9 @@ def lib():
     L.tco_batch_keys.argtypes = [C.POINTER(_Store), C.c_void_p, C.c_void_p, C.POINTER(_BatchIO)]
     L.tco_batch_slots.argtypes = [C.POINTER(_Store), C.c_void_p, C.POINTER(_BatchIO)]
     L.tco_batch_keys_mt.restype = C.c_double
-    L.tco_batch_keys_mt.argtypes = [C.c_int, C.c_size_t, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(_BatchIO)]
+    L.tco_batch_keys_mt.argtypes = [C.c_int, C.c_size_t, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(_BatchIO)]
+    L.tco_reference_shape.restype = C.c_double
+    L.tco_reference_shape.argtypes = [C.c_size_t, C.c_size_t, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.tco_format_keys.restype = C.c_size_t
     L.tco_format_keys.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
     L.tco_hash_bytes.restype = C.c_uint64
@@ -279,14 +281,22 @@ class DenseOracle(_StoreBase):
 
 
 def batch_keys_mt(threads: int, capacity_per_thread: int, created_ns: int, key_bytes, key_off,
-                  burst, count, period, quantity, now):
+                  burst, count, period, quantity, now, max_operations: int = 1_000_000):
     """Hash-sharded multi-thread AdaptiveStore baseline -> (seconds, BatchOut)."""
     n = len(key_off) - 1
     io, out, keep = _make_io(n, burst, count, period, quantity, now)
     kb = np.ascontiguousarray(key_bytes, dtype=np.uint8)
     ko = np.ascontiguousarray(key_off, dtype=np.uint32)
-    secs = lib().tco_batch_keys_mt(threads, capacity_per_thread, created_ns, kb.ctypes.data, ko.ctypes.data, C.byref(io))
+    secs = lib().tco_batch_keys_mt(threads, capacity_per_thread, max_operations, created_ns, kb.ctypes.data, ko.ctypes.data, C.byref(io))
     return float(secs), out
+
+
+def reference_shape(num_keys: int = 2000, iterations: int = 400_000):
+    """The reference's own library benchmark loop (throttlecrab-server/examples/store_comparison.rs:4-34) on the
+    AdaptiveStore port -> (seconds, allowed, blocked)."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    secs = lib().tco_reference_shape(num_keys, iterations, C.byref(a), C.byref(b))
+    return float(secs), int(a.value), int(b.value)
 
 
 def format_keys(ids: np.ndarray, prefix: bytes = b"key_"):
