@@ -1,0 +1,160 @@
+//! include/tcgpu.h, declaration for declaration.  Field order, widths and constant values are checked against
+//! the header by tests/test_rust_shim.py (no Rust toolchain needed for that).
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int, c_void};
+
+pub const TCGPU_ABI_VERSION: u32 = 1;
+
+// per-request status == CellError (throttlecrab/src/core/mod.rs:49-56)
+pub const TC_OK: u8 = 0;
+pub const TC_NEGATIVE_QUANTITY: u8 = 1;
+pub const TC_INVALID_RATE_LIMIT: u8 = 2;
+pub const TC_INTERNAL: u8 = 3;
+
+// call-level return codes
+pub const TC_E_OK: c_int = 0;
+pub const TC_E_INVALID_ARG: c_int = -1;
+pub const TC_E_HIP: c_int = -2;
+pub const TC_E_NOMEM: c_int = -3;
+pub const TC_E_BATCH_TOO_LARGE: c_int = -4;
+pub const TC_E_TABLE_FULL: c_int = -5;
+pub const TC_E_NO_DEVICE: c_int = -6;
+pub const TC_E_UNSUPPORTED: c_int = -7;
+
+pub const TC_CFG_KEY_MODE: u32 = 0x1;
+pub const TC_CFG_TRACK_DENIED: u32 = 0x2;
+pub const TC_CFG_FIXED_PARAMS: u32 = 0x4;
+
+pub const TC_B_DEVICE_PTRS: u32 = 0x1;
+pub const TC_B_REGISTERED_PARAMS: u32 = 0x2;
+pub const TC_B_UNIQUE_SLOTS: u32 = 0x4;
+pub const TC_B_INPUTS_READY: u32 = 0x8;
+pub const TC_B_GROUPED_OUTPUT: u32 = 0x10;
+pub const TC_B_ASYNC: u32 = 0x20;
+
+pub const TC_CNT_TOTAL: usize = 0;
+pub const TC_CNT_ALLOWED: usize = 1;
+pub const TC_CNT_DENIED: usize = 2;
+pub const TC_CNT_ERRORS: usize = 3;
+pub const TC_CNT_SWEPT: usize = 4;
+pub const TC_CNT_BATCHES: usize = 5;
+pub const TC_CNT_KEYS_INSERTED: usize = 6;
+pub const TC_CNT_LIVE_SLOTS: usize = 7;
+pub const TC_CNT_COUNT: usize = 8;
+
+#[repr(C)]
+pub struct tc_engine {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct tc_config {
+    pub struct_size: u32,
+    pub flags: u32,
+    pub device_id: i32,
+    pub reserved0: i32,
+    pub capacity: u64,
+    pub max_batch: u64,
+    pub key_arena_bytes: u64,
+}
+
+#[repr(C)]
+pub struct tc_batch {
+    pub struct_size: u32,
+    pub flags: u32,
+    pub n: u64,
+    pub slot: *const u32,
+    pub key_bytes: *const u8,
+    pub key_off: *const u32,
+    pub max_burst: *const i64,
+    pub count_per_period: *const i64,
+    pub period: *const i64,
+    pub quantity: *const i64,
+    pub now_ns: *const i64,
+    pub max_burst_scalar: i64,
+    pub count_per_period_scalar: i64,
+    pub period_scalar: i64,
+    pub quantity_scalar: i64,
+    pub now_ns_scalar: i64,
+    pub allowed: *mut u8,
+    pub allowed_bits: *mut u64,
+    pub limit: *mut i64,
+    pub remaining: *mut i64,
+    pub reset_after_ns: *mut i64,
+    pub retry_after_ns: *mut i64,
+    pub status: *mut u8,
+    pub result4: *mut i64,
+    pub decisions: *mut tc_decision,
+    pub order: *mut u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct tc_decision {
+    pub remaining: i64,
+    pub reset_after_ns: i64,
+    pub retry_after_ns: i64,
+    pub allowed: u8,
+    pub status: u8,
+    pub pad: [u8; 6],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct tc_result {
+    pub limit: i64,
+    pub remaining: i64,
+    pub reset_after_ns: i64,
+    pub retry_after_ns: i64,
+    pub allowed: u8,
+    pub status: u8,
+}
+
+extern "C" {
+    pub fn tc_abi_version() -> u32;
+    pub fn tc_engine_create(cfg: *const tc_config, err: *mut c_int) -> *mut tc_engine;
+    pub fn tc_engine_destroy(e: *mut tc_engine);
+    pub fn tc_synchronize(e: *mut tc_engine) -> c_int;
+    pub fn tc_last_error(e: *const tc_engine) -> *const c_char;
+    pub fn tc_register_params_uniform(e: *mut tc_engine, max_burst: i64, count_per_period: i64, period: i64) -> c_int;
+    pub fn tc_rate_limit_batch_slots(e: *mut tc_engine, b: *const tc_batch) -> c_int;
+    pub fn tc_rate_limit_batch_keys(e: *mut tc_engine, b: *const tc_batch) -> c_int;
+    pub fn tc_wait_batches(e: *mut tc_engine, max_in_flight: u32) -> c_int;
+    pub fn tc_host_alloc(bytes: usize) -> *mut c_void;
+    pub fn tc_host_free(p: *mut c_void);
+    pub fn tc_rate_limit(
+        e: *mut tc_engine,
+        key: *const u8,
+        key_len: usize,
+        max_burst: i64,
+        count_per_period: i64,
+        period: i64,
+        quantity: i64,
+        now_ns: i64,
+        out: *mut tc_result,
+    ) -> c_int;
+    pub fn tc_sweep_expired(e: *mut tc_engine, now_ns: i64, removed: *mut u64) -> c_int;
+    pub fn tc_counters(e: *mut tc_engine, out: *mut u64) -> c_int;
+    pub fn tc_store_get(e: *mut tc_engine, key: *const u8, key_len: usize, now_ns: i64, value: *mut i64, found: *mut c_int) -> c_int;
+    pub fn tc_store_compare_and_swap_with_ttl(
+        e: *mut tc_engine,
+        key: *const u8,
+        key_len: usize,
+        old_value: i64,
+        new_value: i64,
+        ttl_ns: u64,
+        now_ns: i64,
+        swapped: *mut c_int,
+    ) -> c_int;
+    pub fn tc_store_set_if_not_exists_with_ttl(
+        e: *mut tc_engine,
+        key: *const u8,
+        key_len: usize,
+        value: i64,
+        ttl_ns: u64,
+        now_ns: i64,
+        was_set: *mut c_int,
+    ) -> c_int;
+    pub fn tc_snapshot_save(e: *mut tc_engine, path: *const c_char) -> c_int;
+    pub fn tc_snapshot_load(e: *mut tc_engine, path: *const c_char) -> c_int;
+}

@@ -1,0 +1,246 @@
+//! throttlecrab on an AMD MI355X: the reference's `Store` trait and `RateLimiter` call surface over
+//! libtcgpu.so (include/tcgpu.h).
+//!
+//! * [`GpuStore`] implements `throttlecrab::Store` (throttlecrab/src/core/store/mod.rs:85-133) call for call, so
+//!   `RateLimiter<GpuStore>` works unchanged -- three store operations per request, one kernel launch each: correct,
+//!   and slow.
+//! * [`GpuRateLimiter`] keeps `RateLimiter::rate_limit`'s signature (rate_limiter.rs:102-110) but runs the whole
+//!   decision on the device in one call, and adds `rate_limit_batch`: a slice of requests applied exactly as if
+//!   `rate_limit` had been called on them one by one, in order -- what the server's actor
+//!   (throttlecrab-server/src/actor.rs:217-236) drains its queue into, see `examples` in INTEGRATION.md.
+//!
+//! Threading: one owner, like every store of the reference (store/mod.rs:40-43).
+pub mod ffi;
+
+use std::time::{Duration, SystemTime, UNIX_EPOCH};
+
+use throttlecrab::{CellError, RateLimitResult, Store};
+
+/// `SystemTime` as the engine's i64 nanoseconds since the epoch; times before 1970 become -1, which the engine
+/// answers with status Internal (the reference reads the wall clock there, rate_limiter.rs:126-144).
+fn ns(t: SystemTime) -> i64 {
+    t.duration_since(UNIX_EPOCH).map(|d| d.as_nanos() as i64).unwrap_or(-1)
+}
+
+fn call_error(e: *const ffi::tc_engine, rc: i32) -> String {
+    let msg = unsafe {
+        let p = ffi::tc_last_error(e);
+        if p.is_null() { String::new() } else { std::ffi::CStr::from_ptr(p).to_string_lossy().into_owned() }
+    };
+    format!("tcgpu error {rc}: {msg}")
+}
+
+/// The GPU-resident key store: an engine handle in string-key mode.
+pub struct GpuStore {
+    e: *mut ffi::tc_engine,
+    max_batch: usize,
+}
+
+// single owner; the handle may move between threads like any other store
+unsafe impl Send for GpuStore {}
+
+impl GpuStore {
+    /// `AdaptiveStore::with_capacity` (adaptive_cleanup.rs:93-106): room for `capacity` keys.
+    pub fn with_capacity(capacity: usize) -> Self {
+        Self::new(capacity, 1 << 20, 0)
+    }
+
+    pub fn new(capacity: usize, max_batch: usize, device_id: i32) -> Self {
+        let cfg = ffi::tc_config {
+            struct_size: std::mem::size_of::<ffi::tc_config>() as u32,
+            flags: ffi::TC_CFG_KEY_MODE,
+            device_id,
+            reserved0: 0,
+            capacity: capacity as u64,
+            max_batch: max_batch as u64,
+            key_arena_bytes: 0,
+        };
+        let mut err = 0;
+        let e = unsafe { ffi::tc_engine_create(&cfg, &mut err) };
+        assert!(!e.is_null(), "tc_engine_create failed: {err}");
+        GpuStore { e, max_batch }
+    }
+
+    /// `AdaptiveStore::cleanup` (adaptive_cleanup.rs:173-203), explicitly: the engine never cleans on its own.
+    pub fn cleanup(&mut self, now: SystemTime) -> Result<u64, String> {
+        let mut removed = 0u64;
+        let rc = unsafe { ffi::tc_sweep_expired(self.e, ns(now), &mut removed) };
+        if rc == 0 { Ok(removed) } else { Err(call_error(self.e, rc)) }
+    }
+
+    pub fn counters(&mut self) -> Result<[u64; ffi::TC_CNT_COUNT], String> {
+        let mut out = [0u64; ffi::TC_CNT_COUNT];
+        let rc = unsafe { ffi::tc_counters(self.e, out.as_mut_ptr()) };
+        if rc == 0 { Ok(out) } else { Err(call_error(self.e, rc)) }
+    }
+}
+
+impl Drop for GpuStore {
+    fn drop(&mut self) {
+        unsafe { ffi::tc_engine_destroy(self.e) }
+    }
+}
+
+impl Store for GpuStore {
+    fn compare_and_swap_with_ttl(&mut self, key: &str, old: i64, new: i64, ttl: Duration, now: SystemTime) -> Result<bool, String> {
+        let mut ok = 0;
+        let rc = unsafe {
+            ffi::tc_store_compare_and_swap_with_ttl(self.e, key.as_ptr(), key.len(), old, new, ttl.as_nanos() as u64, ns(now), &mut ok)
+        };
+        if rc == 0 { Ok(ok != 0) } else { Err(call_error(self.e, rc)) }
+    }
+
+    fn get(&self, key: &str, now: SystemTime) -> Result<Option<i64>, String> {
+        let (mut value, mut found) = (0i64, 0);
+        let rc = unsafe { ffi::tc_store_get(self.e, key.as_ptr(), key.len(), ns(now), &mut value, &mut found) };
+        if rc == 0 { Ok((found != 0).then_some(value)) } else { Err(call_error(self.e, rc)) }
+    }
+
+    fn set_if_not_exists_with_ttl(&mut self, key: &str, value: i64, ttl: Duration, now: SystemTime) -> Result<bool, String> {
+        let mut ok = 0;
+        let rc = unsafe {
+            ffi::tc_store_set_if_not_exists_with_ttl(self.e, key.as_ptr(), key.len(), value, ttl.as_nanos() as u64, ns(now), &mut ok)
+        };
+        if rc == 0 { Ok(ok != 0) } else { Err(call_error(self.e, rc)) }
+    }
+}
+
+/// One request of a batch: the argument list of `RateLimiter::rate_limit`.
+pub struct Request<'a> {
+    pub key: &'a str,
+    pub max_burst: i64,
+    pub count_per_period: i64,
+    pub period: i64,
+    pub quantity: i64,
+    pub now: SystemTime,
+}
+
+/// `RateLimiter<GpuStore>` with the decision on the device.
+pub struct GpuRateLimiter {
+    store: GpuStore,
+}
+
+fn decode(r: &ffi::tc_decision, limit: i64, quantity: i64) -> Result<(bool, RateLimitResult), CellError> {
+    match r.status {
+        ffi::TC_OK => Ok((
+            r.allowed != 0,
+            RateLimitResult {
+                limit,
+                remaining: r.remaining,
+                reset_after: Duration::from_nanos(r.reset_after_ns as u64),
+                retry_after: Duration::from_nanos(r.retry_after_ns as u64),
+            },
+        )),
+        ffi::TC_NEGATIVE_QUANTITY => Err(CellError::NegativeQuantity(quantity)),
+        ffi::TC_INVALID_RATE_LIMIT => Err(CellError::InvalidRateLimit),
+        _ => Err(CellError::Internal("outside the engine's validated domain".into())),
+    }
+}
+
+impl GpuRateLimiter {
+    pub fn new(store: GpuStore) -> Self {
+        GpuRateLimiter { store }
+    }
+
+    pub fn store_mut(&mut self) -> &mut GpuStore {
+        &mut self.store
+    }
+
+    /// rate_limiter.rs:102-250 in one call.
+    pub fn rate_limit(
+        &mut self,
+        key: &str,
+        max_burst: i64,
+        count_per_period: i64,
+        period: i64,
+        quantity: i64,
+        now: SystemTime,
+    ) -> Result<(bool, RateLimitResult), CellError> {
+        let mut r = ffi::tc_result::default();
+        let rc = unsafe {
+            ffi::tc_rate_limit(self.store.e, key.as_ptr(), key.len(), max_burst, count_per_period, period, quantity, ns(now), &mut r)
+        };
+        if rc != 0 {
+            return Err(CellError::Internal(call_error(self.store.e, rc)));
+        }
+        let d = ffi::tc_decision {
+            remaining: r.remaining,
+            reset_after_ns: r.reset_after_ns,
+            retry_after_ns: r.retry_after_ns,
+            allowed: r.allowed,
+            status: r.status,
+            pad: [0; 6],
+        };
+        decode(&d, r.limit, quantity)
+    }
+
+    /// The requests of `reqs` applied in order -- bit for bit what calling `rate_limit` on each of them in turn
+    /// returns, duplicates of a key inside the slice included -- as one pass through the engine.
+    pub fn rate_limit_batch(&mut self, reqs: &[Request]) -> Vec<Result<(bool, RateLimitResult), CellError>> {
+        let mut out = Vec::with_capacity(reqs.len());
+        for chunk in reqs.chunks(self.store.max_batch.max(1)) {
+            self.batch_chunk(chunk, &mut out);
+        }
+        out
+    }
+
+    fn batch_chunk(&mut self, reqs: &[Request], out: &mut Vec<Result<(bool, RateLimitResult), CellError>>) {
+        let n = reqs.len();
+        if n == 0 {
+            return;
+        }
+        let mut arena: Vec<u8> = Vec::with_capacity(reqs.iter().map(|r| r.key.len()).sum());
+        let mut off: Vec<u32> = Vec::with_capacity(n + 1);
+        off.push(0);
+        for r in reqs {
+            arena.extend_from_slice(r.key.as_bytes());
+            off.push(arena.len() as u32);
+        }
+        if arena.is_empty() {
+            arena.push(0); // (a non-null arena pointer even when every key is empty)
+        }
+        let burst: Vec<i64> = reqs.iter().map(|r| r.max_burst).collect();
+        let count: Vec<i64> = reqs.iter().map(|r| r.count_per_period).collect();
+        let period: Vec<i64> = reqs.iter().map(|r| r.period).collect();
+        let qty: Vec<i64> = reqs.iter().map(|r| r.quantity).collect();
+        let now: Vec<i64> = reqs.iter().map(|r| ns(r.now)).collect();
+        let mut dec = vec![ffi::tc_decision::default(); n];
+        let b = ffi::tc_batch {
+            struct_size: std::mem::size_of::<ffi::tc_batch>() as u32,
+            flags: 0,
+            n: n as u64,
+            slot: std::ptr::null(),
+            key_bytes: arena.as_ptr(),
+            key_off: off.as_ptr(),
+            max_burst: burst.as_ptr(),
+            count_per_period: count.as_ptr(),
+            period: period.as_ptr(),
+            quantity: qty.as_ptr(),
+            now_ns: now.as_ptr(),
+            max_burst_scalar: 0,
+            count_per_period_scalar: 0,
+            period_scalar: 0,
+            quantity_scalar: 1,
+            now_ns_scalar: 0,
+            allowed: std::ptr::null_mut(),
+            allowed_bits: std::ptr::null_mut(),
+            limit: std::ptr::null_mut(),
+            remaining: std::ptr::null_mut(),
+            reset_after_ns: std::ptr::null_mut(),
+            retry_after_ns: std::ptr::null_mut(),
+            status: std::ptr::null_mut(),
+            result4: std::ptr::null_mut(),
+            decisions: dec.as_mut_ptr(),
+            order: std::ptr::null_mut(),
+        };
+        let rc = unsafe { ffi::tc_rate_limit_batch_keys(self.store.e, &b) };
+        if rc != 0 && rc != ffi::TC_E_TABLE_FULL {
+            // nothing was applied: every request of the chunk reports the call's failure
+            let msg = call_error(self.store.e, rc);
+            out.extend((0..n).map(|_| Err(CellError::Internal(msg.clone()))));
+            return;
+        }
+        // TC_E_TABLE_FULL: the keys that fit were applied, the others carry status Internal
+        out.extend((0..n).map(|i| decode(&dec[i], burst[i], qty[i])));
+    }
+}
