@@ -9,11 +9,17 @@ decided and applied against a 10 M-key resident store through the C ABI
 parameters (100, 1000/3600 s), quantity 1, one timestamp per batch,
 decisions-only output).  Duplicate keys inside a batch are honoured exactly.
 
-N > 1 (torchrun, one rank per GPU): the key space is hash-sharded, every rank
-owns 10 M keys and serves its own 1 Mi-request batch per step (weak scaling, no
-collective on the decision path); the per-GPU counter blocks are all-gathered
-over RCCL every METRICS_EVERY steps and after the last one, inside the timed
-region (the only exchange the path has: aggregate metrics).
+N > 1 (torchrun, one rank per GPU; BASELINE configs[3]): ONE global request stream
+over N x 10 M global key ids, N x 1 Mi requests per step (weak scaling).  Every rank
+is handed the global batch, keeps the requests whose keys it owns with the device
+partition kernel (tc_route_batch: owner and shard-local slot by a bijection of the
+global id space, stable) and decides them on its own engine -- no collective on the
+decision path, routing inside the timed region.  The per-GPU counter blocks are
+all-gathered over RCCL every METRICS_EVERY steps and after the last one, the
+per-GPU top-denied blocks once at the end, both inside the timed region (the only
+exchange the path has: aggregate metrics).  The line carries `per_gpu` (requests
+owned, allowed share, decisions/s): under Zipf the owner of the hottest key gets
+11.6 % of ALL traffic on top of its share.
 
 Prints ONE JSON line on rank 0.
 """
@@ -438,6 +444,125 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
     return also
 
 
+def run_sharded(a, t, W, dev, local, rank, world, dist):
+    """The N > 1 path (also taken with TC_BENCH_FORCE_DIST=1 on one GPU)."""
+    import torch
+    from throttlecrab_amd import sharded
+    B = a.batch
+    G = world * B                       # requests per global batch
+    cap_batch = min(G, 4 * B)           # an owner's share of a global batch, evaluated in chunks of at most this
+    eng = t.Engine(a.keys, cap_batch, device=local, fixed_params=(a.layout == "fixed"), track_denied=True)
+    eng.use_torch_stream()
+    eng.register_params_uniform(*W.REF_PARAMS)
+    nb = a.steps + a.warmup
+    n_distinct = min(nb, 8)
+    if a.workload == "zipf":
+        z = W.Zipf(world * a.keys)
+        host = [z.slots(G, seed=3, start=i * G) for i in range(n_distinct)]   # the same stream on every rank
+    else:
+        host = [W.uniform_slots(world * a.keys, G, seed=2, start=i * G) for i in range(n_distinct)]
+    d_global = [torch.from_numpy(h.astype(np.int32)).to(dev) for h in host]
+    RING = 8  # routed slot columns stay untouched while up to pipeline-depth batches are in flight
+    ring = [(torch.empty(G, dtype=torch.int32, device=dev), None, torch.zeros(world, dtype=torch.int32, device=dev)) for _ in range(RING)]
+    counts_host = [torch.empty(world, dtype=torch.int32).pin_memory() for _ in range(RING)]
+    ready = [torch.cuda.Event() for _ in range(RING)]
+    out = t.BatchResult()
+    cnt_view = sharded.device_counter_view(eng)
+    gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
+    top_gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64, device=dev)
+    decided = 0
+
+    def route(i):
+        r = i % RING
+        eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r])
+        counts_host[r].copy_(ring[r][2], non_blocking=True)
+        ready[r].record()
+
+    def evaluate(i, last=False, metrics=True):
+        nonlocal decided
+        r = i % RING
+        ready[r].synchronize()          # recorded a whole step ago: no stall in steady state
+        mine = int(counts_host[r][rank])
+        for lo in range(0, mine, cap_batch):
+            hi = min(mine, lo + cap_batch)
+            eng.rate_limit_batch_slots(ring[r][0][lo:hi], registered=True, quantity=1, now_ns=W.T0_NS + i * 1_000_000,
+                                       want=("allowed",), out=out, inputs_ready=True)
+        decided += mine
+        if not metrics:
+            return
+        if i % METRICS_EVERY == METRICS_EVERY - 1 or last:
+            eng.counters_refresh()
+            dist.all_gather_into_tensor(gathered, cnt_view)
+        if last:  # the optional part of the metrics payload: every shard's most denied keys as (global id, count)
+            block = torch.from_numpy(sharded.pack_top_denied(eng.top_denied(sharded.TOPK), rank, world, a.keys)).to(dev)
+            dist.all_gather_into_tensor(top_gathered, block)
+
+    # The router runs LOOKAHEAD global batches ahead of the evaluation: the host needs a batch's count (how many of
+    # its requests this rank owns) before it can enqueue the evaluation, and that read must not drain the stream.
+    LOOKAHEAD = 4
+    it = 0
+    for j in range(LOOKAHEAD):
+        route(j)
+    for _ in range(a.warmup):
+        route(it + LOOKAHEAD)
+        evaluate(it)
+        it += 1
+    dist.barrier()
+    torch.cuda.synchronize()
+    decided = 0
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        route(it + LOOKAHEAD)   # (the last LOOKAHEAD of them are routed for nothing: inside the timing, against us)
+        evaluate(it, last=(k == a.steps - 1))
+        it += 1
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt_mine = time.perf_counter() - t0
+    tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dt = float(tm.item())
+    c = eng.counters()
+    mine = torch.tensor([decided, c["allowed"], c["denied"]], dtype=torch.int64, device=dev)
+    everyone = torch.zeros(world * 3, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(everyone, mine)
+    ev = everyone.view(world, 3).cpu().numpy()
+    total_decided = int(ev[:, 0].sum())
+    assert total_decided == a.steps * G, (total_decided, a.steps * G)   # every request of the global stream has one owner
+    per_gpu = [{"rank": r, "decisions": int(ev[r, 0]), "share_of_traffic": float(ev[r, 0]) / max(1, total_decided),
+                "decisions_per_s": float(ev[r, 0]) / dt,
+                "allowed_fraction_since_start": float(ev[r, 1]) / max(1, int(ev[r, 1] + ev[r, 2]))} for r in range(world)]
+    res = {"value": total_decided / dt, "ms_per_step": 1e3 * dt / a.steps, "per_gpu": per_gpu,
+           "imbalance_max_over_mean": float(ev[:, 0].max()) / max(1.0, float(ev[:, 0].mean())),
+           "allowed_fraction": float(ev[:, 1].sum()) / max(1, int(ev[:, 1].sum() + ev[:, 2].sum())),
+           "metrics_exchange": {"counter_block_bytes_per_gpu": 8 * int(cnt_view.numel()), "every_steps": METRICS_EVERY,
+                                "top_denied_block_bytes_per_gpu": 16 * sharded.TOPK, "top_denied_exchanges": 1,
+                                "top_denied_global": sharded.merge_top_denied(top_gathered.cpu().numpy(), 5)}}
+    # roofline of this rank's evaluation (same kernels as the N = 1 run, fed by the router): HIP events per kernel
+    steps_p = min(a.steps, 20)
+    decided = 0
+    eng.profile_enable(True)
+    for _ in range(steps_p):
+        route(it + LOOKAHEAD)
+        evaluate(it, metrics=False)
+        it += 1
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    stages = {k: {"kernel": KERNEL_OF_STAGE[k], "launches_per_batch": calls / steps_p, "avg_ms": ms / calls, "per_batch_ms": ms / steps_p}
+              for k, (ms, calls) in prof.items() if calls}
+    if stages:
+        alg = ALG_BYTES_PER_DECISION * decided / steps_p
+        dom = max(stages, key=lambda k: stages[k]["per_batch_ms"])
+        ach = alg / (stages[dom]["per_batch_ms"] * 1e-3) / 1e9
+        res["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "rank": rank, "algorithmic_bytes_per_batch": alg,
+                           "stage": dom, "kernel": stages[dom]["kernel"], "launches_per_batch": stages[dom]["launches_per_batch"],
+                           "avg_ms": stages[dom]["avg_ms"], "per_batch_ms": stages[dom]["per_batch_ms"], "achieved": ach,
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "stages": {"pipelined": stages},
+                           "whole_step_frac": ALG_BYTES_PER_DECISION * G / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world)}
+    eng.close()
+    return res
+
+
 def main():
     a = parse()
     import torch
@@ -461,8 +586,29 @@ def main():
         local = 0
     dev = torch.device(f"cuda:{local}")
 
-    # per-rank request stream over this rank's shard of the key space (slots are shard-local ids)
-    main_res, eng, d_batches, dt = measure_stream(a, t, W, a.workload, dev, local, rank, 100 * rank, dist, world)
+    if dist is not None:
+        sh = run_sharded(a, t, W, dev, local, rank, world, dist)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "GCRA decisions/sec, 10M keys per GPU", "value": sh["value"], "unit": "decisions/s", "n_gpus": world,
+                "steps": a.steps, "warmup": a.warmup, "ms_per_step": sh["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "int64", "data": "synthetic",
+                "config": {"workload": f"configs[3]: {world} x {a.keys} keys hash-sharded across {world} GPU(s), ONE global {a.workload} "
+                                       f"request stream of {world} x {a.batch} requests per step routed on the device (tc_route_batch), "
+                                       f"params (100,1000/3600s), q=1; RCCL all-gather of the metrics only",
+                           "keys_per_gpu": a.keys, "global_batch": world * a.batch, "stream": a.workload,
+                           "parallelism": f"hash-shard x{world}", "outputs": "allowed u8 (decisions only)",
+                           "resident_state": a.layout, "metrics_allgather_every": METRICS_EVERY},
+                "allowed_fraction": sh["allowed_fraction"], "per_gpu": sh["per_gpu"],
+                "imbalance_max_over_mean": sh["imbalance_max_over_mean"], "metrics_exchange": sh["metrics_exchange"],
+                "roofline": sh.get("roofline"), "cpu_baseline": None,
+                "note": "cpu_baseline is reported by the N = 1 run; roofline here is rank 0's evaluation of the requests it owns "
+                        "(the router's three small kernels over the global batch are not in it)"}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
+
+    main_res, eng, d_batches, dt = measure_stream(a, t, W, a.workload, dev, local, rank, 0, None, 1)
     result = {
         "metric": "GCRA decisions/sec, 10M keys", "value": main_res["value"], "unit": "decisions/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_res["ms_per_step"],

@@ -305,6 +305,35 @@ int tc_denied_reset(tc_engine* e);
 int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,
                  uint32_t* key_off);
 
+/* ---- multi-GPU: routing a global request stream to the GPU that owns each key -----------------------------
+ * The reference has no distributed mode ("use client-side sharding by key", README.md:247-249).  A key space of
+ * world * keys_per_shard GLOBAL ids is sharded without a routing table: a bijection of that range sends id to
+ * (owner = x mod world, shard-local slot = x div world), x = (id * mul + add) mod (world * keys_per_shard), mul
+ * coprime with the modulus -- every shard gets exactly keys_per_shard dense slots.  tc_route_batch keeps, of a
+ * batch of global ids in device memory, the requests a destination owns (stable: the requests of a key keep
+ * their order) as shard-local slots ready for tc_rate_limit_batch_slots; asynchronous on the engine's stream.
+ * No collective is involved: each GPU filters the stream it is handed. */
+typedef struct tc_route {
+    uint32_t struct_size;     /* = sizeof(tc_route) */
+    uint32_t world;           /* number of shards (GPUs), 1..64 */
+    uint64_t keys_per_shard;  /* slots of every shard (the engines' capacity) */
+    uint64_t n;               /* requests in the global batch (<= the engine's max_batch * world) */
+    const uint32_t* global_id; /* [n] device: global key ids in [0, world * keys_per_shard) (others: taken modulo) */
+    int32_t only;             /* >= 0: write that destination's requests only, from out_slot[0];
+                               * -1: every destination's segment, one after the other (start of d = sum of counts before d) */
+    int32_t reserved0;
+    uint32_t* out_slot;       /* [n] device: shard-local slots */
+    uint32_t* out_pos;        /* [n] device or NULL: position of each kept request in the global batch */
+    uint32_t* out_count;      /* [world] device: requests per destination (all of them, whatever `only` is) */
+} tc_route;
+int tc_route_batch(tc_engine* e, const tc_route* r);
+/* The same map on the host: owner and shard-local slot of n global ids (either output may be NULL), and its
+ * inverse (global id of slot `slot` of shard `owner`).  No device needed. */
+int tc_route_host(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* global_id, uint32_t* owner,
+                  uint32_t* slot);
+int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* owner, const uint32_t* slot,
+                     uint64_t* global_id);
+
 /* Number of internal invariant violations the kernels have flagged since creation (always 0
  * unless there is a bug; the parity tests assert it). */
 int tc_selfcheck(tc_engine* e, uint64_t* violations);

@@ -110,6 +110,20 @@ pub struct tc_result {
     pub status: u8,
 }
 
+#[repr(C)]
+pub struct tc_route {
+    pub struct_size: u32,
+    pub world: u32,
+    pub keys_per_shard: u64,
+    pub n: u64,
+    pub global_id: *const u32,
+    pub only: i32,
+    pub reserved0: i32,
+    pub out_slot: *mut u32,
+    pub out_pos: *mut u32,
+    pub out_count: *mut u32,
+}
+
 extern "C" {
     pub fn tc_abi_version() -> u32;
     pub fn tc_engine_create(cfg: *const tc_config, err: *mut c_int) -> *mut tc_engine;
@@ -155,6 +169,9 @@ extern "C" {
         now_ns: i64,
         was_set: *mut c_int,
     ) -> c_int;
+    pub fn tc_route_batch(e: *mut tc_engine, r: *const tc_route) -> c_int;
+    pub fn tc_route_host(world: u32, keys_per_shard: u64, n: u64, global_id: *const u32, owner: *mut u32, slot: *mut u32) -> c_int;
+    pub fn tc_route_inverse(world: u32, keys_per_shard: u64, n: u64, owner: *const u32, slot: *const u32, global_id: *mut u64) -> c_int;
     pub fn tc_snapshot_save(e: *mut tc_engine, path: *const c_char) -> c_int;
     pub fn tc_snapshot_load(e: *mut tc_engine, path: *const c_char) -> c_int;
 }

@@ -1,7 +1,7 @@
-"""N > 1 path with the real engine: two processes (both on cuda:0 -- the GPU box has one device),
-each owning the keys that hash to it, each deciding only its own requests on its own engine; the
-counter blocks are all-gathered (gloo here, RCCL in bench.py).  The union of the shards must equal
-one sequential pass of the oracle over the whole stream."""
+"""N > 1 path with the real engine: two processes (both on cuda:0 -- the GPU box has one device), each handed the
+GLOBAL stream, each keeping the requests it owns with the device partition kernel (tc_route_batch) and
+deciding them on its own engine; the counter blocks and the top-denied blocks are all-gathered (gloo here, RCCL
+in bench.py).  The union of the shards must equal one sequential pass of the oracle over the whole stream."""
 import os
 import socket
 import sys
@@ -30,29 +30,31 @@ def _worker(rank, world, port, q):
     from throttlecrab_amd import sharded, workload as W
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
-    n_keys, n, nb = 20000, 60000, 4
-    eng = t.Engine(n_keys, n)
+    n_keys, n, nb = 20000, 60000, 4  # keys per shard; requests per global batch
+    eng = t.Engine(n_keys, n, track_denied=True)
     eng.use_torch_stream()
-    local = sharded.LocalSlots()
     allowed_global = np.zeros(nb * n, np.int64)
     for b in range(nb):
-        gids = W.Zipf(n_keys).slots(n, start=b * n).astype(np.uint64) + np.uint64(10**9)
-        pos, mine = sharded.partition(gids, world, rank)
-        slots = local.resolve(mine)
-        d = torch.from_numpy(slots.astype(np.int32)).cuda()
+        gids = W.Zipf(world * n_keys).slots(n, start=b * n)   # global key ids, the same stream on every rank
+        d = torch.from_numpy(gids.astype(np.int32)).cuda()
+        slots, pos, counts = eng.route_batch(d, world, only=rank, want_pos=True)   # the device partition kernel
         torch.cuda.synchronize()
-        res = eng.rate_limit_batch_slots(d, max_burst=5, count_per_period=50, period=60, quantity=1,
+        mine = int(counts[rank].item())
+        res = eng.rate_limit_batch_slots(slots[:mine].contiguous(), max_burst=5, count_per_period=50, period=60, quantity=1,
                                          now_ns=W.T0_NS + b * 10**8, want=("allowed",), inputs_ready=True)
         torch.cuda.synchronize()
-        allowed_global[b * n + pos] = res.allowed.cpu().numpy()
+        allowed_global[b * n + pos[:mine].cpu().numpy()] = res.allowed.cpu().numpy()
     c = eng.counters()
     block = torch.tensor([c[k] for k in ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")],
                          dtype=torch.int64)
     per_rank, totals = sharded.all_gather_counters(block, dist, world)
+    top = torch.from_numpy(sharded.pack_top_denied(eng.top_denied(sharded.TOPK), rank, world, n_keys))
+    gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64)
+    dist.all_gather_into_tensor(gathered, top)
     tt = torch.from_numpy(allowed_global)
     dist.all_reduce(tt)
     if rank == 0:
-        q.put((totals, per_rank.tolist(), tt.numpy()))
+        q.put((totals, per_rank.tolist(), tt.numpy(), sharded.merge_top_denied(gathered.numpy(), 10)))
     dist.barrier()
     dist.destroy_process_group()
     eng.close()
@@ -68,17 +70,20 @@ def test_two_engines_two_processes_match_single_pass():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    totals, per_rank, allowed = q.get(timeout=300)
+    totals, per_rank, allowed, top = q.get(timeout=300)
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
     n_keys, n, nb = 20000, 60000, 4
-    orc = O.DenseOracle(n_keys)
-    ref = []
+    orc = O.DenseOracle(2 * n_keys)  # one pass, keyed by the global id
+    ref, denied = [], np.zeros(2 * n_keys, np.int64)
     for b in range(nb):
-        gids = W.Zipf(n_keys).slots(n, start=b * n)
-        ref.append(orc.batch_slots(gids, 5, 50, 60, 1, W.T0_NS + b * 10**8).allowed.astype(np.int64))
+        gids = W.Zipf(2 * n_keys).slots(n, start=b * n)
+        r = orc.batch_slots(gids, 5, 50, 60, 1, W.T0_NS + b * 10**8)
+        ref.append(r.allowed.astype(np.int64))
+        np.add.at(denied, gids[r.allowed == 0], 1)
     ref = np.concatenate(ref)
+    assert top == sorted(((int(g), int(c)) for g, c in enumerate(denied) if c), key=lambda t: (-t[1], t[0]))[:10]
     assert np.array_equal(allowed, ref)
     assert totals["total"] == nb * n and totals["allowed"] == int(ref.sum())
     assert per_rank[0][0] + per_rank[1][0] == nb * n and min(per_rank[0][0], per_rank[1][0]) > 0.2 * nb * n

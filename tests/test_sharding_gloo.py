@@ -21,33 +21,48 @@ def _free_port():
     return p
 
 
+N_KEYS, N_REQ = 5000, 40000  # keys per shard, requests in the global stream
+
+
+def _global_stream(world):
+    """one global Zipf stream over the world * N_KEYS global key ids (the same on every rank)"""
+    from throttlecrab_amd import workload as W
+    gids = W.Zipf(world * N_KEYS).slots(N_REQ).astype(np.uint32)
+    now = W.T0_NS + (np.arange(N_REQ) // 1000) * 1_000_000
+    return gids, now
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch
     import torch.distributed as dist
     from oracle import oracle as O
-    from throttlecrab_amd import sharded, workload as W
+    from throttlecrab_amd import sharded
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_keys, n = 5000, 40000
-    gids = W.Zipf(n_keys).slots(n).astype(np.uint64) + np.uint64(10**9)  # global key ids
-    now = W.T0_NS + (np.arange(n) // 1000) * 1_000_000
-    pos, mine = sharded.partition(gids, world, rank)
-    slots = sharded.LocalSlots().resolve(mine)
-    orc = O.DenseOracle(n_keys)
+    gids, now = _global_stream(world)
+    # routing: the host mirror of the device partition kernel (tc_route_host == rt::k_route_scatter's map)
+    pos, slots = sharded.shard_requests(gids, world, rank, N_KEYS)
+    orc = O.DenseOracle(N_KEYS)
     res = orc.batch_slots(slots, 5, 50, 60, 1, now[pos])
     block = torch.zeros(8, dtype=torch.int64)
     block[0], block[1], block[2] = len(pos), int(res.allowed.sum()), int((1 - res.allowed).sum())
     per_rank, totals = sharded.all_gather_counters(block, dist, world)
-    allowed_global = np.zeros(n, np.int64)
+    # the optional part of the metrics payload: every shard's most denied keys, as (global key id, count)
+    denied = np.bincount(slots[res.allowed == 0], minlength=N_KEYS)
+    top = sorted(((int(s), int(c)) for s, c in enumerate(denied) if c), key=lambda t: (-t[1], t[0]))[: sharded.TOPK]
+    mine = torch.from_numpy(sharded.pack_top_denied(top, rank, world, N_KEYS))
+    gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64)
+    dist.all_gather_into_tensor(gathered, mine)
+    allowed_global = np.zeros(N_REQ, np.int64)
     allowed_global[pos] = res.allowed
     t = torch.from_numpy(allowed_global)
     dist.all_reduce(t)  # disjoint shards: sum == union
-    cover = torch.zeros(n, dtype=torch.int64)
+    cover = torch.zeros(N_REQ, dtype=torch.int64)
     cover[torch.from_numpy(pos)] = 1
     dist.all_reduce(cover)
     if rank == 0:
-        q.put((totals, per_rank.tolist(), t.numpy().tolist(), cover.numpy().tolist()))
+        q.put((totals, per_rank.tolist(), t.numpy().tolist(), cover.numpy().tolist(), sharded.merge_top_denied(gathered.numpy(), 20)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -55,27 +70,49 @@ def _worker(rank, world, port, q):
 def test_two_rank_sharding_matches_single_pass():
     import torch.multiprocessing as mp
     from oracle import oracle as O
-    from throttlecrab_amd import workload as W
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    totals, per_rank, allowed, cover = q.get(timeout=180)
+    totals, per_rank, allowed, cover, top = q.get(timeout=180)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    n_keys, n = 5000, 40000
-    gids = W.Zipf(n_keys).slots(n)
-    now = W.T0_NS + (np.arange(n) // 1000) * 1_000_000
-    ref = O.DenseOracle(n_keys).batch_slots(gids, 5, 50, 60, 1, now)
+    gids, now = _global_stream(2)
+    ref = O.DenseOracle(2 * N_KEYS).batch_slots(gids, 5, 50, 60, 1, now)  # one pass, keyed by the global id
     assert all(c == 1 for c in cover), "every request is owned by exactly one rank"
     assert np.array_equal(np.array(allowed), ref.allowed.astype(np.int64))
-    assert totals["total"] == n and totals["allowed"] == int(ref.allowed.sum())
-    assert totals["allowed"] + totals["denied"] == n
-    assert len(per_rank) == 2 and per_rank[0][0] + per_rank[1][0] == n
-    assert min(per_rank[0][0], per_rank[1][0]) > 0.2 * n  # both shards get real work
+    assert totals["total"] == N_REQ and totals["allowed"] == int(ref.allowed.sum())
+    assert totals["allowed"] + totals["denied"] == N_REQ
+    assert len(per_rank) == 2 and per_rank[0][0] + per_rank[1][0] == N_REQ
+    assert min(per_rank[0][0], per_rank[1][0]) > 0.2 * N_REQ  # both shards get real work
+    # the merged top-denied block == the most denied GLOBAL keys of the single pass
+    denied = np.bincount(gids[ref.allowed == 0], minlength=2 * N_KEYS)
+    want = sorted(((int(g), int(c)) for g, c in enumerate(denied) if c), key=lambda t: (-t[1], t[0]))[:20]
+    assert top == want
+
+
+def test_route_is_a_bijection_onto_dense_shards():
+    """tc_route_host: every global id of [0, world * keys_per_shard) gets its own (owner, slot), every shard exactly
+    keys_per_shard slots; the inverse map returns the id; consecutive ids spread over the owners"""
+    from throttlecrab_amd import sharded
+    for world, cap in ((1, 97), (2, 5000), (3, 77), (8, 4096), (64, 31)):
+        ids = np.arange(world * cap, dtype=np.uint32)
+        owner, slot = sharded.route(ids, world, cap)
+        assert owner.max() == world - 1 and slot.max() == cap - 1
+        assert len(np.unique(owner.astype(np.uint64) * cap + slot)) == world * cap
+        assert np.array_equal(np.bincount(owner, minlength=world), np.full(world, cap))
+        assert np.array_equal(sharded.route_inverse(owner, slot, world, cap), ids.astype(np.uint64))
+        if world > 1:
+            assert (owner[:-1] != owner[1:]).mean() > 0.5
+    # a large key space: balanced owners for a random draw
+    owner, _ = sharded.route(np.random.default_rng(3).integers(0, 8 * 10**7, 200000).astype(np.uint32), 8, 10**7)
+    cnt = np.bincount(owner, minlength=8)
+    assert cnt.min() > 0.95 * 200000 / 8 and cnt.max() < 1.05 * 200000 / 8
+    with pytest.raises(ValueError):
+        sharded.route(np.zeros(1, np.uint32), 65, 10)
 
 
 def test_owner_is_stable_and_balanced():

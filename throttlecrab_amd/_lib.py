@@ -45,6 +45,12 @@ class tc_batch(C.Structure):
                 ("status", C.c_void_p), ("result4", C.c_void_p), ("decisions", C.c_void_p), ("order", C.c_void_p)]
 
 
+class tc_route(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("world", C.c_uint32), ("keys_per_shard", C.c_uint64), ("n", C.c_uint64),
+                ("global_id", C.c_void_p), ("only", C.c_int32), ("reserved0", C.c_int32), ("out_slot", C.c_void_p),
+                ("out_pos", C.c_void_p), ("out_count", C.c_void_p)]
+
+
 class tc_result(C.Structure):
     _fields_ = [("limit", C.c_int64), ("remaining", C.c_int64), ("reset_after_ns", C.c_int64),
                 ("retry_after_ns", C.c_int64), ("allowed", C.c_uint8), ("status", C.c_uint8)]
@@ -86,6 +92,9 @@ SYMBOLS = {
     "tc_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_snapshot_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_snapshot_load": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "tc_route_batch": (C.c_int, [C.c_void_p, C.POINTER(tc_route)]),
+    "tc_route_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tc_route_inverse": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_slot_keys": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 

@@ -37,6 +37,7 @@
 #include "eval_kernels.hpp"
 #include "bucket_path.hpp"
 #include "maintenance_kernels.hpp"
+#include "route_kernels.hpp"
 
 using tc::Cell;
 using tc::RateClass;
@@ -168,6 +169,8 @@ struct tc_engine {
     std::vector<hipEvent_t> async_pool;
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
+    uint32_t* route_ws = nullptr; // tc_route_batch scratch (lazy): tile counts | totals | starts
+    size_t route_ws_words = 0;
 
     // bucket path (bucket_path.hpp): uniform batches are partitioned by key range and ranked per bucket instead of
     // sorted.  Such a batch is enqueued on BOTH paths; the partition's largest bucket (a word in device memory,
@@ -601,7 +604,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->bp_park, e->cells, e->tat8, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
+    void* ptrs[] = {e->route_ws, e->bp_park, e->cells, e->tat8, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};
@@ -2048,6 +2051,72 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     TC_HIP(e, hipMemcpy(e->counters, c.data(), cnt_words * sizeof(unsigned long long), hipMemcpyHostToDevice));
     e->batches = h.batches;
     e->sealed = true; // (fixed layout: the loaded state was written under the loaded plans)
+    return TC_E_OK;
+}
+
+// ---- routing of a global stream (route_kernels.hpp) --------------------------------------------------
+extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
+    if (!e || !rp || rp->struct_size < sizeof(tc_route)) return TC_E_INVALID_ARG;
+    const tc_route& r = *rp;
+    rt::Map m;
+    if (!rt::make_map(r.world, r.keys_per_shard, &m)) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: world must be 1..64 and world * keys_per_shard < 2^39");
+    if (r.only >= (int32_t)r.world || r.only < -1) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: `only` is not a destination");
+    if (!r.global_id || !r.out_slot || !r.out_count) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: NULL array");
+    if (r.n == 0 || r.n > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: n out of range");
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
+    const uint32_t n = (uint32_t)r.n, tiles = (n + rt::TILE - 1) / rt::TILE;
+    const size_t words = (size_t)tiles * r.world + 2 * (size_t)rt::MAX_WORLD + 2;
+    if (words > e->route_ws_words) {
+        if (e->route_ws) {
+            TC_HIP(e, hipStreamSynchronize(s));
+            (void)hipFree(e->route_ws);
+            e->route_ws = nullptr;
+            e->route_ws_words = 0;
+        }
+        TC_HIP(e, hipMalloc(&e->route_ws, words * 2 * sizeof(uint32_t)));
+        e->route_ws_words = words * 2;
+    }
+    rt::Work w;
+    w.tile_cnt = e->route_ws;
+    w.totals = r.out_count;
+    w.starts = e->route_ws + (size_t)tiles * r.world;
+    hipLaunchKernelGGL(rt::k_route_count, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w);
+    hipLaunchKernelGGL(rt::k_route_scan, dim3(1), dim3(rt::MAX_WORLD), 0, s, w, tiles, r.world, (int)r.only);
+    hipLaunchKernelGGL(rt::k_route_scatter, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos);
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
+extern "C" int tc_route_host(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* global_id, uint32_t* owner,
+                             uint32_t* slot) {
+    rt::Map m;
+    if (!rt::make_map(world, keys_per_shard, &m) || (n && !global_id)) return TC_E_INVALID_ARG;
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t x = rt::permute(m, global_id[i]);
+        if (owner) owner[i] = (uint32_t)(x % world);
+        if (slot) slot[i] = (uint32_t)(x / world);
+    }
+    return TC_E_OK;
+}
+
+extern "C" int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* owner, const uint32_t* slot,
+                                uint64_t* global_id) {
+    rt::Map m;
+    if (!rt::make_map(world, keys_per_shard, &m) || (n && (!owner || !slot || !global_id))) return TC_E_INVALID_ARG;
+    // mul^-1 mod modulus by the extended Euclid (mul is coprime with the modulus by construction)
+    __int128 t0 = 0, t1 = 1, r0 = (__int128)m.modulus, r1 = (__int128)m.mul;
+    while (r1 != 0) {
+        const __int128 q = r0 / r1, t2 = t0 - q * t1, r2 = r0 - q * r1;
+        t0 = t1, t1 = t2, r0 = r1, r1 = r2;
+    }
+    const uint64_t inv = (uint64_t)((t0 % (__int128)m.modulus + (__int128)m.modulus) % (__int128)m.modulus);
+    for (uint64_t i = 0; i < n; ++i) {
+        if (owner[i] >= world || slot[i] >= keys_per_shard) return TC_E_INVALID_ARG;
+        const uint64_t x = (uint64_t)slot[i] * world + owner[i];
+        const uint64_t y = (x + m.modulus - m.add % m.modulus) % m.modulus;
+        global_id[i] = (uint64_t)(((unsigned __int128)y * inv) % m.modulus);
+    }
     return TC_E_OK;
 }
 

@@ -309,6 +309,28 @@ class Engine:
                 self._async_keep.append((keep, k2))
         return res
 
+    def route_batch(self, global_ids, world: int, only: int = -1, want_pos: bool = False, out=None):
+        """tc_route_batch: of a CUDA tensor of global key ids (int32 / uint32), keep what destination `only` owns
+        (only = -1: every destination's segment, one after the other) as shard-local slots, in request order.
+        -> (slots int32[n], pos int32[n] or None, counts int32[world]) CUDA tensors; the first counts[only]
+        (resp. sum(counts)) entries are valid.  Asynchronous on the engine's stream: read `counts` after a sync.
+        `out`: (slots, pos or None, counts) tensors to reuse."""
+        import torch
+        assert global_ids.is_cuda and global_ids.is_contiguous() and global_ids.dtype in (torch.int32, torch.uint32)
+        n = global_ids.numel()
+        dev = global_ids.device
+        if out is None:
+            out = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev) if want_pos else None,
+                   torch.zeros(world, dtype=torch.int32, device=dev))
+        slots, pos, counts = out
+        r = L.tc_route()
+        r.struct_size = C.sizeof(L.tc_route)
+        r.world, r.keys_per_shard, r.n, r.only = world, self.capacity, n, only
+        r.global_id, r.out_slot, r.out_count = global_ids.data_ptr(), slots.data_ptr(), counts.data_ptr()
+        r.out_pos = pos.data_ptr() if pos is not None else None
+        self._check(self._lib.tc_route_batch(self._h, C.byref(r)))
+        return slots, pos, counts
+
     def rate_limit(self, key: bytes, max_burst: int, count_per_period: int, period: int, quantity: int, now_ns: int):
         """RateLimiter::rate_limit -> (status, allowed, limit, remaining, reset_after_ns, retry_after_ns)."""
         r = L.tc_result()
