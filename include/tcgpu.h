@@ -57,7 +57,10 @@ enum {
 enum {
     TC_E_OK = 0,
     TC_E_INVALID_ARG = -1,
-    TC_E_HIP = -2,            /* HIP runtime error; see tc_last_error() */
+    TC_E_HIP = -2,            /* HIP runtime error; see tc_last_error().  Raised while a batch's inputs were being staged:
+                               * nothing was applied and the engine is usable.  Raised by a RESULT copy (after the
+                               * evaluation was enqueued): the batch was applied but its results are lost -- treat the
+                               * engine as ahead of the caller (reload a snapshot, or drop it) */
     TC_E_NOMEM = -3,
     TC_E_BATCH_TOO_LARGE = -4,
     TC_E_TABLE_FULL = -5,     /* string mode: no free slot / arena space for a new key */
@@ -337,6 +340,10 @@ int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_t n, const 
 /* Number of internal invariant violations the kernels have flagged since creation (always 0
  * unless there is a bug; the parity tests assert it). */
 int tc_selfcheck(tc_engine* e, uint64_t* violations);
+
+/* Test hook (error paths): the nth host <-> device staging copy from now fails with TC_E_HIP instead of being
+ * issued; 0 disarms.  Not for production use. */
+int tc_debug_fail_copy(tc_engine* e, uint32_t nth);
 
 /* Checkpoint / restore of everything resident (state cells, rate plans, denial counters, in
  * string mode the key table, plus the counter block).  The reference keeps its state in memory

@@ -1,0 +1,179 @@
+"""Error paths and forward progress.
+* A staging copy that fails inside a batch (tc_debug_fail_copy) must fail the call with TC_E_HIP, apply nothing,
+  and leave the engine fully usable -- in every batch path that stages host data (synchronous, TC_B_ASYNC,
+  string keys, pipelined).
+* The engine's wait loops (radix look-back, direct stores of k_eval_sorted, hand-over chain of k_eval_general)
+  each wait only for blocks dispatched earlier.  Two processes drive two engines on ONE device with the
+  batches that lean on those waits hardest (hot keys with runs of 100 000 allowed requests crossing ~1 600
+  waves, per-request timestamps, skewed uniform batches), so that their kernels contend for the same CUs;
+  every result is checked against the oracle and the spin watchdog (tc_selfcheck) must stay silent."""
+import os
+import socket
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from tests.test_gpu_slots import FIELDS, T0, _oracle, assert_same, assert_state_same
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_failed_staging_copy_applies_nothing_and_engine_goes_on():
+    import throttlecrab_amd as t
+    from throttlecrab_amd import _lib as L
+    cap, n = 5000, 20000
+    rng = np.random.default_rng(8)
+    eng, orc = t.Engine(cap, n), _oracle(cap)
+    eng.check_on_close = True
+    eng.register_params_uniform(5, 10, 60)
+
+    def batch(general):
+        slots = ((rng.zipf(1.3, n) * 2654435761) % cap).astype(np.uint32)
+        if general:
+            return slots, rng.integers(0, 3, n), T0 + rng.integers(0, 10**9, n)
+        return slots, 1, T0 + int(rng.integers(0, 10**9))
+
+    def pinned(slots, q, now):
+        s = eng.host_alloc(n, np.uint32)
+        s[:] = slots
+        cols = []
+        for v in (q, now):
+            if isinstance(v, np.ndarray):
+                a = eng.host_alloc(n, np.int64)
+                a[:] = v
+                cols.append(a)
+            else:
+                cols.append(v)
+        return s, cols[0], cols[1]
+
+    step = 0
+    for general in (False, True):
+        for path in ("sync", "async"):
+            for nth in (1, 2, 3):
+                slots, q, now = batch(general)
+                before = eng.counters()
+                state0 = eng.read_state(0, cap)
+                eng.debug_fail_copy(nth)
+                failed = False
+                try:
+                    if path == "sync":
+                        eng.rate_limit_batch_slots(slots, registered=True, quantity=q, now_ns=now)
+                    else:
+                        s, qq, nn = pinned(slots, q, now)
+                        out = t.BatchResult(**{f: eng.host_alloc(n, np.uint8 if f in ("allowed", "status") else np.int64) for f in FIELDS})
+                        eng.rate_limit_batch_slots(s, registered=True, quantity=qq, now_ns=nn, out=out, async_=True)
+                        eng.wait_batches(0)
+                except t.TcError as err:
+                    assert err.code == L.TC_E_HIP
+                    failed = True
+                eng.debug_fail_copy(0)
+                eng.synchronize()
+                if failed:
+                    # (a failure in an INPUT copy: nothing was applied; in a result copy the batch WAS applied -- the
+                    # documented exception -- which the oracle then has to follow)
+                    after = eng.counters()
+                    state1 = eng.read_state(0, cap)
+                    applied = after["total"] != before["total"]
+                    if not applied:
+                        assert np.array_equal(state0[0], state1[0]) and np.array_equal(state0[1], state1[1])
+                        assert after["batches"] == before["batches"]
+                    else:
+                        orc.batch_slots(slots, 5, 10, 60, q, now)
+                else:
+                    orc.batch_slots(slots, 5, 10, 60, q, now)   # fewer copies in this path than nth: the batch went through
+                # the engine goes on, bit-exact
+                slots, q, now = batch(general)
+                ref = orc.batch_slots(slots, 5, 10, 60, q, now)
+                assert_same(eng.rate_limit_batch_slots(slots, registered=True, quantity=q, now_ns=now), ref, f"after {path}/{general}/{nth}")
+                assert_state_same(eng, orc, slots[::3])
+                step += 1
+    eng.close()
+
+    # string keys: the key arena's staging copy fails
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    eng = t.Engine(20000, 8192, key_mode=True)
+    eng.check_on_close = True
+    orc = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
+    for nth in (1, 2):
+        kb, ko = W.string_keys(rng.integers(0, 9000, 5000))
+        before = eng.counters()
+        eng.debug_fail_copy(nth)
+        with pytest.raises(t.TcError) as ei:
+            eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + nth)
+        assert ei.value.code == L.TC_E_HIP
+        eng.debug_fail_copy(0)
+        after = eng.counters()
+        assert (after["keys_inserted"], after["total"], after["batches"]) == (before["keys_inserted"], before["total"], before["batches"])
+        kb, ko = W.string_keys(rng.integers(0, 9000, 5000))
+        ref = orc.batch_keys(kb, ko, 5, 10, 60, 1, T0 + 10 + nth)
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 10 + nth)
+        for f in FIELDS:
+            assert np.array_equal(getattr(res, f).astype(np.int64), getattr(ref, f).astype(np.int64)), (nth, f)
+    eng.close()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _contender(rank, seconds, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    torch.cuda.set_device(0)
+    cap, n = 200_000, 1 << 18
+    rng = np.random.default_rng(100 + rank)
+    eng, orc = t.Engine(cap, n), O.DenseOracle(cap)
+    eng.use_torch_stream()
+    eng.register_params_uniform(200_000, 10**9, 1)   # burst 200 000, 1 ns apart: runs of 100 000 allowed requests
+    tt = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).cuda()
+    t_end, rounds, bad = time.time() + seconds, 0, 0
+    while time.time() < t_end:
+        kind = rounds % 3
+        slots = rng.integers(0, cap, n).astype(np.uint32)
+        hot = rng.random(n) < 0.4
+        slots[hot] = 7 + rank            # ~105 000 requests of one key: >1 600 waves, all allowed
+        base = T0 + rounds * 10**9
+        d = torch.from_numpy(slots.astype(np.int32)).cuda()
+        if kind == 0:    # general path: per-request timestamps, the chain carries the state through every wave
+            now = base + np.sort(rng.integers(0, 10**6, n))
+            ref = orc.batch_slots(slots, 200_000, 10**9, 1, 1, now)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=tt(now), want=("allowed", "remaining"), inputs_ready=True)
+        elif kind == 1:  # uniform, pipelined: radix look-back + direct stores behind earlier rows
+            ref = orc.batch_slots(slots, 200_000, 10**9, 1, 1, base)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=base, want=("allowed", "remaining"), inputs_ready=True)
+        else:            # uniform, in order
+            ref = orc.batch_slots(slots, 200_000, 10**9, 1, 1, base)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=base, want=("allowed", "remaining"))
+        torch.cuda.synchronize()
+        bad += int((res.allowed.cpu().numpy() != ref.allowed).sum()) + int((res.remaining.cpu().numpy() != ref.remaining).sum())
+        rounds += 1
+    q.put((rank, rounds, bad, eng.selfcheck()))
+    eng.close()
+
+
+def test_two_processes_contend_for_one_device():
+    import torch.multiprocessing as mp
+    seconds = float(os.environ.get("TC_STRESS_SECONDS", "20"))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_contender, args=(r, seconds, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=seconds * 10 + 300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for rank, rounds, bad, viol in got:
+        assert rounds >= 3, (rank, rounds)
+        assert bad == 0, (rank, bad)
+        assert viol == 0, f"rank {rank}: the spin watchdog fired {viol} times"

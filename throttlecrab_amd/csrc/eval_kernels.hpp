@@ -648,8 +648,14 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                 const uint32_t w0 = __shfl(seg_start[j], wl, 64) >> 6;
                 for (uint32_t base = w0; base < gw; base += 64) { // 64 earlier rows per round trip
                     const uint32_t w = base + (uint32_t)lane;
-                    while (__ballot(w < gw && __hip_atomic_load(&loaded[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq))
+                    tc::SpinGuard guard;
+                    while (__ballot(w < gw && __hip_atomic_load(&loaded[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq)) {
+                        if (tc::spin_expired(guard)) { // (see tc::SpinGuard: flagged, never hung)
+                            if (lane == 0) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull);
+                            break;
+                        }
                         __builtin_amdgcn_s_sleep(1);
+                    }
                 }
             }
             if (writer[j]) store_state<FIXED>(p, slot, wcell[j]);
@@ -764,7 +770,14 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         uint32_t in_dirty = 0;
         bool direct = false; // give up speculating: wait for the direct predecessor
         uint32_t base = 0;   // records gw-1-base-lane are examined
+        tc::SpinGuard guard;
         while (true) {
+            if (tc::spin_expired(guard)) { // (see tc::SpinGuard: flagged, never hung; this wave goes on from c0)
+                if (lane == 0) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull);
+                in_tat = c0_tat;
+                in_exp = c0_exp;
+                break;
+            }
             const long long j = (long long)gw - 1 - (long long)base - lane;
             unsigned long long fl = 0ull;
             if (j >= 0 && (!direct || lane == 0))

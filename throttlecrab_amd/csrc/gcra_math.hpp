@@ -275,4 +275,26 @@ TC_HD Cell cell_after(int64_t new_tat, int64_t dvt, int64_t now) {
     return c;
 }
 
+// Watchdog for the engine's wait loops (radix look-back, k_eval_sorted's direct stores, k_eval_general's chain).
+// Each of them waits only for blocks that were dispatched earlier, which holds on today's in-order
+// dispatcher but is not something HIP promises; should a wait ever outlast SPIN_LIMIT_TICKS of the 100 MHz wall
+// clock (2 s: four orders of magnitude above the longest legitimate wait) the loop gives up and the engine's
+// invariant counter (tc_selfcheck) is raised, so a broken assumption shows as a failed check instead of a hung GPU.
+#if defined(__HIPCC__)
+constexpr long long SPIN_LIMIT_TICKS = 200000000ll;
+struct SpinGuard {
+    long long t0 = 0;
+    uint32_t polls = 0;
+};
+__device__ __forceinline__ bool spin_expired(SpinGuard& g) {
+    if ((++g.polls & 255u) != 0u) return false;
+    const long long now = wall_clock64();
+    if (g.t0 == 0) {
+        g.t0 = now;
+        return false;
+    }
+    return now - g.t0 > SPIN_LIMIT_TICKS;
+}
+#endif
+
 } // namespace tc

@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gcra_math.hpp" // tc::SpinGuard
+
 #ifndef RS_SPIN_SLEEP
 #define RS_SPIN_SLEEP 8 // s_sleep argument (x64 clocks) between look-back polls
 #endif
@@ -59,6 +61,7 @@ struct Workspace {
     uint32_t* status;    // [MAX_PASSES] x { part[max_tiles] | gacc[max_groups] | gincl[max_groups] } x RADIX
     uint32_t max_tiles;
     uint32_t max_groups;
+    unsigned long long* violations; // the engine's invariant counter (a look-back that outlasts tc::SPIN_LIMIT_TICKS)
 };
 
 __host__ __device__ inline uint32_t groups_of(uint32_t tiles) { return (tiles + GROUP - 1) / GROUP; }
@@ -77,6 +80,7 @@ inline Workspace carve(uint32_t* base, uint32_t parity, uint32_t max_tiles) {
     ws.status = ws.ticket + MAX_PASSES;
     ws.max_tiles = max_tiles;
     ws.max_groups = groups_of(max_tiles);
+    ws.violations = nullptr;
     return ws;
 }
 
@@ -300,7 +304,12 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
                 const uint32_t* pp = part + (size_t)(g * GROUP) * RADIX + d;
                 const uint32_t want = (1u << j) - 1u;
                 uint32_t got = 0;
+                tc::SpinGuard guard;
                 while (true) {
+                    if (tc::spin_expired(guard)) { // (flagged, never hung)
+                        if (ws.violations) atomicAdd(ws.violations, 1ull);
+                        break;
+                    }
                     uint32_t s[GROUP - 1];
 #pragma unroll
                     for (int u = 0; u < GROUP - 1; ++u)
@@ -320,7 +329,12 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
             // (2) whole groups before mine, newest first: a published inclusive prefix ends the
             // walk, a complete accumulator contributes the group's sum, anything else is retried
             int gg = (int)g - 1;
+            tc::SpinGuard guard2;
             while (gg >= 0) {
+                if (tc::spin_expired(guard2)) {
+                    if (ws.violations) atomicAdd(ws.violations, 1ull);
+                    break;
+                }
                 uint32_t a[GROUP_WINDOW], b[GROUP_WINDOW];
 #pragma unroll
                 for (int u = 0; u < GROUP_WINDOW; ++u) {

@@ -169,6 +169,7 @@ struct tc_engine {
     std::vector<hipEvent_t> async_pool;
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
+    uint32_t fault_countdown = 0; // tc_debug_fail_copy: the n-th staging copy from now fails (error-path tests)
     uint32_t* route_ws = nullptr; // tc_route_batch scratch (lazy): tile counts | totals | starts
     size_t route_ws_words = 0;
 
@@ -237,6 +238,12 @@ static void prof_end(tc_engine* e, hipStream_t s) {
     if (!e->prof_on || e->prof_used == e->prof_stage.size()) return;
     (void)hipEventRecord(e->prof_ev[2 * e->prof_used + 1], s);
     e->prof_used++;
+}
+
+// every host <-> device copy of a batch goes through here, so that tests can make one of them fail
+static hipError_t copy_async(tc_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    if (e->fault_countdown && --e->fault_countdown == 0) return hipErrorInvalidValue;
+    return hipMemcpyAsync(dst, src, bytes, kind, st);
 }
 
 #define TC_HIP(e, call)                                                                              \
@@ -509,8 +516,8 @@ static int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* ke
         TC_HIP(e, hipMalloc(&e->k_stage_bytes, want));
         e->k_stage_bytes_cap = want;
     }
-    if (total) TC_HIP(e, hipMemcpyAsync(e->k_stage_bytes, key_bytes, total, hipMemcpyHostToDevice, cur_stream(e)));
-    TC_HIP(e, hipMemcpyAsync(e->k_stage_off, key_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+    if (total) TC_HIP(e, copy_async(e, e->k_stage_bytes, key_bytes, total, hipMemcpyHostToDevice, cur_stream(e)));
+    TC_HIP(e, copy_async(e, e->k_stage_off, key_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
     *d_bytes = e->k_stage_bytes ? e->k_stage_bytes : (const uint8_t*)e->k_stage_off;
     *d_off = e->k_stage_off;
     return TC_E_OK;
@@ -775,7 +782,7 @@ static int copy_back_async(tc_engine* e, void* host, const void* dev, size_t byt
     if (bytes == 0) return TC_E_OK;
     void* hv = device_view_of_host(host);
     if (!hv) {
-        TC_HIP(e, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, st));
+        TC_HIP(e, copy_async(e, host, dev, bytes, hipMemcpyDeviceToHost, st));
         return TC_E_OK;
     }
     // few blocks: the transfer is bound by the PCIe link, and a grid that fills the chip with waves waiting on
@@ -829,7 +836,7 @@ static int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, boo
     const tc_engine::Stage& st = e->stage;
     auto back = [&](void* host, const void* dev, size_t bytes) -> int {
         if (by_kernel) return copy_back_async(e, host, dev, bytes, s);
-        TC_HIP(e, hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, s));
+        TC_HIP(e, copy_async(e, host, dev, bytes, hipMemcpyDeviceToHost, s));
         return TC_E_OK;
     };
     if (b.allowed) TC_TRY(back(b.allowed, st.allowed, n));
@@ -853,7 +860,8 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     const int passes = (bits + 7) / 8;
     const uint32_t tile = rs::THREADS * (piped ? SORT_ITEMS_PIPED : SORT_ITEMS);
     const uint32_t tiles = (n + tile - 1) / tile;
-    const rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
+    rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
+    ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
     ss.hist_parity ^= 1u;
     prof_begin(e, TC_STAGE_PREP, s);
     hipLaunchKernelGGL(rs::k_hist, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap,
@@ -997,7 +1005,7 @@ static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn&
     const uint64_t mb = e->max_batch;
     if (hin.slot) { // (key batches arrive with their slots already resolved on the device)
         if (!ss.h_slot) TC_HIP(e, hipMalloc(&ss.h_slot, mb * sizeof(uint32_t)));
-        TC_HIP(e, hipMemcpyAsync(ss.h_slot, hin.slot, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st)); // SDMA when pinned
+        TC_HIP(e, copy_async(e, ss.h_slot, hin.slot, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st)); // SDMA when pinned
         *d_slot = ss.h_slot;
         p.slot = ss.h_slot;
     }
@@ -1005,7 +1013,7 @@ static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn&
     for (int j = 0; j < 5; ++j) {
         if (!hin.col[j]) continue;
         if (!ss.h_in[j]) TC_HIP(e, hipMalloc(&ss.h_in[j], mb * sizeof(int64_t)));
-        TC_HIP(e, hipMemcpyAsync(ss.h_in[j], hin.col[j], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        TC_HIP(e, copy_async(e, ss.h_in[j], hin.col[j], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
         *dst[j] = ss.h_in[j];
     }
     return TC_E_OK;
@@ -1150,6 +1158,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         prof_end(e, s);
     }
     TC_HIP(e, hipGetLastError());
+    e->batches++; // (a batch that failed on the way here was not applied and is not counted)
     return TC_E_OK;
 }
 
@@ -1169,12 +1178,11 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     for (int j = 0; j < 5; ++j) {
         if (hin[j]) {
             TC_TRY(stage_need(e, e->stage.in[j], e->max_batch));
-            TC_HIP(e, hipMemcpyAsync(e->stage.in[j], hin[j], n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            TC_HIP(e, copy_async(e, e->stage.in[j], hin[j], n * sizeof(int64_t), hipMemcpyHostToDevice, s));
             *din[j] = e->stage.in[j];
         }
     }
     TC_TRY(stage_outputs(e, b, d));
-    e->batches++;
     TC_TRY(run_slots_device(e, d));
     TC_TRY(copy_outputs_back(e, b, s));
     TC_HIP(e, hipStreamSynchronize(s));
@@ -1211,7 +1219,6 @@ static int run_slots_host_async(tc_engine* e, const tc_batch& b) {
     hin.slot = b.slot;
     hin.col[0] = b.max_burst, hin.col[1] = b.count_per_period, hin.col[2] = b.period, hin.col[3] = b.quantity, hin.col[4] = b.now_ns;
     TC_TRY(stage_outputs(e, b, d));
-    e->batches++;
     TC_TRY(run_slots_device(e, d, &hin));
     return finish_async(e, b);
 }
@@ -1353,14 +1360,13 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     TC_HIP(e, hipSetDevice(e->device));
     if (b.flags & TC_B_DEVICE_PTRS) {
         if (b.flags & TC_B_ASYNC) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
-        e->batches++;
         return run_slots_device(e, b);
     }
     if (b.flags & TC_B_ASYNC) return run_slots_host_async(e, b);
     if (small_batch_applies(e, b)) return run_small_batch(e, b);
     // host pointers: stage in, run, stage out, synchronise
     TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
-    TC_HIP(e, hipMemcpyAsync(e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+    TC_HIP(e, copy_async(e, e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
     return run_slots_host_staged(e, b);
 }
 
@@ -1421,8 +1427,8 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     if (!ss.h_key_off) TC_HIP(e, hipMalloc(&ss.h_key_off, (e->max_batch + 1) * sizeof(uint32_t)));
     // the key stage and the evaluation that last used this set's staging and slot column are done
     if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ks, ss.consumed, 0));
-    if (total) TC_HIP(e, hipMemcpyAsync(ss.h_key_bytes, b.key_bytes, total, hipMemcpyHostToDevice, ks));
-    TC_HIP(e, hipMemcpyAsync(ss.h_key_off, b.key_off, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ks));
+    if (total) TC_HIP(e, copy_async(e, ss.h_key_bytes, b.key_bytes, total, hipMemcpyHostToDevice, ks));
+    TC_HIP(e, copy_async(e, ss.h_key_off, b.key_off, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ks));
     TC_TRY(resolve_keys_device(e, ss.h_key_bytes, ss.h_key_off, n, true, ss.k_slot, piped));
     tc_batch d = b;
     d.flags = (b.flags & ~(TC_B_ASYNC | TC_B_INPUTS_READY)) | TC_B_DEVICE_PTRS | (piped ? TC_B_INPUTS_READY : 0u);
@@ -1434,7 +1440,6 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     hin.col[0] = b.max_burst, hin.col[1] = b.count_per_period, hin.col[2] = b.period, hin.col[3] = b.quantity, hin.col[4] = b.now_ns;
     if (piped) e->wait_before_sort = e->k_done;
     TC_TRY(stage_outputs(e, b, d));
-    e->batches++;
     TC_TRY(run_slots_device(e, d, &hin));
     return finish_async(e, b);
 }
@@ -1480,7 +1485,6 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
         if (piped) e->wait_before_sort = e->k_done;
         else s.flags &= ~TC_B_INPUTS_READY; // the slots were resolved on the main stream: group there too
         s.slot = ss.k_slot;
-        e->batches++;
         return run_slots_device(e, s);
     }
     int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, e->k_slot, false);
@@ -2117,6 +2121,14 @@ extern "C" int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_
         const uint64_t y = (x + m.modulus - m.add % m.modulus) % m.modulus;
         global_id[i] = (uint64_t)(((unsigned __int128)y * inv) % m.modulus);
     }
+    return TC_E_OK;
+}
+
+// Test hook: the n-th staging copy (host <-> device, any batch path) from now returns an error instead of
+// being issued.  0 disarms.
+extern "C" int tc_debug_fail_copy(tc_engine* e, uint32_t nth) {
+    if (!e) return TC_E_INVALID_ARG;
+    e->fault_countdown = nth;
     return TC_E_OK;
 }
 

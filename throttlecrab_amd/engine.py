@@ -94,6 +94,10 @@ class Engine:
         self.key_mode = key_mode
         self.check_on_close = False
 
+    def debug_fail_copy(self, nth: int):
+        """test hook: the nth staging copy from now fails (tc_debug_fail_copy)"""
+        self._check(self._lib.tc_debug_fail_copy(self._h, nth))
+
     def selfcheck(self) -> int:
         v = C.c_uint64(0)
         self._check(self._lib.tc_selfcheck(self._h, C.byref(v)))
