@@ -77,3 +77,41 @@ def test_snapshot_string_mode(tmp_path):
     assert a.sweep_expired(T0 + 10**12) == b.sweep_expired(T0 + 10**12)
     a.close()
     b.close()
+
+
+def test_corrupt_or_truncated_snapshot_is_refused_before_the_engine_is_touched(tmp_path):
+    """tc_snapshot_load copied whatever the file held.  The payload now carries its size and a
+    checksum, verified in a first pass over the file: a flipped byte or a short file is refused and the engine
+    keeps answering from the state it had."""
+    import throttlecrab_amd as t
+    from throttlecrab_amd import workload as W
+    cap, n = 3000, 8000
+    rng = np.random.default_rng(6)
+    a = t.Engine(cap, n, key_mode=True)
+    kb, ko = W.string_keys(rng.integers(0, 2500, n))
+    a.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0)
+    good = str(tmp_path / "good.snap")
+    a.snapshot_save(good)
+    raw = bytearray(open(good, "rb").read())
+    bad_byte, short = str(tmp_path / "flipped.snap"), str(tmp_path / "short.snap")
+    flipped = bytearray(raw)
+    flipped[len(raw) // 2] ^= 0x40
+    open(bad_byte, "wb").write(flipped)
+    open(short, "wb").write(raw[: len(raw) - 4096])
+    b = t.Engine(cap, n, key_mode=True)
+    kb2, ko2 = W.string_keys(rng.integers(5000, 6000, n))
+    b.rate_limit_batch_keys(kb2, ko2, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0)
+    before = (b.counters(), b.read_state(0, cap))
+    for path in (bad_byte, short):
+        with pytest.raises(t.TcError):
+            b.snapshot_load(path)
+        after = (b.counters(), b.read_state(0, cap))
+        assert before[0] == after[0] and np.array_equal(before[1][0], after[1][0]) and np.array_equal(before[1][1], after[1][1])
+    # ... and it still works, and takes the good file
+    r1 = b.rate_limit_batch_keys(kb2, ko2, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 1)
+    assert r1.status.max() == 0
+    b.snapshot_load(good)
+    _same(a.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 2),
+          b.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 2))
+    a.close()
+    b.close()

@@ -1926,6 +1926,41 @@ struct SnapHeader {
     uint64_t capacity, nb, overflow_bytes, n_classes;
     uint64_t batches;
     uint64_t counters[TC_CNT_COUNT];
+    uint64_t payload_bytes; // everything after the header
+    uint64_t checksum;      // FNV-1a 64 over the payload: a truncated, corrupt or foreign file is refused BEFORE the engine is touched
+};
+constexpr uint32_t SNAP_VERSION = 2;
+// FNV-1a over 8-byte words of the byte stream (a byte-wise FNV over gigabytes of state would take seconds);
+// independent of how the stream is cut into pieces
+struct StreamSum {
+    uint64_t h = 0xcbf29ce484222325ull;
+    uint8_t tail[8];
+    size_t ntail = 0;
+    void add(const void* data, size_t n) {
+        const uint8_t* p = static_cast<const uint8_t*>(data);
+        while (n && ntail) { // finish the word left over from the previous piece
+            tail[ntail++] = *p++;
+            --n;
+            if (ntail == 8) {
+                uint64_t w;
+                memcpy(&w, tail, 8);
+                h = (h ^ w) * 0x100000001b3ull;
+                ntail = 0;
+            }
+        }
+        size_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t w;
+            memcpy(&w, p + i, 8);
+            h = (h ^ w) * 0x100000001b3ull;
+        }
+        for (; i < n; ++i) tail[ntail++] = p[i];
+    }
+    uint64_t done() const {
+        uint64_t r = h;
+        for (size_t i = 0; i < ntail; ++i) r = (r ^ tail[i]) * 0x100000001b3ull;
+        return r;
+    }
 };
 struct Section {
     void* dev;
@@ -1970,7 +2005,7 @@ extern "C" int tc_snapshot_save(tc_engine* e, const char* path) {
     SnapHeader h;
     memset(&h, 0, sizeof h);
     memcpy(h.magic, "TCGPUSN1", 8);
-    h.version = 1;
+    h.version = SNAP_VERSION;
     h.key_mode = e->key_mode ? 1u : 0u;
     h.capacity = e->capacity;
     h.nb = e->key_mode ? e->kt.nb_mask + 1 : 0;
@@ -1983,21 +2018,32 @@ extern "C" int tc_snapshot_save(tc_engine* e, const char* path) {
         fclose(f);
         return fail(e, TC_E_HIP, "tc_snapshot_save: counter copy failed");
     }
-    bool ok = fwrite(&h, sizeof h, 1, f) == 1;
+    bool ok = fwrite(&h, sizeof h, 1, f) == 1; // (rewritten with the payload's size and checksum at the end)
+    StreamSum sum;
+    uint64_t bytes = 0;
+    auto put = [&](const void* p, size_t n) {
+        if (!ok || n == 0) return;
+        ok = fwrite(p, 1, n, f) == n;
+        sum.add(p, n);
+        bytes += n;
+    };
     // rate plans: the (burst,count,period) keys in id order (the dictionary is rebuilt from them)
     std::vector<int64_t> plans(3 * e->host_classes.size(), 0);
     for (const auto& kv : e->class_of) memcpy(&plans[3 * kv.second], kv.first.data(), 24);
-    ok = ok && (plans.empty() || fwrite(plans.data(), 8, plans.size(), f) == plans.size());
-    ok = ok && fwrite(&e->uniform_id, sizeof e->uniform_id, 1, f) == 1;
+    put(plans.data(), plans.size() * 8);
+    put(&e->uniform_id, sizeof e->uniform_id);
     const size_t CHUNK = 64u << 20;
     std::vector<uint8_t> buf(CHUNK);
     for (const Section& sec : snapshot_sections(e)) {
         for (size_t off = 0; ok && off < sec.bytes; off += CHUNK) {
             const size_t nbytes = std::min(CHUNK, sec.bytes - off);
             if (hipMemcpy(buf.data(), (const uint8_t*)sec.dev + off, nbytes, hipMemcpyDeviceToHost) != hipSuccess) ok = false;
-            ok = ok && fwrite(buf.data(), 1, nbytes, f) == nbytes;
+            put(buf.data(), nbytes);
         }
     }
+    h.payload_bytes = bytes;
+    h.checksum = sum.done();
+    ok = ok && fseek(f, 0, SEEK_SET) == 0 && fwrite(&h, sizeof h, 1, f) == 1;
     ok = (fclose(f) == 0) && ok;
     return ok ? TC_E_OK : fail(e, TC_E_INVALID_ARG, "tc_snapshot_save: write failed");
 }
@@ -2009,13 +2055,27 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(e, TC_E_INVALID_ARG, "tc_snapshot_load: cannot open file");
     SnapHeader h;
-    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "TCGPUSN1", 8) == 0 && h.version == 1;
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "TCGPUSN1", 8) == 0 && h.version == SNAP_VERSION;
     const uint32_t mode = (e->key_mode ? 1u : 0u) | (e->denied ? 2u : 0u) | (e->fixed ? 4u : 0u);
     if (!ok || h.key_mode != mode || h.capacity != e->capacity || (e->key_mode && (h.nb != e->kt.nb_mask + 1 ||
                                                                                   h.overflow_bytes != e->kt.overflow_bytes)) ||
         h.n_classes == 0 || h.n_classes > MAX_CLASSES) {
         fclose(f);
         return fail(e, TC_E_INVALID_ARG, "tc_snapshot_load: not a snapshot of an engine with this configuration");
+    }
+    {   // first pass over the file: size and checksum -- nothing of the engine is touched before they hold
+        StreamSum sum;
+        uint64_t bytes = 0;
+        std::vector<uint8_t> tmp(16u << 20);
+        size_t got;
+        while ((got = fread(tmp.data(), 1, tmp.size(), f)) > 0) {
+            sum.add(tmp.data(), got);
+            bytes += got;
+        }
+        if (bytes != h.payload_bytes || sum.done() != h.checksum || fseek(f, (long)sizeof h, SEEK_SET) != 0) {
+            fclose(f);
+            return fail(e, TC_E_INVALID_ARG, "tc_snapshot_load: truncated or corrupt snapshot (the engine was not touched)");
+        }
     }
     std::vector<int64_t> plans(3 * h.n_classes);
     ok = fread(plans.data(), 8, plans.size(), f) == plans.size();
