@@ -66,7 +66,8 @@ def pmc_traffic(stage, stream, layout, launches_per_batch):
     file (and which commit it was taken at) so that a stale profile cannot pass for a fresh one."""
     import glob
     import re
-    files = glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_{layout}*_pmc.json"))
+    files = glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_{layout}*_pmc.json")) + \
+        glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_pmc.json"))
     if layout == "wide":  # (round-1 summaries carry no layout tag: they are the 16-byte layout)
         files += [f for f in glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_1M*_pmc.json"))]
     want = PROFILE_NAME_OF_STAGE.get(stage)
@@ -104,7 +105,7 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--profile-run", action="store_true",
                     help="warmup + timed region only (what rocprofv3 is pointed at: no per-kernel events, no secondary runs)")
-    ap.add_argument("--layout", default="wide", choices=["wide", "fixed"],
+    ap.add_argument("--layout", default="fixed", choices=["wide", "fixed"],
                     help="resident state: 16-byte {tat, expiry} cells, or TC_CFG_FIXED_PARAMS (8-byte TAT column)")
     return ap.parse_args()
 

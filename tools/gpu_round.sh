@@ -1,23 +1,30 @@
 #!/bin/bash
-# One GPU-box visit: parity tests, bench line, rocprofv3 kernel stats + PMC passes.
-# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [notests]
+# One GPU-box visit: rocprofv3 kernel stats + PMC passes of the commands bench.py times, summarised into profiles/.
+# usage (from the repo root on the GPU box): bash tools/gpu_round.sh <tag> [configs...]   e.g.  r02_v3 uniform_fixed zipf_fixed keys_short
+# Each rocprofv3 run is wrapped in its own timeout (a profiler that does not come back must not eat the visit).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
+shift
+CONFIGS=${@:-uniform_fixed uniform_wide zipf_fixed string_keys string_keys_long}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
-cd $R
-if [ "${2:-}" != "notests" ]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?" >> $O/pytest.log
-  tail -3 $O/pytest.log
-fi
-timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"
-tail -c 600 $O/bench.json
-BENCH="python $R/bench.py --steps 20 --warmup 3 --no-cpu --no-also"
-cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $O/stats -o s -- $BENCH > $O/stats.log 2>&1; echo "stats rc=$?"
-timeout 600 rocprofv3 --pmc FETCH_SIZE -d $O/pmc_fetch -o f -- $BENCH > $O/pmc_fetch.log 2>&1; echo "fetch rc=$?"
-timeout 600 rocprofv3 --pmc WRITE_SIZE -d $O/pmc_write -o w -- $BENCH > $O/pmc_write.log 2>&1; echo "write rc=$?"
-cd $R
-find $O -name "*.csv" | head -20
+for C in $CONFIGS; do
+  case $C in
+    uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed" ;;
+    uniform_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide" ;;
+    zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf" ;;
+    zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf" ;;
+    string_keys) CMD="python $R/tools/profile_keys.py short 8" ;;
+    string_keys_long) CMD="python $R/tools/profile_keys.py long 8" ;;
+    *) echo "unknown config $C"; continue ;;
+  esac
+  cd /tmp
+  timeout 240 rocprofv3 --kernel-trace --stats -d $O/${C}_stats -o s -- $CMD > $O/${C}_stats.log 2>&1; echo "$C stats rc=$?"
+  timeout 240 rocprofv3 --pmc FETCH_SIZE -d $O/${C}_fetch -o f -- $CMD > $O/${C}_fetch.log 2>&1; echo "$C fetch rc=$?"
+  timeout 240 rocprofv3 --pmc WRITE_SIZE -d $O/${C}_write -o w -- $CMD > $O/${C}_write.log 2>&1; echo "$C write rc=$?"
+  cd $R
+  python tools/summarize_prof.py ${TAG}_${C} $O/${C}_stats $O/${C}_fetch $O/${C}_write "$CMD" > $O/${C}_summary.log 2>&1; tail -1 $O/${C}_summary.log
+  mkdir -p $O/profiles; cp profiles/${TAG}_${C}* $O/profiles/ 2>/dev/null
+done

@@ -72,7 +72,8 @@ def main():
             pm[short(k)] = {"FETCH_SIZE_KB": fa, "WRITE_SIZE_KB": wa, "launches": len(fs)}
         import subprocess
         try:
-            sha = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None
+            sha = (os.environ.get("TC_GIT_SHA") or
+                   subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True).stdout.strip() or None)
         except OSError:
             sha = None
         json.dump({"tag": tag, "git_sha": sha, "command": sys.argv[5] if len(sys.argv) > 5 else None, "note": "raw rocprofv3 PMC values per dispatch; gfx950 FETCH_SIZE tallies a 128-B "
