@@ -92,6 +92,12 @@ def pmc_traffic(stage, stream, layout, launches_per_batch):
     return None, None
 
 
+def log(msg):
+    """progress to stderr (stdout carries the one JSON line)"""
+    if os.environ.get("TC_BENCH_VERBOSE"):
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -248,6 +254,7 @@ def keys_bench(a, dev):
     steps = max(4, min(a.steps, 16) // 4 * 4)
     out = {}
     for label, long in (("key_%d", False), ("ascii_32_64", True)):
+        log(f"  key set {label}")
         st = W.Config4Stream(B, n_prefill=n_prefill, long=long, sweep_every=4)
         cap = B * n_prefill + B
         eng = t.Engine(cap, B, device=dev.index or 0, key_mode=True, key_arena_bytes=(448 << 20) if long else 0)
@@ -359,6 +366,7 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
     dt3, _ = run_gpu(eng2, ob, full, W.T0_NS + 10**9, a.steps, 2, None, None, None,
                      want=t.Engine.ALL_FIELDS)
     also[f"{other}_stream_full_result"] = {"value": a.steps * a.batch / dt3, "unit": "decisions/s"}
+    log("  records")
     rec = t.BatchResult()
     dt4, _ = run_gpu(eng2, ob, rec, W.T0_NS + 3 * 10**9, a.steps, 2, None, None, None,
                      want=t.Engine.RECORD_FIELDS)
@@ -371,6 +379,7 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
         "value": a.steps * a.batch / dt5, "unit": "decisions/s",
         "note": "tc_decision: remaining, reset_after, retry_after, allowed, status in one 32-byte record"}
     # grouped output (TC_B_GROUPED_OUTPUT): rows in evaluation order + the request index of each row
+    log("  grouped")
     grp = t.BatchResult()
     d_main = d_batches
     for label, streams, want in ((f"{a.workload}_stream_grouped_output", d_main, ("allowed",)),
@@ -390,6 +399,7 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
         grp = t.BatchResult()
     # general batches: every request carries its own timestamp (strictly increasing inside
     # the batch), so the closed form does not apply and k_eval_general runs
+    log("  per-request timestamps")
     nows = [torch.arange(a.batch, dtype=torch.int64, device=dev) + (W.T0_NS + 4 * 10**9 + b * 10**6)
             for b in range(a.warmup + a.steps)]
     gout = t.BatchResult()
@@ -408,6 +418,7 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
         torch.cuda.synchronize()
         also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s"}
         eng3.close()
+    log("  host buffers")
     # PCIe-inclusive rate: the same stream handed over as HOST buffers (never `value`)
     hb = make_batches(other, a.keys, a.batch, 8)
     hout = t.BatchResult()
@@ -609,6 +620,7 @@ def main():
         dist.destroy_process_group()
         return
 
+    log(f"headline: {a.workload} / {a.layout}")
     main_res, eng, d_batches, dt = measure_stream(a, t, W, a.workload, dev, local, rank, 0, None, 1)
     result = {
         "metric": "GCRA decisions/sec, 10M keys", "value": main_res["value"], "unit": "decisions/s",
@@ -633,20 +645,25 @@ def main():
         if not a.no_also and world == 1 and not a.profile_run:
             other = "zipf" if a.workload == "uniform" else "uniform"
             # the other BASELINE stream (configs[2]: Zipf s = 1.1, north_star's target stream), measured the same way
+            log(f"other stream: {other}")
             o_res, eng2, ob, _ = measure_stream(a, t, W, other, dev, local, 0, 0, None, 1)
             o_res["config"] = f"configs[{2 if other == 'zipf' else 1}]: same engine shape, {other} request stream"
             result[f"{other}_stream"] = o_res
             # the headline stream on the other resident-state layout
             a2 = argparse.Namespace(**vars(a))
             a2.layout = "fixed" if a.layout == "wide" else "wide"
+            log(f"other layout: {a2.layout}")
             l_res, eng_l, _, _ = measure_stream(a2, t, W, a.workload, dev, local, 0, 0, None, 1)
             eng_l.close()
             l_res.pop("roofline", None)
             result[f"{a.workload}_stream_{a2.layout}_layout"] = l_res
+            log("secondary output forms")
             result["also"] = secondary(a, t, W, eng2, ob, d_batches, dev, local, other)
             eng2.close()
+            log("string keys")
             result["also"]["string_keys_config4"] = keys_bench(a, dev)
         if not a.no_cpu and not a.profile_run:
+            log("cpu baseline")
             result["cpu_baseline"] = cpu_baseline(a.workload, a.keys, a.batch, a.cpu_sample_batches)
         print(json.dumps(result))
     if dist is not None:

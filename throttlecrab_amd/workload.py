@@ -147,7 +147,12 @@ def _long_keys_torch(ids, device):
     off[1:] = torch.cumsum(lens, 0)
     keep = torch.arange(64, device=device)[None, :] < lens[:, None]
     buf = chars[keep]
-    return (buf if buf.numel() else torch.zeros(1, dtype=torch.uint8, device=device)), off.to(torch.int32)
+    off = off.to(torch.int32)
+    if buf.is_cuda:
+        # the arena is COMPLETE in device memory on return: what TC_B_INPUTS_READY requires of its caller (the
+        # engine reads it on a stream of its own, which is not ordered behind torch's)
+        torch.cuda.current_stream(buf.device).synchronize()
+    return (buf if buf.numel() else torch.zeros(1, dtype=torch.uint8, device=device)), off
 
 
 class Config4Stream:
