@@ -27,4 +27,5 @@ for C in $CONFIGS; do
   cd $R
   python tools/summarize_prof.py ${TAG}_${C} $O/${C}_stats $O/${C}_fetch $O/${C}_write "$CMD" > $O/${C}_summary.log 2>&1; tail -1 $O/${C}_summary.log
   mkdir -p $O/profiles; cp profiles/${TAG}_${C}* $O/profiles/ 2>/dev/null
+  rm -rf $O/${C}_stats $O/${C}_fetch $O/${C}_write   # (the rocpd databases are tens of MB each: gpurun brings back 64 MiB at most)
 done
