@@ -81,7 +81,8 @@ def pmc_traffic(stage, stream, layout, launches_per_batch):
         doc = json.load(open(path))
         total, names = 0.0, []
         for name, v in doc["kernels"].items():
-            if want in name and v.get("launches", 0) >= 3:
+            # (launches that left at once -- the gated-off path of a batch enqueued on both -- carry a few KB)
+            if want in name and v.get("launches", 0) >= 3 and 2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"] > 512.0:
                 # several variants of one stage (first / later radix pass): weigh by launches
                 total += (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * v["launches"]
                 names.append((name, v["launches"]))
@@ -109,6 +110,7 @@ def parse():
     ap.add_argument("--cpu-sample-batches", type=int, default=8)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--in-order", action="store_true", help="with --profile-run: batches without TC_B_INPUTS_READY (one stream)")
     ap.add_argument("--profile-run", action="store_true",
                     help="warmup + timed region only (what rocprofv3 is pointed at: no per-kernel events, no secondary runs)")
     ap.add_argument("--layout", default="fixed", choices=["wide", "fixed"],
@@ -124,14 +126,14 @@ def make_batches(kind, n_keys, batch, count, seed_shift=0):
     return [W.uniform_slots(n_keys, batch, seed=2 + seed_shift, start=i * batch) for i in range(count)]
 
 
-def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",)):
+def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",), piped=True):
     """warmup + timed region; returns seconds for `steps` batches (max over ranks)."""
     import torch
     it = 0
 
     def one(i, last=False):
         eng.rate_limit_batch_slots(d_batches[i % len(d_batches)], registered=True, quantity=1,
-                                   now_ns=now0 + i * 1_000_000, want=want, out=out, inputs_ready=True)
+                                   now_ns=now0 + i * 1_000_000, want=want, out=out, inputs_ready=piped)
         if dist is not None and (i % METRICS_EVERY == METRICS_EVERY - 1 or last):
             eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
@@ -227,7 +229,7 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world):
         from throttlecrab_amd.sharded import device_counter_view
         cnt_view = device_counter_view(eng)
         gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
-    dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered)
+    dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered, piped=not a.in_order)
     c = eng.counters()
     res = {"value": a.steps * a.batch * world / dt, "unit": "decisions/s", "ms_per_step": 1e3 * dt / a.steps,
            "allowed_fraction": c["allowed"] / max(1, c["total"])}

@@ -11,21 +11,26 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
 for C in $CONFIGS; do
+  PMCENV=""
   case $C in
-    uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed" ;;
-    uniform_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide" ;;
-    zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf" ;;
-    zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf" ;;
+    # PMC passes serialise the streams (the engine then finds no concurrent grouping stream and runs its batches in
+    # order); TCGPU_BUCKET=0 keeps those in-order batches on the SORT path, i.e. on the kernels of the timed,
+    # pipelined configuration.  The *_bucket configs profile the in-order bucket path instead.
+    uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed"; PMCENV="TCGPU_BUCKET=0" ;;
+    uniform_fixed_bucket) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --in-order" ;;
+    uniform_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide"; PMCENV="TCGPU_BUCKET=0" ;;
+    zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf"; PMCENV="TCGPU_BUCKET=0" ;;
+    zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf"; PMCENV="TCGPU_BUCKET=0" ;;
     string_keys) CMD="python $R/tools/profile_keys.py short 8" ;;
     string_keys_long) CMD="python $R/tools/profile_keys.py long 8" ;;
     *) echo "unknown config $C"; continue ;;
   esac
   cd /tmp
   timeout 240 rocprofv3 --kernel-trace --stats -d $O/${C}_stats -o s -- $CMD > $O/${C}_stats.log 2>&1; echo "$C stats rc=$?"
-  timeout 240 rocprofv3 --pmc FETCH_SIZE -d $O/${C}_fetch -o f -- $CMD > $O/${C}_fetch.log 2>&1; echo "$C fetch rc=$?"
-  timeout 240 rocprofv3 --pmc WRITE_SIZE -d $O/${C}_write -o w -- $CMD > $O/${C}_write.log 2>&1; echo "$C write rc=$?"
+  env $PMCENV timeout 240 rocprofv3 --pmc FETCH_SIZE -d $O/${C}_fetch -o f -- $CMD > $O/${C}_fetch.log 2>&1; echo "$C fetch rc=$?"
+  env $PMCENV timeout 240 rocprofv3 --pmc WRITE_SIZE -d $O/${C}_write -o w -- $CMD > $O/${C}_write.log 2>&1; echo "$C write rc=$?"
   cd $R
-  python tools/summarize_prof.py ${TAG}_${C} $O/${C}_stats $O/${C}_fetch $O/${C}_write "$CMD" > $O/${C}_summary.log 2>&1; tail -1 $O/${C}_summary.log
+  python tools/summarize_prof.py ${TAG}_${C} $O/${C}_stats $O/${C}_fetch $O/${C}_write "$CMD  [PMC passes: $PMCENV, streams serialised by the profiler]" > $O/${C}_summary.log 2>&1; tail -1 $O/${C}_summary.log
   mkdir -p $O/profiles; cp profiles/${TAG}_${C}* $O/profiles/ 2>/dev/null
   rm -rf $O/${C}_stats $O/${C}_fetch $O/${C}_write   # (the rocpd databases are tens of MB each: gpurun brings back 64 MiB at most)
 done
