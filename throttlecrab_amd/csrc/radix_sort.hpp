@@ -98,23 +98,24 @@ __device__ __forceinline__ bool gated_off(const uint32_t* __restrict__ gate, uin
     return gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min;
 }
 
-__global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
                                                   int passes, Workspace ws, uint32_t tiles, const uint32_t* __restrict__ gate,
                                                   uint32_t gate_min) {
     __shared__ uint32_t s_h[MAX_PASSES][RADIX];
     if (gated_off(gate, gate_min)) {
         if (blockIdx.x == 0)
-            for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += HIST_THREADS) ws.hist_next[i] = 0;
+            for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) ws.hist_next[i] = 0;
         return;
     }
-    for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += HIST_THREADS) (&s_h[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) (&s_h[0][0])[i] = 0;
     // clear the look-back words this sort will use (every pass: part | gacc | gincl) + tickets
     {
         const uint32_t groups = groups_of(tiles);
         const uint32_t per_pass = (tiles + 2 * groups) * RADIX;
         const size_t pass_stride = pass_status_words(ws.max_tiles, ws.max_groups);
         const uint32_t total_status = (uint32_t)passes * per_pass;
-        for (uint32_t i = blockIdx.x * HIST_THREADS + threadIdx.x; i < total_status; i += gridDim.x * HIST_THREADS) {
+        for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < total_status; i += gridDim.x * NT) {
             const uint32_t p = i / per_pass;
             uint32_t r = i % per_pass;
             size_t at;
@@ -126,13 +127,13 @@ __global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint32_t* __restric
     }
     if (blockIdx.x == 0) {
         if (threadIdx.x < MAX_PASSES) ws.ticket[threadIdx.x] = 0;
-        for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += HIST_THREADS) ws.hist_next[i] = 0;
+        for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) ws.hist_next[i] = 0;
     }
     __syncthreads();
     {
         // 4 independent loads in flight per lane (the loop is latency-, not bandwidth-bound)
-        const uint32_t stride = gridDim.x * HIST_THREADS;
-        uint32_t i = blockIdx.x * HIST_THREADS + threadIdx.x;
+        const uint32_t stride = gridDim.x * NT;
+        uint32_t i = blockIdx.x * NT + threadIdx.x;
         for (; i + 3 * stride < n; i += 4 * stride) {
             uint32_t k[4];
 #pragma unroll
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(HIST_THREADS) void k_hist(const uint32_t* __restric
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < passes * RADIX; i += HIST_THREADS) {
+    for (int i = threadIdx.x; i < passes * RADIX; i += NT) {
         const uint32_t v = (&s_h[0][0])[i];
         if (v) atomicAdd(&ws.hist[i], v);
     }

@@ -864,8 +864,7 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
     ss.hist_parity ^= 1u;
     prof_begin(e, TC_STAGE_PREP, s);
-    hipLaunchKernelGGL(rs::k_hist, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap,
-                       passes, ws, tiles, gate, gate_min);
+    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min);
     prof_end(e, s);
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
     const uint64_t* in = nullptr;
