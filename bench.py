@@ -342,15 +342,24 @@ def cpu_baseline(kind, n_keys, batch, n_batches):
     st.batch_keys(kb, ko, b, c, p, 1, now)
     t1 = time.perf_counter() - t0
     del st
-    # the cores this process may actually run on (a container's CPU set can be smaller than the machine's)
+    # the cores this process may actually use: its CPU set, and the container's CPU-time quota if it has one
     ncores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64)
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    if quota:
+        ncores = max(1, min(ncores, int(quota + 0.5)))
     tm, _ = O.batch_keys_mt(ncores, max(1000, n_keys // ncores), W.T0_NS, kb, ko, b, c, p, 1, now)
     O.reference_shape(2000, 50_000)  # warm
     ts, allowed, blocked = min(O.reference_shape(2000, 400_000) for _ in range(3))
     return {"value": slots.size / t1, "unit": "decisions/s", "cores": 1, "kind": "port",
             "sample": f"first {n_batches} batches ({slots.size} requests) of the same {kind} stream, "
                       f"string keys key_<slot>, AdaptiveStore port, 1 thread",
-            "all_cores": {"value": slots.size / tm, "cores": ncores, "machine_cores": os.cpu_count(), "speedup_over_one_thread": t1 / tm,
+            "all_cores": {"value": slots.size / tm, "cores": ncores, "machine_cores": os.cpu_count(), "cgroup_cpu_quota": quota, "speedup_over_one_thread": t1 / tm,
                           "note": "one AdaptiveStore port per thread, keys routed by hash (routing inside the timing)"},
             "reference_shape": {"value": 400_000 / ts, "unit": "decisions/s", "cores": 1, "allowed": allowed, "blocked": blocked,
                                 "sample": "throttlecrab-server/examples/store_comparison.rs: 400 000 rate_limit calls over 2 000 keys key_<i>, "
