@@ -327,7 +327,7 @@ __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t
         const uint32_t rank = kt::block_rank<SMALL_MAX>(i < n && st == kt::ST_CLAIMANT, total); // one barrier
         const int top = *t.free_top; // (thread 0 moves it after the next barrier)
         if (i < n && st == kt::ST_CLAIMANT) {
-            slot = kt::bind_claimant(t, key_bytes, key_off, i, ax, h, slot, top - 1 - (int)rank);
+            slot = kt::bind_claimant(t, key_bytes, key_off, n, i, ax, h, slot, top - 1 - (int)rank);
         } else if (i < n && st == kt::ST_NOSPACE) {
             kt::release_claim(t, key_off, i, ax, h);
             slot = kt::NO_SLOT;
