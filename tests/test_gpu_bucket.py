@@ -1,12 +1,14 @@
-"""GPU parity of the bucket path (csrc/bucket_path.hpp): uniform batches that run in order on the engine's
-stream are grouped by a stable partition into key-range buckets + a per-bucket rank pass instead of a sort,
-with the sort path enqueued behind a device-side gate (the partition's largest bucket).  Every mode must give
-the oracle's results bit for bit, on all outputs and on the resident state:
-  default       the engine's own thresholds (batches >= 16384 requests, buckets <= 1024 requests)
-  all_sizes     every eligible batch, however small
-  long_buckets  ... and buckets of any length stay on the bucket path (the walk in pieces with parked stores)
-  gate_trips    ... and every batch trips the gate (bucket kernels leave at once, the gated sort path runs)
-  off           the bucket path disabled"""
+"""GPU parity of the sort-free grouping paths.  Uniform batches are grouped by a stable partition into key ranges
+instead of a full sort, with the sort path enqueued behind a device-side gate (the partition's largest range):
+the block path (csrc/block_path.hpp: 256 ranges, one block per range sorts in LDS and evaluates) and the older
+bucket path (csrc/bucket_path.hpp: thousands of buckets, one wave per bucket).  Every mode must give the
+oracle's results bit for bit, on all outputs and on the resident state:
+  default            the engine's own thresholds (block path for batches >= 16384 requests, ranges <= 6144 requests)
+  block_all_sizes    every uniform batch, however small
+  block_mixed        ... with ranges of at most 300 requests: some batches take the block path, some trip the gate
+  block_gate_trips   ... and (nearly) every batch trips the gate: block kernels leave at once, the gated sort path runs
+  bucket, bucket_all_sizes, bucket_long, bucket_gate_trips   the same for the bucket path (block path off)
+  off                both paths disabled"""
 import numpy as np
 import pytest
 
@@ -16,16 +18,22 @@ pytestmark = pytest.mark.gpu
 
 MODES = {
     "default": {},
-    "all_sizes": {"TCGPU_BUCKET_MIN_N": "1"},
-    "long_buckets": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "32767"},
-    "gate_trips": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "1"},
-    "off": {"TCGPU_BUCKET": "0"},
+    "block_all_sizes": {"TCGPU_BLOCK_MIN_N": "1"},
+    "block_mixed": {"TCGPU_BLOCK_MIN_N": "1", "TCGPU_BLOCK_CAP": "300"},
+    "block_gate_trips": {"TCGPU_BLOCK_MIN_N": "1", "TCGPU_BLOCK_CAP": "2"},
+    "bucket": {"TCGPU_BLOCK": "0"},
+    "bucket_all_sizes": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET_MIN_N": "1"},
+    "bucket_long": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "32767"},
+    "bucket_gate_trips": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "1"},
+    "off": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET": "0"},
 }
+ENV = ("TCGPU_BLOCK", "TCGPU_BLOCK_MIN_N", "TCGPU_BLOCK_CAP", "TCGPU_BLOCK_PIPED", "TCGPU_BUCKET", "TCGPU_BUCKET_MIN_N", "TCGPU_BUCKET_SKEW",
+       "TCGPU_BUCKET_PIPED")
 
 
 @pytest.fixture(params=list(MODES), ids=list(MODES))
 def mode(request, monkeypatch):
-    for k in ("TCGPU_BUCKET", "TCGPU_BUCKET_MIN_N", "TCGPU_BUCKET_SKEW", "TCGPU_BUCKET_PIPED"):
+    for k in ENV:
         monkeypatch.delenv(k, raising=False)
     for k, v in MODES[request.param].items():
         monkeypatch.setenv(k, v)
@@ -34,7 +42,7 @@ def mode(request, monkeypatch):
 
 def _engine(capacity, max_batch):
     import throttlecrab_amd as t
-    e = t.Engine(capacity, max_batch)  # (reads the TCGPU_BUCKET* variables now)
+    e = t.Engine(capacity, max_batch)  # (reads the TCGPU_BLOCK* / TCGPU_BUCKET* variables now)
     e.check_on_close = True
     return e
 
@@ -112,8 +120,53 @@ def test_edge_sizes(mode, n):
     eng.close()
 
 
+REGIMES = [
+    (1, 1, 1, 1, "burst 1"),
+    (1, 1, 1, 0, "q=0 burst 1"),
+    (10, 100, 60, 0, "q=0"),
+    (10, 2**62, 60, 1, "ei=0"),
+    (10, 10, 60, 2**62, "huge q"),
+    (2**63 - 1, 2**63 - 1, 2**63 - 1, 1, "i64::MAX"),
+    (4, 10, 60, 1, "regular"),
+]
+
+
+@pytest.mark.parametrize("burst,count,period,q,label", REGIMES, ids=[c[4] for c in REGIMES])
+@pytest.mark.parametrize("grouped", [False, True], ids=["by_index", "grouped_rows"])
+def test_irregular_runs_and_grouped_rows(mode, burst, count, period, q, label, grouped):
+    """runs the host cannot prove regular (walked request by request inside the block) and TC_B_GROUPED_OUTPUT rows,
+    keys with ~10 requests each, all outputs"""
+    import torch
+    import zlib
+    cap, n = 40_000, 24_000
+    rng = np.random.default_rng(zlib.crc32(label.encode()))
+    eng, orc = _engine(cap, n), _oracle(cap)
+    eng.use_torch_stream()
+    for rnd in range(3):
+        slots = (rng.integers(0, 2400, n) * 17 % cap).astype(np.uint32)
+        slots[rng.random(n) < 0.01] = cap + 1
+        now = T0 + rnd * 300_000_000
+        ref = orc.batch_slots(slots, burst, count, period, q, now)
+        res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).cuda(), max_burst=burst, count_per_period=count, period=period,
+                                         quantity=q, now_ns=now, want=FIELDS, grouped=grouped, inputs_ready=(rnd == 1))
+        torch.cuda.synchronize()
+        if not grouped:
+            assert_same(res, ref, f"{mode}/{label} round {rnd}")
+        else:
+            order = res.order.cpu().numpy().astype(np.int64)
+            assert np.array_equal(np.sort(order), np.arange(n))
+            sk = np.minimum(slots[order].astype(np.int64), cap)
+            assert np.all(np.diff(sk) >= 0) and np.all((np.diff(sk) > 0) | (np.diff(order) > 0)), "rows grouped by key, index order inside"
+            for f in FIELDS:
+                back = np.empty(n, np.int64)
+                back[order] = getattr(res, f).cpu().numpy().astype(np.int64)
+                assert np.array_equal(back, getattr(ref, f).astype(np.int64)), (mode, label, f, rnd)
+        assert_state_same(eng, orc, slots[::5])
+    eng.close()
+
+
 def test_in_order_batches_between_pipelined_ones(mode):
-    """device batches: in-order ones (bucket path) and TC_B_INPUTS_READY ones (sorted on the auxiliary streams) mixed
+    """device batches: in-order ones and TC_B_INPUTS_READY ones (grouped on the auxiliary streams) mixed
     without a host synchronisation in between; counters and state at the end"""
     import torch
     cap, n = 200_000, 40_000
@@ -160,7 +213,8 @@ def test_denied_counters(mode, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["uniform", "hot_key"])
 def test_full_size_in_order(kind):
-    """BASELINE configs[1] shape in order on one stream: 10 M keys, 1 Mi requests per batch (2048-slot buckets)"""
+    """BASELINE configs[1] shape in order on one stream: 10 M keys, 1 Mi requests per batch (256 ranges of 39 063 slots;
+    the hot key's range trips the gate)"""
     import torch
     cap, n = 10_000_000, 1 << 20
     rng = np.random.default_rng(99)
