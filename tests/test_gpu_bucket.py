@@ -1,14 +1,12 @@
-"""GPU parity of the sort-free grouping paths.  Uniform batches are grouped by a stable partition into key ranges
-instead of a full sort, with the sort path enqueued behind a device-side gate (the partition's largest range):
-the block path (csrc/block_path.hpp: 256 ranges, one block per range sorts in LDS and evaluates) and the older
-bucket path (csrc/bucket_path.hpp: thousands of buckets, one wave per bucket).  Every mode must give the
-oracle's results bit for bit, on all outputs and on the resident state:
-  default            the engine's own thresholds (block path for batches >= 16384 requests, ranges <= 6144 requests)
-  block_all_sizes    every uniform batch, however small
-  block_mixed        ... with ranges of at most 300 requests: some batches take the block path, some trip the gate
-  block_gate_trips   ... and (nearly) every batch trips the gate: block kernels leave at once, the gated sort path runs
-  bucket, bucket_all_sizes, bucket_long, bucket_gate_trips   the same for the bucket path (block path off)
-  off                both paths disabled"""
+"""GPU parity of the bucket path (csrc/bucket_path.hpp): uniform batches that run in order on the engine's
+stream are grouped by a stable partition into key-range buckets + a per-bucket rank pass instead of a sort,
+with the sort path enqueued behind a device-side gate (the partition's largest bucket).  Every mode must give
+the oracle's results bit for bit, on all outputs and on the resident state:
+  default       the engine's own thresholds (batches >= 16384 requests, buckets <= 1024 requests)
+  all_sizes     every eligible batch, however small
+  long_buckets  ... and buckets of any length stay on the bucket path (the walk in pieces with parked stores)
+  gate_trips    ... and every batch trips the gate (bucket kernels leave at once, the gated sort path runs)
+  off           the bucket path disabled"""
 import numpy as np
 import pytest
 
@@ -18,17 +16,12 @@ pytestmark = pytest.mark.gpu
 
 MODES = {
     "default": {},
-    "block_all_sizes": {"TCGPU_BLOCK_MIN_N": "1"},
-    "block_mixed": {"TCGPU_BLOCK_MIN_N": "1", "TCGPU_BLOCK_CAP": "300"},
-    "block_gate_trips": {"TCGPU_BLOCK_MIN_N": "1", "TCGPU_BLOCK_CAP": "2"},
-    "bucket": {"TCGPU_BLOCK": "0"},
-    "bucket_all_sizes": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET_MIN_N": "1"},
-    "bucket_long": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "32767"},
-    "bucket_gate_trips": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "1"},
-    "off": {"TCGPU_BLOCK": "0", "TCGPU_BUCKET": "0"},
+    "all_sizes": {"TCGPU_BUCKET_MIN_N": "1"},
+    "long_buckets": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "32767"},
+    "gate_trips": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "1"},
+    "off": {"TCGPU_BUCKET": "0"},
 }
-ENV = ("TCGPU_BLOCK", "TCGPU_BLOCK_MIN_N", "TCGPU_BLOCK_CAP", "TCGPU_BLOCK_PIPED", "TCGPU_BUCKET", "TCGPU_BUCKET_MIN_N", "TCGPU_BUCKET_SKEW",
-       "TCGPU_BUCKET_PIPED")
+ENV = ("TCGPU_BUCKET", "TCGPU_BUCKET_MIN_N", "TCGPU_BUCKET_SKEW", "TCGPU_BUCKET_PIPED")
 
 
 @pytest.fixture(params=list(MODES), ids=list(MODES))
@@ -42,7 +35,7 @@ def mode(request, monkeypatch):
 
 def _engine(capacity, max_batch):
     import throttlecrab_amd as t
-    e = t.Engine(capacity, max_batch)  # (reads the TCGPU_BLOCK* / TCGPU_BUCKET* variables now)
+    e = t.Engine(capacity, max_batch)  # (reads the TCGPU_BUCKET* variables now)
     e.check_on_close = True
     return e
 
@@ -134,7 +127,7 @@ REGIMES = [
 @pytest.mark.parametrize("burst,count,period,q,label", REGIMES, ids=[c[4] for c in REGIMES])
 @pytest.mark.parametrize("grouped", [False, True], ids=["by_index", "grouped_rows"])
 def test_irregular_runs_and_grouped_rows(mode, burst, count, period, q, label, grouped):
-    """runs the host cannot prove regular (walked request by request inside the block) and TC_B_GROUPED_OUTPUT rows,
+    """runs the host cannot prove regular and TC_B_GROUPED_OUTPUT rows (both stay on the sort path whatever the mode),
     keys with ~10 requests each, all outputs"""
     import torch
     import zlib
@@ -213,8 +206,7 @@ def test_denied_counters(mode, monkeypatch):
 
 @pytest.mark.parametrize("kind", ["uniform", "hot_key"])
 def test_full_size_in_order(kind):
-    """BASELINE configs[1] shape in order on one stream: 10 M keys, 1 Mi requests per batch (256 ranges of 39 063 slots;
-    the hot key's range trips the gate)"""
+    """BASELINE configs[1] shape in order on one stream: 10 M keys, 1 Mi requests per batch (2048-slot buckets)"""
     import torch
     cap, n = 10_000_000, 1 << 20
     rng = np.random.default_rng(99)

@@ -34,10 +34,6 @@ constexpr int RADIX = 256;
 constexpr int MAX_PASSES = 4;
 constexpr int GROUP = 16;          // tiles per look-back group
 constexpr int GROUP_WINDOW = 16;   // predecessor groups examined per look-back round trip
-constexpr int EXTRA_WORDS = 4;     // gate, done, 2 spare
-constexpr int RANGE_ROW = 3;       // histogram / look-back row of the key-range partition (block_path.hpp); needs passes <= 3
-constexpr int SUB_BITS = 2;        // every range is evaluated as 4 sub-ranges (one block each)
-constexpr int SUBS = RADIX << SUB_BITS; // sub-ranges of the key space: __umulhi(slot, rmul) < SUBS, range = that >> SUB_BITS
 constexpr uint32_t RESIDENT_TILES = 1024; // <= this many tiles are co-resident on 256 CUs (>= 4 blocks/CU)
 
 constexpr uint32_t FLAG_PARTIAL = 1u << 30;
@@ -62,10 +58,6 @@ struct Workspace {
     uint32_t* hist;      // [MAX_PASSES][RADIX] digit histograms of this batch (zero on entry)
     uint32_t* hist_next; // the other parity's histograms: cleared here for the next batch
     uint32_t* ticket;    // [MAX_PASSES] dynamic tile ids (forward progress for the look-back)
-    uint32_t* gate;      // block path: the longest sub-range of this batch (k_hist's last block publishes it)
-    uint32_t* done;      // ... blocks of k_hist that have added their counts (reset by the last one)
-    uint32_t* sub;       // ... [SUBS] requests per sub-range (zero on entry)
-    uint32_t* sub_next;  // ... the other parity's, cleared here
     uint32_t* status;    // [MAX_PASSES] x { part[max_tiles] | gacc[max_groups] | gincl[max_groups] } x RADIX
     uint32_t max_tiles;
     uint32_t max_groups;
@@ -78,19 +70,14 @@ __host__ __device__ inline size_t pass_status_words(uint32_t max_tiles, uint32_t
 }
 // words of the whole workspace (two histogram parities | tickets | status)
 inline size_t workspace_words(uint32_t max_tiles) {
-    return (size_t)2 * MAX_PASSES * RADIX + MAX_PASSES + EXTRA_WORDS + (size_t)2 * SUBS +
-           (size_t)MAX_PASSES * pass_status_words(max_tiles, groups_of(max_tiles));
+    return (size_t)2 * MAX_PASSES * RADIX + MAX_PASSES + (size_t)MAX_PASSES * pass_status_words(max_tiles, groups_of(max_tiles));
 }
 inline Workspace carve(uint32_t* base, uint32_t parity, uint32_t max_tiles) {
     Workspace ws;
     ws.hist = base + (size_t)parity * MAX_PASSES * RADIX;
     ws.hist_next = base + (size_t)(parity ^ 1u) * MAX_PASSES * RADIX;
     ws.ticket = base + (size_t)2 * MAX_PASSES * RADIX;
-    ws.gate = ws.ticket + MAX_PASSES;
-    ws.done = ws.gate + 1;
-    ws.sub = ws.ticket + MAX_PASSES + EXTRA_WORDS + (size_t)parity * SUBS;
-    ws.sub_next = ws.ticket + MAX_PASSES + EXTRA_WORDS + (size_t)(parity ^ 1u) * SUBS;
-    ws.status = ws.ticket + MAX_PASSES + EXTRA_WORDS + (size_t)2 * SUBS;
+    ws.status = ws.ticket + MAX_PASSES;
     ws.max_tiles = max_tiles;
     ws.max_groups = groups_of(max_tiles);
     ws.violations = nullptr;
@@ -111,33 +98,25 @@ __device__ __forceinline__ bool gated_off(const uint32_t* __restrict__ gate, uin
     return gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min;
 }
 
-// `rmul` != 0: the batch is also enqueued on the block path (block_path.hpp).  ws.sub gets the histogram of the
-// SUBS equal sub-ranges of the key space, __umulhi(slot, rmul); the block that finishes last publishes the
-// longest sub-range in *ws.gate -- which decides on the device which of the two paths' kernels run -- and the
-// requests per range (4 sub-ranges) as row RANGE_ROW, the digit histogram of the partition pass.
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
                                                   int passes, Workspace ws, uint32_t tiles, const uint32_t* __restrict__ gate,
-                                                  uint32_t gate_min, uint32_t rmul) {
+                                                  uint32_t gate_min) {
     __shared__ uint32_t s_h[MAX_PASSES][RADIX];
-    __shared__ uint32_t s_sub[SUBS];
     if (gated_off(gate, gate_min)) {
         if (blockIdx.x == 0)
             for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) ws.hist_next[i] = 0;
         return;
     }
     for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) (&s_h[0][0])[i] = 0;
-    if (rmul)
-        for (int i = threadIdx.x; i < SUBS; i += NT) s_sub[i] = 0;
     // clear the look-back words this sort will use (every pass: part | gacc | gincl) + tickets
     {
         const uint32_t groups = groups_of(tiles);
         const uint32_t per_pass = (tiles + 2 * groups) * RADIX;
         const size_t pass_stride = pass_status_words(ws.max_tiles, ws.max_groups);
-        const uint32_t total_status = (uint32_t)(passes + (rmul ? 1 : 0)) * per_pass;
+        const uint32_t total_status = (uint32_t)passes * per_pass;
         for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < total_status; i += gridDim.x * NT) {
-            uint32_t p = i / per_pass;
-            if (p >= (uint32_t)passes) p = RANGE_ROW;
+            const uint32_t p = i / per_pass;
             uint32_t r = i % per_pass;
             size_t at;
             if (r < tiles * RADIX) at = r;
@@ -149,7 +128,6 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
     if (blockIdx.x == 0) {
         if (threadIdx.x < MAX_PASSES) ws.ticket[threadIdx.x] = 0;
         for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) ws.hist_next[i] = 0;
-        for (int i = threadIdx.x; i < SUBS; i += NT) ws.sub_next[i] = 0;
     }
     __syncthreads();
     {
@@ -164,48 +142,17 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
             for (int u = 0; u < 4; ++u) {
                 const uint32_t kk = clamp_slot(k[u], cap);
                 for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-                if (rmul) atomicAdd(&s_sub[__umulhi(kk, rmul)], 1u);
             }
         }
         for (; i < n; i += stride) {
             const uint32_t kk = clamp_slot(slot[i], cap);
             for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-            if (rmul) atomicAdd(&s_sub[__umulhi(kk, rmul)], 1u);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) {
-        const uint32_t v = (&s_h[0][0])[i]; // (rows nobody counted into are zero)
+    for (int i = threadIdx.x; i < passes * RADIX; i += NT) {
+        const uint32_t v = (&s_h[0][0])[i];
         if (v) atomicAdd(&ws.hist[i], v);
-    }
-    if (rmul) {
-        for (int i = threadIdx.x; i < SUBS; i += NT)
-            if (s_sub[i]) atomicAdd(&ws.sub[i], s_sub[i]);
-        // the last block to get here sees every block's counts (device-scope atomics, fence, ticket)
-        __shared__ uint32_t s_last, s_max[NT / 64];
-        __threadfence();
-        __syncthreads();
-        if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ws.done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
-        __syncthreads();
-        if (!s_last) return;
-        uint32_t v = 0;
-        for (int i = threadIdx.x; i < RADIX; i += NT) {
-            uint32_t sum = 0;
-            for (int u = 0; u < (1 << SUB_BITS); ++u) {
-                const uint32_t c = __hip_atomic_load(&ws.sub[(i << SUB_BITS) + u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                v = max(v, c);
-                sum += c;
-            }
-            ws.hist[RANGE_ROW * RADIX + i] = sum;
-        }
-        for (int off = 32; off > 0; off >>= 1) v = max(v, __shfl_down(v, off, 64));
-        if ((threadIdx.x & 63) == 0) s_max[threadIdx.x >> 6] = v;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            for (int w = 1; w < NT / 64; ++w) v = max(v, s_max[w]);
-            *ws.gate = v;
-            *ws.done = 0;
-        }
     }
 }
 
@@ -216,12 +163,9 @@ template <int ITEMS, bool FIRST>
 __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict__ slot_in,
                                                       const uint64_t* __restrict__ elem_in,
                                                       uint64_t* __restrict__ elem_out, uint32_t n, uint32_t cap,
-                                                      int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min,
-                                                      uint32_t rmul) {
+                                                      int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min) {
     constexpr int TILE = THREADS * ITEMS;
-    // rmul != 0: the block path's partition by key range (digit = __umulhi(slot, rmul) >> SUB_BITS, pass == RANGE_ROW),
-    // which runs when the longest sub-range is NOT longer than gate_min -- the opposite sense of the LSD passes'
-    if (rmul ? (__builtin_nontemporal_load(gate) > gate_min) : gated_off(gate, gate_min)) return; // (the whole grid: nobody is left waiting)
+    if (gated_off(gate, gate_min)) return; // (the whole grid: nobody is left waiting in a look-back)
     __shared__ uint32_t s_base[RADIX];          // global exclusive start of each digit
     __shared__ uint32_t s_wave[WAVES][RADIX];   // per-wave digit counts -> exclusive prefix over waves
     __shared__ uint32_t s_off[RADIX];           // where this tile's run of each digit starts
@@ -285,7 +229,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool valid = (wbase + j * 64) < n;
-        const uint32_t d = rmul ? (valid ? __umulhi(key[j], rmul) >> SUB_BITS : 255u) : (key[j] >> shift) & 255u;
+        const uint32_t d = (key[j] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -342,7 +286,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if ((wbase + j * 64) < n) {
-            const uint32_t d = rmul ? __umulhi(key[j], rmul) >> SUB_BITS : (key[j] >> shift) & 255u;
+            const uint32_t d = (key[j] >> shift) & 255u;
             s_elem[s_tstart[d] + s_wave[wave][d] + rank[j]] = ((uint64_t)key[j] << 32) | val[j];
         }
     }
@@ -437,7 +381,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
         const uint32_t i = j * THREADS + threadIdx.x;
         if (i < nvalid) {
             const uint64_t e = s_elem[i];
-            const uint32_t d = rmul ? __umulhi((uint32_t)(e >> 32), rmul) >> SUB_BITS : ((uint32_t)(e >> 32) >> shift) & 255u;
+            const uint32_t d = ((uint32_t)(e >> 32) >> shift) & 255u;
             elem_out[i + s_off[d]] = e;
         }
     }

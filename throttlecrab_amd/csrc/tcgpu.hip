@@ -36,7 +36,6 @@
 
 #include "eval_kernels.hpp"
 #include "bucket_path.hpp"
-#include "block_path.hpp"
 #include "maintenance_kernels.hpp"
 #include "route_kernels.hpp"
 
@@ -177,13 +176,6 @@ struct tc_engine {
     // bucket path (bucket_path.hpp): uniform batches are partitioned by key range and ranked per bucket instead of
     // sorted.  Such a batch is enqueued on BOTH paths; the partition's largest bucket (a word in device memory,
     // the gate) decides on the device which of the two runs, so a skewed batch never waits for the host.
-    // block path (block_path.hpp): one partition pass by key range + one block per sub-range (LDS sort + evaluation)
-    bool bk_ok = false;      // the key space fits (every sub-range < 65536 slots); TCGPU_BLOCK=0 switches the path off
-    uint32_t bk_mul = 0;     // slot -> sub-range multiplier
-    uint32_t bk_bits = 0;    // bits of a slot's offset inside its sub-range
-    uint32_t bk_min_n = 16384;
-    uint32_t bk_cap = bk::CAP; // longest range the path takes on (TCGPU_BLOCK_CAP <= bk::CAP: the tests trip the gate with it)
-    bool bk_piped = true;    // also for TC_B_INPUTS_READY batches (TCGPU_BLOCK_PIPED=0: those are sorted)
     bool bp_ok = false;      // the key space fits the path (<= bp::MAX_BUCKETS buckets)
     int bp_lb = 0;           // log2(slots per bucket)
     uint32_t bp_nbk = 0;
@@ -323,22 +315,10 @@ static int engine_alloc(tc_engine* e) {
         TC_HIP(e, hipEventCreateWithFlags(&ss.consumed, hipEventDisableTiming));
     }
     {
-        const char* off = getenv("TCGPU_BLOCK");
-        const int bits = std::max(1, bit_width_u64(e->capacity));
-        e->bk_ok = bk::fits(cap) && (bits + 7) / 8 < rs::MAX_PASSES && !(off && atoi(off) == 0); // (row RANGE_ROW of the sort's histograms must be free)
-        if (e->bk_ok) {
-            e->bk_mul = bk::range_mul(cap);
-            e->bk_bits = (uint32_t)bit_width_u64(bk::range_width(e->bk_mul) - 1);
-        }
-        if (const char* d = getenv("TCGPU_BLOCK_PIPED")) e->bk_piped = atoi(d) != 0;
-        if (const char* d = getenv("TCGPU_BLOCK_MIN_N")) e->bk_min_n = (uint32_t)std::max(atoi(d), 1);
-        if (const char* d = getenv("TCGPU_BLOCK_CAP")) e->bk_cap = (uint32_t)std::min<long long>(std::max(atoll(d), 1ll), bk::CAP);
-    }
-    {
         e->bp_max_n = (uint32_t)std::min<uint64_t>(mb, bp::MAX_N);
         e->bp_lb = bp::pick_lb(cap, e->bp_max_n);
         const char* off = getenv("TCGPU_BUCKET");
-        e->bp_ok = !e->bk_ok && e->bp_lb >= 0 && !(off && atoi(off) == 0);
+        e->bp_ok = e->bp_lb >= 0 && !(off && atoi(off) == 0);
         e->bp_min_n = 16384;
         if (const char* d = getenv("TCGPU_BUCKET_PIPED")) e->bp_piped = atoi(d) != 0;
         if (const char* d = getenv("TCGPU_BUCKET_MIN_N")) e->bp_min_n = (uint32_t)std::max(atoi(d), 1);
@@ -873,15 +853,8 @@ static int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, boo
 
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
 // returns the buffer holding the result
-// `blk` != nullptr: the batch goes down the block path as well (block_path.hpp).  k_hist also counts the key
-// ranges and publishes the largest (ws.gate); the partition by range runs if that fits a block, the LSD passes
-// (gated the other way) if not.  blk gets what k_block_eval needs.
-struct BlockJob {
-    const uint64_t* part = nullptr; // the batch partitioned by key range
-    rs::Workspace ws;
-};
 static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
-                                    bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0, BlockJob* blk = nullptr) {
+                                    bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
     const int passes = (bits + 7) / 8;
@@ -890,26 +863,10 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
     ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
     ss.hist_parity ^= 1u;
-    const uint32_t rmul = blk ? e->bk_mul : 0u;
     prof_begin(e, TC_STAGE_PREP, s);
-    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, rmul);
+    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min);
     prof_end(e, s);
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
-    if (blk) {
-        // (only one of the two paths really runs: they share the element buffers)
-        gate = ws.gate;
-        gate_min = e->bk_cap;
-        prof_begin(e, TC_STAGE_BUCKET_SCATTER, s);
-        if (piped)
-            hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                               (const uint64_t*)nullptr, bufs[1], n, cap, rs::RANGE_ROW, ws, gate, gate_min, rmul);
-        else
-            hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                               (const uint64_t*)nullptr, bufs[1], n, cap, rs::RANGE_ROW, ws, gate, gate_min, rmul);
-        prof_end(e, s);
-        blk->part = bufs[1];
-        blk->ws = ws;
-    }
     const uint64_t* in = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
@@ -917,17 +874,17 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
         if (p == 0) {
             if (piped)
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min, 0u);
+                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min);
             else
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min, 0u);
+                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min);
         } else {
             if (piped)
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
-                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min, 0u);
+                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min);
             else
                 hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
-                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min, 0u);
+                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min);
         }
         prof_end(e, s);
         in = out;
@@ -1032,17 +989,6 @@ static void bucket_eval(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, con
     default: TC_BEV(true, true, true); break;
     }
 #undef TC_BEV
-    prof_end(e, s);
-}
-
-// ---- block path (block_path.hpp): one block per key range -------------------------------------------
-static void block_eval(tc_engine* e, hipStream_t s, const Params& p, bool full, const BlockJob& job) {
-    const dim3 grid(bk::SUBS), block(bk::THREADS);
-    prof_begin(e, TC_STAGE_BUCKET_EVAL, s);
-    if (full && e->fixed) hipLaunchKernelGGL((bk::k_block_eval<true, true>), grid, block, 0, s, p, job.part, job.ws, e->bk_mul, e->bk_bits, e->bk_cap);
-    else if (full) hipLaunchKernelGGL((bk::k_block_eval<true, false>), grid, block, 0, s, p, job.part, job.ws, e->bk_mul, e->bk_bits, e->bk_cap);
-    else if (e->fixed) hipLaunchKernelGGL((bk::k_block_eval<false, true>), grid, block, 0, s, p, job.part, job.ws, e->bk_mul, e->bk_bits, e->bk_cap);
-    else hipLaunchKernelGGL((bk::k_block_eval<false, false>), grid, block, 0, s, p, job.part, job.ws, e->bk_mul, e->bk_bits, e->bk_cap);
     prof_end(e, s);
 }
 
@@ -1159,13 +1105,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         // the sort's three coalesced passes (69-86 vs 66 us per 1 Mi batch).
         // (TC_B_GROUPED_OUTPUT promises rows grouped by key: that is the sorted order)
         const bool bucketed = direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
-        // Block path: every uniform batch (regular runs or not) is partitioned by key range and evaluated by one
-        // block per range, with the sort path gated behind it for batches whose largest range does not fit a block.
-        const bool blocked = uniform && e->bk_ok && n >= e->bk_min_n && n <= bk::CAP * (uint32_t)bk::SUBS && (!piped || e->bk_piped);
-        BlockJob job;
-        BlockJob* blk = blocked ? &job : nullptr;
         const uint32_t* gate = bucketed ? ss.bpw.maxb : nullptr;
-        uint32_t gate_min = e->bp_skew;
         const uint64_t* sorted;
         const uint32_t* d_slot = b.slot;
         if (piped) {
@@ -1175,7 +1115,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
             if (bucketed) bucket_partition(e, ss, ax, d_slot, n);
-            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, gate_min, blk);
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew);
             TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
         } else {
@@ -1183,12 +1123,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             // and every auxiliary sort was joined into `s` before its evaluation
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
             if (bucketed) bucket_partition(e, ss, s, d_slot, n);
-            sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, gate_min, blk);
-        }
-        if (blocked) {
-            gate = job.ws.gate;
-            gate_min = e->bk_cap;
-            block_eval(e, s, p, full, job);
+            sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
         }
         if (bucketed) bucket_eval(e, ss, s, p, full);
         prof_begin(e, TC_STAGE_EVAL, s);
@@ -1198,7 +1133,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
                 if (++e->loaded_seq == 0u) e->loaded_seq = 1u;
                 seq = e->loaded_seq;
             }
-            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, gate_min);
+            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew);
             prof_end(e, s);
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
