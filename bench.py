@@ -488,24 +488,28 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     d_global = [torch.from_numpy(h.astype(np.int32)).to(dev) for h in host]
     RING = 8  # routed slot columns stay untouched while up to pipeline-depth batches are in flight
     ring = [(torch.empty(G, dtype=torch.int32, device=dev), None, torch.zeros(world, dtype=torch.int32, device=dev)) for _ in range(RING)]
-    counts_host = [torch.empty(world, dtype=torch.int32).pin_memory() for _ in range(RING)]
-    ready = [torch.cuda.Event() for _ in range(RING)]
+    counts_host = [eng.host_alloc(world + 1, np.uint32) for _ in range(RING)]   # pinned: counts, then the batch's tag
+    for c in counts_host:
+        c[:] = 0
     out = t.BatchResult()
     cnt_view = sharded.device_counter_view(eng)
     gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
     top_gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64, device=dev)
     decided = 0
 
+    # TC_ROUTE_AHEAD: the router runs on the engine's grouping streams, beside the evaluations of earlier batches (it
+    # only reads the global batch and writes a ring entry whose last reader is already on the engine's stream), and
+    # its last block writes the counts + the batch's tag into pinned host memory: the host learns how many requests
+    # it owns by polling that word -- no event, no stream synchronisation on the way.
     def route(i):
         r = i % RING
-        eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r])
-        counts_host[r].copy_(ring[r][2], non_blocking=True)
-        ready[r].record()
+        eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r], ahead=True, host_counts=counts_host[r], tag=i + 1)
 
     def evaluate(i, last=False, metrics=True):
         nonlocal decided
         r = i % RING
-        ready[r].synchronize()          # recorded a whole step ago: no stall in steady state
+        while int(counts_host[r][world]) != i + 1:   # routed LOOKAHEAD steps ago: no wait in steady state
+            pass
         mine = int(counts_host[r][rank])
         for lo in range(0, mine, cap_batch):
             hi = min(mine, lo + cap_batch)
@@ -611,7 +615,11 @@ def main():
     dev = torch.device(f"cuda:{local}")
 
     if dist is not None:
-        sh = run_sharded(a, t, W, dev, local, rank, world, dist)
+        # a real stream for the engine AND torch / RCCL (torch's default stream has handle 0, which the engine reads as
+        # "use your own stream": the metrics all-gather would then not be ordered behind the counters' refresh)
+        with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+            sh = run_sharded(a, t, W, dev, local, rank, world, dist)
+            torch.cuda.synchronize()
         if rank == 0:
             print(json.dumps({
                 "metric": "GCRA decisions/sec, 10M keys per GPU", "value": sh["value"], "unit": "decisions/s", "n_gpus": world,

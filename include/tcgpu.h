@@ -310,12 +310,21 @@ int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_b
 
 /* ---- multi-GPU: routing a global request stream to the GPU that owns each key -----------------------------
  * The reference has no distributed mode ("use client-side sharding by key", README.md:247-249).  A key space of
- * world * keys_per_shard GLOBAL ids is sharded without a routing table: a bijection of that range sends id to
- * (owner = x mod world, shard-local slot = x div world), x = (id * mul + add) mod (world * keys_per_shard), mul
- * coprime with the modulus -- every shard gets exactly keys_per_shard dense slots.  tc_route_batch keeps, of a
- * batch of global ids in device memory, the requests a destination owns (stable: the requests of a key keep
- * their order) as shard-local slots ready for tc_rate_limit_batch_slots; asynchronous on the engine's stream.
+ * world * keys_per_shard GLOBAL ids is sharded without a routing table by a bijection of that range:
+ *     q = id div world, r = id mod world:   shard-local slot = q,   owner = (r + mix(q)) mod world
+ * (mix(q) = the top bits of q * 0x9E3779B1 scaled to [0, world): ids that share a residue are still spread over all
+ * owners) -- every shard gets exactly keys_per_shard dense slots.  tc_route_batch keeps, of a batch of global ids
+ * in device memory, the requests a destination owns (stable: the requests of a key keep their order) as
+ * shard-local slots ready for tc_rate_limit_batch_slots; asynchronous on the engine's stream (or on r->stream).
  * No collective is involved: each GPU filters the stream it is handed. */
+/* tc_route.flags */
+#define TC_ROUTE_AHEAD 0x1u   /* run the router on one of the engine's grouping streams, ordered behind the grouping of
+                               * every batch whose call has returned (the last reader of a slot column -- except for
+                               * TC_B_UNIQUE_SLOTS batches, whose evaluation reads it -- so out_slot may be a buffer an
+                               * earlier batch call was given); successive routers rotate over those streams and do
+                               * not wait for one another (give each its own out_* buffers): it then
+                               * works beside the evaluations of earlier batches instead of between them -- with
+                               * out_count_host, the way to route several global batches ahead of the evaluation */
 typedef struct tc_route {
     uint32_t struct_size;     /* = sizeof(tc_route) */
     uint32_t world;           /* number of shards (GPUs), 1..64 */
@@ -324,10 +333,19 @@ typedef struct tc_route {
     const uint32_t* global_id; /* [n] device: global key ids in [0, world * keys_per_shard) (others: taken modulo) */
     int32_t only;             /* >= 0: write that destination's requests only, from out_slot[0];
                                * -1: every destination's segment, one after the other (start of d = sum of counts before d) */
-    int32_t reserved0;
+    uint32_t flags;           /* TC_ROUTE_* */
     uint32_t* out_slot;       /* [n] device: shard-local slots */
     uint32_t* out_pos;        /* [n] device or NULL: position of each kept request in the global batch */
     uint32_t* out_count;      /* [world] device: requests per destination (all of them, whatever `only` is) */
+    void* stream;             /* NULL: the engine's stream.  Else the hipStream_t to enqueue the router on (the caller
+                               * orders that stream before the batch call that reads out_slot; successive
+                               * tc_route_batch calls must use one stream) */
+    uint32_t* out_count_host; /* NULL or [world + 1] PINNED host memory (tc_host_alloc): the router's last block
+                               * writes the counts there and, after them, `tag` into out_count_host[world].  A caller
+                               * that polls that word needs no stream synchronisation to learn how many requests it
+                               * owns: once the tag is there, out_slot / out_pos are complete too. */
+    uint32_t tag;             /* any value the previous use of out_count_host did not leave there */
+    uint32_t reserved1;
 } tc_route;
 int tc_route_batch(tc_engine* e, const tc_route* r);
 /* The same map on the host: owner and shard-local slot of n global ids (either output may be NULL), and its

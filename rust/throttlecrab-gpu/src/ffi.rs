@@ -32,6 +32,8 @@ pub const TC_B_INPUTS_READY: u32 = 0x8;
 pub const TC_B_GROUPED_OUTPUT: u32 = 0x10;
 pub const TC_B_ASYNC: u32 = 0x20;
 
+pub const TC_ROUTE_AHEAD: u32 = 0x1;
+
 pub const TC_CNT_TOTAL: usize = 0;
 pub const TC_CNT_ALLOWED: usize = 1;
 pub const TC_CNT_DENIED: usize = 2;
@@ -118,10 +120,14 @@ pub struct tc_route {
     pub n: u64,
     pub global_id: *const u32,
     pub only: i32,
-    pub reserved0: i32,
+    pub flags: u32,
     pub out_slot: *mut u32,
     pub out_pos: *mut u32,
     pub out_count: *mut u32,
+    pub stream: *mut c_void,
+    pub out_count_host: *mut u32,
+    pub tag: u32,
+    pub reserved1: u32,
 }
 
 extern "C" {

@@ -8,8 +8,13 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 8, 64])
+@pytest.mark.parametrize("passes", ["default", "three_kernels"])
 @pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4096, 4097, 300_000])
-def test_device_partition_equals_host_mirror(world, n):
+def test_device_partition_equals_host_mirror(world, n, passes, monkeypatch):
+    if passes == "three_kernels":  # (one destination is otherwise routed in one pass over the ids)
+        monkeypatch.setenv("TCGPU_ROUTE_3PASS", "1")
+    else:
+        monkeypatch.delenv("TCGPU_ROUTE_3PASS", raising=False)
     import torch
     import throttlecrab_amd as t
     from throttlecrab_amd import sharded
@@ -42,4 +47,92 @@ def test_device_partition_equals_host_mirror(world, n):
         assert np.array_equal(c2.cpu().numpy(), counts)
         assert np.array_equal(p2.cpu().numpy()[: len(want)], want)
         assert np.array_equal(s2.cpu().numpy().astype(np.uint32)[: len(want)], slot[want])
+    eng.close()
+
+
+@pytest.mark.parametrize("n,world", [(4_100_000, 2), (6_000_000, 8), (8 << 20, 8), (9_000_000, 3)])
+def test_one_destination_of_a_big_global_batch(n, world):
+    """the one-pass router at its grid limits: 1001 tiles of 4096 ids, 733 and 1024 tiles of 8192, and beyond them
+    (count | scan | scatter)"""
+    import torch
+    import throttlecrab_amd as t
+    from throttlecrab_amd import sharded
+    cap = 10_000_000
+    rng = np.random.default_rng(n)
+    ids = rng.integers(0, world * cap, n).astype(np.uint32)
+    owner, slot = sharded.route(ids, world, cap)
+    eng = t.Engine(cap, 1 << 16)
+    eng.use_torch_stream()
+    d = torch.from_numpy(ids.astype(np.int32)).cuda()
+    for dest in (0, world - 1):
+        s2, p2, c2 = eng.route_batch(d, world, only=dest, want_pos=True)
+        torch.cuda.synchronize()
+        want = np.nonzero(owner == dest)[0]
+        assert np.array_equal(c2.cpu().numpy(), np.bincount(owner, minlength=world))
+        assert np.array_equal(p2.cpu().numpy()[: len(want)], want)
+        assert np.array_equal(s2.cpu().numpy().astype(np.uint32)[: len(want)], slot[want])
+    assert eng.selfcheck() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("how", ["side_stream", "ahead"])
+def test_router_ahead_of_pipelined_batches(how):
+    """The router several global batches ahead of the evaluations (what bench.py --gpus N does): on a caller's side
+    stream (tc_route.stream), or on the engine's grouping streams with the counts polled from pinned host memory
+    (TC_ROUTE_AHEAD + out_count_host, ring entries reused); the routed batches evaluated as TC_B_INPUTS_READY
+    batches give the oracle's results"""
+    import torch
+    import throttlecrab_amd as t
+    from throttlecrab_amd import sharded
+    from tests.test_gpu_slots import T0, _oracle
+    world, me, cap, n, ring_n, nb = 4, 2, 50_000, 120_000, 3, 9
+    rng = np.random.default_rng(77)
+    eng, orc = t.Engine(cap, n), _oracle(cap)
+    eng.use_torch_stream()
+    eng.register_params_uniform(5, 10, 60)
+    side = torch.cuda.Stream()
+    batches = [rng.integers(0, world * cap, n).astype(np.uint32) for _ in range(nb)]
+    d = [torch.from_numpy(b.astype(np.int32)).cuda() for b in batches]
+    ring = [(torch.empty(n, dtype=torch.int32, device="cuda"), None, torch.zeros(world, dtype=torch.int32, device="cuda")) for _ in range(ring_n)]
+    host = [eng.host_alloc(world + 1, np.uint32) for _ in range(ring_n)]
+    for h in host:
+        h[:] = 0
+    done = [torch.cuda.Event() for _ in range(ring_n)]
+    torch.cuda.synchronize()
+
+    def route(i):
+        r = i % ring_n
+        if how == "ahead":
+            eng.route_batch(d[i], world, only=me, out=ring[r], ahead=True, host_counts=host[r], tag=i + 1)
+        else:
+            side.wait_stream(torch.cuda.current_stream())  # the ring entry's last reader
+            eng.route_batch(d[i], world, only=me, out=ring[r], stream=side)
+            done[r].record(side)
+
+    outs = []
+    for j in range(ring_n - 1):
+        route(j)
+    for i in range(nb):
+        if i + ring_n - 1 < nb:
+            route(i + ring_n - 1)  # (its ring entry was read by batch i - 1, which is on the engine's stream)
+        r = i % ring_n
+        if how == "ahead":
+            while int(host[r][world]) != i + 1:
+                pass
+            mine = int(host[r][me])
+        else:
+            done[r].synchronize()
+            mine = int(ring[r][2].cpu()[me])
+        res = eng.rate_limit_batch_slots(ring[r][0][:mine], registered=True, quantity=1, now_ns=T0 + i * 10**8, want=("allowed", "status"),
+                                         inputs_ready=True)
+        outs.append((mine, res.allowed, res.status))  # (each call has its own result tensors; read after the synchronisation)
+    torch.cuda.synchronize()
+    for i, (mine, allowed, status) in enumerate(outs):
+        owner, slot = sharded.route(batches[i], world, cap)
+        want = slot[owner == me]
+        assert mine == len(want), i
+        ref = orc.batch_slots(want, 5, 10, 60, 1, T0 + i * 10**8)
+        assert np.array_equal(allowed.cpu().numpy(), ref.allowed.astype(np.uint8)), i
+        assert np.array_equal(status.cpu().numpy(), ref.status.astype(np.uint8)), i
+    assert eng.selfcheck() == 0
     eng.close()

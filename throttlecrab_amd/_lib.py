@@ -20,6 +20,7 @@ TC_CFG_TRACK_DENIED = 0x2
 TC_CFG_FIXED_PARAMS = 0x4
 TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY, TC_B_GROUPED_OUTPUT = 0x1, 0x2, 0x4, 0x8, 0x10
 TC_B_ASYNC = 0x20
+TC_ROUTE_AHEAD = 0x1
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
 TC_CNT_COUNT = 8
 TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash", "bucket_hist", "bucket_scan", "bucket_scatter",
@@ -47,8 +48,8 @@ class tc_batch(C.Structure):
 
 class tc_route(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("world", C.c_uint32), ("keys_per_shard", C.c_uint64), ("n", C.c_uint64),
-                ("global_id", C.c_void_p), ("only", C.c_int32), ("reserved0", C.c_int32), ("out_slot", C.c_void_p),
-                ("out_pos", C.c_void_p), ("out_count", C.c_void_p)]
+                ("global_id", C.c_void_p), ("only", C.c_int32), ("flags", C.c_uint32), ("out_slot", C.c_void_p),
+                ("out_pos", C.c_void_p), ("out_count", C.c_void_p), ("stream", C.c_void_p), ("out_count_host", C.c_void_p), ("tag", C.c_uint32), ("reserved1", C.c_uint32)]
 
 
 class tc_result(C.Structure):

@@ -3,14 +3,20 @@
 // The reference has no distributed mode ("use client-side sharding by key", README.md:247-249); here keys are
 // independent units, so a key space of `world * keys_per_shard` global ids is sharded with no data-path
 // collective: every global id maps to (owner, shard-local slot) by a BIJECTION of [0, world * keys_per_shard)
-//     x = (id * mul + add) mod (world * keys_per_shard),   owner = x mod world,   slot = x div world
-// (mul coprime with the modulus: every shard gets exactly keys_per_shard dense slots, consecutive ids land
-// on different owners, and no routing table is needed).  A GPU is handed the global batch -- or its part of
-// it -- and keeps what it owns:
+//     q = id div world,  r = id mod world:    slot = q,    owner = (r + mix(q)) mod world,
+//     mix(q) = the top bits of q * 0x9E3779B1 scaled to [0, world)
+// -- every shard gets exactly keys_per_shard dense slots, consecutive ids land on different owners, ids that
+// share a residue mod world (a strided id space) are still spread over all owners, no routing table is needed,
+// and the inverse is as cheap (id = slot * world + (owner - mix(slot)) mod world).  The router looks at every id
+// of the global batch on every GPU, so the map has to be cheap: ~12 integer instructions, no division (round 2's
+// first map, a multiplicative permutation modulo world * keys_per_shard, needed two 64-bit reductions per id and
+// made the router ALU-bound: 62 us of kernels for 8 Mi ids).
+// A GPU is handed the global batch -- or its part of it -- and keeps what it owns:
 //   k_route_count    requests per destination, per 4096-request tile
-//   k_route_scan     prefix of those counts over the tiles + destination totals            (one block)
+//   k_route_scan     prefix of those counts over the tiles + destination totals            (one block per destination)
 //   k_route_scatter  stable compaction per destination (wave ballots): shard-local slots and, optionally, the
 //                    requests' positions in the global batch, in request order
+//   k_route_publish  (callers that poll pinned host memory) the totals and the caller's tag
 // Stable: the requests of a key keep their order, which is all the sequence semantics need.
 // `only` >= 0 writes that destination's requests alone (what one rank of bench.py --gpus N does); -1 writes every
 // destination's segment one after the other (a front end that forwards segments over xGMI).
@@ -19,95 +25,137 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "gcra_math.hpp" // tc::SpinGuard
+
 namespace rt {
 
 constexpr int THREADS = 256, ITEMS = 16;
 constexpr uint32_t TILE = THREADS * ITEMS;
 constexpr uint32_t MAX_WORLD = 64;
+constexpr uint32_t MIX = 0x9E3779B1u;
 
 struct Map {
-    uint64_t modulus; // world * keys_per_shard
-    uint64_t mul, add;
+    uint64_t modulus; // world * keys_per_shard: ids at or above it are taken modulo
     uint32_t world;
+    uint32_t inv_world; // floor(2^32 / world) (world >= 2): the device divides by multiplying
 };
-// mul < 2^24 and modulus < 2^39: the product stays below 2^63
-__host__ __device__ inline uint64_t permute(const Map& m, uint64_t id) { return (id % m.modulus * m.mul + m.add) % m.modulus; }
 
-inline uint64_t gcd64(uint64_t a, uint64_t b) {
-    while (b) {
-        const uint64_t t = a % b;
-        a = b;
-        b = t;
-    }
-    return a;
-}
 // the map of a (world, keys_per_shard) pair: the same on every rank, the host mirror and the device
 inline bool make_map(uint32_t world, uint64_t keys_per_shard, Map* out) {
     if (world == 0 || world > MAX_WORLD || keys_per_shard == 0 || keys_per_shard > ((uint64_t)1 << 32)) return false;
-    const uint64_t modulus = (uint64_t)world * keys_per_shard;
-    if (modulus >= ((uint64_t)1 << 39)) return false;
-    static const uint64_t primes[] = {10000019ull, 9999991ull, 8388617ull, 7654321ull, 6700417ull, 5000011ull, 4999999ull, 3999971ull};
-    for (uint64_t p : primes)
-        if (gcd64(p, modulus) == 1) {
-            out->modulus = modulus;
-            out->mul = p;
-            out->add = 0x5bd1e995ull % modulus;
-            out->world = world;
-            return true;
-        }
-    return false;
+    out->modulus = (uint64_t)world * keys_per_shard;
+    out->world = world;
+    out->inv_world = world > 1 ? (uint32_t)(((uint64_t)1 << 32) / world) : 0u;
+    return true;
+}
+inline uint32_t mix_of(uint32_t q, uint32_t world) { return (uint32_t)(((uint64_t)(uint32_t)(q * MIX) * world) >> 32); }
+// host mirror (and the definition): plain division
+inline void route_of_host(const Map& m, uint32_t id, uint32_t& owner, uint32_t& slot) {
+    const uint64_t v = (uint64_t)id < m.modulus ? id : (uint64_t)id % m.modulus;
+    const uint32_t q = (uint32_t)(v / m.world), r = (uint32_t)(v % m.world);
+    slot = q;
+    owner = (r + mix_of(q, m.world)) % m.world;
+}
+inline uint64_t route_inverse_host(const Map& m, uint32_t owner, uint32_t slot) {
+    const uint32_t r = (owner + m.world - mix_of(slot, m.world)) % m.world;
+    return (uint64_t)slot * m.world + r;
 }
 
+#if defined(__HIPCC__)
+// the same values without a division instruction: q' = floor(v * floor(2^32 / world) / 2^32) is q or q - 1
+__device__ __forceinline__ void route_of(const Map& m, uint32_t id, uint32_t& owner, uint32_t& slot) {
+    uint32_t v = id;
+    if ((uint64_t)v >= m.modulus) v = (uint32_t)((uint64_t)v % m.modulus); // (ids outside the key space: rare, slow path)
+    uint32_t q = v, r = 0;
+    if (m.world > 1) {
+        q = __umulhi(v, m.inv_world);
+        r = v - q * m.world;
+        if (r >= m.world) {
+            r -= m.world;
+            q += 1;
+        }
+    }
+    uint32_t o = r + __umulhi(q * MIX, m.world);
+    if (o >= m.world) o -= m.world;
+    owner = o;
+    slot = q;
+}
+#endif
+
 struct Work {
-    uint32_t* tile_cnt; // [tiles][world] -> exclusive prefix over the tiles
+    uint32_t* tile_cnt; // [world][tiles] requests per destination and tile -> exclusive prefix over the tiles
     uint32_t* totals;   // [world]
-    uint32_t* starts;   // [world + 1] segment starts in the output (only < 0), else {0, totals[only]}
+    uint32_t tiles;
+    volatile uint32_t* host_totals; // NULL or pinned host memory [world + 1]: the totals, then `tag` (written last)
+    uint32_t tag;
 };
 
 __global__ __launch_bounds__(THREADS) void k_route_count(const uint32_t* __restrict__ id, uint32_t n, Map m, Work w) {
     __shared__ uint32_t s_c[MAX_WORLD];
     if (threadIdx.x < MAX_WORLD) s_c[threadIdx.x] = 0;
     __syncthreads();
+    const int lane = threadIdx.x & 63;
     const uint32_t base = blockIdx.x * TILE + threadIdx.x;
+    const int bits = m.world > 1 ? 32 - __clz((int)m.world - 1) : 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
     uint32_t v[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) v[j] = base + j * THREADS < n ? id[base + j * THREADS] : 0u;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j)
-        if (base + j * THREADS < n) atomicAdd(&s_c[permute(m, v[j]) % m.world], 1u);
+    for (int j = 0; j < ITEMS; ++j) {
+        // one LDS atomic per destination and wave step (64 lanes adding to a handful of words serialise otherwise)
+        const bool valid = base + j * THREADS < n;
+        uint32_t owner, slot;
+        route_of(m, v[j], owner, slot);
+        unsigned long long mm = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            const unsigned long long bb = __ballot((owner >> b) & 1u);
+            mm &= ((owner >> b) & 1u) ? bb : ~bb;
+        }
+        if (valid && (mm & lt) == 0ull) atomicAdd(&s_c[owner], (uint32_t)__popcll(mm));
+    }
     __syncthreads();
-    if (threadIdx.x < m.world) w.tile_cnt[(size_t)blockIdx.x * m.world + threadIdx.x] = s_c[threadIdx.x];
+    if (threadIdx.x < m.world) w.tile_cnt[(size_t)threadIdx.x * w.tiles + blockIdx.x] = s_c[threadIdx.x];
 }
 
-// one block: thread d < world walks the tiles of destination d
-__global__ __launch_bounds__(MAX_WORLD) void k_route_scan(Work w, uint32_t tiles, uint32_t world, int only) {
-    __shared__ uint32_t s_tot[MAX_WORLD];
-    const uint32_t d = threadIdx.x;
-    uint32_t run = 0;
-    if (d < world)
-        for (uint32_t t = 0; t < tiles; ++t) {
-            const uint32_t c = w.tile_cnt[(size_t)t * world + d];
-            w.tile_cnt[(size_t)t * world + d] = run;
-            run += c;
-        }
-    s_tot[d] = d < world ? run : 0u;
-    if (d < world) w.totals[d] = run;
+// one block per destination: exclusive prefix of its counts over the tiles (each thread a contiguous piece), total
+__global__ __launch_bounds__(THREADS) void k_route_scan(Work w) {
+    __shared__ uint32_t s_part[THREADS];
+    uint32_t* row = w.tile_cnt + (size_t)blockIdx.x * w.tiles;
+    const uint32_t per = (w.tiles + THREADS - 1) / THREADS;
+    const uint32_t lo = min(threadIdx.x * per, w.tiles), hi = min(lo + per, w.tiles);
+    uint32_t sum = 0;
+    for (uint32_t t = lo; t < hi; ++t) sum += row[t];
+    s_part[threadIdx.x] = sum;
     __syncthreads();
-    if (d == 0) {
-        uint32_t at = 0;
-        for (uint32_t k = 0; k < world; ++k) {
-            w.starts[k] = only < 0 ? at : 0u;
-            at += s_tot[k];
-        }
-        w.starts[world] = only < 0 ? at : s_tot[only];
+    // exclusive prefix of the pieces (Hillis-Steele over 256 values in LDS)
+    for (uint32_t off = 1; off < THREADS; off <<= 1) {
+        const uint32_t o = threadIdx.x >= off ? s_part[threadIdx.x - off] : 0u;
+        __syncthreads();
+        s_part[threadIdx.x] += o;
+        __syncthreads();
     }
+    uint32_t run = s_part[threadIdx.x] - sum;
+    for (uint32_t t = lo; t < hi; ++t) {
+        const uint32_t c = row[t];
+        row[t] = run;
+        run += c;
+    }
+    if (threadIdx.x == THREADS - 1) w.totals[blockIdx.x] = s_part[THREADS - 1];
 }
 
 __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __restrict__ id, uint32_t n, Map m, Work w, int only,
                                                             uint32_t* __restrict__ out_slot, uint32_t* __restrict__ out_pos) {
     __shared__ uint32_t s_wave[THREADS / 64][MAX_WORLD]; // per-wave counts -> exclusive prefix over the waves
+    __shared__ uint32_t s_start[MAX_WORLD];              // where each destination's segment starts in the output
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < (THREADS / 64) * MAX_WORLD; i += THREADS) (&s_wave[0][0])[i] = 0;
+    if (threadIdx.x < m.world) {
+        uint32_t at = 0;
+        if (only < 0)
+            for (uint32_t k = 0; k < threadIdx.x; ++k) at += w.totals[k];
+        s_start[threadIdx.x] = at;
+    }
     __syncthreads();
     // wave-striped: step j of wave k covers requests tile*TILE + k*1024 + j*64 + lane (request order inside a wave)
     const uint32_t first = blockIdx.x * TILE + wave * (64 * ITEMS) + lane;
@@ -115,9 +163,8 @@ __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __res
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint32_t pos = first + j * 64;
-        const uint64_t x = pos < n ? permute(m, id[pos]) : 0ull;
-        dest[j] = pos < n ? (uint32_t)(x % m.world) : 0xFFFFFFFFu;
-        slot[j] = (uint32_t)(x / m.world);
+        route_of(m, pos < n ? id[pos] : 0u, dest[j], slot[j]);
+        if (pos >= n) dest[j] = 0xFFFFFFFFu;
     }
     const unsigned long long lt = (1ull << lane) - 1ull;
 #pragma unroll
@@ -146,10 +193,123 @@ __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __res
     for (int j = 0; j < ITEMS; ++j) {
         const uint32_t pos = first + j * 64, d = dest[j];
         if (pos < n && (only < 0 || d == (uint32_t)only)) {
-            const uint32_t at = w.starts[d] + w.tile_cnt[(size_t)blockIdx.x * m.world + d] + s_wave[wave][d] + rank[j];
+            const uint32_t at = s_start[d] + w.tile_cnt[(size_t)d * w.tiles + blockIdx.x] + s_wave[wave][d] + rank[j];
             out_slot[at] = slot[j];
             if (out_pos) out_pos[at] = pos;
         }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// `only` >= 0 in ONE pass over the ids: count, offset and scatter in the same kernel.  A tile's offset in the
+// output is the number of kept requests in the tiles before it -- a single running sum, so tiles chain through one
+// status word each (decoupled look-back: a tile publishes its own count at once, then sums its predecessors' words,
+// 64 per round trip, until it meets one that already carries an inclusive prefix).  Words are tagged with the
+// call's sequence number: nothing to clear between calls.  A tile waits for lower-numbered tiles only; the host
+// launches this kernel only for grids that are co-resident (<= ONE_PASS_TILES), like the radix sort's look-back.
+// ---------------------------------------------------------------------------
+constexpr uint32_t ONE_PASS_TILES = 1024;
+// status word: sequence number (30 bits) | flag (2 bits) | value (32 bits)
+constexpr unsigned long long ST_PARTIAL = 1ull << 32, ST_INCLUSIVE = 2ull << 32, ST_FLAGS = 3ull << 32, ST_VALUE = 0xFFFFFFFFull;
+constexpr uint32_t SEQ_MASK = 0x3FFFFFFFu;
+
+template <int IT>
+__global__ __launch_bounds__(THREADS) void k_route_one(const uint32_t* __restrict__ id, uint32_t n, Map m, Work w, uint32_t only,
+                                                        unsigned long long* __restrict__ status, uint32_t seq,
+                                                        uint32_t* __restrict__ out_slot, uint32_t* __restrict__ out_pos,
+                                                        unsigned long long* __restrict__ violations) {
+    __shared__ uint32_t s_c[MAX_WORLD];
+    __shared__ uint32_t s_wcnt[THREADS / 64];
+    __shared__ uint32_t s_excl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < MAX_WORLD) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t tile = blockIdx.x;
+    const uint32_t first = tile * (THREADS * IT) + wave * (64 * IT) + lane; // wave-striped: request order inside a wave
+    const int bits = m.world > 1 ? 32 - __clz((int)m.world - 1) : 0;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t v[IT], slot[IT], rank[IT];
+    bool keep[IT];
+#pragma unroll
+    for (int j = 0; j < IT; ++j) v[j] = first + j * 64 < n ? id[first + j * 64] : 0u;
+    uint32_t mine = 0; // kept by my wave so far (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < IT; ++j) {
+        const bool valid = first + j * 64 < n;
+        uint32_t owner;
+        route_of(m, v[j], owner, slot[j]);
+        // requests per destination (the totals): one LDS atomic per destination and wave step
+        unsigned long long mm = __ballot(valid);
+        for (int b = 0; b < bits; ++b) {
+            const unsigned long long bb = __ballot((owner >> b) & 1u);
+            mm &= ((owner >> b) & 1u) ? bb : ~bb;
+        }
+        if (valid && (mm & lt) == 0ull) atomicAdd(&s_c[owner], (uint32_t)__popcll(mm));
+        keep[j] = valid && owner == only;
+        const unsigned long long km = __ballot(keep[j]);
+        rank[j] = mine + (uint32_t)__popcll(km & lt);
+        mine += (uint32_t)__popcll(km);
+    }
+    if (lane == 0) s_wcnt[wave] = mine;
+    __syncthreads();
+    if (threadIdx.x < m.world) w.tile_cnt[(size_t)threadIdx.x * w.tiles + tile] = s_c[threadIdx.x];
+    uint32_t before = 0, total = 0;
+    for (int k = 0; k < THREADS / 64; ++k) {
+        if (k < wave) before += s_wcnt[k];
+        total += s_wcnt[k];
+    }
+    if (wave == 0) {
+        const unsigned long long tagged = (unsigned long long)(seq & SEQ_MASK) << 34;
+        if (lane == 0)
+            __hip_atomic_store(&status[tile], tagged | (tile == 0 ? ST_INCLUSIVE : ST_PARTIAL) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t excl = 0;
+        int at = (int)tile - 1; // nearest predecessor not yet summed
+        tc::SpinGuard guard;
+        while (at >= 0) {
+            if (tc::spin_expired(guard)) { // (flagged, never hung)
+                if (lane == 0 && violations) atomicAdd(violations, 1ull);
+                break;
+            }
+            const int t = at - lane;
+            const unsigned long long sv = t >= 0 ? __hip_atomic_load(&status[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : (tagged | ST_INCLUSIVE);
+            const bool ready = (uint32_t)(sv >> 34) == (seq & SEQ_MASK) && (sv & ST_FLAGS) != 0ull;
+            const unsigned long long rm = __ballot(ready), im = __ballot(ready && (sv & ST_FLAGS) == ST_INCLUSIVE);
+            const int run = rm == ~0ull ? 64 : __builtin_ctzll(~rm);            // lanes 0 .. run-1: words that are there
+            const int stop = im ? __builtin_ctzll(im) : 64;                       // the first inclusive prefix among them
+            const int take = stop < run ? stop + 1 : run;                         // words that can be summed now
+            uint32_t part = lane < take ? (uint32_t)(sv & ST_VALUE) : 0u;
+            for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+            excl += __shfl(part, 0, 64);
+            if (stop < run) break;
+            at -= take;
+            if (take == 0) __builtin_amdgcn_s_sleep(2);
+        }
+        if (lane == 0) {
+            s_excl = excl;
+            if (tile != 0)
+                __hip_atomic_store(&status[tile], tagged | ST_INCLUSIVE | (excl + total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    __syncthreads();
+    const uint32_t base = s_excl + before;
+#pragma unroll
+    for (int j = 0; j < IT; ++j)
+        if (keep[j]) {
+            out_slot[base + rank[j]] = slot[j];
+            if (out_pos) out_pos[base + rank[j]] = first + j * 64;
+        }
+}
+
+// A caller that polls host memory instead of synchronising: behind the scatter on the same stream, the totals and,
+// after them, the caller's tag.  (A ticket taken by every tile of the scatter kernel -- "the last one publishes" --
+// cost 100 ns per tile: 2048 device-scope atomics on one word are 0.2 ms.)
+__global__ __launch_bounds__(MAX_WORLD) void k_route_publish(Work w, uint32_t world) {
+    if (threadIdx.x < world) w.host_totals[threadIdx.x] = w.totals[threadIdx.x];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        w.host_totals[world] = w.tag;
+        __threadfence_system();
     }
 }
 

@@ -119,6 +119,9 @@ struct tc_engine {
         hipEvent_t sorted = nullptr;   // recorded on the auxiliary stream after the last pass
         hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
         bool in_use = false;
+        bool grouped_aside = false;    // the set's last batch was grouped on an auxiliary stream (`sorted` says when)
+        const uint32_t* slot_src = nullptr; // ... and read this caller's slot column (tc_route_batch orders itself behind its readers)
+        size_t slot_src_n = 0;
     } sets[PIPE_DEPTH_MAX];
     uint32_t depth = 0; // sets actually allocated
     hipStream_t aux[AUX_MAX] = {};       // set k groups on aux[k % n_aux]
@@ -170,8 +173,10 @@ struct tc_engine {
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
     uint32_t fault_countdown = 0; // tc_debug_fail_copy: the n-th staging copy from now fails (error-path tests)
-    uint32_t* route_ws = nullptr; // tc_route_batch scratch (lazy): tile counts | totals | starts
-    size_t route_ws_words = 0;
+    uint32_t* route_ws = nullptr; // tc_route_batch scratch (lazy): per stream it may run on: tile counts per destination
+    size_t route_ws_words = 0;    // words of one of them
+    uint32_t next_route = 0;
+    uint32_t route_seq = 0;       // sequence number of the one-pass router's look-back words
 
     // bucket path (bucket_path.hpp): uniform batches are partitioned by key range and ranked per bucket instead of
     // sorted.  Such a batch is enqueued on BOTH paths; the partition's largest bucket (a word in device memory,
@@ -1108,6 +1113,8 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         const uint32_t* gate = bucketed ? ss.bpw.maxb : nullptr;
         const uint64_t* sorted;
         const uint32_t* d_slot = b.slot;
+        ss.slot_src = hin ? nullptr : b.slot;
+        ss.slot_src_n = n;
         if (piped) {
             hipStream_t ax = e->aux[e->next_aux];
             e->next_aux = (e->next_aux + 1) % e->n_aux;
@@ -1118,10 +1125,12 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew);
             TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
+            ss.grouped_aside = true;
         } else {
             // everything that used this set earlier is ordered before us on `s`: evaluations ran on `s`,
             // and every auxiliary sort was joined into `s` before its evaluation
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
+            ss.grouped_aside = false;
             if (bucketed) bucket_partition(e, ss, s, d_slot, n);
             sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
         }
@@ -2119,34 +2128,85 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
 
 // ---- routing of a global stream (route_kernels.hpp) --------------------------------------------------
 extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
-    if (!e || !rp || rp->struct_size < sizeof(tc_route)) return TC_E_INVALID_ARG;
-    const tc_route& r = *rp;
+    if (!e || !rp || rp->struct_size < offsetof(tc_route, stream)) return TC_E_INVALID_ARG;
+    tc_route r; // (callers built against the struct without `stream` get the engine's stream)
+    memset(&r, 0, sizeof(r));
+    memcpy(&r, rp, std::min<size_t>(rp->struct_size, sizeof(r)));
     rt::Map m;
-    if (!rt::make_map(r.world, r.keys_per_shard, &m)) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: world must be 1..64 and world * keys_per_shard < 2^39");
+    if (!rt::make_map(r.world, r.keys_per_shard, &m)) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: world must be 1..64 and keys_per_shard 1..2^32");
     if (r.only >= (int32_t)r.world || r.only < -1) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: `only` is not a destination");
     if (!r.global_id || !r.out_slot || !r.out_count) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: NULL array");
     if (r.n == 0 || r.n > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: n out of range");
     TC_HIP(e, hipSetDevice(e->device));
-    hipStream_t s = cur_stream(e);
+    hipStream_t s = r.stream ? (hipStream_t)r.stream : cur_stream(e);
+    uint32_t lane = 0; // which scratch
+    if ((r.flags & TC_ROUTE_AHEAD) && !r.stream) {
+        TC_TRY(ensure_side_streams(e));
+        if (e->n_aux) {
+            // Beside the evaluations: on a grouping stream, behind the GROUPING of every batch enqueued so far -- a
+            // slot column is read by the grouping kernels only, so that is the last reader of whatever buffer this
+            // call overwrites; waiting for the evaluations too would chain the next batches' grouping, queued behind
+            // the router on this stream, to them.  Every grouping stream has its own router scratch.
+            lane = 1 + e->next_route++ % e->n_aux;
+            s = e->aux[lane - 1];
+            // (the batches that read the very buffer being overwritten, if the engine still knows them; else all)
+            bool known = false;
+            for (int pass = 0; pass < 2 && !known; ++pass)
+                for (uint32_t si = 0; si < e->depth; ++si) {
+                    tc_engine::SortSet& ss = e->sets[si];
+                    if (!ss.in_use) continue;
+                    const bool reads = ss.slot_src && ss.slot_src < r.out_slot + r.n && r.out_slot < ss.slot_src + ss.slot_src_n;
+                    if (pass == 0 && !reads) continue;
+                    if (pass == 0) known = true;
+                    TC_HIP(e, hipStreamWaitEvent(s, ss.grouped_aside ? ss.sorted : ss.consumed, 0));
+                }
+        }
+    }
     const uint32_t n = (uint32_t)r.n, tiles = (n + rt::TILE - 1) / rt::TILE;
-    const size_t words = (size_t)tiles * r.world + 2 * (size_t)rt::MAX_WORLD + 2;
+    const size_t words = (size_t)tiles * r.world + 4 + 2 * (size_t)rt::ONE_PASS_TILES;
     if (words > e->route_ws_words) {
         if (e->route_ws) {
-            TC_HIP(e, hipStreamSynchronize(s));
+            TC_HIP(e, hipDeviceSynchronize()); // (whatever streams earlier routers ran on)
             (void)hipFree(e->route_ws);
             e->route_ws = nullptr;
             e->route_ws_words = 0;
         }
-        TC_HIP(e, hipMalloc(&e->route_ws, words * 2 * sizeof(uint32_t)));
-        e->route_ws_words = words * 2;
+        // one scratch per stream a router may run on (the caller's / the engine's, each grouping stream): routers on
+        // different streams never wait for one another
+        const size_t each = (words * 2 + 1) & ~(size_t)1;
+        TC_HIP(e, hipMalloc(&e->route_ws, each * (1 + AUX_MAX) * sizeof(uint32_t)));
+        TC_HIP(e, hipMemset(e->route_ws, 0, each * (1 + AUX_MAX) * sizeof(uint32_t)));
+        e->route_ws_words = each;
     }
     rt::Work w;
-    w.tile_cnt = e->route_ws;
+    uint32_t* scratch = e->route_ws + (size_t)lane * e->route_ws_words;
+    unsigned long long* status = reinterpret_cast<unsigned long long*>(scratch); // [ONE_PASS_TILES] look-back words of the one-pass router
+    w.tile_cnt = scratch + 2 * (size_t)rt::ONE_PASS_TILES;
     w.totals = r.out_count;
-    w.starts = e->route_ws + (size_t)tiles * r.world;
-    hipLaunchKernelGGL(rt::k_route_count, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w);
-    hipLaunchKernelGGL(rt::k_route_scan, dim3(1), dim3(rt::MAX_WORLD), 0, s, w, tiles, r.world, (int)r.only);
-    hipLaunchKernelGGL(rt::k_route_scatter, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos);
+    w.tiles = tiles;
+    w.host_totals = r.out_count_host;
+    w.tag = r.tag;
+    // one destination: count, offset and scatter in ONE pass over the ids if the grid is co-resident (tiles of 4096
+    // or 8192 ids); every destination, or a bigger batch: count | scan | scatter
+    const uint32_t tiles32 = (n + 2 * rt::TILE - 1) / (2 * rt::TILE);
+    if (r.only >= 0 && tiles32 <= rt::ONE_PASS_TILES && !getenv("TCGPU_ROUTE_3PASS")) {
+        if (++e->route_seq == 0u) e->route_seq = 1u;
+        unsigned long long* viol = e->counters + (TC_CNT_COUNT + 1) + 3;
+        if (tiles <= rt::ONE_PASS_TILES) {
+            hipLaunchKernelGGL((rt::k_route_one<rt::ITEMS>), dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (uint32_t)r.only, status,
+                               e->route_seq, r.out_slot, r.out_pos, viol);
+        } else {
+            w.tiles = tiles32;
+            hipLaunchKernelGGL((rt::k_route_one<2 * rt::ITEMS>), dim3(tiles32), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (uint32_t)r.only,
+                               status, e->route_seq, r.out_slot, r.out_pos, viol);
+        }
+        hipLaunchKernelGGL(rt::k_route_scan, dim3(r.world), dim3(rt::THREADS), 0, s, w); // (the totals)
+    } else {
+        hipLaunchKernelGGL(rt::k_route_count, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w);
+        hipLaunchKernelGGL(rt::k_route_scan, dim3(r.world), dim3(rt::THREADS), 0, s, w);
+        hipLaunchKernelGGL(rt::k_route_scatter, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos);
+    }
+    if (r.out_count_host) hipLaunchKernelGGL(rt::k_route_publish, dim3(1), dim3(rt::MAX_WORLD), 0, s, w, r.world);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
@@ -2156,29 +2216,20 @@ extern "C" int tc_route_host(uint32_t world, uint64_t keys_per_shard, uint64_t n
     rt::Map m;
     if (!rt::make_map(world, keys_per_shard, &m) || (n && !global_id)) return TC_E_INVALID_ARG;
     for (uint64_t i = 0; i < n; ++i) {
-        const uint64_t x = rt::permute(m, global_id[i]);
-        if (owner) owner[i] = (uint32_t)(x % world);
-        if (slot) slot[i] = (uint32_t)(x / world);
+        uint32_t o, sl;
+        rt::route_of_host(m, global_id[i], o, sl);
+        if (owner) owner[i] = o;
+        if (slot) slot[i] = sl;
     }
     return TC_E_OK;
 }
-
 extern "C" int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* owner, const uint32_t* slot,
                                 uint64_t* global_id) {
     rt::Map m;
     if (!rt::make_map(world, keys_per_shard, &m) || (n && (!owner || !slot || !global_id))) return TC_E_INVALID_ARG;
-    // mul^-1 mod modulus by the extended Euclid (mul is coprime with the modulus by construction)
-    __int128 t0 = 0, t1 = 1, r0 = (__int128)m.modulus, r1 = (__int128)m.mul;
-    while (r1 != 0) {
-        const __int128 q = r0 / r1, t2 = t0 - q * t1, r2 = r0 - q * r1;
-        t0 = t1, t1 = t2, r0 = r1, r1 = r2;
-    }
-    const uint64_t inv = (uint64_t)((t0 % (__int128)m.modulus + (__int128)m.modulus) % (__int128)m.modulus);
     for (uint64_t i = 0; i < n; ++i) {
         if (owner[i] >= world || slot[i] >= keys_per_shard) return TC_E_INVALID_ARG;
-        const uint64_t x = (uint64_t)slot[i] * world + owner[i];
-        const uint64_t y = (x + m.modulus - m.add % m.modulus) % m.modulus;
-        global_id[i] = (uint64_t)(((unsigned __int128)y * inv) % m.modulus);
+        global_id[i] = rt::route_inverse_host(m, owner[i], slot[i]);
     }
     return TC_E_OK;
 }

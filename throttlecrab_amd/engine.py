@@ -127,6 +127,9 @@ class Engine:
         self._check(self._lib.tc_engine_set_stream(self._h, C.c_void_p(hip_stream or 0)))
 
     def use_torch_stream(self):
+        """Run on torch's CURRENT stream.  torch's default stream has handle 0, which tc_set_stream reads as "the
+        engine's own stream": work torch enqueues afterwards is then NOT ordered behind the engine's -- synchronise
+        (torch.cuda.synchronize()) before reading results, or call this inside `with torch.cuda.stream(s)`."""
         import torch
         self.set_stream(torch.cuda.current_stream(self.device).cuda_stream)
 
@@ -313,12 +316,17 @@ class Engine:
                 self._async_keep.append((keep, k2))
         return res
 
-    def route_batch(self, global_ids, world: int, only: int = -1, want_pos: bool = False, out=None):
+    def route_batch(self, global_ids, world: int, only: int = -1, want_pos: bool = False, out=None, stream=None, ahead: bool = False,
+                    host_counts=None, tag: int = 0):
         """tc_route_batch: of a CUDA tensor of global key ids (int32 / uint32), keep what destination `only` owns
         (only = -1: every destination's segment, one after the other) as shard-local slots, in request order.
         -> (slots int32[n], pos int32[n] or None, counts int32[world]) CUDA tensors; the first counts[only]
         (resp. sum(counts)) entries are valid.  Asynchronous on the engine's stream: read `counts` after a sync.
-        `out`: (slots, pos or None, counts) tensors to reuse."""
+        `out`: (slots, pos or None, counts) tensors to reuse.  `stream`: a torch.cuda.Stream to run the router on
+        instead; the caller orders it before the batch call that reads `slots`.
+        ahead=True (TC_ROUTE_AHEAD): the engine runs the router on one of its grouping streams, beside the
+        evaluations of earlier batches.  host_counts: a pinned uint32 array of world + 1 words (host_alloc) that
+        receives the counts and then `tag` in its last word -- poll that word instead of synchronising."""
         import torch
         assert global_ids.is_cuda and global_ids.is_contiguous() and global_ids.dtype in (torch.int32, torch.uint32)
         n = global_ids.numel()
@@ -332,6 +340,11 @@ class Engine:
         r.world, r.keys_per_shard, r.n, r.only = world, self.capacity, n, only
         r.global_id, r.out_slot, r.out_count = global_ids.data_ptr(), slots.data_ptr(), counts.data_ptr()
         r.out_pos = pos.data_ptr() if pos is not None else None
+        r.stream = stream.cuda_stream if stream is not None else None
+        r.flags = L.TC_ROUTE_AHEAD if ahead else 0
+        if host_counts is not None:
+            assert host_counts.dtype == np.uint32 and host_counts.size >= world + 1
+            r.out_count_host, r.tag = host_counts.ctypes.data, tag
         self._check(self._lib.tc_route_batch(self._h, C.byref(r)))
         return slots, pos, counts
 
