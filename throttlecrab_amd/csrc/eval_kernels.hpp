@@ -322,7 +322,10 @@ __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t
         if (i == 0 && atomicExch(t.error_flag, 0u) != 0u) table_full[1] = 1u;
         uint32_t st = kt::ST_FOUND, ax = 0;
         uint64_t h = 0;
-        if (i < n) st = kt::probe_request<true>(t, key_bytes, key_off, n, i, slot, ax, h);
+        bool recycled = false;
+        if (i < n) st = kt::probe_request<true>(t, key_bytes, key_off, n, i, slot, ax, h, recycled);
+        kt::tombs_sub(t, recycled);
+        kt::reserve_overflow<SMALL_MAX>(t, i < n, i < n ? key_off[i + 1] - key_off[i] : 0u, st, slot);
         uint32_t total = 0;
         const uint32_t rank = kt::block_rank<SMALL_MAX>(i < n && st == kt::ST_CLAIMANT, total); // one barrier
         const int top = *t.free_top; // (thread 0 moves it after the next barrier)

@@ -254,8 +254,9 @@ __device__ __forceinline__ uint64_t load_and_hash(const uint8_t* __restrict__ ke
 template <bool INSERT>
 __device__ __forceinline__ uint32_t probe_request(const Table& t, const uint8_t* __restrict__ key_bytes,
                                                   const uint32_t* __restrict__ key_off, uint32_t n, uint32_t i, uint32_t& slot,
-                                                  uint32_t& ax, uint64_t& h) {
+                                                  uint32_t& ax, uint64_t& h, bool& recycled) {
     uint32_t st = ST_MISSING;
+    recycled = false; // the claim took a tombstone: the caller takes it off t.tombs (tombs_sub: one atomic per wave)
     const uint32_t off = key_off[i], len = key_off[i + 1] - off, arena = key_off[n];
     const uint8_t* key = key_bytes + off;
     uint64_t k0 = 0, k1 = 0;
@@ -341,18 +342,52 @@ __device__ __forceinline__ uint32_t probe_request(const Table& t, const uint8_t*
                                                  __HIP_MEMORY_SCOPE_AGENT)) {
             st = ST_CLAIMANT;
             ax = (uint32_t)target;
-            if (tomb_pos != ~0ull) atomicSub(t.tombs, 1u);
+            recycled = tomb_pos != ~0ull;
         }
         // else: somebody claimed that entry in the meantime -- walk again (it now shows as a pending claim)
     }
     if (INSERT && st == ST_MISSING) atomicExch(t.error_flag, 1u); // no room on this key's chain: TC_E_TABLE_FULL
-    if (INSERT && st == ST_CLAIMANT && len > INLINE_KEY) {
-        // long key: reserve its overflow bytes now, so that binding knows who takes a slot (offset / 16 rides in `slot`)
-        const unsigned long long ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
+    return st;
+}
+
+// tombstones recycled by this wave's claims come off the table's count with one atomic (reached by the whole wave)
+__device__ __forceinline__ void tombs_sub(const Table& t, bool recycled) {
+    const unsigned long long m = __ballot(recycled);
+    if (m && (threadIdx.x & 63) == 0) atomicSub(t.tombs, (uint32_t)__popcll(m));
+}
+
+// Claimants of keys longer than INLINE_KEY reserve their overflow bytes before binding, so that binding knows who
+// takes a slot (offset / 16 rides in `slot`).  ONE atomic per block: the block's claimants line their (16-byte
+// rounded) sizes up with a scan and share the block's reservation.  (One returning atomicAdd per claimant on the
+// arena's cursor -- a single word -- was the whole cost of k_probe on long keys: ~100 k of them per 1 Mi-key batch
+// of the configs[4] mix serialise at ~6 ns each, 0.6 of the kernel's 0.73 ms.)  Reached by every thread of the block.
+template <int NT>
+__device__ __forceinline__ void reserve_overflow(const Table& t, bool live, uint32_t len, uint32_t& st, uint32_t& slot) {
+    __shared__ uint32_t s_w[NT / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool need = live && st == ST_CLAIMANT && len > INLINE_KEY;
+    const uint32_t bytes = need ? (len + 15u) & ~15u : 0u;
+    uint32_t v = bytes;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    if (lane == 63) s_w[wave] = v;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (int w = 0; w < NT / 64; ++w) {
+        if (w < wave) before += s_w[w];
+        total += s_w[w];
+    }
+    if (total == 0) return; // (block-uniform)
+    if (threadIdx.x == 0) s_base = atomicAdd(t.overflow_used, (unsigned long long)total);
+    __syncthreads();
+    if (need) {
+        const unsigned long long ovf = s_base + before + (v - bytes);
         if (ovf + len > t.overflow_bytes) st = ST_NOSPACE;
         else slot = (uint32_t)(ovf >> 4);
     }
-    return st;
 }
 
 // outputs: slot_out[i], state[i], aux[i], hash_out[i] as probe_request leaves them; claim_cnt[block]
@@ -364,10 +399,15 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
                                                    uint32_t* __restrict__ claim_cnt) {
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     uint32_t st = ST_MISSING;
+    uint32_t slot = NO_SLOT, ax = 0;
+    uint64_t h = 0;
+    bool recycled = false;
     if (i < n) {
-        uint32_t slot, ax;
-        uint64_t h;
-        st = probe_request<INSERT>(t, key_bytes, key_off, n, i, slot, ax, h);
+        st = probe_request<INSERT>(t, key_bytes, key_off, n, i, slot, ax, h, recycled);
+    }
+    if (INSERT) tombs_sub(t, recycled);
+    if (INSERT) reserve_overflow<THREADS>(t, i < n, i < n ? key_off[i + 1] - key_off[i] : 0u, st, slot);
+    if (i < n) {
         hash_out[i] = h;
         slot_out[i] = slot;
         state[i] = st;
@@ -627,26 +667,67 @@ __global__ void k_overflow_decide(Table t, unsigned long long* __restrict__ flag
         flag[1] = 0ull;
     }
 }
+// (one reservation per block and 2048 slots: a returning atomicAdd per copied key on the new half's cursor -- one
+// word -- serialised the kernel: 1.7 ms for the ~3 M long keys of the configs[4] stream)
+constexpr int COMPACT_ITEMS = 8;
 __global__ __launch_bounds__(THREADS) void k_overflow_compact(Table t, unsigned long long* __restrict__ flag) {
     if (flag[0] == 0ull) return;
+    __shared__ uint32_t s_w[THREADS / 64];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t from = (uint64_t)*t.overflow_half * t.overflow_bytes, to = (uint64_t)(*t.overflow_half ^ 1u) * t.overflow_bytes;
-    for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
-        if (!t.bound[s]) continue;
-        const uint32_t len = t.rec[s].len;
-        if (len <= INLINE_KEY || len == NO_SLOT) continue;
-        uint64_t off;
-        __builtin_memcpy(&off, t.rec[s].bytes, 8);
-        const uint64_t at = atomicAdd(&flag[1], (unsigned long long)((len + 15u) & ~15u));
-        const uint8_t* src = t.overflow + from + off;
-        uint8_t* dst = t.overflow + to + at;
-        uint32_t b = 0;
-        for (; b + 8 <= len; b += 8) {
-            uint64_t w;
-            __builtin_memcpy(&w, src + b, 8);
-            __builtin_memcpy(dst + b, &w, 8);
+    const uint32_t chunk = THREADS * COMPACT_ITEMS;
+    for (uint32_t c0 = blockIdx.x * chunk; c0 < t.capacity; c0 += gridDim.x * chunk) { // (block-uniform trip count)
+        uint32_t len[COMPACT_ITEMS];
+        uint64_t off[COMPACT_ITEMS];
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < COMPACT_ITEMS; ++j) {
+            const uint32_t s = c0 + j * THREADS + threadIdx.x;
+            len[j] = 0;
+            off[j] = 0;
+            if (s < t.capacity && t.bound[s]) {
+                const uint32_t l = t.rec[s].len;
+                if (l > INLINE_KEY && l != NO_SLOT) {
+                    len[j] = l;
+                    __builtin_memcpy(&off[j], t.rec[s].bytes, 8);
+                    mine += (l + 15u) & ~15u;
+                }
+            }
         }
-        for (; b < len; ++b) dst[b] = src[b];
-        __builtin_memcpy(t.rec[s].bytes, &at, 8);
+        uint32_t v = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t x = __shfl_up(v, o, 64);
+            if (lane >= o) v += x;
+        }
+        __syncthreads(); // (s_w / s_base of the previous chunk have been read)
+        if (lane == 63) s_w[wave] = v;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int w = 0; w < THREADS / 64; ++w) {
+            if (w < wave) before += s_w[w];
+            total += s_w[w];
+        }
+        if (total == 0) continue; // (block-uniform)
+        if (threadIdx.x == 0) s_base = atomicAdd(&flag[1], (unsigned long long)total);
+        __syncthreads();
+        uint64_t at = s_base + before + (v - mine);
+#pragma unroll
+        for (int j = 0; j < COMPACT_ITEMS; ++j) {
+            if (len[j] == 0) continue;
+            const uint32_t s = c0 + j * THREADS + threadIdx.x;
+            const uint8_t* src = t.overflow + from + off[j];
+            uint8_t* dst = t.overflow + to + at;
+            uint32_t b = 0;
+            for (; b + 8 <= len[j]; b += 8) {
+                uint64_t w8;
+                __builtin_memcpy(&w8, src + b, 8);
+                __builtin_memcpy(dst + b, &w8, 8);
+            }
+            for (; b < len[j]; ++b) dst[b] = src[b];
+            __builtin_memcpy(t.rec[s].bytes, &at, 8);
+            at += (len[j] + 15u) & ~15u;
+        }
     }
 }
 __global__ void k_overflow_swap(Table t, const unsigned long long* __restrict__ flag) {

@@ -332,8 +332,10 @@ class Engine:
         n = global_ids.numel()
         dev = global_ids.device
         if out is None:
+            # (torch.empty, not zeros: a fill enqueued on torch's stream is not ordered with the engine's stream when
+            # that is the engine's own -- see use_torch_stream -- and the router writes every entry anyway)
             out = (torch.empty(n, dtype=torch.int32, device=dev), torch.empty(n, dtype=torch.int32, device=dev) if want_pos else None,
-                   torch.zeros(world, dtype=torch.int32, device=dev))
+                   torch.empty(world, dtype=torch.int32, device=dev))
         slots, pos, counts = out
         r = L.tc_route()
         r.struct_size = C.sizeof(L.tc_route)
