@@ -264,7 +264,7 @@ def keys_bench(a, dev):
         res = t.BatchResult()
         b, c, p = W.Config4Stream.PARAMS
 
-        def one(arena, now, piped=True):
+        def one(arena, now, piped=os.environ.get("TC_BENCH_KEYS_IN_ORDER") != "1"):
             eng.rate_limit_batch_keys(arena[0], arena[1], max_burst=b, count_per_period=c, period=p, quantity=1, now_ns=now,
                                       want=("allowed",), out=res, inputs_ready=piped)
         for k in range(n_prefill):
