@@ -395,6 +395,7 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
     grp = t.BatchResult()
     d_main = d_batches
     for label, streams, want in ((f"{a.workload}_stream_grouped_output", d_main, ("allowed",)),
+                                 (f"{a.workload}_stream_grouped_bits", d_main, ("allowed_bits",)),
                                  (f"{a.workload}_stream_grouped_decision_records", d_main, t.Engine.DECISION_FIELDS)):
         for i in range(a.warmup):
             eng2.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=W.T0_NS + 5 * 10**9 + i,
@@ -407,7 +408,9 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
                                         grouped=True)
         torch.cuda.synchronize()
         also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s",
-                       "note": "output rows in the engine's evaluation order + order[] (request index of each row)"}
+                       "note": "output rows in the engine's evaluation order + order[] (request index of each row)" +
+                               ("; the decisions as one bit per row, packed by the evaluation's own wave ballots (no byte column)"
+                                if want == ("allowed_bits",) else "")}
         grp = t.BatchResult()
     # general batches: every request carries its own timestamp (strictly increasing inside
     # the batch), so the closed form does not apply and k_eval_general runs

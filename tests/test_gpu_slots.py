@@ -536,7 +536,7 @@ def test_grouped_output_rows(mode, dev):
         else:
             q, now = rng.integers(0, 3, m), T0 + rnd * 10**9 + rng.integers(0, 10**9, m)
         ref = orc.batch_slots(slots, 4, 10, 60, q, now)
-        want = FIELDS + ("decisions",)
+        want = FIELDS + ("decisions", "allowed_bits")  # (uniform batches: the bits of the grouped rows come from the evaluation's own ballots)
         if dev:
             tt = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).cuda()
             res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).cuda(), max_burst=4, count_per_period=10,
@@ -553,6 +553,9 @@ def test_grouped_output_rows(mode, dev):
         if mode != "unique":   # rows are grouped by key, index order inside a key
             s = slots[order].astype(np.int64)
             assert np.all(np.diff(s) >= 0) and np.all((np.diff(s) > 0) | (np.diff(order) > 0))
+        bits = res.allowed_bits.cpu().numpy() if not isinstance(res.allowed_bits, np.ndarray) else res.allowed_bits
+        rows_allowed = res.allowed.cpu().numpy() if not isinstance(res.allowed, np.ndarray) else res.allowed
+        assert np.array_equal(np.unpackbits(bits.view(np.uint8), bitorder="little")[:m], rows_allowed.astype(np.uint8)), (mode, rnd)
         for f in FIELDS:
             rows = getattr(res, f)
             rows = rows.cpu().numpy() if not isinstance(rows, np.ndarray) else rows

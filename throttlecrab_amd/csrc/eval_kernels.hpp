@@ -56,6 +56,8 @@ struct Params {
     uint64_t capacity;
     unsigned long long* counters;
     uint32_t* denied; // per-slot denial counters (TC_CFG_TRACK_DENIED) or nullptr
+    uint64_t* row_bits; // TC_B_GROUPED_OUTPUT + allowed_bits on a batch whose runs are all regular: the evaluation packs
+                        // the decisions of its 64-row waves itself (one ballot, one 8-byte store), no byte column
 };
 
 struct Req {
@@ -119,7 +121,8 @@ __device__ __forceinline__ Req make_req_rc(const Params& p, uint32_t slot, const
     return r;
 }
 
-__device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req& r, const Decision& d) {
+// (returns the decision: 1 = allowed)
+__device__ __forceinline__ bool write_out(const Params& p, uint32_t i, const Req& r, const Decision& d) {
     const bool ok = r.status == tc::ST_OK;
     if (p.allowed) p.allowed[i] = (ok && d.allowed) ? 1 : 0;
     if (p.status) p.status[i] = (uint8_t)r.status;
@@ -139,6 +142,7 @@ __device__ __forceinline__ void write_out(const Params& p, uint32_t i, const Req
         dr[0] = make_longlong2(ok ? d.remaining : 0, ok ? d.reset_after : 0);
         dr[1] = make_longlong2(ok ? d.retry_after : 0, flags); // allowed | status << 8, pad = 0 (little endian)
     }
+    return ok && d.allowed;
 }
 
 // The resident state of `slot` under either layout.  TC_CFG_FIXED_PARAMS engines keep one TAT per key
@@ -563,70 +567,76 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
         denied_here[j] = false;
         wcell[j].tat = 0;
         wcell[j].expiry = 0;
-        if (!valid) continue;
-        const uint32_t r = k - seg_start[j];
-        const Req rq = make_req_rc(p, slot, rc[j]);
-        Decision d;
-        d.allowed = false;
-        d.remaining = d.reset_after = d.retry_after = 0;
-        if (rq.status != tc::ST_OK) {
-            ne += 1;
-            write_out(p, orow, rq, d);
-            continue;
-        }
-        Cell c = FIXED ? tc::fixed_cell(cell[j].tat, rq.dvt) : cell[j];
-        const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
-        if (!d0.allowed) {
-            // request 0 denied => state untouched => every request of the run equals request 0
-            nd += 1;
-            denied_here[j] = true;
-            write_out(p, orow, rq, d0);
-        } else if (head[j] && is_last[j]) {
-            na += 1; // a key requested once in this batch: no closed form, no 64-bit division
-            write_out(p, orow, rq, d0);
-            writer[j] = true;
-            wcell[j] = c;
-        } else {
-            const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
-            if (r == 0) {
-                na += 1;
-                write_out(p, orow, rq, d0);
-                if (is_last[j] || (f.regular && f.n_tot == 1)) {
-                    writer[j] = true;
-                    wcell[j] = c;
-                } else if (!f.regular) {
-                    // irregular run (saturation, zero increment, immediate expiry): walk the rest one by one
-                    if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // the host's proof was wrong: must stay 0
-                    uint32_t wd = 0;
-                    for (uint32_t q = k + 1; q < n; ++q) {
-                        const uint64_t nx = sorted[q];
-                        if ((uint32_t)(nx >> 32) != slot) break;
-                        const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
-                        na += dj.allowed;
-                        wd += !dj.allowed;
-                        write_out(p, p.order ? q : (uint32_t)nx, rq, dj);
-                    }
-                    nd += wd;
-                    if (p.denied && wd) atomicAdd(&p.denied[slot], wd); // the whole run's denials sit in this lane
-                    writer[j] = true;
-                    wcell[j] = c;
-                }
-            } else if (f.regular) {
-                const int64_t jj = (int64_t)r < f.n_tot ? (int64_t)r : f.n_tot;
-                Cell v;
-                v.tat = f.new0 + (jj - 1) * f.inc;
-                v.expiry = UINT64_MAX;
-                d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
-                na += d.allowed;
-                nd += !d.allowed;
-                denied_here[j] = !d.allowed;
+        bool bit = false; // my decision (every valid lane of a DIRECT batch writes its own outputs exactly once)
+        if (valid) {
+            const uint32_t r = k - seg_start[j];
+            const Req rq = make_req_rc(p, slot, rc[j]);
+            Decision d;
+            d.allowed = false;
+            d.remaining = d.reset_after = d.retry_after = 0;
+            if (rq.status != tc::ST_OK) {
+                ne += 1;
                 write_out(p, orow, rq, d);
-                if (d.allowed && (is_last[j] || (int64_t)r + 1 == f.n_tot)) {
+            } else {
+                Cell c = FIXED ? tc::fixed_cell(cell[j].tat, rq.dvt) : cell[j];
+                const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
+                if (!d0.allowed) {
+                    // request 0 denied => state untouched => every request of the run equals request 0
+                    nd += 1;
+                    denied_here[j] = true;
+                    bit = write_out(p, orow, rq, d0);
+                } else if (head[j] && is_last[j]) {
+                    na += 1; // a key requested once in this batch: no closed form, no 64-bit division
+                    bit = write_out(p, orow, rq, d0);
                     writer[j] = true;
-                    wcell[j] = v;
+                    wcell[j] = c;
+                } else {
+                    const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
+                    if (r == 0) {
+                        na += 1;
+                        bit = write_out(p, orow, rq, d0);
+                        if (is_last[j] || (f.regular && f.n_tot == 1)) {
+                            writer[j] = true;
+                            wcell[j] = c;
+                        } else if (!f.regular) {
+                            // irregular run (saturation, zero increment, immediate expiry): walk the rest one by one
+                            if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // the host's proof was wrong: must stay 0
+                            uint32_t wd = 0;
+                            for (uint32_t q = k + 1; q < n; ++q) {
+                                const uint64_t nx = sorted[q];
+                                if ((uint32_t)(nx >> 32) != slot) break;
+                                const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
+                                na += dj.allowed;
+                                wd += !dj.allowed;
+                                write_out(p, p.order ? q : (uint32_t)nx, rq, dj);
+                            }
+                            nd += wd;
+                            if (p.denied && wd) atomicAdd(&p.denied[slot], wd); // the whole run's denials sit in this lane
+                            writer[j] = true;
+                            wcell[j] = c;
+                        }
+                    } else if (f.regular) {
+                        const int64_t jj = (int64_t)r < f.n_tot ? (int64_t)r : f.n_tot;
+                        Cell v;
+                        v.tat = f.new0 + (jj - 1) * f.inc;
+                        v.expiry = UINT64_MAX;
+                        d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
+                        na += d.allowed;
+                        nd += !d.allowed;
+                        denied_here[j] = !d.allowed;
+                        bit = write_out(p, orow, rq, d);
+                        if (d.allowed && (is_last[j] || (int64_t)r + 1 == f.n_tot)) {
+                            writer[j] = true;
+                            wcell[j] = v;
+                        }
+                    }
+                    // irregular && r > 0: the head lane produced this request's outputs
                 }
             }
-            // irregular && r > 0: the head lane produced this request's outputs
+        }
+        if (DIRECT && p.row_bits) { // (wave-uniform; a wave's j-th items are 64 consecutive rows)
+            const unsigned long long bm = __ballot(bit);
+            if (lane == 0 && valid) p.row_bits[k >> 6] = bm;
         }
     }
 

@@ -1056,6 +1056,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
     p.classes = e->classes;
     p.uniform_class = e->uniform_id;
     p.denied = e->denied;
+    p.row_bits = nullptr;
     p.capacity = e->capacity;
     p.counters = e->counters;
     if (b.flags & TC_B_REGISTERED_PARAMS) {
@@ -1065,6 +1066,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
     const bool full = p.remaining || p.reset || p.retry || p.result4 || p.decisions;
     const dim3 grid(nblocks(n)), block(BLOCK);
     hipStream_t s = cur_stream(e);
+    bool bits_in_kernel = false;
 
     if (b.flags & TC_B_UNIQUE_SLOTS) {
         if (hin) {
@@ -1110,6 +1112,13 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         // the sort's three coalesced passes (69-86 vs 66 us per 1 Mi batch).
         // (TC_B_GROUPED_OUTPUT promises rows grouped by key: that is the sorted order)
         const bool bucketed = direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
+        // Grouped rows + a bitmask of them, every run regular: the evaluation's waves hold 64 consecutive rows each and
+        // pack their decisions with one ballot (no byte column, no k_pack_bits launch).
+        if (b.allowed_bits && p.order && direct) {
+            p.row_bits = b.allowed_bits;
+            bits_in_kernel = true;
+            if (!b.allowed) p.allowed = nullptr;
+        }
         const uint32_t* gate = bucketed ? ss.bpw.maxb : nullptr;
         const uint64_t* sorted;
         const uint32_t* d_slot = b.slot;
@@ -1160,7 +1169,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         TC_HIP(e, hipEventRecord(ss.consumed, s));
         ss.in_use = true;
     }
-    if (b.allowed_bits) {
+    if (b.allowed_bits && !bits_in_kernel) {
         prof_begin(e, TC_STAGE_PACK, s);
         hipLaunchKernelGGL(k_pack_bits, grid, block, 0, s, p.allowed, n, b.allowed_bits);
         prof_end(e, s);
