@@ -205,8 +205,10 @@ __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __res
 // output is the number of kept requests in the tiles before it -- a single running sum, so tiles chain through one
 // status word each (decoupled look-back: a tile publishes its own count at once, then sums its predecessors' words,
 // 64 per round trip, until it meets one that already carries an inclusive prefix).  Words are tagged with the
-// call's sequence number: nothing to clear between calls.  A tile waits for lower-numbered tiles only; the host
-// launches this kernel only for grids that are co-resident (<= ONE_PASS_TILES), like the radix sort's look-back.
+// call's sequence number: nothing to clear between calls.  A tile waits for lower-numbered tiles only, which the
+// dispatcher started earlier (blocks of a grid are dispatched in index order: the assumption the radix sort's
+// look-back and the direct stores of k_eval_sorted rest on as well, guarded by the same watchdog, tc::SpinGuard).
+// ONE_PASS_TILES bounds the status array; bigger batches take the three kernels above.
 // ---------------------------------------------------------------------------
 constexpr uint32_t ONE_PASS_TILES = 1024;
 // status word: sequence number (30 bits) | flag (2 bits) | value (32 bits)

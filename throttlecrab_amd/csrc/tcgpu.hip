@@ -2195,7 +2195,7 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     w.tiles = tiles;
     w.host_totals = r.out_count_host;
     w.tag = r.tag;
-    // one destination: count, offset and scatter in ONE pass over the ids if the grid is co-resident (tiles of 4096
+    // one destination: count, offset and scatter in ONE pass over the ids for grids of at most ONE_PASS_TILES (tiles of 4096
     // or 8192 ids); every destination, or a bigger batch: count | scan | scatter
     const uint32_t tiles32 = (n + 2 * rt::TILE - 1) / (2 * rt::TILE);
     if (r.only >= 0 && tiles32 <= rt::ONE_PASS_TILES && !getenv("TCGPU_ROUTE_3PASS")) {
