@@ -591,14 +591,40 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                     writer[j] = true;
                     wcell[j] = c;
                 } else {
-                    const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
+                    // closed form of the run: tc::run_form; decisions only: tc::run_lite, the same provisos without the
+                    // 64-bit division (nearly every wave holds some key with two requests, so every wave would pay it)
+                    bool regular, ok_r = true, owner = false;
+                    Cell v = c;
+                    if (FULL) {
+                        const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
+                        regular = f.regular;
+                        if (regular && r != 0) {
+                            const int64_t jj = (int64_t)r < f.n_tot ? (int64_t)r : f.n_tot;
+                            v.tat = f.new0 + (jj - 1) * f.inc; // the state my r predecessors leave behind
+                            v.expiry = UINT64_MAX;
+                            d = tc::gcra_step<true>(v, rq.ei, rq.dvt, rq.q, rq.now);
+                            ok_r = d.allowed;
+                            owner = ok_r && (is_last[j] || (int64_t)r + 1 == f.n_tot);
+                        } else if (regular) {
+                            owner = is_last[j] || f.n_tot == 1;
+                        }
+                    } else {
+                        const tc::RunLite f = tc::run_lite(c, rq.ei, rq.dvt, rq.q, rq.now);
+                        regular = f.regular;
+                        if (regular) {
+                            ok_r = r == 0 || tc::rank_allowed(f, r);
+                            owner = ok_r && (is_last[j] || !tc::rank_allowed(f, r + 1u));
+                            if (owner && r != 0) v = tc::cell_after(f.new0 + (int64_t)r * f.inc, rq.dvt, rq.now);
+                            d.allowed = ok_r;
+                        }
+                    }
                     if (r == 0) {
                         na += 1;
                         bit = write_out(p, orow, rq, d0);
-                        if (is_last[j] || (f.regular && f.n_tot == 1)) {
-                            writer[j] = true;
+                        if (regular || is_last[j]) {
+                            writer[j] = owner || is_last[j];
                             wcell[j] = c;
-                        } else if (!f.regular) {
+                        } else {
                             // irregular run (saturation, zero increment, immediate expiry): walk the rest one by one
                             if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // the host's proof was wrong: must stay 0
                             uint32_t wd = 0;
@@ -615,20 +641,13 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                             writer[j] = true;
                             wcell[j] = c;
                         }
-                    } else if (f.regular) {
-                        const int64_t jj = (int64_t)r < f.n_tot ? (int64_t)r : f.n_tot;
-                        Cell v;
-                        v.tat = f.new0 + (jj - 1) * f.inc;
-                        v.expiry = UINT64_MAX;
-                        d = tc::gcra_step<FULL>(v, rq.ei, rq.dvt, rq.q, rq.now);
-                        na += d.allowed;
-                        nd += !d.allowed;
-                        denied_here[j] = !d.allowed;
+                    } else if (regular) {
+                        na += ok_r;
+                        nd += !ok_r;
+                        denied_here[j] = !ok_r;
                         bit = write_out(p, orow, rq, d);
-                        if (d.allowed && (is_last[j] || (int64_t)r + 1 == f.n_tot)) {
-                            writer[j] = true;
-                            wcell[j] = v;
-                        }
+                        writer[j] = owner;
+                        wcell[j] = v;
                     }
                     // irregular && r > 0: the head lane produced this request's outputs
                 }
