@@ -178,6 +178,26 @@ extern "C" {
     pub fn tc_route_batch(e: *mut tc_engine, r: *const tc_route) -> c_int;
     pub fn tc_route_host(world: u32, keys_per_shard: u64, n: u64, global_id: *const u32, owner: *mut u32, slot: *mut u32) -> c_int;
     pub fn tc_route_inverse(world: u32, keys_per_shard: u64, n: u64, owner: *const u32, slot: *const u32, global_id: *mut u64) -> c_int;
+    pub fn tc_engine_set_stream(e: *mut tc_engine, hip_stream: *mut c_void) -> c_int;
+    pub fn tc_register_params(
+        e: *mut tc_engine,
+        n: u64,
+        slots: *const u32,
+        max_burst: *const i64,
+        count_per_period: *const i64,
+        period: *const i64,
+    ) -> c_int;
+    pub fn tc_lookup_slot(e: *mut tc_engine, key: *const u8, key_len: usize, slot: *mut i64) -> c_int;
+    pub fn tc_counters_refresh(e: *mut tc_engine) -> c_int;
+    pub fn tc_counters_device_ptr(e: *mut tc_engine, dptr: *mut *mut c_void) -> c_int;
+    pub fn tc_top_denied(e: *mut tc_engine, k: u32, slots: *mut u32, counts: *mut u64, n_out: *mut u32) -> c_int;
+    pub fn tc_denied_reset(e: *mut tc_engine) -> c_int;
+    pub fn tc_slot_keys(e: *mut tc_engine, n: u32, slots: *const u32, key_bytes: *mut u8, key_bytes_cap: usize, key_off: *mut u32) -> c_int;
+    pub fn tc_read_state(e: *mut tc_engine, first: u64, n: u64, tat: *mut i64, expiry: *mut u64) -> c_int;
+    pub fn tc_profile_enable(e: *mut tc_engine, on: c_int) -> c_int;
+    pub fn tc_profile_read(e: *mut tc_engine, total_ms: *mut f64, calls: *mut u64) -> c_int;
+    pub fn tc_selfcheck(e: *mut tc_engine, violations: *mut u64) -> c_int;
+    pub fn tc_debug_fail_copy(e: *mut tc_engine, nth: u32) -> c_int;
     pub fn tc_snapshot_save(e: *mut tc_engine, path: *const c_char) -> c_int;
     pub fn tc_snapshot_load(e: *mut tc_engine, path: *const c_char) -> c_int;
 }

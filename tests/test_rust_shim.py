@@ -130,7 +130,9 @@ def test_extern_declarations_match_the_header():
         assert rust_args == c_args, f"{name}: rust {rust_args} != header {c_args}"
         assert (ret.strip() if ret else None) == c_ret, f"{name}: return {ret} != {c_ret}"
         n += 1
-    assert n >= 18
+    bound = set(re.findall(r"pub fn (tc_\w+)", block))
+    missing = sorted(set(c) - bound)
+    assert not missing, f"tcgpu.h declares {missing}, which ffi.rs does not bind"
     for needed in ("tc_engine_create", "tc_engine_destroy", "tc_rate_limit", "tc_rate_limit_batch_keys", "tc_store_get",
                    "tc_store_compare_and_swap_with_ttl", "tc_store_set_if_not_exists_with_ttl", "tc_sweep_expired"):
         assert re.search(rf"pub fn {needed}\(", block), needed
