@@ -136,9 +136,33 @@ def _contender(rank, seconds, q):
     eng.use_torch_stream()
     eng.register_params_uniform(200_000, 10**9, 1)   # burst 200 000, 1 ns apart: runs of 100 000 allowed requests
     tt = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).cuda()
+    from throttlecrab_amd import sharded
+    host_counts = eng.host_alloc(3, np.uint32)
+    host_counts[:] = 0
     t_end, rounds, bad = time.time() + seconds, 0, 0
     while time.time() < t_end:
-        kind = rounds % 3
+        kind = rounds % 4
+        if kind == 3:
+            # a global batch of 2 shards routed on the grouping streams (one-pass router: tiles chained by look-back),
+            # the count polled from pinned memory, what this shard owns evaluated as a pipelined batch
+            gids = rng.integers(0, 2 * cap, 2 * n - 5000).astype(np.uint32)
+            owner, slot = sharded.route(gids, 2, cap)
+            want = slot[owner == rank]
+            base = T0 + rounds * 10**9
+            ref = orc.batch_slots(want, 200_000, 10**9, 1, 1, base)
+            g = torch.from_numpy(gids.astype(np.int32)).cuda()
+            torch.cuda.synchronize()
+            slots_d, _, _ = eng.route_batch(g, 2, only=rank, ahead=True, host_counts=host_counts, tag=rounds + 1)
+            while int(host_counts[2]) != rounds + 1:
+                pass
+            mine = int(host_counts[rank])
+            bad += int(mine != len(want))
+            res = eng.rate_limit_batch_slots(slots_d[:mine], registered=True, quantity=1, now_ns=base, want=("allowed", "remaining"), inputs_ready=True)
+            torch.cuda.synchronize()
+            if mine == len(want):
+                bad += int((res.allowed.cpu().numpy() != ref.allowed).sum()) + int((res.remaining.cpu().numpy() != ref.remaining).sum())
+            rounds += 1
+            continue
         slots = rng.integers(0, cap, n).astype(np.uint32)
         hot = rng.random(n) < 0.4
         slots[hot] = 7 + rank            # ~105 000 requests of one key: >1 600 waves, all allowed
@@ -174,6 +198,6 @@ def test_two_processes_contend_for_one_device():
         p.join(timeout=120)
         assert p.exitcode == 0
     for rank, rounds, bad, viol in got:
-        assert rounds >= 3, (rank, rounds)
+        assert rounds >= 4, (rank, rounds)
         assert bad == 0, (rank, bad)
         assert viol == 0, f"rank {rank}: the spin watchdog fired {viol} times"
