@@ -6,6 +6,8 @@ the oracle's results bit for bit, on all outputs and on the resident state:
   all_sizes     every eligible batch, however small
   long_buckets  ... and buckets of any length stay on the bucket path (the walk in pieces with parked stores)
   gate_trips    ... and every batch trips the gate (bucket kernels leave at once, the gated sort path runs)
+  gate_trips_backoff  ... with the engine's back-off: once the host has seen a tripped gate, the next 32 batches are
+                sorted without being partitioned first
   off           the bucket path disabled"""
 import numpy as np
 import pytest
@@ -18,10 +20,11 @@ MODES = {
     "default": {},
     "all_sizes": {"TCGPU_BUCKET_MIN_N": "1"},
     "long_buckets": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "32767"},
-    "gate_trips": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "1"},
+    "gate_trips": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "1", "TCGPU_BUCKET_BACKOFF": "0"},
+    "gate_trips_backoff": {"TCGPU_BUCKET_MIN_N": "1", "TCGPU_BUCKET_SKEW": "1"},
     "off": {"TCGPU_BUCKET": "0"},
 }
-ENV = ("TCGPU_BUCKET", "TCGPU_BUCKET_MIN_N", "TCGPU_BUCKET_SKEW", "TCGPU_BUCKET_PIPED")
+ENV = ("TCGPU_BUCKET", "TCGPU_BUCKET_MIN_N", "TCGPU_BUCKET_SKEW", "TCGPU_BUCKET_PIPED", "TCGPU_BUCKET_BACKOFF")
 
 
 @pytest.fixture(params=list(MODES), ids=list(MODES))

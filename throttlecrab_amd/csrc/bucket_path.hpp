@@ -78,6 +78,8 @@ struct Work {
     uint32_t skew;       //                longest bucket this path takes on
     uint32_t nbk;
     int lb;
+    volatile uint32_t* gate_host; // pinned host word or NULL: k_scatter mirrors the gate there, so that the host -- which
+                         //                cannot wait for it -- at least learns what recent batches looked like
 };
 inline size_t work_bytes(uint32_t max_n, uint32_t nbk) {
     const size_t tiles = tiles_of(max_n);
@@ -103,6 +105,7 @@ inline Work carve(void* base, uint32_t max_n, uint32_t nbk, int lb) {
     w.nbk = nbk;
     w.lb = lb;
     w.skew = 1024;
+    w.gate_host = nullptr;
     return w;
 }
 // where bucket j's requests start in elems (j == nbk: the end of the last bucket)
@@ -244,7 +247,9 @@ inline size_t scatter_lds_bytes(uint32_t nbk) { return (size_t)pad4(nbk) * 4 * 2
 
 __global__ __launch_bounds__(TILE_THREADS) void k_scatter(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap, Work w) {
     extern __shared__ uint32_t s_mem[];
-    if (__builtin_nontemporal_load(w.maxb) > w.skew) return; // a skewed batch: the sort path (enqueued as well) takes it
+    const uint32_t longest = __builtin_nontemporal_load(w.maxb);
+    if (w.gate_host && blockIdx.x == 0 && threadIdx.x == 0) *w.gate_host = longest;
+    if (longest > w.skew) return; // a skewed batch: the sort path (enqueued as well) takes it
     const uint32_t nbk = w.nbk, nbkp = pad4(nbk);
     const int lb = w.lb;
     uint16_t* s_cnt = reinterpret_cast<uint16_t*>(s_mem);

@@ -54,6 +54,7 @@ namespace {
 constexpr int SORT_ITEMS = 8;        // batches that run in order on the engine's stream
 constexpr int SORT_ITEMS_PIPED = 16; // TC_B_INPUTS_READY batches (grouped on the auxiliary streams)
 constexpr int PIPE_DEPTH_MAX = 8;
+constexpr uint32_t BP_BACKOFF = 32;          // batches sorted without trying the bucket path after a skewed one was seen
 constexpr int AUX_MAX = 4;                  // auxiliary (grouping) streams
 // HIP multiplexes streams onto 4 hardware queues; two ACTIVE streams on one queue serialise each other
 // (a barrier packet of one blocks the other: measured 14.7 -> 7.4 G/s with a fifth stream).  Slot mode:
@@ -188,6 +189,9 @@ struct tc_engine {
     uint32_t bp_min_n = 0;   // smaller batches are sorted (TCGPU_BUCKET_MIN_N)
     uint32_t bp_skew = 1024; // longest bucket the path takes on (TCGPU_BUCKET_SKEW)
     bool bp_piped = false;   // also for TC_B_INPUTS_READY batches (TCGPU_BUCKET_PIPED=1; measured slower)
+    uint32_t* bp_gate_host = nullptr; // pinned: the gate of a recent batch, mirrored by the device (a hint, never waited for)
+    uint32_t bp_backoff = 0;  // batches left during which the bucket path is not even tried (the stream looked skewed)
+    uint32_t bp_backoff_len = BP_BACKOFF; // (TCGPU_BUCKET_BACKOFF; 0: always try)
     PendEntry* bp_park = nullptr; // parked cell stores of long buckets, one entry per request
 
     // string-key mode (TC_CFG_KEY_MODE): device hash table + per-batch resolution scratch
@@ -326,9 +330,12 @@ static int engine_alloc(tc_engine* e) {
         e->bp_ok = e->bp_lb >= 0 && !(off && atoi(off) == 0);
         e->bp_min_n = 16384;
         if (const char* d = getenv("TCGPU_BUCKET_PIPED")) e->bp_piped = atoi(d) != 0;
+        if (const char* d = getenv("TCGPU_BUCKET_BACKOFF")) e->bp_backoff_len = (uint32_t)std::max(atoi(d), 0);
         if (const char* d = getenv("TCGPU_BUCKET_MIN_N")) e->bp_min_n = (uint32_t)std::max(atoi(d), 1);
         if (const char* d = getenv("TCGPU_BUCKET_SKEW")) e->bp_skew = (uint32_t)std::min<long long>(std::max(atoll(d), 1ll), bp::MAX_SKEW);
         if (e->bp_ok) {
+            TC_HIP(e, hipHostMalloc((void**)&e->bp_gate_host, sizeof(uint32_t), hipHostMallocDefault));
+            *e->bp_gate_host = 0;
             e->bp_nbk = bp::buckets_of(cap, e->bp_lb);
             const size_t bytes = bp::work_bytes(e->bp_max_n, e->bp_nbk);
             for (uint32_t si = 0; si < e->depth; ++si) {
@@ -336,6 +343,7 @@ static int engine_alloc(tc_engine* e) {
                 TC_HIP(e, hipMalloc(&ss.bp_scratch, bytes));
                 ss.bpw = bp::carve(ss.bp_scratch, e->bp_max_n, e->bp_nbk, e->bp_lb);
                 ss.bpw.skew = e->bp_skew;
+                ss.bpw.gate_host = e->bp_gate_host;
             }
             TC_HIP(e, hipMalloc(&e->bp_park, (size_t)e->bp_max_n * sizeof(PendEntry)));
         }
@@ -626,6 +634,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         (void)hipStreamSynchronize(e->key_stream);
         (void)hipStreamDestroy(e->key_stream);
     }
+    if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
     if (e->k_done) (void)hipEventDestroy(e->k_done);
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
@@ -1111,7 +1120,22 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         // beside the evaluation of earlier batches the partition's scattered 4-byte writes cost more than
         // the sort's three coalesced passes (69-86 vs 66 us per 1 Mi batch).
         // (TC_B_GROUPED_OUTPUT promises rows grouped by key: that is the sorted order)
-        const bool bucketed = direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
+        // A skewed batch pays for the partition and then takes the sort path anyway.  The host cannot wait for the
+        // gate, but the device mirrors it into pinned memory: when a recent batch tripped it, the next BP_BACKOFF
+        // batches are not partitioned at all (the sort path alone is always correct), then the path is tried again.
+        bool eligible = direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
+        if (eligible && e->bp_gate_host && e->bp_backoff_len) {
+            const uint32_t seen = *(volatile uint32_t*)e->bp_gate_host;
+            if (seen > e->bp_skew && e->bp_backoff == 0) {
+                e->bp_backoff = e->bp_backoff_len;
+                *(volatile uint32_t*)e->bp_gate_host = 0; // (consumed; the next partition that runs writes a fresh one)
+            }
+            if (e->bp_backoff) {
+                --e->bp_backoff;
+                eligible = false;
+            }
+        }
+        const bool bucketed = eligible;
         // Grouped rows + a bitmask of them, every run regular: the evaluation's waves hold 64 consecutive rows each and
         // pack their decisions with one ballot (no byte column, no k_pack_bits launch).
         if (b.allowed_bits && p.order && direct) {
