@@ -21,7 +21,9 @@ exchange the path has: aggregate metrics).  The line carries `per_gpu` (requests
 owned, allowed share, decisions/s): under Zipf the owner of the hottest key gets
 11.6 % of ALL traffic on top of its share.
 
-Prints ONE JSON line on rank 0.
+Output (rank 0): the LAST stdout line is ONE compact JSON object (< 4 KB: headline, roofline of the critical-path
+kernel, cpu_baseline, one number per secondary workload); everything else (per-stage tables, PMC provenance, notes)
+goes to gpurun_out/bench_detail.json.
 """
 import argparse
 import json
@@ -44,6 +46,9 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 N_KEYS = 10_000_000
 BATCH = 1 << 20
 ALG_BYTES_PER_DECISION = 36.125  # SURVEY.md section 8(d), slot mode, decisions only
+ALG_BYTES_GENERAL = 44.125       # ... + the request's own 8-byte timestamp (general batches: per-request `now`)
+COMPACT_LIMIT = 4096             # bytes: the driver keeps an 8 KB stdout tail; the compact line stays well inside it
+DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRICS_EVERY = 32               # N > 1: RCCL all-gather of the counter blocks every this many steps (+ the last)
 
@@ -54,7 +59,7 @@ KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep", "eval": "ev::
 # kernel name fragments in the rocprofv3 summaries under profiles/
 PROFILE_NAME_OF_STAGE = {"prep": "rs::k_hist", "sort": "k_onesweep", "eval": "k_eval_sorted", "commit": "k_commit_list",
                          "bucket_hist": "k_tile_hist", "bucket_scan": "k_bucket_scan", "bucket_scatter": "k_scatter",
-                         "bucket_eval": "k_bucket_eval", "hash": "kt::k_probe"}
+                         "bucket_eval": "k_bucket_eval", "hash": "kt::k_probe", "eval_general": "k_eval_general"}
 COPY_CEILING_GBS = 6290.0        # MI355X_MICROARCH.md: measured copy ceiling (what line-granular traffic can reach)
 
 
@@ -66,10 +71,10 @@ def pmc_traffic(stage, stream, layout, launches_per_batch):
     file (and which commit it was taken at) so that a stale profile cannot pass for a fresh one."""
     import glob
     import re
-    files = glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_{layout}*_pmc.json")) + \
-        glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_pmc.json"))
-    if layout == "wide":  # (round-1 summaries carry no layout tag: they are the 16-byte layout)
-        files += [f for f in glob.glob(os.path.join(ROOT, "profiles", f"r*_{stream}_1M*_pmc.json"))]
+    pat = re.compile(rf"r\d+_v\d+_{re.escape(stream)}(_{re.escape(layout)})?(_1M)?(_piped)?_pmc\.json$")
+    files = [f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")) if pat.match(os.path.basename(f))]
+    if layout != "wide":  # (summaries without a layout tag are round 1's: the 16-byte layout)
+        files = [f for f in files if f"_{layout}" in os.path.basename(f)]
     want = PROFILE_NAME_OF_STAGE.get(stage)
     if not files or not want:
         return None, None
@@ -104,7 +109,13 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default="uniform", choices=["uniform", "zipf"])
+    ap.add_argument("--workload", default="uniform", choices=["uniform", "zipf", "general", "general_zipf"],
+                    help="uniform / zipf: one timestamp per batch (BASELINE configs[1] / [2]); general / general_zipf: the same "
+                         "slot streams with a timestamp PER REQUEST, as every transport stamps them "
+                         "(throttlecrab-server/src/transport/http.rs:128) -- k_eval_general")
+    ap.add_argument("--route", default="exchange", choices=["exchange", "replicate"],
+                    help="N > 1: exchange = every rank routes 1/N of the global stream and forwards the segments to their "
+                         "owners (peer copies); replicate = every rank filters the whole global stream")
     ap.add_argument("--keys", type=int, default=N_KEYS)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-sample-batches", type=int, default=8)
@@ -126,14 +137,27 @@ def make_batches(kind, n_keys, batch, count, seed_shift=0):
     return [W.uniform_slots(n_keys, batch, seed=2 + seed_shift, start=i * batch) for i in range(count)]
 
 
-def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",), piped=True):
-    """warmup + timed region; returns seconds for `steps` batches (max over ranks)."""
+def now_of(now0, i, nows):
+    """the batch's timestamp: one scalar (1 ms per batch), or -- general batches -- a resident column of per-request
+    timestamps (request j of batch i is stamped i ms + j ns: strictly increasing inside the batch)"""
+    return now0 + i * 1_000_000 if nows is None else nows[i % len(nows)]
+
+
+def make_nows(dev, batch, count, now0):
+    import torch
+    return [torch.arange(batch, dtype=torch.int64, device=dev) + (now0 + b * 1_000_000) for b in range(count)]
+
+
+def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",), piped=True, nows=None):
+    """warmup + timed region; returns seconds for `steps` batches (max over ranks).  (With `nows` the columns repeat
+    after len(nows) batches: timestamps then go back by that many ms once per cycle, which the general path takes
+    like any other non-monotone clock.)"""
     import torch
     it = 0
 
     def one(i, last=False):
         eng.rate_limit_batch_slots(d_batches[i % len(d_batches)], registered=True, quantity=1,
-                                   now_ns=now0 + i * 1_000_000, want=want, out=out, inputs_ready=piped)
+                                   now_ns=now_of(now0, i, nows), want=want, out=out, inputs_ready=piped)
         if dist is not None and (i % METRICS_EVERY == METRICS_EVERY - 1 or last):
             eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
@@ -159,7 +183,7 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
     return dt, it
 
 
-def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True):
+def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True, nows=None):
     """`steps` more batches with a HIP event pair around each of the engine's kernels (recorded on the stream the
     kernel runs on).  piped=True: issued exactly like the timed region (the grouping of later batches overlaps
     the evaluation of earlier ones), so the durations include that contention.
@@ -168,7 +192,7 @@ def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True):
     eng.profile_enable(True)
     for i in range(steps):
         eng.rate_limit_batch_slots(d_batches[(it0 + i) % len(d_batches)], registered=True, quantity=1,
-                                   now_ns=now0 + (it0 + i) * 1_000_000, want=("allowed",), out=out, inputs_ready=piped)
+                                   now_ns=now_of(now0, it0 + i, nows), want=("allowed",), out=out, inputs_ready=piped)
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile_enable(False)
@@ -176,55 +200,46 @@ def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True):
             for k, (ms, calls) in prof.items() if calls}
 
 
-def roofline_block(a, stream, dt, piped, inorder):
-    """achieved = algorithmic bytes (36.125 B per decision x the batch) / duration, against the
-    8 TB/s HBM peak.  The headline entry is the stage with the largest PER-BATCH total in the configuration that
-    was timed (pipelined: `value` comes from there); `stages` has every stage, in that configuration and with
-    the batches strictly in order on one stream (what rocprofv3 --kernel-trace shows: the tracer serialises)."""
-    alg = ALG_BYTES_PER_DECISION * a.batch
-
-    def fill(st, k):
+def stage_table(stages, alg, stream, layout, gated=()):
+    """Detail only (bench_detail.json): every stage with its algorithmic rate and the PMC traffic of the newest committed
+    profile.  A stage that did not do a whole batch's work per batch (gated-off launches, < 1 launch per batch) gets
+    no rate: algorithmic bytes divided by the time of a kernel that left at once is not a roofline figure."""
+    out = {}
+    for k, st in stages.items():
         s = dict(st)
-        s["achieved_GBs"] = alg / (s["per_batch_ms"] * 1e-3) / 1e9
-        s["frac"] = s["achieved_GBs"] / HBM_PEAK_GBS
-        tr, src = pmc_traffic(k, stream, a.layout, s["launches_per_batch"])
-        s["traffic_bytes_per_batch"] = tr
-        if tr:
-            s["traffic_floor_ms"] = tr / (COPY_CEILING_GBS * 1e9) * 1e3  # what this traffic costs at the copy ceiling
-            s["traffic_source"] = src
-        return s
-    p_st = {k: fill(v, k) for k, v in piped.items()}
-    i_st = {k: fill(v, k) for k, v in inorder.items()}
-    if "bucket_eval" in i_st:
-        # in order the batch took the bucket path: the sort path's kernels were launched behind the gate and left at
-        # once (what is timed is the launch), they move no data
-        for k in ("prep", "sort", "eval"):
-            if k in i_st:
-                for f in ("traffic_floor_ms", "traffic_source", "achieved_GBs", "frac"):
-                    i_st[k].pop(f, None)
-                i_st[k]["traffic_bytes_per_batch"] = None
-                i_st[k]["note"] = "gated off: launched behind the bucket path's gate and left at once"
-    dom = max(p_st, key=lambda k: p_st[k]["per_batch_ms"])
-    d = p_st[dom]
-    # the kernel that touches the resident state (what the algorithmic bytes describe), in both configurations
-    ev_p = p_st.get("eval") or p_st.get("bucket_eval")
-    ev_i = max((i_st[k] for k in ("eval", "bucket_eval") if k in i_st), key=lambda s: s["per_batch_ms"])
-    block = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_batch": alg,
-             "stage": dom, "kernel": d["kernel"], "launches_per_batch": d["launches_per_batch"], "avg_ms": d["avg_ms"],
-             "per_batch_ms": d["per_batch_ms"], "achieved": d["achieved_GBs"], "frac": d["frac"],
-             "traffic": d["traffic_bytes_per_batch"], "traffic_source": d.get("traffic_source"),
-             "measured_in": "the configuration of the timed region (batches pipelined with TC_B_INPUTS_READY; HIP events on the "
-                            "stream each kernel runs on, same process, right after the timed region)",
-             "whole_step_frac": alg / (dt / a.steps) / 1e9 / HBM_PEAK_GBS,
-             "whole_step_GBs": alg / (dt / a.steps) / 1e9,
-             "evaluation_kernel": {"pipelined": ev_p, "in_order": ev_i},
-             "stages": {"pipelined": p_st, "in_order": i_st},
-             "in_order_sum_ms": sum(s["per_batch_ms"] for s in i_st.values())}
-    return block
+        if k in gated or s["launches_per_batch"] < 0.999:
+            s["note"] = "gated off or not launched for every batch: no rate"
+        else:
+            s["achieved_GBs"] = alg / (s["per_batch_ms"] * 1e-3) / 1e9
+            tr, src = pmc_traffic(k, stream, layout, s["launches_per_batch"])
+            s["traffic_bytes_per_batch"] = tr
+            if tr:
+                s["traffic_floor_ms"] = tr / (COPY_CEILING_GBS * 1e9) * 1e3  # what this traffic costs at the copy ceiling
+                s["traffic_source"] = src
+        out[k] = s
+    return out
 
 
-def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world):
-    """One engine, one request stream: warmup + timed region (pipelined), then the per-kernel profile."""
+def roofline_entry(kernel, avg_ms, alg, ms_per_step, traffic, source):
+    """The roofline object of the JSON line for ONE launch of the critical-path kernel.  achieved = algorithmic bytes
+    of the launch / its average duration (HIP events on the stream it runs on, inside this process); frac must lie
+    in (0, 1] and the kernel cannot take longer than the step it is part of -- otherwise the entry is withheld."""
+    ach = alg / (avg_ms * 1e-3) / 1e9
+    frac = ach / HBM_PEAK_GBS
+    r = {"bound": "hbm", "kernel": kernel, "avg_ms": avg_ms, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac,
+         "traffic": traffic, "traffic_over_algorithmic": (traffic / alg) if traffic else None,
+         "whole_step_frac": alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes": alg, "source": source}
+    if not (0.0 < frac <= 1.0):
+        r.update({"achieved": None, "frac": None, "invalid": "frac outside (0, 1]"})
+    elif avg_ms > ms_per_step * 1.02:
+        # events on a stream that other streams contend with can stretch; a kernel "longer than its step" is not evidence
+        r["invalid"] = "avg_ms > ms_per_step: per-kernel events stretched by concurrent streams"
+    return r
+
+
+def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, general=False, profile=True):
+    """One engine, one request stream: warmup + timed region (pipelined), then the per-kernel profile.
+    general: every request carries its own timestamp (k_eval_general instead of k_eval_sorted)."""
     import torch
     eng = t.Engine(a.keys, a.batch, device=local, fixed_params=(a.layout == "fixed"))
     eng.use_torch_stream()
@@ -232,20 +247,37 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world):
     nb = a.steps + a.warmup
     host_batches = make_batches(stream, a.keys, a.batch, min(nb, 64), seed_shift=seed_shift)
     d_batches = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in host_batches]
+    nows = make_nows(dev, a.batch, min(nb + 2 * a.steps, 32), W.T0_NS) if general else None
     out = t.BatchResult()
     cnt_view = gathered = None
     if dist is not None:
         from throttlecrab_amd.sharded import device_counter_view
         cnt_view = device_counter_view(eng)
         gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
-    dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered, piped=not a.in_order)
+    dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered, piped=not a.in_order, nows=nows)
     c = eng.counters()
-    res = {"value": a.steps * a.batch * world / dt, "unit": "decisions/s", "ms_per_step": 1e3 * dt / a.steps,
-           "allowed_fraction": c["allowed"] / max(1, c["total"])}
-    if rank == 0 and not a.profile_run:
-        piped = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True)
-        inorder = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False)
-        res["roofline"] = roofline_block(a, stream, dt, piped, inorder)
+    ms = 1e3 * dt / a.steps
+    alg = (ALG_BYTES_GENERAL if general else ALG_BYTES_PER_DECISION) * a.batch
+    res = {"value": a.steps * a.batch * world / dt, "unit": "decisions/s", "ms_per_step": ms,
+           "allowed_fraction": c["allowed"] / max(1, c["total"]), "whole_step_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if rank == 0 and profile and not a.profile_run:
+        piped = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True, nows=nows)
+        inorder = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False, nows=nows)
+        tag = ("general_" if general else "") + stream
+        # The critical-path kernel of the pipelined run is the evaluation on the engine's stream (the grouping of later
+        # batches runs beside it on the auxiliary streams): its average launch duration as timed in the pipelined
+        # configuration is the roofline's avg_ms.
+        ev = piped.get("eval") or piped.get("bucket_eval")
+        kname = "ev::k_eval_general" if general else ev["kernel"]
+        tr, src = pmc_traffic("eval_general" if general else "eval", tag, a.layout, 1.0)
+        source = {"avg_ms": "HIP events around the kernel on the engine's stream, pipelined run of this process",
+                  "traffic": (src or {}).get("file")}
+        res["roofline"] = roofline_entry(kname, ev["avg_ms"], alg, ms, tr, source)
+        gated = ("prep", "sort", "eval") if "bucket_eval" in inorder else ()
+        res["detail"] = {"stages": {"pipelined": stage_table(piped, alg, tag, a.layout),
+                                    "in_order": stage_table(inorder, alg, tag, a.layout, gated=gated)},
+                         "in_order_sum_ms": sum(s["per_batch_ms"] for s in inorder.values()),
+                         "traffic_source": src}
     return res, eng, d_batches, dt
 
 
@@ -317,13 +349,15 @@ def keys_bench(a, dev):
         dom = max(stages, key=lambda k: stages[k]["per_batch_ms"])
         d = stages[dom]
         tr, src = pmc_traffic(dom, "string_keys" + ("_long" if long else ""), "wide", d["launches_per_batch"])
-        ach = alg / (d["per_batch_ms"] * 1e-3) / 1e9
-        r["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "algorithmic_bytes_per_batch": alg,
-                         "algorithmic_bytes_per_decision": alg / B, "stage": dom, "kernel": d["kernel"],
-                         "launches_per_batch": d["launches_per_batch"], "avg_ms": d["avg_ms"], "per_batch_ms": d["per_batch_ms"],
-                         "achieved": ach, "frac": ach / HBM_PEAK_GBS, "traffic": tr, "traffic_source": src,
-                         "whole_step_frac": alg / (dt / steps) / 1e9 / HBM_PEAK_GBS, "stages": {"pipelined": stages},
-                         "note": "the timed region also holds the sweeps (" + str(steps // 4) + "), the profile steps do not"}
+        r["whole_step_frac"] = alg / (dt / steps) / 1e9 / HBM_PEAK_GBS
+        r["algorithmic_bytes_per_decision"] = alg / B
+        r["launches_per_batch"] = sum(st_["launches_per_batch"] for st_ in stages.values())
+        # the dominant stage's kernels as ONE roofline entry (per-batch total of the stage: the key stage is several launches)
+        r["roofline"] = roofline_entry(d["kernel"], d["per_batch_ms"], alg, 1e3 * dt / steps, tr,
+                                       {"avg_ms": "HIP events, per-batch total of the stage's launches, pipelined profile steps "
+                                                  "(sweeps left out)", "traffic": (src or {}).get("file")})
+        r["detail"] = {"stages": {"pipelined": stages}, "traffic_source": src,
+                       "note": "the timed region also holds the sweeps (" + str(steps // 4) + "), the profile steps do not"}
         out[label] = r
         eng.close()
         del mixed
@@ -421,27 +455,6 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
                                ("; the decisions as one bit per row, packed by the evaluation's own wave ballots (no byte column)"
                                 if want == ("allowed_bits",) else "")}
         grp = t.BatchResult()
-    # general batches: every request carries its own timestamp (strictly increasing inside
-    # the batch), so the closed form does not apply and k_eval_general runs
-    log("  per-request timestamps")
-    nows = [torch.arange(a.batch, dtype=torch.int64, device=dev) + (W.T0_NS + 4 * 10**9 + b * 10**6)
-            for b in range(a.warmup + a.steps)]
-    gout = t.BatchResult()
-    for label, streams in ((f"{other}_stream_per_request_timestamps", ob), (f"{a.workload}_stream_per_request_timestamps", d_batches)):
-        eng3 = t.Engine(a.keys, a.batch, device=local, fixed_params=(a.layout == "fixed"))
-        eng3.use_torch_stream()
-        eng3.register_params_uniform(*W.REF_PARAMS)
-        for i in range(a.warmup):
-            eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
-                                        want=("allowed",), out=gout, inputs_ready=True)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(a.warmup, a.warmup + a.steps):
-            eng3.rate_limit_batch_slots(streams[i % len(streams)], registered=True, quantity=1, now_ns=nows[i],
-                                        want=("allowed",), out=gout, inputs_ready=True)
-        torch.cuda.synchronize()
-        also[label] = {"value": a.steps * a.batch / (time.perf_counter() - t0), "unit": "decisions/s"}
-        eng3.close()
     log("  host buffers")
     # PCIe-inclusive rate: the same stream handed over as HOST buffers (never `value`)
     hb = make_batches(other, a.keys, a.batch, 8)
@@ -592,13 +605,12 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
               for k, (ms, calls) in prof.items() if calls}
     if stages:
         alg = ALG_BYTES_PER_DECISION * decided / steps_p
-        dom = max(stages, key=lambda k: stages[k]["per_batch_ms"])
-        ach = alg / (stages[dom]["per_batch_ms"] * 1e-3) / 1e9
-        res["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "rank": rank, "algorithmic_bytes_per_batch": alg,
-                           "stage": dom, "kernel": stages[dom]["kernel"], "launches_per_batch": stages[dom]["launches_per_batch"],
-                           "avg_ms": stages[dom]["avg_ms"], "per_batch_ms": stages[dom]["per_batch_ms"], "achieved": ach,
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None, "stages": {"pipelined": stages},
-                           "whole_step_frac": ALG_BYTES_PER_DECISION * G / (dt / a.steps) / 1e9 / (HBM_PEAK_GBS * world)}
+        ev = stages.get("eval") or stages.get("bucket_eval")
+        if ev and ev["launches_per_batch"] >= 0.999:
+            # (an owner's share may be evaluated in several chunks: per-step total of the evaluation launches)
+            res["roofline"] = roofline_entry(ev["kernel"], ev["per_batch_ms"], alg, 1e3 * dt / a.steps, None,
+                                             {"avg_ms": f"HIP events, rank {rank}, per-step total of the evaluation launches", "traffic": None})
+        res["stages"] = stages
     eng.close()
     return res
 
@@ -633,75 +645,168 @@ def main():
             sh = run_sharded(a, t, W, dev, local, rank, world, dist)
             torch.cuda.synchronize()
         if rank == 0:
-            print(json.dumps({
+            res = {
                 "metric": "GCRA decisions/sec, 10M keys per GPU", "value": sh["value"], "unit": "decisions/s", "n_gpus": world,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": sh["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "int64", "data": "synthetic",
                 "config": {"workload": f"configs[3]: {world} x {a.keys} keys hash-sharded across {world} GPU(s), ONE global {a.workload} "
-                                       f"request stream of {world} x {a.batch} requests per step routed on the device (tc_route_batch), "
+                                       f"stream of {world} x {a.batch} requests per step, route={sh.get('route', a.route)}, "
                                        f"params (100,1000/3600s), q=1; RCCL all-gather of the metrics only",
-                           "keys_per_gpu": a.keys, "global_batch": world * a.batch, "stream": a.workload,
-                           "parallelism": f"hash-shard x{world}", "outputs": "allowed u8 (decisions only)",
-                           "resident_state": a.layout, "metrics_allgather_every": METRICS_EVERY},
-                "allowed_fraction": sh["allowed_fraction"], "per_gpu": sh["per_gpu"],
-                "imbalance_max_over_mean": sh["imbalance_max_over_mean"], "metrics_exchange": sh["metrics_exchange"],
-                "roofline": sh.get("roofline"), "cpu_baseline": None,
-                "note": "cpu_baseline is reported by the N = 1 run; roofline here is rank 0's evaluation of the requests it owns "
-                        "(the router's three small kernels over the global batch are not in it)"}))
+                           "keys_per_gpu": a.keys, "batch": world * a.batch, "stream": a.workload, "resident_state": a.layout},
+                "allowed_fraction": sh["allowed_fraction"], "per_gpu": sh["per_gpu"], "route": sh.get("route", a.route),
+                "router_ms_per_step": sh.get("router_ms_per_step"),
+                "imbalance_max_over_mean": sh["imbalance_max_over_mean"],
+                "roofline": sh.get("roofline"), "cpu_baseline": None}
+            emit(res, {"metrics_exchange": sh["metrics_exchange"], "stages": sh.get("stages"),
+                       "note": "cpu_baseline is reported by the N = 1 run; roofline here is rank 0's evaluation kernel over the "
+                               "requests it owns (the router's kernels are not in it)"})
         dist.barrier()
         dist.destroy_process_group()
         return
 
+    general = a.workload.startswith("general")
+    stream = {"general": "uniform", "general_zipf": "zipf"}.get(a.workload, a.workload)
     log(f"headline: {a.workload} / {a.layout}")
-    main_res, eng, d_batches, dt = measure_stream(a, t, W, a.workload, dev, local, rank, 0, None, 1)
+    main_res, eng, d_batches, dt = measure_stream(a, t, W, stream, dev, local, rank, 0, None, 1, general=general)
+    cfg_no = {"uniform": 1, "zipf": 2}[stream]
     result = {
         "metric": "GCRA decisions/sec, 10M keys", "value": main_res["value"], "unit": "decisions/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": main_res["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
         "data": "synthetic",
-        "config": {"workload": f"configs[{1 if a.workload == 'uniform' else 2}]: {a.keys} pre-hashed keys SoA per GPU, "
-                               f"{a.workload} request stream, batch={a.batch}, params (100,1000/3600s), q=1",
-                   "keys_per_gpu": a.keys, "batch": a.batch, "stream": a.workload,
-                   "resident_state": ("TC_CFG_FIXED_PARAMS: TAT column, 8 B per key + the plan dictionary (emission interval, "
-                                      "tolerance, burst capacity per plan)" if a.layout == "fixed" else
-                                      "{tat, expiry} cell, 16 B per key + plan id column + the plan dictionary"),
-                   "parallelism": f"hash-shard x{world}", "outputs": "allowed u8 (decisions only)",
-                   "pipelining": "TC_B_INPUTS_READY: batch k+1.. grouped on auxiliary streams while batch k is evaluated",
-                   "metrics_allgather_every": METRICS_EVERY if world > 1 else None},
+        "config": {"workload": f"configs[{cfg_no}]: {a.keys} pre-hashed keys SoA on 1 GPU, {stream} request stream, batch={a.batch}, "
+                               f"params (100,1000/3600s), q=1, " + ("a timestamp per request" if general else "one timestamp per batch") +
+                               ", decisions only",
+                   "keys_per_gpu": a.keys, "batch": a.batch, "stream": a.workload, "resident_state": a.layout,
+                   "pipelined": not a.in_order},
         "allowed_fraction": main_res["allowed_fraction"],
     }
+    detail = {"headline": main_res.pop("detail", None),
+              "notes": {"resident_state": {"fixed": "TC_CFG_FIXED_PARAMS: TAT column, 8 B per key + the plan dictionary (emission interval, "
+                                                    "tolerance, burst capacity per plan)",
+                                           "wide": "{tat, expiry} cell, 16 B per key + plan id column + the plan dictionary"},
+                        "pipelining": "TC_B_INPUTS_READY: batch k+1.. grouped on auxiliary streams while batch k is evaluated",
+                        "outputs": "allowed u8 (decisions only)"}}
     if "roofline" in main_res:
         result["roofline"] = main_res["roofline"]
 
     if rank == 0:
-        if not a.no_also and world == 1 and not a.profile_run:
-            other = "zipf" if a.workload == "uniform" else "uniform"
-            # the other BASELINE stream (configs[2]: Zipf s = 1.1, north_star's target stream), measured the same way
+        if not a.no_also and not a.profile_run:
+            # the other BASELINE stream (configs[1] <-> configs[2]), measured the same way
+            other = "zipf" if stream == "uniform" else "uniform"
             log(f"other stream: {other}")
             o_res, eng2, ob, _ = measure_stream(a, t, W, other, dev, local, 0, 0, None, 1)
-            o_res["config"] = f"configs[{2 if other == 'zipf' else 1}]: same engine shape, {other} request stream"
+            detail[f"{other}_stream"] = o_res.pop("detail", None)
             result[f"{other}_stream"] = o_res
             # the headline stream on the other resident-state layout
             a2 = argparse.Namespace(**vars(a))
             a2.layout = "fixed" if a.layout == "wide" else "wide"
             log(f"other layout: {a2.layout}")
-            l_res, eng_l, _, _ = measure_stream(a2, t, W, a.workload, dev, local, 0, 0, None, 1)
+            l_res, eng_l, _, _ = measure_stream(a2, t, W, stream, dev, local, 0, 0, None, 1, general=general)
             eng_l.close()
-            l_res.pop("roofline", None)
-            result[f"{a.workload}_stream_{a2.layout}_layout"] = l_res
+            detail[f"{a2.layout}_layout"] = l_res.pop("detail", None)
+            result[f"{a2.layout}_layout"] = l_res
+            # what a server's queue looks like: a timestamp per request (k_eval_general), both slot streams
+            for gs in ("uniform", "zipf"):
+                if general and gs == stream:
+                    continue
+                log(f"general batches: {gs}")
+                g_res, eng_g, _, _ = measure_stream(a, t, W, gs, dev, local, 0, 0, None, 1, general=True)
+                eng_g.close()
+                detail[f"general_{gs}"] = g_res.pop("detail", None)
+                result[f"general_{gs}"] = g_res
             log("secondary output forms")
-            result["also"] = secondary(a, t, W, eng2, ob, d_batches, dev, local, other)
+            detail["also"] = secondary(a, t, W, eng2, ob, d_batches, dev, local, other)
             eng2.close()
             log("string keys")
-            result["also"]["string_keys_config4"] = keys_bench(a, dev)
+            sk = keys_bench(a, dev)
+            detail["string_keys"] = {k: (v.pop("detail", None) if isinstance(v, dict) else v) for k, v in sk.items()}
+            result["string_keys"] = {k: v for k, v in sk.items() if isinstance(v, dict)}
         if not a.no_cpu and not a.profile_run:
             log("cpu baseline")
-            result["cpu_baseline"] = cpu_baseline(a.workload, a.keys, a.batch, a.cpu_sample_batches)
-        print(json.dumps(result))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+            result["cpu_baseline"] = cpu_baseline(stream, a.keys, a.batch, a.cpu_sample_batches)
+        emit(result, detail)
     eng.close()
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d is not None and k in d}
+
+
+def _r(x, nd=4):
+    """round floats (recursively) so that the compact line stays compact"""
+    if isinstance(x, float):
+        return float(f"{x:.{nd + 2}g}")
+    if isinstance(x, dict):
+        return {k: _r(v, nd) for k, v in x.items()}
+    if isinstance(x, list):
+        return [_r(v, nd) for v in x]
+    return x
+
+
+def compact_line(result):
+    """The ONE JSON line the driver parses: the contract keys, the roofline of the critical-path kernel, the CPU
+    baseline, and one number (+ its whole-step roofline fraction) per secondary workload.  Everything else lives in
+    bench_detail.json.  Never longer than COMPACT_LIMIT bytes."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+           "dtype", "data", "config", "allowed_fraction", "imbalance_max_over_mean", "router_ms_per_step", "route")
+    c = _pick(result, top)
+    rf = result.get("roofline")
+    if rf:
+        c["roofline"] = _pick(rf, ("bound", "kernel", "avg_ms", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic",
+                                   "whole_step_frac", "invalid"))
+        c["roofline"]["source"] = (rf.get("source") or {}).get("traffic") if isinstance(rf.get("source"), dict) else rf.get("source")
+        if c["roofline"].get("frac") is not None:
+            assert 0.0 < c["roofline"]["frac"] <= 1.0, c["roofline"]
+    cb = result.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind"))
+        c["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:160]
+        if cb.get("all_cores"):
+            c["cpu_baseline"]["all_cores"] = _pick(cb["all_cores"], ("value", "cores"))
+        if cb.get("reference_shape"):
+            c["cpu_baseline"]["reference_shape"] = _pick(cb["reference_shape"], ("value",))
+    else:
+        c["cpu_baseline"] = None
+    one = ("value", "ms_per_step", "whole_step_frac")
+    for k in ("zipf_stream", "uniform_stream", "wide_layout", "fixed_layout", "general_uniform", "general_zipf"):
+        if isinstance(result.get(k), dict):
+            c[k] = _pick(result[k], one)
+            r2 = result[k].get("roofline")
+            if r2 and r2.get("frac") is not None and "invalid" not in r2:
+                c[k]["kernel_frac"] = r2["frac"]
+                c[k]["kernel_ms"] = r2["avg_ms"]
+    if isinstance(result.get("string_keys"), dict):
+        c["string_keys"] = {k: _pick(v, one + ("launches_per_batch",)) for k, v in result["string_keys"].items() if isinstance(v, dict)}
+    if isinstance(result.get("per_gpu"), list):
+        c["per_gpu"] = [_pick(g, ("rank", "share_of_traffic", "decisions_per_s")) for g in result["per_gpu"]][:8]
+    c["detail"] = DETAIL_PATH
+    c = _r(c)
+    line = json.dumps(c, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:  # shed the optional parts, largest first, rather than break the contract
+        for k in ("per_gpu", "string_keys", "general_uniform", "fixed_layout", "wide_layout", "allowed_fraction"):
+            c.pop(k, None)
+            line = json.dumps(c, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    return line
+
+
+def emit(result, detail):
+    """detail file (best effort) + stderr pointer, then the compact line as the LAST line on stdout"""
+    full = dict(result)
+    full["detail"] = detail
+    try:
+        path = os.path.join(ROOT, DETAIL_PATH)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        print(f"[bench] detail written to {path}", file=sys.stderr, flush=True)
+    except OSError as e:
+        print(f"[bench] could not write the detail file: {e}", file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(compact_line(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,101 @@
+"""bench.py's output contract (no GPU): the LAST stdout line is one compact JSON object the driver can parse from
+an 8 KB tail -- round 2 printed 24 KB and the record came back `parsed: null`."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def canned():
+    alg = bench.ALG_BYTES_PER_DECISION * bench.BATCH
+    rf = bench.roofline_entry("ev::k_eval_sorted", 0.0481234567, alg, 0.0581234567, 118.2e6,
+                              {"avg_ms": "HIP events ...", "traffic": "profiles/r03_v1_uniform_fixed_pmc.json"})
+    one = {"value": 17.123456789e9, "unit": "decisions/s", "ms_per_step": 0.06123456, "allowed_fraction": 0.18123,
+           "whole_step_frac": 0.0771234, "roofline": rf, "detail": {"stages": {"x": list(range(1000))}}}
+    return {
+        "metric": "GCRA decisions/sec, 10M keys", "value": 18.04e9, "unit": "decisions/s", "n_gpus": 1, "steps": 20, "warmup": 5,
+        "ms_per_step": 0.0581234567, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": "configs[1]: 10000000 pre-hashed keys SoA on 1 GPU, uniform request stream, batch=1048576, "
+                               "params (100,1000/3600s), q=1, one timestamp per batch, decisions only",
+                   "keys_per_gpu": 10_000_000, "batch": 1 << 20, "stream": "uniform", "resident_state": "fixed", "pipelined": True},
+        "allowed_fraction": 0.999, "roofline": rf,
+        "zipf_stream": dict(one), "wide_layout": dict(one), "general_uniform": dict(one), "general_zipf": dict(one),
+        "string_keys": {"key_%d": dict(one, launches_per_batch=6.0), "ascii_32_64": dict(one, launches_per_batch=6.0),
+                        "workload": "a long description " * 20},
+        "cpu_baseline": {"value": 1.81e6, "unit": "decisions/s", "cores": 1, "kind": "port", "sample": "first 8 batches " * 30,
+                         "all_cores": {"value": 14.1e6, "cores": 16, "machine_cores": 256, "note": "x" * 500},
+                         "reference_shape": {"value": 11.2e6, "unit": "decisions/s", "sample": "y" * 500,
+                                             "published_by_reference": {"value": 12_500_000}}},
+    }
+
+
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+            "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def test_compact_line_is_small_and_complete():
+    line = bench.compact_line(canned())
+    assert "\n" not in line
+    assert len(line) < 4096, len(line)
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+    for k in ("workload", "keys_per_gpu", "batch", "stream", "resident_state"):
+        assert k in d["config"], k
+    r = d["roofline"]
+    for k in ("bound", "kernel", "avg_ms", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "whole_step_frac",
+              "source"):
+        assert k in r, k
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.0 < r["frac"] <= 1.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6
+    assert r["avg_ms"] <= d["ms_per_step"]                       # the kernel is part of the step
+    assert abs(r["traffic_over_algorithmic"] - 118.2e6 / (36.125 * (1 << 20))) < 1e-3
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in cb, k
+    assert cb["all_cores"]["cores"] == 16 and cb["reference_shape"]["value"] == 11.2e6
+    for k in ("zipf_stream", "wide_layout", "general_zipf"):
+        assert set(("value", "whole_step_frac")) <= set(d[k]), k
+    assert set(d["string_keys"]) == {"key_%d", "ascii_32_64"}
+    assert "stages" not in line and "traffic_source" not in line  # the per-stage tables live in the detail file
+
+
+def test_a_fraction_above_one_is_never_printed():
+    alg = bench.ALG_BYTES_PER_DECISION * bench.BATCH
+    r = bench.roofline_entry("bp::k_scatter", 0.0003, alg, 0.06, None, None)  # a launch that left at once
+    assert r["frac"] is None and r["achieved"] is None and "invalid" in r
+    res = canned()
+    res["roofline"] = r
+    d = json.loads(bench.compact_line(res))
+    assert d["roofline"]["frac"] is None
+
+
+def test_a_kernel_longer_than_its_step_is_flagged():
+    alg = bench.ALG_BYTES_PER_DECISION * bench.BATCH
+    r = bench.roofline_entry("rs::k_onesweep", 0.1085, alg, 0.0615, None, None)  # round 2's headline entry
+    assert "invalid" in r
+
+
+def test_oversized_results_shed_optional_parts_not_the_contract():
+    res = canned()
+    res["per_gpu"] = [{"rank": i, "share_of_traffic": 0.125, "decisions_per_s": 1e9, "junk": "z" * 300} for i in range(8)]
+    res["config"]["workload"] = "w" * 2500
+    line = bench.compact_line(res)
+    assert len(line) <= 4096
+    d = json.loads(line)
+    for k in REQUIRED:
+        assert k in d, k
+
+
+def test_stage_table_gives_no_rate_to_partial_launches():
+    st = {"bucket_scatter": {"kernel": "bp::k_scatter", "launches_per_batch": 0.05, "avg_ms": 0.02, "per_batch_ms": 0.001},
+          "eval": {"kernel": "ev::k_eval_sorted", "launches_per_batch": 1.0, "avg_ms": 0.04, "per_batch_ms": 0.04}}
+    out = bench.stage_table(st, 37.9e6, "uniform", "fixed")
+    assert "achieved_GBs" not in out["bucket_scatter"] and "note" in out["bucket_scatter"]
+    assert out["eval"]["achieved_GBs"] > 0

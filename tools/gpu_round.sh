@@ -21,6 +21,8 @@ for C in $CONFIGS; do
     uniform_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide"; PMCENV="TCGPU_BUCKET=0" ;;
     zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf"; PMCENV="TCGPU_BUCKET=0" ;;
     zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf"; PMCENV="TCGPU_BUCKET=0" ;;
+    general_uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general" ;;
+    general_zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general_zipf" ;;
     string_keys) CMD="python $R/tools/profile_keys.py short 8" ;;
     string_keys_long) CMD="python $R/tools/profile_keys.py long 8" ;;
     *) echo "unknown config $C"; continue ;;
