@@ -47,6 +47,7 @@ N_KEYS = 10_000_000
 BATCH = 1 << 20
 ALG_BYTES_PER_DECISION = 36.125  # SURVEY.md section 8(d), slot mode, decisions only
 ALG_BYTES_GENERAL = 44.125       # ... + the request's own 8-byte timestamp (general batches: per-request `now`)
+OUT_RING = 8                     # result sets the pipelined runs cycle through (more than the engine keeps in flight)
 COMPACT_LIMIT = 4096             # bytes: the driver keeps an 8 KB stdout tail; the compact line stays well inside it
 DETAIL_PATH = os.path.join("gpurun_out", "bench_detail.json")
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
@@ -155,9 +156,15 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
     import torch
     it = 0
 
+    # every batch in flight writes its results to arrays of its own (a ring of OUT_RING result sets, as a consumer that
+    # reads them later needs anyway); decisions-only pipelined batches say so with TC_B_OUTPUTS_IDLE
+    ring = out if isinstance(out, list) else [out]
+    idle = piped and len(ring) > 1
+
     def one(i, last=False):
         eng.rate_limit_batch_slots(d_batches[i % len(d_batches)], registered=True, quantity=1,
-                                   now_ns=now_of(now0, i, nows), want=want, out=out, inputs_ready=piped)
+                                   now_ns=now_of(now0, i, nows), want=want, out=ring[i % len(ring)], inputs_ready=piped,
+                                   outputs_idle=idle)
         if dist is not None and (i % METRICS_EVERY == METRICS_EVERY - 1 or last):
             eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
@@ -190,9 +197,11 @@ def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True, nows=None):
     -> {stage: {"kernel", "launches_per_batch", "avg_ms", "per_batch_ms"}}"""
     import torch
     eng.profile_enable(True)
+    ring = out if isinstance(out, list) else [out]
     for i in range(steps):
         eng.rate_limit_batch_slots(d_batches[(it0 + i) % len(d_batches)], registered=True, quantity=1,
-                                   now_ns=now_of(now0, it0 + i, nows), want=("allowed",), out=out, inputs_ready=piped)
+                                   now_ns=now_of(now0, it0 + i, nows), want=("allowed",), out=ring[(it0 + i) % len(ring)],
+                                   inputs_ready=piped, outputs_idle=piped and len(ring) > 1)
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile_enable(False)
@@ -248,7 +257,7 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
     host_batches = make_batches(stream, a.keys, a.batch, min(nb, 64), seed_shift=seed_shift)
     d_batches = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in host_batches]
     nows = make_nows(dev, a.batch, min(nb + 2 * a.steps, 32), W.T0_NS) if general else None
-    out = t.BatchResult()
+    out = [t.BatchResult() for _ in range(OUT_RING)]
     cnt_view = gathered = None
     if dist is not None:
         from throttlecrab_amd.sharded import device_counter_view

@@ -113,6 +113,12 @@ typedef struct tc_config {
                                      * store per request; for consumers that walk all results anyway (a reply
                                      * fan-out).  Without the flag row i belongs to request i, as everywhere else. */
 
+#define TC_B_OUTPUTS_IDLE 0x40u      /* with TC_B_INPUTS_READY: nothing enqueued before this call reads or writes the call's
+                                     * output arrays (every batch in flight has arrays of its own, as a consumer that
+                                     * reads results later needs anyway): the engine may initialise them on an internal
+                                     * stream ahead of the evaluation.  Decisions-only batches then cost one store per
+                                     * MINORITY decision instead of one per request.  Results are unchanged. */
+
 /* One batch of requests = the argument list of RateLimiter::rate_limit
  * (rate_limiter.rs:102-110), columnar.  A NULL input column means "use the
  * scalar of the same name for every request". */

@@ -41,6 +41,10 @@ def check_step(name, i, st, got):
         assert reset_ns // 10**9 == e["reset_after_s"], where
     if "retry_after_s" in e:
         assert retry_ns // 10**9 == e["retry_after_s"], where
+    if "reset_after_ns" in e:
+        assert reset_ns == e["reset_after_ns"], f"{where}: reset_after {reset_ns} ns, want {e['reset_after_ns']}"
+    if "retry_after_ns" in e:
+        assert retry_ns == e["retry_after_ns"], f"{where}: retry_after {retry_ns} ns, want {e['retry_after_ns']}"
 
 
 def replay_scenario(sc, limiter):
@@ -56,10 +60,27 @@ def replay_scenario(sc, limiter):
     return results
 
 
+def _sweep(store, now):
+    """AdaptiveStore::cleanup at `now`, whatever the store under test calls it"""
+    for name in ("sweep_expired", "force_cleanup", "cleanup", "sweep"):
+        if hasattr(store, name):
+            return getattr(store, name)(now)
+    raise AssertionError("store has no cleanup entry point")
+
+
+def _live(store):
+    if hasattr(store, "live_count"):
+        return store.live_count()
+    if hasattr(store, "counters"):  # the engine: its live-slot counter is refreshed by a sweep (at time 0 nothing expires)
+        store.sweep_expired(0)
+        return store.counters()["live_slots"]
+    return len(store)
+
+
 def replay_store_contract(case, store, t0):
     for op in case["ops"]:
         kind = op[0]
-        key = op[1].encode("utf-8")
+        key = op[1].encode("utf-8") if isinstance(op[1], str) else None
         if kind == "set_nx":
             _, _, val, ttl, t, exp = op
             assert store.set_if_not_exists_with_ttl(key, val, ttl, t0 + t) == exp, (case["name"], op[:2])
@@ -69,5 +90,10 @@ def replay_store_contract(case, store, t0):
         elif kind == "cas":
             _, _, old, new, ttl, t, exp = op
             assert store.compare_and_swap_with_ttl(key, old, new, ttl, t0 + t) == exp, (case["name"], op[:2])
+        elif kind == "sweep":
+            _sweep(store, t0 + op[1])
+        elif kind == "len":
+            n = _live(store)
+            assert op[1] <= n <= op[2], (case["name"], op, n)
         else:
             raise AssertionError(kind)

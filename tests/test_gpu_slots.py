@@ -84,7 +84,7 @@ def test_reference_known_answers(sc):
 @pytest.mark.parametrize("case", [c for c in KAT["store_contract"] if c["name"] not in ("special_keys", "many_keys")],
                          ids=lambda c: c["name"])
 def test_store_contract(case):
-    eng = _engine(64, 64)
+    eng = _engine(2048, 64)
 
     class S:
         def __init__(self):
@@ -101,6 +101,13 @@ def test_store_contract(case):
 
         def compare_and_swap_with_ttl(self, key, old, new, ttl, now):
             return eng.compare_and_swap_with_ttl(self._k(key), old, new, ttl, now)
+
+        def sweep_expired(self, now):  # AdaptiveStore::cleanup (cleanup_test.rs cases)
+            return eng.sweep_expired(now)
+
+        def live_count(self):
+            eng.sweep_expired(0)  # (refreshes the live-slot counter; nothing expires at time 0)
+            return eng.counters()["live_slots"]
 
     kat.replay_store_contract(case, S(), T0)
     eng.close()

@@ -23,6 +23,9 @@ constexpr int BLOCK = 256;
 constexpr uint32_t F_REGISTERED = 1u;    // Params.flags: per-slot registered rate plan
 constexpr uint32_t F_UNIFORM_CLASS = 2u; // every slot carries plan `uniform_class`: skip the rate_id[] read
 constexpr uint32_t F_FIXED = 4u;         // TC_CFG_FIXED_PARAMS engine: 8-byte TAT column (tat8), timestamps < 2^62
+constexpr uint32_t F_PREFILL0 = 16u;     // TC_B_OUTPUTS_IDLE batch whose `allowed` bytes were all set to 0 ahead of the evaluation
+constexpr uint32_t F_PREFILL1 = 32u;     // ... to 1: the evaluation only stores the decisions that differ from the fill
+constexpr uint32_t F_DEBUG_NOSTORE = 8u; // measurement only (TCGPU_DEBUG_NO_DECISION_STORE): the lean kernel skips its decision bytes
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
 constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
 
@@ -145,6 +148,20 @@ __device__ __forceinline__ bool write_out(const Params& p, uint32_t i, const Req
     return ok && d.allowed;
 }
 
+// LEAN batches ask for the decision bytes only (no status / limit / result columns, request order): the other
+// output pointers are then not even looked at, which keeps the kernel's scalar registers under the 80 that eight
+// 256-thread blocks per CU need (MI355X_MICROARCH.md, residency).
+template <bool LEAN>
+__device__ __forceinline__ bool put_out(const Params& p, uint32_t i, const Req& r, const Decision& d) {
+    if (LEAN) {
+        const bool a = r.status == tc::ST_OK && d.allowed;
+        // (prefilled batches: the byte is already there unless this decision is the batch's minority one)
+        if (!(p.flags & (a ? (F_PREFILL1 | F_DEBUG_NOSTORE) : (F_PREFILL0 | F_DEBUG_NOSTORE)))) p.allowed[i] = a ? 1 : 0;
+        return a;
+    }
+    return write_out(p, i, r, d);
+}
+
 // The resident state of `slot` under either layout.  TC_CFG_FIXED_PARAMS engines keep one TAT per key
 // (p.tat8, p.cells == nullptr; tc::fixed_cell rebuilds the expiry from the key's dvt); the raw load does
 // not need the rate yet, so it can be issued before the plan is known.
@@ -181,8 +198,10 @@ constexpr int NSHARD = 256;
 constexpr int SHARD_WORDS = 4; // allowed, denied, errors, pad
 
 // sum three per-thread counts over the block, one atomic each per block
+// `hint` (one designated block per launch, else nullptr): a pinned host word that receives "most of this block's decisions
+// were allowed" -- the host reads it, without ever waiting, to choose the fill value of later TC_B_OUTPUTS_IDLE batches
 template <int NT = BLOCK>
-__device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c, unsigned long long* counters) {
+__device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c, unsigned long long* counters, uint32_t* hint = nullptr) {
     __shared__ uint32_t s_cnt[3][NT / 64];
     for (int off = 32; off > 0; off >>= 1) {
         a += __shfl_down(a, off, 64);
@@ -203,6 +222,14 @@ __device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c,
             unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + (blockIdx.x % NSHARD) * SHARD_WORDS;
             atomicAdd(&shard[threadIdx.x], (unsigned long long)t);
         }
+    }
+    if (hint != nullptr && threadIdx.x == 64) {
+        uint32_t ta = 0, tb = 0;
+        for (int w = 0; w < NT / 64; ++w) {
+            ta += s_cnt[0][w];
+            tb += s_cnt[1][w];
+        }
+        __hip_atomic_store(hint, ta >= tb ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -447,11 +474,14 @@ struct __attribute__((aligned(16))) PendEntry {
 //     16-byte cells cost, not by latency), record outputs gain 15 % at ITEMS = 4 in order, the Zipf stream
 //     7 % at ITEMS = 2 when overlapped with the next batch's sort.
 // ---------------------------------------------------------------------------
-template <bool FULL, bool DIRECT, int ITEMS, bool FIXED>
-__global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted,
-                                                             PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
-                                                             uint32_t* __restrict__ loaded, uint32_t seq,
-                                                             const uint32_t* __restrict__ gate, uint32_t gate_min) {
+#ifndef TC_EVAL_LEAN_WAVES
+#define TC_EVAL_LEAN_WAVES 8 // waves per SIMD the LEAN variants are compiled for (= 256-thread blocks per CU)
+#endif
+template <bool FULL, bool DIRECT, int ITEMS, bool FIXED, bool LEAN>
+__device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t* __restrict__ sorted,
+                                                 PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
+                                                 uint32_t* __restrict__ loaded, uint32_t seq,
+                                                 const uint32_t* __restrict__ gate, uint32_t gate_min, uint32_t* hint = nullptr) {
     if (gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min) return; // this batch took the bucket path (bucket_path.hpp)
     const uint32_t n = p.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -561,8 +591,8 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
         const uint32_t k = kk[j];
         const bool valid = k < n;
         const uint32_t slot = (uint32_t)(me[j] >> 32), idx = (uint32_t)me[j];
-        const uint32_t orow = p.order ? k : idx;
-        if (p.order && valid) p.order[k] = idx;
+        const uint32_t orow = (!LEAN && p.order) ? k : idx;
+        if (!LEAN && p.order && valid) p.order[k] = idx;
         writer[j] = false;
         denied_here[j] = false;
         wcell[j].tat = 0;
@@ -576,7 +606,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
             d.remaining = d.reset_after = d.retry_after = 0;
             if (rq.status != tc::ST_OK) {
                 ne += 1;
-                write_out(p, orow, rq, d);
+                put_out<LEAN>(p, orow, rq, d);
             } else {
                 Cell c = FIXED ? tc::fixed_cell(cell[j].tat, rq.dvt) : cell[j];
                 const Decision d0 = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
@@ -584,10 +614,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                     // request 0 denied => state untouched => every request of the run equals request 0
                     nd += 1;
                     denied_here[j] = true;
-                    bit = write_out(p, orow, rq, d0);
+                    bit = put_out<LEAN>(p, orow, rq, d0);
                 } else if (head[j] && is_last[j]) {
                     na += 1; // a key requested once in this batch: no closed form, no 64-bit division
-                    bit = write_out(p, orow, rq, d0);
+                    bit = put_out<LEAN>(p, orow, rq, d0);
                     writer[j] = true;
                     wcell[j] = c;
                 } else {
@@ -620,7 +650,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                     }
                     if (r == 0) {
                         na += 1;
-                        bit = write_out(p, orow, rq, d0);
+                        bit = put_out<LEAN>(p, orow, rq, d0);
                         if (regular || is_last[j]) {
                             writer[j] = owner || is_last[j];
                             wcell[j] = c;
@@ -634,7 +664,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                                 const Decision dj = tc::gcra_step<FULL>(c, rq.ei, rq.dvt, rq.q, rq.now);
                                 na += dj.allowed;
                                 wd += !dj.allowed;
-                                write_out(p, p.order ? q : (uint32_t)nx, rq, dj);
+                                put_out<LEAN>(p, (!LEAN && p.order) ? q : (uint32_t)nx, rq, dj);
                             }
                             nd += wd;
                             if (p.denied && wd) atomicAdd(&p.denied[slot], wd); // the whole run's denials sit in this lane
@@ -645,7 +675,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                         na += ok_r;
                         nd += !ok_r;
                         denied_here[j] = !ok_r;
-                        bit = write_out(p, orow, rq, d);
+                        bit = put_out<LEAN>(p, orow, rq, d);
                         writer[j] = owner;
                         wcell[j] = v;
                     }
@@ -653,7 +683,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
                 }
             }
         }
-        if (DIRECT && p.row_bits) { // (wave-uniform; a wave's j-th items are 64 consecutive rows)
+        if (DIRECT && !LEAN && p.row_bits) { // (wave-uniform; a wave's j-th items are 64 consecutive rows)
             const unsigned long long bm = __ballot(bit);
             if (lane == 0 && valid) p.row_bits[k >> 6] = bm;
         }
@@ -710,7 +740,23 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
         }
         wave_denied_add(p, slot, denied_here[j]);
     }
-    block_count3(na, nd, ne, p.counters);
+    block_count3(na, nd, ne, p.counters, (LEAN && blockIdx.x == gridDim.x / 2) ? hint : nullptr);
+}
+
+template <bool FULL, bool DIRECT, int ITEMS, bool FIXED>
+__global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted, PendEntry* __restrict__ pend,
+                                                       uint32_t* __restrict__ pend_count, uint32_t* __restrict__ loaded, uint32_t seq,
+                                                       const uint32_t* __restrict__ gate, uint32_t gate_min) {
+    eval_sorted_body<FULL, DIRECT, ITEMS, FIXED, false>(p, sorted, pend, pend_count, loaded, seq, gate, gate_min);
+}
+// decisions only, direct stores, only the `allowed` byte column asked for: at most 80 scalar and 64 vector registers,
+// so that EIGHT blocks fit a CU (k_eval_sorted's 106 SGPRs admit six) -- the kernel waits on random memory, and what
+// hides that is resident waves
+template <int ITEMS, bool FIXED>
+__global__ __launch_bounds__(BLOCK, TC_EVAL_LEAN_WAVES) __attribute__((amdgpu_num_sgpr(80))) void k_eval_sorted_lean(
+    Params p, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ loaded, uint32_t seq, const uint32_t* __restrict__ gate,
+    uint32_t gate_min, uint32_t* hint) {
+    eval_sorted_body<false, true, ITEMS, FIXED, true>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint);
 }
 
 // ---------------------------------------------------------------------------

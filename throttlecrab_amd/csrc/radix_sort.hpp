@@ -98,11 +98,25 @@ __device__ __forceinline__ bool gated_off(const uint32_t* __restrict__ gate, uin
     return gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min;
 }
 
+// `fill` (TC_B_OUTPUTS_IDLE batches): the batch's decision bytes, set to fill_value here, ahead of the evaluation,
+// which then only stores the decisions that differ (16-byte stores; the tail bytewise)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
                                                   int passes, Workspace ws, uint32_t tiles, const uint32_t* __restrict__ gate,
-                                                  uint32_t gate_min) {
+                                                  uint32_t gate_min, uint8_t* __restrict__ fill, uint32_t fill_value) {
     __shared__ uint32_t s_h[MAX_PASSES][RADIX];
+    if (fill != nullptr) {
+        const uint32_t v4 = fill_value * 0x01010101u;
+        const uint32_t head = (uint32_t)((16u - ((uintptr_t)fill & 15u)) & 15u); // bytes before the first aligned 16
+        const uint32_t h = head < n ? head : n;
+        uint4* f16 = reinterpret_cast<uint4*>(fill + h);
+        const uint32_t n16 = (n - h) / 16u;
+        for (uint32_t i = blockIdx.x * NT + threadIdx.x; i < n16; i += gridDim.x * NT) f16[i] = make_uint4(v4, v4, v4, v4);
+        if (blockIdx.x == 0) {
+            for (uint32_t i = threadIdx.x; i < h; i += NT) fill[i] = (uint8_t)fill_value;
+            for (uint32_t i = h + n16 * 16u + threadIdx.x; i < n; i += NT) fill[i] = (uint8_t)fill_value;
+        }
+    }
     if (gated_off(gate, gate_min)) {
         if (blockIdx.x == 0)
             for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) ws.hist_next[i] = 0;

@@ -18,6 +18,7 @@
 // evaluated on the engine's stream.  HBM-transaction-bound integer work; MFMA is not used (no
 // dense contraction).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -129,6 +130,7 @@ struct tc_engine {
     uint32_t n_aux = 0;
     uint32_t next_aux = 0;
     uint32_t n_aux_want = 0;             // configured number of grouping streams
+    int sort_items_piped = SORT_ITEMS_PIPED; // requests per thread of a sort tile, pipelined batches (TCGPU_SORT_ITEMS_PIPED = 8 | 16 | 32)
     hipStream_t side_for = nullptr;      // main stream the side streams were probed against
     bool side_ready = false;
     int aux_priority = 0;
@@ -140,6 +142,12 @@ struct tc_engine {
     uint32_t chain_seq = 0;
     uint32_t* loaded = nullptr; // k_eval_sorted<DIRECT>: per-wave "cells read" flags
     int eval_items = 0;         // sorted positions per lane in k_eval_sorted (0: chosen per batch)
+    bool eval_lean = true;      // k_eval_sorted_lean for decisions-only batches (TCGPU_EVAL_LEAN=0: the general kernel)
+    bool stop_events = true;    // events ride on kernels' completion signals instead of marker packets (TCGPU_STOP_EVENTS=0: hipEventRecord)
+    bool prefill_on = true;     // TC_B_OUTPUTS_IDLE batches: decision bytes preset on the grouping stream (TCGPU_PREFILL=0: off)
+    uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting
+    uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
+    bool debug_nostore = false; // TCGPU_DEBUG_NO_DECISION_STORE=1: MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)
     uint32_t loaded_seq = 0;
     // bounds over the registered rate plans (for all_runs_regular)
     int64_t cls_min_ei = INT64_MAX, cls_max_ei = 0, cls_min_dvt = INT64_MAX, cls_max_dvt = 0;
@@ -264,6 +272,15 @@ static hipError_t copy_async(tc_engine* e, void* dst, const void* src, size_t by
         }                                                                                            \
     } while (0)
 
+// A kernel launch whose completion is `stop` (hipExtLaunchKernelGGL: the event rides on the dispatch packet's own
+// completion signal -- no marker packet behind the kernel, which the next kernel of the stream would wait for), or a
+// plain launch when stop == nullptr.
+#define TC_LAUNCH(stop, kernel, grid, block, lds, stream, ...)                                               \
+    do {                                                                                                     \
+        if (stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop, 0, __VA_ARGS__);    \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                              \
+    } while (0)
+
 static int fail(tc_engine* e, int code, const char* msg) {
     if (e) e->err = msg;
     return code;
@@ -300,11 +317,26 @@ static int engine_alloc(tc_engine* e) {
     const size_t words = sort_ws_words(e->sort_max_tiles);
     e->n_aux = (e->cfg_flags & TC_CFG_KEY_MODE) ? AUX_KEY_MODE : AUX_SLOT_MODE;
     if (const char* d = getenv("TCGPU_AUX_STREAMS")) e->n_aux = (uint32_t)std::min(std::max(atoi(d), 1), AUX_MAX);
-    e->depth = e->n_aux + 1;
+    e->depth = e->n_aux + 3; // scratch sets: the grouping streams run up to two batches further ahead of the evaluation (47.3 -> 45-47 us)
     if (const char* d = getenv("TCGPU_PIPE_DEPTH")) e->depth = (uint32_t)std::min(std::max(atoi(d), 1), PIPE_DEPTH_MAX);
     int prio_lo = 0, prio_hi = 0;
     TC_HIP(e, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
     if (const char* d = getenv("TCGPU_EVAL_ITEMS")) e->eval_items = atoi(d);
+    if (const char* d = getenv("TCGPU_EVAL_LEAN")) e->eval_lean = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_STOP_EVENTS")) e->stop_events = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_DEBUG_NO_DECISION_STORE")) e->debug_nostore = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
+    {
+        TC_HIP(e, hipHostMalloc((void**)&e->fill_hint_host, 64, hipHostMallocDefault));
+        *e->fill_hint_host = 1u;
+        void* dv = nullptr;
+        TC_HIP(e, hipHostGetDevicePointer(&dv, e->fill_hint_host, 0));
+        e->fill_hint_dev = (uint32_t*)dv;
+    }
+    if (const char* d = getenv("TCGPU_SORT_ITEMS_PIPED")) {
+        const int v = atoi(d);
+        if (v == 8 || v == 16 || v == 32) e->sort_items_piped = v;
+    }
     if (const char* d = getenv("TCGPU_NO_SMALL_BATCH")) e->small_off = atoi(d) != 0;
     const char* pe = getenv("TCGPU_AUX_PRIORITY");
     const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
@@ -635,6 +667,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         (void)hipStreamDestroy(e->key_stream);
     }
     if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
+    if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
     if (e->k_done) (void)hipEventDestroy(e->k_done);
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
@@ -868,38 +901,39 @@ static int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, boo
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
 // returns the buffer holding the result
 static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
-                                    bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0) {
+                                    bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
+                                    uint8_t* fill = nullptr, uint32_t fill_value = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
     const int passes = (bits + 7) / 8;
-    const uint32_t tile = rs::THREADS * (piped ? SORT_ITEMS_PIPED : SORT_ITEMS);
+    const int items = piped ? e->sort_items_piped : SORT_ITEMS;
+    const uint32_t tile = rs::THREADS * (uint32_t)items;
     const uint32_t tiles = (n + tile - 1) / tile;
     rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
     ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
     ss.hist_parity ^= 1u;
     prof_begin(e, TC_STAGE_PREP, s);
-    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min);
+    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value);
     prof_end(e, s);
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
     const uint64_t* in = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
         prof_begin(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
+        hipEvent_t stop = (p + 1 == passes && !e->prof_on) ? stop_last : nullptr;
+#define TC_PASS(IT, FI) \
+    TC_LAUNCH(stop, (rs::k_onesweep<IT, FI>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
+              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min)
         if (p == 0) {
-            if (piped)
-                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min);
-            else
-                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot,
-                                   (const uint64_t*)nullptr, out, n, cap, p, ws, gate, gate_min);
+            if (items == 32) TC_PASS(32, true);
+            else if (items == 16) TC_PASS(16, true);
+            else TC_PASS(8, true);
         } else {
-            if (piped)
-                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS_PIPED, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
-                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min);
-            else
-                hipLaunchKernelGGL((rs::k_onesweep<SORT_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, s,
-                                   (const uint32_t*)nullptr, in, out, n, cap, p, ws, gate, gate_min);
+            if (items == 32) TC_PASS(32, false);
+            else if (items == 16) TC_PASS(16, false);
+            else TC_PASS(8, false);
         }
+#undef TC_PASS
         prof_end(e, s);
         in = out;
     }
@@ -942,28 +976,42 @@ static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params
 // k_eval_sorted<.., ITEMS>: 2 positions per lane when the batch overlaps with its neighbours' sorts,
 // 4 when it runs alone (measured; 8 is slower everywhere; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
 template <int ITEMS, bool FIXED>
-static void launch_eval_items(tc_engine* e, bool full, bool direct, uint32_t n, hipStream_t s, const Params& p, const uint64_t* sorted,
-                              uint32_t seq, const uint32_t* gate, uint32_t gate_min) {
+static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, uint32_t n, hipStream_t s, const Params& p, const uint64_t* sorted,
+                              uint32_t seq, const uint32_t* gate, uint32_t gate_min, hipEvent_t stop) {
+    (void)lean;
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
-    if (full && direct) hipLaunchKernelGGL((k_eval_sorted<true, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else if (full) hipLaunchKernelGGL((k_eval_sorted<true, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else if (direct) hipLaunchKernelGGL((k_eval_sorted<false, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else hipLaunchKernelGGL((k_eval_sorted<false, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    if (lean) {
+        if constexpr (ITEMS <= 2) {
+            TC_LAUNCH(stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
+            return;
+        }
+    }
+    if (full && direct) TC_LAUNCH(stop, (k_eval_sorted<true, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (full) TC_LAUNCH(stop, (k_eval_sorted<true, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (direct) TC_LAUNCH(stop, (k_eval_sorted<false, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else TC_LAUNCH(stop, (k_eval_sorted<false, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+}
+static int eval_items_of(const tc_engine* e, bool piped) { return e->eval_items ? e->eval_items : (piped ? 2 : 4); }
+// LEAN: decisions only, direct stores, nothing asked for but the `allowed` bytes in request order (k_eval_sorted_lean)
+static bool lean_applies(const tc_engine* e, bool full, bool direct, bool piped, const Params& p) {
+    return e->eval_lean && !full && direct && eval_items_of(e, piped) <= 2 && p.allowed && !p.status && !p.limit && !p.order && !p.row_bits;
 }
 static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped, uint32_t n, hipStream_t s, const Params& p,
-                               const uint64_t* sorted, uint32_t seq, const uint32_t* gate = nullptr, uint32_t gate_min = 0) {
-    const int items = e->eval_items ? e->eval_items : (piped ? 2 : 4);
+                               const uint64_t* sorted, uint32_t seq, const uint32_t* gate = nullptr, uint32_t gate_min = 0,
+                               hipEvent_t stop = nullptr) {
+    const int items = eval_items_of(e, piped);
+    const bool lean = lean_applies(e, full, direct, piped, p);
     if (e->fixed) {
         switch (items) {
-        case 1: launch_eval_items<1, true>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
-        case 2: launch_eval_items<2, true>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
-        default: launch_eval_items<4, true>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+        case 1: launch_eval_items<1, true>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+        case 2: launch_eval_items<2, true>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+        default: launch_eval_items<4, true>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
         }
     }
     switch (items) {
-    case 1: launch_eval_items<1, false>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
-    case 2: launch_eval_items<2, false>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
-    default: launch_eval_items<4, false>(e, full, direct, n, s, p, sorted, seq, gate, gate_min); return;
+    case 1: launch_eval_items<1, false>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+    case 2: launch_eval_items<2, false>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+    default: launch_eval_items<4, false>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
     }
 }
 
@@ -1061,6 +1109,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
     p.cells = e->cells;
     p.tat8 = e->tat8;
     if (e->fixed) p.flags |= F_FIXED;
+    if (e->debug_nostore) p.flags |= F_DEBUG_NOSTORE;
     p.rate_id = e->rate_id;
     p.classes = e->classes;
     p.uniform_class = e->uniform_id;
@@ -1155,8 +1204,20 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
             if (bucketed) bucket_partition(e, ss, ax, d_slot, n);
-            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew);
-            TC_HIP(e, hipEventRecord(ss.sorted, ax));
+            const bool ride = e->stop_events && !e->prof_on; // `sorted` rides on the last pass's own completion signal
+            // TC_B_OUTPUTS_IDLE: nothing enqueued earlier touches this call's `allowed` bytes, so they are preset here, on
+            // the grouping stream, to what most decisions of a recent batch were, and the evaluation only stores the
+            // others -- 1 Mi one-byte stores scattered over the batch were 6 of its 53 us
+            uint8_t* fill = nullptr;
+            uint32_t fill_value = 0;
+            if ((b.flags & TC_B_OUTPUTS_IDLE) && e->prefill_on && !hin && !bucketed && uniform && lean_applies(e, full, direct, true, p) &&
+                p.allowed == b.allowed) {
+                fill = b.allowed;
+                fill_value = *(volatile uint32_t*)e->fill_hint_host & 1u;
+                p.flags |= fill_value ? F_PREFILL1 : F_PREFILL0;
+            }
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value);
+            if (!ride) TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
             ss.grouped_aside = true;
         } else {
@@ -1169,13 +1230,16 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         }
         if (bucketed) bucket_eval(e, ss, s, p, full);
         prof_begin(e, TC_STAGE_EVAL, s);
+        bool consumed_rides = false;
         if (uniform) {
             uint32_t seq = 0u;
             if (direct) {
                 if (++e->loaded_seq == 0u) e->loaded_seq = 1u;
                 seq = e->loaded_seq;
             }
-            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew);
+            // (direct: the evaluation is the last reader of the set -- `consumed` can ride on its completion signal)
+            consumed_rides = direct && e->stop_events && !e->prof_on;
+            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr);
             prof_end(e, s);
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
@@ -1190,7 +1254,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         }
         e->wait_before_sort = nullptr;
         // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream
-        TC_HIP(e, hipEventRecord(ss.consumed, s));
+        if (!consumed_rides) TC_HIP(e, hipEventRecord(ss.consumed, s));
         ss.in_use = true;
     }
     if (b.allowed_bits && !bits_in_kernel) {

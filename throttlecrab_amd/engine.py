@@ -172,7 +172,7 @@ class Engine:
         setattr(batch, name, arr.ctypes.data)
 
     def _prepare(self, n, dev, max_burst, count_per_period, period, quantity, now_ns, registered, unique,
-                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False, async_=False):
+                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False, async_=False, outputs_idle=False):
         keep = []
         b = L.tc_batch()
         b.struct_size = C.sizeof(L.tc_batch)
@@ -190,6 +190,10 @@ class Engine:
             flags |= L.TC_B_INPUTS_READY
         if grouped:
             flags |= L.TC_B_GROUPED_OUTPUT
+        if outputs_idle:
+            if not inputs_ready:
+                raise ValueError("outputs_idle goes with inputs_ready")
+            flags |= L.TC_B_OUTPUTS_IDLE
         if async_:
             if dev:
                 raise ValueError("async_ applies to host-array batches (CUDA-tensor batches are asynchronous anyway)")
@@ -234,7 +238,7 @@ class Engine:
     def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
                                now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
                                out: Optional[BatchResult] = None, inputs_ready=False, grouped=False,
-                               async_=False) -> BatchResult:
+                               async_=False, outputs_idle=False) -> BatchResult:
         """rate_limit_batch over pre-resolved slots (sequential semantics, index order).
         async_=True (TC_B_ASYNC, host arrays): only enqueue -- transfers and evaluation overlap with
         other batches; `slots`, per-request columns and the arrays of `out` must be uint32 / int64 /
@@ -243,7 +247,9 @@ class Engine:
         res.order[k] is the request index of row k.
         inputs_ready=True (TC_B_INPUTS_READY): the CUDA `slots` tensor is already complete and
         stays untouched until the results are ready, so the engine may group this batch on its
-        auxiliary stream while earlier batches are still being evaluated."""
+        auxiliary stream while earlier batches are still being evaluated.
+        outputs_idle=True (TC_B_OUTPUTS_IDLE, with inputs_ready): nothing enqueued earlier reads or writes the
+        arrays of `out` (every batch in flight has its own), so the engine may initialise them early."""
         dev = _is_torch(slots)
         keep = []
         if dev:
@@ -259,7 +265,7 @@ class Engine:
             n = sl.size
             sp = sl.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
-                                   unique, want, out, inputs_ready, grouped, async_)
+                                   unique, want, out, inputs_ready, grouped, async_, outputs_idle)
         b.slot = sp
         if n:
             self._check(self._lib.tc_rate_limit_batch_slots(self._h, C.byref(b)))

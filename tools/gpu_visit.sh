@@ -1,0 +1,24 @@
+#!/bin/bash
+# One GPU-box visit of round 3 (run from the repo root): probe, parity tests, knob A/B, the bench line, profiles.
+# usage: bash tools/gpu_visit.sh <tag> [steps...]   steps: tests quick ab bench prof timeline
+set -u
+TAG=${1:-r03_v1}; shift
+STEPS=${@:-tests ab bench prof}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
+export TC_GIT_SHA=$(cat $R/.git_sha 2>/dev/null || echo unknown)
+for S in $STEPS; do
+  case $S in
+    tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "tests rc=$?"; tail -5 $O/pytest_gpu.log ;;
+    quick) timeout 600 python -m pytest tests/test_gpu_prefill.py tests/test_gpu_fixed.py tests/test_gpu_slots.py -m gpu -x -q > $O/pytest_quick.log 2>&1; echo "quick rc=$?"; tail -15 $O/pytest_quick.log ;;
+    ab) timeout 600 python tools/ab_step.py 100 > $O/ab_step.txt 2>&1; echo "ab rc=$?"; cat $O/ab_step.txt ;;
+    bench) TC_BENCH_VERBOSE=1 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_stdout.txt 2> $O/bench_stderr.txt; echo "bench rc=$?"
+           tail -c 4200 $O/bench_stdout.txt; echo; wc -c $O/bench_stdout.txt; cp gpurun_out/bench_detail.json $O/ 2>/dev/null ;;
+    prof) bash tools/gpu_round.sh $TAG uniform_fixed zipf_fixed general_uniform_fixed general_zipf_fixed ;;
+    timeline) cd /tmp; export TMPDIR=/tmp
+           for WL in uniform zipf; do
+             timeout 240 rocprofv3 --kernel-trace -d $O/tl_$WL -o t -- python $R/bench.py --profile-run --steps 40 --warmup 5 --layout fixed --workload $WL > $O/tl_$WL.log 2>&1
+             python $R/tools/timeline.py $O/tl_$WL > $O/timeline_$WL.txt 2>&1; tail -30 $O/timeline_$WL.txt; rm -rf $O/tl_$WL
+           done; cd $R ;;
+    *) echo "unknown step $S" ;;
+  esac
+done

@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
     for (int it = 0; it < iters + 3; ++it) {
         const rs::Workspace ws = rs::carve(wsmem, parity, tiles); parity ^= 1;
         CK(hipEventRecord(ev[0]));
-        hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, 0, d_slot, n, cap, passes, ws, tiles, nullptr, 0u);
+        hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, 0, d_slot, n, cap, passes, ws, tiles, nullptr, 0u, (uint8_t*)nullptr, 0u);
         CK(hipEventRecord(ev[1]));
         hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, 0, d_slot, (const uint64_t*)nullptr, a, n, cap, 0, ws, nullptr, 0u);
         CK(hipEventRecord(ev[2]));
