@@ -65,7 +65,12 @@ enum {
     TC_E_BATCH_TOO_LARGE = -4,
     TC_E_TABLE_FULL = -5,     /* string mode: no free slot / arena space for a new key */
     TC_E_NO_DEVICE = -6,
-    TC_E_UNSUPPORTED = -7
+    TC_E_UNSUPPORTED = -7,
+    TC_E_INVARIANT = -8       /* a kernel flagged a broken internal invariant (a wait on another workgroup gave up after
+                               * 2 s, a closed form met a state it was proven not to meet): results and resident state
+                               * since the last call that returned TC_E_OK from tc_synchronize() are UNDEFINED.  Sticky:
+                               * every later call on the engine returns it; destroy the engine (reload a snapshot).
+                               * Never seen unless there is a bug or the device lost forward progress. */
 };
 
 /* tc_config.flags */
@@ -368,6 +373,10 @@ int tc_selfcheck(tc_engine* e, uint64_t* violations);
 /* Test hook (error paths): the nth host <-> device staging copy from now fails with TC_E_HIP instead of being
  * issued; 0 disarms.  Not for production use. */
 int tc_debug_fail_copy(tc_engine* e, uint32_t nth);
+/* Test hook (watchdog): the next uniform batch's evaluation withholds the "row 0 has read its cells" announcement,
+ * so a key whose requests span more than one row makes its owner wait until the watchdog gives up (2 s) and the
+ * engine is poisoned (TC_E_INVARIANT).  Not for production use. */
+int tc_debug_break_wait(tc_engine* e, uint32_t on);
 
 /* Checkpoint / restore of everything resident (state cells, rate plans, denial counters, in
  * string mode the key table, plus the counter block).  The reference keeps its state in memory

@@ -20,6 +20,7 @@ pub const TC_E_BATCH_TOO_LARGE: c_int = -4;
 pub const TC_E_TABLE_FULL: c_int = -5;
 pub const TC_E_NO_DEVICE: c_int = -6;
 pub const TC_E_UNSUPPORTED: c_int = -7;
+pub const TC_E_INVARIANT: c_int = -8;
 
 pub const TC_CFG_KEY_MODE: u32 = 0x1;
 pub const TC_CFG_TRACK_DENIED: u32 = 0x2;
@@ -199,6 +200,7 @@ extern "C" {
     pub fn tc_profile_read(e: *mut tc_engine, total_ms: *mut f64, calls: *mut u64) -> c_int;
     pub fn tc_selfcheck(e: *mut tc_engine, violations: *mut u64) -> c_int;
     pub fn tc_debug_fail_copy(e: *mut tc_engine, nth: u32) -> c_int;
+    pub fn tc_debug_break_wait(e: *mut tc_engine, on: u32) -> c_int;
     pub fn tc_snapshot_save(e: *mut tc_engine, path: *const c_char) -> c_int;
     pub fn tc_snapshot_load(e: *mut tc_engine, path: *const c_char) -> c_int;
 }

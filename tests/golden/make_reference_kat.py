@@ -129,6 +129,14 @@ scenario("remaining_count_all_stores(AdaptiveStore)", f"{CORE}:299-347",
          + [step("test_key", 3, 6, 60, 1, allowed=False, remaining=0),
             step("test_key", 3, 6, 60, 1, t=10 * S, allowed=True, remaining=0)])
 
+# the same sequence is asserted for every store type (test_all_stores!): the engine claims decision parity with all three
+# (cleanup policies differ, decisions do not: adaptive_cleanup.rs:246-278 / periodic.rs:175-209 / probabilistic.rs:157-183)
+for _store in ("PeriodicStore", "ProbabilisticStore"):
+    scenario(f"remaining_count_all_stores({_store})", f"{CORE}:299-347",
+             [step("test_key", 3, 6, 60, 1, allowed=True, remaining=3 - i) for i in range(1, 4)]
+             + [step("test_key", 3, 6, 60, 1, allowed=False, remaining=0),
+                step("test_key", 3, 6, 60, 1, t=10 * S, allowed=True, remaining=0)])
+
 scenario("edge_cases_zero_remaining", f"{CORE}:350-412",
          [step("exact_timing", 2, 120, 60, 1, allowed=True, remaining=1),
           step("exact_timing", 2, 120, 60, 1, allowed=True, remaining=0),
@@ -156,13 +164,18 @@ for millis, _avail, rem in [(500, 1, 0), (1000, 2, 1), (1500, 3, 2), (2000, 4, 3
     _grad += [step(k, 5, 120, 60, 1, t=millis * MS, allowed=True, remaining=rem)]
 scenario("quantity_variations_and_replenishment", f"{CORE}:415-500", _grad)
 
-_cx = [step("partial_burst", 8, 240, 60, 6, allowed=True, remaining=2),
-       step("partial_burst", 8, 240, 60, 1, t=500 * MS, allowed=True, remaining=3),
-       step("partial_burst", 8, 240, 60, 1, t=1500 * MS, allowed=True, remaining=6)]
-_cx += [step("slow_replenish", 3, 6, 60, 1) for _ in range(3)]
-_cx += [step("slow_replenish", 3, 6, 60, 1, t=5 * S, allowed=False),
-        step("slow_replenish", 3, 6, 60, 1, t=10 * S, allowed=True, remaining=0),
-        step("slow_replenish", 3, 6, 60, 1, t=20 * S, allowed=True, remaining=0)]
+# (8, 240, 60): ei = 0.25e9, dvt = 1.75e9.  q6 fresh: new_tat = t0 - ei + 6 ei = t0 + 1.25e9: reset 1.25e9 + 1.75e9 = 3e9.
+# +0.5 s q1: new_tat = t0 + 1.5e9: reset (1.5e9 - 0.5e9) + 1.75e9 = 2.75e9.  +1.5 s q1: new_tat = t0 + 1.75e9: reset 0.25e9 + 1.75e9.
+_cx = [step("partial_burst", 8, 240, 60, 6, allowed=True, remaining=2, reset_after_ns=3000 * MS, retry_after_ns=0),
+       step("partial_burst", 8, 240, 60, 1, t=500 * MS, allowed=True, remaining=3, reset_after_ns=2750 * MS, retry_after_ns=0),
+       step("partial_burst", 8, 240, 60, 1, t=1500 * MS, allowed=True, remaining=6, reset_after_ns=2000 * MS, retry_after_ns=0)]
+# (3, 6, 60): ei = 10e9, dvt = 20e9.  Three at t0: new_tat = t0, t0 + 10e9, t0 + 20e9 (reset 20e9, 30e9, 40e9).
+# +5 s: new_tat = t0 + 30e9, allow_at = t0 + 10e9 > now: denied, retry 5e9, cur = t0 + 20e9: reset 15e9 + 20e9.
+# +10 s: allow_at = now: allowed, cur = t0 + 30e9: reset 20e9 + 20e9.  +20 s: new_tat = t0 + 40e9: reset 20e9 + 20e9.
+_cx += [step("slow_replenish", 3, 6, 60, 1, reset_after_ns=(20 + 10 * i) * S, retry_after_ns=0) for i in range(3)]
+_cx += [step("slow_replenish", 3, 6, 60, 1, t=5 * S, allowed=False, reset_after_ns=35 * S, retry_after_ns=5 * S),
+        step("slow_replenish", 3, 6, 60, 1, t=10 * S, allowed=True, remaining=0, reset_after_ns=40 * S, retry_after_ns=0),
+        step("slow_replenish", 3, 6, 60, 1, t=20 * S, allowed=True, remaining=0, reset_after_ns=40 * S, retry_after_ns=0)]
 _cx += [step("fractional_accumulation", 5, 100, 60, 1) for _ in range(5)]
 for millis, rem in [(600, 0), (1200, 1), (1800, 2), (2400, 3), (3000, 4)]:
     k = f"fractional_accumulation_{millis}"
@@ -175,9 +188,13 @@ scenario("quantity_edge_cases", f"{CORE}:604-655",
           step("neg_quantity", 10, 100, 60, -5, status="err"),
           step("large_quantity", 5, 100, 60, 10, allowed=False, remaining=5),
           step("exact_burst", 10, 100, 60, 10, allowed=True, remaining=0),
-          step("large_quantity_replenish", 20, 600, 60, 15, allowed=True, remaining=5),
-          step("large_quantity_replenish", 20, 600, 60, 12, t=1 * S, allowed=True, remaining=3),
-          step("large_quantity_replenish", 20, 600, 60, 5, t=1 * S, allowed=False, remaining=3)])
+          # (20, 600, 60): ei = 0.1e9, dvt = 1.9e9.  q15 fresh: new_tat = t0 + 1.4e9: reset 1.4e9 + 1.9e9.
+          # +1 s q12: new_tat = t0 + 2.6e9, allow_at = t0 + 0.7e9 <= now: allowed, reset 1.6e9 + 1.9e9.
+          # q5: new_tat = t0 + 3.1e9, allow_at = t0 + 1.2e9 > now: denied, retry 0.2e9, cur = t0 + 2.6e9: reset 3.5e9.
+          step("large_quantity_replenish", 20, 600, 60, 15, allowed=True, remaining=5, reset_after_ns=3300 * MS, retry_after_ns=0),
+          step("large_quantity_replenish", 20, 600, 60, 12, t=1 * S, allowed=True, remaining=3, reset_after_ns=3500 * MS, retry_after_ns=0),
+          step("large_quantity_replenish", 20, 600, 60, 5, t=1 * S, allowed=False, remaining=3, reset_after_ns=3500 * MS,
+               retry_after_ns=200 * MS)])
 
 scenario("rapid_time_changes", f"{CORE}:658-694",
          [step("time_jump", 3, 10, 60, 1, allowed=True),
@@ -190,6 +207,12 @@ scenario("rate_limiting_all_stores(AdaptiveStore)", f"{SUITE}:542-598",
          [step("test_key", 5, 10, 3600, 1, allowed=True, remaining=5 - i - 1) for i in range(5)]
          + [step("test_key", 5, 10, 3600, 1, allowed=False),
             step("test_key", 5, 10, 3600, 1, t=360 * S, allowed=True, remaining=0)])
+
+for _store in ("PeriodicStore", "ProbabilisticStore"):
+    scenario(f"rate_limiting_all_stores({_store})", f"{SUITE}:542-598",
+             [step("test_key", 5, 10, 3600, 1, allowed=True, remaining=5 - i - 1) for i in range(5)]
+             + [step("test_key", 5, 10, 3600, 1, allowed=False),
+                step("test_key", 5, 10, 3600, 1, t=360 * S, allowed=True, remaining=0)])
 
 # ---- redis_test.rs (process_command -> actor -> rate_limit; secs-truncated) ---
 # (10, 100, 60): ei = 0.6e9, dvt = 5.4e9.  q1 fresh: new_tat = t0: reset = dvt = 5.4e9 (5 s on the wire).
@@ -251,9 +274,18 @@ _rep += [step("ns_replenish_early", 5, 120, 60, 1, t=400 * MS, allowed=False, re
               retry_after_ns=100 * MS)]
 scenario("gradual_replenishment_ns_exact", f"{CORE}:444-500 (values by hand from rate_limiter.rs:151-238)", _rep)
 
+scenario("redis_mixed_commands", f"{REDIS}:422-473",
+         [step("mixed_key", 10, 100, 60, 1, allowed=True), step("mixed_key", 10, 100, 60, 1, allowed=True, remaining=8)])
+
 # ---- actor_tests.rs / grpc.rs -------------------------------------------------
 scenario("actor_concurrent_requests", "throttlecrab-server/src/actor_tests.rs:34-70",
          [step("concurrent_test", 10, 10, 60, 1) for _ in range(20)], allowed_total=10)
+scenario("actor_basic_rate_limiting", "throttlecrab-server/src/actor_tests.rs:8-31",
+         [step("test", 5, 10, 60, 1, allowed=True, limit=5, remaining=4)])
+# the client loop stops at the first denial: five allowed, the sixth denied with retry_after > 0 (seconds on the wire: 6)
+scenario("grpc_rate_limiting", "throttlecrab-server/src/transport/grpc.rs:244-295",
+         [step("rate_limit_test", 5, 10, 60, 1, allowed=True) for _ in range(5)]
+         + [step("rate_limit_test", 5, 10, 60, 1, allowed=False, retry_after_s_gt=0)], allowed_total=5)
 scenario("grpc_server_basic", "throttlecrab-server/src/transport/grpc.rs:203-242",
          [step("test_key", 10, 20, 60, 1, allowed=True, limit=10, remaining=9)])
 
@@ -325,6 +357,18 @@ store_contract = [
         [["set_nx", f"key_{i}", i, 3600 * S, 0, True] for i in range(100)]
         + [["get", f"key_{i}", 0, i] for i in range(10)]
         + [["len", 100, 100], ["sweep", 0], ["len", 100, 100]]},
+    {"name": "memory_store_set_and_get", "source": "throttlecrab/src/core/store/tests.rs:5-28", "ops": [
+        ["set_nx", "key1", 42, TTL60, 0, True], ["get", "key1", 0, 42], ["set_nx", "key1", 100, TTL60, 0, False], ["get", "key1", 0, 42]]},
+    {"name": "memory_store_compare_and_swap", "source": "throttlecrab/src/core/store/tests.rs:31-57", "ops": [
+        ["set_nx", "key1", 10, TTL60, 0, True], ["cas", "key1", 10, 20, TTL60, 0, True], ["get", "key1", 0, 20],
+        ["cas", "key1", 10, 30, TTL60, 0, False], ["get", "key1", 0, 20]]},
+    {"name": "memory_store_ttl", "source": "throttlecrab/src/core/store/tests.rs:60-84", "ops": [
+        ["set_nx", "key1", 42, 100 * MS, 0, True], ["get", "key1", 0, 42], ["set_nx", "key2", 100, TTL60, 200 * MS, True],
+        ["get", "key1", 200 * MS, None]]},
+    {"name": "memory_store_get_nonexistent", "source": "throttlecrab/src/core/store/tests.rs:87-93", "ops": [
+        ["get", "nonexistent", 0, None]]},
+    {"name": "memory_store_multiple_keys", "source": "throttlecrab/src/core/store/tests.rs:96-114", "ops":
+        [["set_nx", f"key{i}", i * 10, TTL60, 0, True] for i in range(10)] + [["get", f"key{i}", 0, i * 10] for i in range(10)]},
     {"name": "zero_ttl", "source": f"{SUITE}:464-487", "ops": [
         ["set_nx", "key1", 100, 0, 0, True], ["get", "key1", 1, None]]},
     {"name": "many_keys", "source": f"{SUITE}:490-539", "ops":

@@ -210,3 +210,47 @@ def test_same_results_as_the_wide_layout_at_full_size():
     assert wide.counters()["allowed"] == fix.counters()["allowed"]
     wide.close()
     fix.close()
+
+
+def _fixed_eligible(sc):
+    """A reference scenario can be replayed on the 8-byte layout when every key keeps ONE valid plan with burst >= 2
+    and nothing in it expects an error (the layout takes registered plans only)."""
+    plans = {}
+    for st in sc["steps"]:
+        if st["expect"].get("status") not in (None, 0) or st["q"] < 0:
+            return None
+        plan = (st["burst"], st["count"], st["period"])
+        if plans.setdefault(st["key"], plan) != plan:
+            return None
+        b, c, p = plan
+        if not (2 <= b < 2**31 and 0 < c and 0 < p and p * 10**9 // c > 0 and p * 10**9 // c * (b - 1) < 2**60 and p < 2**30):
+            return None
+    return plans
+
+
+_KAT_FIXED = [s for s in __import__("tests.kat", fromlist=["load"]).load()["scenarios"] if _fixed_eligible(s)]
+
+
+@pytest.mark.parametrize("sc", _KAT_FIXED, ids=[s["name"] for s in _KAT_FIXED])
+def test_reference_known_answers_fixed_layout(sc):
+    """the reference's own assertions (tests/golden/reference_kat.json) through the 8-byte TAT column"""
+    from tests import kat
+    plans = _fixed_eligible(sc)
+    keys = sorted(plans)
+    slot_of = {k: i for i, k in enumerate(keys)}
+    eng = _fixed(max(64, len(keys)), 64)
+    tr = np.array([plans[k] for k in keys], dtype=np.int64)
+    eng.register_params(tr[:, 0], tr[:, 1], tr[:, 2], slots=np.arange(len(keys), dtype=np.uint32))
+
+    class L:
+        def rate_limit(self, key, burst, count, period, q, now):
+            r = eng.rate_limit_batch_slots(np.array([slot_of[key.decode("utf-8")]], np.uint32), registered=True, quantity=q, now_ns=now,
+                                           want=FIELDS)
+            return (int(r.status[0]), bool(r.allowed[0]), int(r.limit[0]), int(r.remaining[0]), int(r.reset_after_ns[0]),
+                    int(r.retry_after_ns[0]))
+    kat.replay_scenario(sc, L())
+    eng.close()
+
+
+def test_most_reference_scenarios_fit_the_fixed_layout():
+    assert len(_KAT_FIXED) >= 25, len(_KAT_FIXED)

@@ -201,3 +201,47 @@ def test_two_processes_contend_for_one_device():
         assert rounds >= 4, (rank, rounds)
         assert bad == 0, (rank, bad)
         assert viol == 0, f"rank {rank}: the spin watchdog fired {viol} times"
+
+
+@pytest.mark.parametrize("sync_batch", [True, False], ids=["host_batch", "device_batch"])
+def test_a_tripped_watchdog_fails_the_engine_loudly(sync_batch):
+    """a wait that gives up must not leave silently wrong results behind.  tc_debug_break_wait withholds
+    ONE "row has read its cells" announcement; the owner of a key whose requests span several rows then waits until the
+    watchdog expires (2 s), the kernel raises the engine's poison word, and the batch call (synchronous batch) or the
+    next call / tc_synchronize (asynchronous batch) returns TC_E_INVARIANT -- as does everything after it."""
+    import torch
+
+    import throttlecrab_amd as t
+    from throttlecrab_amd import _lib as L
+    eng = t.Engine(1000, 1 << 16)
+    eng.register_params_uniform(1000, 1000, 60)
+    slots = np.zeros(2000, np.uint32)  # one key, 2000 allowed requests: the run crosses 31 rows
+    slots[1000:] = 7
+    # a healthy batch first: no trip, no poison
+    r = eng.rate_limit_batch_slots(slots.copy(), registered=True, quantity=1, now_ns=T0, want=("allowed",))
+    assert r.allowed.all() and eng.selfcheck() == 0
+    eng.debug_break_wait(True)
+    t0 = time.time()
+    if sync_batch:
+        with pytest.raises(t.engine.TcError) as ei:
+            eng.rate_limit_batch_slots(np.full(2000, 5, np.uint32), registered=True, quantity=1, now_ns=T0 + 1, want=("allowed",))  # a fresh key
+        assert ei.value.code == L.TC_E_INVARIANT
+    else:
+        d = torch.full((8000,), 5, dtype=torch.int32, device="cuda")  # a fresh key: 1000 allowed requests, the owner sits in row 15
+        eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=T0 + 1, want=("allowed",))  # enqueued: returns at once
+        with pytest.raises(t.engine.TcError) as ei:
+            eng.synchronize()
+        assert ei.value.code == L.TC_E_INVARIANT
+    assert 1.0 < time.time() - t0 < 30.0  # the watchdog's two seconds, not a hang
+    assert eng.selfcheck() >= 1
+    for call in (lambda: eng.rate_limit_batch_slots(slots, registered=True, quantity=1, now_ns=T0 + 2, want=("allowed",)),
+                 lambda: eng.counters(), lambda: eng.sweep_expired(T0), lambda: eng.synchronize()):
+        with pytest.raises(t.engine.TcError) as ei:
+            call()
+        assert ei.value.code == L.TC_E_INVARIANT  # sticky
+    eng.close()
+    # a fresh engine is unaffected
+    e2 = t.Engine(1000, 1 << 16)
+    e2.register_params_uniform(5, 10, 60)
+    assert e2.rate_limit_batch_slots(np.arange(10, dtype=np.uint32), registered=True, quantity=1, now_ns=T0, want=("allowed",)).allowed.all()
+    e2.close()

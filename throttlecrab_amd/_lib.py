@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libtcgpu.so")
 TC_OK, TC_NEGATIVE_QUANTITY, TC_INVALID_RATE_LIMIT, TC_INTERNAL = 0, 1, 2, 3
 # call-level return codes
 (TC_E_OK, TC_E_INVALID_ARG, TC_E_HIP, TC_E_NOMEM, TC_E_BATCH_TOO_LARGE, TC_E_TABLE_FULL, TC_E_NO_DEVICE,
- TC_E_UNSUPPORTED) = (0, -1, -2, -3, -4, -5, -6, -7)
+ TC_E_UNSUPPORTED, TC_E_INVARIANT) = (0, -1, -2, -3, -4, -5, -6, -7, -8)
 TC_CFG_KEY_MODE = 0x1
 TC_CFG_TRACK_DENIED = 0x2
 TC_CFG_FIXED_PARAMS = 0x4
@@ -92,6 +92,7 @@ SYMBOLS = {
     "tc_top_denied": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "tc_denied_reset": (C.c_int, [C.c_void_p]),
     "tc_debug_fail_copy": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "tc_debug_break_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tc_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_snapshot_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_snapshot_load": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -393,7 +393,7 @@ __device__ __forceinline__ void eval_step(const Params& p, const Req& rq0, uint3
                 wcell = c;
             } else if (FULL) {
                 const tc::RunForm f = tc::run_form(c, rq.ei, rq.dvt, rq.q, rq.now);
-                if (!f.regular) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // the host's proof was wrong: must stay 0
+                if (!f.regular) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]); // the host's proof was wrong: must stay 0
                 if (r == 0) {
                     t.na += 1;
                     ev::write_out(p, orow, rq, d0);
@@ -415,7 +415,7 @@ __device__ __forceinline__ void eval_step(const Params& p, const Req& rq0, uint3
             } else {
                 // decisions only: rank r is allowed <=> r * inc <= room (no 64-bit division)
                 const tc::RunLite f = tc::run_lite(c, rq.ei, rq.dvt, rq.q, rq.now);
-                if (!f.regular) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull);
+                if (!f.regular) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]);
                 const bool ok_r = r == 0 || tc::rank_allowed(f, r);
                 d.allowed = ok_r;
                 t.na += ok_r;
@@ -428,7 +428,7 @@ __device__ __forceinline__ void eval_step(const Params& p, const Req& rq0, uint3
                 }
             }
             if (FIXED && writer && wcell.expiry != (uint64_t)(wcell.tat + rq.dvt))
-                atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // the 8-byte layout would lose information: must stay 0
+                tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]); // the 8-byte layout would lose information: must stay 0
         }
         if (p.denied && denied_here) atomicAdd(&p.denied[slot], 1u); // (skewed streams take the sort path: one atomic per key run there)
     }

@@ -25,6 +25,7 @@ constexpr uint32_t F_UNIFORM_CLASS = 2u; // every slot carries plan `uniform_cla
 constexpr uint32_t F_FIXED = 4u;         // TC_CFG_FIXED_PARAMS engine: 8-byte TAT column (tat8), timestamps < 2^62
 constexpr uint32_t F_PREFILL0 = 16u;     // TC_B_OUTPUTS_IDLE batch whose `allowed` bytes were all set to 0 ahead of the evaluation
 constexpr uint32_t F_PREFILL1 = 32u;     // ... to 1: the evaluation only stores the decisions that differ from the fill
+constexpr uint32_t F_DEBUG_NO_ANNOUNCE = 64u; // tc_debug_break_wait: row 0 never announces (the watchdog's test)
 constexpr uint32_t F_DEBUG_NOSTORE = 8u; // measurement only (TCGPU_DEBUG_NO_DECISION_STORE): the lean kernel skips its decision bytes
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
 constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
@@ -656,7 +657,7 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
                             wcell[j] = c;
                         } else {
                             // irregular run (saturation, zero increment, immediate expiry): walk the rest one by one
-                            if (DIRECT) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull); // the host's proof was wrong: must stay 0
+                            if (DIRECT) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]); // the host's proof was wrong: must stay 0
                             uint32_t wd = 0;
                             for (uint32_t q = k + 1; q < n; ++q) {
                                 const uint64_t nx = sorted[q];
@@ -701,7 +702,8 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
         if (DIRECT) {
             const uint32_t gw = k >> 6; // row number
             // announce "this row has read its cells" if a later row may have to wait for it
-            if (lane == 63 && valid && !is_last[j]) __hip_atomic_store(&loaded[gw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 63 && valid && !is_last[j] && !((p.flags & F_DEBUG_NO_ANNOUNCE) && gw == 0u))
+                __hip_atomic_store(&loaded[gw], seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t row_first = k - (uint32_t)lane;
             const bool must_wait = writer[j] && seg_start[j] < row_first; // at most one such run per row
             const unsigned long long wm = __ballot(must_wait);
@@ -713,7 +715,7 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
                     tc::SpinGuard guard;
                     while (__ballot(w < gw && __hip_atomic_load(&loaded[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq)) {
                         if (tc::spin_expired(guard)) { // (see tc::SpinGuard: flagged, never hung)
-                            if (lane == 0) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull);
+                            if (lane == 0) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]);
                             break;
                         }
                         __builtin_amdgcn_s_sleep(1);
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         tc::SpinGuard guard;
         while (true) {
             if (tc::spin_expired(guard)) { // (see tc::SpinGuard: flagged, never hung; this wave goes on from c0)
-                if (lane == 0) atomicAdd(&p.counters[(TC_CNT_COUNT + 1) + 3], 1ull);
+                if (lane == 0) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]);
                 in_tat = c0_tat;
                 in_exp = c0_exp;
                 break;

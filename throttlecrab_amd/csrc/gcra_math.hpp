@@ -281,6 +281,17 @@ TC_HD Cell cell_after(int64_t new_tat, int64_t dvt, int64_t now) {
 // clock (2 s: four orders of magnitude above the longest legitimate wait) the loop gives up and the engine's
 // invariant counter (tc_selfcheck) is raised, so a broken assumption shows as a failed check instead of a hung GPU.
 #if defined(__HIPCC__)
+// A tripped watchdog (or any other broken invariant) POISONS the engine: besides the device-side counter that
+// tc_selfcheck reads, the kernel raises a word in pinned host memory whose address sits POISON_PTR_WORDS words behind the
+// counter.  Every ABI call looks at that word: from then on the engine answers TC_E_INVARIANT instead of handing out
+// results computed from a state somebody stopped waiting for.
+constexpr int POISON_PTR_WORDS = 4;
+__device__ __forceinline__ void invariant_failed(unsigned long long* violations) {
+    if (violations == nullptr) return;
+    atomicAdd(violations, 1ull);
+    uint32_t* host = reinterpret_cast<uint32_t*>(__hip_atomic_load(violations + POISON_PTR_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if (host != nullptr) __hip_atomic_store(host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 constexpr long long SPIN_LIMIT_TICKS = 200000000ll;
 struct SpinGuard {
     long long t0 = 0;

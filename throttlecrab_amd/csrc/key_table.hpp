@@ -381,7 +381,16 @@ __device__ __forceinline__ void reserve_overflow(const Table& t, bool live, uint
         total += s_w[w];
     }
     if (total == 0) return; // (block-uniform)
-    if (threadIdx.x == 0) s_base = atomicAdd(t.overflow_used, (unsigned long long)total);
+    if (threadIdx.x == 0) {
+        const unsigned long long base = atomicAdd(t.overflow_used, (unsigned long long)total);
+        s_base = base;
+        // what reaches past the end of the arena is handed back at once: a cursor left beyond the end would refuse every
+        // later long key, shorter ones included, until the next sweep compacts the arena
+        if (base + total > t.overflow_bytes) {
+            const unsigned long long keep = base < t.overflow_bytes ? t.overflow_bytes - base : 0ull;
+            atomicAdd(t.overflow_used, ~((unsigned long long)total - keep) + 1ull); // -= the part beyond the end
+        }
+    }
     __syncthreads();
     if (need) {
         const unsigned long long ovf = s_base + before + (v - bytes);
@@ -618,8 +627,12 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
         do {
             unsigned long long ovf = 0;
             if (len > INLINE_KEY) {
-                ovf = atomicAdd(t.overflow_used, (unsigned long long)((len + 15u) & ~15u));
-                if (ovf + len > t.overflow_bytes) break;
+                const unsigned long long want = (len + 15u) & ~15u;
+                ovf = atomicAdd(t.overflow_used, want);
+                if (ovf + len > t.overflow_bytes) {
+                    atomicAdd(t.overflow_used, ~want + 1ull); // give it back: shorter keys may still fit
+                    break;
+                }
             }
             const int old = atomicSub(t.free_top, 1);
             if (old <= 0) {

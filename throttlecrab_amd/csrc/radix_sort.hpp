@@ -322,7 +322,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
                 tc::SpinGuard guard;
                 while (true) {
                     if (tc::spin_expired(guard)) { // (flagged, never hung)
-                        if (ws.violations) atomicAdd(ws.violations, 1ull);
+                        tc::invariant_failed(ws.violations);
                         break;
                     }
                     uint32_t s[GROUP - 1];
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
             tc::SpinGuard guard2;
             while (gg >= 0) {
                 if (tc::spin_expired(guard2)) {
-                    if (ws.violations) atomicAdd(ws.violations, 1ull);
+                    tc::invariant_failed(ws.violations);
                     break;
                 }
                 uint32_t a[GROUP_WINDOW], b[GROUP_WINDOW];

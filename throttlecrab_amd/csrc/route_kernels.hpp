@@ -269,7 +269,7 @@ __global__ __launch_bounds__(THREADS) void k_route_one(const uint32_t* __restric
         tc::SpinGuard guard;
         while (at >= 0) {
             if (tc::spin_expired(guard)) { // (flagged, never hung)
-                if (lane == 0 && violations) atomicAdd(violations, 1ull);
+                if (lane == 0) tc::invariant_failed(violations);
                 break;
             }
             const int t = at - lane;

@@ -181,6 +181,8 @@ struct tc_engine {
     std::vector<hipEvent_t> async_pool;
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
+    uint32_t* poison_host = nullptr; // pinned: raised by tc::invariant_failed; every ABI call checks it (TC_E_INVARIANT)
+    bool debug_break_wait = false;   // tc_debug_break_wait
     uint32_t fault_countdown = 0; // tc_debug_fail_copy: the n-th staging copy from now fails (error-path tests)
     uint32_t* route_ws = nullptr; // tc_route_batch scratch (lazy): per stream it may run on: tile counts per destination
     size_t route_ws_words = 0;    // words of one of them
@@ -292,6 +294,35 @@ extern "C" const char* tc_last_error(const tc_engine* e) { return e ? e->err.c_s
 
 static size_t sort_ws_words(uint32_t max_tiles) { return rs::workspace_words(max_tiles); }
 
+// the device-side address of the poison word goes into the counter block, POISON_PTR_WORDS behind the violation counter
+// (tc::invariant_failed finds it there: no kernel carries an extra argument for something that never happens)
+static int publish_poison_ptr(tc_engine* e) {
+    void* dv = nullptr;
+    TC_HIP(e, hipHostGetDevicePointer(&dv, e->poison_host, 0));
+    const unsigned long long v = (unsigned long long)(uintptr_t)dv;
+    TC_HIP(e, hipMemcpy(e->counters + (TC_CNT_COUNT + 1) + 3 + tc::POISON_PTR_WORDS, &v, sizeof v, hipMemcpyHostToDevice));
+    return TC_E_OK;
+}
+#define TC_TRY_EARLY(call)                \
+    do {                                  \
+        int _trc = (call);                \
+        if (_trc != TC_E_OK) return _trc; \
+    } while (0)
+// sticky: once a kernel has flagged a broken invariant the engine answers nothing else
+static int poisoned(tc_engine* e) {
+    if (e->poison_host && *(volatile uint32_t*)e->poison_host != 0u) {
+        e->err = "an internal invariant failed on the device (a wait gave up, or a closed form met a state it was proven not to meet): "
+                 "results and state are undefined -- destroy the engine";
+        return TC_E_INVARIANT;
+    }
+    return TC_E_OK;
+}
+#define TC_CHECK_POISON(e)              \
+    do {                                \
+        int _prc = poisoned(e);         \
+        if (_prc != TC_E_OK) return _prc; \
+    } while (0)
+
 static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipSetDevice(e->device));
     const uint64_t cap = e->capacity, mb = e->max_batch;
@@ -313,6 +344,9 @@ static int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipMemsetAsync(e->rate_id, 0, cap * sizeof(uint16_t), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(e->classes, 0, (size_t)MAX_CLASSES * sizeof(RateClass), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), (hipStream_t)0));
+    TC_HIP(e, hipHostMalloc((void**)&e->poison_host, 64, hipHostMallocDefault));
+    *e->poison_host = 0u;
+    TC_TRY_EARLY(publish_poison_ptr(e));
     e->sort_max_tiles = (uint32_t)((mb + rs::THREADS * SORT_ITEMS - 1) / (rs::THREADS * SORT_ITEMS));
     const size_t words = sort_ws_words(e->sort_max_tiles);
     e->n_aux = (e->cfg_flags & TC_CFG_KEY_MODE) ? AUX_KEY_MODE : AUX_SLOT_MODE;
@@ -365,6 +399,16 @@ static int engine_alloc(tc_engine* e) {
         if (const char* d = getenv("TCGPU_BUCKET_BACKOFF")) e->bp_backoff_len = (uint32_t)std::max(atoi(d), 0);
         if (const char* d = getenv("TCGPU_BUCKET_MIN_N")) e->bp_min_n = (uint32_t)std::max(atoi(d), 1);
         if (const char* d = getenv("TCGPU_BUCKET_SKEW")) e->bp_skew = (uint32_t)std::min<long long>(std::max(atoll(d), 1ll), bp::MAX_SKEW);
+        if (e->bp_ok) {
+            // the partition kernels size their LDS by the bucket count (k_scatter: 8 B per bucket + marks, k_tile_hist:
+            // 4 B per bucket) and the evaluation by the bucket width: a key space whose bucket count needs more than a
+            // block may have is sorted instead (a rejected launch would leave stale elements behind a valid gate)
+            hipDeviceProp_t prop;
+            TC_HIP(e, hipGetDeviceProperties(&prop, e->device));
+            const uint32_t nbk = bp::buckets_of(cap, e->bp_lb);
+            const size_t need = std::max({bp::scatter_lds_bytes(nbk), (size_t)nbk * sizeof(uint32_t), bp::eval_lds_bytes(e->bp_lb)});
+            if (need > (size_t)prop.sharedMemPerBlock) e->bp_ok = false;
+        }
         if (e->bp_ok) {
             TC_HIP(e, hipHostMalloc((void**)&e->bp_gate_host, sizeof(uint32_t), hipHostMallocDefault));
             *e->bp_gate_host = 0;
@@ -668,6 +712,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     }
     if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
+    if (e->poison_host) (void)hipHostFree(e->poison_host);
     if (e->k_done) (void)hipEventDestroy(e->k_done);
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
@@ -701,7 +746,7 @@ extern "C" int tc_synchronize(tc_engine* e) {
         e->async_pool.push_back(e->async_done.front());
         e->async_done.pop_front();
     }
-    return TC_E_OK;
+    return poisoned(e);
 }
 
 // (burst, count, period) -> class id, creating (and uploading) the class if new.
@@ -734,6 +779,7 @@ static int upload_classes(tc_engine* e) {
 
 extern "C" int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64_t count_per_period, int64_t period) {
     if (!e) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     bool grew = false;
     const int id = intern_class(e, max_burst, count_per_period, period, &grew);
     if (id == 0) return fail(e, TC_E_INVALID_ARG, "tc_register_params_uniform: invalid (burst,count,period)");
@@ -759,6 +805,7 @@ extern "C" int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64
 extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slots, const int64_t* max_burst,
                                   const int64_t* count_per_period, const int64_t* period) {
     if (!e || !max_burst || !count_per_period || !period) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     if (n == 0) return TC_E_OK;
     if (!slots && n > e->capacity) return fail(e, TC_E_INVALID_ARG, "tc_register_params: n > capacity");
     // validate everything before touching the dictionary or the device
@@ -1017,7 +1064,8 @@ static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped,
 
 // ---- bucket path (bucket_path.hpp) -------------------------------------------------------------------
 // partition of the batch by key range, on stream `s` (k_tile_hist, k_bucket_scan, k_scatter)
-static void bucket_partition(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n) {
+// (false: a launch was rejected -- the caller must not enqueue the bucket evaluation behind this partition)
+static bool bucket_partition(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n) {
     const bp::Work& w = ss.bpw;
     const uint32_t tiles = bp::tiles_of(n), cap = (uint32_t)e->capacity;
     prof_begin(e, TC_STAGE_BUCKET_HIST, s);
@@ -1029,6 +1077,7 @@ static void bucket_partition(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s
     prof_begin(e, TC_STAGE_BUCKET_SCATTER, s);
     hipLaunchKernelGGL(bp::k_scatter, dim3(tiles), dim3(bp::TILE_THREADS), bp::scatter_lds_bytes(w.nbk), s, d_slot, n, cap, w);
     prof_end(e, s);
+    return hipGetLastError() == hipSuccess;
 }
 // evaluation of the partitioned batch: one wave per bucket (k_bucket_eval)
 static void bucket_eval(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const Params& p, bool full) {
@@ -1110,6 +1159,10 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
     p.tat8 = e->tat8;
     if (e->fixed) p.flags |= F_FIXED;
     if (e->debug_nostore) p.flags |= F_DEBUG_NOSTORE;
+    if (e->debug_break_wait) {
+        p.flags |= F_DEBUG_NO_ANNOUNCE;
+        e->debug_break_wait = false; // one batch
+    }
     p.rate_id = e->rate_id;
     p.classes = e->classes;
     p.uniform_class = e->uniform_id;
@@ -1203,7 +1256,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
             if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
-            if (bucketed) bucket_partition(e, ss, ax, d_slot, n);
+            if (bucketed && !bucket_partition(e, ss, ax, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
             const bool ride = e->stop_events && !e->prof_on; // `sorted` rides on the last pass's own completion signal
             // TC_B_OUTPUTS_IDLE: nothing enqueued earlier touches this call's `allowed` bytes, so they are preset here, on
             // the grouping stream, to what most decisions of a recent batch were, and the evaluation only stores the
@@ -1225,7 +1278,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             // and every auxiliary sort was joined into `s` before its evaluation
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
             ss.grouped_aside = false;
-            if (bucketed) bucket_partition(e, ss, s, d_slot, n);
+            if (bucketed && !bucket_partition(e, ss, s, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
             sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
         }
         if (bucketed) bucket_eval(e, ss, s, p, full);
@@ -1291,7 +1344,7 @@ static int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     TC_TRY(run_slots_device(e, d));
     TC_TRY(copy_outputs_back(e, b, s));
     TC_HIP(e, hipStreamSynchronize(s));
-    return TC_E_OK;
+    return poisoned(e); // (a synchronous batch whose kernels flagged an invariant fails itself, not the next call)
 }
 
 // results back to the caller's arrays behind the evaluation + the batch's completion event
@@ -1451,6 +1504,7 @@ static int run_small_batch(tc_engine* e, const tc_batch& b) {
 
 extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     const tc_batch& b = *bp;
     if (b.n == 0) return TC_E_OK;
     if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
@@ -1460,23 +1514,31 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     if (e->fixed) {
         if (!(b.flags & TC_B_REGISTERED_PARAMS))
             return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: batches use the registered plans (TC_B_REGISTERED_PARAMS)");
-        e->sealed = true;
     }
     TC_HIP(e, hipSetDevice(e->device));
+    int rc;
     if (b.flags & TC_B_DEVICE_PTRS) {
         if (b.flags & TC_B_ASYNC) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
-        return run_slots_device(e, b);
+        rc = run_slots_device(e, b);
+    } else if (b.flags & TC_B_ASYNC) {
+        rc = run_slots_host_async(e, b);
+    } else if (small_batch_applies(e, b)) {
+        rc = run_small_batch(e, b);
+    } else {
+        // host pointers: stage in, run, stage out, synchronise
+        TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
+        TC_HIP(e, copy_async(e, e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+        rc = run_slots_host_staged(e, b);
     }
-    if (b.flags & TC_B_ASYNC) return run_slots_host_async(e, b);
-    if (small_batch_applies(e, b)) return run_small_batch(e, b);
-    // host pointers: stage in, run, stage out, synchronise
-    TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
-    TC_HIP(e, copy_async(e, e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
-    return run_slots_host_staged(e, b);
+    // fixed layout: once a request has been decided the plans can no longer change (a batch that was rejected, or
+    // whose staging failed, applied nothing and seals nothing)
+    if (e->fixed && rc == TC_E_OK) e->sealed = true;
+    return rc;
 }
 
 extern "C" int tc_wait_batches(tc_engine* e, uint32_t max_in_flight) {
     if (!e) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     TC_HIP(e, hipSetDevice(e->device));
     while (e->async_done.size() > max_in_flight) {
         hipEvent_t ev = e->async_done.front();
@@ -1484,7 +1546,7 @@ extern "C" int tc_wait_batches(tc_engine* e, uint32_t max_in_flight) {
         e->async_done.pop_front();
         e->async_pool.push_back(ev);
     }
-    return TC_E_OK;
+    return poisoned(e);
 }
 
 extern "C" void* tc_host_alloc(size_t bytes) {
@@ -1551,6 +1613,7 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
 
 extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
     const tc_batch& b = *bp;
     if (b.n == 0) return TC_E_OK;
@@ -1607,6 +1670,7 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
                              int64_t count_per_period, int64_t period, int64_t quantity, int64_t now_ns,
                              tc_result* out) {
     if (!e || !out || (!key && key_len)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     if (key_len > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "key too long");
     if (e->fixed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: single calls carry their own rate; use a registered batch");
     TC_HIP(e, hipSetDevice(e->device));
@@ -1679,6 +1743,7 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
 
 extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed) {
     if (!e) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     TC_HIP(e, hipSetDevice(e->device));
     hipStream_t s = cur_stream(e);
     unsigned long long* scratch = e->counters + TC_CNT_COUNT;
@@ -1724,6 +1789,7 @@ extern "C" int tc_counters_refresh(tc_engine* e) {
 
 extern "C" int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]) {
     if (!e || !out) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     int rc = tc_counters_refresh(e);
     if (rc != TC_E_OK) return rc;
     TC_HIP(e, hipMemcpyAsync(out, e->counters, TC_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, cur_stream(e)));
@@ -1808,6 +1874,7 @@ static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, u
 
 extern "C" int tc_store_get(tc_engine* e, const uint8_t* key, size_t key_len, int64_t now_ns, int64_t* value, int* found) {
     if (!e || !value || !found) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     uint64_t slot;
     int rc = store_slot_of(e, key, key_len, false, &slot);
     if (rc != TC_E_OK) return rc;
@@ -1827,6 +1894,7 @@ extern "C" int tc_store_get(tc_engine* e, const uint8_t* key, size_t key_len, in
 extern "C" int tc_store_compare_and_swap_with_ttl(tc_engine* e, const uint8_t* key, size_t key_len, int64_t old_value,
                                                   int64_t new_value, uint64_t ttl_ns, int64_t now_ns, int* swapped) {
     if (!e || !swapped) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     uint64_t slot;
     int rc = store_slot_of(e, key, key_len, false, &slot);
     if (rc != TC_E_OK) return rc;
@@ -1844,6 +1912,7 @@ extern "C" int tc_store_compare_and_swap_with_ttl(tc_engine* e, const uint8_t* k
 extern "C" int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* key, size_t key_len, int64_t value,
                                                    uint64_t ttl_ns, int64_t now_ns, int* was_set) {
     if (!e || !was_set) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     uint64_t slot;
     int rc = store_slot_of(e, key, key_len, true, &slot);
     if (rc != TC_E_OK) return rc;
@@ -1856,6 +1925,7 @@ extern "C" int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* 
 
 extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* tat, uint64_t* expiry) {
     if (!e || n > e->capacity || first > e->capacity - n) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     if (n == 0) return TC_E_OK;
     TC_HIP(e, hipSetDevice(e->device));
     if (e->fixed) { // expiry == tat + dvt of the key's plan (gcra_math.hpp: fixed_cell)
@@ -1884,6 +1954,7 @@ extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* 
 
 extern "C" int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, int64_t* slot) {
     if (!e || !slot) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
     TC_HIP(e, hipSetDevice(e->device));
     uint64_t s = kt::NO_SLOT;
@@ -1896,6 +1967,7 @@ extern "C" int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, 
 // ---- denied-key metrics ---------------------------------------------------------
 extern "C" int tc_top_denied(tc_engine* e, uint32_t k, uint32_t* slots, uint64_t* counts, uint32_t* n_out) {
     if (!e || !slots || !counts || !n_out) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
     *n_out = 0;
     if (k == 0) return TC_E_OK;
@@ -2103,6 +2175,7 @@ int drain_for_snapshot(tc_engine* e) {
 
 extern "C" int tc_snapshot_save(tc_engine* e, const char* path) {
     if (!e || !path) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     int rc = drain_for_snapshot(e);
     if (rc != TC_E_OK) return rc;
     FILE* f = fopen(path, "wb");
@@ -2160,7 +2233,15 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     FILE* f = fopen(path, "rb");
     if (!f) return fail(e, TC_E_INVALID_ARG, "tc_snapshot_load: cannot open file");
     SnapHeader h;
-    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "TCGPUSN1", 8) == 0 && h.version == SNAP_VERSION;
+    bool ok = fread(&h, sizeof h, 1, f) == 1 && memcmp(h.magic, "TCGPUSN1", 8) == 0;
+    if (ok && h.version != SNAP_VERSION) {
+        // the on-disk layout follows the resident layout and changes with it; there is no migration (README.md,
+        // "Snapshots"): a snapshot is a restart aid for ONE build, the state itself expires within minutes anyway
+        fclose(f);
+        e->err = "tc_snapshot_load: snapshot format version " + std::to_string(h.version) + ", this build reads version " +
+                 std::to_string(SNAP_VERSION) + " only (no migration: take a new snapshot with this build)";
+        return TC_E_UNSUPPORTED;
+    }
     const uint32_t mode = (e->key_mode ? 1u : 0u) | (e->denied ? 2u : 0u) | (e->fixed ? 4u : 0u);
     if (!ok || h.key_mode != mode || h.capacity != e->capacity || (e->key_mode && (h.nb != e->kt.nb_mask + 1 ||
                                                                                   h.overflow_bytes != e->kt.overflow_bytes)) ||
@@ -2218,6 +2299,7 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     c[(TC_CNT_COUNT + 1) + 1] = h.counters[TC_CNT_DENIED];
     c[(TC_CNT_COUNT + 1) + 2] = h.counters[TC_CNT_ERRORS];
     TC_HIP(e, hipMemcpy(e->counters, c.data(), cnt_words * sizeof(unsigned long long), hipMemcpyHostToDevice));
+    TC_TRY(publish_poison_ptr(e));
     e->batches = h.batches;
     e->sealed = true; // (fixed layout: the loaded state was written under the loaded plans)
     return TC_E_OK;
@@ -2226,6 +2308,7 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
 // ---- routing of a global stream (route_kernels.hpp) --------------------------------------------------
 extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     if (!e || !rp || rp->struct_size < offsetof(tc_route, stream)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
     tc_route r; // (callers built against the struct without `stream` get the engine's stream)
     memset(&r, 0, sizeof(r));
     memcpy(&r, rp, std::min<size_t>(rp->struct_size, sizeof(r)));
@@ -2246,17 +2329,13 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
             // the router on this stream, to them.  Every grouping stream has its own router scratch.
             lane = 1 + e->next_route++ % e->n_aux;
             s = e->aux[lane - 1];
-            // (the batches that read the very buffer being overwritten, if the engine still knows them; else all)
-            bool known = false;
-            for (int pass = 0; pass < 2 && !known; ++pass)
-                for (uint32_t si = 0; si < e->depth; ++si) {
-                    tc_engine::SortSet& ss = e->sets[si];
-                    if (!ss.in_use) continue;
-                    const bool reads = ss.slot_src && ss.slot_src < r.out_slot + r.n && r.out_slot < ss.slot_src + ss.slot_src_n;
-                    if (pass == 0 && !reads) continue;
-                    if (pass == 0) known = true;
-                    TC_HIP(e, hipStreamWaitEvent(s, ss.grouped_aside ? ss.sorted : ss.consumed, 0));
-                }
+            // Behind the grouping of EVERY batch whose set is still in use: a set only remembers its latest batch, so
+            // "the readers of this very buffer" cannot be told from the sets alone once a set has been reused
+            // (ADVICE r2); an event that has already fired costs the stream nothing.
+            for (uint32_t si = 0; si < e->depth; ++si) {
+                tc_engine::SortSet& ss = e->sets[si];
+                if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(s, ss.grouped_aside ? ss.sorted : ss.consumed, 0));
+            }
         }
     }
     const uint32_t n = (uint32_t)r.n, tiles = (n + rt::TILE - 1) / rt::TILE;
@@ -2333,6 +2412,12 @@ extern "C" int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_
 
 // Test hook: the n-th staging copy (host <-> device, any batch path) from now returns an error instead of
 // being issued.  0 disarms.
+extern "C" int tc_debug_break_wait(tc_engine* e, uint32_t on) {
+    if (!e) return TC_E_INVALID_ARG;
+    e->debug_break_wait = on != 0;
+    return TC_E_OK;
+}
+
 extern "C" int tc_debug_fail_copy(tc_engine* e, uint32_t nth) {
     if (!e) return TC_E_INVALID_ARG;
     e->fault_countdown = nth;

@@ -98,6 +98,10 @@ class Engine:
         """test hook: the nth staging copy from now fails (tc_debug_fail_copy)"""
         self._check(self._lib.tc_debug_fail_copy(self._h, nth))
 
+    def debug_break_wait(self, on: bool = True):
+        """test hook: the next uniform batch withholds one cross-row announcement (tc_debug_break_wait)"""
+        self._check(self._lib.tc_debug_break_wait(self._h, 1 if on else 0))
+
     def selfcheck(self) -> int:
         v = C.c_uint64(0)
         self._check(self._lib.tc_selfcheck(self._h, C.byref(v)))
