@@ -254,3 +254,52 @@ def test_reference_known_answers_fixed_layout(sc):
 
 def test_most_reference_scenarios_fit_the_fixed_layout():
     assert len(_KAT_FIXED) >= 25, len(_KAT_FIXED)
+
+
+@pytest.mark.parametrize("shape", ["steady_denials", "tokens_trickle_in", "jitter_and_errors", "expired_between"])
+def test_general_decisions_only_hot_keys(shape):
+    """decisions-only batches with a timestamp per request on the 8-byte layout: waves of a hot key's run that find the
+    resident state live and deny everything under it do not wait for the state that reaches them (strong
+    transparency, k_eval_general).  Hot keys whose runs cross hundreds of waves, tokens becoming available in the
+    middle of a run, timestamps that jump back, quantities 0 / 1 / 2 / huge, error requests, entries that expire
+    between batches -- decisions, statuses and the resident state must equal the oracle's after every batch."""
+    import torch
+    cap, n = 4_000, 60_000
+    rng = np.random.default_rng({"steady_denials": 1, "tokens_trickle_in": 2, "jitter_and_errors": 3, "expired_between": 4}[shape])
+    eng, orc = _fixed(cap, n), _oracle(cap)
+    eng.use_torch_stream()
+    plan = (5, 600, 60) if shape != "expired_between" else (3, 60, 60)   # ei = 0.1 s / 1 s
+    eng.register_params_uniform(*plan)
+    tt = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).cuda()
+    hot = rng.permutation(cap)[:6]
+    base = T0
+    for rnd in range(7):
+        slots = rng.integers(0, cap, n).astype(np.uint32)
+        heavy = rng.random(n) < 0.85
+        slots[heavy] = hot[rng.integers(0, len(hot), int(heavy.sum()))]   # ~8 500 requests per hot key: 130+ waves each
+        if shape == "steady_denials":
+            base += 1_000_000
+            now = base + np.arange(n, dtype=np.int64)                       # 60 us across the batch: no token in sight
+            q = np.ones(n, np.int64)
+        elif shape == "tokens_trickle_in":
+            base += 50_000_000
+            now = base + np.arange(n, dtype=np.int64) * 20_000              # 1.2 s across the batch: a dozen tokens per key
+            q = np.ones(n, np.int64)
+        elif shape == "jitter_and_errors":
+            base += 300_000_000
+            now = base + rng.integers(0, 400_000_000, n)
+            now[rng.random(n) < 0.01] -= 3 * 10**9                         # the clock jumps back
+            q = rng.choice(np.array([0, 1, 1, 1, 2, 7, -1, 2**61], dtype=np.int64), n)
+        else:
+            base += 9 * 10**9                                               # every entry has expired since the last batch
+            now = base + np.sort(rng.integers(0, 3 * 10**9, n))
+            q = rng.choice(np.array([1, 1, 2, 4], dtype=np.int64), n)       # 4 > burst: denied fresh, allowed on a stale live entry
+        ref = orc.batch_slots(slots, *plan, q, now)
+        res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).cuda(), registered=True, quantity=tt(q), now_ns=tt(now),
+                                         want=("allowed", "status"), inputs_ready=bool(rnd % 2))
+        torch.cuda.synchronize()
+        assert_same(res, ref, f"{shape} round {rnd}")
+        assert_state_same(eng, orc, np.concatenate([hot.astype(np.uint32), slots[::7]]))
+    c = eng.counters()
+    assert c["denied"] > c["allowed"] > 0
+    eng.close()

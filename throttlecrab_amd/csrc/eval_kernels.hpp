@@ -778,8 +778,9 @@ __global__ __launch_bounds__(BLOCK, TC_EVAL_LEAN_WAVES) __attribute__((amdgpu_nu
 struct __attribute__((aligned(32))) ChainRec {
     unsigned long long tat, expiry; // state the wave's last piece leaves (valid once fin == batch sequence number)
     uint32_t fin;                   // low half of the 8-byte flag word
-    uint32_t spec;                  // == sequence number: "my lanes are all denied if my segment still has its
-                                    // resident state when it reaches me" (published before the wave waits)
+    uint32_t spec;                  // == sequence number << 1 | strong: "my lanes are all denied if my segment still has its
+                                    // resident state when it reaches me" (published before the wave waits); strong: "...
+                                    // whatever state reaches me" (see k_eval_general)
     uint32_t dirty;
     uint32_t pad;
 };
@@ -832,26 +833,37 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     c.tat = 0;
     c.expiry = 0;
     bool dirty = false;
+    bool strong_wave = false; // (wave-uniform) see below: this wave neither needs nor publishes the segment's state
     if (valid && slot < p.capacity) c = load_state_rt(p, slot, r.dvt); // continued lanes: c0, the guess
     if (__ballot(continued) != 0ull) { // wave-uniform: lane 0 is continued
-        bool spec_allow = false;
+        bool spec_allow = false, c0_dead = false;
         if (continued && ok) {
             Cell t0 = c;
             spec_allow = tc::gcra_step<false>(t0, r.ei, r.dvt, r.q, r.now).allowed;
+            c0_dead = !(c.expiry > (uint64_t)r.now);
         }
         const bool transparent = __ballot(spec_allow) == 0ull;
         const bool through = __shfl((int)(continued && !is_last), 63, 64) != 0; // the segment runs through this whole wave
+        // STRONG transparency (decisions only, TC_CFG_FIXED_PARAMS): under the 8-byte layout a key's plan never changes and
+        // expiry == tat + dvt, so within a batch the key's TAT only grows and a state that is live at `now` stays live.
+        // A request that finds c0 LIVE and is denied under c0 is therefore denied under every state the segment can be
+        // in when it reaches this wave (allow_at = max(tat, now - dvt) + inc - dvt grows with tat): the wave's decisions
+        // are final without knowing the incoming state, and it hands on whatever state reaches it.  Such a wave waits
+        // for nobody and publishes no state; later waves look THROUGH it to the nearest wave that did.  (A request
+        // that finds c0 expired is judged as a fresh key, which can be stricter than a live entry: not strong.)
+        strong_wave = !FULL && (p.flags & F_FIXED) != 0u && transparent && through && __ballot(continued && ok && c0_dead) == 0ull;
         if (transparent && through && lane == 0)
-            __hip_atomic_store(&chain[gw].spec, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&chain[gw].spec, (seq << 1) | (strong_wave ? 1u : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const long long c0_tat = __shfl((long long)c.tat, 0, 64);
         const unsigned long long c0_exp = __shfl((unsigned long long)c.expiry, 0, 64);
-        long long in_tat = 0;
-        unsigned long long in_exp = 0;
+        long long in_tat = c0_tat;
+        unsigned long long in_exp = c0_exp;
         uint32_t in_dirty = 0;
-        bool direct = false; // give up speculating: wait for the direct predecessor
-        uint32_t base = 0;   // records gw-1-base-lane are examined
+        bool direct = false;    // speculation failed: only an exact hand-over will do
+        bool skipped_weak = false; // a weakly transparent wave lies between me and the records being examined
+        uint32_t base = 0;      // records gw-1-base-lane are examined
         tc::SpinGuard guard;
-        while (true) {
+        while (!strong_wave) {
             if (tc::spin_expired(guard)) { // (see tc::SpinGuard: flagged, never hung; this wave goes on from c0)
                 if (lane == 0) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]);
                 in_tat = c0_tat;
@@ -860,24 +872,35 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             }
             const long long j = (long long)gw - 1 - (long long)base - lane;
             unsigned long long fl = 0ull;
-            if (j >= 0 && (!direct || lane == 0))
+            if (j >= 0)
                 fl = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&chain[j].fin), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_AGENT);
-            const bool is_fin = (uint32_t)fl == seq, is_spec = (uint32_t)(fl >> 32) == seq;
-            const unsigned long long fm = __ballot(is_fin), sm = __ballot(is_spec);
-            int d = -1; // lane whose record ends the look-back
-            if (direct) {
-                if (fm & 1ull) d = 0;
-            } else if (fm) {
+            const uint32_t sp = (uint32_t)(fl >> 32);
+            const bool is_fin = (uint32_t)fl == seq, is_spec = (sp >> 1) == seq, is_strong = is_spec && (sp & 1u);
+            const unsigned long long fm = __ballot(is_fin), sm = __ballot(is_spec), tm = __ballot(is_strong);
+            // the nearest record that carries a state, and what lies between it and me
+            int d = -1;
+            bool exact = false;
+            if (fm) {
                 const int f = __builtin_ctzll(fm);
                 const unsigned long long below = f ? ((1ull << f) - 1ull) : 0ull;
-                if ((~sm & below) == 0ull) d = f; // everything nearer than the final record is transparent
-            } else if (~sm == 0ull) {
+                if ((~tm & below) == 0ull && !skipped_weak) {
+                    d = f;        // only strongly transparent waves in between: that state IS the one that reaches me
+                    exact = true;
+                } else if (!direct && (~sm & below) == 0ull) {
+                    d = f;        // transparent if the state is still c0: to be checked
+                }
+            } else if (~tm == 0ull) {
+                base += 64; // 64 strongly transparent waves: look further back
+                continue;
+            } else if (!direct && ~sm == 0ull) {
+                skipped_weak = true;
                 base += 64; // 64 transparent waves: look further back
                 continue;
             }
             if (d < 0) {
                 base = 0; // something in between is not ready: look again from the nearest record
+                skipped_weak = false;
                 __builtin_amdgcn_s_sleep(2);
                 continue;
             }
@@ -892,20 +915,15 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             vt = __shfl(vt, d, 64);
             vx = __shfl(vx, d, 64);
             vd = __shfl(vd, d, 64);
-            if (d == 0 && base == 0) { // the direct predecessor: exact
+            if (exact || (vt == c0_tat && vx == c0_exp)) { // (the weakly transparent waves in between were right)
                 in_tat = vt;
                 in_exp = vx;
                 in_dirty = vd;
                 break;
             }
-            if (vt == c0_tat && vx == c0_exp) { // the transparent waves in between were right
-                in_tat = vt;
-                in_exp = vx;
-                in_dirty = vd;
-                break;
-            }
-            direct = true; // the state changed on the way: no shortcut
+            direct = true; // the state changed on the way: no shortcut through weakly transparent waves
             base = 0;
+            skipped_weak = false;
         }
         if (continued) {
             c.tat = in_tat;
@@ -967,7 +985,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         }
     }
     // the last lane of the piece owns the state the piece leaves
-    if (valid && lane == pend) {
+    if (valid && lane == pend && !strong_wave) { // (a strongly transparent wave hands on a state it never learnt: nothing to publish)
         const Cell out = was_allowed ? mine : c;
         const bool out_dirty = dirty || was_allowed;
         if (is_last) {

@@ -1300,7 +1300,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
                 prof_end(e, s);
             }
         } else {
-            if (++e->chain_seq == 0u) e->chain_seq = 1u; // 0 = "never written"
+            if (++e->chain_seq >= 0x7FFFFFFFu) e->chain_seq = 1u; // 0 = "never written"; 31 bits: the spec word carries a flag
             if (full) hipLaunchKernelGGL(k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
             else hipLaunchKernelGGL(k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
             prof_end(e, s);
