@@ -114,9 +114,10 @@ def parse():
                     help="uniform / zipf: one timestamp per batch (BASELINE configs[1] / [2]); general / general_zipf: the same "
                          "slot streams with a timestamp PER REQUEST, as every transport stamps them "
                          "(throttlecrab-server/src/transport/http.rs:128) -- k_eval_general")
-    ap.add_argument("--route", default="exchange", choices=["exchange", "replicate"],
-                    help="N > 1: exchange = every rank routes 1/N of the global stream and forwards the segments to their "
-                         "owners (peer copies); replicate = every rank filters the whole global stream")
+    ap.add_argument("--route", default="replicate", choices=["exchange", "replicate"],
+                    help="N > 1: replicate = every rank is handed the whole global batch and keeps what it owns (default: faster "
+                         "on every configuration that could be measured, DESIGN.md section 9); exchange = every rank routes only its "
+                         "1/N slice straight into the owners' inboxes (peer memory), per-GPU routing work independent of N")
     ap.add_argument("--keys", type=int, default=N_KEYS)
     ap.add_argument("--batch", type=int, default=BATCH)
     ap.add_argument("--cpu-sample-batches", type=int, default=8)
@@ -502,6 +503,131 @@ def secondary(a, t, W, eng2, ob, d_batches, dev, local, other):
     return also
 
 
+def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
+    """--route exchange: rank r is handed slice r (a.batch requests) of every global batch, routes it into one segment
+    per destination (tc_route_batch, only = -1), puts the segments into the destinations' inboxes (tc_forward_segments:
+    peer copies, no collective) and evaluates the `world` inboxes of a step as ONE batch (segmented slot column,
+    sources in rank order).  Per-GPU routing work is a.batch ids per step whatever the number of GPUs."""
+    import torch
+    from throttlecrab_amd import sharded
+    B = a.batch
+    G = world * B
+    eng = t.Engine(a.keys, 2 * B, device=local, fixed_params=(a.layout == "fixed"), track_denied=True)
+    eng.use_torch_stream()
+    eng.register_params_uniform(*W.REF_PARAMS)
+    n_distinct = 8
+    if a.workload == "zipf":
+        z = W.Zipf(world * a.keys)
+        host = [z.slots(B, seed=3, start=i * G + rank * B) for i in range(n_distinct)]   # slice `rank` of global batch i
+    else:
+        host = [W.uniform_slots(world * a.keys, B, seed=2, start=i * G + rank * B) for i in range(n_distinct)]
+    d_slice = [torch.from_numpy(h.astype(np.int32)).to(dev) for h in host]
+    xr = sharded.ExchangeRank(eng, fab, rank, world, B, route_ring=8)
+    outs = [t.BatchResult() for _ in range(OUT_RING)]
+    cnt_view = sharded.device_counter_view(eng)
+    gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
+    top_gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64, device=dev)
+    decided = 0
+    # the host never waits in steady state: a slice is routed (straight into the destinations' inboxes) LA_ROUTE steps and
+    # announced LA_POST steps before it is evaluated
+    LA_ROUTE, LA_POST = 4, 1
+
+    def step(i, last=False, metrics=True):
+        nonlocal decided
+        xr.timed("route", i + LA_ROUTE, d_slice[(i + LA_ROUTE) % n_distinct])
+        xr.timed("post", i + LA_POST)
+        segs = xr.timed("collect", i)
+        decided += xr.timed("evaluate", i, segs, W.T0_NS + i * 1_000_000, outs)
+        if not metrics:
+            return
+        if i % METRICS_EVERY == METRICS_EVERY - 1 or last:
+            eng.counters_refresh()
+            dist.all_gather_into_tensor(gathered, cnt_view)
+        if last:
+            block = torch.from_numpy(sharded.pack_top_denied(eng.top_denied(sharded.TOPK), rank, world, a.keys)).to(dev)
+            dist.all_gather_into_tensor(top_gathered, block)
+
+    for j in range(LA_ROUTE):
+        xr.route(j, d_slice[j % n_distinct])
+    for j in range(LA_POST):
+        xr.post(j)
+    it = 0
+    for _ in range(a.warmup):
+        step(it)
+        it += 1
+    dist.barrier()
+    torch.cuda.synchronize()
+    decided = 0
+    t0 = time.perf_counter()
+    for k in range(a.steps):
+        step(it, last=(k == a.steps - 1))
+        it += 1
+    torch.cuda.synchronize()
+    dist.barrier()
+    dt_mine = time.perf_counter() - t0
+    tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    dt = float(tm.item())
+    res = sharded_summary(a, t, W, eng, dev, rank, world, dist, dt, decided, G, cnt_view, top_gathered)
+    res["route"] = "exchange"
+    res["host_us_per_step"] = {k: 1e6 * v / (a.steps + a.warmup) for k, v in xr.host_s.items()}  # where the host's time goes
+    print(f"[bench] rank {rank} host us/step: {res['host_us_per_step']}", file=sys.stderr, flush=True)
+    # roofline of this rank's evaluation: HIP events per kernel (needs no peers: the inboxes of the last steps again)
+    steps_p = min(a.steps, 12)
+    segs_last = [xr.collect(it - 1 - (k % 2)) for k in range(2)]
+    eng.profile_enable(True)
+    n_prof = 0
+    for k in range(steps_p):
+        n_prof += xr.evaluate(it + 100 + k, segs_last[k % 2], W.T0_NS + (it + k) * 1_000_000, outs)
+    torch.cuda.synchronize()
+    prof = eng.profile_read()
+    eng.profile_enable(False)
+    stages = {k: {"kernel": KERNEL_OF_STAGE[k], "launches_per_batch": calls / steps_p, "avg_ms": ms / calls, "per_batch_ms": ms / steps_p}
+              for k, (ms, calls) in prof.items() if calls}
+    if stages:
+        alg = ALG_BYTES_PER_DECISION * n_prof / steps_p
+        ev = stages.get("eval") or stages.get("bucket_eval")
+        if ev and ev["launches_per_batch"] >= 0.999:
+            res["roofline"] = roofline_entry(ev["kernel"], ev["per_batch_ms"], alg, 1e3 * dt / a.steps, None,
+                                             {"avg_ms": f"HIP events, rank {rank}, per-step total of the evaluation launches", "traffic": None})
+        res["stages"] = stages
+    # the routing front end alone (this rank's slice routed straight into the inboxes, 8 routers drained), for the record;
+    # the inboxes are scratch by now -- once every rank has left its profile steps
+    dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for k in range(8):
+        eng.route_batch(d_slice[k % n_distinct], world, only=-1, out=(None, None, xr.counts_dev[k % xr.route_ring]), ahead=True, no_readers=True,
+                        out_dst=[fab.inbox(d, k % fab.ring, rank) for d in range(world)])
+    torch.cuda.synchronize()
+    res["router_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / 8
+    dist.barrier()
+    eng.close()
+    return res
+
+
+def sharded_summary(a, t, W, eng, dev, rank, world, dist, dt, decided, G, cnt_view, top_gathered):
+    """what every --route mode reports: whole-job rate, per-GPU shares, imbalance, the metrics exchange"""
+    import torch
+    from throttlecrab_amd import sharded
+    c = eng.counters()
+    mine = torch.tensor([decided, c["allowed"], c["denied"]], dtype=torch.int64, device=dev)
+    everyone = torch.zeros(world * 3, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(everyone, mine)
+    ev = everyone.view(world, 3).cpu().numpy()
+    total_decided = int(ev[:, 0].sum())
+    assert total_decided == a.steps * G, (total_decided, a.steps * G)   # every request of the global stream has one owner
+    per_gpu = [{"rank": r, "decisions": int(ev[r, 0]), "share_of_traffic": float(ev[r, 0]) / max(1, total_decided),
+                "decisions_per_s": float(ev[r, 0]) / dt,
+                "allowed_fraction_since_start": float(ev[r, 1]) / max(1, int(ev[r, 1] + ev[r, 2]))} for r in range(world)]
+    return {"value": total_decided / dt, "ms_per_step": 1e3 * dt / a.steps, "per_gpu": per_gpu,
+            "imbalance_max_over_mean": float(ev[:, 0].max()) / max(1.0, float(ev[:, 0].mean())),
+            "allowed_fraction": float(ev[:, 1].sum()) / max(1, int(ev[:, 1].sum() + ev[:, 2].sum())),
+            "metrics_exchange": {"counter_block_bytes_per_gpu": 8 * int(cnt_view.numel()), "every_steps": METRICS_EVERY,
+                                 "top_denied_block_bytes_per_gpu": 16 * sharded.TOPK, "top_denied_exchanges": 1,
+                                 "top_denied_global": sharded.merge_top_denied(top_gathered.cpu().numpy(), 5)}}
+
+
 def run_sharded(a, t, W, dev, local, rank, world, dist):
     """The N > 1 path (also taken with TC_BENCH_FORCE_DIST=1 on one GPU)."""
     import torch
@@ -583,22 +709,8 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     dt = float(tm.item())
-    c = eng.counters()
-    mine = torch.tensor([decided, c["allowed"], c["denied"]], dtype=torch.int64, device=dev)
-    everyone = torch.zeros(world * 3, dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(everyone, mine)
-    ev = everyone.view(world, 3).cpu().numpy()
-    total_decided = int(ev[:, 0].sum())
-    assert total_decided == a.steps * G, (total_decided, a.steps * G)   # every request of the global stream has one owner
-    per_gpu = [{"rank": r, "decisions": int(ev[r, 0]), "share_of_traffic": float(ev[r, 0]) / max(1, total_decided),
-                "decisions_per_s": float(ev[r, 0]) / dt,
-                "allowed_fraction_since_start": float(ev[r, 1]) / max(1, int(ev[r, 1] + ev[r, 2]))} for r in range(world)]
-    res = {"value": total_decided / dt, "ms_per_step": 1e3 * dt / a.steps, "per_gpu": per_gpu,
-           "imbalance_max_over_mean": float(ev[:, 0].max()) / max(1.0, float(ev[:, 0].mean())),
-           "allowed_fraction": float(ev[:, 1].sum()) / max(1, int(ev[:, 1].sum() + ev[:, 2].sum())),
-           "metrics_exchange": {"counter_block_bytes_per_gpu": 8 * int(cnt_view.numel()), "every_steps": METRICS_EVERY,
-                                "top_denied_block_bytes_per_gpu": 16 * sharded.TOPK, "top_denied_exchanges": 1,
-                                "top_denied_global": sharded.merge_top_denied(top_gathered.cpu().numpy(), 5)}}
+    res = sharded_summary(a, t, W, eng, dev, rank, world, dist, dt, decided, G, cnt_view, top_gathered)
+    res["route"] = "replicate"
     # roofline of this rank's evaluation (same kernels as the N = 1 run, fed by the router): HIP events per kernel
     steps_p = min(a.steps, 20)
     decided = 0
@@ -640,8 +752,14 @@ def main():
     if world > 1 or os.environ.get("TC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if os.environ.get("TC_BENCH_ONE_DEVICE") == "1":  # several ranks on ONE GPU (what a 1-GPU box can test of the N > 1 path)
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if os.environ.get("TC_BENCH_ONE_DEVICE") == "1":
+            dist.init_process_group("gloo")   # (RCCL refuses two ranks on one GPU; gloo carries the metrics through host memory)
+            _patch_collectives_for_gloo(dist)
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     else:
         torch.cuda.set_device(0)
         local = 0
@@ -651,7 +769,29 @@ def main():
         # a real stream for the engine AND torch / RCCL (torch's default stream has handle 0, which the engine reads as
         # "use your own stream": the metrics all-gather would then not be ordered behind the counters' refresh)
         with torch.cuda.stream(torch.cuda.Stream(device=dev)):
-            sh = run_sharded(a, t, W, dev, local, rank, world, dist)
+            fab = None
+            if a.route == "exchange":
+                # inboxes shared through IPC handles, mailboxes in shared memory: set up ONCE, outside the timed region.
+                # Every rank must succeed, else all of them fall back to --route replicate (which needs no peer memory).
+                from throttlecrab_amd import sharded
+                ok = 1
+                try:
+                    fab = sharded.IpcFabric(dist, rank, world, a.batch, 8, dev)  # 8 ring slots of world x batch ids per rank
+                except Exception as ex:  # noqa: BLE001 (whatever the IPC layer raises: fall back, but say so)
+                    print(f"[bench] rank {rank}: exchange set-up failed ({type(ex).__name__}: {ex}); falling back to --route replicate",
+                          file=sys.stderr, flush=True)
+                    ok = 0
+                flag = torch.tensor([ok], dtype=torch.int64, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    if fab is not None:
+                        fab.close()
+                    fab = None
+            if fab is not None:
+                sh = run_exchange(a, t, W, dev, local, rank, world, dist, fab)
+                fab.close()
+            else:
+                sh = run_sharded(a, t, W, dev, local, rank, world, dist)
             torch.cuda.synchronize()
         if rank == 0:
             res = {
@@ -736,6 +876,23 @@ def main():
             result["cpu_baseline"] = cpu_baseline(stream, a.keys, a.batch, a.cpu_sample_batches)
         emit(result, detail)
     eng.close()
+
+
+def _patch_collectives_for_gloo(dist):
+    """TC_BENCH_ONE_DEVICE=1 only: gloo has no all_gather_into_tensor and reduces CUDA tensors through the host"""
+    import torch
+    real_ag, real_ar = dist.all_gather, dist.all_reduce
+
+    def all_gather_into_tensor(out, inp):
+        parts = [torch.zeros_like(inp, device="cpu") for _ in range(dist.get_world_size())]
+        real_ag(parts, inp.cpu())
+        out.copy_(torch.cat([p.reshape(-1) for p in parts]).reshape(out.shape))
+
+    def all_reduce(tns, op=dist.ReduceOp.SUM):
+        c = tns.cpu()
+        real_ar(c, op=op)
+        tns.copy_(c)
+    dist.all_gather_into_tensor, dist.all_reduce = all_gather_into_tensor, all_reduce
 
 
 def _pick(d, keys):

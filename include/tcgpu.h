@@ -172,7 +172,20 @@ typedef struct tc_batch {
     int64_t* result4;        /* [n][4] */
     struct tc_decision* decisions; /* [n] 32-byte records (see tc_decision below); 16-byte aligned */
     uint32_t* order;         /* [n] TC_B_GROUPED_OUTPUT: request index of each output row */
+
+    /* A slot column that arrives in PIECES (tc_rate_limit_batch_slots, TC_B_DEVICE_PTRS): n_segments > 0 replaces
+     * `slot` by seg_slot[0..n_segments) -- HOST arrays of device pointers and lengths, sum(seg_n) == n -- taken one
+     * after the other: request i of the batch is the i-th entry of the concatenation.  What a shard of a multi-GPU
+     * deployment receives: one segment per source GPU, in source order, so that a key's requests keep the order
+     * of the global stream (tc_route_batch with only = -1 produces the segments).  The engine gathers the pieces on
+     * the stream that groups the batch; with TC_B_INPUTS_READY every piece is complete in device memory at call time.
+     * At most TC_MAX_SEGMENTS pieces. */
+    uint32_t n_segments;
+    uint32_t reserved_seg;
+    const uint32_t* const* seg_slot; /* host array [n_segments] of device pointers */
+    const uint32_t* seg_n;           /* host array [n_segments] */
 } tc_batch;
+#define TC_MAX_SEGMENTS 64
 
 /* Everything rate_limit returns for one request except `limit` (== the request's max_burst, resp.
  * the key's registered burst), as ONE 32-byte record: a full result then costs a single scattered
@@ -336,6 +349,8 @@ int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_b
                                * not wait for one another (give each its own out_* buffers): it then
                                * works beside the evaluations of earlier batches instead of between them -- with
                                * out_count_host, the way to route several global batches ahead of the evaluation */
+#define TC_ROUTE_NO_READERS 0x2u /* with TC_ROUTE_AHEAD: out_slot is not the slot column of any batch still in flight (the
+                               * caller forwards the segments elsewhere, tc_forward_segments): the router waits for nothing */
 typedef struct tc_route {
     uint32_t struct_size;     /* = sizeof(tc_route) */
     uint32_t world;           /* number of shards (GPUs), 1..64 */
@@ -357,8 +372,30 @@ typedef struct tc_route {
                                * owns: once the tag is there, out_slot / out_pos are complete too. */
     uint32_t tag;             /* any value the previous use of out_count_host did not leave there */
     uint32_t reserved1;
+    uint32_t* const* out_dst; /* NULL, or (only == -1) a HOST array [world] of device pointers: segment d is written to
+                               * out_dst[d], from its start, instead of into out_slot (which may then be NULL; out_pos is
+                               * not written) -- out_dst[d] is the inbox destination d keeps for this source, in d's own
+                               * memory (peer memory over xGMI, hipIpcOpenMemHandle): routing and forwarding in one pass.
+                               * Once out_count_host carries the tag, every segment has landed. */
 } tc_route;
 int tc_route_batch(tc_engine* e, const tc_route* r);
+/* The exchange step of a sharded deployment in which every GPU routes only ITS slice of the global stream
+ * (tc_route_batch with only = -1: one segment per destination, one after the other in out_slot): copy segment d to
+ * dst[d] -- the inbox the destination keeps for this source, in its own memory (peer memory over xGMI, mapped
+ * through hipIpcOpenMemHandle; dst[own rank] is local) -- in ONE launch on `stream` (NULL: the engine's stream).
+ * count[] is the host copy of tc_route.out_count (out_count_host).  Peer copies, no collective: the decision path
+ * of the reference has none either (README.md:247-249 shards on the client).  The destination evaluates the
+ * inboxes of a step as one batch with a segmented slot column (tc_batch.seg_slot), sources in rank order. */
+typedef struct tc_forward {
+    uint32_t struct_size;      /* = sizeof(tc_forward) */
+    uint32_t world;            /* 1..64 */
+    const uint32_t* src;       /* device: the router's out_slot */
+    const uint32_t* count;     /* HOST [world]: requests per destination */
+    uint32_t* const* dst;      /* HOST [world]: device pointers, dst[d] has room for count[d] entries */
+    void* stream;              /* hipStream_t or NULL */
+} tc_forward;
+int tc_forward_segments(tc_engine* e, const tc_forward* f);
+
 /* The same map on the host: owner and shard-local slot of n global ids (either output may be NULL), and its
  * inverse (global id of slot `slot` of shard `owner`).  No device needed. */
 int tc_route_host(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* global_id, uint32_t* owner,

@@ -35,6 +35,7 @@ pub const TC_B_ASYNC: u32 = 0x20;
 pub const TC_B_OUTPUTS_IDLE: u32 = 0x40;
 
 pub const TC_ROUTE_AHEAD: u32 = 0x1;
+pub const TC_ROUTE_NO_READERS: u32 = 0x2;
 
 pub const TC_CNT_TOTAL: usize = 0;
 pub const TC_CNT_ALLOWED: usize = 1;
@@ -90,6 +91,10 @@ pub struct tc_batch {
     pub result4: *mut i64,
     pub decisions: *mut tc_decision,
     pub order: *mut u32,
+    pub n_segments: u32,
+    pub reserved_seg: u32,
+    pub seg_slot: *const *const u32,
+    pub seg_n: *const u32,
 }
 
 #[repr(C)]
@@ -130,6 +135,17 @@ pub struct tc_route {
     pub out_count_host: *mut u32,
     pub tag: u32,
     pub reserved1: u32,
+    pub out_dst: *const *mut u32,
+}
+
+#[repr(C)]
+pub struct tc_forward {
+    pub struct_size: u32,
+    pub world: u32,
+    pub src: *const u32,
+    pub count: *const u32,
+    pub dst: *const *mut u32,
+    pub stream: *mut c_void,
 }
 
 extern "C" {
@@ -178,6 +194,7 @@ extern "C" {
         was_set: *mut c_int,
     ) -> c_int;
     pub fn tc_route_batch(e: *mut tc_engine, r: *const tc_route) -> c_int;
+    pub fn tc_forward_segments(e: *mut tc_engine, f: *const tc_forward) -> c_int;
     pub fn tc_route_host(world: u32, keys_per_shard: u64, n: u64, global_id: *const u32, owner: *mut u32, slot: *mut u32) -> c_int;
     pub fn tc_route_inverse(world: u32, keys_per_shard: u64, n: u64, owner: *const u32, slot: *const u32, global_id: *mut u64) -> c_int;
     pub fn tc_engine_set_stream(e: *mut tc_engine, hip_stream: *mut c_void) -> c_int;

@@ -232,6 +232,10 @@ impl GpuRateLimiter {
             result4: std::ptr::null_mut(),
             decisions: dec.as_mut_ptr(),
             order: std::ptr::null_mut(),
+            n_segments: 0,
+            reserved_seg: 0,
+            seg_slot: std::ptr::null(),
+            seg_n: std::ptr::null(),
         };
         let rc = unsafe { ffi::tc_rate_limit_batch_keys(self.store.e, &b) };
         if rc != 0 && rc != ffi::TC_E_TABLE_FULL {

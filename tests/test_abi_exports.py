@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libtcgpu.so does not export {name}"
     assert set(_lib.SYMBOLS) == set(declared), set(_lib.SYMBOLS) ^ set(declared)
     assert lib.tc_abi_version() == 1
-    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 10 * 8  # incl. result4, decisions, order
+    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 10 * 8 + 8 + 16  # incl. result4, decisions, order, segments
     assert ctypes.sizeof(_lib.tc_config) == 40
 
 
@@ -94,4 +94,5 @@ def test_python_constants_match_the_header():
     assert L.tc_batch.result4.offset == 8 + 8 + 8 * 8 + 5 * 8 + 7 * 8
     assert L.tc_batch.decisions.offset == L.tc_batch.result4.offset + 8
     assert L.tc_batch.order.offset == L.tc_batch.decisions.offset + 8
-    assert C.sizeof(L.tc_batch) == L.tc_batch.order.offset + 8
+    assert L.tc_batch.n_segments.offset == L.tc_batch.order.offset + 8
+    assert C.sizeof(L.tc_batch) == L.tc_batch.order.offset + 8 + 8 + 16

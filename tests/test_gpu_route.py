@@ -136,3 +136,119 @@ def test_router_ahead_of_pipelined_batches(how):
         assert np.array_equal(status.cpu().numpy(), ref.status.astype(np.uint8)), i
     assert eng.selfcheck() == 0
     eng.close()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("stream_kind", ["uniform", "zipf"])
+def test_exchange_between_engines_equals_one_sequential_pass(world, stream_kind):
+    """--route exchange with every shard in ONE process (sharded.LocalFabric: a peer copy degenerates to a device-to-device
+    copy): rank r routes only slice r of each global batch (tc_route_batch, only = -1), tc_forward_segments puts the
+    segments into the destinations' inboxes, every destination evaluates its `world` inboxes as ONE batch with a
+    segmented slot column, sources in rank order.  The union of the shards' decisions == one sequential pass of the
+    oracle keyed by the global id, although no shard ever sees the whole stream."""
+    import torch
+
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    from tests.test_gpu_slots import T0
+    from throttlecrab_amd import sharded
+    from throttlecrab_amd import workload as W
+    cap, B, steps, LA = 6000, 20_000, 9, 2
+    n_glob = world * cap
+    rng = np.random.default_rng(world)
+    z = W.Zipf(n_glob)
+    glob = [(z.slots(world * B, start=i * world * B) if stream_kind == "zipf" else rng.integers(0, n_glob, world * B)).astype(np.uint32)
+            for i in range(steps)]
+    dev = torch.device("cuda:0")
+    fab = sharded.LocalFabric(world, B, ring=4, device=dev)
+    engs, ranks = [], []
+    for r in range(world):
+        e = t.Engine(cap, 2 * B, fixed_params=True)
+        e.use_torch_stream()
+        e.register_params_uniform(5, 10, 60)
+        engs.append(e)
+        ranks.append(sharded.ExchangeRank(e, fab, r, world, B, route_ring=4))
+    d_slices = [[torch.from_numpy(g[r * B:(r + 1) * B].astype(np.int32)).to(dev) for r in range(world)] for g in glob]
+    outs = [[t.BatchResult() for _ in range(8)] for _ in range(world)]
+    got = {}  # (step, rank) -> (segments' counts, result)
+    # the same pipeline bench.py runs per rank, all ranks stepped in one loop
+    for i in range(steps + LA):
+        for r in range(world):
+            if i < steps:
+                ranks[r].route(i, d_slices[i][r])
+        for r in range(world):
+            if 0 <= i - 1 < steps:
+                ranks[r].post(i - 1)
+        for r in range(world):
+            st = i - LA
+            if 0 <= st < steps:
+                segs = ranks[r].collect(st)
+                res = t.BatchResult()
+                n = ranks[r].evaluate(st, segs, T0 + st * 300_000_000, [res])
+                got[(st, r)] = ([c for _, c in segs], res, n)
+    torch.cuda.synchronize()
+    ref_orc = O.DenseOracle(n_glob)
+    for st in range(steps):
+        g = glob[st]
+        ref = ref_orc.batch_slots(g, 5, 10, 60, 1, T0 + st * 300_000_000)
+        owner, _ = sharded.route(g, world, cap)
+        for r in range(world):
+            counts, res, n = got[(st, r)]
+            # what rank r evaluated, in its order: for each source s, the requests of slice s that r owns
+            idx = np.concatenate([s * B + np.nonzero(owner[s * B:(s + 1) * B] == r)[0] for s in range(world)])
+            assert counts == [int((owner[s * B:(s + 1) * B] == r).sum()) for s in range(world)]
+            assert n == len(idx)
+            assert np.array_equal(res.allowed.cpu().numpy()[:n], ref.allowed[idx].astype(np.uint8)), (st, r)
+    for e in engs:
+        assert e.selfcheck() == 0
+        e.close()
+    fab.close()
+
+
+def test_segmented_slot_column_equals_the_concatenation():
+    """tc_batch.seg_slot: pieces of any size (empty ones included), in order and pipelined, full result"""
+    import torch
+
+    import throttlecrab_amd as t
+    from tests.test_gpu_slots import FIELDS, T0, _oracle, assert_same
+    cap = 3000
+    eng, orc = t.Engine(cap, 1 << 16), _oracle(cap)
+    eng.use_torch_stream()
+    eng.register_params_uniform(5, 10, 60)
+    rng = np.random.default_rng(12)
+    for rnd, sizes in enumerate(([7], [0, 5, 0], [1000, 1, 63, 64, 65, 0, 4097], [30000, 20000], [1] * 64)):
+        pieces = [rng.integers(0, cap, n).astype(np.uint32) for n in sizes]
+        d = [torch.from_numpy(np.concatenate([p, rng.integers(0, cap, 5).astype(np.uint32)]).astype(np.int32)).cuda() for p in pieces]  # (slack behind each piece)
+        whole = np.concatenate(pieces)
+        ref = orc.batch_slots(whole, 5, 10, 60, 1, T0 + rnd * 10**9)
+        res = eng.rate_limit_batch_slots(None, segments=[(x, n) for x, n in zip(d, sizes)], registered=True, quantity=1, now_ns=T0 + rnd * 10**9,
+                                         want=FIELDS, inputs_ready=bool(rnd % 2))
+        torch.cuda.synchronize()
+        assert_same(res, ref, f"round {rnd}")
+    with pytest.raises(t.engine.TcError):
+        eng.rate_limit_batch_slots(None, segments=[(d[0], 1)] * 65 if False else [(d[0], 1)], registered=True, quantity=1, now_ns=T0, unique=True)
+    assert eng.selfcheck() == 0
+    eng.close()
+
+
+def test_forward_segments_copies_every_piece_to_its_destination():
+    """tc_forward_segments: the router's contiguous segments -> one destination buffer each, in one launch"""
+    import torch
+
+    import throttlecrab_amd as t
+    from throttlecrab_amd import sharded
+    world, cap, n = 5, 1000, 40_000
+    ids = np.random.default_rng(2).integers(0, world * cap, n).astype(np.uint32)
+    eng = t.Engine(cap, 1 << 16)
+    eng.use_torch_stream()
+    slots, _, counts = eng.route_batch(torch.from_numpy(ids.astype(np.int32)).cuda(), world, only=-1)
+    torch.cuda.synchronize()
+    cnt = counts.cpu().numpy().tolist()
+    dsts = [torch.full((max(c, 1) + 3,), -1, dtype=torch.int32, device="cuda") for c in cnt]
+    eng.forward_segments(slots, cnt, dsts)
+    torch.cuda.synchronize()
+    segs = sharded.split_segments(ids, world, cap)
+    for d in range(world):
+        got = dsts[d].cpu().numpy()
+        assert np.array_equal(got[:cnt[d]].astype(np.uint32), segs[d]) and (got[cnt[d]:] == -1).all(), d
+    eng.close()

@@ -14,7 +14,7 @@ LIB = open(os.path.join(ROOT, "rust", "throttlecrab-gpu", "src", "lib.rs")).read
 C_SCALARS = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": "u64", "int8_t": "i8", "int32_t": "i32",
              "int64_t": "i64", "size_t": "usize", "int": "c_int", "char": "c_char", "void": "c_void", "double": "f64",
              "tc_engine": "tc_engine", "tc_config": "tc_config", "tc_batch": "tc_batch", "tc_result": "tc_result",
-             "tc_decision": "tc_decision", "tc_route": "tc_route"}
+             "tc_decision": "tc_decision", "tc_route": "tc_route", "tc_forward": "tc_forward"}
 
 
 def strip_comments(c):
@@ -22,15 +22,16 @@ def strip_comments(c):
 
 
 def c_type_to_rust(t):
-    """'const uint32_t*' -> '*const u32', 'struct tc_decision*' -> '*mut tc_decision', 'int64_t' -> 'i64'"""
-    t = t.replace("struct ", "").strip()
-    stars = t.count("*")
-    base = t.replace("*", "").strip()
-    const = base.startswith("const ")
-    base = base[6:].strip() if const else base
+    """'const uint32_t*' -> '*const u32', 'struct tc_decision*' -> '*mut tc_decision', 'int64_t' -> 'i64',
+    'const uint32_t* const*' -> '*const *const u32', 'uint32_t* const*' -> '*const *mut u32'"""
+    parts = [x.strip() for x in t.replace("struct ", "").strip().split("*")]
+    base = parts[0]
+    pointee_const = base.startswith("const ") or base.endswith(" const")
+    base = base.replace("const", "").strip()
     rust = C_SCALARS[base]
-    for _ in range(stars):
-        rust = ("*const " if const else "*mut ") + rust
+    for qual in parts[1:]:  # one pointer level per '*': what it points to is const if the level to its left said so
+        rust = ("*const " if pointee_const else "*mut ") + rust
+        pointee_const = "const" in qual.split()
     return rust
 
 
@@ -61,7 +62,7 @@ def rust_structs():
 
 def test_repr_c_structs_match_the_header():
     c, r = c_structs(), rust_structs()
-    for name in ("tc_config", "tc_batch", "tc_decision", "tc_result", "tc_route"):
+    for name in ("tc_config", "tc_batch", "tc_decision", "tc_result", "tc_route", "tc_forward"):
         assert name in c and name in r, name
         assert r[name] == c[name], f"{name}: rust {r[name]} != header {c[name]}"
     assert r["tc_engine"] == [("_private", "[u8; 0]")]  # opaque

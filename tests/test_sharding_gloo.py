@@ -115,11 +115,98 @@ def test_route_is_a_bijection_onto_dense_shards():
         sharded.route(np.zeros(1, np.uint32), 65, 10)
 
 
-def test_owner_is_stable_and_balanced():
+def _exchange_worker(rank, world, port, q):
+    """--route exchange on CPU: every rank routes only ITS slice of each global batch into one segment per destination
+    (sharded.split_segments == tc_route_batch(only = -1)), the segments travel point to point (gloo send / recv here,
+    peer copies on GPUs), and a destination evaluates what it received as one batch, sources in rank order."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
     from throttlecrab_amd import sharded
-    ids = np.arange(100000, dtype=np.uint64)
-    for world in (2, 4, 8):
-        o = sharded.owner_of(ids, world)
-        assert np.array_equal(o, sharded.owner_of(ids, world))
-        cnt = np.bincount(o, minlength=world)
-        assert cnt.min() > 0.9 * len(ids) / world
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    gids, now = _global_stream(world)
+    n_batches, B = 8, N_REQ // 8 // world           # a global batch = world slices of B requests
+    orc = O.DenseOracle(N_KEYS)
+    allowed_global = np.zeros(N_REQ, np.int64)
+    cover = np.zeros(N_REQ, np.int64)
+    decided = 0
+    for b in range(n_batches):
+        lo = b * world * B
+        my_slice = gids[lo + rank * B: lo + (rank + 1) * B]
+        owner, slot = sharded.route(my_slice, world, N_KEYS)
+        segs = sharded.split_segments(my_slice, world, N_KEYS)
+        pos_of = [lo + rank * B + np.nonzero(owner == d)[0] for d in range(world)]   # (test only: where each request came from)
+        assert all(np.array_equal(segs[d], slot[owner == d]) for d in range(world))
+        # point-to-point: lower rank sends first (two ranks: no deadlock)
+        recv_slots, recv_pos = [None] * world, [None] * world
+        recv_slots[rank], recv_pos[rank] = segs[rank], pos_of[rank]
+        for peer in range(world):
+            if peer == rank:
+                continue
+            def send():
+                hdr = torch.tensor([len(segs[peer])], dtype=torch.int64)
+                dist.send(hdr, peer)
+                if len(segs[peer]):
+                    dist.send(torch.from_numpy(segs[peer].astype(np.int64)), peer)
+                    dist.send(torch.from_numpy(pos_of[peer].astype(np.int64)), peer)
+            def recv():
+                hdr = torch.zeros(1, dtype=torch.int64)
+                dist.recv(hdr, peer)
+                n = int(hdr[0])
+                a, c = torch.zeros(n, dtype=torch.int64), torch.zeros(n, dtype=torch.int64)
+                if n:
+                    dist.recv(a, peer)
+                    dist.recv(c, peer)
+                recv_slots[peer], recv_pos[peer] = a.numpy().astype(np.uint32), c.numpy()
+            if rank < peer:
+                send(); recv()
+            else:
+                recv(); send()
+        # sources in rank order: a key's requests keep the order of the global stream
+        slots_cat, pos_cat = np.concatenate(recv_slots), np.concatenate(recv_pos)
+        assert np.all(np.diff(pos_cat) > 0)          # the concatenation IS in global order
+        res = orc.batch_slots(slots_cat, 5, 50, 60, 1, now[pos_cat])
+        allowed_global[pos_cat] = res.allowed
+        cover[pos_cat] += 1
+        decided += len(pos_cat)
+    t, c = torch.from_numpy(allowed_global), torch.from_numpy(cover)
+    dist.all_reduce(t)
+    dist.all_reduce(c)
+    if rank == 0:
+        q.put((t.numpy().tolist(), c.numpy().tolist(), n_batches * world * B))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_matches_single_pass():
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exchange_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    allowed, cover, n_used = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    gids, now = _global_stream(2)
+    ref = O.DenseOracle(2 * N_KEYS).batch_slots(gids[:n_used], 5, 50, 60, 1, now[:n_used])  # one pass, keyed by the global id
+    assert all(c == 1 for c in cover[:n_used]), "every request reaches exactly one owner"
+    assert np.array_equal(np.array(allowed[:n_used]), ref.allowed.astype(np.int64))
+    assert 0 < ref.allowed.sum() < n_used
+
+
+def test_split_segments_is_the_router_with_every_destination():
+    from throttlecrab_amd import sharded
+    rng = np.random.default_rng(4)
+    for world, cap in ((2, 5000), (3, 77), (8, 4096)):
+        ids = rng.integers(0, world * cap, 20000).astype(np.uint32)
+        segs = sharded.split_segments(ids, world, cap)
+        assert sum(len(s) for s in segs) == len(ids)
+        for d in range(world):
+            pos, slots = sharded.shard_requests(ids, world, d, cap)
+            assert np.array_equal(segs[d], slots)

@@ -22,6 +22,7 @@ TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY, 
 TC_B_ASYNC = 0x20
 TC_B_OUTPUTS_IDLE = 0x40
 TC_ROUTE_AHEAD = 0x1
+TC_ROUTE_NO_READERS = 0x2
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")
 TC_CNT_COUNT = 8
 TC_STAGE_NAMES = ("prep", "sort", "eval", "commit", "pack", "hash", "bucket_hist", "bucket_scan", "bucket_scatter",
@@ -44,13 +45,19 @@ class tc_batch(C.Structure):
                 ("period_scalar", C.c_int64), ("quantity_scalar", C.c_int64), ("now_ns_scalar", C.c_int64),
                 ("allowed", C.c_void_p), ("allowed_bits", C.c_void_p), ("limit", C.c_void_p),
                 ("remaining", C.c_void_p), ("reset_after_ns", C.c_void_p), ("retry_after_ns", C.c_void_p),
-                ("status", C.c_void_p), ("result4", C.c_void_p), ("decisions", C.c_void_p), ("order", C.c_void_p)]
+                ("status", C.c_void_p), ("result4", C.c_void_p), ("decisions", C.c_void_p), ("order", C.c_void_p),
+                ("n_segments", C.c_uint32), ("reserved_seg", C.c_uint32), ("seg_slot", C.c_void_p), ("seg_n", C.c_void_p)]
+
+
+class tc_forward(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("world", C.c_uint32), ("src", C.c_void_p), ("count", C.c_void_p),
+                ("dst", C.c_void_p), ("stream", C.c_void_p)]
 
 
 class tc_route(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("world", C.c_uint32), ("keys_per_shard", C.c_uint64), ("n", C.c_uint64),
                 ("global_id", C.c_void_p), ("only", C.c_int32), ("flags", C.c_uint32), ("out_slot", C.c_void_p),
-                ("out_pos", C.c_void_p), ("out_count", C.c_void_p), ("stream", C.c_void_p), ("out_count_host", C.c_void_p), ("tag", C.c_uint32), ("reserved1", C.c_uint32)]
+                ("out_pos", C.c_void_p), ("out_count", C.c_void_p), ("stream", C.c_void_p), ("out_count_host", C.c_void_p), ("tag", C.c_uint32), ("reserved1", C.c_uint32), ("out_dst", C.c_void_p)]
 
 
 class tc_result(C.Structure):
@@ -97,6 +104,7 @@ SYMBOLS = {
     "tc_snapshot_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_snapshot_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_route_batch": (C.c_int, [C.c_void_p, C.POINTER(tc_route)]),
+    "tc_forward_segments": (C.c_int, [C.c_void_p, C.POINTER(tc_forward)]),
     "tc_route_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_route_inverse": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_slot_keys": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

@@ -304,6 +304,40 @@ __global__ void k_probe_set(uint32_t* flag) {
 }
 
 // ---------------------------------------------------------------------------
+// A slot column that arrives in pieces (tc_batch.seg_slot: one piece per source GPU of a sharded deployment) gathered
+// into one column: block b copies entries [b * PER_BLOCK, ...) of the concatenation, finding its piece by a walk over
+// the (at most 64) prefix sums.
+// ---------------------------------------------------------------------------
+struct Segments {
+    const uint32_t* ptr[64];
+    uint32_t start[65]; // prefix sums; start[n] = total
+    uint32_t n;
+};
+__global__ __launch_bounds__(BLOCK) void k_concat(Segments sg, uint32_t* __restrict__ out) {
+    const uint32_t total = sg.start[sg.n];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += gridDim.x * BLOCK) {
+        uint32_t s = 0;
+        while (s + 1 < sg.n && i >= sg.start[s + 1]) ++s;
+        out[i] = sg.ptr[s][i - sg.start[s]];
+    }
+}
+
+// the other direction: one column (the router's segments, one after the other) scattered to one destination per segment
+struct Destinations {
+    uint32_t* ptr[64];
+    uint32_t start[65];
+    uint32_t n;
+};
+__global__ __launch_bounds__(BLOCK) void k_forward(const uint32_t* __restrict__ src, Destinations ds) {
+    const uint32_t total = ds.start[ds.n];
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += gridDim.x * BLOCK) {
+        uint32_t s = 0;
+        while (s + 1 < ds.n && i >= ds.start[s + 1]) ++s;
+        ds.ptr[s][i - ds.start[s]] = src[i];
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Plain copy, used for device memory -> PINNED host memory (which the GPU addresses directly): the result
 // transfers of TC_B_ASYNC batches are ordinary kernels on the engine's stream (see copy_back_async).
 // 16 bytes per lane per step when both ends and the size allow, else bytes.

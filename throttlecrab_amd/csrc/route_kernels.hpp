@@ -144,15 +144,21 @@ __global__ __launch_bounds__(THREADS) void k_route_scan(Work w) {
     if (threadIdx.x == THREADS - 1) w.totals[blockIdx.x] = s_part[THREADS - 1];
 }
 
+// SPLIT (only < 0): segment d goes to dst.ptr[d], from its start -- the destination's inbox in ITS memory (peer memory
+// over xGMI) -- instead of into one column: the exchange of a sharded deployment needs no separate forwarding step
+struct SplitOut {
+    uint32_t* ptr[MAX_WORLD];
+};
+template <bool SPLIT>
 __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __restrict__ id, uint32_t n, Map m, Work w, int only,
-                                                            uint32_t* __restrict__ out_slot, uint32_t* __restrict__ out_pos) {
+                                                            uint32_t* __restrict__ out_slot, uint32_t* __restrict__ out_pos, SplitOut dst) {
     __shared__ uint32_t s_wave[THREADS / 64][MAX_WORLD]; // per-wave counts -> exclusive prefix over the waves
     __shared__ uint32_t s_start[MAX_WORLD];              // where each destination's segment starts in the output
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < (THREADS / 64) * MAX_WORLD; i += THREADS) (&s_wave[0][0])[i] = 0;
     if (threadIdx.x < m.world) {
         uint32_t at = 0;
-        if (only < 0)
+        if (only < 0 && !SPLIT)
             for (uint32_t k = 0; k < threadIdx.x; ++k) at += w.totals[k];
         s_start[threadIdx.x] = at;
     }
@@ -194,8 +200,12 @@ __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __res
         const uint32_t pos = first + j * 64, d = dest[j];
         if (pos < n && (only < 0 || d == (uint32_t)only)) {
             const uint32_t at = s_start[d] + w.tile_cnt[(size_t)d * w.tiles + blockIdx.x] + s_wave[wave][d] + rank[j];
-            out_slot[at] = slot[j];
-            if (out_pos) out_pos[at] = pos;
+            if (SPLIT) {
+                dst.ptr[d][at] = slot[j];
+            } else {
+                out_slot[at] = slot[j];
+                if (out_pos) out_pos[at] = pos;
+            }
         }
     }
 }

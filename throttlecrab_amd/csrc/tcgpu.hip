@@ -122,8 +122,15 @@ struct tc_engine {
         hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
         bool in_use = false;
         bool grouped_aside = false;    // the set's last batch was grouped on an auxiliary stream (`sorted` says when)
-        const uint32_t* slot_src = nullptr; // ... and read this caller's slot column (tc_route_batch orders itself behind its readers)
-        size_t slot_src_n = 0;
+        // the caller-owned slot columns this set's batches read (the latest few: a set is reused every `depth` batches).
+        // tc_route_batch (TC_ROUTE_AHEAD) orders itself behind the readers of the buffer it overwrites: waiting for the
+        // set's CURRENT grouping covers every earlier batch of the set too (a set's next grouping waits for the
+        // evaluation of its previous batch, which waited for that batch's grouping)
+        struct Reader {
+            const uint32_t* ptr = nullptr;
+            size_t n = 0;
+        } readers[4];
+        uint32_t next_reader = 0;
     } sets[PIPE_DEPTH_MAX];
     uint32_t depth = 0; // sets actually allocated
     hipStream_t aux[AUX_MAX] = {};       // set k groups on aux[k % n_aux]
@@ -1129,6 +1136,25 @@ static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn&
     return TC_E_OK;
 }
 
+// the pieces of a segmented slot column -> the scratch set's staging column, on stream `st`
+static int gather_segments(tc_engine* e, tc_engine::SortSet& ss, const tc_batch& b, uint32_t n, hipStream_t st, Params& p, const uint32_t** d_slot) {
+    if (!ss.h_slot) TC_HIP(e, hipMalloc(&ss.h_slot, e->max_batch * sizeof(uint32_t)));
+    mk::Segments sg;
+    memset(&sg, 0, sizeof sg);
+    sg.n = b.n_segments;
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < b.n_segments; ++i) {
+        sg.ptr[i] = b.seg_slot[i];
+        sg.start[i] = at;
+        at += b.seg_n[i];
+    }
+    sg.start[b.n_segments] = at; // (== n: checked by the caller)
+    hipLaunchKernelGGL(mk::k_concat, dim3(std::min<uint32_t>(nblocks(n), 1024u)), dim3(BLOCK), 0, st, sg, ss.h_slot);
+    *d_slot = ss.h_slot;
+    p.slot = ss.h_slot;
+    return TC_E_OK;
+}
+
 // all pointers in `b` are device pointers here (hin: the inputs are host arrays still to be staged)
 static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin = nullptr) {
     const uint32_t n = (uint32_t)b.n;
@@ -1248,14 +1274,18 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
         const uint32_t* gate = bucketed ? ss.bpw.maxb : nullptr;
         const uint64_t* sorted;
         const uint32_t* d_slot = b.slot;
-        ss.slot_src = hin ? nullptr : b.slot;
-        ss.slot_src_n = n;
+        if (!hin && !b.n_segments) {
+            ss.readers[ss.next_reader % 4].ptr = b.slot;
+            ss.readers[ss.next_reader % 4].n = n;
+            ss.next_reader++;
+        }
         if (piped) {
             hipStream_t ax = e->aux[e->next_aux];
             e->next_aux = (e->next_aux + 1) % e->n_aux;
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
             if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
+            if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, ax, p, &d_slot));
             if (bucketed && !bucket_partition(e, ss, ax, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
             const bool ride = e->stop_events && !e->prof_on; // `sorted` rides on the last pass's own completion signal
             // TC_B_OUTPUTS_IDLE: nothing enqueued earlier touches this call's `allowed` bytes, so they are preset here, on
@@ -1277,6 +1307,7 @@ static int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin =
             // everything that used this set earlier is ordered before us on `s`: evaluations ran on `s`,
             // and every auxiliary sort was joined into `s` before its evaluation
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
+            if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, s, p, &d_slot));
             ss.grouped_aside = false;
             if (bucketed && !bucket_partition(e, ss, s, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
             sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
@@ -1503,12 +1534,26 @@ static int run_small_batch(tc_engine* e, const tc_batch& b) {
 }
 
 extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
-    if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
+    // (callers built against the struct without the segment fields pass its old size: those fields read as zero)
+    if (!e || !bp || bp->struct_size < offsetof(tc_batch, n_segments)) return TC_E_INVALID_ARG;
     TC_CHECK_POISON(e);
-    const tc_batch& b = *bp;
+    tc_batch b;
+    memset(&b, 0, sizeof b);
+    memcpy(&b, bp, std::min<size_t>(bp->struct_size, sizeof b));
     if (b.n == 0) return TC_E_OK;
     if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
-    if (!b.slot) return fail(e, TC_E_INVALID_ARG, "slot column is NULL");
+    const bool segmented = b.n_segments != 0;
+    if (segmented) {
+        if (!(b.flags & TC_B_DEVICE_PTRS) || (b.flags & (TC_B_UNIQUE_SLOTS | TC_B_ASYNC)))
+            return fail(e, TC_E_INVALID_ARG, "a segmented slot column needs TC_B_DEVICE_PTRS (and is neither TC_B_UNIQUE_SLOTS nor TC_B_ASYNC)");
+        if (b.n_segments > TC_MAX_SEGMENTS || !b.seg_slot || !b.seg_n) return fail(e, TC_E_INVALID_ARG, "segments: 1..64 pieces, both arrays given");
+        uint64_t tot = 0;
+        for (uint32_t i = 0; i < b.n_segments; ++i) {
+            if (b.seg_n[i] && !b.seg_slot[i]) return fail(e, TC_E_INVALID_ARG, "segments: NULL piece");
+            tot += b.seg_n[i];
+        }
+        if (tot != b.n) return fail(e, TC_E_INVALID_ARG, "segments: the pieces do not add up to n");
+    } else if (!b.slot) return fail(e, TC_E_INVALID_ARG, "slot column is NULL");
     if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
     if (e->key_mode) return fail(e, TC_E_INVALID_ARG, "key-mode engine: slots are assigned by the key table; use tc_rate_limit_batch_keys");
     if (e->fixed) {
@@ -1612,10 +1657,13 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
 }
 
 extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
-    if (!e || !bp || bp->struct_size < sizeof(tc_batch)) return TC_E_INVALID_ARG;
+    if (!e || !bp || bp->struct_size < offsetof(tc_batch, n_segments)) return TC_E_INVALID_ARG;
     TC_CHECK_POISON(e);
     if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
-    const tc_batch& b = *bp;
+    tc_batch b;
+    memset(&b, 0, sizeof b);
+    memcpy(&b, bp, std::min<size_t>(bp->struct_size, sizeof b));
+    if (b.n_segments) return fail(e, TC_E_INVALID_ARG, "segments belong to slot batches");
     if (b.n == 0) return TC_E_OK;
     if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
     if (!b.key_bytes || !b.key_off) return fail(e, TC_E_INVALID_ARG, "key_bytes/key_off is NULL");
@@ -2315,7 +2363,15 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     rt::Map m;
     if (!rt::make_map(r.world, r.keys_per_shard, &m)) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: world must be 1..64 and keys_per_shard 1..2^32");
     if (r.only >= (int32_t)r.world || r.only < -1) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: `only` is not a destination");
-    if (!r.global_id || !r.out_slot || !r.out_count) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: NULL array");
+    if (r.out_dst && r.only != -1) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: out_dst goes with only = -1");
+    if (!r.global_id || (!r.out_slot && !r.out_dst) || !r.out_count) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: NULL array");
+    rt::SplitOut split;
+    memset(&split, 0, sizeof split);
+    if (r.out_dst)
+        for (uint32_t d = 0; d < r.world; ++d) {
+            if (!r.out_dst[d]) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: NULL destination in out_dst");
+            split.ptr[d] = r.out_dst[d];
+        }
     if (r.n == 0 || r.n > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "tc_route_batch: n out of range");
     TC_HIP(e, hipSetDevice(e->device));
     hipStream_t s = r.stream ? (hipStream_t)r.stream : cur_stream(e);
@@ -2329,12 +2385,23 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
             // the router on this stream, to them.  Every grouping stream has its own router scratch.
             lane = 1 + e->next_route++ % e->n_aux;
             s = e->aux[lane - 1];
-            // Behind the grouping of EVERY batch whose set is still in use: a set only remembers its latest batch, so
-            // "the readers of this very buffer" cannot be told from the sets alone once a set has been reused
-            // (ADVICE r2); an event that has already fired costs the stream nothing.
-            for (uint32_t si = 0; si < e->depth; ++si) {
-                tc_engine::SortSet& ss = e->sets[si];
-                if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(s, ss.grouped_aside ? ss.sorted : ss.consumed, 0));
+            // Behind the batches that read the very buffer being overwritten, if the engine still knows them (every set
+            // remembers the slot columns of its last four batches; waiting for a set's current grouping covers its
+            // earlier batches too, see SortSet::readers), else behind every batch in flight.  TC_ROUTE_NO_READERS: the
+            // caller vouches that out_slot is no batch's slot column (it copies the segments elsewhere: the exchange).
+            if (!(r.flags & TC_ROUTE_NO_READERS)) {
+                bool known = false;
+                for (int pass = 0; pass < 2 && !known; ++pass)
+                    for (uint32_t si = 0; si < e->depth; ++si) {
+                        tc_engine::SortSet& ss = e->sets[si];
+                        if (!ss.in_use) continue;
+                        bool reads = false;
+                        for (const auto& rd : ss.readers)
+                            reads = reads || (rd.ptr && r.out_slot && rd.ptr < r.out_slot + r.n && r.out_slot < rd.ptr + rd.n);
+                        if (pass == 0 && !reads) continue;
+                        if (pass == 0) known = true;
+                        TC_HIP(e, hipStreamWaitEvent(s, ss.grouped_aside ? ss.sorted : ss.consumed, 0));
+                    }
             }
         }
     }
@@ -2380,9 +2447,34 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     } else {
         hipLaunchKernelGGL(rt::k_route_count, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w);
         hipLaunchKernelGGL(rt::k_route_scan, dim3(r.world), dim3(rt::THREADS), 0, s, w);
-        hipLaunchKernelGGL(rt::k_route_scatter, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos);
+        if (r.out_dst) hipLaunchKernelGGL(rt::k_route_scatter<true>, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos, split);
+        else hipLaunchKernelGGL(rt::k_route_scatter<false>, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos, split);
     }
     if (r.out_count_host) hipLaunchKernelGGL(rt::k_route_publish, dim3(1), dim3(rt::MAX_WORLD), 0, s, w, r.world);
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
+extern "C" int tc_forward_segments(tc_engine* e, const tc_forward* f) {
+    if (!e || !f || f->struct_size < sizeof(tc_forward)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (f->world == 0 || f->world > 64 || !f->src || !f->count || !f->dst) return fail(e, TC_E_INVALID_ARG, "tc_forward_segments: world 1..64, arrays given");
+    TC_HIP(e, hipSetDevice(e->device));
+    mk::Destinations ds;
+    memset(&ds, 0, sizeof ds);
+    ds.n = f->world;
+    uint64_t at = 0;
+    for (uint32_t d = 0; d < f->world; ++d) {
+        if (f->count[d] && !f->dst[d]) return fail(e, TC_E_INVALID_ARG, "tc_forward_segments: NULL destination");
+        ds.ptr[d] = f->dst[d];
+        ds.start[d] = (uint32_t)at;
+        at += f->count[d];
+    }
+    if (at > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "tc_forward_segments: too many requests");
+    ds.start[f->world] = (uint32_t)at;
+    if (at == 0) return TC_E_OK;
+    hipStream_t s = f->stream ? (hipStream_t)f->stream : cur_stream(e);
+    hipLaunchKernelGGL(mk::k_forward, dim3(std::min<uint32_t>(nblocks(at), 512u)), dim3(BLOCK), 0, s, f->src, ds);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }

@@ -242,8 +242,9 @@ class Engine:
     def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
                                now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
                                out: Optional[BatchResult] = None, inputs_ready=False, grouped=False,
-                               async_=False, outputs_idle=False) -> BatchResult:
+                               async_=False, outputs_idle=False, segments=None) -> BatchResult:
         """rate_limit_batch over pre-resolved slots (sequential semantics, index order).
+        segments=[(tensor, count), ...] (with slots=None): the slot column in pieces, e.g. one per source GPU.
         async_=True (TC_B_ASYNC, host arrays): only enqueue -- transfers and evaluation overlap with
         other batches; `slots`, per-request columns and the arrays of `out` must be uint32 / int64 /
         uint8 numpy arrays (pinned: host_alloc) that stay untouched until wait_batches() says so.
@@ -254,9 +255,23 @@ class Engine:
         auxiliary stream while earlier batches are still being evaluated.
         outputs_idle=True (TC_B_OUTPUTS_IDLE, with inputs_ready): nothing enqueued earlier reads or writes the
         arrays of `out` (every batch in flight has its own), so the engine may initialise them early."""
-        dev = _is_torch(slots)
+        dev = _is_torch(slots) or segments is not None
         keep = []
-        if dev:
+        seg_arrays = None
+        if segments is not None:
+            # a slot column in pieces (tc_batch.seg_slot): [(CUDA int32 tensor, count), ...] taken one after the other
+            import torch
+            assert slots is None and 0 < len(segments) <= 64
+            if __debug__ and len(segments) <= 4:  # (a rank of a large deployment passes dozens of pieces every few microseconds)
+                for tns, cnt in segments:
+                    assert tns.is_cuda and tns.is_contiguous() and tns.dtype in (torch.int32, torch.uint32) and 0 <= cnt <= tns.numel()
+            ptrs = (C.c_void_p * len(segments))(*[tns.data_ptr() for tns, _ in segments])
+            cnts = (C.c_uint32 * len(segments))(*[int(cnt) for _, cnt in segments])
+            keep += [ptrs, cnts] + [tns for tns, _ in segments]
+            seg_arrays = (ptrs, cnts)
+            n = int(sum(cnt for _, cnt in segments))
+            sp = None
+        elif dev:
             import torch
             assert slots.is_cuda and slots.is_contiguous() and slots.dtype in (torch.int32, torch.uint32)
             n = slots.numel()
@@ -271,6 +286,10 @@ class Engine:
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
                                    unique, want, out, inputs_ready, grouped, async_, outputs_idle)
         b.slot = sp
+        if seg_arrays is not None:
+            b.n_segments = len(segments)
+            b.seg_slot = C.cast(seg_arrays[0], C.c_void_p)
+            b.seg_n = C.cast(seg_arrays[1], C.c_void_p)
         if n:
             self._check(self._lib.tc_rate_limit_batch_slots(self._h, C.byref(b)))
             if async_:
@@ -327,7 +346,7 @@ class Engine:
         return res
 
     def route_batch(self, global_ids, world: int, only: int = -1, want_pos: bool = False, out=None, stream=None, ahead: bool = False,
-                    host_counts=None, tag: int = 0):
+                    host_counts=None, tag: int = 0, no_readers: bool = False, out_dst=None):
         """tc_route_batch: of a CUDA tensor of global key ids (int32 / uint32), keep what destination `only` owns
         (only = -1: every destination's segment, one after the other) as shard-local slots, in request order.
         -> (slots int32[n], pos int32[n] or None, counts int32[world]) CUDA tensors; the first counts[only]
@@ -341,6 +360,13 @@ class Engine:
         assert global_ids.is_cuda and global_ids.is_contiguous() and global_ids.dtype in (torch.int32, torch.uint32)
         n = global_ids.numel()
         dev = global_ids.device
+        keep_dst = None
+        if out_dst is not None:
+            # segment d goes straight to out_dst[d] (CUDA int32 tensors; peer memory allowed) instead of into `slots`
+            assert only == -1 and len(out_dst) == world
+            keep_dst = (C.c_void_p * world)(*[d.data_ptr() for d in out_dst])
+            if out is None:
+                out = (None, None, torch.empty(world, dtype=torch.int32, device=dev))
         if out is None:
             # (torch.empty, not zeros: a fill enqueued on torch's stream is not ordered with the engine's stream when
             # that is the engine's own -- see use_torch_stream -- and the router writes every entry anyway)
@@ -350,15 +376,32 @@ class Engine:
         r = L.tc_route()
         r.struct_size = C.sizeof(L.tc_route)
         r.world, r.keys_per_shard, r.n, r.only = world, self.capacity, n, only
-        r.global_id, r.out_slot, r.out_count = global_ids.data_ptr(), slots.data_ptr(), counts.data_ptr()
+        r.global_id, r.out_slot, r.out_count = global_ids.data_ptr(), (slots.data_ptr() if slots is not None else None), counts.data_ptr()
+        if keep_dst is not None:
+            r.out_dst = C.cast(keep_dst, C.c_void_p)
         r.out_pos = pos.data_ptr() if pos is not None else None
         r.stream = stream.cuda_stream if stream is not None else None
-        r.flags = L.TC_ROUTE_AHEAD if ahead else 0
+        r.flags = (L.TC_ROUTE_AHEAD if ahead else 0) | (L.TC_ROUTE_NO_READERS if no_readers else 0)
         if host_counts is not None:
             assert host_counts.dtype == np.uint32 and host_counts.size >= world + 1
             r.out_count_host, r.tag = host_counts.ctypes.data, tag
         self._check(self._lib.tc_route_batch(self._h, C.byref(r)))
         return slots, pos, counts
+
+    def forward_segments(self, src, counts, dsts, stream=None):
+        """tc_forward_segments: the router's segments (tc_route_batch with only = -1; `src` = its slot tensor, `counts` = the
+        host copy of its counts) -> dsts[d][:counts[d]] for every destination d, in one launch (dsts: CUDA int32 tensors,
+        peer memory allowed).  stream: a torch.cuda.Stream (default: the engine's stream)."""
+        world = len(counts)
+        f = L.tc_forward()
+        f.struct_size = C.sizeof(L.tc_forward)
+        f.world = world
+        f.src = src.data_ptr()
+        cnt = (C.c_uint32 * world)(*[int(c) for c in counts])
+        dst = (C.c_void_p * world)(*[d.data_ptr() for d in dsts])
+        f.count, f.dst = C.cast(cnt, C.c_void_p), C.cast(dst, C.c_void_p)
+        f.stream = stream.cuda_stream if stream is not None else None
+        self._check(self._lib.tc_forward_segments(self._h, C.byref(f)))
 
     def rate_limit(self, key: bytes, max_burst: int, count_per_period: int, period: int, quantity: int, now_ns: int):
         """RateLimiter::rate_limit -> (status, allowed, limit, remaining, reset_after_ns, retry_after_ns)."""
