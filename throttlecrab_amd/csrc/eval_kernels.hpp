@@ -356,7 +356,7 @@ __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t
         uint64_t h = 0;
         bool recycled = false;
         if (i < n) st = kt::probe_request<true>(t, key_bytes, key_off, n, i, slot, ax, h, recycled);
-        kt::tombs_sub(t, recycled);
+        kt::tombs_sub<SMALL_MAX>(t, recycled);
         kt::reserve_overflow<SMALL_MAX>(t, i < n, i < n ? key_off[i + 1] - key_off[i] : 0u, st, slot);
         uint32_t total = 0;
         const uint32_t rank = kt::block_rank<SMALL_MAX>(i < n && st == kt::ST_CLAIMANT, total); // one barrier

@@ -42,6 +42,10 @@ constexpr uint32_t ST_FOUND = 0u, ST_CLAIMANT = 1u, ST_FOLLOWER = 2u, ST_MISSING
 constexpr uint32_t INLINE_KEY = 48u;  // KeyRec
 constexpr uint32_t ENTRY_KEY = 16u;   // Entry
 constexpr uint32_t LEN8_LONG = 255u;
+// The tombstone count only feeds the rebuild decision, but every probe block and every sweep block moves it: one word
+// took 16 384 atomics of a 1 Mi-key batch once the table held tombstones to recycle (~12 ns each, serialised: k_probe 60
+// -> 390-450 us, and every kernel beside it slowed down with it).  64 shards, one atomic per BLOCK.
+constexpr uint32_t TOMB_SHARDS = 64u;
 
 struct __attribute__((aligned(32))) Entry {
     unsigned long long w;
@@ -67,7 +71,7 @@ struct Table {
     uint32_t* overflow_half;           // 0 / 1
     uint32_t* free_slots;
     int* free_top;
-    uint32_t* tombs;        // tombstones currently in ktab
+    uint32_t* tombs;        // [TOMB_SHARDS] tombstones currently in ktab, as shards that sum to the count (wrap-around arithmetic)
     uint32_t* error_flag;   // != 0: a key could not be bound (no slot / no overflow space)
     uint32_t capacity;
 };
@@ -350,10 +354,19 @@ __device__ __forceinline__ uint32_t probe_request(const Table& t, const uint8_t*
     return st;
 }
 
-// tombstones recycled by this wave's claims come off the table's count with one atomic (reached by the whole wave)
+// tombstones recycled by this BLOCK's claims come off the table's count with one atomic on the block's shard
+// (reached by every thread of the block; one barrier)
+template <int NT>
 __device__ __forceinline__ void tombs_sub(const Table& t, bool recycled) {
+    __shared__ uint32_t s_t[NT / 64];
     const unsigned long long m = __ballot(recycled);
-    if (m && (threadIdx.x & 63) == 0) atomicSub(t.tombs, (uint32_t)__popcll(m));
+    if ((threadIdx.x & 63) == 0) s_t[threadIdx.x >> 6] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t c = 0;
+        for (int w = 0; w < NT / 64; ++w) c += s_t[w];
+        if (c) atomicSub(&t.tombs[blockIdx.x % TOMB_SHARDS], c);
+    }
 }
 
 // Claimants of keys longer than INLINE_KEY reserve their overflow bytes before binding, so that binding knows who
@@ -414,7 +427,7 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
     if (i < n) {
         st = probe_request<INSERT>(t, key_bytes, key_off, n, i, slot, ax, h, recycled);
     }
-    if (INSERT) tombs_sub(t, recycled);
+    if (INSERT) tombs_sub<THREADS>(t, recycled);
     if (INSERT) reserve_overflow<THREADS>(t, i < n, i < n ? key_off[i + 1] - key_off[i] : 0u, st, slot);
     if (i < n) {
         hash_out[i] = h;
@@ -500,7 +513,7 @@ __device__ __forceinline__ uint32_t bind_claimant(const Table& t, const uint8_t*
         en->w = entry_meta(h, len) | (unsigned long long)(slot + 2u);
     } else { // the free stack ran dry
         t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
-        atomicAdd(t.tombs, 1u);
+        atomicAdd(&t.tombs[pos % TOMB_SHARDS], 1u);
         atomicExch(t.error_flag, 1u);
     }
     return slot;
@@ -509,7 +522,7 @@ __device__ __forceinline__ uint32_t bind_claimant(const Table& t, const uint8_t*
 __device__ __forceinline__ void release_claim(const Table& t, const uint32_t* __restrict__ key_off, uint32_t i, uint32_t pos, uint64_t h) {
     const uint32_t len = key_off[i + 1] - key_off[i];
     t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
-    atomicAdd(t.tombs, 1u);
+    atomicAdd(&t.tombs[pos % TOMB_SHARDS], 1u);
     atomicExch(t.error_flag, 1u);
 }
 
@@ -657,7 +670,7 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
             en->key[0] = k0;
             en->key[1] = k1;
             en->w = meta | (unsigned long long)(slot + 2u);
-            if (target == tomb_pos) atomicSub(t.tombs, 1u);
+            if (target == tomb_pos) atomicSub(&t.tombs[0], 1u);
             atomicAdd(inserted_counter, 1ull);
             return slot;
         } while (false);
@@ -755,7 +768,11 @@ __global__ void k_overflow_swap(Table t, const unsigned long long* __restrict__ 
 // a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (three near-empty
 // launches, ~10 us, when no rebuild is due).
 __global__ void k_rebuild_decide(Table t, uint32_t* __restrict__ flag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *flag = (uint64_t)*t.tombs > (t.nb_mask + 1) / 4 ? 1u : 0u;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t tombs = 0; // (the shards wrap around individually; their sum is the count)
+        for (uint32_t s = 0; s < TOMB_SHARDS; ++s) tombs += t.tombs[s];
+        *flag = (uint64_t)tombs > (t.nb_mask + 1) / 4 ? 1u : 0u;
+    }
 }
 
 __global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32_t* __restrict__ flag) {
@@ -770,7 +787,7 @@ __global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32
 // re-enter every bound slot into the cleared table
 __global__ __launch_bounds__(THREADS) void k_reinsert(Table t, const uint32_t* __restrict__ flag) {
     if (*flag == 0u) return;
-    if (blockIdx.x == 0 && threadIdx.x == 0) *t.tombs = 0u;
+    if (blockIdx.x == 0 && threadIdx.x < TOMB_SHARDS) t.tombs[threadIdx.x] = 0u;
     for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
         if (!t.bound[s]) continue;
         const uint64_t h = t.rec[s].hash;

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, 
         __syncthreads(); // block_rank's scratch is reused next round
     }
     if (fill) flush();
-    if (threadIdx.x == 0 && unbound_total) atomicAdd(t.tombs, unbound_total);
+    if (threadIdx.x == 0 && unbound_total) atomicAdd(&t.tombs[blockIdx.x % kt::TOMB_SHARDS], unbound_total);
     __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
         removed += __shfl_down(removed, off, 64);

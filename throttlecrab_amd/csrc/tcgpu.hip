@@ -461,11 +461,12 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
         return at;
     };
     const size_t o_ktab = take(nb * sizeof(kt::Entry)), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(2 * overflow),
-                 o_free = take(cap * 4), o_misc = take(64);
+                 o_free = take(cap * 4), o_misc = take(64), o_tombs = take(kt::TOMB_SHARDS * 4);
     TC_HIP(e, hipMalloc(&e->kt_block, off));
     uint8_t* base = (uint8_t*)e->kt_block;
     TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * sizeof(kt::Entry), (hipStream_t)0));
     TC_HIP(e, hipMemsetAsync(base + o_misc, 0, 64, (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(base + o_tombs, 0, kt::TOMB_SHARDS * 4, (hipStream_t)0));
     kt::Table& t = e->kt;
     t.ktab = (kt::Entry*)(base + o_ktab);
     t.nb_mask = nb - 1;
@@ -475,7 +476,7 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     t.overflow_bytes = overflow;
     t.overflow_used = (unsigned long long*)(base + o_misc);
     t.free_top = (int*)(base + o_misc + 8);
-    t.tombs = (uint32_t*)(base + o_misc + 12);
+    t.tombs = (uint32_t*)(base + o_tombs);
     t.error_flag = (uint32_t*)(base + o_misc + 16); // (+20: the rebuild's flag word)
     t.overflow_half = (uint32_t*)(base + o_misc + 24);
     // (+32, +40: the overflow compaction's flag words)
@@ -2154,7 +2155,7 @@ struct SnapHeader {
     uint64_t payload_bytes; // everything after the header
     uint64_t checksum;      // FNV-1a 64 over the payload: a truncated, corrupt or foreign file is refused BEFORE the engine is touched
 };
-constexpr uint32_t SNAP_VERSION = 2;
+constexpr uint32_t SNAP_VERSION = 3; // 3: sharded tombstone count
 // FNV-1a over 8-byte words of the byte stream (a byte-wise FNV over gigabytes of state would take seconds);
 // independent of how the stream is cut into pieces
 struct StreamSum {
@@ -2204,7 +2205,8 @@ std::vector<Section> snapshot_sections(tc_engine* e) {
         v.push_back({t.bound, (size_t)t.capacity});
         v.push_back({t.overflow, (size_t)t.overflow_bytes * 2});
         v.push_back({t.free_slots, (size_t)t.capacity * 4});
-        v.push_back({t.overflow_used, 64}); // overflow_used | free_top | tombs | error_flag
+        v.push_back({t.overflow_used, 64}); // overflow_used | free_top | error_flag | overflow_half
+        v.push_back({t.tombs, kt::TOMB_SHARDS * 4});
     }
     return v;
 }

@@ -28,6 +28,12 @@ for S in $STEPS; do
            RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29535 TC_BENCH_FORCE_DIST=1 timeout 120 rocprofv3 --kernel-trace --stats -d $O/x_stats -o s -- python $R/bench.py --gpus 1 --steps 40 --warmup 10 --route exchange > $O/x_stats.log 2>&1; echo "rc=$?"
            cd $R; python tools/trace_seq.py $O/x_stats -520 160 > $O/trace_seq.txt 2>&1; python tools/summarize_prof.py ${TAG}_exchange_1rank $O/x_stats > /dev/null 2>&1; head -24 profiles/${TAG}_exchange_1rank.txt; mkdir -p $O/profiles; cp profiles/${TAG}_exchange_1rank* $O/profiles/; rm -rf $O/x_stats ;;
     segab) timeout 120 python tools/seg_ab.py 2>&1 | grep -v amdgpu.ids ;;
+    keysq) timeout 200 python tools/keys_only.py 2>/dev/null | tail -1 ;;
+    keys) timeout 200 python tools/keys_only.py 2>/dev/null | tail -1
+          cd /tmp; export TMPDIR=/tmp
+          timeout 200 rocprofv3 --kernel-trace --stats -d $O/k_stats -o s -- python $R/tools/profile_keys.py short 16 > $O/k_stats.log 2>&1; echo "rc=$?"
+          cd $R; python tools/trace_seq.py $O/k_stats -420 420 > $O/keys_trace_seq.txt 2>&1; python tools/summarize_prof.py ${TAG}_string_keys_trace $O/k_stats > /dev/null 2>&1; mkdir -p $O/profiles; cp profiles/${TAG}_string_keys_trace* $O/profiles/; rm -rf $O/k_stats ;;
+    keytests) timeout 600 python -m pytest tests/test_gpu_keys.py tests/test_gpu_keys_spec.py tests/test_gpu_metrics.py tests/test_gpu_snapshot.py -m gpu -x -q > $O/pytest_keys.log 2>&1; echo "key tests rc=$?"; tail -4 $O/pytest_keys.log ;;
     ab) timeout 600 python tools/ab_step.py 100 > $O/ab_step.txt 2>&1; echo "ab rc=$?"; cat $O/ab_step.txt ;;
     bench) TC_BENCH_VERBOSE=1 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_stdout.txt 2> $O/bench_stderr.txt; echo "bench rc=$?"
            tail -c 4200 $O/bench_stdout.txt; echo; wc -c $O/bench_stdout.txt; cp gpurun_out/bench_detail.json $O/ 2>/dev/null ;;
