@@ -98,8 +98,8 @@ typedef struct tc_config {
     int32_t reserved0;
     uint64_t capacity;        /* number of key slots resident in HBM */
     uint64_t max_batch;       /* largest n accepted by one rate_limit_batch call */
-    uint64_t key_arena_bytes; /* string mode: overflow arena for keys longer than 48 bytes (shorter keys are
-                               * stored inside their slot's record); 0 = max(1 MiB, 4 B/slot) */
+    uint64_t key_arena_bytes; /* string mode: overflow arena for keys longer than 112 bytes (shorter keys are
+                               * stored inside their slot's 128-byte record); 0 = max(1 MiB, 4 B/slot) */
 } tc_config;
 
 /* tc_batch.flags */

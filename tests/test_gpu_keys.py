@@ -69,6 +69,8 @@ def _keyset(rng, n_keys):
             keys.append(("kéy-\U0001F980-%d" % i).encode())
         else:
             keys.append(b"x" * 31 + b"%d" % (i % 10) if i < 50 else b"p%dq" % i)     # shared 31-byte prefixes
+    for i in range(7, n_keys, 25):  # beyond the 112 bytes a slot's record holds inline: the overflow arena
+        keys[i] = b"L%d|" % i + bytes([33 + (i + j) % 90 for j in range(113 + i % 200)])
     keys[0] = b""  # the empty key is a key (store_test_suite.rs:289-300)
     return keys
 
@@ -236,7 +238,7 @@ def test_pipelined_key_batches_inputs_ready():
     for bidx in range(nb):
         hi = 4000 + 4000 * bidx
         idx = np.where(rng.random(n) < 0.3, np.minimum(rng.zipf(1.3, n) - 1, hi - 1), rng.integers(0, hi, n))
-        idx[:50] = len(keys) - 1 - rng.integers(0, 500, 50)   # a few keys beyond the inline 48 bytes
+        idx[:50] = len(keys) - 1 - rng.integers(0, 500, 50)   # a few keys beyond the inline 112 bytes
         kb, ko = O.pack_keys([keys[i] for i in idx])
         staged.append((kb, ko, torch.from_numpy(kb).cuda(), torch.from_numpy(ko.astype(np.int32)).cuda()))
     torch.cuda.synchronize()
@@ -328,7 +330,7 @@ def test_async_host_key_batches(general):
             got.append({f: getattr(r["out"], f).copy() for f in F})
         hi = 3000 + 3000 * bidx
         idx = np.where(rng.random(n) < 0.3, np.minimum(rng.zipf(1.3, n) - 1, hi - 1), rng.integers(0, hi, n))
-        idx[:40] = len(keys) - 1 - rng.integers(0, 300, 40)   # a few keys beyond the inline 48 bytes
+        idx[:40] = len(keys) - 1 - rng.integers(0, 300, 40)   # a few keys beyond the inline 112 bytes
         kb, ko = O.pack_keys([keys[i] for i in idx])
         r["kb"][:kb.size] = kb
         r["ko"][:] = ko

@@ -100,18 +100,18 @@ def test_tombstones_are_recycled_and_failed_binds_do_not_pile_up():
 
 
 def test_overflow_arena_is_reclaimed_by_the_sweep():
-    """keys longer than 48 bytes live in an arena whose space was never given back: churn of
-    long keys exhausted it for good.  Ten generations of long keys, each swept before the next arrives, through an
-    arena that holds two of them."""
+    """keys too long for their slot's record (over 112 bytes) live in an arena whose space was never
+    given back: churn of long keys exhausted it for good.  Ten generations of 113..240-byte keys, each swept before the
+    next arrives, through an arena that holds two of them."""
     from oracle import oracle as O
     from throttlecrab_amd import workload as W
     n = 20_000
-    eng = _engine(2 * n, n, key_arena_bytes=2 * n * 64)
+    eng = _engine(2 * n, n, key_arena_bytes=2 * n * 256)
     orc = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
     now = T0
     for gen in range(10):
         ids = np.arange(gen * n, (gen + 1) * n)
-        kb, ko = W.long_keys(ids)
+        kb, ko = W.pack_keys([(b"%d/" % i) + bytes([33 + (i * 7 + j) % 90 for j in range(113 + i % 128)]) for i in ids.tolist()])
         for rep in range(2):
             ref = orc.batch_keys(kb, ko, 5, 10, 60, 1, now)
             res = eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=now)

@@ -39,7 +39,7 @@ constexpr int THREADS = 256;
 constexpr uint32_t VAL_EMPTY = 0u, VAL_TOMB = 1u, VAL_PENDING = 0x80000000u;
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
 constexpr uint32_t ST_FOUND = 0u, ST_CLAIMANT = 1u, ST_FOLLOWER = 2u, ST_MISSING = 3u, ST_NOSPACE = 4u; // NOSPACE: claimed an entry, but the overflow arena is full
-constexpr uint32_t INLINE_KEY = 48u;  // KeyRec
+constexpr uint32_t INLINE_KEY = 112u; // KeyRec: one 128-byte line holds hash, length, entry position and the key
 constexpr uint32_t ENTRY_KEY = 16u;   // Entry
 constexpr uint32_t LEN8_LONG = 255u;
 // The tombstone count only feeds the rebuild decision, but every probe block and every sweep block moves it: one word
@@ -53,7 +53,7 @@ struct __attribute__((aligned(32))) Entry {
     uint64_t key[2];
 };
 
-struct __attribute__((aligned(64))) KeyRec {
+struct __attribute__((aligned(128))) KeyRec {
     uint64_t hash;
     uint32_t len; // NO_SLOT = slot not bound
     uint32_t pos;
@@ -322,8 +322,16 @@ __device__ __forceinline__ uint32_t probe_request(const Table& t, const uint8_t*
                 const uint32_t s = val - 2u;
                 bool same;
                 if (len <= ENTRY_KEY) same = hi.x == k0 && hi.y == k1;
-                else if (in_words) // (a stored key is readable up to the next multiple of 16 bytes: key record / arena reservation)
-                    same = t.rec[s].len == len && key_equals_words(stored_key(t, s, len), (len + 15u) & ~15u, len, key, kw);
+                else if (in_words) {
+                    // 17..64 bytes: the key sits inside its slot's record (one 128-byte line: length and key words are
+                    // all requested before any of them is looked at -- a second dependent round trip costs as much as
+                    // the first)
+                    const KeyRec& kr = t.rec[s];
+                    const uint32_t rlen = kr.len;
+                    uint64_t o[KEY_WORDS];
+                    load_words(kr.bytes, len, INLINE_KEY, o);
+                    same = (rlen == len) & words_equal(o, kw);
+                }
                 else same = t.rec[s].len == len && bytes_equal(stored_key(t, s, len), key, len);
                 if (same) {
                     st = ST_FOUND;

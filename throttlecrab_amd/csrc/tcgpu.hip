@@ -452,7 +452,7 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     const uint64_t cap = e->capacity, mb = e->max_batch;
     uint64_t nb = 1;
     while (nb < 2 * cap) nb <<= 1; // load factor <= 0.5
-    // keys up to 48 bytes live inside their slot's KeyRec; longer ones in the overflow arena
+    // keys up to 112 bytes live inside their slot's KeyRec (one 128-byte line); longer ones in the overflow arena
     const uint64_t overflow = align_up(key_arena_bytes ? key_arena_bytes : std::max<uint64_t>(1u << 20, cap * 4), 256);
     size_t off = 0;
     auto take = [&](size_t bytes) {
