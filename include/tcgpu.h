@@ -321,12 +321,20 @@ int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, int64_t* sl
 
 /* Top denied keys (metrics.rs:24-76,296-309: `throttlecrab_top_denied_keys{key,rank}`).  Needs
  * TC_CFG_TRACK_DENIED.  Counts are exact (the reference's capped HashMap forgets keys when it
- * overflows) and live as long as the key's slot: a key-mode sweep that unbinds a key resets
- * its counter.  Returns the k slots with the most denials since creation / tc_denied_reset,
+ * overflows).  Slot mode: a slot IS the key.  Key mode: this call reports the keys that currently
+ * hold a slot; tc_top_denied_keys also knows the keys a sweep has unbound (the reference counts by
+ * key, whatever its store cleans up).  Returns the k slots with the most denials since creation / tc_denied_reset,
  * most denied first (ties: lower slot first), k is capped at 10 000 like the reference's
  * MAX_DENIED_KEYS_LIMIT; slots never denied are not listed.  *n_out <= k entries are written. */
 int tc_top_denied(tc_engine* e, uint32_t k, uint32_t* slots, uint64_t* counts, uint32_t* n_out);
 int tc_denied_reset(tc_engine* e);
+/* string mode: TopDeniedKeys::get_top (metrics.rs:66-76) -- the k most denied KEYS, most denied first (ties: key
+ * bytes ascending), as a key arena (key_off[k + 1]) + counts.  A key's denials follow the key: a sweep that unbinds it
+ * moves the count into a side table of 32 768 keys (keys of up to 256 bytes, the reference's MAX_KEY_LENGTH; trimmed
+ * to the 10 000 most denied ones once it passes 30 000, like TopDeniedKeys::cleanup), and binding the key again
+ * moves it back.  k is capped at 10 000.  TC_E_INVALID_ARG if key_bytes_cap is too small. */
+int tc_top_denied_keys(tc_engine* e, uint32_t k, uint8_t* key_bytes, size_t key_bytes_cap, uint32_t* key_off, uint64_t* counts,
+                       uint32_t* n_out);
 /* string mode: the keys bound to `slots` as an arena (key_off[n+1]); an unbound slot yields an
  * empty key.  TC_E_INVALID_ARG if key_bytes_cap is too small. */
 int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,

@@ -69,27 +69,31 @@ class Metrics {
         total_requests.store(c[TC_CNT_TOTAL]);
         top_.clear();
         if (max_denied_keys_ == 0) return TC_E_OK;
-        std::vector<uint32_t> slots(max_denied_keys_);
         std::vector<uint64_t> counts(max_denied_keys_);
         uint32_t n = 0;
+        // string keys: by KEY, the keys a sweep has unbound included (the reference counts by key, metrics.rs:24-76)
+        {
+            std::vector<uint32_t> off(max_denied_keys_ + 1, 0);
+            std::vector<uint8_t> bytes(max_denied_keys_ * 64 + 64);
+            while ((rc = tc_top_denied_keys(e, (uint32_t)max_denied_keys_, bytes.data(), bytes.size(), off.data(), counts.data(), &n)) ==
+                       TC_E_INVALID_ARG && bytes.size() < (1u << 30))
+                bytes.resize(bytes.size() * 8);
+            if (rc == TC_E_OK) {
+                for (uint32_t i = 0; i < n; ++i) {
+                    const size_t len = off[i + 1] - off[i];
+                    if (len > MAX_KEY_LENGTH) continue; // metrics.rs:39-42: over-long keys are not tracked
+                    top_.emplace_back(std::string((const char*)bytes.data() + off[i], len), counts[i]);
+                }
+                return TC_E_OK;
+            }
+            if (rc != TC_E_UNSUPPORTED) return rc;
+        }
+        // slot-mode engine (label = the slot id), or no TC_CFG_TRACK_DENIED (counters only)
+        std::vector<uint32_t> slots(max_denied_keys_);
         rc = tc_top_denied(e, (uint32_t)max_denied_keys_, slots.data(), counts.data(), &n);
-        if (rc == TC_E_UNSUPPORTED) return TC_E_OK; // engine without TC_CFG_TRACK_DENIED: counters only
+        if (rc == TC_E_UNSUPPORTED) return TC_E_OK;
         if (rc != TC_E_OK) return rc;
-        std::vector<uint32_t> off(n + 1, 0);
-        std::vector<uint8_t> bytes((size_t)n * 64 + 64);
-        while ((rc = tc_slot_keys(e, n, slots.data(), bytes.data(), bytes.size(), off.data())) == TC_E_INVALID_ARG &&
-               bytes.size() < (1u << 30))
-            bytes.resize(bytes.size() * 8);
-        if (rc == TC_E_UNSUPPORTED) { // slot-mode engine: label = the slot id
-            for (uint32_t i = 0; i < n; ++i) top_.emplace_back("slot:" + std::to_string(slots[i]), counts[i]);
-            return TC_E_OK;
-        }
-        if (rc != TC_E_OK) return rc;
-        for (uint32_t i = 0; i < n; ++i) {
-            const size_t len = off[i + 1] - off[i];
-            if (len > MAX_KEY_LENGTH) continue; // metrics.rs:39-42: over-long keys are not tracked
-            top_.emplace_back(std::string((const char*)bytes.data() + off[i], len), counts[i]);
-        }
+        for (uint32_t i = 0; i < n; ++i) top_.emplace_back("slot:" + std::to_string(slots[i]), counts[i]);
         return TC_E_OK;
     }
     // for hosts that track denied keys themselves: most denied first

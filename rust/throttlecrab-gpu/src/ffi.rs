@@ -211,6 +211,7 @@ extern "C" {
     pub fn tc_counters_device_ptr(e: *mut tc_engine, dptr: *mut *mut c_void) -> c_int;
     pub fn tc_top_denied(e: *mut tc_engine, k: u32, slots: *mut u32, counts: *mut u64, n_out: *mut u32) -> c_int;
     pub fn tc_denied_reset(e: *mut tc_engine) -> c_int;
+    pub fn tc_top_denied_keys(e: *mut tc_engine, k: u32, key_bytes: *mut u8, key_bytes_cap: usize, key_off: *mut u32, counts: *mut u64, n_out: *mut u32) -> c_int;
     pub fn tc_slot_keys(e: *mut tc_engine, n: u32, slots: *const u32, key_bytes: *mut u8, key_bytes_cap: usize, key_off: *mut u32) -> c_int;
     pub fn tc_read_state(e: *mut tc_engine, first: u64, n: u64, tat: *mut i64, expiry: *mut u64) -> c_int;
     pub fn tc_profile_enable(e: *mut tc_engine, on: c_int) -> c_int;

@@ -63,11 +63,11 @@ def test_denied_counts_match_oracle_slot_mode(mode):
     eng.close()
 
 
-def test_top_denied_keys_string_mode_and_sweep_reset():
+def test_top_denied_keys_string_mode():
     import throttlecrab_amd as t
     from oracle import oracle as O
     rng = np.random.default_rng(3)
-    keys = [b"user:%d" % i for i in range(2000)] + [b"very-long-key/" + b"z" * 70 + b"/%d" % i for i in range(20)]
+    keys = [b"user:%d" % i for i in range(2000)] + [b"very-long-key/" + b"z" * 130 + b"/%d" % i for i in range(20)]
     eng = t.Engine(8192, 50000, key_mode=True, track_denied=True)
     orc = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
     want = collections.Counter()
@@ -82,15 +82,67 @@ def test_top_denied_keys_string_mode_and_sweep_reset():
         assert np.array_equal(res.allowed, ref.allowed)
         for i in idx[(ref.allowed == 0) & (ref.status == 0)].tolist():
             want[keys[i]] += 1
-    got = eng.top_denied(25)
-    exp_counts = sorted(want.values(), reverse=True)[:25]
-    assert [c for _, c in got] == exp_counts
-    for key, c in got:
-        assert want[key] == c, key           # the right keys (ties may be ordered differently: slots, not key text)
-    assert any(len(k) > 48 for k, _ in eng.top_denied(2000))  # keys beyond the inline 48 bytes come back intact
-    # a sweep that unbinds every key resets their counters (the slots will serve other keys)
+    for k in (1, 25, 3000):
+        assert eng.top_denied(k) == _top_expected(want, k), k   # most denied first, ties by key bytes
+    assert any(len(k) > 112 for k, _ in eng.top_denied(3000))   # keys beyond the inline 112 bytes come back intact
+    # the counts belong to the KEYS: a sweep that unbinds every key changes nothing (metrics.rs:24-76 counts by key,
+    # whatever the store cleans up) ...
     eng.sweep_expired(T0 + 10**12)
+    assert eng.counters()["live_slots"] == 0
+    assert eng.top_denied(25) == _top_expected(want, 25)
+    # ... and tc_denied_reset forgets them all
+    eng.denied_reset()
     assert eng.top_denied(10) == []
+    eng.close()
+
+
+class _TopDeniedModel:
+    """TopDeniedKeys (throttlecrab-server/src/metrics.rs:24-76) without its size cap: a count per key, bumped on every
+    denial, independent of the store; keys over MAX_KEY_LENGTH = 256 bytes are not tracked (metrics.rs:36-39)."""
+
+    def __init__(self):
+        self.counts = collections.Counter()
+
+    def update(self, key):
+        if len(key) <= 256:
+            self.counts[key] += 1
+
+    def get_top(self, k):
+        return _top_expected(self.counts, k)
+
+
+def test_top_denied_follows_keys_through_sweeps_and_rebinding():
+    """generations of keys are denied, expire, are swept (their slots go to other keys), come back and
+    are denied again; a key's count must be the sum over all its lives, exactly as the reference's map has it."""
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    rng = np.random.default_rng(17)
+    pool = [b"k%d" % i for i in range(600)] + [b"tenant/%d/" % i + b"q" * (20 + i % 120) for i in range(200)] + [b"huge/" + b"h" * 300]
+    eng = t.Engine(1024, 30000, key_mode=True, track_denied=True)   # fewer slots than keys: slots are reused across generations
+    orc = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
+    model = _TopDeniedModel()
+    now = T0
+    for gen in range(6):
+        live = rng.permutation(len(pool))[:700]                      # this generation's keys (overlaps with earlier ones)
+        for rnd in range(2):
+            idx = live[np.minimum(rng.zipf(1.3, 20000) - 1, len(live) - 1)]
+            kb, ko = O.pack_keys([pool[i] for i in idx])
+            ref = orc.batch_keys(kb, ko, 3, 6, 60, 1, now)
+            res = eng.rate_limit_batch_keys(kb, ko, max_burst=3, count_per_period=6, period=60, quantity=1, now_ns=now,
+                                            want=("allowed", "status"), inputs_ready=False)
+            assert np.array_equal(res.allowed, ref.allowed), (gen, rnd)
+            for i in idx[(ref.allowed == 0) & (ref.status == 0)].tolist():
+                model.update(pool[i])
+            now += 10**8
+        for k in (5, 50, 1000):
+            assert eng.top_denied(k) == model.get_top(k), (gen, k)
+        now += 200 * 10**9                                           # everything expires ...
+        orc.force_cleanup(now)
+        assert eng.sweep_expired(now) > 0                            # ... and is swept: every key loses its slot
+        assert eng.counters()["live_slots"] == 0
+        for k in (5, 50, 1000):
+            assert eng.top_denied(k) == model.get_top(k), ("after sweep", gen, k)
+    assert model.counts[pool[-1]] == 0                               # (the 305-byte key was denied but is not tracked)
     eng.close()
 
 

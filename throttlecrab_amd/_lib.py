@@ -98,6 +98,7 @@ SYMBOLS = {
     "tc_lookup_slot": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "tc_top_denied": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "tc_denied_reset": (C.c_int, [C.c_void_p]),
+    "tc_top_denied_keys": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
     "tc_debug_fail_copy": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tc_debug_break_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tc_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),

@@ -60,6 +60,21 @@ struct __attribute__((aligned(128))) KeyRec {
     uint8_t bytes[INLINE_KEY];
 };
 
+// Denial counts outlive a key's slot (the reference counts by KEY, independent of what its store sweeps:
+// throttlecrab-server/src/metrics.rs:24-76).  When a sweep unbinds a key whose slot counted denials, key and count move
+// into this small open-addressed side table; when the key is bound again, the count moves back to its new slot's
+// counter -- a key's denials are always in exactly one place.  RETIRED_CAP entries (3 x the reference's 10 000-key
+// limit, metrics.rs:17: the host trims to the top 10 000 once the table passes 30 000, like TopDeniedKeys::cleanup);
+// keys over RETIRED_KEY bytes are not kept (the reference ignores keys over 256 bytes, metrics.rs:11,37).
+constexpr uint32_t RETIRED_CAP = 32768u, RETIRED_KEY = 256u, RETIRED_PROBES = 128u;
+constexpr unsigned long long RT_EMPTY = 0ull, RT_BUSY = 1ull, RT_DELETED = 2ull, RT_VALID = 1ull << 63;
+struct RetiredRec {
+    unsigned long long tag; // RT_EMPTY / RT_BUSY / RT_DELETED / hash | RT_VALID
+    uint32_t count;
+    uint32_t len;
+    uint8_t bytes[RETIRED_KEY];
+};
+
 struct Table {
     Entry* ktab;
     uint64_t nb_mask;
@@ -74,6 +89,8 @@ struct Table {
     uint32_t* tombs;        // [TOMB_SHARDS] tombstones currently in ktab, as shards that sum to the count (wrap-around arithmetic)
     uint32_t* error_flag;   // != 0: a key could not be bound (no slot / no overflow space)
     uint32_t capacity;
+    RetiredRec* retired;    // TC_CFG_TRACK_DENIED: denial counts of keys that lost their slot (else nullptr)
+    uint32_t* denied;       // ... and the per-slot denial counters
 };
 
 // upper half of Entry::w for a key: 24 tag bits of the hash + len8
@@ -227,6 +244,56 @@ __device__ __forceinline__ bool key_equals_words(const uint8_t* __restrict__ oth
     uint64_t o[KEY_WORDS];
     load_words(other, len, other_safe, o);
     return words_equal(o, mine);
+}
+
+// ---- denial counts of keys without a slot (RetiredRec) ---------------------------------------------------------
+// sweep side: the key of slot `s` (hash h, len bytes at `key`) leaves with `count` denials
+__device__ inline void retire_denials(const Table& t, uint64_t h, const uint8_t* key, uint32_t len, uint32_t count) {
+    if (t.retired == nullptr || count == 0u || len > RETIRED_KEY) return;
+    const unsigned long long mine = h | RT_VALID;
+    uint32_t pos = (uint32_t)(h >> 17) & (RETIRED_CAP - 1u);
+    for (uint32_t probes = 0; probes < RETIRED_PROBES; ++probes, pos = (pos + 1u) & (RETIRED_CAP - 1u)) {
+        RetiredRec* r = &t.retired[pos];
+        unsigned long long tag = __hip_atomic_load(&r->tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        for (int spin = 0; tag == RT_BUSY && spin < 100000; ++spin) { // somebody is writing this record: a few hundred cycles
+            __builtin_amdgcn_s_sleep(2);
+            tag = __hip_atomic_load(&r->tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tag == mine && r->len == len && bytes_equal(r->bytes, key, len)) {
+            atomicAdd(&r->count, count);
+            return;
+        }
+        if (tag == RT_EMPTY || tag == RT_DELETED) {
+            unsigned long long expected = tag;
+            if (__hip_atomic_compare_exchange_strong(&r->tag, &expected, RT_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                r->count = count;
+                r->len = len;
+                for (uint32_t b = 0; b < len; ++b) r->bytes[b] = key[b];
+                __hip_atomic_store(&r->tag, mine, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+            --probes; // lost the record to another key: look at it again
+            pos = (pos + RETIRED_CAP - 1u) & (RETIRED_CAP - 1u);
+        }
+    }
+    // no room within RETIRED_PROBES records: the count is dropped (the reference's capped map forgets keys too)
+}
+// bind side: a key that gets a slot again takes its retired denials along
+__device__ inline void resurrect_denials(const Table& t, uint64_t h, const uint8_t* key, uint32_t len, uint32_t slot) {
+    if (t.retired == nullptr || len > RETIRED_KEY) return;
+    const unsigned long long mine = h | RT_VALID;
+    uint32_t pos = (uint32_t)(h >> 17) & (RETIRED_CAP - 1u);
+    for (uint32_t probes = 0; probes < RETIRED_PROBES; ++probes, pos = (pos + 1u) & (RETIRED_CAP - 1u)) {
+        RetiredRec* r = &t.retired[pos];
+        const unsigned long long tag = __hip_atomic_load(&r->tag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (tag == RT_EMPTY) return;
+        if (tag == mine && r->len == len && bytes_equal(r->bytes, key, len)) {
+            const uint32_t c = atomicExch(&r->count, 0u);
+            if (c) atomicAdd(&t.denied[slot], c);
+            __hip_atomic_store(&r->tag, RT_DELETED, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
 }
 
 // A request's key as (hash, k0, k1).  Keys of at most 16 bytes that do not end within 16 bytes of the
@@ -519,6 +586,7 @@ __device__ __forceinline__ uint32_t bind_claimant(const Table& t, const uint8_t*
         en->key[0] = k0;
         en->key[1] = k1;
         en->w = entry_meta(h, len) | (unsigned long long)(slot + 2u);
+        resurrect_denials(t, h, key, len, slot);
     } else { // the free stack ran dry
         t.ktab[pos].w = entry_meta(h, len) | VAL_TOMB;
         atomicAdd(&t.tombs[pos % TOMB_SHARDS], 1u);
@@ -678,6 +746,7 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
             en->key[0] = k0;
             en->key[1] = k1;
             en->w = meta | (unsigned long long)(slot + 2u);
+            resurrect_denials(t, h, key, len, slot);
             if (target == tomb_pos) atomicSub(&t.tombs[0], 1u);
             atomicAdd(inserted_counter, 1ull);
             return slot;

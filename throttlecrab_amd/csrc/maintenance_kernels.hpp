@@ -146,7 +146,15 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, 
             const uint32_t pos = t.rec[i].pos;
             t.ktab[pos].w = (t.ktab[pos].w & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
             t.bound[i] = 0;
-            if (denied) denied[i] = 0; // the slot will serve another key
+            if (denied) {
+                // the slot will serve another key; its denials stay with the key it served (kt::RetiredRec)
+                const uint32_t dc = denied[i];
+                if (dc) {
+                    const uint32_t klen = t.rec[i].len;
+                    if (klen != kt::NO_SLOT) kt::retire_denials(t, t.rec[i].hash, kt::stored_key(t, (uint32_t)i, klen), klen, dc);
+                    denied[i] = 0;
+                }
+            }
             s_buf[fill + rank] = (uint32_t)i;
         }
         fill += total;

@@ -215,6 +215,7 @@ struct tc_engine {
     bool key_mode = false;
     kt::Table kt;
     void* kt_block = nullptr;        // one allocation backing every kt.* array
+    kt::RetiredRec* retired = nullptr; // key mode + TC_CFG_TRACK_DENIED: denial counts of keys without a slot
     uint32_t *k_slot = nullptr, *k_state = nullptr, *k_aux = nullptr; // max_batch each
     uint32_t* k_claim = nullptr;     // keys first seen in the batch, per k_probe block
     uint64_t* k_hash = nullptr;
@@ -482,6 +483,13 @@ static int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     // (+32, +40: the overflow compaction's flag words)
     t.free_slots = (uint32_t*)(base + o_free);
     t.capacity = (uint32_t)cap;
+    t.retired = nullptr;
+    t.denied = e->denied;
+    if (e->denied) { // denial counts of keys that lose their slot (kt::RetiredRec)
+        TC_HIP(e, hipMalloc(&e->retired, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec)));
+        TC_HIP(e, hipMemsetAsync(e->retired, 0, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec), (hipStream_t)0));
+        t.retired = e->retired;
+    }
     hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, (hipStream_t)0,
                        t.free_slots, t.bound, (uint32_t)cap);
     const int top = (int)cap;
@@ -725,7 +733,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
         if (ss.k_slot) (void)hipFree(ss.k_slot);
-    void* kptrs[] = {e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_hash, e->k_stage_bytes, e->k_stage_off};
+    void* kptrs[] = {e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_hash, e->k_stage_bytes, e->k_stage_off};
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
     if (e->small_io) (void)hipHostFree(e->small_io);
@@ -2089,6 +2097,81 @@ extern "C" int tc_denied_reset(tc_engine* e) {
     if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
     TC_HIP(e, hipSetDevice(e->device));
     TC_HIP(e, hipMemsetAsync(e->denied, 0, e->capacity * sizeof(uint32_t), cur_stream(e)));
+    if (e->retired) TC_HIP(e, hipMemsetAsync(e->retired, 0, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec), cur_stream(e)));
+    return TC_E_OK;
+}
+
+// Top denied KEYS (key mode): the slots' counters and the side table of keys without a slot, merged.
+extern "C" int tc_top_denied_keys(tc_engine* e, uint32_t k, uint8_t* key_bytes, size_t key_bytes_cap, uint32_t* key_off, uint64_t* counts,
+                                  uint32_t* n_out) {
+    if (!e || !key_off || !counts || !n_out || (key_bytes_cap && !key_bytes)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
+    *n_out = 0;
+    key_off[0] = 0;
+    if (k == 0) return TC_E_OK;
+    if (k > TOPK_MAX) k = TOPK_MAX;
+    // keys that hold a slot
+    // (keys over 256 bytes are not tracked by the reference, metrics.rs:36-39: they are filtered out below, so a few
+    // more candidates than k are fetched)
+    const uint32_t k_live = std::min<uint32_t>(k + 64u, TOPK_MAX);
+    std::vector<uint32_t> slots(k_live);
+    std::vector<uint64_t> cnt(k_live);
+    uint32_t n_live = 0;
+    TC_TRY(tc_top_denied(e, k_live, slots.data(), cnt.data(), &n_live));
+    std::vector<std::pair<std::string, uint64_t>> all;
+    if (n_live) {
+        std::vector<uint32_t> off(n_live + 1);
+        std::vector<uint8_t> bytes(std::max<size_t>(1, (size_t)n_live * 64));
+        int rc;
+        while ((rc = tc_slot_keys(e, n_live, slots.data(), bytes.data(), bytes.size(), off.data())) == TC_E_INVALID_ARG && bytes.size() < ((size_t)1 << 31))
+            bytes.resize(bytes.size() * 4);
+        if (rc != TC_E_OK) return rc;
+        for (uint32_t i = 0; i < n_live; ++i)
+            if (off[i + 1] - off[i] <= kt::RETIRED_KEY) all.emplace_back(std::string((const char*)bytes.data() + off[i], off[i + 1] - off[i]), cnt[i]);
+    }
+    // keys that lost theirs (a key's denials are in exactly one place: see kt::RetiredRec)
+    std::vector<kt::RetiredRec> rt(kt::RETIRED_CAP);
+    hipStream_t s = cur_stream(e);
+    TC_HIP(e, hipMemcpyAsync(rt.data(), e->retired, rt.size() * sizeof(kt::RetiredRec), hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    std::vector<std::pair<std::string, uint64_t>> retired;
+    for (const kt::RetiredRec& r : rt)
+        if ((r.tag & kt::RT_VALID) && r.count) retired.emplace_back(std::string((const char*)r.bytes, r.len), (uint64_t)r.count);
+    auto by_count = [](const std::pair<std::string, uint64_t>& a, const std::pair<std::string, uint64_t>& b) {
+        return a.second != b.second ? a.second > b.second : a.first < b.first;
+    };
+    if (retired.size() > 3u * TOPK_MAX) {
+        // TopDeniedKeys::cleanup (metrics.rs:52-64): past 3 x the limit only the most denied `limit` keys are kept.
+        // The table is rewritten from the host (the engine is drained: this is a synchronous call).
+        std::sort(retired.begin(), retired.end(), by_count);
+        retired.resize(TOPK_MAX);
+        std::fill(rt.begin(), rt.end(), kt::RetiredRec{});
+        for (const auto& kv : retired) {
+            const uint64_t h = kt::hash_key((const uint8_t*)kv.first.data(), (uint32_t)kv.first.size());
+            uint32_t pos = (uint32_t)(h >> 17) & (kt::RETIRED_CAP - 1u);
+            while (rt[pos].tag != kt::RT_EMPTY) pos = (pos + 1u) & (kt::RETIRED_CAP - 1u);
+            rt[pos].tag = h | kt::RT_VALID;
+            rt[pos].count = (uint32_t)kv.second;
+            rt[pos].len = (uint32_t)kv.first.size();
+            memcpy(rt[pos].bytes, kv.first.data(), kv.first.size());
+        }
+        TC_HIP(e, hipMemcpyAsync(e->retired, rt.data(), rt.size() * sizeof(kt::RetiredRec), hipMemcpyHostToDevice, s));
+        TC_HIP(e, hipStreamSynchronize(s));
+    }
+    all.insert(all.end(), retired.begin(), retired.end());
+    std::sort(all.begin(), all.end(), by_count);
+    if (all.size() > k) all.resize(k);
+    size_t at = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (at + all[i].first.size() > key_bytes_cap) return fail(e, TC_E_INVALID_ARG, "tc_top_denied_keys: key_bytes_cap too small");
+        memcpy(key_bytes + at, all[i].first.data(), all[i].first.size());
+        at += all[i].first.size();
+        key_off[i + 1] = (uint32_t)at;
+        counts[i] = all[i].second;
+    }
+    *n_out = (uint32_t)all.size();
     return TC_E_OK;
 }
 
@@ -2207,6 +2290,7 @@ std::vector<Section> snapshot_sections(tc_engine* e) {
         v.push_back({t.free_slots, (size_t)t.capacity * 4});
         v.push_back({t.overflow_used, 64}); // overflow_used | free_top | error_flag | overflow_half
         v.push_back({t.tombs, kt::TOMB_SHARDS * 4});
+        if (e->retired) v.push_back({e->retired, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec)});
     }
     return v;
 }

@@ -460,16 +460,19 @@ class Engine:
         slots, counts = slots[: n.value], counts[: n.value]
         if not self.key_mode:
             return [(int(s), int(c)) for s, c in zip(slots, counts)]
-        off = np.zeros(n.value + 1, np.uint32)
-        buf = np.zeros(max(1, 256 * n.value), np.uint8)
+        # key mode: by KEY, the keys a sweep has unbound included (tc_top_denied_keys)
+        kk = max(k, 1)
+        off = np.zeros(kk + 1, np.uint32)
+        cnt = np.zeros(kk, np.uint64)
+        buf = np.zeros(max(1, 64 * kk), np.uint8)
         while True:
-            rc = self._lib.tc_slot_keys(self._h, n.value, slots.ctypes.data, buf.ctypes.data, buf.size, off.ctypes.data)
+            rc = self._lib.tc_top_denied_keys(self._h, k, buf.ctypes.data, buf.size, off.ctypes.data, cnt.ctypes.data, C.byref(n))
             if rc == L.TC_E_INVALID_ARG and buf.size < (1 << 30):
                 buf = np.zeros(buf.size * 8, np.uint8)
                 continue
             self._check(rc)
             break
-        return [(bytes(buf[off[i]:off[i + 1]]), int(counts[i])) for i in range(n.value)]
+        return [(bytes(buf[off[i]:off[i + 1]]), int(cnt[i])) for i in range(n.value)]
 
     def snapshot_save(self, path: str):
         self._check(self._lib.tc_snapshot_save(self._h, path.encode()))
