@@ -2,7 +2,7 @@
 // inline), no GPU needed.  They pin the three facts the evaluation kernels rest on:
 //   (1) closed form == sequence: for a regular run of identical requests, request r sees the cell
 //       new0 + (min(r, n_tot) - 1) * inc  (k_eval_sorted);
-//   (2) the host's proof obligation for direct stores (all_runs_regular in tcgpu.hip): with
+//   (2) the host's proof obligation for direct stores (all_runs_regular in slots.hip): with
 //       ei > 0, dvt > 0, q > 0, ei*q < 2^62, 0 <= now, now + dvt < 2^62, ANY cell whose first request
 //       is allowed gives a regular run;
 //   (3) late readers are harmless: once the run's allowance is used up, a request evaluated against

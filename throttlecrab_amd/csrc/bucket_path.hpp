@@ -152,7 +152,7 @@ __device__ __forceinline__ void settle_groups(bool active, uint32_t v, uint32_t 
 // ---------------------------------------------------------------------------
 // K1: requests per bucket, per tile
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(TILE_THREADS) void k_tile_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap, Work w) {
+static __global__ __launch_bounds__(TILE_THREADS) void k_tile_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap, Work w) {
     extern __shared__ uint32_t s_h[]; // [nbk]
     const uint32_t nbk = w.nbk;
     const uint32_t base = blockIdx.x * TILE + threadIdx.x;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_hist(const uint32_t* __re
 // K2: per bucket, exclusive prefix of the tile counts over the tiles + the bucket's total.
 // Block = 16 waves x 64 consecutive buckets; wave k owns a contiguous run of tiles.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(SCAN_THREADS) void k_bucket_scan(Work w, uint32_t tiles) {
+static __global__ __launch_bounds__(SCAN_THREADS) void k_bucket_scan(Work w, uint32_t tiles) {
     __shared__ uint32_t s_tot[SCAN_THREADS / 64][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t nbk = w.nbk;
@@ -245,7 +245,7 @@ __host__ __device__ inline uint32_t pad4(uint32_t v) { return (v + 3u) & ~3u; }
 constexpr uint32_t SCATTER_MARKS = 2048; // mark bytes per wave (hashed by the low bucket bits)
 inline size_t scatter_lds_bytes(uint32_t nbk) { return (size_t)pad4(nbk) * 4 * 2 + (size_t)SCATTER_MARKS * 4; }
 
-__global__ __launch_bounds__(TILE_THREADS) void k_scatter(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap, Work w) {
+static __global__ __launch_bounds__(TILE_THREADS) void k_scatter(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap, Work w) {
     extern __shared__ uint32_t s_mem[];
     const uint32_t longest = __builtin_nontemporal_load(w.maxb);
     if (w.gate_host && blockIdx.x == 0 && threadIdx.x == 0) *w.gate_host = longest;

@@ -1,0 +1,601 @@
+// engine.hip -- engine life cycle: allocation, streams, rate plans, counters, profiling, test hooks (include/tcgpu.h)
+#include "engine.hpp"
+
+hipStream_t cur_stream(tc_engine* e) {
+    if (e->user_stream) return e->user_stream;
+    if (!e->own_stream && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    return e->own_stream;
+}
+
+// begin / end of one kernel of `stage` on stream `s` (no-ops unless profiling)
+void prof_begin(tc_engine* e, int stage, hipStream_t s) {
+    if (!e->prof_on) return;
+    if (e->prof_used == e->prof_stage.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+        e->prof_ev.push_back(a);
+        e->prof_ev.push_back(b);
+        e->prof_stage.push_back(-1);
+    }
+    e->prof_stage[e->prof_used] = stage;
+    (void)hipEventRecord(e->prof_ev[2 * e->prof_used], s);
+}
+
+void prof_end(tc_engine* e, hipStream_t s) {
+    if (!e->prof_on || e->prof_used == e->prof_stage.size()) return;
+    (void)hipEventRecord(e->prof_ev[2 * e->prof_used + 1], s);
+    e->prof_used++;
+}
+
+// every host <-> device copy of a batch goes through here, so that tests can make one of them fail
+hipError_t copy_async(tc_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+    if (e->fault_countdown && --e->fault_countdown == 0) return hipErrorInvalidValue;
+    return hipMemcpyAsync(dst, src, bytes, kind, st);
+}
+
+int fail(tc_engine* e, int code, const char* msg) {
+    if (e) e->err = msg;
+    return code;
+}
+
+extern "C" uint32_t tc_abi_version(void) { return TCGPU_ABI_VERSION; }
+
+extern "C" const char* tc_last_error(const tc_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+static size_t sort_ws_words(uint32_t max_tiles) { return rs::workspace_words(max_tiles); }
+
+// the device-side address of the poison word goes into the counter block, POISON_PTR_WORDS behind the violation counter
+// (tc::invariant_failed finds it there: no kernel carries an extra argument for something that never happens)
+int publish_poison_ptr(tc_engine* e) {
+    void* dv = nullptr;
+    TC_HIP(e, hipHostGetDevicePointer(&dv, e->poison_host, 0));
+    const unsigned long long v = (unsigned long long)(uintptr_t)dv;
+    TC_HIP(e, hipMemcpy(e->counters + (TC_CNT_COUNT + 1) + 3 + tc::POISON_PTR_WORDS, &v, sizeof v, hipMemcpyHostToDevice));
+    return TC_E_OK;
+}
+
+// sticky: once a kernel has flagged a broken invariant the engine answers nothing else
+int poisoned(tc_engine* e) {
+    if (e->poison_host && *(volatile uint32_t*)e->poison_host != 0u) {
+        e->err = "an internal invariant failed on the device (a wait gave up, or a closed form met a state it was proven not to meet): "
+                 "results and state are undefined -- destroy the engine";
+        return TC_E_INVARIANT;
+    }
+    return TC_E_OK;
+}
+
+int engine_alloc(tc_engine* e) {
+    TC_HIP(e, hipSetDevice(e->device));
+    const uint64_t cap = e->capacity, mb = e->max_batch;
+    e->fixed = (e->cfg_flags & TC_CFG_FIXED_PARAMS) != 0;
+    if (e->fixed) TC_HIP(e, hipMalloc(&e->tat8, cap * sizeof(int64_t)));
+    else TC_HIP(e, hipMalloc(&e->cells, cap * sizeof(Cell)));
+    TC_HIP(e, hipMalloc(&e->rate_id, cap * sizeof(uint16_t)));
+    TC_HIP(e, hipMalloc(&e->classes, (size_t)MAX_CLASSES * sizeof(RateClass)));
+    e->host_classes.assign(1, RateClass{0, 0, 0, 0});
+    if (e->cfg_flags & TC_CFG_TRACK_DENIED) {
+        TC_HIP(e, hipMalloc(&e->denied, cap * sizeof(uint32_t)));
+        TC_HIP(e, hipMemsetAsync(e->denied, 0, cap * sizeof(uint32_t), (hipStream_t)0));
+        TC_HIP(e, hipMalloc(&e->topk_ws, (256 + 2 + 4 * (size_t)TOPK_MAX) * sizeof(uint32_t)));
+    }
+    const size_t cnt_words = (TC_CNT_COUNT + 1) + (size_t)NSHARD * SHARD_WORDS;
+    TC_HIP(e, hipMalloc(&e->counters, cnt_words * sizeof(unsigned long long)));
+    if (e->fixed) hipLaunchKernelGGL(k_fill_i64, dim3(std::min<uint64_t>(nblocks(cap), 4096)), dim3(BLOCK), 0, (hipStream_t)0, e->tat8, cap, tc::TAT_VACANT);
+    else TC_HIP(e, hipMemsetAsync(e->cells, 0, cap * sizeof(Cell), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->rate_id, 0, cap * sizeof(uint16_t), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->classes, 0, (size_t)MAX_CLASSES * sizeof(RateClass), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(e->counters, 0, cnt_words * sizeof(unsigned long long), (hipStream_t)0));
+    TC_HIP(e, hipHostMalloc((void**)&e->poison_host, 64, hipHostMallocDefault));
+    *e->poison_host = 0u;
+    TC_TRY_EARLY(publish_poison_ptr(e));
+    e->sort_max_tiles = (uint32_t)((mb + rs::THREADS * SORT_ITEMS - 1) / (rs::THREADS * SORT_ITEMS));
+    const size_t words = sort_ws_words(e->sort_max_tiles);
+    e->n_aux = (e->cfg_flags & TC_CFG_KEY_MODE) ? AUX_KEY_MODE : AUX_SLOT_MODE;
+    if (const char* d = getenv("TCGPU_AUX_STREAMS")) e->n_aux = (uint32_t)std::min(std::max(atoi(d), 1), AUX_MAX);
+    e->depth = e->n_aux + 3; // scratch sets: the grouping streams run up to two batches further ahead of the evaluation (47.3 -> 45-47 us)
+    if (const char* d = getenv("TCGPU_PIPE_DEPTH")) e->depth = (uint32_t)std::min(std::max(atoi(d), 1), PIPE_DEPTH_MAX);
+    int prio_lo = 0, prio_hi = 0;
+    TC_HIP(e, hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    if (const char* d = getenv("TCGPU_EVAL_ITEMS")) e->eval_items = atoi(d);
+    if (const char* d = getenv("TCGPU_EVAL_LEAN")) e->eval_lean = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_STOP_EVENTS")) e->stop_events = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_DEBUG_NO_DECISION_STORE")) e->debug_nostore = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
+    {
+        TC_HIP(e, hipHostMalloc((void**)&e->fill_hint_host, 64, hipHostMallocDefault));
+        *e->fill_hint_host = 1u;
+        void* dv = nullptr;
+        TC_HIP(e, hipHostGetDevicePointer(&dv, e->fill_hint_host, 0));
+        e->fill_hint_dev = (uint32_t*)dv;
+    }
+    if (const char* d = getenv("TCGPU_SORT_ITEMS_PIPED")) {
+        const int v = atoi(d);
+        if (v == 8 || v == 16 || v == 32) e->sort_items_piped = v;
+    }
+    if (const char* d = getenv("TCGPU_NO_SMALL_BATCH")) e->small_off = atoi(d) != 0;
+    const char* pe = getenv("TCGPU_AUX_PRIORITY");
+    const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
+    // the evaluation kernel on the main stream is the critical path of the pipeline: grouping runs at
+    // the lowest priority and fills what the evaluation leaves free (TCGPU_AUX_PRIORITY=1 flips it)
+    e->n_aux_want = e->n_aux;
+    e->aux_priority = aux_high ? prio_hi : prio_lo;
+    TC_HIP(e, hipMalloc(&e->probe_ws, 2 * sizeof(uint32_t)));
+    // (the grouping streams themselves are created by ensure_side_streams, against the actual main stream)
+    for (uint32_t si = 0; si < e->depth; ++si) {
+        tc_engine::SortSet& ss = e->sets[si];
+        TC_HIP(e, hipMalloc(&ss.elem_a, mb * sizeof(uint64_t)));
+        TC_HIP(e, hipMalloc(&ss.elem_b, mb * sizeof(uint64_t)));
+        TC_HIP(e, hipMalloc(&ss.ws, words * sizeof(uint32_t)));
+        TC_HIP(e, hipMemsetAsync(ss.ws, 0, words * sizeof(uint32_t), (hipStream_t)0));
+        TC_HIP(e, hipEventCreateWithFlags(&ss.sorted, hipEventDisableTiming));
+        TC_HIP(e, hipEventCreateWithFlags(&ss.consumed, hipEventDisableTiming));
+    }
+    {
+        e->bp_max_n = (uint32_t)std::min<uint64_t>(mb, bp::MAX_N);
+        e->bp_lb = bp::pick_lb(cap, e->bp_max_n);
+        const char* off = getenv("TCGPU_BUCKET");
+        e->bp_ok = e->bp_lb >= 0 && !(off && atoi(off) == 0);
+        e->bp_min_n = 16384;
+        if (const char* d = getenv("TCGPU_BUCKET_PIPED")) e->bp_piped = atoi(d) != 0;
+        if (const char* d = getenv("TCGPU_BUCKET_BACKOFF")) e->bp_backoff_len = (uint32_t)std::max(atoi(d), 0);
+        if (const char* d = getenv("TCGPU_BUCKET_MIN_N")) e->bp_min_n = (uint32_t)std::max(atoi(d), 1);
+        if (const char* d = getenv("TCGPU_BUCKET_SKEW")) e->bp_skew = (uint32_t)std::min<long long>(std::max(atoll(d), 1ll), bp::MAX_SKEW);
+        if (e->bp_ok) {
+            // the partition kernels size their LDS by the bucket count (k_scatter: 8 B per bucket + marks, k_tile_hist:
+            // 4 B per bucket) and the evaluation by the bucket width: a key space whose bucket count needs more than a
+            // block may have is sorted instead (a rejected launch would leave stale elements behind a valid gate)
+            hipDeviceProp_t prop;
+            TC_HIP(e, hipGetDeviceProperties(&prop, e->device));
+            const uint32_t nbk = bp::buckets_of(cap, e->bp_lb);
+            const size_t need = std::max({bp::scatter_lds_bytes(nbk), (size_t)nbk * sizeof(uint32_t), bp::eval_lds_bytes(e->bp_lb)});
+            if (need > (size_t)prop.sharedMemPerBlock) e->bp_ok = false;
+        }
+        if (e->bp_ok) {
+            TC_HIP(e, hipHostMalloc((void**)&e->bp_gate_host, sizeof(uint32_t), hipHostMallocDefault));
+            *e->bp_gate_host = 0;
+            e->bp_nbk = bp::buckets_of(cap, e->bp_lb);
+            const size_t bytes = bp::work_bytes(e->bp_max_n, e->bp_nbk);
+            for (uint32_t si = 0; si < e->depth; ++si) {
+                tc_engine::SortSet& ss = e->sets[si];
+                TC_HIP(e, hipMalloc(&ss.bp_scratch, bytes));
+                ss.bpw = bp::carve(ss.bp_scratch, e->bp_max_n, e->bp_nbk, e->bp_lb);
+                ss.bpw.skew = e->bp_skew;
+                ss.bpw.gate_host = e->bp_gate_host;
+            }
+            TC_HIP(e, hipMalloc(&e->bp_park, (size_t)e->bp_max_n * sizeof(PendEntry)));
+        }
+    }
+    TC_HIP(e, hipMalloc(&e->pend, (mb / 32 + 1024) * sizeof(PendEntry)));
+    TC_HIP(e, hipMalloc(&e->chain, (mb / 64 + 2) * sizeof(ChainRec)));
+    TC_HIP(e, hipMemsetAsync(e->chain, 0, (mb / 64 + 2) * sizeof(ChainRec), (hipStream_t)0));
+    TC_HIP(e, hipMalloc(&e->loaded, (mb / 64 + 2) * sizeof(uint32_t)));
+    TC_HIP(e, hipMemsetAsync(e->loaded, 0, (mb / 64 + 2) * sizeof(uint32_t), (hipStream_t)0));
+    TC_HIP(e, hipMalloc(&e->pend_count, 2 * sizeof(uint32_t)));
+    TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), (hipStream_t)0));
+    TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
+    TC_HIP(e, hipMalloc(&e->op_result, sizeof(StoreOpResult)));
+    TC_HIP(e, hipMalloc(&e->one_result, sizeof(OneResult)));
+    TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
+    return TC_E_OK;
+}
+
+// ---- string-key mode ----------------------------------------------------------
+static size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
+    const uint64_t cap = e->capacity, mb = e->max_batch;
+    uint64_t nb = 1;
+    while (nb < 2 * cap) nb <<= 1; // load factor <= 0.5
+    // keys up to 112 bytes live inside their slot's KeyRec (one 128-byte line); longer ones in the overflow arena
+    const uint64_t overflow = align_up(key_arena_bytes ? key_arena_bytes : std::max<uint64_t>(1u << 20, cap * 4), 256);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = align_up(off + bytes, 256);
+        return at;
+    };
+    const size_t o_ktab = take(nb * sizeof(kt::Entry)), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(2 * overflow),
+                 o_free = take(cap * 4), o_misc = take(64), o_tombs = take(kt::TOMB_SHARDS * 4);
+    TC_HIP(e, hipMalloc(&e->kt_block, off));
+    uint8_t* base = (uint8_t*)e->kt_block;
+    TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * sizeof(kt::Entry), (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(base + o_misc, 0, 64, (hipStream_t)0));
+    TC_HIP(e, hipMemsetAsync(base + o_tombs, 0, kt::TOMB_SHARDS * 4, (hipStream_t)0));
+    kt::Table& t = e->kt;
+    t.ktab = (kt::Entry*)(base + o_ktab);
+    t.nb_mask = nb - 1;
+    t.rec = (kt::KeyRec*)(base + o_rec);
+    t.bound = base + o_bound;
+    t.overflow = base + o_ovf;
+    t.overflow_bytes = overflow;
+    t.overflow_used = (unsigned long long*)(base + o_misc);
+    t.free_top = (int*)(base + o_misc + 8);
+    t.tombs = (uint32_t*)(base + o_tombs);
+    t.error_flag = (uint32_t*)(base + o_misc + 16); // (+20: the rebuild's flag word)
+    t.overflow_half = (uint32_t*)(base + o_misc + 24);
+    // (+32, +40: the overflow compaction's flag words)
+    t.free_slots = (uint32_t*)(base + o_free);
+    t.capacity = (uint32_t)cap;
+    t.retired = nullptr;
+    t.denied = e->denied;
+    if (e->denied) { // denial counts of keys that lose their slot (kt::RetiredRec)
+        TC_HIP(e, hipMalloc(&e->retired, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec)));
+        TC_HIP(e, hipMemsetAsync(e->retired, 0, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec), (hipStream_t)0));
+        t.retired = e->retired;
+    }
+    hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, (hipStream_t)0,
+                       t.free_slots, t.bound, (uint32_t)cap);
+    const int top = (int)cap;
+    TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, (hipStream_t)0));
+    TC_HIP(e, hipMalloc(&e->k_slot, mb * 4));
+    for (uint32_t si = 0; si < e->depth; ++si) TC_HIP(e, hipMalloc(&e->sets[si].k_slot, mb * 4));
+    TC_HIP(e, hipEventCreateWithFlags(&e->k_done, hipEventDisableTiming));
+    TC_HIP(e, hipEventCreateWithFlags(&e->m_done, hipEventDisableTiming));
+    TC_HIP(e, hipMalloc(&e->k_state, mb * 4));
+    TC_HIP(e, hipMalloc(&e->k_aux, mb * 4));
+    TC_HIP(e, hipMalloc(&e->k_claim, ((size_t)nblocks(mb) + 1) * 4));
+    TC_HIP(e, hipMalloc(&e->k_hash, mb * 8));
+    TC_HIP(e, hipMalloc(&e->k_stage_off, (mb + 1) * 4));
+    TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
+    e->key_mode = true;
+    return TC_E_OK;
+}
+
+// true if work on `b` runs while work on `a` is running (different hardware queues)
+static int streams_concurrent(tc_engine* e, hipStream_t a, hipStream_t b, bool* out) {
+    uint32_t zero[2] = {0u, 0u}, saw = 0;
+    TC_HIP(e, hipMemcpyAsync(e->probe_ws, zero, sizeof zero, hipMemcpyHostToDevice, a));
+    TC_HIP(e, hipStreamSynchronize(a));
+    TC_HIP(e, hipStreamSynchronize(b));
+    hipLaunchKernelGGL(k_probe_spin, dim3(1), dim3(64), 0, a, e->probe_ws, e->probe_ws + 1, 30000LL); // <= 300 us
+    hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(64), 0, b, e->probe_ws);
+    TC_HIP(e, hipGetLastError());
+    TC_HIP(e, hipStreamSynchronize(a));
+    TC_HIP(e, hipStreamSynchronize(b));
+    TC_HIP(e, hipMemcpy(&saw, e->probe_ws + 1, sizeof saw, hipMemcpyDeviceToHost));
+    *out = saw != 0u;
+    return TC_E_OK;
+}
+
+// The grouping streams (and the key stream) must not share a hardware queue with the main stream or
+// with each other: two active streams on one queue serialise, which costs the pipeline half its
+// throughput.  Which queue a new stream lands on depends on everything the
+// process created before (torch, RCCL, other engines), so candidates are created and PROBED against
+// the main stream in use; the ones that do not run concurrently are dropped.  ~0.5 ms, once per main stream.
+int ensure_side_streams(tc_engine* e) {
+    hipStream_t m = cur_stream(e);
+    if (e->side_ready && e->side_for == m) return TC_E_OK;
+    TC_HIP(e, hipStreamSynchronize(m));
+    for (hipStream_t& a : e->aux)
+        if (a) {
+            TC_HIP(e, hipStreamSynchronize(a));
+            (void)hipStreamDestroy(a);
+            a = nullptr;
+        }
+    if (e->key_stream) {
+        TC_HIP(e, hipStreamSynchronize(e->key_stream));
+        (void)hipStreamDestroy(e->key_stream);
+        e->key_stream = nullptr;
+    }
+    const uint32_t want = e->n_aux_want + (e->key_mode ? 1u : 0u);
+    std::vector<hipStream_t> good, bad;
+    for (int c = 0; c < 16 && good.size() < want; ++c) {
+        hipStream_t s = nullptr;
+        int rc = TC_E_OK;
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, e->aux_priority) != hipSuccess) rc = fail(e, TC_E_HIP, "hipStreamCreateWithPriority failed");
+        bool ok = false;
+        if (rc == TC_E_OK) rc = streams_concurrent(e, m, s, &ok);
+        for (size_t g = 0; rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
+        if (rc != TC_E_OK) {
+            if (s) (void)hipStreamDestroy(s);
+            for (hipStream_t x : good) (void)hipStreamDestroy(x);
+            for (hipStream_t x : bad) (void)hipStreamDestroy(x);
+            return rc;
+        }
+        (ok ? good : bad).push_back(s);
+    }
+    for (hipStream_t s : bad) (void)hipStreamDestroy(s);
+    size_t gi = 0;
+    if (e->key_mode && !good.empty()) e->key_stream = good[gi++];
+    e->n_aux = 0;
+    for (; gi < good.size() && e->n_aux < (uint32_t)AUX_MAX; ++gi) e->aux[e->n_aux++] = good[gi];
+    e->next_aux = 0;
+    e->side_for = m;
+    e->side_ready = true;
+    return TC_E_OK; // n_aux == 0: no free hardware queue, TC_B_INPUTS_READY batches run in order on the main stream
+}
+
+extern "C" tc_engine* tc_engine_create(const tc_config* cfg, int* err) {
+    int dummy;
+    if (!err) err = &dummy;
+    *err = TC_E_OK;
+    if (!cfg || cfg->struct_size < sizeof(tc_config) || cfg->capacity == 0 || cfg->max_batch == 0 ||
+        cfg->capacity >= 0x7FFFFFFFull || cfg->max_batch >= 0x3FFFFFFFull) {
+        *err = TC_E_INVALID_ARG;
+        return nullptr;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id < 0 || cfg->device_id >= ndev) {
+        *err = TC_E_NO_DEVICE;
+        return nullptr;
+    }
+    if ((cfg->flags & TC_CFG_FIXED_PARAMS) && (cfg->flags & TC_CFG_KEY_MODE)) {
+        *err = TC_E_UNSUPPORTED; // string keys carry their rate with every request: nothing is fixed
+        return nullptr;
+    }
+    tc_engine* e = new (std::nothrow) tc_engine();
+    if (!e) {
+        *err = TC_E_NOMEM;
+        return nullptr;
+    }
+    e->device = cfg->device_id;
+    e->capacity = cfg->capacity;
+    e->max_batch = cfg->max_batch;
+    e->cfg_flags = cfg->flags;
+    int rc = engine_alloc(e);
+    if (rc == TC_E_OK && (cfg->flags & TC_CFG_KEY_MODE)) rc = key_mode_alloc(e, cfg->key_arena_bytes);
+    if (rc != TC_E_OK) {
+        fprintf(stderr, "tcgpu: engine_create failed: %s\n", e->err.c_str());
+        *err = rc;
+        tc_engine_destroy(e);
+        return nullptr;
+    }
+    return e;
+}
+
+extern "C" void tc_engine_destroy(tc_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->user_stream) (void)hipStreamSynchronize(e->user_stream);
+    if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
+    for (hipStream_t a : e->aux)
+        if (a) {
+            (void)hipStreamSynchronize(a);
+            (void)hipStreamDestroy(a);
+        }
+    for (tc_engine::SortSet& ss : e->sets) {
+        if (ss.sorted) (void)hipEventDestroy(ss.sorted);
+        if (ss.consumed) (void)hipEventDestroy(ss.consumed);
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        for (void* p : sp)
+            if (p) (void)hipFree(p);
+    }
+    void* ptrs[] = {e->route_ws, e->bp_park, e->cells, e->tat8, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
+                    e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
+                    e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
+                    e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};
+    for (void* p : ptrs)
+        if (p) (void)hipFree(p);
+    if (e->key_stream) {
+        (void)hipStreamSynchronize(e->key_stream);
+        (void)hipStreamDestroy(e->key_stream);
+    }
+    if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
+    if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
+    if (e->poison_host) (void)hipHostFree(e->poison_host);
+    if (e->k_done) (void)hipEventDestroy(e->k_done);
+    if (e->m_done) (void)hipEventDestroy(e->m_done);
+    for (tc_engine::SortSet& ss : e->sets)
+        if (ss.k_slot) (void)hipFree(ss.k_slot);
+    void* kptrs[] = {e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_hash, e->k_stage_bytes, e->k_stage_off};
+    for (void* p : kptrs)
+        if (p) (void)hipFree(p);
+    if (e->small_io) (void)hipHostFree(e->small_io);
+    for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->async_done) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : e->async_pool) (void)hipEventDestroy(ev);
+    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    delete e;
+}
+
+extern "C" int tc_engine_set_stream(tc_engine* e, void* hip_stream) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    if (e->user_stream || e->own_stream) TC_HIP(e, hipStreamSynchronize(cur_stream(e))); // drain the old one first
+    e->user_stream = (hipStream_t)hip_stream;
+    e->side_ready = false; // the side streams are probed against the main stream in use
+    return TC_E_OK;
+}
+
+extern "C" int tc_synchronize(tc_engine* e) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    // every TC_B_ASYNC batch recorded its completion on this stream
+    while (!e->async_done.empty()) {
+        e->async_pool.push_back(e->async_done.front());
+        e->async_done.pop_front();
+    }
+    return poisoned(e);
+}
+
+// (burst, count, period) -> class id, creating (and uploading) the class if new.
+// 0 = invalid triple; -1 = dictionary full.
+int intern_class(tc_engine* e, int64_t burst, int64_t count, int64_t period, bool* grew) {
+    RateClass rc{0, 0, 0, 0};
+    if (tc::derive_rate(burst, count, period, rc.ei, rc.dvt) != tc::ST_OK) return 0;
+    rc.burst = burst;
+    const int64_t key[3] = {burst, count, period};
+    const std::string k((const char*)key, sizeof key);
+    auto it = e->class_of.find(k);
+    if (it != e->class_of.end()) return it->second;
+    if (e->host_classes.size() >= MAX_CLASSES) return -1;
+    const uint16_t id = (uint16_t)e->host_classes.size();
+    e->cls_min_ei = std::min(e->cls_min_ei, rc.ei);
+    e->cls_max_ei = std::max(e->cls_max_ei, rc.ei);
+    e->cls_min_dvt = std::min(e->cls_min_dvt, rc.dvt);
+    e->cls_max_dvt = std::max(e->cls_max_dvt, rc.dvt);
+    e->host_classes.push_back(rc);
+    e->class_of.emplace(k, id);
+    *grew = true;
+    return id;
+}
+
+int upload_classes(tc_engine* e) {
+    TC_HIP(e, hipMemcpyAsync(e->classes, e->host_classes.data(), e->host_classes.size() * sizeof(RateClass),
+                             hipMemcpyHostToDevice, cur_stream(e)));
+    return TC_E_OK;
+}
+
+extern "C" int tc_register_params_uniform(tc_engine* e, int64_t max_burst, int64_t count_per_period, int64_t period) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    bool grew = false;
+    const int id = intern_class(e, max_burst, count_per_period, period, &grew);
+    if (id == 0) return fail(e, TC_E_INVALID_ARG, "tc_register_params_uniform: invalid (burst,count,period)");
+    if (id < 0) return fail(e, TC_E_UNSUPPORTED, "more than 65535 distinct rate plans registered");
+    if (e->fixed) {
+        if (e->sealed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: plans cannot change once a request has been decided");
+        const RateClass& rc = e->host_classes[id];
+        if (!tc::fixed_plan_ok(rc.ei, rc.dvt)) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: the plan needs burst >= 2 and an emission interval / tolerance below 2^60 ns");
+    }
+    TC_HIP(e, hipSetDevice(e->device));
+    if (grew) {
+        int rc = upload_classes(e);
+        if (rc != TC_E_OK) return rc;
+    }
+    hipLaunchKernelGGL(k_fill_rate_id, dim3(std::min<uint64_t>(nblocks(e->capacity), 4096)), dim3(BLOCK), 0, cur_stream(e),
+                       e->rate_id, e->capacity, (uint16_t)id);
+    TC_HIP(e, hipGetLastError());
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    e->uniform_id = (uint16_t)id;
+    return TC_E_OK;
+}
+
+extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slots, const int64_t* max_burst,
+                                  const int64_t* count_per_period, const int64_t* period) {
+    if (!e || !max_burst || !count_per_period || !period) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (n == 0) return TC_E_OK;
+    if (!slots && n > e->capacity) return fail(e, TC_E_INVALID_ARG, "tc_register_params: n > capacity");
+    // validate everything before touching the dictionary or the device
+    if (e->fixed && e->sealed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: plans cannot change once a request has been decided");
+    for (uint64_t i = 0; i < n; ++i) {
+        if (slots && slots[i] >= e->capacity) return fail(e, TC_E_INVALID_ARG, "tc_register_params: slot out of range");
+        int64_t ei, dvt;
+        if (tc::derive_rate(max_burst[i], count_per_period[i], period[i], ei, dvt) != tc::ST_OK)
+            return fail(e, TC_E_INVALID_ARG, "tc_register_params: invalid (burst,count,period)");
+        if (e->fixed && !tc::fixed_plan_ok(ei, dvt))
+            return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: every plan needs burst >= 2 and an emission interval / tolerance below 2^60 ns");
+    }
+    std::vector<uint16_t> ids(n);
+    bool grew = false;
+    int last_id = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (i && max_burst[i] == max_burst[i - 1] && count_per_period[i] == count_per_period[i - 1] && period[i] == period[i - 1]) {
+            ids[i] = (uint16_t)last_id; // runs of one plan are the common case
+            continue;
+        }
+        last_id = intern_class(e, max_burst[i], count_per_period[i], period[i], &grew);
+        if (last_id < 0) return fail(e, TC_E_UNSUPPORTED, "more than 65535 distinct rate plans registered");
+        ids[i] = (uint16_t)last_id;
+    }
+    TC_HIP(e, hipSetDevice(e->device));
+    if (grew) {
+        int rc = upload_classes(e);
+        if (rc != TC_E_OK) return rc;
+    }
+    struct Tmp { // upload buffers, released on every exit
+        uint16_t* id = nullptr;
+        uint32_t* slot = nullptr;
+        ~Tmp() {
+            if (id) (void)hipFree(id);
+            if (slot) (void)hipFree(slot);
+        }
+    } d;
+    TC_HIP(e, hipMalloc(&d.id, n * sizeof(uint16_t)));
+    if (slots) TC_HIP(e, hipMalloc(&d.slot, n * sizeof(uint32_t)));
+    TC_HIP(e, hipMemcpyAsync(d.id, ids.data(), n * sizeof(uint16_t), hipMemcpyHostToDevice, cur_stream(e)));
+    if (slots) TC_HIP(e, hipMemcpyAsync(d.slot, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+    hipLaunchKernelGGL(k_scatter_rate_id, dim3(nblocks(n)), dim3(BLOCK), 0, cur_stream(e), e->rate_id, d.slot, d.id, n);
+    TC_HIP(e, hipGetLastError());
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    e->uniform_id = 0; // per-slot plans from now on: evaluation reads rate_id[]
+    return TC_E_OK;
+}
+
+extern "C" int tc_counters_refresh(tc_engine* e) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(NSHARD), 0, cur_stream(e), e->counters);
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
+extern "C" int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]) {
+    if (!e || !out) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    int rc = tc_counters_refresh(e);
+    if (rc != TC_E_OK) return rc;
+    TC_HIP(e, hipMemcpyAsync(out, e->counters, TC_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    out[TC_CNT_BATCHES] = e->batches;
+    return TC_E_OK;
+}
+
+extern "C" int tc_profile_enable(tc_engine* e, int on) {
+    if (!e) return TC_E_INVALID_ARG;
+    e->prof_on = on != 0;
+    e->prof_used = 0;
+    for (int i = 0; i < TC_STAGE_COUNT; ++i) {
+        e->prof_ms[i] = 0;
+        e->prof_calls[i] = 0;
+    }
+    return TC_E_OK;
+}
+
+extern "C" int tc_profile_read(tc_engine* e, double total_ms[TC_STAGE_COUNT], uint64_t calls[TC_STAGE_COUNT]) {
+    if (!e || !total_ms || !calls) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    for (hipStream_t a : e->aux)
+        if (a) TC_HIP(e, hipStreamSynchronize(a));
+    if (e->key_stream) TC_HIP(e, hipStreamSynchronize(e->key_stream));
+    for (size_t i = 0; i < e->prof_used; ++i) {
+        const int st = e->prof_stage[i];
+        if (st < 0) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e->prof_ev[2 * i], e->prof_ev[2 * i + 1]) == hipSuccess) {
+            e->prof_ms[st] += ms;
+            e->prof_calls[st] += 1;
+        }
+    }
+    e->prof_used = 0;
+    for (int i = 0; i < TC_STAGE_COUNT; ++i) {
+        total_ms[i] = e->prof_ms[i];
+        calls[i] = e->prof_calls[i];
+    }
+    return TC_E_OK;
+}
+
+extern "C" int tc_counters_device_ptr(tc_engine* e, void** dptr) {
+    if (!e || !dptr) return TC_E_INVALID_ARG;
+    *dptr = e->counters;
+    return TC_E_OK;
+}
+
+// Test hook: the n-th staging copy (host <-> device, any batch path) from now returns an error instead of
+// being issued.  0 disarms.
+extern "C" int tc_debug_break_wait(tc_engine* e, uint32_t on) {
+    if (!e) return TC_E_INVALID_ARG;
+    e->debug_break_wait = on != 0;
+    return TC_E_OK;
+}
+
+extern "C" int tc_debug_fail_copy(tc_engine* e, uint32_t nth) {
+    if (!e) return TC_E_INVALID_ARG;
+    e->fault_countdown = nth;
+    return TC_E_OK;
+}
+
+// Internal invariant violations seen so far (0 unless there is a bug): runs that turned out
+// irregular in a batch the host had proved regular (k_eval_sorted<DIRECT>).
+extern "C" int tc_selfcheck(tc_engine* e, uint64_t* violations) {
+    if (!e || !violations) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    unsigned long long v = 0;
+    TC_HIP(e, hipMemcpyAsync(&v, e->counters + (TC_CNT_COUNT + 1) + 3, sizeof v, hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    *violations = v;
+    return TC_E_OK;
+}

@@ -1,0 +1,309 @@
+// engine.hpp -- what the translation units of libtcgpu.so share: the engine's state (struct tc_engine), the error /
+// launch macros and the handful of host helpers that more than one unit calls.  The kernels live in the *_kernels.hpp /
+// radix_sort.hpp / bucket_path.hpp / key_table.hpp headers (internal linkage: every unit compiles the ones it launches).
+//   engine.hip    create / destroy, allocation, streams, rate plans, counters, profiling, hooks
+//   slots.hip     tc_rate_limit_batch_slots: staging, grouping (sort / bucket path), evaluation, small batches
+//   keys.hip      string keys: key stages, tc_rate_limit_batch_keys, tc_rate_limit, the `trait Store` shims
+//   maint.hip     sweep, top denied keys, state introspection
+//   snapshot.hip  tc_snapshot_save / load
+//   route.hip     multi-GPU: tc_route_batch, tc_forward_segments, the host mirror of the map
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <deque>
+#include <vector>
+
+#include "../../include/tcgpu.h"
+#include "gcra_math.hpp"
+#include "key_table.hpp"
+#include "radix_sort.hpp"
+
+#include "eval_kernels.hpp"
+#include "bucket_path.hpp"
+#include "maintenance_kernels.hpp"
+#include "route_kernels.hpp"
+
+using tc::Cell;
+using tc::RateClass;
+
+using namespace ev;
+using namespace mk;
+
+namespace tcg {
+
+
+// Items per thread of a sort tile.  Alone on the chip, 2048-request tiles (512 blocks per 1 Mi batch) are
+// fastest (18.6 vs 21.1 us per pass).  Pipelined, the tiles of up to three sorts spin in their look-back
+// next to the evaluation kernel and every one of them holds 4 wave slots: 4096-request tiles halve that
+// (evaluation 63 -> 56 us under overlap, 13.9 -> 15.1 G decisions/s).
+constexpr int SORT_ITEMS = 8;        // batches that run in order on the engine's stream
+constexpr int SORT_ITEMS_PIPED = 16; // TC_B_INPUTS_READY batches (grouped on the auxiliary streams)
+constexpr int PIPE_DEPTH_MAX = 8;
+constexpr uint32_t BP_BACKOFF = 32;          // batches sorted without trying the bucket path after a skewed one was seen
+constexpr int AUX_MAX = 4;                  // auxiliary (grouping) streams
+// HIP multiplexes streams onto 4 hardware queues; two ACTIVE streams on one queue serialise each other
+// (a barrier packet of one blocks the other: measured 14.7 -> 7.4 G/s with a fifth stream).  Slot mode:
+// main + 3 grouping streams; string mode: main + key stream + 2.  TCGPU_AUX_STREAMS / TCGPU_PIPE_DEPTH
+// override (bench.py uses 2 when RCCL's stream is in the process too).
+constexpr int AUX_SLOT_MODE = 3, AUX_KEY_MODE = 2;
+// grouping scratch sets = batches whose sort may be in flight at once: one more than the grouping streams
+
+inline uint32_t nblocks(uint64_t n) { return (uint32_t)((n + BLOCK - 1) / BLOCK); }
+inline int bit_width_u64(uint64_t v) {
+    int b = 0;
+    while (v) {
+        ++b;
+        v >>= 1;
+    }
+    return b;
+}
+
+} // namespace tcg
+using namespace tcg;
+
+// ---------------------------------------------------------------------------
+// engine
+// ---------------------------------------------------------------------------
+struct tc_engine {
+    int device = 0;
+    // The stream evaluations are ordered on: the caller's (tc_engine_set_stream) or a private
+    // one that is only created when first needed -- HIP multiplexes streams onto few hardware
+    // queues (4 by default), and a main stream that shares a queue with an auxiliary stream
+    // serialises the pipeline (measured: 12 -> 5.7 G decisions/s), so no stream is created idly.
+    hipStream_t own_stream = nullptr;
+    hipStream_t user_stream = nullptr;
+    uint64_t capacity = 0, max_batch = 0;
+    uint32_t cfg_flags = 0;
+
+    Cell* cells = nullptr;
+    int64_t* tat8 = nullptr;                 // TC_CFG_FIXED_PARAMS: one TAT per key instead of cells (gcra_math.hpp)
+    bool fixed = false;
+    bool sealed = false;                     // fixed layout: a request has been decided, the plans can no longer change
+    uint16_t* rate_id = nullptr;
+    RateClass* classes = nullptr;            // device, MAX_CLASSES entries, [0] = all zero
+    std::vector<RateClass> host_classes;     // host mirror, index = class id
+    std::unordered_map<std::string, uint16_t> class_of; // (burst,count,period) bytes -> id
+    uint16_t uniform_id = 0;                 // != 0: every slot carries this plan
+    uint32_t* denied = nullptr;              // TC_CFG_TRACK_DENIED: denials per slot
+    uint32_t* topk_ws = nullptr;             // tc_top_denied scratch: 256 histogram words | 2 counters | lists
+    unsigned long long* counters = nullptr; // TC_CNT_COUNT canonical + 1 scratch + NSHARD*SHARD_WORDS shards
+
+    // grouping scratch: a ring of `depth` sets.  A batch flagged TC_B_INPUTS_READY is
+    // sorted on its set's auxiliary stream while earlier batches are still being evaluated
+    // on `stream` (the sort never touches the resident state); evaluation stays in order.
+    struct SortSet {
+        uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
+        uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
+        uint32_t* k_slot = nullptr;                    // key mode: slots resolved for the batch using this set
+        uint32_t* h_slot = nullptr;                    // TC_B_ASYNC: the host batch's slot column, staged (lazy)
+        int64_t* h_in[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // ... and its request columns (lazy)
+        uint8_t* h_key_bytes = nullptr;                // TC_B_ASYNC key batch: its key arena and offsets, staged (lazy)
+        size_t h_key_cap = 0;
+        uint32_t* h_key_off = nullptr;
+        uint32_t hist_parity = 0;
+        void* bp_scratch = nullptr;    // bucket path: tile histograms, offsets, partitioned elements, gate
+        bp::Work bpw;
+        hipEvent_t sorted = nullptr;   // recorded on the auxiliary stream after the last pass
+        hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
+        bool in_use = false;
+        bool grouped_aside = false;    // the set's last batch was grouped on an auxiliary stream (`sorted` says when)
+        // the caller-owned slot columns this set's batches read (the latest few: a set is reused every `depth` batches).
+        // tc_route_batch (TC_ROUTE_AHEAD) orders itself behind the readers of the buffer it overwrites: waiting for the
+        // set's CURRENT grouping covers every earlier batch of the set too (a set's next grouping waits for the
+        // evaluation of its previous batch, which waited for that batch's grouping)
+        struct Reader {
+            const uint32_t* ptr = nullptr;
+            size_t n = 0;
+        } readers[4];
+        uint32_t next_reader = 0;
+    } sets[PIPE_DEPTH_MAX];
+    uint32_t depth = 0; // sets actually allocated
+    hipStream_t aux[AUX_MAX] = {};       // set k groups on aux[k % n_aux]
+    uint32_t n_aux = 0;
+    uint32_t next_aux = 0;
+    uint32_t n_aux_want = 0;             // configured number of grouping streams
+    int sort_items_piped = SORT_ITEMS_PIPED; // requests per thread of a sort tile, pipelined batches (TCGPU_SORT_ITEMS_PIPED = 8 | 16 | 32)
+    hipStream_t side_for = nullptr;      // main stream the side streams were probed against
+    bool side_ready = false;
+    int aux_priority = 0;
+    uint32_t* probe_ws = nullptr;        // {flag, saw}
+    uint32_t next_set = 0;
+    uint32_t sort_max_tiles = 0;
+    PendEntry* pend = nullptr;
+    ChainRec* chain = nullptr; // k_eval_general: per-wave hand-over records
+    uint32_t chain_seq = 0;
+    uint32_t* loaded = nullptr; // k_eval_sorted<DIRECT>: per-wave "cells read" flags
+    int eval_items = 0;         // sorted positions per lane in k_eval_sorted (0: chosen per batch)
+    bool eval_lean = true;      // k_eval_sorted_lean for decisions-only batches (TCGPU_EVAL_LEAN=0: the general kernel)
+    bool stop_events = true;    // events ride on kernels' completion signals instead of marker packets (TCGPU_STOP_EVENTS=0: hipEventRecord)
+    bool prefill_on = true;     // TC_B_OUTPUTS_IDLE batches: decision bytes preset on the grouping stream (TCGPU_PREFILL=0: off)
+    uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting
+    uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
+    bool debug_nostore = false; // TCGPU_DEBUG_NO_DECISION_STORE=1: MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)
+    uint32_t loaded_seq = 0;
+    // bounds over the registered rate plans (for all_runs_regular)
+    int64_t cls_min_ei = INT64_MAX, cls_max_ei = 0, cls_min_dvt = INT64_MAX, cls_max_dvt = 0;
+    uint32_t* pend_count = nullptr;
+    uint8_t* allowed_tmp = nullptr;
+    StoreOpResult* op_result = nullptr;
+    OneResult* one_result = nullptr; // tc_rate_limit: the single request's result
+
+    // staging for host-pointer batches (lazy)
+    struct Stage {
+        uint32_t* slot = nullptr;
+        int64_t* in[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        uint8_t* allowed = nullptr;
+        uint64_t* bits = nullptr;
+        int64_t* out[4] = {nullptr, nullptr, nullptr, nullptr};
+        int64_t* result4 = nullptr;
+        tc_decision* decisions = nullptr;
+        uint32_t* order = nullptr;
+        uint8_t* status = nullptr;
+    } stage;
+
+    // small host-pointer batches (k_small_batch): one pinned block the kernel reads its inputs from and writes
+    // its results to (the caller's arrays are copied in and out by the host)
+    uint8_t* small_io = nullptr;  // host address
+    uint8_t* small_io_dev = nullptr; // the same block as the device addresses it
+    size_t small_io_bytes = 0;
+    bool small_off = false;       // TCGPU_NO_SMALL_BATCH=1: always take the big pipeline
+
+    // TC_B_ASYNC host batches still in flight, oldest first: one event per batch, recorded behind its last copy
+    std::deque<hipEvent_t> async_done;
+    std::vector<hipEvent_t> async_pool;
+
+    uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
+    uint32_t* poison_host = nullptr; // pinned: raised by tc::invariant_failed; every ABI call checks it (TC_E_INVARIANT)
+    bool debug_break_wait = false;   // tc_debug_break_wait
+    uint32_t fault_countdown = 0; // tc_debug_fail_copy: the n-th staging copy from now fails (error-path tests)
+    uint32_t* route_ws = nullptr; // tc_route_batch scratch (lazy): per stream it may run on: tile counts per destination
+    size_t route_ws_words = 0;    // words of one of them
+    uint32_t next_route = 0;
+    uint32_t route_seq = 0;       // sequence number of the one-pass router's look-back words
+
+    // bucket path (bucket_path.hpp): uniform batches are partitioned by key range and ranked per bucket instead of
+    // sorted.  Such a batch is enqueued on BOTH paths; the partition's largest bucket (a word in device memory,
+    // the gate) decides on the device which of the two runs, so a skewed batch never waits for the host.
+    bool bp_ok = false;      // the key space fits the path (<= bp::MAX_BUCKETS buckets)
+    int bp_lb = 0;           // log2(slots per bucket)
+    uint32_t bp_nbk = 0;
+    uint32_t bp_max_n = 0;   // largest batch the scratch is sized for (<= bp::MAX_N)
+    uint32_t bp_min_n = 0;   // smaller batches are sorted (TCGPU_BUCKET_MIN_N)
+    uint32_t bp_skew = 1024; // longest bucket the path takes on (TCGPU_BUCKET_SKEW)
+    bool bp_piped = false;   // also for TC_B_INPUTS_READY batches (TCGPU_BUCKET_PIPED=1; measured slower)
+    uint32_t* bp_gate_host = nullptr; // pinned: the gate of a recent batch, mirrored by the device (a hint, never waited for)
+    uint32_t bp_backoff = 0;  // batches left during which the bucket path is not even tried (the stream looked skewed)
+    uint32_t bp_backoff_len = BP_BACKOFF; // (TCGPU_BUCKET_BACKOFF; 0: always try)
+    PendEntry* bp_park = nullptr; // parked cell stores of long buckets, one entry per request
+
+    // string-key mode (TC_CFG_KEY_MODE): device hash table + per-batch resolution scratch
+    bool key_mode = false;
+    kt::Table kt;
+    void* kt_block = nullptr;        // one allocation backing every kt.* array
+    kt::RetiredRec* retired = nullptr; // key mode + TC_CFG_TRACK_DENIED: denial counts of keys without a slot
+    uint32_t *k_slot = nullptr, *k_state = nullptr, *k_aux = nullptr; // max_batch each
+    uint32_t* k_claim = nullptr;     // keys first seen in the batch, per k_probe block
+    uint64_t* k_hash = nullptr;
+    // Key stages mutate the key table and share the scratch above, so they run one after another in
+    // call order: on the key stream for TC_B_INPUTS_READY device batches (overlapping the grouping and
+    // evaluation of earlier batches), else on the main stream; the two events hand the order across.
+    hipStream_t key_stream = nullptr;
+    hipEvent_t k_done = nullptr, m_done = nullptr;
+    bool k_busy = false, m_busy = false;
+    hipEvent_t wait_before_sort = nullptr; // piped key batch: the auxiliary sort waits for its key stage
+    uint8_t* k_stage_bytes = nullptr; // host-pointer batches: staged key arena
+    size_t k_stage_bytes_cap = 0;
+    uint32_t* k_stage_off = nullptr;  // max_batch + 1
+
+    // optional per-stage HIP-event timing (tc_profile_*): a (begin, end) event pair per
+    // kernel, recorded on the stream the kernel is launched on
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev; // 2 per record
+    std::vector<int> prof_stage;
+    size_t prof_used = 0;            // records
+    double prof_ms[TC_STAGE_COUNT] = {0};
+    uint64_t prof_calls[TC_STAGE_COUNT] = {0};
+
+    std::string err;
+};
+#define TC_HIP(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _rc = (call);                                                                     \
+        if (_rc != hipSuccess) {                                                                     \
+            (e)->err = std::string(#call) + ": " + hipGetErrorString(_rc);                           \
+            return TC_E_HIP;                                                                         \
+        }                                                                                            \
+    } while (0)
+
+// A kernel launch whose completion is `stop` (hipExtLaunchKernelGGL: the event rides on the dispatch packet's own
+// completion signal -- no marker packet behind the kernel, which the next kernel of the stream would wait for), or a
+// plain launch when stop == nullptr.
+#define TC_LAUNCH(stop, kernel, grid, block, lds, stream, ...)                                               \
+    do {                                                                                                     \
+        if (stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop, 0, __VA_ARGS__);    \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                              \
+    } while (0)
+
+#define TC_TRY_EARLY(call)                \
+    do {                                  \
+        int _trc = (call);                \
+        if (_trc != TC_E_OK) return _trc; \
+    } while (0)
+
+#define TC_CHECK_POISON(e)              \
+    do {                                \
+        int _prc = poisoned(e);         \
+        if (_prc != TC_E_OK) return _prc; \
+    } while (0)
+
+#define TC_TRY(call)                  \
+    do {                              \
+        int _trc = (call);            \
+        if (_trc != TC_E_OK) return _trc; \
+    } while (0)
+
+// input arrays of a TC_B_ASYNC host batch, staged inside run_slots_device on the stream that groups the batch
+struct HostIn {
+    const uint32_t* slot = nullptr;
+    const int64_t* col[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // burst, count, period, quantity, now
+};
+
+// ---- helpers shared by the units (defined in the unit named) ----------------------------------------------------
+// engine.hip
+hipStream_t cur_stream(tc_engine* e);
+void prof_begin(tc_engine* e, int stage, hipStream_t s);
+void prof_end(tc_engine* e, hipStream_t s);
+hipError_t copy_async(tc_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st);
+int fail(tc_engine* e, int code, const char* msg);
+int publish_poison_ptr(tc_engine* e);
+int poisoned(tc_engine* e);
+int ensure_side_streams(tc_engine* e);
+int upload_classes(tc_engine* e);
+int intern_class(tc_engine* e, int64_t burst, int64_t count, int64_t period, bool* grew);
+// slots.hip
+int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d);
+int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_kernel = false);
+int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin = nullptr);
+int run_slots_host_staged(tc_engine* e, const tc_batch& b);
+int finish_async(tc_engine* e, const tc_batch& b);
+bool small_batch_applies(const tc_engine* e, const tc_batch& b);
+int run_small_batch(tc_engine* e, const tc_batch& b);
+// device staging for host-pointer batches, allocated per array on first use
+template <class T>
+inline int stage_need(tc_engine* e, T*& p, size_t count) {
+    if (!p) TC_HIP(e, hipMalloc(&p, count * sizeof(T)));
+    return TC_E_OK;
+}
+// keys.hip
+int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert, uint32_t* out_slot, bool on_key_stream);
+int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n, const uint8_t** d_bytes, const uint32_t** d_off);
+int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint32_t* slot);
+int rebuild_key_table_if_due(tc_engine* e);

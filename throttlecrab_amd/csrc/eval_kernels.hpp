@@ -4,7 +4,7 @@
 //   k_eval_sorted   batches with one `now` / `quantity`: closed form per key run
 //   k_eval_general  per-request now / quantity / rate: wave-cooperative, cross-wave hand-over chain
 //   k_commit_list, k_fold_counters, k_pack_bits
-// Included once, by tcgpu.hip (the engine and the C ABI).
+// Kernels have internal linkage: every translation unit (engine.hpp) compiles the ones it launches.(the engine and the C ABI).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -297,7 +297,7 @@ struct OneResult {
     uint32_t table_full;
     uint32_t pad;
 };
-__global__ void k_rate_limit_one(Params p, kt::Table t, int key_mode, InlineKey ik, const uint8_t* __restrict__ long_key,
+static __global__ void k_rate_limit_one(Params p, kt::Table t, int key_mode, InlineKey ik, const uint8_t* __restrict__ long_key,
                                  uint32_t slot_in, OneResult* __restrict__ out, unsigned long long* inserted) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     uint32_t slot = slot_in;
@@ -342,7 +342,7 @@ __global__ void k_rate_limit_one(Params p, kt::Table t, int key_mode, InlineKey 
 // its queue holds a handful of requests (actor.rs:217-236 answers them one by one).
 // ---------------------------------------------------------------------------
 constexpr int SMALL_MAX = 1024;
-__global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t, int key_mode, const uint8_t* __restrict__ key_bytes,
+static __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t, int key_mode, const uint8_t* __restrict__ key_bytes,
                                                            const uint32_t* __restrict__ key_off, uint32_t* __restrict__ table_full,
                                                            unsigned long long* inserted) {
     __shared__ uint64_t s_key[SMALL_MAX]; // slot << 32 | request index; padding = ~0
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     block_count3(na, nd, ne, p.counters);
 }
 
-__global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restrict__ pend,
+static __global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restrict__ pend,
                                                        uint32_t* __restrict__ pend_count, Cell* __restrict__ cells,
                                                        int64_t* __restrict__ tat8) {
     // pend_count[0] = entries, pend_count[1] = blocks of this launch that are done
@@ -1026,7 +1026,7 @@ __global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restri
     }
 }
 
-__global__ __launch_bounds__(NSHARD) void k_fold_counters(unsigned long long* counters) {
+static __global__ __launch_bounds__(NSHARD) void k_fold_counters(unsigned long long* counters) {
     __shared__ unsigned long long s[3][NSHARD / 64];
     const unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + threadIdx.x * SHARD_WORDS;
     unsigned long long v[3] = {shard[0], shard[1], shard[2]};
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(NSHARD) void k_fold_counters(unsigned long long* co
 }
 
 // allowed[] bytes -> bitmask (wavefront ballot, one u64 per wave)
-__global__ __launch_bounds__(BLOCK) void k_pack_bits(const uint8_t* __restrict__ allowed, uint32_t n,
+static __global__ __launch_bounds__(BLOCK) void k_pack_bits(const uint8_t* __restrict__ allowed, uint32_t n,
                                                      uint64_t* __restrict__ bits) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     const bool a = i < n && allowed[i];

@@ -604,7 +604,7 @@ __device__ __forceinline__ void release_claim(const Table& t, const uint32_t* __
 
 // claim_cnt[b] (claimants of k_probe's block b) -> claimants in the blocks before b; claim_cnt[n_blocks] = all of them.
 // One block: a batch has at most a few thousand probe blocks.
-__global__ __launch_bounds__(1024) void k_claim_scan(uint32_t* __restrict__ claim_cnt, uint32_t n_blocks) {
+static __global__ __launch_bounds__(1024) void k_claim_scan(uint32_t* __restrict__ claim_cnt, uint32_t n_blocks) {
     __shared__ uint32_t s_w[16];
     __shared__ uint32_t s_carry;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -634,7 +634,7 @@ __global__ __launch_bounds__(1024) void k_claim_scan(uint32_t* __restrict__ clai
 // order: k_probe left the number of claimants per block in claim_cnt[], k_claim_scan made them offsets) takes free_slots[top - 1 - R]; the
 // stack pointer itself moves once, in k_follow.  No atomics: one on a single address costs ~12 ns and
 // serialises (a per-wave pop was 197 us of a 225 us kernel, a per-1024-block pop still 12 us).
-__global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
+static __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
                                                   const uint32_t* __restrict__ key_off, uint32_t n,
                                                   uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ state,
                                                   const uint32_t* __restrict__ aux, const uint64_t* __restrict__ hash_in,
@@ -656,7 +656,7 @@ __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __rest
 
 // duplicates of a key first seen in this batch take the claimant's slot; block 0 also moves the free
 // stack's pointer past the slots k_bind handed out and counts the insertions
-__global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __restrict__ slot_out,
+static __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __restrict__ slot_out,
                                                     const uint32_t* __restrict__ state, const uint32_t* __restrict__ aux, Table t,
                                                     const uint32_t* __restrict__ claim_cnt, uint32_t n_blocks,
                                                     unsigned long long* inserted_counter) {
@@ -673,7 +673,7 @@ __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __rest
     }
 }
 
-__global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint8_t* bound, uint32_t capacity) {
+static __global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint8_t* bound, uint32_t capacity) {
     for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < capacity; i += gridDim.x * THREADS) {
         free_slots[i] = capacity - 1u - i; // slot 0 is handed out first
         bound[i] = 0;
@@ -764,7 +764,7 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
 // handed out, every bound long key is copied into the other half (fresh bump pointer) and the halves swap.
 // Decided and done ON THE DEVICE (the asynchronous sweep never waits for the host); three near-empty
 // launches when nothing is due.  flag[0] = compact now, flag[1] = bytes handed out in the new half.
-__global__ void k_overflow_decide(Table t, unsigned long long* __restrict__ flag) {
+static __global__ void k_overflow_decide(Table t, unsigned long long* __restrict__ flag) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         flag[0] = *t.overflow_used > t.overflow_bytes / 2 ? 1ull : 0ull;
         flag[1] = 0ull;
@@ -773,7 +773,7 @@ __global__ void k_overflow_decide(Table t, unsigned long long* __restrict__ flag
 // (one reservation per block and 2048 slots: a returning atomicAdd per copied key on the new half's cursor -- one
 // word -- serialised the kernel: 1.7 ms for the ~3 M long keys of the configs[4] stream)
 constexpr int COMPACT_ITEMS = 8;
-__global__ __launch_bounds__(THREADS) void k_overflow_compact(Table t, unsigned long long* __restrict__ flag) {
+static __global__ __launch_bounds__(THREADS) void k_overflow_compact(Table t, unsigned long long* __restrict__ flag) {
     if (flag[0] == 0ull) return;
     __shared__ uint32_t s_w[THREADS / 64];
     __shared__ unsigned long long s_base;
@@ -833,7 +833,7 @@ __global__ __launch_bounds__(THREADS) void k_overflow_compact(Table t, unsigned 
         }
     }
 }
-__global__ void k_overflow_swap(Table t, const unsigned long long* __restrict__ flag) {
+static __global__ void k_overflow_swap(Table t, const unsigned long long* __restrict__ flag) {
     if (blockIdx.x == 0 && threadIdx.x == 0 && flag[0] != 0ull) {
         *t.overflow_used = flag[1];
         *t.overflow_half ^= 1u;
@@ -844,7 +844,7 @@ __global__ void k_overflow_swap(Table t, const unsigned long long* __restrict__ 
 // a sweep never waits for the host -- k_rebuild_decide latches "tombstones > 1/4 of the table" into
 // a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (three near-empty
 // launches, ~10 us, when no rebuild is due).
-__global__ void k_rebuild_decide(Table t, uint32_t* __restrict__ flag) {
+static __global__ void k_rebuild_decide(Table t, uint32_t* __restrict__ flag) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint32_t tombs = 0; // (the shards wrap around individually; their sum is the count)
         for (uint32_t s = 0; s < TOMB_SHARDS; ++s) tombs += t.tombs[s];
@@ -852,7 +852,7 @@ __global__ void k_rebuild_decide(Table t, uint32_t* __restrict__ flag) {
     }
 }
 
-__global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32_t* __restrict__ flag) {
+static __global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32_t* __restrict__ flag) {
     if (*flag == 0u) return;
     // 32-byte entries as two 16-byte stores per thread
     ulonglong2* raw = reinterpret_cast<ulonglong2*>(t.ktab);
@@ -862,7 +862,7 @@ __global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32
 }
 
 // re-enter every bound slot into the cleared table
-__global__ __launch_bounds__(THREADS) void k_reinsert(Table t, const uint32_t* __restrict__ flag) {
+static __global__ __launch_bounds__(THREADS) void k_reinsert(Table t, const uint32_t* __restrict__ flag) {
     if (*flag == 0u) return;
     if (blockIdx.x == 0 && threadIdx.x < TOMB_SHARDS) t.tombs[threadIdx.x] = 0u;
     for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {

@@ -1,0 +1,423 @@
+// keys.hip -- string keys: key stages on the key stream, tc_rate_limit_batch_keys, tc_rate_limit, the `trait Store` shims, key introspection
+#include "engine.hpp"
+
+// keys (device arena) -> out_slot[0..n): found slot, freshly bound slot, or NO_SLOT.
+// on_key_stream: issue on the key stream (the caller vouched for the inputs), else on the main stream.
+int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert,
+                               uint32_t* out_slot, bool on_key_stream) {
+    hipStream_t s = on_key_stream ? e->key_stream : cur_stream(e);
+    if (on_key_stream) {
+        if (e->m_busy) TC_HIP(e, hipStreamWaitEvent(s, e->m_done, 0));
+    } else {
+        if (e->k_busy) TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+    }
+    const dim3 grid(nblocks(n)), block(kt::THREADS);
+    prof_begin(e, TC_STAGE_HASH, s);
+    if (insert) {
+        hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux,
+                           e->k_hash, e->k_claim);
+        hipLaunchKernelGGL(kt::k_claim_scan, dim3(1), dim3(1024), 0, s, e->k_claim, grid.x);
+        hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_hash,
+                           e->k_claim);
+        hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, out_slot, e->k_state, e->k_aux, e->kt, e->k_claim, grid.x,
+                           e->counters + TC_CNT_KEYS_INSERTED);
+    } else {
+        hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state,
+                           e->k_aux, e->k_hash, (uint32_t*)nullptr);
+    }
+    prof_end(e, s);
+    TC_HIP(e, hipGetLastError());
+    if (on_key_stream) {
+        TC_HIP(e, hipEventRecord(e->k_done, s));
+        e->k_busy = true;
+        e->m_busy = false;
+    } else {
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
+        e->k_busy = false;
+    }
+    return TC_E_OK;
+}
+
+// host key arena -> staged on device
+int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n,
+                      const uint8_t** d_bytes, const uint32_t** d_off) {
+    const size_t total = key_off[n];
+    if (total > e->k_stage_bytes_cap) {
+        if (e->k_stage_bytes) (void)hipFree(e->k_stage_bytes);
+        e->k_stage_bytes = nullptr;
+        const size_t want = std::max<size_t>(total * 2, 1 << 16);
+        TC_HIP(e, hipMalloc(&e->k_stage_bytes, want));
+        e->k_stage_bytes_cap = want;
+    }
+    if (total) TC_HIP(e, copy_async(e, e->k_stage_bytes, key_bytes, total, hipMemcpyHostToDevice, cur_stream(e)));
+    TC_HIP(e, copy_async(e, e->k_stage_off, key_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+    *d_bytes = e->k_stage_bytes ? e->k_stage_bytes : (const uint8_t*)e->k_stage_off;
+    *d_off = e->k_stage_off;
+    return TC_E_OK;
+}
+
+// one key (host bytes) -> slot on the host; insert binds a fresh slot if unseen
+int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint32_t* slot) {
+    if (key_len > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "key too long");
+    const uint32_t off[2] = {0u, (uint32_t)key_len};
+    const uint8_t* d_bytes;
+    const uint32_t* d_off;
+    int rc = stage_keys(e, key, off, 1, &d_bytes, &d_off);
+    if (rc != TC_E_OK) return rc;
+    rc = resolve_keys_device(e, d_bytes, d_off, 1, insert, e->k_slot, false);
+    if (rc != TC_E_OK) return rc;
+    TC_HIP(e, hipMemcpyAsync(slot, e->k_slot, sizeof(uint32_t), hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    return TC_E_OK;
+}
+
+// rebuild the key table if tombstones fill more than 1/4 of it (checked on the device)
+int rebuild_key_table_if_due(tc_engine* e) {
+    kt::Table& t = e->kt;
+    hipStream_t s = cur_stream(e);
+    uint32_t* flag = t.error_flag + 1; // spare word of the table's misc block
+    const dim3 grid(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block(kt::THREADS);
+    hipLaunchKernelGGL(kt::k_rebuild_decide, dim3(1), dim3(64), 0, s, t, flag);
+    hipLaunchKernelGGL(kt::k_rebuild_clear, grid, block, 0, s, t, flag);
+    hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, flag);
+    // ... and compact the overflow arena (keys longer than 48 bytes) once more than half of it is handed out
+    unsigned long long* oflag = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 32);
+    hipLaunchKernelGGL(kt::k_overflow_decide, dim3(1), dim3(64), 0, s, t, oflag);
+    hipLaunchKernelGGL(kt::k_overflow_compact, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, oflag);
+    hipLaunchKernelGGL(kt::k_overflow_swap, dim3(1), dim3(64), 0, s, t, oflag);
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
+// did any key of the batches since the last check fail to get a slot?
+static int check_key_errors(tc_engine* e) {
+    uint32_t flag = 0;
+    TC_HIP(e, hipMemcpyAsync(&flag, e->kt.error_flag, sizeof flag, hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    if (flag) {
+        TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, cur_stream(e)));
+        return fail(e, TC_E_TABLE_FULL, "key table full: some keys got status Internal (raise capacity or sweep)");
+    }
+    return TC_E_OK;
+}
+
+// TC_B_ASYNC key batch: key arena and offsets are staged on the key stream (SDMA), resolved there, grouped on
+// an auxiliary stream, evaluated in order, results copied back behind the evaluation; nothing waits.  A full
+// key table shows as status Internal on the affected requests; the TC_E_TABLE_FULL return code is delivered
+// by the next synchronous key call.  (Staging on the auxiliary stream that will group the batch, to overlap
+// the transfer with the previous batch's key stage, measured slower: 1.5 vs 2.0 G decisions/s.)
+static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
+    const uint32_t n = (uint32_t)b.n;
+    TC_TRY(ensure_side_streams(e));
+    const bool piped = e->key_stream != nullptr && e->n_aux != 0;
+    tc_engine::SortSet& ss = e->sets[e->next_set];
+    hipStream_t ks = piped ? e->key_stream : cur_stream(e);
+    const size_t total = b.key_off[n];
+    if (total > ss.h_key_cap) { // grow (hipFree waits for everything that may still read the old buffer)
+        if (ss.h_key_bytes) (void)hipFree(ss.h_key_bytes);
+        ss.h_key_bytes = nullptr;
+        ss.h_key_cap = 0;
+        const size_t want = std::max<size_t>(total * 2, 1 << 16);
+        TC_HIP(e, hipMalloc(&ss.h_key_bytes, want));
+        ss.h_key_cap = want;
+    }
+    if (!ss.h_key_off) TC_HIP(e, hipMalloc(&ss.h_key_off, (e->max_batch + 1) * sizeof(uint32_t)));
+    // the key stage and the evaluation that last used this set's staging and slot column are done
+    if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ks, ss.consumed, 0));
+    if (total) TC_HIP(e, copy_async(e, ss.h_key_bytes, b.key_bytes, total, hipMemcpyHostToDevice, ks));
+    TC_HIP(e, copy_async(e, ss.h_key_off, b.key_off, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ks));
+    TC_TRY(resolve_keys_device(e, ss.h_key_bytes, ss.h_key_off, n, true, ss.k_slot, piped));
+    tc_batch d = b;
+    d.flags = (b.flags & ~(TC_B_ASYNC | TC_B_INPUTS_READY)) | TC_B_DEVICE_PTRS | (piped ? TC_B_INPUTS_READY : 0u);
+    d.slot = ss.k_slot;
+    d.key_bytes = nullptr;
+    d.key_off = nullptr;
+    d.max_burst = d.count_per_period = d.period = d.quantity = d.now_ns = nullptr;
+    HostIn hin;
+    hin.col[0] = b.max_burst, hin.col[1] = b.count_per_period, hin.col[2] = b.period, hin.col[3] = b.quantity, hin.col[4] = b.now_ns;
+    if (piped) e->wait_before_sort = e->k_done;
+    TC_TRY(stage_outputs(e, b, d));
+    TC_TRY(run_slots_device(e, d, &hin));
+    return finish_async(e, b);
+}
+
+extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
+    if (!e || !bp || bp->struct_size < offsetof(tc_batch, n_segments)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    tc_batch b;
+    memset(&b, 0, sizeof b);
+    memcpy(&b, bp, std::min<size_t>(bp->struct_size, sizeof b));
+    if (b.n_segments) return fail(e, TC_E_INVALID_ARG, "segments belong to slot batches");
+    if (b.n == 0) return TC_E_OK;
+    if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
+    if (!b.key_bytes || !b.key_off) return fail(e, TC_E_INVALID_ARG, "key_bytes/key_off is NULL");
+    if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
+    if (b.flags & (TC_B_REGISTERED_PARAMS | TC_B_UNIQUE_SLOTS))
+        return fail(e, TC_E_INVALID_ARG, "registered params / unique-slot promise do not apply to string keys");
+    TC_HIP(e, hipSetDevice(e->device));
+    if (b.flags & TC_B_ASYNC) {
+        if (b.flags & TC_B_DEVICE_PTRS) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
+        return run_keys_host_async(e, b);
+    }
+    const uint8_t* d_bytes = b.key_bytes;
+    const uint32_t* d_off = b.key_off;
+    const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
+    if (!dev && small_batch_applies(e, b)) return run_small_batch(e, b);
+    if (!dev) {
+        int rc = stage_keys(e, b.key_bytes, b.key_off, b.n, &d_bytes, &d_off);
+        if (rc != TC_E_OK) return rc;
+    }
+    tc_batch s = b;
+    s.key_bytes = nullptr;
+    s.key_off = nullptr;
+    if (dev) {
+        // the slots go into the scratch set the grouping stage is about to use
+        tc_engine::SortSet& ss = e->sets[e->next_set];
+        bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        if (piped) {
+            int rc = ensure_side_streams(e);
+            if (rc != TC_E_OK) return rc;
+            piped = e->key_stream != nullptr && e->n_aux != 0;
+        }
+        if (piped && ss.in_use) TC_HIP(e, hipStreamWaitEvent(e->key_stream, ss.consumed, 0)); // ss.k_slot is free again
+        int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, ss.k_slot, piped);
+        if (rc != TC_E_OK) return rc;
+        if (piped) e->wait_before_sort = e->k_done;
+        else s.flags &= ~TC_B_INPUTS_READY; // the slots were resolved on the main stream: group there too
+        s.slot = ss.k_slot;
+        return run_slots_device(e, s);
+    }
+    int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, e->k_slot, false);
+    if (rc != TC_E_OK) return rc;
+    // host pointers for everything else: reuse the slot path's staging, with the
+    // slot column already on the device
+    TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
+    TC_HIP(e, hipMemcpyAsync(e->stage.slot, e->k_slot, b.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, cur_stream(e)));
+    rc = run_slots_host_staged(e, b);
+    if (rc != TC_E_OK) return rc;
+    return check_key_errors(e);
+}
+
+extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, int64_t max_burst,
+                             int64_t count_per_period, int64_t period, int64_t quantity, int64_t now_ns,
+                             tc_result* out) {
+    if (!e || !out || (!key && key_len)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (key_len > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "key too long");
+    if (e->fixed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: single calls carry their own rate; use a registered batch");
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
+    uint32_t slot = 0;
+    InlineKey ik;
+    memset(&ik, 0, sizeof ik);
+    const uint8_t* d_long = nullptr;
+    if (e->key_mode) {
+        ik.len = (uint32_t)key_len;
+        ik.is_inline = key_len <= sizeof ik.bytes;
+        if (ik.is_inline) {
+            if (key_len) memcpy(ik.bytes, key, key_len);
+        } else { // long key: through the staging arena
+            const uint32_t off[2] = {0u, (uint32_t)key_len};
+            const uint32_t* d_off;
+            int rc = stage_keys(e, key, off, 1, &d_long, &d_off);
+            if (rc != TC_E_OK) return rc;
+        }
+        if (e->k_busy) { // key stages on the key stream come first
+            TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+            e->k_busy = false;
+        }
+    } else {
+        // slot-mode engines: the key is the 4-byte little-endian slot id
+        if (key_len != 4) return fail(e, TC_E_INVALID_ARG, "slot-mode engine: key must be a 4-byte slot id");
+        memcpy(&slot, key, 4);
+    }
+    Params p;
+    memset(&p, 0, sizeof p);
+    p.n = 1;
+    p.burst_s = max_burst;
+    p.count_s = count_per_period;
+    p.period_s = period;
+    p.q_s = quantity;
+    p.now_s = now_ns;
+    p.cells = e->cells;
+    p.rate_id = e->rate_id;
+    p.classes = e->classes;
+    p.capacity = e->capacity;
+    p.counters = e->counters;
+    p.denied = e->denied;
+    prof_begin(e, TC_STAGE_EVAL, s);
+    hipLaunchKernelGGL(k_rate_limit_one, dim3(1), dim3(64), 0, s, p, e->kt, e->key_mode ? 1 : 0, ik, d_long, slot, e->one_result,
+                       e->counters + TC_CNT_KEYS_INSERTED);
+    prof_end(e, s);
+    TC_HIP(e, hipGetLastError());
+    if (e->key_mode) { // the key table may have changed: later key stages on the key stream wait for this
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
+    }
+    OneResult r;
+    TC_HIP(e, hipMemcpyAsync(&r, e->one_result, sizeof r, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    e->batches++;
+    if (r.table_full) {
+        uint32_t zero = 0;
+        TC_HIP(e, hipMemcpyAsync(e->kt.error_flag, &zero, sizeof zero, hipMemcpyHostToDevice, s));
+        TC_HIP(e, hipStreamSynchronize(s));
+        return fail(e, TC_E_TABLE_FULL, "key table full: the key got status Internal (raise capacity or sweep)");
+    }
+    out->allowed = r.d.allowed;
+    out->status = r.d.status;
+    out->limit = r.limit;
+    out->remaining = r.d.remaining;
+    out->reset_after_ns = r.d.reset_after_ns;
+    out->retry_after_ns = r.d.retry_after_ns;
+    return TC_E_OK;
+}
+
+// *slot = NO_SLOT when a key-mode lookup (insert == false) does not find the key
+static int store_slot_of(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint64_t* slot) {
+    TC_HIP(e, hipSetDevice(e->device)); // (the key is resolved on the engine's device whatever the caller's current one is)
+    if (e->key_mode) {
+        if (!key && key_len) return TC_E_INVALID_ARG;
+        static const uint8_t empty = 0;
+        uint32_t s32 = kt::NO_SLOT;
+        int rc = resolve_one_key(e, key_len ? key : &empty, key_len, insert, &s32);
+        if (rc != TC_E_OK) return rc;
+        if (insert && s32 == kt::NO_SLOT) return check_key_errors(e) == TC_E_OK ? fail(e, TC_E_TABLE_FULL, "key table full") : TC_E_TABLE_FULL;
+        *slot = s32;
+        return TC_E_OK;
+    }
+    if (!key || key_len != 4) return fail(e, TC_E_INVALID_ARG, "slot-mode engine: key must be a 4-byte slot id");
+    uint32_t s;
+    memcpy(&s, key, 4);
+    if (s >= e->capacity) return fail(e, TC_E_INVALID_ARG, "slot out of range");
+    *slot = s;
+    return TC_E_OK;
+}
+
+static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
+                    StoreOpResult* r) {
+    if (e->fixed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: the 8-byte layout cannot hold a free ttl (Store operations need the 16-byte cell)");
+    if (now < 0) return fail(e, TC_E_INVALID_ARG, "now_ns < 0");
+    TC_HIP(e, hipSetDevice(e->device));
+    hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, cur_stream(e), e->cells, slot, op, a, b, ttl, now, e->op_result);
+    TC_HIP(e, hipGetLastError());
+    TC_HIP(e, hipMemcpyAsync(r, e->op_result, sizeof *r, hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    return TC_E_OK;
+}
+
+extern "C" int tc_store_get(tc_engine* e, const uint8_t* key, size_t key_len, int64_t now_ns, int64_t* value, int* found) {
+    if (!e || !value || !found) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    uint64_t slot;
+    int rc = store_slot_of(e, key, key_len, false, &slot);
+    if (rc != TC_E_OK) return rc;
+    if (slot == kt::NO_SLOT) { // key-mode: key never seen -> None
+        *value = 0;
+        *found = 0;
+        return TC_E_OK;
+    }
+    StoreOpResult r;
+    rc = store_op(e, slot, 0, 0, 0, 0, now_ns, &r);
+    if (rc != TC_E_OK) return rc;
+    *value = r.value;
+    *found = r.flag;
+    return TC_E_OK;
+}
+
+extern "C" int tc_store_compare_and_swap_with_ttl(tc_engine* e, const uint8_t* key, size_t key_len, int64_t old_value,
+                                                  int64_t new_value, uint64_t ttl_ns, int64_t now_ns, int* swapped) {
+    if (!e || !swapped) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    uint64_t slot;
+    int rc = store_slot_of(e, key, key_len, false, &slot);
+    if (rc != TC_E_OK) return rc;
+    if (slot == kt::NO_SLOT) { // adaptive_cleanup.rs:242: None => Ok(false)
+        *swapped = 0;
+        return TC_E_OK;
+    }
+    StoreOpResult r;
+    rc = store_op(e, slot, 1, old_value, new_value, ttl_ns, now_ns, &r);
+    if (rc != TC_E_OK) return rc;
+    *swapped = r.flag;
+    return TC_E_OK;
+}
+
+extern "C" int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* key, size_t key_len, int64_t value,
+                                                   uint64_t ttl_ns, int64_t now_ns, int* was_set) {
+    if (!e || !was_set) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    uint64_t slot;
+    int rc = store_slot_of(e, key, key_len, true, &slot);
+    if (rc != TC_E_OK) return rc;
+    StoreOpResult r;
+    rc = store_op(e, slot, 2, value, 0, ttl_ns, now_ns, &r);
+    if (rc != TC_E_OK) return rc;
+    *was_set = r.flag;
+    return TC_E_OK;
+}
+
+extern "C" int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, int64_t* slot) {
+    if (!e || !slot) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    TC_HIP(e, hipSetDevice(e->device));
+    uint64_t s = kt::NO_SLOT;
+    int rc = store_slot_of(e, key, key_len, false, &s);
+    if (rc != TC_E_OK) return rc;
+    *slot = s == kt::NO_SLOT ? -1 : (int64_t)s;
+    return TC_E_OK;
+}
+
+extern "C" int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,
+                            uint32_t* key_off) {
+    if (!e || (n && (!slots || !key_off)) || (key_bytes_cap && !key_bytes)) return TC_E_INVALID_ARG;
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    if (n == 0) return TC_E_OK;
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
+    if (e->k_busy) {
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        e->k_busy = false;
+    }
+    struct Tmp { // scratch, released on every exit
+        uint32_t* slots = nullptr;
+        kt::KeyRec* rec = nullptr;
+        ~Tmp() {
+            if (slots) (void)hipFree(slots);
+            if (rec) (void)hipFree(rec);
+        }
+    } d;
+    TC_HIP(e, hipMalloc(&d.slots, n * sizeof(uint32_t)));
+    TC_HIP(e, hipMalloc(&d.rec, n * sizeof(kt::KeyRec)));
+    TC_HIP(e, hipMemcpyAsync(d.slots, slots, n * sizeof(uint32_t), hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(k_gather_keyrecs, dim3(nblocks(n)), dim3(BLOCK), 0, s, e->kt, d.slots, n, d.rec);
+    std::vector<kt::KeyRec> h(n);
+    TC_HIP(e, hipMemcpyAsync(h.data(), d.rec, n * sizeof(kt::KeyRec), hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    size_t at = 0;
+    int rc = TC_E_OK;
+    key_off[0] = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t len = h[i].len == kt::NO_SLOT ? 0u : h[i].len; // unbound slot: empty key
+        if (at + len <= key_bytes_cap) {
+            if (len <= kt::INLINE_KEY) {
+                memcpy(key_bytes + at, h[i].bytes, len);
+            } else {
+                uint64_t off;
+                memcpy(&off, h[i].bytes, 8);
+                uint32_t half = 0;
+                TC_HIP(e, hipMemcpy(&half, e->kt.overflow_half, sizeof half, hipMemcpyDeviceToHost));
+                TC_HIP(e, hipMemcpy(key_bytes + at, e->kt.overflow + (size_t)half * e->kt.overflow_bytes + off, len, hipMemcpyDeviceToHost));
+            }
+            at += len;
+        } else {
+            rc = TC_E_INVALID_ARG; // buffer too small: offsets still describe what fits
+        }
+        key_off[i + 1] = (uint32_t)at;
+    }
+    if (rc != TC_E_OK) return fail(e, rc, "tc_slot_keys: key_bytes_cap too small");
+    return TC_E_OK;
+}

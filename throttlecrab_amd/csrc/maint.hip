@@ -1,0 +1,223 @@
+// maint.hip -- maintenance: AdaptiveStore::cleanup (tc_sweep_expired), top denied keys, raw state for differential tests
+#include "engine.hpp"
+
+extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
+    unsigned long long* scratch = e->counters + TC_CNT_COUNT;
+    if (e->k_busy) { // key stages still in flight on the key stream come first
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        e->k_busy = false;
+    }
+    TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s));
+    TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), s));
+    if (e->key_mode)
+        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
+                           e->cells, e->kt, now_ns, e->counters, scratch, e->denied);
+    else if (e->fixed)
+        hipLaunchKernelGGL(k_sweep_fixed, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s, e->tat8, e->rate_id,
+                           e->classes, (uint32_t)e->uniform_id, e->capacity, now_ns, e->counters, scratch);
+    else
+        hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
+                           e->cells, e->capacity, now_ns, e->counters, scratch);
+    TC_HIP(e, hipGetLastError());
+    if (e->key_mode) {
+        // tombstones lengthen probe chains: rebuild the table once they fill 1/4 of it
+        int rc = rebuild_key_table_if_due(e);
+        if (rc != TC_E_OK) return rc;
+        // the sweep (and a rebuild) changed the key table: later key stages on the key stream wait for it
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
+    }
+    if (!removed) return TC_E_OK; // asynchronous: the count goes to TC_CNT_SWEPT
+    unsigned long long r = 0;
+    TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    *removed = r;
+    return TC_E_OK;
+}
+
+extern "C" int tc_read_state(tc_engine* e, uint64_t first, uint64_t n, int64_t* tat, uint64_t* expiry) {
+    if (!e || n > e->capacity || first > e->capacity - n) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (n == 0) return TC_E_OK;
+    TC_HIP(e, hipSetDevice(e->device));
+    if (e->fixed) { // expiry == tat + dvt of the key's plan (gcra_math.hpp: fixed_cell)
+        std::vector<int64_t> t(n);
+        std::vector<uint16_t> id(n);
+        TC_HIP(e, hipMemcpyAsync(t.data(), e->tat8 + first, n * sizeof(int64_t), hipMemcpyDeviceToHost, cur_stream(e)));
+        TC_HIP(e, hipMemcpyAsync(id.data(), e->rate_id + first, n * sizeof(uint16_t), hipMemcpyDeviceToHost, cur_stream(e)));
+        TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+        for (uint64_t i = 0; i < n; ++i) {
+            const int64_t dvt = id[i] < e->host_classes.size() ? e->host_classes[id[i]].dvt : 0;
+            const Cell c = tc::fixed_cell(t[i], dvt);
+            if (tat) tat[i] = c.tat;
+            if (expiry) expiry[i] = c.expiry;
+        }
+        return TC_E_OK;
+    }
+    std::vector<Cell> h(n);
+    TC_HIP(e, hipMemcpyAsync(h.data(), e->cells + first, n * sizeof(Cell), hipMemcpyDeviceToHost, cur_stream(e)));
+    TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    for (uint64_t i = 0; i < n; ++i) {
+        if (tat) tat[i] = h[i].tat;
+        if (expiry) expiry[i] = h[i].expiry;
+    }
+    return TC_E_OK;
+}
+
+// ---- denied-key metrics ---------------------------------------------------------
+extern "C" int tc_top_denied(tc_engine* e, uint32_t k, uint32_t* slots, uint64_t* counts, uint32_t* n_out) {
+    if (!e || !slots || !counts || !n_out) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
+    *n_out = 0;
+    if (k == 0) return TC_E_OK;
+    if (k > TOPK_MAX) k = TOPK_MAX; // MAX_DENIED_KEYS_LIMIT
+    TC_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = cur_stream(e);
+    uint32_t* hist = e->topk_ws;
+    uint32_t* n2 = e->topk_ws + 256;
+    uint32_t* lists = e->topk_ws + 258;
+    const dim3 grid(std::min<uint64_t>(nblocks(e->capacity), 2048)), block(BLOCK);
+    // radix select: T = the k-th largest non-zero count (1 if fewer than k keys were ever denied)
+    uint32_t prefix = 0, mask = 0, want = k, T = 1;
+    bool all = false;
+    for (int shift = 24; shift >= 0 && !all; shift -= 8) {
+        uint32_t h[256];
+        TC_HIP(e, hipMemsetAsync(hist, 0, 256 * sizeof(uint32_t), s));
+        hipLaunchKernelGGL(k_denied_hist, grid, block, 0, s, e->denied, e->capacity, prefix, mask, (uint32_t)shift, hist);
+        TC_HIP(e, hipMemcpyAsync(h, hist, sizeof h, hipMemcpyDeviceToHost, s));
+        TC_HIP(e, hipStreamSynchronize(s));
+        if (shift == 24) {
+            uint64_t total = 0;
+            for (uint32_t v : h) total += v;
+            if (total <= k) { // everything that was ever denied fits
+                all = true;
+                break;
+            }
+        }
+        int d = 255;
+        for (; d > 0; --d) {
+            if (h[d] >= want) break;
+            want -= h[d];
+        }
+        prefix |= (uint32_t)d << shift;
+        mask |= 255u << shift;
+        T = prefix;
+    }
+    if (all) T = 1;
+    TC_HIP(e, hipMemsetAsync(n2, 0, 2 * sizeof(uint32_t), s));
+    hipLaunchKernelGGL(k_denied_collect, grid, block, 0, s, e->denied, e->capacity, T, n2, lists, TOPK_MAX);
+    TC_HIP(e, hipGetLastError());
+    uint32_t hn[2];
+    TC_HIP(e, hipMemcpyAsync(hn, n2, sizeof hn, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    const uint32_t n_gt = std::min(hn[0], TOPK_MAX), n_eq = std::min(hn[1], TOPK_MAX);
+    std::vector<uint32_t> gt(2 * (size_t)n_gt), eq(2 * (size_t)n_eq);
+    if (n_gt) TC_HIP(e, hipMemcpyAsync(gt.data(), lists, gt.size() * 4, hipMemcpyDeviceToHost, s));
+    if (n_eq) TC_HIP(e, hipMemcpyAsync(eq.data(), lists + 2 * (size_t)TOPK_MAX, eq.size() * 4, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    std::vector<std::pair<uint32_t, uint32_t>> ent; // (count, slot)
+    for (uint32_t i = 0; i < n_gt; ++i) ent.emplace_back(gt[2 * i + 1], gt[2 * i]);
+    std::vector<std::pair<uint32_t, uint32_t>> ties;
+    for (uint32_t i = 0; i < n_eq; ++i) ties.emplace_back(eq[2 * i + 1], eq[2 * i]);
+    std::sort(ties.begin(), ties.end(), [](auto& a, auto& b) { return a.second < b.second; }); // deterministic choice among ties
+    for (auto& t2 : ties) {
+        if (ent.size() >= k) break;
+        ent.push_back(t2);
+    }
+    std::sort(ent.begin(), ent.end(), [](auto& a, auto& b) { return a.first != b.first ? a.first > b.first : a.second < b.second; });
+    if (ent.size() > k) ent.resize(k);
+    for (size_t i = 0; i < ent.size(); ++i) {
+        slots[i] = ent[i].second;
+        counts[i] = ent[i].first;
+    }
+    *n_out = (uint32_t)ent.size();
+    return TC_E_OK;
+}
+
+extern "C" int tc_denied_reset(tc_engine* e) {
+    if (!e) return TC_E_INVALID_ARG;
+    if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_HIP(e, hipMemsetAsync(e->denied, 0, e->capacity * sizeof(uint32_t), cur_stream(e)));
+    if (e->retired) TC_HIP(e, hipMemsetAsync(e->retired, 0, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec), cur_stream(e)));
+    return TC_E_OK;
+}
+
+// Top denied KEYS (key mode): the slots' counters and the side table of keys without a slot, merged.
+extern "C" int tc_top_denied_keys(tc_engine* e, uint32_t k, uint8_t* key_bytes, size_t key_bytes_cap, uint32_t* key_off, uint64_t* counts,
+                                  uint32_t* n_out) {
+    if (!e || !key_off || !counts || !n_out || (key_bytes_cap && !key_bytes)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
+    *n_out = 0;
+    key_off[0] = 0;
+    if (k == 0) return TC_E_OK;
+    if (k > TOPK_MAX) k = TOPK_MAX;
+    // keys that hold a slot
+    // (keys over 256 bytes are not tracked by the reference, metrics.rs:36-39: they are filtered out below, so a few
+    // more candidates than k are fetched)
+    const uint32_t k_live = std::min<uint32_t>(k + 64u, TOPK_MAX);
+    std::vector<uint32_t> slots(k_live);
+    std::vector<uint64_t> cnt(k_live);
+    uint32_t n_live = 0;
+    TC_TRY(tc_top_denied(e, k_live, slots.data(), cnt.data(), &n_live));
+    std::vector<std::pair<std::string, uint64_t>> all;
+    if (n_live) {
+        std::vector<uint32_t> off(n_live + 1);
+        std::vector<uint8_t> bytes(std::max<size_t>(1, (size_t)n_live * 64));
+        int rc;
+        while ((rc = tc_slot_keys(e, n_live, slots.data(), bytes.data(), bytes.size(), off.data())) == TC_E_INVALID_ARG && bytes.size() < ((size_t)1 << 31))
+            bytes.resize(bytes.size() * 4);
+        if (rc != TC_E_OK) return rc;
+        for (uint32_t i = 0; i < n_live; ++i)
+            if (off[i + 1] - off[i] <= kt::RETIRED_KEY) all.emplace_back(std::string((const char*)bytes.data() + off[i], off[i + 1] - off[i]), cnt[i]);
+    }
+    // keys that lost theirs (a key's denials are in exactly one place: see kt::RetiredRec)
+    std::vector<kt::RetiredRec> rt(kt::RETIRED_CAP);
+    hipStream_t s = cur_stream(e);
+    TC_HIP(e, hipMemcpyAsync(rt.data(), e->retired, rt.size() * sizeof(kt::RetiredRec), hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    std::vector<std::pair<std::string, uint64_t>> retired;
+    for (const kt::RetiredRec& r : rt)
+        if ((r.tag & kt::RT_VALID) && r.count) retired.emplace_back(std::string((const char*)r.bytes, r.len), (uint64_t)r.count);
+    auto by_count = [](const std::pair<std::string, uint64_t>& a, const std::pair<std::string, uint64_t>& b) {
+        return a.second != b.second ? a.second > b.second : a.first < b.first;
+    };
+    if (retired.size() > 3u * TOPK_MAX) {
+        // TopDeniedKeys::cleanup (metrics.rs:52-64): past 3 x the limit only the most denied `limit` keys are kept.
+        // The table is rewritten from the host (the engine is drained: this is a synchronous call).
+        std::sort(retired.begin(), retired.end(), by_count);
+        retired.resize(TOPK_MAX);
+        std::fill(rt.begin(), rt.end(), kt::RetiredRec{});
+        for (const auto& kv : retired) {
+            const uint64_t h = kt::hash_key((const uint8_t*)kv.first.data(), (uint32_t)kv.first.size());
+            uint32_t pos = (uint32_t)(h >> 17) & (kt::RETIRED_CAP - 1u);
+            while (rt[pos].tag != kt::RT_EMPTY) pos = (pos + 1u) & (kt::RETIRED_CAP - 1u);
+            rt[pos].tag = h | kt::RT_VALID;
+            rt[pos].count = (uint32_t)kv.second;
+            rt[pos].len = (uint32_t)kv.first.size();
+            memcpy(rt[pos].bytes, kv.first.data(), kv.first.size());
+        }
+        TC_HIP(e, hipMemcpyAsync(e->retired, rt.data(), rt.size() * sizeof(kt::RetiredRec), hipMemcpyHostToDevice, s));
+        TC_HIP(e, hipStreamSynchronize(s));
+    }
+    all.insert(all.end(), retired.begin(), retired.end());
+    std::sort(all.begin(), all.end(), by_count);
+    if (all.size() > k) all.resize(k);
+    size_t at = 0;
+    for (size_t i = 0; i < all.size(); ++i) {
+        if (at + all[i].first.size() > key_bytes_cap) return fail(e, TC_E_INVALID_ARG, "tc_top_denied_keys: key_bytes_cap too small");
+        memcpy(key_bytes + at, all[i].first.data(), all[i].first.size());
+        at += all[i].first.size();
+        key_off[i + 1] = (uint32_t)at;
+        counts[i] = all[i].second;
+    }
+    *n_out = (uint32_t)all.size();
+    return TC_E_OK;
+}

@@ -1,6 +1,6 @@
 // maintenance_kernels.hpp -- everything that is not a decision: expiry sweep (== AdaptiveStore::cleanup),
 // top-denied-key selection, rate-plan id fills, the single-key `trait Store` operations.
-// Included once, by tcgpu.hip.
+// Kernels have internal linkage: every translation unit (engine.hpp) compiles the ones it launches.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -19,7 +19,7 @@ using tc::Cell;
 // ---------------------------------------------------------------------------
 // K4: expiry sweep == AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint64_t capacity, int64_t now,
+static __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint64_t capacity, int64_t now,
                                                  unsigned long long* counters, unsigned long long* removed_out) {
     uint32_t removed = 0, live = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint6
 }
 
 // TC_CFG_FIXED_PARAMS layout: expiry == tat + dvt of the key's plan (tc::fixed_cell); vacant == TAT_VACANT
-__global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restrict__ tat8, const uint16_t* __restrict__ rate_id,
+static __global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restrict__ tat8, const uint16_t* __restrict__ rate_id,
                                                        const tc::RateClass* __restrict__ classes, uint32_t uniform_class, uint64_t capacity,
                                                        int64_t now, unsigned long long* counters, unsigned long long* removed_out) {
     uint32_t removed = 0, live = 0;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restrict__ tat
 // LDS and pushes them with ONE stack reservation per SWEEP_BUF slots (an atomic on
 // the stack top costs ~12 ns and serialises: one per 256 slots was most of the kernel).
 constexpr int SWEEP_BUF = 4096;
-__global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
+static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
                                                       unsigned long long* counters, unsigned long long* removed_out,
                                                       uint32_t* __restrict__ denied) {
     __shared__ uint32_t s_buf[SWEEP_BUF];
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, 
 // exact, one u32 per slot, and the top K are selected on demand: radix select of the K-th
 // largest count, 8 bits per pass, then one compaction pass)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_denied_hist(const uint32_t* __restrict__ denied, uint64_t capacity,
+static __global__ __launch_bounds__(BLOCK) void k_denied_hist(const uint32_t* __restrict__ denied, uint64_t capacity,
                                                        uint32_t prefix, uint32_t prefix_mask, uint32_t shift,
                                                        uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_h[256];
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(BLOCK) void k_denied_hist(const uint32_t* __restric
 }
 
 // entries with count > T go to list 0, entries with count == T to list 1 (each capped at `cap_out`)
-__global__ __launch_bounds__(BLOCK) void k_denied_collect(const uint32_t* __restrict__ denied, uint64_t capacity, uint32_t T,
+static __global__ __launch_bounds__(BLOCK) void k_denied_collect(const uint32_t* __restrict__ denied, uint64_t capacity, uint32_t T,
                                                           uint32_t* __restrict__ n_out /*[2]*/, uint32_t* __restrict__ lists,
                                                           uint32_t cap_out) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(BLOCK) void k_denied_collect(const uint32_t* __rest
 }
 
 // key mode: copy the KeyRec of each listed slot into a dense array
-__global__ __launch_bounds__(BLOCK) void k_gather_keyrecs(kt::Table t, const uint32_t* __restrict__ slots, uint32_t n,
+static __global__ __launch_bounds__(BLOCK) void k_gather_keyrecs(kt::Table t, const uint32_t* __restrict__ slots, uint32_t n,
                                                           kt::KeyRec* __restrict__ out) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
@@ -237,16 +237,16 @@ __global__ __launch_bounds__(BLOCK) void k_gather_keyrecs(kt::Table t, const uin
     out[i] = r;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_fill_i64(int64_t* __restrict__ a, uint64_t n, int64_t v) {
+static __global__ __launch_bounds__(BLOCK) void k_fill_i64(int64_t* __restrict__ a, uint64_t n, int64_t v) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) a[i] = v;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_fill_rate_id(uint16_t* __restrict__ rate_id, uint64_t capacity, uint16_t id) {
+static __global__ __launch_bounds__(BLOCK) void k_fill_rate_id(uint16_t* __restrict__ rate_id, uint64_t capacity, uint16_t id) {
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK)
         rate_id[i] = id;
 }
 
-__global__ __launch_bounds__(BLOCK) void k_scatter_rate_id(uint16_t* __restrict__ rate_id, const uint32_t* __restrict__ slots,
+static __global__ __launch_bounds__(BLOCK) void k_scatter_rate_id(uint16_t* __restrict__ rate_id, const uint32_t* __restrict__ slots,
                                                            const uint16_t* __restrict__ src, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (i < n) rate_id[slots ? slots[i] : i] = src[i];
@@ -259,7 +259,7 @@ struct StoreOpResult {
     int32_t flag;
     int32_t pad;
 };
-__global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
+static __global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
                            StoreOpResult* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     Cell c = cells[slot];
@@ -299,7 +299,7 @@ __global__ void k_store_op(Cell* cells, uint64_t slot, int op, int64_t a, int64_
 // flag that only k_probe_set (on stream B) raises, or gives up after `timeout` ticks of the 100 MHz
 // wall clock: if it saw the flag, B ran while A was running.
 // ---------------------------------------------------------------------------
-__global__ void k_probe_spin(uint32_t* flag, uint32_t* saw, long long timeout) {
+static __global__ void k_probe_spin(uint32_t* flag, uint32_t* saw, long long timeout) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long long t0 = wall_clock64();
     uint32_t v = 0;
@@ -307,7 +307,7 @@ __global__ void k_probe_spin(uint32_t* flag, uint32_t* saw, long long timeout) {
         __builtin_amdgcn_s_sleep(8);
     *saw = v;
 }
-__global__ void k_probe_set(uint32_t* flag) {
+static __global__ void k_probe_set(uint32_t* flag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -321,7 +321,7 @@ struct Segments {
     uint32_t start[65]; // prefix sums; start[n] = total
     uint32_t n;
 };
-__global__ __launch_bounds__(BLOCK) void k_concat(Segments sg, uint32_t* __restrict__ out) {
+static __global__ __launch_bounds__(BLOCK) void k_concat(Segments sg, uint32_t* __restrict__ out) {
     const uint32_t total = sg.start[sg.n];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += gridDim.x * BLOCK) {
         uint32_t s = 0;
@@ -336,7 +336,7 @@ struct Destinations {
     uint32_t start[65];
     uint32_t n;
 };
-__global__ __launch_bounds__(BLOCK) void k_forward(const uint32_t* __restrict__ src, Destinations ds) {
+static __global__ __launch_bounds__(BLOCK) void k_forward(const uint32_t* __restrict__ src, Destinations ds) {
     const uint32_t total = ds.start[ds.n];
     for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < total; i += gridDim.x * BLOCK) {
         uint32_t s = 0;
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(BLOCK) void k_forward(const uint32_t* __restrict__ 
 // transfers of TC_B_ASYNC batches are ordinary kernels on the engine's stream (see copy_back_async).
 // 16 bytes per lane per step when both ends and the size allow, else bytes.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, const void* __restrict__ src, size_t bytes) {
+static __global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, const void* __restrict__ src, size_t bytes) {
     const size_t tid = (size_t)blockIdx.x * BLOCK + threadIdx.x, nthreads = (size_t)gridDim.x * BLOCK;
     if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
         const size_t n16 = bytes / 16;

@@ -90,7 +90,7 @@ struct Work {
     uint32_t tag;
 };
 
-__global__ __launch_bounds__(THREADS) void k_route_count(const uint32_t* __restrict__ id, uint32_t n, Map m, Work w) {
+static __global__ __launch_bounds__(THREADS) void k_route_count(const uint32_t* __restrict__ id, uint32_t n, Map m, Work w) {
     __shared__ uint32_t s_c[MAX_WORLD];
     if (threadIdx.x < MAX_WORLD) s_c[threadIdx.x] = 0;
     __syncthreads();
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(THREADS) void k_route_count(const uint32_t* __restr
 }
 
 // one block per destination: exclusive prefix of its counts over the tiles (each thread a contiguous piece), total
-__global__ __launch_bounds__(THREADS) void k_route_scan(Work w) {
+static __global__ __launch_bounds__(THREADS) void k_route_scan(Work w) {
     __shared__ uint32_t s_part[THREADS];
     uint32_t* row = w.tile_cnt + (size_t)blockIdx.x * w.tiles;
     const uint32_t per = (w.tiles + THREADS - 1) / THREADS;
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(THREADS) void k_route_one(const uint32_t* __restric
 // A caller that polls host memory instead of synchronising: behind the scatter on the same stream, the totals and,
 // after them, the caller's tag.  (A ticket taken by every tile of the scatter kernel -- "the last one publishes" --
 // cost 100 ns per tile: 2048 device-scope atomics on one word are 0.2 ms.)
-__global__ __launch_bounds__(MAX_WORLD) void k_route_publish(Work w, uint32_t world) {
+static __global__ __launch_bounds__(MAX_WORLD) void k_route_publish(Work w, uint32_t world) {
     if (threadIdx.x < world) w.host_totals[threadIdx.x] = w.totals[threadIdx.x];
     __threadfence_system();
     __syncthreads();

@@ -1,0 +1,731 @@
+// slots.hip -- tc_rate_limit_batch_slots: staging, grouping (radix sort / bucket path), evaluation, one-launch small batches
+#include "engine.hpp"
+
+// ---- batch over slots -------------------------------------------------------
+// The device-side address of a pinned host array (tc_host_alloc / hipHostMalloc / hipHostRegister), or
+// nullptr for pageable memory.
+static void* device_view_of_host(const void* host) {
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, host) != hipSuccess) {
+        (void)hipGetLastError(); // pageable memory: not an error for us
+        return nullptr;
+    }
+    if (at.type != hipMemoryTypeHost || !at.devicePointer) return nullptr;
+    return at.devicePointer;
+}
+
+// Results of a TC_B_ASYNC batch -> the caller's host array, on stream `st`: a copy kernel when the array is
+// pinned, hipMemcpyAsync otherwise (correct, but the call may wait for the transfer).  hipMemcpyAsync of
+// device -> pinned host memory behind kernels stalled the submitting thread for 7-13 ms every few dozen
+// batches (host -> device through the SDMA engines does not, and unlike a copy kernel reading over PCIe it
+// does not slow the kernels running beside it: 41 vs 100 us for the evaluation).
+static int copy_back_async(tc_engine* e, void* host, const void* dev, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return TC_E_OK;
+    void* hv = device_view_of_host(host);
+    if (!hv) {
+        TC_HIP(e, copy_async(e, host, dev, bytes, hipMemcpyDeviceToHost, st));
+        return TC_E_OK;
+    }
+    // few blocks: the transfer is bound by the PCIe link, and a grid that fills the chip with waves waiting on
+    // the link starves the kernels running beside it
+    const uint32_t blocks = (uint32_t)std::min<size_t>((bytes / 16 + BLOCK - 1) / BLOCK + 1, 48);
+    hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(BLOCK), 0, st, hv, dev, bytes);
+    return TC_E_OK;
+}
+
+// output staging for the arrays `b` asks for; `d` gets the device pointers
+int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d) {
+    const uint64_t mb = e->max_batch;
+    tc_engine::Stage& st = e->stage;
+    if (b.allowed) TC_TRY(stage_need(e, st.allowed, mb));
+    if (b.allowed_bits) TC_TRY(stage_need(e, st.bits, (mb + 63) / 64));
+    int64_t* const want[4] = {b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns};
+    for (int j = 0; j < 4; ++j)
+        if (want[j]) TC_TRY(stage_need(e, st.out[j], mb));
+    if (b.status) TC_TRY(stage_need(e, st.status, mb));
+    if (b.result4) TC_TRY(stage_need(e, st.result4, mb * 4));
+    if (b.decisions) TC_TRY(stage_need(e, st.decisions, mb));
+    if (b.order) TC_TRY(stage_need(e, st.order, mb));
+    d.allowed = b.allowed ? st.allowed : nullptr;
+    d.allowed_bits = b.allowed_bits ? st.bits : nullptr;
+    d.limit = b.limit ? st.out[0] : nullptr;
+    d.remaining = b.remaining ? st.out[1] : nullptr;
+    d.reset_after_ns = b.reset_after_ns ? st.out[2] : nullptr;
+    d.retry_after_ns = b.retry_after_ns ? st.out[3] : nullptr;
+    d.status = b.status ? st.status : nullptr;
+    d.result4 = b.result4 ? st.result4 : nullptr;
+    d.decisions = b.decisions ? st.decisions : nullptr;
+    d.order = b.order ? st.order : nullptr;
+    return TC_E_OK;
+}
+
+// staged outputs -> the caller's host arrays, enqueued on `s` (by_kernel: TC_B_ASYNC, see copy_back_async)
+int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_kernel) {
+    const uint64_t n = b.n;
+    const tc_engine::Stage& st = e->stage;
+    auto back = [&](void* host, const void* dev, size_t bytes) -> int {
+        if (by_kernel) return copy_back_async(e, host, dev, bytes, s);
+        TC_HIP(e, copy_async(e, host, dev, bytes, hipMemcpyDeviceToHost, s));
+        return TC_E_OK;
+    };
+    if (b.allowed) TC_TRY(back(b.allowed, st.allowed, n));
+    if (b.allowed_bits) TC_TRY(back(b.allowed_bits, st.bits, ((n + 63) / 64) * sizeof(uint64_t)));
+    int64_t* hout[4] = {b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns};
+    for (int j = 0; j < 4; ++j)
+        if (hout[j]) TC_TRY(back(hout[j], st.out[j], n * sizeof(int64_t)));
+    if (b.status) TC_TRY(back(b.status, st.status, n));
+    if (b.result4) TC_TRY(back(b.result4, st.result4, n * 4 * sizeof(int64_t)));
+    if (b.decisions) TC_TRY(back(b.decisions, st.decisions, n * sizeof(tc_decision)));
+    if (b.order && (b.flags & TC_B_GROUPED_OUTPUT)) TC_TRY(back(b.order, st.order, n * sizeof(uint32_t)));
+    return TC_E_OK;
+}
+
+// stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
+// returns the buffer holding the result
+static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
+                                    bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
+                                    uint8_t* fill = nullptr, uint32_t fill_value = 0) {
+    const uint32_t cap = (uint32_t)e->capacity;
+    const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
+    const int passes = (bits + 7) / 8;
+    const int items = piped ? e->sort_items_piped : SORT_ITEMS;
+    const uint32_t tile = rs::THREADS * (uint32_t)items;
+    const uint32_t tiles = (n + tile - 1) / tile;
+    rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
+    ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
+    ss.hist_parity ^= 1u;
+    prof_begin(e, TC_STAGE_PREP, s);
+    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value);
+    prof_end(e, s);
+    uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
+    const uint64_t* in = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        uint64_t* out = bufs[p & 1];
+        prof_begin(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
+        hipEvent_t stop = (p + 1 == passes && !e->prof_on) ? stop_last : nullptr;
+#define TC_PASS(IT, FI) \
+    TC_LAUNCH(stop, (rs::k_onesweep<IT, FI>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
+              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min)
+        if (p == 0) {
+            if (items == 32) TC_PASS(32, true);
+            else if (items == 16) TC_PASS(16, true);
+            else TC_PASS(8, true);
+        } else {
+            if (items == 32) TC_PASS(32, false);
+            else if (items == 16) TC_PASS(16, false);
+            else TC_PASS(8, false);
+        }
+#undef TC_PASS
+        prof_end(e, s);
+        in = out;
+    }
+    return in;
+}
+
+// Uniform batch (one `now`, one `quantity`): is every run regular (tc::run_form) whatever the cells
+// hold?  With request 0 of a run allowed, new0 lies in [now - dvt + inc, now + dvt], so the
+// cell-dependent provisos of run_form hold by themselves once the parameters satisfy
+//     ei > 0,  dvt > 0 (burst >= 2: the entry outlives its own timestamp),  q > 0,
+//     ei * q < 2^62,  0 <= now,  now + dvt < 2^62,
+// checked here for the batch's scalar rate or for the bounds over all registered plans.
+static bool all_runs_regular(const tc_engine* e, const tc_batch& b, const Params& p) {
+    const int64_t LIM = (int64_t)1 << 62;
+    const int64_t q = p.q_s, now = p.now_s;
+    if (q <= 0 || now < 0) return false;
+    int64_t lo_ei, hi_ei, lo_dvt, hi_dvt;
+    if (p.flags & F_REGISTERED) {
+        if (e->uniform_id) {
+            const RateClass& rc = e->host_classes[e->uniform_id];
+            lo_ei = hi_ei = rc.ei;
+            lo_dvt = hi_dvt = rc.dvt;
+        } else {
+            if (e->host_classes.size() <= 1) return false;
+            lo_ei = e->cls_min_ei, hi_ei = e->cls_max_ei, lo_dvt = e->cls_min_dvt, hi_dvt = e->cls_max_dvt;
+        }
+    } else {
+        int64_t ei, dvt;
+        if (tc::derive_rate(b.max_burst_scalar, b.count_per_period_scalar, b.period_scalar, ei, dvt) != tc::ST_OK) return false;
+        lo_ei = hi_ei = ei;
+        lo_dvt = hi_dvt = dvt;
+    }
+    int64_t inc, lim;
+    if (lo_ei <= 0 || lo_dvt <= 0) return false;
+    if (__builtin_mul_overflow(hi_ei, q, &inc) || inc >= LIM) return false;
+    if (__builtin_add_overflow(now, hi_dvt, &lim) || lim >= LIM) return false;
+    return true;
+}
+
+// k_eval_sorted<.., ITEMS>: 2 positions per lane when the batch overlaps with its neighbours' sorts,
+// 4 when it runs alone (measured; 8 is slower everywhere; TCGPU_EVAL_ITEMS = 1 | 2 | 4 overrides)
+template <int ITEMS, bool FIXED>
+static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, uint32_t n, hipStream_t s, const Params& p, const uint64_t* sorted,
+                              uint32_t seq, const uint32_t* gate, uint32_t gate_min, hipEvent_t stop) {
+    (void)lean;
+    const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
+    if (lean) {
+        if constexpr (ITEMS <= 2) {
+            TC_LAUNCH(stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
+            return;
+        }
+    }
+    if (full && direct) TC_LAUNCH(stop, (k_eval_sorted<true, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (full) TC_LAUNCH(stop, (k_eval_sorted<true, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (direct) TC_LAUNCH(stop, (k_eval_sorted<false, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else TC_LAUNCH(stop, (k_eval_sorted<false, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+}
+
+static int eval_items_of(const tc_engine* e, bool piped) { return e->eval_items ? e->eval_items : (piped ? 2 : 4); }
+
+// LEAN: decisions only, direct stores, nothing asked for but the `allowed` bytes in request order (k_eval_sorted_lean)
+static bool lean_applies(const tc_engine* e, bool full, bool direct, bool piped, const Params& p) {
+    return e->eval_lean && !full && direct && eval_items_of(e, piped) <= 2 && p.allowed && !p.status && !p.limit && !p.order && !p.row_bits;
+}
+
+static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped, uint32_t n, hipStream_t s, const Params& p,
+                               const uint64_t* sorted, uint32_t seq, const uint32_t* gate = nullptr, uint32_t gate_min = 0,
+                               hipEvent_t stop = nullptr) {
+    const int items = eval_items_of(e, piped);
+    const bool lean = lean_applies(e, full, direct, piped, p);
+    if (e->fixed) {
+        switch (items) {
+        case 1: launch_eval_items<1, true>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+        case 2: launch_eval_items<2, true>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+        default: launch_eval_items<4, true>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+        }
+    }
+    switch (items) {
+    case 1: launch_eval_items<1, false>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+    case 2: launch_eval_items<2, false>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+    default: launch_eval_items<4, false>(e, full, direct, lean, n, s, p, sorted, seq, gate, gate_min, stop); return;
+    }
+}
+
+// ---- bucket path (bucket_path.hpp) -------------------------------------------------------------------
+// partition of the batch by key range, on stream `s` (k_tile_hist, k_bucket_scan, k_scatter)
+// (false: a launch was rejected -- the caller must not enqueue the bucket evaluation behind this partition)
+static bool bucket_partition(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n) {
+    const bp::Work& w = ss.bpw;
+    const uint32_t tiles = bp::tiles_of(n), cap = (uint32_t)e->capacity;
+    prof_begin(e, TC_STAGE_BUCKET_HIST, s);
+    hipLaunchKernelGGL(bp::k_tile_hist, dim3(tiles), dim3(bp::TILE_THREADS), w.nbk * sizeof(uint32_t), s, d_slot, n, cap, w);
+    prof_end(e, s);
+    prof_begin(e, TC_STAGE_BUCKET_SCAN, s);
+    hipLaunchKernelGGL(bp::k_bucket_scan, dim3(bp::scan_blocks(w.nbk)), dim3(bp::SCAN_THREADS), 0, s, w, tiles);
+    prof_end(e, s);
+    prof_begin(e, TC_STAGE_BUCKET_SCATTER, s);
+    hipLaunchKernelGGL(bp::k_scatter, dim3(tiles), dim3(bp::TILE_THREADS), bp::scatter_lds_bytes(w.nbk), s, d_slot, n, cap, w);
+    prof_end(e, s);
+    return hipGetLastError() == hipSuccess;
+}
+
+// evaluation of the partitioned batch: one wave per bucket (k_bucket_eval)
+static void bucket_eval(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const Params& p, bool full) {
+    const bp::Work& w = ss.bpw;
+    const bool by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS);
+    const bool fixed = (p.flags & F_FIXED) != 0;
+    const dim3 grid(w.nbk), block(64);
+    const size_t lds = bp::eval_lds_bytes(w.lb);
+    prof_begin(e, TC_STAGE_BUCKET_EVAL, s);
+#define TC_BEV(FU, FI, BS) \
+    hipLaunchKernelGGL((bp::k_bucket_eval<FU, FI, BS>), grid, block, lds, s, p, w, e->bp_park)
+    switch ((full ? 4 : 0) | (fixed ? 2 : 0) | (by_slot ? 1 : 0)) {
+    case 0: TC_BEV(false, false, false); break;
+    case 1: TC_BEV(false, false, true); break;
+    case 2: TC_BEV(false, true, false); break;
+    case 3: TC_BEV(false, true, true); break;
+    case 4: TC_BEV(true, false, false); break;
+    case 5: TC_BEV(true, false, true); break;
+    case 6: TC_BEV(true, true, false); break;
+    default: TC_BEV(true, true, true); break;
+    }
+#undef TC_BEV
+    prof_end(e, s);
+}
+
+// host arrays -> the scratch set's staging columns, enqueued on `st`; `p` gets the device pointers
+static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn& hin, uint32_t n, hipStream_t st, Params& p,
+                             const uint32_t** d_slot) {
+    const uint64_t mb = e->max_batch;
+    if (hin.slot) { // (key batches arrive with their slots already resolved on the device)
+        if (!ss.h_slot) TC_HIP(e, hipMalloc(&ss.h_slot, mb * sizeof(uint32_t)));
+        TC_HIP(e, copy_async(e, ss.h_slot, hin.slot, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st)); // SDMA when pinned
+        *d_slot = ss.h_slot;
+        p.slot = ss.h_slot;
+    }
+    const int64_t** dst[5] = {&p.burst, &p.count, &p.period, &p.q, &p.now};
+    for (int j = 0; j < 5; ++j) {
+        if (!hin.col[j]) continue;
+        if (!ss.h_in[j]) TC_HIP(e, hipMalloc(&ss.h_in[j], mb * sizeof(int64_t)));
+        TC_HIP(e, copy_async(e, ss.h_in[j], hin.col[j], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        *dst[j] = ss.h_in[j];
+    }
+    return TC_E_OK;
+}
+
+// the pieces of a segmented slot column -> the scratch set's staging column, on stream `st`
+static int gather_segments(tc_engine* e, tc_engine::SortSet& ss, const tc_batch& b, uint32_t n, hipStream_t st, Params& p, const uint32_t** d_slot) {
+    if (!ss.h_slot) TC_HIP(e, hipMalloc(&ss.h_slot, e->max_batch * sizeof(uint32_t)));
+    mk::Segments sg;
+    memset(&sg, 0, sizeof sg);
+    sg.n = b.n_segments;
+    uint32_t at = 0;
+    for (uint32_t i = 0; i < b.n_segments; ++i) {
+        sg.ptr[i] = b.seg_slot[i];
+        sg.start[i] = at;
+        at += b.seg_n[i];
+    }
+    sg.start[b.n_segments] = at; // (== n: checked by the caller)
+    hipLaunchKernelGGL(mk::k_concat, dim3(std::min<uint32_t>(nblocks(n), 1024u)), dim3(BLOCK), 0, st, sg, ss.h_slot);
+    *d_slot = ss.h_slot;
+    p.slot = ss.h_slot;
+    return TC_E_OK;
+}
+
+// all pointers in `b` are device pointers here (hin: the inputs are host arrays still to be staged)
+int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
+    const uint32_t n = (uint32_t)b.n;
+    Params p;
+    p.n = n;
+    p.flags = 0;
+    p.slot = b.slot;
+    p.burst = b.max_burst;
+    p.count = b.count_per_period;
+    p.period = b.period;
+    p.q = b.quantity;
+    p.now = b.now_ns;
+    p.burst_s = b.max_burst_scalar;
+    p.count_s = b.count_per_period_scalar;
+    p.period_s = b.period_scalar;
+    p.q_s = b.quantity_scalar;
+    p.now_s = b.now_ns_scalar;
+    p.allowed = b.allowed ? b.allowed : (b.allowed_bits ? e->allowed_tmp : nullptr);
+    p.limit = b.limit;
+    p.remaining = b.remaining;
+    p.reset = b.reset_after_ns;
+    p.retry = b.retry_after_ns;
+    p.status = b.status;
+    p.result4 = b.result4;
+    p.decisions = b.decisions;
+    p.order = (b.flags & TC_B_GROUPED_OUTPUT) ? b.order : nullptr;
+    p.cells = e->cells;
+    p.tat8 = e->tat8;
+    if (e->fixed) p.flags |= F_FIXED;
+    if (e->debug_nostore) p.flags |= F_DEBUG_NOSTORE;
+    if (e->debug_break_wait) {
+        p.flags |= F_DEBUG_NO_ANNOUNCE;
+        e->debug_break_wait = false; // one batch
+    }
+    p.rate_id = e->rate_id;
+    p.classes = e->classes;
+    p.uniform_class = e->uniform_id;
+    p.denied = e->denied;
+    p.row_bits = nullptr;
+    p.capacity = e->capacity;
+    p.counters = e->counters;
+    if (b.flags & TC_B_REGISTERED_PARAMS) {
+        p.flags |= F_REGISTERED;
+        if (e->uniform_id) p.flags |= F_UNIFORM_CLASS;
+    }
+    const bool full = p.remaining || p.reset || p.retry || p.result4 || p.decisions;
+    const dim3 grid(nblocks(n)), block(BLOCK);
+    hipStream_t s = cur_stream(e);
+    bool bits_in_kernel = false;
+
+    if (b.flags & TC_B_UNIQUE_SLOTS) {
+        if (hin) {
+            // (a set's staging columns are only read by work that this stream has already been ordered behind)
+            tc_engine::SortSet& ss = e->sets[e->next_set];
+            e->next_set = (e->next_set + 1) % e->depth;
+            if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(s, ss.consumed, 0));
+            const uint32_t* d_slot = nullptr;
+            TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
+        }
+        prof_begin(e, TC_STAGE_EVAL, s);
+        if (full) hipLaunchKernelGGL(k_eval_unique<true>, grid, block, 0, s, p);
+        else hipLaunchKernelGGL(k_eval_unique<false>, grid, block, 0, s, p);
+        prof_end(e, s);
+        if (hin) {
+            tc_engine::SortSet& ss = e->sets[(e->next_set + e->depth - 1) % e->depth];
+            TC_HIP(e, hipEventRecord(ss.consumed, s));
+            ss.in_use = true;
+        }
+    } else {
+        // grouping: on the set's auxiliary stream when the caller vouches for the inputs
+        // (overlaps with the evaluation of earlier batches), else in order on `s`
+        tc_engine::SortSet& ss = e->sets[e->next_set];
+        e->next_set = (e->next_set + 1) % e->depth;
+        bool piped = (b.flags & TC_B_INPUTS_READY) != 0;
+        if (piped) {
+            int rc = ensure_side_streams(e);
+            if (rc != TC_E_OK) return rc;
+            piped = e->n_aux != 0; // no free hardware queue: in order on the main stream
+        }
+        // (the per-request columns of a TC_B_ASYNC host batch are still to be staged: they are in `hin`)
+        auto column = [&](const int64_t* dev, int j) { return dev != nullptr || (hin && hin->col[j] != nullptr); };
+        const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!column(p.burst, 0) && !column(p.count, 1) && !column(p.period, 2));
+        const bool uniform = !column(p.q, 3) && !column(p.now, 4) && params_by_slot;
+        // direct: every run is regular whatever the cells hold: owners store directly, no commit launch
+        const bool direct = uniform && all_runs_regular(e, b, p);
+        // Uniform batches whose runs are all regular, running IN ORDER on the engine's stream, are enqueued on
+        // BOTH grouping paths: the partition by key range (bucket_path.hpp) and, gated behind it, the sort.  The
+        // partition publishes its largest bucket; if that is longer than bp_skew (a skewed stream) the bucket
+        // kernels leave at once and the sort path runs, otherwise the other way round -- decided on the
+        // device, batch by batch (the host may be hundreds of batches ahead).  Pipelined batches are sorted:
+        // beside the evaluation of earlier batches the partition's scattered 4-byte writes cost more than
+        // the sort's three coalesced passes (69-86 vs 66 us per 1 Mi batch).
+        // (TC_B_GROUPED_OUTPUT promises rows grouped by key: that is the sorted order)
+        // A skewed batch pays for the partition and then takes the sort path anyway.  The host cannot wait for the
+        // gate, but the device mirrors it into pinned memory: when a recent batch tripped it, the next BP_BACKOFF
+        // batches are not partitioned at all (the sort path alone is always correct), then the path is tried again.
+        bool eligible = direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
+        if (eligible && e->bp_gate_host && e->bp_backoff_len) {
+            const uint32_t seen = *(volatile uint32_t*)e->bp_gate_host;
+            if (seen > e->bp_skew && e->bp_backoff == 0) {
+                e->bp_backoff = e->bp_backoff_len;
+                *(volatile uint32_t*)e->bp_gate_host = 0; // (consumed; the next partition that runs writes a fresh one)
+            }
+            if (e->bp_backoff) {
+                --e->bp_backoff;
+                eligible = false;
+            }
+        }
+        const bool bucketed = eligible;
+        // Grouped rows + a bitmask of them, every run regular: the evaluation's waves hold 64 consecutive rows each and
+        // pack their decisions with one ballot (no byte column, no k_pack_bits launch).
+        if (b.allowed_bits && p.order && direct) {
+            p.row_bits = b.allowed_bits;
+            bits_in_kernel = true;
+            if (!b.allowed) p.allowed = nullptr;
+        }
+        const uint32_t* gate = bucketed ? ss.bpw.maxb : nullptr;
+        const uint64_t* sorted;
+        const uint32_t* d_slot = b.slot;
+        if (!hin && !b.n_segments) {
+            ss.readers[ss.next_reader % 4].ptr = b.slot;
+            ss.readers[ss.next_reader % 4].n = n;
+            ss.next_reader++;
+        }
+        if (piped) {
+            hipStream_t ax = e->aux[e->next_aux];
+            e->next_aux = (e->next_aux + 1) % e->n_aux;
+            if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
+            if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
+            if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
+            if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, ax, p, &d_slot));
+            if (bucketed && !bucket_partition(e, ss, ax, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
+            const bool ride = e->stop_events && !e->prof_on; // `sorted` rides on the last pass's own completion signal
+            // TC_B_OUTPUTS_IDLE: nothing enqueued earlier touches this call's `allowed` bytes, so they are preset here, on
+            // the grouping stream, to what most decisions of a recent batch were, and the evaluation only stores the
+            // others -- 1 Mi one-byte stores scattered over the batch were 6 of its 53 us
+            uint8_t* fill = nullptr;
+            uint32_t fill_value = 0;
+            if ((b.flags & TC_B_OUTPUTS_IDLE) && e->prefill_on && !hin && !bucketed && uniform && lean_applies(e, full, direct, true, p) &&
+                p.allowed == b.allowed) {
+                fill = b.allowed;
+                fill_value = *(volatile uint32_t*)e->fill_hint_host & 1u;
+                p.flags |= fill_value ? F_PREFILL1 : F_PREFILL0;
+            }
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value);
+            if (!ride) TC_HIP(e, hipEventRecord(ss.sorted, ax));
+            TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
+            ss.grouped_aside = true;
+        } else {
+            // everything that used this set earlier is ordered before us on `s`: evaluations ran on `s`,
+            // and every auxiliary sort was joined into `s` before its evaluation
+            if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
+            if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, s, p, &d_slot));
+            ss.grouped_aside = false;
+            if (bucketed && !bucket_partition(e, ss, s, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
+            sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
+        }
+        if (bucketed) bucket_eval(e, ss, s, p, full);
+        prof_begin(e, TC_STAGE_EVAL, s);
+        bool consumed_rides = false;
+        if (uniform) {
+            uint32_t seq = 0u;
+            if (direct) {
+                if (++e->loaded_seq == 0u) e->loaded_seq = 1u;
+                seq = e->loaded_seq;
+            }
+            // (direct: the evaluation is the last reader of the set -- `consumed` can ride on its completion signal)
+            consumed_rides = direct && e->stop_events && !e->prof_on;
+            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr);
+            prof_end(e, s);
+            if (!direct) {
+                prof_begin(e, TC_STAGE_COMMIT, s);
+                hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells, e->tat8);
+                prof_end(e, s);
+            }
+        } else {
+            if (++e->chain_seq >= 0x7FFFFFFFu) e->chain_seq = 1u; // 0 = "never written"; 31 bits: the spec word carries a flag
+            if (full) hipLaunchKernelGGL(k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
+            else hipLaunchKernelGGL(k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
+            prof_end(e, s);
+        }
+        e->wait_before_sort = nullptr;
+        // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream
+        if (!consumed_rides) TC_HIP(e, hipEventRecord(ss.consumed, s));
+        ss.in_use = true;
+    }
+    if (b.allowed_bits && !bits_in_kernel) {
+        prof_begin(e, TC_STAGE_PACK, s);
+        hipLaunchKernelGGL(k_pack_bits, grid, block, 0, s, p.allowed, n, b.allowed_bits);
+        prof_end(e, s);
+    }
+    TC_HIP(e, hipGetLastError());
+    e->batches++; // (a batch that failed on the way here was not applied and is not counted)
+    return TC_E_OK;
+}
+
+// Host-pointer batch whose slot column is already in e->stage.slot: stage the
+// other inputs, run, copy the outputs back, synchronise.
+int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
+    const uint64_t n = b.n;
+    hipStream_t s = cur_stream(e);
+    tc_batch d = b;
+    d.flags |= TC_B_DEVICE_PTRS;
+    d.flags &= ~(TC_B_INPUTS_READY | TC_B_ASYNC);
+    d.slot = e->stage.slot;
+    d.key_bytes = nullptr;
+    d.key_off = nullptr;
+    const int64_t* hin[5] = {b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns};
+    const int64_t** din[5] = {&d.max_burst, &d.count_per_period, &d.period, &d.quantity, &d.now_ns};
+    for (int j = 0; j < 5; ++j) {
+        if (hin[j]) {
+            TC_TRY(stage_need(e, e->stage.in[j], e->max_batch));
+            TC_HIP(e, copy_async(e, e->stage.in[j], hin[j], n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            *din[j] = e->stage.in[j];
+        }
+    }
+    TC_TRY(stage_outputs(e, b, d));
+    TC_TRY(run_slots_device(e, d));
+    TC_TRY(copy_outputs_back(e, b, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    return poisoned(e); // (a synchronous batch whose kernels flagged an invariant fails itself, not the next call)
+}
+
+// results back to the caller's arrays behind the evaluation + the batch's completion event
+int finish_async(tc_engine* e, const tc_batch& b) {
+    hipStream_t s = cur_stream(e);
+    TC_TRY(copy_outputs_back(e, b, s, true));
+    hipEvent_t ev = nullptr;
+    if (!e->async_pool.empty()) {
+        ev = e->async_pool.back();
+        e->async_pool.pop_back();
+    } else {
+        TC_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    }
+    e->async_done.push_back(ev);
+    TC_HIP(e, hipEventRecord(ev, s));
+    return TC_E_OK;
+}
+
+// TC_B_ASYNC: the host batch's inputs are staged on the stream that groups it (overlapping the evaluation
+// of earlier batches), the outputs are copied back behind its evaluation, nothing waits.
+static int run_slots_host_async(tc_engine* e, const tc_batch& b) {
+    tc_batch d = b;
+    d.flags |= TC_B_DEVICE_PTRS | TC_B_INPUTS_READY; // the host arrays are complete at call time by contract
+    d.flags &= ~TC_B_ASYNC;
+    d.slot = nullptr;
+    d.max_burst = d.count_per_period = d.period = d.quantity = d.now_ns = nullptr;
+    d.key_bytes = nullptr;
+    d.key_off = nullptr;
+    HostIn hin;
+    hin.slot = b.slot;
+    hin.col[0] = b.max_burst, hin.col[1] = b.count_per_period, hin.col[2] = b.period, hin.col[3] = b.quantity, hin.col[4] = b.now_ns;
+    TC_TRY(stage_outputs(e, b, d));
+    TC_TRY(run_slots_device(e, d, &hin));
+    return finish_async(e, b);
+}
+
+// ---- small host-pointer batches: one launch (k_small_batch) ----------------------------------------
+constexpr size_t SMALL_KEY_BYTES = 128 * 1024; // string mode: batches with a larger key arena take the big pipeline
+
+bool small_batch_applies(const tc_engine* e, const tc_batch& b) {
+    if (e->small_off || b.n > (uint64_t)SMALL_MAX) return false;
+    if (b.flags & (TC_B_DEVICE_PTRS | TC_B_ASYNC | TC_B_GROUPED_OUTPUT)) return false;
+    if (b.allowed_bits) return false; // (packed bits come out of the big pipeline only)
+    if (e->key_mode && b.key_off[b.n] > SMALL_KEY_BYTES) return false;
+    return true;
+}
+
+// Host-pointer batch of at most SMALL_MAX requests, slot or string mode.  Same results as the big pipeline
+// (the run walker is the plain sequence); ordering against key stages on the key stream as tc_rate_limit.
+int run_small_batch(tc_engine* e, const tc_batch& b) {
+    const size_t n = b.n;
+    if (!e->small_io) {
+        const size_t bytes = 64 + SMALL_KEY_BYTES + (size_t)SMALL_MAX * (4 + 4 + 5 * 8 + 1 + 1 + 4 * 8 + 32 + 32) + 16 * 16;
+        TC_HIP(e, hipHostMalloc((void**)&e->small_io, bytes, hipHostMallocDefault));
+        void* dv = nullptr;
+        TC_HIP(e, hipHostGetDevicePointer(&dv, e->small_io, 0));
+        e->small_io_dev = (uint8_t*)dv;
+        e->small_io_bytes = bytes;
+    }
+    size_t off = 64; // [0, 64): header: word 0 = "a key could not be bound"
+    auto take = [&](size_t bytes) {
+        const size_t at = off;
+        off = (off + bytes + 15) & ~(size_t)15;
+        return at;
+    };
+    uint8_t* h = e->small_io;
+    uint8_t* d = e->small_io_dev;
+    std::memset(h, 0, 64);
+    Params p;
+    std::memset(&p, 0, sizeof p);
+    p.n = (uint32_t)n;
+    const uint8_t* d_key_bytes = nullptr;
+    const uint32_t* d_key_off = nullptr;
+    if (e->key_mode) {
+        const size_t total = b.key_off[n];
+        const size_t o_off = take((n + 1) * 4), o_bytes = take(total + 16);
+        std::memcpy(h + o_off, b.key_off, (n + 1) * 4);
+        if (total) std::memcpy(h + o_bytes, b.key_bytes, total);
+        d_key_off = (const uint32_t*)(d + o_off);
+        d_key_bytes = d + o_bytes;
+    } else {
+        const size_t o = take(n * 4);
+        std::memcpy(h + o, b.slot, n * 4);
+        p.slot = (const uint32_t*)(d + o);
+    }
+    const int64_t* hin[5] = {b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns};
+    const int64_t** din[5] = {&p.burst, &p.count, &p.period, &p.q, &p.now};
+    for (int j = 0; j < 5; ++j) {
+        if (!hin[j]) continue;
+        const size_t o = take(n * 8);
+        std::memcpy(h + o, hin[j], n * 8);
+        *din[j] = (const int64_t*)(d + o);
+    }
+    p.burst_s = b.max_burst_scalar;
+    p.count_s = b.count_per_period_scalar;
+    p.period_s = b.period_scalar;
+    p.q_s = b.quantity_scalar;
+    p.now_s = b.now_ns_scalar;
+    struct Out {
+        void* host;
+        size_t at, bytes;
+    } outs[9];
+    int n_out = 0;
+    auto out_col = [&](void* host, size_t bytes) -> uint8_t* {
+        if (!host) return nullptr;
+        const size_t o = take(bytes);
+        outs[n_out++] = Out{host, o, bytes};
+        return d + o;
+    };
+    p.allowed = out_col(b.allowed, n);
+    p.status = out_col(b.status, n);
+    p.limit = (int64_t*)out_col(b.limit, n * 8);
+    p.remaining = (int64_t*)out_col(b.remaining, n * 8);
+    p.reset = (int64_t*)out_col(b.reset_after_ns, n * 8);
+    p.retry = (int64_t*)out_col(b.retry_after_ns, n * 8);
+    p.result4 = (int64_t*)out_col(b.result4, n * 32);
+    p.decisions = (tc_decision*)out_col(b.decisions, n * sizeof(tc_decision));
+    if (off > e->small_io_bytes) return fail(e, TC_E_INVALID_ARG, "small batch does not fit its staging block");
+    p.cells = e->cells;
+    p.tat8 = e->tat8;
+    if (e->fixed) p.flags |= F_FIXED;
+    p.rate_id = e->rate_id;
+    p.classes = e->classes;
+    p.uniform_class = e->uniform_id;
+    p.denied = e->denied;
+    p.capacity = e->capacity;
+    p.counters = e->counters;
+    if (b.flags & TC_B_REGISTERED_PARAMS) {
+        p.flags |= F_REGISTERED;
+        if (e->uniform_id) p.flags |= F_UNIFORM_CLASS;
+    }
+    hipStream_t s = cur_stream(e);
+    if (e->key_mode && e->k_busy) { // key stages on the key stream come first
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        e->k_busy = false;
+    }
+    prof_begin(e, TC_STAGE_EVAL, s);
+    hipLaunchKernelGGL(k_small_batch, dim3(1), dim3(SMALL_MAX), 0, s, p, e->kt, e->key_mode ? 1 : 0, d_key_bytes, d_key_off,
+                       (uint32_t*)d, e->counters + TC_CNT_KEYS_INSERTED);
+    prof_end(e, s);
+    TC_HIP(e, hipGetLastError());
+    if (e->key_mode) { // the key table may have changed: later key stages on the key stream wait for this
+        TC_HIP(e, hipEventRecord(e->m_done, s));
+        e->m_busy = true;
+    }
+    TC_HIP(e, hipStreamSynchronize(s));
+    e->batches++;
+    for (int j = 0; j < n_out; ++j) std::memcpy(outs[j].host, h + outs[j].at, outs[j].bytes);
+    uint32_t full[2] = {0, 0}; // [0]: in this batch; [1]: in an asynchronous batch before it
+    std::memcpy(full, h, sizeof full);
+    if (full[0]) TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof(uint32_t), s));
+    if (full[0] || full[1])
+        return fail(e, TC_E_TABLE_FULL, full[0] ? "key table full: some keys got status Internal (raise capacity or sweep)"
+                                                : "key table full in an earlier TC_B_ASYNC batch: some of its keys got status Internal");
+    return TC_E_OK;
+}
+
+extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
+    // (callers built against the struct without the segment fields pass its old size: those fields read as zero)
+    if (!e || !bp || bp->struct_size < offsetof(tc_batch, n_segments)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    tc_batch b;
+    memset(&b, 0, sizeof b);
+    memcpy(&b, bp, std::min<size_t>(bp->struct_size, sizeof b));
+    if (b.n == 0) return TC_E_OK;
+    if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
+    const bool segmented = b.n_segments != 0;
+    if (segmented) {
+        if (!(b.flags & TC_B_DEVICE_PTRS) || (b.flags & (TC_B_UNIQUE_SLOTS | TC_B_ASYNC)))
+            return fail(e, TC_E_INVALID_ARG, "a segmented slot column needs TC_B_DEVICE_PTRS (and is neither TC_B_UNIQUE_SLOTS nor TC_B_ASYNC)");
+        if (b.n_segments > TC_MAX_SEGMENTS || !b.seg_slot || !b.seg_n) return fail(e, TC_E_INVALID_ARG, "segments: 1..64 pieces, both arrays given");
+        uint64_t tot = 0;
+        for (uint32_t i = 0; i < b.n_segments; ++i) {
+            if (b.seg_n[i] && !b.seg_slot[i]) return fail(e, TC_E_INVALID_ARG, "segments: NULL piece");
+            tot += b.seg_n[i];
+        }
+        if (tot != b.n) return fail(e, TC_E_INVALID_ARG, "segments: the pieces do not add up to n");
+    } else if (!b.slot) return fail(e, TC_E_INVALID_ARG, "slot column is NULL");
+    if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
+    if (e->key_mode) return fail(e, TC_E_INVALID_ARG, "key-mode engine: slots are assigned by the key table; use tc_rate_limit_batch_keys");
+    if (e->fixed) {
+        if (!(b.flags & TC_B_REGISTERED_PARAMS))
+            return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: batches use the registered plans (TC_B_REGISTERED_PARAMS)");
+    }
+    TC_HIP(e, hipSetDevice(e->device));
+    int rc;
+    if (b.flags & TC_B_DEVICE_PTRS) {
+        if (b.flags & TC_B_ASYNC) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
+        rc = run_slots_device(e, b);
+    } else if (b.flags & TC_B_ASYNC) {
+        rc = run_slots_host_async(e, b);
+    } else if (small_batch_applies(e, b)) {
+        rc = run_small_batch(e, b);
+    } else {
+        // host pointers: stage in, run, stage out, synchronise
+        TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
+        TC_HIP(e, copy_async(e, e->stage.slot, b.slot, b.n * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+        rc = run_slots_host_staged(e, b);
+    }
+    // fixed layout: once a request has been decided the plans can no longer change (a batch that was rejected, or
+    // whose staging failed, applied nothing and seals nothing)
+    if (e->fixed && rc == TC_E_OK) e->sealed = true;
+    return rc;
+}
+
+extern "C" int tc_wait_batches(tc_engine* e, uint32_t max_in_flight) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    TC_HIP(e, hipSetDevice(e->device));
+    while (e->async_done.size() > max_in_flight) {
+        hipEvent_t ev = e->async_done.front();
+        TC_HIP(e, hipEventSynchronize(ev));
+        e->async_done.pop_front();
+        e->async_pool.push_back(ev);
+    }
+    return poisoned(e);
+}
+
+extern "C" void* tc_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+extern "C" void tc_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
