@@ -115,7 +115,11 @@ static __global__ __launch_bounds__(THREADS) void k_route_count(const uint32_t* 
         if (valid && (mm & lt) == 0ull) atomicAdd(&s_c[owner], (uint32_t)__popcll(mm));
     }
     __syncthreads();
-    if (threadIdx.x < m.world) w.tile_cnt[(size_t)threadIdx.x * w.tiles + blockIdx.x] = s_c[threadIdx.x];
+    // (tile counts, their prefixes and the totals travel between three small kernels whose blocks sit on different XCDs:
+    // written and read at agent scope -- past the XCDs' private L2s -- so that they never depend on what a kernel
+    // boundary does to a few dirty words)
+    if (threadIdx.x < m.world)
+        __hip_atomic_store(&w.tile_cnt[(size_t)threadIdx.x * w.tiles + blockIdx.x], s_c[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // one block per destination: exclusive prefix of its counts over the tiles (each thread a contiguous piece), total
@@ -125,7 +129,7 @@ static __global__ __launch_bounds__(THREADS) void k_route_scan(Work w) {
     const uint32_t per = (w.tiles + THREADS - 1) / THREADS;
     const uint32_t lo = min(threadIdx.x * per, w.tiles), hi = min(lo + per, w.tiles);
     uint32_t sum = 0;
-    for (uint32_t t = lo; t < hi; ++t) sum += row[t];
+    for (uint32_t t = lo; t < hi; ++t) sum += __hip_atomic_load(&row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_part[threadIdx.x] = sum;
     __syncthreads();
     // exclusive prefix of the pieces (Hillis-Steele over 256 values in LDS)
@@ -137,11 +141,11 @@ static __global__ __launch_bounds__(THREADS) void k_route_scan(Work w) {
     }
     uint32_t run = s_part[threadIdx.x] - sum;
     for (uint32_t t = lo; t < hi; ++t) {
-        const uint32_t c = row[t];
-        row[t] = run;
+        const uint32_t c = __hip_atomic_load(&row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&row[t], run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         run += c;
     }
-    if (threadIdx.x == THREADS - 1) w.totals[blockIdx.x] = s_part[THREADS - 1];
+    if (threadIdx.x == THREADS - 1) __hip_atomic_store(&w.totals[blockIdx.x], s_part[THREADS - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // SPLIT (only < 0): segment d goes to dst.ptr[d], from its start -- the destination's inbox in ITS memory (peer memory
@@ -154,13 +158,15 @@ __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __res
                                                             uint32_t* __restrict__ out_slot, uint32_t* __restrict__ out_pos, SplitOut dst) {
     __shared__ uint32_t s_wave[THREADS / 64][MAX_WORLD]; // per-wave counts -> exclusive prefix over the waves
     __shared__ uint32_t s_start[MAX_WORLD];              // where each destination's segment starts in the output
+    __shared__ uint32_t s_tile[MAX_WORLD];               // ... and this tile's requests inside it (k_route_scan's prefix)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < (THREADS / 64) * MAX_WORLD; i += THREADS) (&s_wave[0][0])[i] = 0;
     if (threadIdx.x < m.world) {
         uint32_t at = 0;
         if (only < 0 && !SPLIT)
-            for (uint32_t k = 0; k < threadIdx.x; ++k) at += w.totals[k];
+            for (uint32_t k = 0; k < threadIdx.x; ++k) at += __hip_atomic_load(&w.totals[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         s_start[threadIdx.x] = at;
+        s_tile[threadIdx.x] = __hip_atomic_load(&w.tile_cnt[(size_t)threadIdx.x * w.tiles + blockIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     // wave-striped: step j of wave k covers requests tile*TILE + k*1024 + j*64 + lane (request order inside a wave)
@@ -199,7 +205,7 @@ __global__ __launch_bounds__(THREADS) void k_route_scatter(const uint32_t* __res
     for (int j = 0; j < ITEMS; ++j) {
         const uint32_t pos = first + j * 64, d = dest[j];
         if (pos < n && (only < 0 || d == (uint32_t)only)) {
-            const uint32_t at = s_start[d] + w.tile_cnt[(size_t)d * w.tiles + blockIdx.x] + s_wave[wave][d] + rank[j];
+            const uint32_t at = s_start[d] + s_tile[d] + s_wave[wave][d] + rank[j];
             if (SPLIT) {
                 dst.ptr[d][at] = slot[j];
             } else {
@@ -264,7 +270,7 @@ __global__ __launch_bounds__(THREADS) void k_route_one(const uint32_t* __restric
     }
     if (lane == 0) s_wcnt[wave] = mine;
     __syncthreads();
-    if (threadIdx.x < m.world) w.tile_cnt[(size_t)threadIdx.x * w.tiles + tile] = s_c[threadIdx.x];
+    if (threadIdx.x < m.world) __hip_atomic_store(&w.tile_cnt[(size_t)threadIdx.x * w.tiles + tile], s_c[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     uint32_t before = 0, total = 0;
     for (int k = 0; k < THREADS / 64; ++k) {
         if (k < wave) before += s_wcnt[k];
@@ -316,7 +322,7 @@ __global__ __launch_bounds__(THREADS) void k_route_one(const uint32_t* __restric
 // after them, the caller's tag.  (A ticket taken by every tile of the scatter kernel -- "the last one publishes" --
 // cost 100 ns per tile: 2048 device-scope atomics on one word are 0.2 ms.)
 static __global__ __launch_bounds__(MAX_WORLD) void k_route_publish(Work w, uint32_t world) {
-    if (threadIdx.x < world) w.host_totals[threadIdx.x] = w.totals[threadIdx.x];
+    if (threadIdx.x < world) w.host_totals[threadIdx.x] = __hip_atomic_load(&w.totals[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {

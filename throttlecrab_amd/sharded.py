@@ -120,9 +120,15 @@ class LocalFabric:
         self._inbox = [torch.empty((ring, world, seg_cap), dtype=torch.int32, device=device) for _ in range(world)]
         self.mail = np.zeros((world, ring, world, 2), np.uint32)  # [dst][ring slot][src] = (count, step + 1)
         self.done = np.zeros(world, np.int64)                      # [dst] steps whose inboxes may be overwritten
+        self.ranks = []                                            # the ExchangeRanks driven by this one thread
 
     def inbox(self, dst: int, slot: int, src: int):
         return self._inbox[dst][slot, src]
+
+    def poll(self):
+        """one thread drives every shard: a rank that waits for another rank's progress has to note it itself"""
+        for r in self.ranks:
+            r._publish_done()
 
     def close(self):
         pass
@@ -192,13 +198,15 @@ class ExchangeRank:
             c[:] = 0
         self.eval_events = {}
         self._event_pool = []
+        if hasattr(fabric, "ranks"):
+            fabric.ranks.append(self)
         self.host_s = {"route": 0.0, "post": 0.0, "collect": 0.0, "evaluate": 0.0}  # host seconds per phase (diagnostics)
 
     def route(self, step: int, global_slice):
         r, k = step % self.route_ring, step % self.fab.ring
         # flow control: a destination's inbox slot is free once it has evaluated step - ring
         while any(int(self.fab.done[d]) < step - self.fab.ring + 1 for d in range(self.world)):
-            self._publish_done()
+            self.fab.poll() if hasattr(self.fab, "poll") else self._publish_done()
         if global_slice.numel() > self.fab.seg_cap:
             raise RuntimeError(f"a slice of {global_slice.numel()} requests exceeds the inbox capacity {self.fab.seg_cap}")
         # (the router's output goes to the inboxes, never to a batch's slot column: it need not wait for any batch in flight)
@@ -250,8 +258,7 @@ class ExchangeRank:
         ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
         ev.record(torch.cuda.current_stream(self.eng.device))
         self.eval_events[step] = ev
-        if step % 2 == 0:
-            self._publish_done()
+        self._publish_done()
         return total
 
     def timed(self, name, *args, **kw):

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; O=$R/gpurun_out/$TAG; mkdir -p $O
 export TC_GIT_SHA=$(cat $R/.git_sha 2>/dev/null || echo unknown)
 for S in $STEPS; do
   case $S in
-    tests) timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "tests rc=$?"; tail -5 $O/pytest_gpu.log ;;
+    tests) timeout 400 python -m pytest tests -m gpu -x -q --timeout 120 > $O/pytest_gpu.log 2>&1; echo "tests rc=$?"; tail -5 $O/pytest_gpu.log ;;
     quick) timeout 600 python -m pytest tests/test_gpu_prefill.py tests/test_gpu_fixed.py tests/test_gpu_slots.py -m gpu -x -q > $O/pytest_quick.log 2>&1; echo "quick rc=$?"; tail -15 $O/pytest_quick.log ;;
     general) timeout 600 python -m pytest tests/test_gpu_slots.py tests/test_gpu_fixed.py tests/test_gpu_fuzz.py tests/test_gpu_robustness.py -m gpu -x -q > $O/pytest_general.log 2>&1; echo "general tests rc=$?"; tail -4 $O/pytest_general.log
              for WL in general general_zipf; do timeout 300 python bench.py --workload $WL --no-also --no-cpu --steps 40 --warmup 10 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['config']['stream'], round(d['ms_per_step']*1e3,1), 'us/step', round(d['value']/1e9,2), 'G/s', 'kernel', d.get('roofline',{}).get('avg_ms'))"; done ;;
@@ -35,6 +35,7 @@ for S in $STEPS; do
           timeout 200 rocprofv3 --kernel-trace --stats -d $O/k_stats -o s -- python $R/tools/profile_keys.py short 16 > $O/k_stats.log 2>&1; echo "rc=$?"
           cd $R; python tools/trace_seq.py $O/k_stats -420 420 > $O/keys_trace_seq.txt 2>&1; python tools/summarize_prof.py ${TAG}_string_keys_trace $O/k_stats > /dev/null 2>&1; mkdir -p $O/profiles; cp profiles/${TAG}_string_keys_trace* $O/profiles/; rm -rf $O/k_stats ;;
     keytests) timeout 600 python -m pytest tests/test_gpu_keys.py tests/test_gpu_keys_spec.py tests/test_gpu_metrics.py tests/test_gpu_snapshot.py -m gpu -x -q > $O/pytest_keys.log 2>&1; echo "key tests rc=$?"; tail -4 $O/pytest_keys.log ;;
+    routeflaky) for i in $(seq 1 40); do timeout 120 python -m pytest tests/test_gpu_route.py -m gpu -x -q --timeout 60 > $O/rf_$i.log 2>&1; if grep -q failed $O/rf_$i.log; then echo "run $i FAILED"; grep -E "^E  |FAILED|assert" $O/rf_$i.log | head -12; else rm $O/rf_$i.log; fi; done; echo loop done ;;
     ab) timeout 600 python tools/ab_step.py 100 > $O/ab_step.txt 2>&1; echo "ab rc=$?"; cat $O/ab_step.txt ;;
     bench) TC_BENCH_VERBOSE=1 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_stdout.txt 2> $O/bench_stderr.txt; echo "bench rc=$?"
            tail -c 4200 $O/bench_stdout.txt; echo; wc -c $O/bench_stdout.txt; cp gpurun_out/bench_detail.json $O/ 2>/dev/null ;;
