@@ -66,7 +66,11 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
         // different streams never wait for one another
         const size_t each = (words * 2 + 1) & ~(size_t)1;
         TC_HIP(e, hipMalloc(&e->route_ws, each * (1 + AUX_MAX) * sizeof(uint32_t)));
+        // (hipMemset on device memory returns before the fill has run, and the fill runs on the NULL stream, which the
+        // engine's non-blocking streams are not ordered behind: without the wait the fill could land on top of the
+        // first router's tile counts -- seen as a 1-in-50 wrong partition on a fresh engine)
         TC_HIP(e, hipMemset(e->route_ws, 0, each * (1 + AUX_MAX) * sizeof(uint32_t)));
+        TC_HIP(e, hipDeviceSynchronize());
         e->route_ws_words = each;
     }
     rt::Work w;
