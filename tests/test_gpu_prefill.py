@@ -117,3 +117,50 @@ def test_out_of_range_slots_and_unregistered_plans_keep_their_zero():
         got = out.allowed.cpu().numpy()
         assert (got[bad] == 0).all() and (got[~bad] == 1).all(), b
     eng.close()
+
+
+@pytest.mark.parametrize("sync_each", [False, True], ids=["host_ahead", "hint_follows"])
+@pytest.mark.parametrize("fixed", [False, True], ids=["wide", "fixed"])
+def test_general_batches_with_preset_decision_bytes(fixed, sync_each):
+    """per-request timestamps (k_eval_general) with TC_B_OUTPUTS_IDLE: hot keys that run dry (the majority flips),
+    out-of-range slots (status != OK keeps its 0 under a fill value of 1), ragged sizes, an unaligned output array"""
+    import torch
+
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    n_keys, plan = 2000, (20, 100, 60)
+    eng = t.Engine(n_keys, 1 << 16, fixed_params=fixed)
+    eng.check_on_close = True
+    eng.use_torch_stream()
+    eng.register_params_uniform(*plan)
+    orc = O.DenseOracle(n_keys)
+    rng = np.random.default_rng(11)
+    sizes = [30000, 65536, 1, 17, 40001, 30000, 30000, 65535, 30000, 30000]
+    ring = [torch.full((70000,), 7, dtype=torch.uint8, device="cuda") for _ in sizes]
+    pending, t_ns = [], T0
+    for b, n in enumerate(sizes):
+        slots = np.where(rng.random(n) < 0.7, rng.integers(0, 40, n), rng.integers(0, n_keys, n)).astype(np.uint32)
+        bad = rng.random(n) < 0.02
+        slots[bad] = n_keys + 5
+        now = t_ns + np.sort(rng.integers(0, 2_000_000, n)).astype(np.int64)
+        t_ns += 2_000_000 if b != 5 else 120 * 10**9   # (a long pause: the keys refill, the majority flips back)
+        ref = orc.batch_slots(slots, *plan, 1, now)
+        out = t.BatchResult(allowed=ring[b][3:3 + n])
+        keep = (torch.from_numpy(slots.astype(np.int32)).cuda(), torch.from_numpy(now).cuda())
+        eng.rate_limit_batch_slots(keep[0], registered=True, quantity=1, now_ns=keep[1], want=("allowed",), out=out, inputs_ready=True,
+                                   outputs_idle=True)
+        pending.append((b, n, keep, ref, bad))
+        if sync_each:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    seen = set()
+    for b, n, _, ref, bad in pending:
+        got = ring[b].cpu().numpy()
+        want = ref.allowed.astype(np.uint8)
+        assert (want[bad] == 0).all()
+        diff = np.nonzero(got[3:3 + n] != want)[0]
+        assert diff.size == 0, f"batch {b} (n={n}): decisions differ at {diff[:8]}"
+        assert (got[:3] == 7).all() and (got[3 + n:] == 7).all(), f"batch {b}: bytes outside the batch were written"
+        seen.add(bool(want.mean() > 0.5))
+    assert seen == {True, False}, "the stream must have batches of either majority"
+    eng.close()

@@ -785,9 +785,21 @@ struct __attribute__((aligned(32))) ChainRec {
     uint32_t pad;
 };
 
+// (general batches, decisions only, TC_B_OUTPUTS_IDLE: the bytes were preset on the grouping stream like the lean
+// kernel's -- the host sets F_PREFILLx only when `allowed` in request order is the one output of the batch)
+template <bool FULL>
+__device__ __forceinline__ void write_out_general(const Params& p, uint32_t i, const Req& r, const Decision& d) {
+    if (!FULL && (p.flags & (F_PREFILL0 | F_PREFILL1)) != 0u) {
+        const bool a = r.status == tc::ST_OK && d.allowed;
+        if (!(p.flags & (a ? F_PREFILL1 : F_PREFILL0))) p.allowed[i] = a ? 1 : 0;
+        return;
+    }
+    write_out(p, i, r, d);
+}
+
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t* __restrict__ sorted,
-                                                        ChainRec* __restrict__ chain, uint32_t seq) {
+                                                        ChainRec* __restrict__ chain, uint32_t seq, uint32_t* hint) {
     const uint32_t n = p.n;
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -941,7 +953,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         Decision z;
         z.allowed = false;
         z.remaining = z.reset_after = z.retry_after = 0;
-        write_out(p, orow, r, z);
+        write_out_general<FULL>(p, orow, r, z);
         ne = 1;
         fin = true;
     }
@@ -964,7 +976,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
                 d.allowed = allow;
                 d.remaining = d.reset_after = d.retry_after = 0;
             }
-            write_out(p, orow, r, d);
+            write_out_general<FULL>(p, orow, r, d);
             if (lane == first) {
                 na = 1;
                 was_allowed = true;
@@ -1003,7 +1015,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         }
     }
     wave_denied_add(p, slot, nd != 0);
-    block_count3(na, nd, ne, p.counters);
+    block_count3(na, nd, ne, p.counters, blockIdx.x == gridDim.x / 2 ? hint : nullptr);
 }
 
 static __global__ __launch_bounds__(BLOCK) void k_commit_list(const PendEntry* __restrict__ pend,

@@ -419,8 +419,9 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // others -- 1 Mi one-byte stores scattered over the batch were 6 of its 53 us
             uint8_t* fill = nullptr;
             uint32_t fill_value = 0;
-            if ((b.flags & TC_B_OUTPUTS_IDLE) && e->prefill_on && !hin && !bucketed && uniform && lean_applies(e, full, direct, true, p) &&
-                p.allowed == b.allowed) {
+            const bool only_allowed = !full && p.allowed && !p.status && !p.limit && !p.order && !p.row_bits && p.allowed == b.allowed;
+            if ((b.flags & TC_B_OUTPUTS_IDLE) && e->prefill_on && !hin && !bucketed && only_allowed &&
+                (uniform ? lean_applies(e, full, direct, true, p) : true)) {
                 fill = b.allowed;
                 fill_value = *(volatile uint32_t*)e->fill_hint_host & 1u;
                 p.flags |= fill_value ? F_PREFILL1 : F_PREFILL0;
@@ -458,8 +459,11 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             }
         } else {
             if (++e->chain_seq >= 0x7FFFFFFFu) e->chain_seq = 1u; // 0 = "never written"; 31 bits: the spec word carries a flag
-            if (full) hipLaunchKernelGGL(k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
-            else hipLaunchKernelGGL(k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq);
+            // (the evaluation is the last reader of the set: `consumed` rides on its completion signal)
+            consumed_rides = e->stop_events && !e->prof_on;
+            hipEvent_t stop = consumed_rides ? ss.consumed : nullptr;
+            if (full) TC_LAUNCH(stop, k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
+            else TC_LAUNCH(stop, k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
             prof_end(e, s);
         }
         e->wait_before_sort = nullptr;
