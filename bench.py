@@ -840,40 +840,68 @@ def main():
         result["roofline"] = main_res["roofline"]
 
     if rank == 0:
+        # Every secondary leg is optional: whatever goes wrong in one of them (a HIP error, a full table, no memory) is
+        # recorded under "errors" and the headline line is still printed -- the driver's record depends on that line.
+        errors = {}
+
+        def leg(name, fn):
+            log(name)
+            try:
+                fn()
+            except Exception as ex:  # noqa: BLE001
+                errors[name] = f"{type(ex).__name__}: {ex}"[:200]
+                print(f"[bench] secondary leg '{name}' failed: {errors[name]}", file=sys.stderr, flush=True)
+
         if not a.no_also and not a.profile_run:
-            # the other BASELINE stream (configs[1] <-> configs[2]), measured the same way
             other = "zipf" if stream == "uniform" else "uniform"
-            log(f"other stream: {other}")
-            o_res, eng2, ob, _ = measure_stream(a, t, W, other, dev, local, 0, 0, None, 1)
-            detail[f"{other}_stream"] = o_res.pop("detail", None)
-            result[f"{other}_stream"] = o_res
-            # the headline stream on the other resident-state layout
-            a2 = argparse.Namespace(**vars(a))
-            a2.layout = "fixed" if a.layout == "wide" else "wide"
-            log(f"other layout: {a2.layout}")
-            l_res, eng_l, _, _ = measure_stream(a2, t, W, stream, dev, local, 0, 0, None, 1, general=general)
-            eng_l.close()
-            detail[f"{a2.layout}_layout"] = l_res.pop("detail", None)
-            result[f"{a2.layout}_layout"] = l_res
-            # what a server's queue looks like: a timestamp per request (k_eval_general), both slot streams
+            held = {}
+
+            def other_stream():  # the other BASELINE stream (configs[1] <-> configs[2]), measured the same way
+                o_res, held["eng2"], held["ob"], _ = measure_stream(a, t, W, other, dev, local, 0, 0, None, 1)
+                detail[f"{other}_stream"] = o_res.pop("detail", None)
+                result[f"{other}_stream"] = o_res
+
+            def other_layout():  # the headline stream on the other resident-state layout
+                a2 = argparse.Namespace(**vars(a))
+                a2.layout = "fixed" if a.layout == "wide" else "wide"
+                l_res, eng_l, _, _ = measure_stream(a2, t, W, stream, dev, local, 0, 0, None, 1, general=general)
+                eng_l.close()
+                detail[f"{a2.layout}_layout"] = l_res.pop("detail", None)
+                result[f"{a2.layout}_layout"] = l_res
+
+            def general_of(gs):  # what a server's queue looks like: a timestamp per request (k_eval_general)
+                def run():
+                    g_res, eng_g, _, _ = measure_stream(a, t, W, gs, dev, local, 0, 0, None, 1, general=True)
+                    eng_g.close()
+                    detail[f"general_{gs}"] = g_res.pop("detail", None)
+                    result[f"general_{gs}"] = g_res
+                return run
+
+            def output_forms():
+                if "eng2" in held:
+                    detail["also"] = secondary(a, t, W, held["eng2"], held["ob"], d_batches, dev, local, other)
+
+            def string_keys():
+                sk = keys_bench(a, dev)
+                detail["string_keys"] = {k: (v.pop("detail", None) if isinstance(v, dict) else v) for k, v in sk.items()}
+                result["string_keys"] = {k: v for k, v in sk.items() if isinstance(v, dict)}
+
+            leg(f"other stream: {other}", other_stream)
+            leg("other layout", other_layout)
             for gs in ("uniform", "zipf"):
-                if general and gs == stream:
-                    continue
-                log(f"general batches: {gs}")
-                g_res, eng_g, _, _ = measure_stream(a, t, W, gs, dev, local, 0, 0, None, 1, general=True)
-                eng_g.close()
-                detail[f"general_{gs}"] = g_res.pop("detail", None)
-                result[f"general_{gs}"] = g_res
-            log("secondary output forms")
-            detail["also"] = secondary(a, t, W, eng2, ob, d_batches, dev, local, other)
-            eng2.close()
-            log("string keys")
-            sk = keys_bench(a, dev)
-            detail["string_keys"] = {k: (v.pop("detail", None) if isinstance(v, dict) else v) for k, v in sk.items()}
-            result["string_keys"] = {k: v for k, v in sk.items() if isinstance(v, dict)}
+                if not (general and gs == stream):
+                    leg(f"general batches: {gs}", general_of(gs))
+            leg("secondary output forms", output_forms)
+            if "eng2" in held:
+                leg("close second engine", held["eng2"].close)
+            leg("string keys", string_keys)
         if not a.no_cpu and not a.profile_run:
-            log("cpu baseline")
-            result["cpu_baseline"] = cpu_baseline(stream, a.keys, a.batch, a.cpu_sample_batches)
+            def cpu():
+                result["cpu_baseline"] = cpu_baseline(stream, a.keys, a.batch, a.cpu_sample_batches)
+            leg("cpu baseline", cpu)
+        if errors:
+            detail["errors"] = errors
+            result["errors"] = sorted(errors)
         emit(result, detail)
     eng.close()
 
@@ -915,7 +943,7 @@ def compact_line(result):
     baseline, and one number (+ its whole-step roofline fraction) per secondary workload.  Everything else lives in
     bench_detail.json.  Never longer than COMPACT_LIMIT bytes."""
     top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-           "dtype", "data", "config", "allowed_fraction", "imbalance_max_over_mean", "router_ms_per_step", "route")
+           "dtype", "data", "config", "allowed_fraction", "imbalance_max_over_mean", "router_ms_per_step", "route", "errors")
     c = _pick(result, top)
     rf = result.get("roofline")
     if rf:

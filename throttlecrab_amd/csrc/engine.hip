@@ -278,14 +278,20 @@ int ensure_side_streams(tc_engine* e) {
         e->key_stream = nullptr;
     }
     const uint32_t want = e->n_aux_want + (e->key_mode ? 1u : 0u);
+    const char* as = getenv("TCGPU_ASSUME_CONCURRENT");
+    const bool assume = as && atoi(as) != 0;
     std::vector<hipStream_t> good, bad;
     for (int c = 0; c < 16 && good.size() < want; ++c) {
         hipStream_t s = nullptr;
         int rc = TC_E_OK;
         if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, e->aux_priority) != hipSuccess) rc = fail(e, TC_E_HIP, "hipStreamCreateWithPriority failed");
         bool ok = false;
-        if (rc == TC_E_OK) rc = streams_concurrent(e, m, s, &ok);
-        for (size_t g = 0; rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
+        // TCGPU_ASSUME_CONCURRENT=1 (counter passes of a profiler that serialises every dispatch: the probe then finds
+        // no concurrent stream and the batches would run in order, on other kernel variants than the timed run's):
+        // take the candidates unprobed.  Ordering is by events either way; only the overlap is lost.
+        if (assume) ok = true;
+        else if (rc == TC_E_OK) rc = streams_concurrent(e, m, s, &ok);
+        for (size_t g = 0; !assume && rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
         if (rc != TC_E_OK) {
             if (s) (void)hipStreamDestroy(s);
             for (hipStream_t x : good) (void)hipStreamDestroy(x);

@@ -13,16 +13,18 @@ export TMPDIR=/tmp
 for C in $CONFIGS; do
   PMCENV=""
   case $C in
-    # PMC passes serialise the streams (the engine then finds no concurrent grouping stream and runs its batches in
-    # order); TCGPU_BUCKET=0 keeps those in-order batches on the SORT path, i.e. on the kernels of the timed,
-    # pipelined configuration.  The *_bucket configs profile the in-order bucket path instead.
-    uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed"; PMCENV="TCGPU_BUCKET=0" ;;
+    # PMC passes serialise the dispatches: the engine's probe then finds no concurrent grouping stream and would run
+    # its batches in order, on other kernel variants (4 items per lane, no preset decision bytes, bucket path) than
+    # the timed, pipelined run.  TCGPU_ASSUME_CONCURRENT=1 skips the probe, so the counter passes see exactly the
+    # kernels of the timed configuration (ordering is by events either way).  The *_bucket configs profile the
+    # in-order bucket path instead.
+    uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     uniform_fixed_bucket) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --in-order" ;;
-    uniform_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide"; PMCENV="TCGPU_BUCKET=0" ;;
-    zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf"; PMCENV="TCGPU_BUCKET=0" ;;
-    zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf"; PMCENV="TCGPU_BUCKET=0" ;;
-    general_uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general" ;;
-    general_zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general_zipf" ;;
+    uniform_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    general_uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    general_zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general_zipf"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     string_keys) CMD="python $R/tools/profile_keys.py short 8" ;;
     string_keys_long) CMD="python $R/tools/profile_keys.py long 8" ;;
     *) echo "unknown config $C"; continue ;;
