@@ -278,11 +278,13 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
         # batches runs beside it on the auxiliary streams): its average launch duration as timed in the pipelined
         # configuration is the roofline's avg_ms.
         ev = piped.get("eval") or piped.get("bucket_eval")
-        kname = "ev::k_eval_general" if general else ev["kernel"]
         tr, src = pmc_traffic("eval_general" if general else "eval", tag, a.layout, 1.0)
-        source = {"avg_ms": "HIP events around the kernel on the engine's stream, pipelined run of this process",
-                  "traffic": (src or {}).get("file")}
-        res["roofline"] = roofline_entry(kname, ev["avg_ms"], alg, ms, tr, source)
+        if ev:  # (no record: the launch went untimed -- the line then carries no roofline rather than a made-up one)
+            kname = "ev::k_eval_general" if general else ev["kernel"]
+            source = {"avg_ms": "start/stop HIP events on the kernel's own dispatch packet (hipExtLaunchKernelGGL), engine's "
+                                "stream, pipelined run of this process",
+                      "traffic": (src or {}).get("file")}
+            res["roofline"] = roofline_entry(kname, ev["avg_ms"], alg, ms, tr, source)
         gated = ("prep", "sort", "eval") if "bucket_eval" in inorder else ()
         res["detail"] = {"stages": {"pipelined": stage_table(piped, alg, tag, a.layout),
                                     "in_order": stage_table(inorder, alg, tag, a.layout, gated=gated)},

@@ -27,6 +27,24 @@ void prof_end(tc_engine* e, hipStream_t s) {
     e->prof_used++;
 }
 
+// one record whose two events ride on a kernel's own dispatch packet (TC_LAUNCH_T); false: no record could be made
+// (the launch then goes untimed).  TCGPU_PROF_MARKERS=1: the old way, marker events before and after the kernel.
+bool prof_pair(tc_engine* e, int stage, hipEvent_t* start, hipEvent_t* stop) {
+    if (!e->prof_on || e->prof_markers) return false;
+    if (e->prof_used == e->prof_stage.size()) {
+        hipEvent_t a, b;
+        if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return false;
+        e->prof_ev.push_back(a);
+        e->prof_ev.push_back(b);
+        e->prof_stage.push_back(-1);
+    }
+    e->prof_stage[e->prof_used] = stage;
+    *start = e->prof_ev[2 * e->prof_used];
+    *stop = e->prof_ev[2 * e->prof_used + 1];
+    e->prof_used++;
+    return true;
+}
+
 // every host <-> device copy of a batch goes through here, so that tests can make one of them fail
 hipError_t copy_async(tc_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
     if (e->fault_countdown && --e->fault_countdown == 0) return hipErrorInvalidValue;
@@ -99,6 +117,7 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_EVAL_ITEMS")) e->eval_items = atoi(d);
     if (const char* d = getenv("TCGPU_EVAL_LEAN")) e->eval_lean = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_STOP_EVENTS")) e->stop_events = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_PROF_MARKERS")) e->prof_markers = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_DEBUG_NO_DECISION_STORE")) e->debug_nostore = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
     {

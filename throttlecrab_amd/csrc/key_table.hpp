@@ -15,11 +15,12 @@
 //                   key  = the key itself, zero padded, when it is at most 16 bytes long
 //                   A key of up to 16 bytes ("user:123", "key_1234567") is therefore found and CONFIRMED
 //                   with one 32-byte access; longer keys are confirmed against their slot's KeyRec.
-//   rec[cap]        one 64-byte KeyRec per slot: full hash, key length, position of the slot's ktab entry
-//                   (for unbinding) and the key bytes inline (<= 48 B; a longer key keeps an 8-byte offset
-//                   into the overflow arena)
+//   rec[cap]        one 128-byte KeyRec per slot (ONE memory line): full hash, key length, position of the slot's
+//                   ktab entry (for unbinding) and the key bytes inline (<= 112 B; a longer key keeps an 8-byte
+//                   offset into the overflow arena).  A confirm requests the length word and the key words of
+//                   the line together, so a hit on a 17..112-byte key costs the entry line + this line.
 //   bound[cap]      u8 1 = slot has a key (the compact column the expiry sweep scans:
-//                   walking the 64-byte records would read 4x the bytes)
+//                   walking the 128-byte records would read 128x the bytes)
 //   free_slots[cap] stack of unbound slots, free_top = number of free slots
 //
 // Inserting inside a batch is a three-kernel protocol without spinning (a wave

@@ -94,17 +94,17 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
     ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
     ss.hist_parity ^= 1u;
-    prof_begin(e, TC_STAGE_PREP, s);
-    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value);
-    prof_end(e, s);
+    prof_begin_m(e, TC_STAGE_PREP, s);
+    TC_LAUNCH_T(e, TC_STAGE_PREP, (hipEvent_t) nullptr, rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value);
+    prof_end_m(e, s);
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
     const uint64_t* in = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
-        prof_begin(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
+        prof_begin_m(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
         hipEvent_t stop = (p + 1 == passes && !e->prof_on) ? stop_last : nullptr;
 #define TC_PASS(IT, FI) \
-    TC_LAUNCH(stop, (rs::k_onesweep<IT, FI>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
+    TC_LAUNCH_T(e, TC_STAGE_SORT, stop, (rs::k_onesweep<IT, FI>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
               (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min)
         if (p == 0) {
             if (items == 32) TC_PASS(32, true);
@@ -116,7 +116,7 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
             else TC_PASS(8, false);
         }
 #undef TC_PASS
-        prof_end(e, s);
+        prof_end_m(e, s);
         in = out;
     }
     return in;
@@ -164,14 +164,14 @@ static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, u
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
     if (lean) {
         if constexpr (ITEMS <= 2) {
-            TC_LAUNCH(stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
+            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
             return;
         }
     }
-    if (full && direct) TC_LAUNCH(stop, (k_eval_sorted<true, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else if (full) TC_LAUNCH(stop, (k_eval_sorted<true, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else if (direct) TC_LAUNCH(stop, (k_eval_sorted<false, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
-    else TC_LAUNCH(stop, (k_eval_sorted<false, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    if (full && direct) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted<true, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (full) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted<true, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else if (direct) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted<false, true, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
+    else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted<false, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
 }
 
 static int eval_items_of(const tc_engine* e, bool piped) { return e->eval_items ? e->eval_items : (piped ? 2 : 4); }
@@ -440,7 +440,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
         }
         if (bucketed) bucket_eval(e, ss, s, p, full);
-        prof_begin(e, TC_STAGE_EVAL, s);
+        prof_begin_m(e, TC_STAGE_EVAL, s);
         bool consumed_rides = false;
         if (uniform) {
             uint32_t seq = 0u;
@@ -451,7 +451,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // (direct: the evaluation is the last reader of the set -- `consumed` can ride on its completion signal)
             consumed_rides = direct && e->stop_events && !e->prof_on;
             launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr);
-            prof_end(e, s);
+            prof_end_m(e, s);
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
                 hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells, e->tat8);
@@ -462,9 +462,9 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // (the evaluation is the last reader of the set: `consumed` rides on its completion signal)
             consumed_rides = e->stop_events && !e->prof_on;
             hipEvent_t stop = consumed_rides ? ss.consumed : nullptr;
-            if (full) TC_LAUNCH(stop, k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
-            else TC_LAUNCH(stop, k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
-            prof_end(e, s);
+            if (full) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
+            else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
+            prof_end_m(e, s);
         }
         e->wait_before_sort = nullptr;
         // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream

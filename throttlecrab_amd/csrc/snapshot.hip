@@ -13,7 +13,7 @@ struct SnapHeader {
     uint64_t payload_bytes; // everything after the header
     uint64_t checksum;      // FNV-1a 64 over the payload: a truncated, corrupt or foreign file is refused BEFORE the engine is touched
 };
-constexpr uint32_t SNAP_VERSION = 3; // 3: sharded tombstone count
+constexpr uint32_t SNAP_VERSION = 4; // 3: sharded tombstone count; 4: 128-byte key records, table of retired keys (denial counts)
 // FNV-1a over 8-byte words of the byte stream (a byte-wise FNV over gigabytes of state would take seconds);
 // independent of how the stream is cut into pieces
 struct StreamSum {
