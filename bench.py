@@ -653,7 +653,9 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     counts_host = [eng.host_alloc(world + 1, np.uint32) for _ in range(RING)]   # pinned: counts, then the batch's tag
     for c in counts_host:
         c[:] = 0
-    out = t.BatchResult()
+    # every batch in flight writes its decisions to an array of its own (as the N = 1 run does): TC_B_OUTPUTS_IDLE
+    outs = [t.BatchResult(allowed=torch.empty(cap_batch, dtype=torch.uint8, device=dev)) for _ in range(OUT_RING)]
+    n_calls = 0
     cnt_view = sharded.device_counter_view(eng)
     gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
     top_gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64, device=dev)
@@ -663,20 +665,29 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     # only reads the global batch and writes a ring entry whose last reader is already on the engine's stream), and
     # its last block writes the counts + the batch's tag into pinned host memory: the host learns how many requests
     # it owns by polling that word -- no event, no stream synchronisation on the way.
+    host_s = {"route": 0.0, "poll": 0.0, "evaluate": 0.0}   # where the host's time goes (diagnostics, stderr + detail)
+
     def route(i):
         r = i % RING
+        t_ = time.perf_counter()
         eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r], ahead=True, host_counts=counts_host[r], tag=i + 1)
+        host_s["route"] += time.perf_counter() - t_
 
     def evaluate(i, last=False, metrics=True):
-        nonlocal decided
+        nonlocal decided, n_calls
         r = i % RING
+        t_ = time.perf_counter()
         while int(counts_host[r][world]) != i + 1:   # routed LOOKAHEAD steps ago: no wait in steady state
             pass
         mine = int(counts_host[r][rank])
+        t2_ = time.perf_counter()
+        host_s["poll"] += t2_ - t_
         for lo in range(0, mine, cap_batch):
             hi = min(mine, lo + cap_batch)
             eng.rate_limit_batch_slots(ring[r][0][lo:hi], registered=True, quantity=1, now_ns=W.T0_NS + i * 1_000_000,
-                                       want=("allowed",), out=out, inputs_ready=True)
+                                       want=("allowed",), out=outs[n_calls % OUT_RING], inputs_ready=True, outputs_idle=True)
+            n_calls += 1
+        host_s["evaluate"] += time.perf_counter() - t2_
         decided += mine
         if not metrics:
             return
@@ -713,6 +724,8 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     dt = float(tm.item())
     res = sharded_summary(a, t, W, eng, dev, rank, world, dist, dt, decided, G, cnt_view, top_gathered)
     res["route"] = "replicate"
+    res["host_us_per_step"] = {k: 1e6 * v / (a.steps + a.warmup) for k, v in host_s.items()}
+    print(f"[bench] rank {rank} host us/step: {res['host_us_per_step']}", file=sys.stderr, flush=True)
     # roofline of this rank's evaluation (same kernels as the N = 1 run, fed by the router): HIP events per kernel
     steps_p = min(a.steps, 20)
     decided = 0
@@ -808,7 +821,7 @@ def main():
                 "router_ms_per_step": sh.get("router_ms_per_step"),
                 "imbalance_max_over_mean": sh["imbalance_max_over_mean"],
                 "roofline": sh.get("roofline"), "cpu_baseline": None}
-            emit(res, {"metrics_exchange": sh["metrics_exchange"], "stages": sh.get("stages"),
+            emit(res, {"metrics_exchange": sh["metrics_exchange"], "stages": sh.get("stages"), "host_us_per_step": sh.get("host_us_per_step"),
                        "note": "cpu_baseline is reported by the N = 1 run; roofline here is rank 0's evaluation kernel over the "
                                "requests it owns (the router's kernels are not in it)"})
         dist.barrier()

@@ -164,3 +164,34 @@ def test_general_batches_with_preset_decision_bytes(fixed, sync_each):
         seen.add(bool(want.mean() > 0.5))
     assert seen == {True, False}, "the stream must have batches of either majority"
     eng.close()
+
+
+def test_result_set_reused_for_a_larger_batch_gets_new_arrays():
+    """the Python wrapper never lets the library write past the end of a result array that an earlier, smaller batch
+    allocated (an owner's share of a routed global batch changes from step to step)"""
+    import torch
+
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    eng = t.Engine(10_000, 1 << 16)
+    eng.check_on_close = True
+    eng.use_torch_stream()
+    eng.register_params_uniform(*PLAN)
+    orc = O.DenseOracle(10_000)
+    rng = np.random.default_rng(3)
+    out = t.BatchResult()
+    guard = None
+    for b, n in enumerate([1000, 999, 4097, 65536, 17]):
+        slots = rng.integers(0, 10_000, n).astype(np.uint32)
+        ref = orc.batch_slots(slots, *PLAN, 1, T0 + b)
+        before = out.allowed
+        eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).cuda(), registered=True, quantity=1, now_ns=T0 + b,
+                                   want=("allowed",), out=out)
+        torch.cuda.synchronize()
+        assert out.allowed.numel() >= n
+        if before is not None and before.numel() >= n:
+            assert out.allowed is before  # large enough: reused
+        assert (out.allowed.cpu().numpy()[:n] == ref.allowed.astype(np.uint8)).all()
+        guard = out.allowed
+    assert guard is not None
+    eng.close()

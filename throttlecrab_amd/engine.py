@@ -227,6 +227,10 @@ class Engine:
         for name in want:
             cur = getattr(res, name)
             ln = (n + 63) // 64 if name == "allowed_bits" else (4 * n if name in ("result4", "decisions") else n)
+            if cur is not None and (cur.numel() if _is_torch(cur) else cur.size) < ln:
+                if async_:
+                    raise ValueError(f"async_: the {name} array holds fewer than {ln} entries (no hidden reallocation may be made)")
+                cur = None  # a result set reused for a larger batch: a new array, never a write past the old one's end
             if cur is None:
                 if dev:
                     import torch
