@@ -165,7 +165,7 @@ def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, 
     def one(i, last=False):
         eng.rate_limit_batch_slots(d_batches[i % len(d_batches)], registered=True, quantity=1,
                                    now_ns=now_of(now0, i, nows), want=want, out=ring[i % len(ring)], inputs_ready=piped,
-                                   outputs_idle=idle, columns_ready=piped and nows is not None)  # (the timestamp columns are resident too)
+                                   outputs_idle=idle)
         if dist is not None and (i % METRICS_EVERY == METRICS_EVERY - 1 or last):
             eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
@@ -202,7 +202,7 @@ def stage_profile(eng, d_batches, out, now0, steps, it0, piped=True, nows=None):
     for i in range(steps):
         eng.rate_limit_batch_slots(d_batches[(it0 + i) % len(d_batches)], registered=True, quantity=1,
                                    now_ns=now_of(now0, it0 + i, nows), want=("allowed",), out=ring[(it0 + i) % len(ring)],
-                                   inputs_ready=piped, outputs_idle=piped and len(ring) > 1, columns_ready=piped and nows is not None)
+                                   inputs_ready=piped, outputs_idle=piped and len(ring) > 1)
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile_enable(False)

@@ -124,14 +124,6 @@ typedef struct tc_config {
                                      * stream ahead of the evaluation.  Decisions-only batches then cost one store per
                                      * MINORITY decision instead of one per request.  Results are unchanged. */
 
-#define TC_B_COLUMNS_READY 0x80u     /* with TC_B_INPUTS_READY: the per-request input columns (now_ns; the others are read on
-                                     * the engine's stream as before) are complete in device memory at call time too and
-                                     * stay untouched until the results are ready.  The engine then carries every request's
-                                     * timestamp through the last pass of the grouping, on its internal stream, and the
-                                     * evaluation reads it in the order it evaluates in (coalesced) instead of gathering it
-                                     * by request index (one memory line per request: most of a general batch's traffic).
-                                     * Results are unchanged. */
-
 /* One batch of requests = the argument list of RateLimiter::rate_limit
  * (rate_limiter.rs:102-110), columnar.  A NULL input column means "use the
  * scalar of the same name for every request". */

@@ -33,7 +33,6 @@ pub const TC_B_INPUTS_READY: u32 = 0x8;
 pub const TC_B_GROUPED_OUTPUT: u32 = 0x10;
 pub const TC_B_ASYNC: u32 = 0x20;
 pub const TC_B_OUTPUTS_IDLE: u32 = 0x40;
-pub const TC_B_COLUMNS_READY: u32 = 0x80;
 
 pub const TC_ROUTE_AHEAD: u32 = 0x1;
 pub const TC_ROUTE_NO_READERS: u32 = 0x2;

@@ -21,7 +21,6 @@ TC_CFG_FIXED_PARAMS = 0x4
 TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY, TC_B_GROUPED_OUTPUT = 0x1, 0x2, 0x4, 0x8, 0x10
 TC_B_ASYNC = 0x20
 TC_B_OUTPUTS_IDLE = 0x40
-TC_B_COLUMNS_READY = 0x80
 TC_ROUTE_AHEAD = 0x1
 TC_ROUTE_NO_READERS = 0x2
 TC_CNT_NAMES = ("total", "allowed", "denied", "errors", "swept", "batches", "keys_inserted", "live_slots")

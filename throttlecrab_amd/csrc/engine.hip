@@ -118,12 +118,6 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_EVAL_LEAN")) e->eval_lean = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_STOP_EVENTS")) e->stop_events = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_PROF_MARKERS")) e->prof_markers = atoi(d) != 0;
-    if (const char* d = getenv("TCGPU_CARRY_NOW")) e->carry_on = atoi(d) != 0;
-    if (const char* d = getenv("TCGPU_COLUMNS_READY")) e->assume_columns_ready = atoi(d) != 0;
-    if (const char* d = getenv("TCGPU_EVAL_MAX_BLOCKS")) {
-        const int m = atoi(d);
-        if (m >= 2 && m <= 7) e->eval_lds_pad = (uint32_t)(163840 / m - 512);
-    }
     if (const char* d = getenv("TCGPU_DEBUG_NO_DECISION_STORE")) e->debug_nostore = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
     {
@@ -387,7 +381,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.ws, ss.carry, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }

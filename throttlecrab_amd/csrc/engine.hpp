@@ -108,7 +108,6 @@ struct tc_engine {
         uint8_t* h_key_bytes = nullptr;                // TC_B_ASYNC key batch: its key arena and offsets, staged (lazy)
         size_t h_key_cap = 0;
         uint32_t* h_key_off = nullptr;
-        int64_t* carry = nullptr;                      // general batches: now[] in evaluation order (lazy; TC_B_COLUMNS_READY)
         uint32_t hist_parity = 0;
         void* bp_scratch = nullptr;    // bucket path: tile histograms, offsets, partitioned elements, gate
         bp::Work bpw;
@@ -143,9 +142,6 @@ struct tc_engine {
     uint32_t chain_seq = 0;
     uint32_t* loaded = nullptr; // k_eval_sorted<DIRECT>: per-wave "cells read" flags
     int eval_items = 0;         // sorted positions per lane in k_eval_sorted (0: chosen per batch)
-    bool carry_on = true;              // TCGPU_CARRY_NOW=0: general batches gather their timestamps by request index in the evaluation
-    bool assume_columns_ready = false; // TCGPU_COLUMNS_READY=1: every TC_B_INPUTS_READY batch is treated as TC_B_COLUMNS_READY (tests)
-    uint32_t eval_lds_pad = 0;  // TCGPU_EVAL_MAX_BLOCKS=4..7: unused dynamic LDS that caps the lean kernel's blocks per CU (experiment knob)
     bool eval_lean = true;      // k_eval_sorted_lean for decisions-only batches (TCGPU_EVAL_LEAN=0: the general kernel)
     bool stop_events = true;    // events ride on kernels' completion signals instead of marker packets (TCGPU_STOP_EVENTS=0: hipEventRecord)
     bool prefill_on = true;     // TC_B_OUTPUTS_IDLE batches: decision bytes preset on the grouping stream (TCGPU_PREFILL=0: off)

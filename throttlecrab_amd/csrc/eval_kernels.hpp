@@ -60,7 +60,6 @@ struct Params {
     uint64_t capacity;
     unsigned long long* counters;
     uint32_t* denied; // per-slot denial counters (TC_CFG_TRACK_DENIED) or nullptr
-    const int64_t* now_sorted; // general batches, TC_B_COLUMNS_READY: now[] in evaluation order (carried through the last radix pass)
     uint64_t* row_bits; // TC_B_GROUPED_OUTPUT + allowed_bits on a batch whose runs are all regular: the evaluation packs
                         // the decisions of its 64-row waves itself (one ballot, one 8-byte store), no byte column
 };
@@ -71,11 +70,10 @@ struct Req {
 };
 
 // Request i against `slot`: arguments, derived rate and status (rate_limiter.rs:111-123).
-// (k: the request's position in evaluation order, for the columns that were carried through the sort; ~0u: none)
-__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot, uint32_t k = 0xFFFFFFFFu) {
+__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot) {
     Req r;
     r.q = p.q ? p.q[i] : p.q_s;
-    r.now = (k != 0xFFFFFFFFu && p.now_sorted) ? p.now_sorted[k] : (p.now ? p.now[i] : p.now_s);
+    r.now = p.now ? p.now[i] : p.now_s;
     r.ei = r.dvt = r.limit = 0;
     if (slot >= p.capacity) {
         r.status = tc::ST_INTERNAL;
@@ -821,7 +819,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     Req r;
     r.ei = r.dvt = r.q = r.now = r.limit = 0;
     r.status = tc::ST_INTERNAL;
-    if (valid) r = make_req(p, idx, slot, k);
+    if (valid) r = make_req(p, idx, slot);
     const bool ok = valid && r.status == tc::ST_OK;
 
     // my piece = lanes [pstart, pend] of this wave that belong to my segment

@@ -173,16 +173,11 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
 // ---------------------------------------------------------------------------
 // one LSD pass.  FIRST: input is the raw slot column (value = position).
 // ---------------------------------------------------------------------------
-// CARRY (the LAST pass of a general batch): every element takes one 8-byte value of a per-request column with it --
-// carry_out[final position] = carry_in[request index] -- so that the evaluation reads the column in the order it
-// evaluates in instead of gathering it by request index.  The gather happens here, in the write-out, on the grouping
-// stream; the stores are the coalesced ones of the element itself.
-template <int ITEMS, bool FIRST, bool CARRY = false>
+template <int ITEMS, bool FIRST>
 __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict__ slot_in,
                                                       const uint64_t* __restrict__ elem_in,
                                                       uint64_t* __restrict__ elem_out, uint32_t n, uint32_t cap,
-                                                      int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min,
-                                                      const int64_t* __restrict__ carry_in = nullptr, int64_t* __restrict__ carry_out = nullptr) {
+                                                      int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min) {
     constexpr int TILE = THREADS * ITEMS;
     if (gated_off(gate, gate_min)) return; // (the whole grid: nobody is left waiting in a look-back)
     __shared__ uint32_t s_base[RADIX];          // global exclusive start of each digit
@@ -395,28 +390,6 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
     if (RS_ABLATE == 4) return; // everything but the write-out
     const uint32_t tile_first = tile * TILE;
     const uint32_t nvalid = (n - tile_first) < (uint32_t)TILE ? (n - tile_first) : (uint32_t)TILE;
-    if (CARRY) {
-        // all of the lane's gathers in flight before the first store
-        uint64_t e[ITEMS];
-        int64_t c[ITEMS];
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const uint32_t i = j * THREADS + threadIdx.x;
-            e[j] = i < nvalid ? s_elem[i] : 0ull;
-            c[j] = carry_in[i < nvalid ? (uint32_t)e[j] : 0u];
-        }
-#pragma unroll
-        for (int j = 0; j < ITEMS; ++j) {
-            const uint32_t i = j * THREADS + threadIdx.x;
-            if (i < nvalid) {
-                const uint32_t d = ((uint32_t)(e[j] >> 32) >> shift) & 255u;
-                const uint32_t at = i + s_off[d];
-                elem_out[at] = e[j];
-                carry_out[at] = c[j];
-            }
-        }
-        return;
-    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const uint32_t i = j * THREADS + threadIdx.x;

@@ -84,8 +84,7 @@ int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_ke
 // returns the buffer holding the result
 static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
                                     bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
-                                    uint8_t* fill = nullptr, uint32_t fill_value = 0, const int64_t* carry_in = nullptr,
-                                    int64_t* carry_out = nullptr) {
+                                    uint8_t* fill = nullptr, uint32_t fill_value = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
     const int passes = (bits + 7) / 8;
@@ -104,15 +103,9 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
         uint64_t* out = bufs[p & 1];
         prof_begin_m(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
         hipEvent_t stop = (p + 1 == passes && !e->prof_on) ? stop_last : nullptr;
-        // (carry: the last pass takes the per-request timestamps along, see rs::k_onesweep<.., CARRY>)
-#define TC_PASS2(IT, FI, CA) \
-    TC_LAUNCH_T(e, TC_STAGE_SORT, stop, (rs::k_onesweep<IT, FI, CA>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
-              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min, carry_in, carry_out)
-#define TC_PASS(IT, FI)                                        \
-    do {                                                       \
-        if (carry_in && p + 1 == passes) TC_PASS2(IT, FI, true); \
-        else TC_PASS2(IT, FI, false);                          \
-    } while (0)
+#define TC_PASS(IT, FI) \
+    TC_LAUNCH_T(e, TC_STAGE_SORT, stop, (rs::k_onesweep<IT, FI>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
+              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min)
         if (p == 0) {
             if (items == 32) TC_PASS(32, true);
             else if (items == 16) TC_PASS(16, true);
@@ -123,7 +116,6 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
             else TC_PASS(8, false);
         }
 #undef TC_PASS
-#undef TC_PASS2
         prof_end_m(e, s);
         in = out;
     }
@@ -172,7 +164,7 @@ static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, u
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
     if (lean) {
         if constexpr (ITEMS <= 2) {
-            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, e->eval_lds_pad, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
+            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
             return;
         }
     }
@@ -328,7 +320,6 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
     p.uniform_class = e->uniform_id;
     p.denied = e->denied;
     p.row_bits = nullptr;
-    p.now_sorted = nullptr;
     p.capacity = e->capacity;
     p.counters = e->counters;
     if (b.flags & TC_B_REGISTERED_PARAMS) {
@@ -435,18 +426,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
                 fill_value = *(volatile uint32_t*)e->fill_hint_host & 1u;
                 p.flags |= fill_value ? F_PREFILL1 : F_PREFILL0;
             }
-            // General batches: the requests' timestamps ride through the last radix pass (rs::k_onesweep<.., CARRY>) when the
-            // column may be read on this stream -- the caller vouched for it (TC_B_COLUMNS_READY), or it was staged on this
-            // very stream a few lines up -- and the evaluation reads them in its own order: the gather by request index was
-            // most of a general batch's memory traffic, and it sat on the engine's stream, which is the bottleneck of general
-            // batches (the grouping streams have headroom there)
-            const int64_t* carry_in = nullptr;
-            if (!uniform && p.now && e->carry_on && ((b.flags & TC_B_COLUMNS_READY) || e->assume_columns_ready || (hin && hin->col[4]))) {
-                if (!ss.carry) TC_HIP(e, hipMalloc(&ss.carry, e->max_batch * sizeof(int64_t)));
-                carry_in = p.now;
-                p.now_sorted = ss.carry;
-            }
-            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value, carry_in, ss.carry);
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value);
             if (!ride) TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
             ss.grouped_aside = true;

@@ -176,8 +176,7 @@ class Engine:
         setattr(batch, name, arr.ctypes.data)
 
     def _prepare(self, n, dev, max_burst, count_per_period, period, quantity, now_ns, registered, unique,
-                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False, async_=False, outputs_idle=False,
-                 columns_ready=False):
+                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False, async_=False, outputs_idle=False):
         keep = []
         b = L.tc_batch()
         b.struct_size = C.sizeof(L.tc_batch)
@@ -199,10 +198,6 @@ class Engine:
             if not inputs_ready:
                 raise ValueError("outputs_idle goes with inputs_ready")
             flags |= L.TC_B_OUTPUTS_IDLE
-        if columns_ready:
-            if not inputs_ready:
-                raise ValueError("columns_ready goes with inputs_ready")
-            flags |= L.TC_B_COLUMNS_READY
         if async_:
             if dev:
                 raise ValueError("async_ applies to host-array batches (CUDA-tensor batches are asynchronous anyway)")
@@ -251,7 +246,7 @@ class Engine:
     def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
                                now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
                                out: Optional[BatchResult] = None, inputs_ready=False, grouped=False,
-                               async_=False, outputs_idle=False, segments=None, columns_ready=False) -> BatchResult:
+                               async_=False, outputs_idle=False, segments=None) -> BatchResult:
         """rate_limit_batch over pre-resolved slots (sequential semantics, index order).
         segments=[(tensor, count), ...] (with slots=None): the slot column in pieces, e.g. one per source GPU.
         async_=True (TC_B_ASYNC, host arrays): only enqueue -- transfers and evaluation overlap with
@@ -263,9 +258,7 @@ class Engine:
         stays untouched until the results are ready, so the engine may group this batch on its
         auxiliary stream while earlier batches are still being evaluated.
         outputs_idle=True (TC_B_OUTPUTS_IDLE, with inputs_ready): nothing enqueued earlier reads or writes the
-        arrays of `out` (every batch in flight has its own), so the engine may initialise them early.
-        columns_ready=True (TC_B_COLUMNS_READY, with inputs_ready): the per-request `now_ns` tensor is complete and stays
-        untouched too, so the engine may carry the timestamps through its grouping instead of gathering them later."""
+        arrays of `out` (every batch in flight has its own), so the engine may initialise them early."""
         dev = _is_torch(slots) or segments is not None
         keep = []
         seg_arrays = None
@@ -295,7 +288,7 @@ class Engine:
             n = sl.size
             sp = sl.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
-                                   unique, want, out, inputs_ready, grouped, async_, outputs_idle, columns_ready)
+                                   unique, want, out, inputs_ready, grouped, async_, outputs_idle)
         b.slot = sp
         if seg_arrays is not None:
             b.n_segments = len(segments)
