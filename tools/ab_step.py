@@ -1,77 +1,99 @@
 #!/usr/bin/env python3
-"""A/B of engine knobs on the headline configuration (10 M keys, 1 Mi-request batches, pipelined, decisions only):
-one process, one engine per configuration (the knobs are environment variables read at engine creation).
+"""A/B of engine knobs on the headline configuration (10 M keys, 1 Mi-request batches, pipelined, decisions only).
+EVERY configuration runs in a process of its own: the knobs are environment variables read at engine creation, and which
+hardware queue a HIP stream lands on depends on everything the process created before (a configuration with four
+grouping streams left every later engine of the same process at half speed: r03_v33).
 
     python tools/ab_step.py [steps] [config-name ...]
 """
 import os
+import subprocess
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-import torch  # noqa: E402
 
-import throttlecrab_amd as t  # noqa: E402
-from throttlecrab_amd import workload as W  # noqa: E402
-
-KNOBS = ("TCGPU_EVAL_LEAN", "TCGPU_STOP_EVENTS", "TCGPU_EVAL_ITEMS", "TCGPU_SORT_ITEMS_PIPED", "TCGPU_AUX_CU_MASK",
-         "TCGPU_DEBUG_NO_DECISION_STORE", "TCGPU_AUX_STREAMS", "TCGPU_PIPE_DEPTH", "TCGPU_AUX_PRIORITY", "TCGPU_GATE", "TCGPU_PREFILL")
-HALF = ",".join(["ffff"] * 8)
-QUARTER = ",".join(["ff"] * 8)
+KNOBS = ("TCGPU_EVAL_LEAN", "TCGPU_STOP_EVENTS", "TCGPU_EVAL_ITEMS", "TCGPU_SORT_ITEMS_PIPED", "TCGPU_DEBUG_NO_DECISION_STORE",
+         "TCGPU_AUX_STREAMS", "TCGPU_PIPE_DEPTH", "TCGPU_AUX_PRIORITY", "TCGPU_PREFILL")
 # "_idle": the batches carry TC_B_OUTPUTS_IDLE (a ring of 8 output arrays instead of one)
 CONFIGS = {
-    "r2": {"TCGPU_EVAL_LEAN": "0", "TCGPU_STOP_EVENTS": "0", "TCGPU_GATE": "0"},
-    "idle_events": {"_idle": "1", "TCGPU_GATE": "0"},
-    "idle_gate1": {"_idle": "1", "TCGPU_GATE": "1"},
-    "idle_gate2": {"_idle": "1", "TCGPU_GATE": "2"},
-    "idle_gate1_d6": {"_idle": "1", "TCGPU_GATE": "1", "TCGPU_PIPE_DEPTH": "6"},
-    "idle_gate2_d6": {"_idle": "1", "TCGPU_GATE": "2", "TCGPU_PIPE_DEPTH": "6"},
-    "idle_gate1_d8": {"_idle": "1", "TCGPU_GATE": "1", "TCGPU_PIPE_DEPTH": "8"},
-    "idle_gate1_d6_items1": {"_idle": "1", "TCGPU_GATE": "1", "TCGPU_PIPE_DEPTH": "6", "TCGPU_EVAL_ITEMS": "1"},
-    "gate1_d6": {"TCGPU_GATE": "1", "TCGPU_PIPE_DEPTH": "6"},
-    "idle_gate1_d6_nostore": {"_idle": "1", "TCGPU_GATE": "1", "TCGPU_PIPE_DEPTH": "6", "TCGPU_DEBUG_NO_DECISION_STORE": "1"},
+    "default": {"_idle": "1"},
+    "default_again": {"_idle": "1"},
+    "aux2": {"_idle": "1", "TCGPU_AUX_STREAMS": "2"},
+    "aux4": {"_idle": "1", "TCGPU_AUX_STREAMS": "4"},
+    "depth4": {"_idle": "1", "TCGPU_PIPE_DEPTH": "4"},
+    "depth8": {"_idle": "1", "TCGPU_PIPE_DEPTH": "8"},
+    "sort8": {"_idle": "1", "TCGPU_SORT_ITEMS_PIPED": "8"},
+    "sort32": {"_idle": "1", "TCGPU_SORT_ITEMS_PIPED": "32"},
+    "items1": {"_idle": "1", "TCGPU_EVAL_ITEMS": "1"},
+    "prio": {"_idle": "1", "TCGPU_AUX_PRIORITY": "-1"},
+    "prio_again": {"_idle": "1", "TCGPU_AUX_PRIORITY": "-1"},
+    "prio_low": {"_idle": "1", "TCGPU_AUX_PRIORITY": "1"},
+    "prio_sort32": {"_idle": "1", "TCGPU_AUX_PRIORITY": "-1", "TCGPU_SORT_ITEMS_PIPED": "32"},
+    "prio_sort8": {"_idle": "1", "TCGPU_AUX_PRIORITY": "-1", "TCGPU_SORT_ITEMS_PIPED": "8"},
+    "prio_items1": {"_idle": "1", "TCGPU_AUX_PRIORITY": "-1", "TCGPU_EVAL_ITEMS": "1"},
+    "prio_aux2": {"_idle": "1", "TCGPU_AUX_PRIORITY": "-1", "TCGPU_AUX_STREAMS": "2"},
+    "no_idle": {},
+    "r2": {"TCGPU_EVAL_LEAN": "0", "TCGPU_STOP_EVENTS": "0"},
+    "nostore": {"_idle": "1", "TCGPU_DEBUG_NO_DECISION_STORE": "1"},
 }
+CACHE = "/tmp/ab_step_streams.npz"
+
+
+def child(name, steps):
+    import torch
+
+    import throttlecrab_amd as t
+    from throttlecrab_amd import workload as W
+    keys, batch = 10_000_000, 1 << 20
+    idle = CONFIGS[name].get("_idle") == "1"
+    z = np.load(CACHE)
+    dev = torch.device("cuda:0")
+    for sname in ("uniform", "zipf"):
+        db = [torch.from_numpy(b).to(dev) for b in z[sname]]
+        nb = len(db)
+        eng = t.Engine(keys, batch, fixed_params=True)
+        eng.use_torch_stream()
+        eng.register_params_uniform(*W.REF_PARAMS)
+        outs = [t.BatchResult() for _ in range(8 if idle else 1)]
+        general = os.environ.get("AB_GENERAL") == "1"   # a timestamp per request (k_eval_general)
+        nows = [torch.arange(batch, dtype=torch.int64, device=dev) + (W.T0_NS + b * 1_000_000) for b in range(16)] if general else None
+        it, best = 0, 1e9
+        for rep in range(4):
+            n = 10 if rep == 0 else steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                eng.rate_limit_batch_slots(db[it % nb], registered=True, quantity=1, now_ns=(nows[it % 16] if general else W.T0_NS + it * 1_000_000), want=("allowed",),
+                                           out=outs[it % len(outs)], inputs_ready=True, outputs_idle=idle)
+                it += 1
+            torch.cuda.synchronize()
+            if rep:
+                best = min(best, (time.perf_counter() - t0) / n)
+        bad = eng.selfcheck()
+        print(f"{name:22s} {('g_' if general else '') + sname:8s} {best * 1e6:8.1f} {batch / best / 1e9:7.2f}" + (f"   SELFCHECK {bad}" if bad else ""), flush=True)
+        eng.close()
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--child":
+        return child(sys.argv[2], int(sys.argv[3]))
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     names = sys.argv[2:] or list(CONFIGS)
-    keys, batch, layout_fixed = 10_000_000, 1 << 20, True
-    dev = torch.device("cuda:0")
+    from throttlecrab_amd import workload as W
+    keys, batch, nb = 10_000_000, 1 << 20, 16
     z = W.Zipf(keys)
-    nb = 32
-    streams = {"uniform": [torch.from_numpy(W.uniform_slots(keys, batch, start=i * batch).astype(np.int32)).to(dev) for i in range(nb)],
-               "zipf": [torch.from_numpy(z.slots(batch, start=i * batch).astype(np.int32)).to(dev) for i in range(nb)]}
-    print(f"{'config':22s} {'stream':8s} {'us/step':>8s} {'G/s':>7s}   (best of 3 x {steps} steps)", flush=True)
+    np.savez(CACHE, uniform=np.stack([W.uniform_slots(keys, batch, start=i * batch).astype(np.int32) for i in range(nb)]),
+             zipf=np.stack([z.slots(batch, start=i * batch).astype(np.int32) for i in range(nb)]))
+    print(f"{'config':22s} {'stream':8s} {'us/step':>8s} {'G/s':>7s}   (best of 3 x {steps} steps, one process per configuration)", flush=True)
     for name in names:
-        for k in KNOBS:
-            os.environ.pop(k, None)
-        os.environ.update({k: v for k, v in CONFIGS[name].items() if not k.startswith("_")})
-        idle = CONFIGS[name].get("_idle") == "1"
-        for sname, db in streams.items():
-            eng = t.Engine(keys, batch, fixed_params=layout_fixed)
-            eng.use_torch_stream()
-            eng.register_params_uniform(*W.REF_PARAMS)
-            outs = [t.BatchResult() for _ in range(8 if idle else 1)]
-            it = 0
-            best = 1e9
-            for rep in range(4):
-                n = 10 if rep == 0 else steps
-                torch.cuda.synchronize()
-                t0 = time.perf_counter()
-                for _ in range(n):
-                    eng.rate_limit_batch_slots(db[it % nb], registered=True, quantity=1, now_ns=W.T0_NS + it * 1_000_000, want=("allowed",),
-                                               out=outs[it % len(outs)], inputs_ready=True, outputs_idle=idle)
-                    it += 1
-                torch.cuda.synchronize()
-                if rep:
-                    best = min(best, (time.perf_counter() - t0) / n)
-            bad = eng.selfcheck()
-            print(f"{name:22s} {sname:8s} {best * 1e6:8.1f} {batch / best / 1e9:7.2f}" + (f"   SELFCHECK {bad}" if bad else ""), flush=True)
-            eng.close()
+        env = {k: v for k, v in os.environ.items() if k not in KNOBS}
+        env.update({k: v for k, v in CONFIGS[name].items() if not k.startswith("_")})
+        subprocess.run([sys.executable, os.path.abspath(__file__), "--child", name, str(steps)], env=env, timeout=120, check=False)
 
 
 if __name__ == "__main__":
