@@ -258,7 +258,9 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
     host_batches = make_batches(stream, a.keys, a.batch, min(nb, 64), seed_shift=seed_shift)
     d_batches = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in host_batches]
     nows = make_nows(dev, a.batch, min(nb + 2 * a.steps, 32), W.T0_NS) if general else None
-    out = [t.BatchResult() for _ in range(OUT_RING)]
+    # result arrays allocated up front: with a warmup shorter than the ring, the first use of a ring entry (a device
+    # allocation) would otherwise fall into the timed region (20 timed batches: 53 instead of 48 us per batch)
+    out = [t.BatchResult(allowed=torch.empty(a.batch, dtype=torch.uint8, device=dev)) for _ in range(OUT_RING)]
     cnt_view = gathered = None
     if dist is not None:
         from throttlecrab_amd.sharded import device_counter_view
@@ -525,7 +527,7 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
         host = [W.uniform_slots(world * a.keys, B, seed=2, start=i * G + rank * B) for i in range(n_distinct)]
     d_slice = [torch.from_numpy(h.astype(np.int32)).to(dev) for h in host]
     xr = sharded.ExchangeRank(eng, fab, rank, world, B, route_ring=8)
-    outs = [t.BatchResult() for _ in range(OUT_RING)]
+    outs = [t.BatchResult(allowed=torch.empty(2 * B, dtype=torch.uint8, device=dev)) for _ in range(OUT_RING)]
     cnt_view = sharded.device_counter_view(eng)
     gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
     top_gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64, device=dev)
