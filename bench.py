@@ -562,6 +562,8 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     dist.barrier()
     torch.cuda.synchronize()
     decided = 0
+    for k_ in xr.host_s:
+        xr.host_s[k_] = 0.0   # (the warmup holds one-time costs: scratch allocation, the stream probe)
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(it, last=(k == a.steps - 1))
@@ -569,13 +571,14 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     torch.cuda.synchronize()
     dist.barrier()
     dt_mine = time.perf_counter() - t0
+    host_us = {k_: 1e6 * v / a.steps for k_, v in xr.host_s.items()}   # of the timed region only
     tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     dt = float(tm.item())
     res = sharded_summary(a, t, W, eng, dev, rank, world, dist, dt, decided, G, cnt_view, top_gathered)
     res["route"] = "exchange"
-    res["host_us_per_step"] = {k: 1e6 * v / (a.steps + a.warmup) for k, v in xr.host_s.items()}  # where the host's time goes
-    print(f"[bench] rank {rank} host us/step: {res['host_us_per_step']}", file=sys.stderr, flush=True)
+    res["host_us_per_step"] = host_us  # where the host's time goes
+    print(f"[bench] rank {rank} host us/step (timed region): {host_us}", file=sys.stderr, flush=True)
     # roofline of this rank's evaluation: HIP events per kernel (needs no peers: the inboxes of the last steps again)
     steps_p = min(a.steps, 12)
     segs_last = [xr.collect(it - 1 - (k % 2)) for k in range(2)]
@@ -668,11 +671,12 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     # its last block writes the counts + the batch's tag into pinned host memory: the host learns how many requests
     # it owns by polling that word -- no event, no stream synchronisation on the way.
     host_s = {"route": 0.0, "poll": 0.0, "evaluate": 0.0}   # where the host's time goes (diagnostics, stderr + detail)
+    ROUTE_AHEAD = os.environ.get("TC_BENCH_ROUTE_AHEAD", "1") == "1"
 
     def route(i):
         r = i % RING
         t_ = time.perf_counter()
-        eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r], ahead=True, host_counts=counts_host[r], tag=i + 1)
+        eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r], ahead=ROUTE_AHEAD, host_counts=counts_host[r], tag=i + 1)
         host_s["route"] += time.perf_counter() - t_
 
     def evaluate(i, last=False, metrics=True):
@@ -713,6 +717,8 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     dist.barrier()
     torch.cuda.synchronize()
     decided = 0
+    for k_ in host_s:
+        host_s[k_] = 0.0   # (the warmup holds one-time costs: scratch allocation, the stream probe)
     t0 = time.perf_counter()
     for k in range(a.steps):
         route(it + LOOKAHEAD)   # (the last LOOKAHEAD of them are routed for nothing: inside the timing, against us)
@@ -721,13 +727,14 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     torch.cuda.synchronize()
     dist.barrier()
     dt_mine = time.perf_counter() - t0
+    host_us = {k_: 1e6 * v / a.steps for k_, v in host_s.items()}   # of the timed region only
+    print(f"[bench] rank {rank} host us/step (timed region): {host_us}", file=sys.stderr, flush=True)
     tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     dt = float(tm.item())
     res = sharded_summary(a, t, W, eng, dev, rank, world, dist, dt, decided, G, cnt_view, top_gathered)
     res["route"] = "replicate"
-    res["host_us_per_step"] = {k: 1e6 * v / (a.steps + a.warmup) for k, v in host_s.items()}
-    print(f"[bench] rank {rank} host us/step: {res['host_us_per_step']}", file=sys.stderr, flush=True)
+    res["host_us_per_step"] = host_us
     # roofline of this rank's evaluation (same kernels as the N = 1 run, fed by the router): HIP events per kernel
     steps_p = min(a.steps, 20)
     decided = 0
