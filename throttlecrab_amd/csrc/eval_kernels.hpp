@@ -798,7 +798,7 @@ __device__ __forceinline__ void write_out_general(const Params& p, uint32_t i, c
 }
 
 template <bool FULL>
-__global__ __launch_bounds__(BLOCK, FULL ? 5 : 6) void k_eval_general(Params p, const uint64_t* __restrict__ sorted,
+__global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t* __restrict__ sorted,
                                                         ChainRec* __restrict__ chain, uint32_t seq, uint32_t* hint) {
     const uint32_t n = p.n;
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
@@ -946,6 +946,9 @@ __global__ __launch_bounds__(BLOCK, FULL ? 5 : 6) void k_eval_general(Params p, 
 
     uint32_t na = 0, nd = 0, ne = 0;
     bool fin = !valid, was_allowed = false;
+    Cell mine; // state after my request, if it was allowed
+    mine.tat = 0;
+    mine.expiry = 0;
     if (valid && !ok) { // errors leave the state alone (rate_limiter.rs:111-117)
         Decision z;
         z.allowed = false;
@@ -954,16 +957,6 @@ __global__ __launch_bounds__(BLOCK, FULL ? 5 : 6) void k_eval_general(Params p, 
         ne = 1;
         fin = true;
     }
-    // Every round settles, per piece, (1) the requests that are DENIED against the piece's current state, up to the
-    // first one that state allows, and (2) from that request on a whole RUN OF ALLOWED requests at once.  An allowed
-    // request maps the TAT t to max(t, now - dvt) + inc as long as the entry stays live and nothing saturates, and such
-    // maps compose: (A, B) stands for t -> max(t + B, A), two in a row give (max(A1 + B2, A2), B1 + B2) -- a prefix scan
-    // over the piece's lanes PREDICTS the state every lane would see if all requests before it were allowed.  The
-    // prediction decides nothing: every lane runs the real step (tc::gcra_step, saturations and liveness included)
-    // on the state its predecessor predicted, and the run ends at the first lane whose real step is denied or leaves
-    // another state than predicted; up to that lane every input was the exact state (induction over the lanes), so
-    // all of them are final.  Rounds per wave = alternations between allowed runs and denials in its longest piece, not
-    // allowed requests: a hot key that drains its burst inside one batch costs two rounds instead of sixty-four.
     while (true) {
         Cell c2 = c;
         bool allow = false;
@@ -971,68 +964,41 @@ __global__ __launch_bounds__(BLOCK, FULL ? 5 : 6) void k_eval_general(Params p, 
         const unsigned long long open = __ballot(!fin);
         if (open == 0ull) break;
         const unsigned long long ap = __ballot(allow) & piece;
-        const int first = ap ? __builtin_ctzll(ap) : 64; // (in MY piece; every unfinished lane of a piece holds the same c)
-        // the predictor (wrapping arithmetic: whatever it yields is only ever compared with the real step's result)
-        const unsigned long long pb = (unsigned long long)tc::sat_mul(r.ei, r.q);
-        unsigned long long A = (unsigned long long)tc::sat_sub(r.now, r.dvt) + pb, B = pb;
-        if (__ballot(!fin && lane > first) != 0ull) { // (wave-uniform: somebody waits behind an allowed request of its piece)
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned long long Ae = __shfl_up(A, off, 64), Be = __shfl_up(B, off, 64);
-                if (lane >= first + off) { // (the lane `off` below me belongs to the run that starts at `first`)
-                    const long long x = (long long)(Ae + B), y = (long long)A;
-                    A = (unsigned long long)(x > y ? x : y);
-                    B = Be + B;
-                }
+        const int first = ap ? __builtin_ctzll(ap) : 64;
+        if (!fin && lane <= first) {
+            // lanes before the first allowed request are denied against the current state,
+            // the first allowed request is allowed against it: both final
+            Decision d;
+            if (FULL) {
+                Cell tmp = c;
+                d = tc::gcra_step<true>(tmp, r.ei, r.dvt, r.q, r.now);
+            } else {
+                d.allowed = allow;
+                d.remaining = d.reset_after = d.retry_after = 0;
             }
-        }
-        Cell pred;
-        {
-            const long long x = (long long)((unsigned long long)c.tat + B), y = (long long)A;
-            pred = tc::cell_after((int64_t)(x > y ? x : y), r.dvt, r.now);
-        }
-        const long long ptat = __shfl_up((long long)pred.tat, 1, 64);
-        const unsigned long long pexp = __shfl_up((unsigned long long)pred.expiry, 1, 64);
-        // from here on c is the state MY request sees: the piece's current one, or what the lane below me predicted
-        // (finished lanes -- error requests -- track it too: one of them may be the piece's last lane, which owns
-        // the state the piece leaves)
-        if (lane > first) {
-            c.tat = ptat;
-            c.expiry = pexp;
-            dirty = true; // (an earlier request of my segment was allowed in this batch)
-        }
-        Cell cw = c;
-        Decision d;
-        d.allowed = false;
-        d.remaining = d.reset_after = d.retry_after = 0;
-        if (!fin) d = tc::gcra_step<FULL>(cw, r.ei, r.dvt, r.q, r.now); // lanes below `first`: denied against c, as before
-        const bool consistent = !fin && d.allowed && cw.tat == pred.tat && cw.expiry == pred.expiry;
-        const unsigned long long bad = __ballot(lane >= first && !consistent) & piece;
-        const int brk = bad ? __builtin_ctzll(bad) : 64; // the run of allowed requests ends here (64: at the piece's end)
-        // what the lanes behind `brk` go on from: its new state if it was an open request that got allowed, else its input
-        const bool takes = !fin && d.allowed;
-        const int src = brk < 64 ? brk : lane;
-        const long long nt = __shfl((long long)(takes ? cw.tat : c.tat), src, 64);
-        const unsigned long long nx = __shfl((unsigned long long)(takes ? cw.expiry : c.expiry), src, 64);
-        if (!fin && (lane < first || lane <= brk)) {
             write_out_general<FULL>(p, orow, r, d);
-            if (d.allowed) {
+            if (lane == first) {
                 na = 1;
                 was_allowed = true;
-                c = cw; // (the state after me; a denied request leaves the one it saw)
+                mine = c2;
             } else {
                 nd = 1;
             }
             fin = true;
         }
-        if (brk < 64 && lane > brk) {
+        // the lanes after `first` in its piece continue from the state it leaves
+        const int src = first < 64 ? first : lane;
+        const long long nt = __shfl((long long)c2.tat, src, 64);
+        const unsigned long long nx = __shfl((unsigned long long)c2.expiry, src, 64);
+        if (first < 64 && lane > first) { // (lanes beyond pend are masked out by `piece` in `ap`: first is in MY piece)
             c.tat = nt;
             c.expiry = nx;
+            dirty = true;
         }
     }
     // the last lane of the piece owns the state the piece leaves
     if (valid && lane == pend && !strong_wave) { // (a strongly transparent wave hands on a state it never learnt: nothing to publish)
-        const Cell out = c; // (the state after the piece's last request, or the one that passed it)
+        const Cell out = was_allowed ? mine : c;
         const bool out_dirty = dirty || was_allowed;
         if (is_last) {
             if (out_dirty && slot < p.capacity) store_state_rt(p, slot, out);
