@@ -282,7 +282,8 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
         ev = piped.get("eval") or piped.get("bucket_eval")
         tr, src = pmc_traffic("eval_general" if general else "eval", tag, a.layout, 1.0)
         if ev:  # (no record: the launch went untimed -- the line then carries no roofline rather than a made-up one)
-            kname = "ev::k_eval_general" if general else ev["kernel"]
+            # (pipelined, decisions only, every run regular: the evaluation the engine launches is the lean variant)
+            kname = "ev::k_eval_general" if general else ("ev::k_eval_sorted_lean" if ev["kernel"] == "ev::k_eval_sorted" else ev["kernel"])
             source = {"avg_ms": "start/stop HIP events on the kernel's own dispatch packet (hipExtLaunchKernelGGL), engine's "
                                 "stream, pipelined run of this process",
                       "traffic": (src or {}).get("file")}
