@@ -126,6 +126,11 @@ def parse():
     ap.add_argument("--in-order", action="store_true", help="with --profile-run: batches without TC_B_INPUTS_READY (one stream)")
     ap.add_argument("--profile-run", action="store_true",
                     help="warmup + timed region only (what rocprofv3 is pointed at: no per-kernel events, no secondary runs)")
+    ap.add_argument("--plans", default="one", choices=["one", "tiers4", "tiers1000"],
+                    help="rate plans of the headline run: one plan for the whole table (tc_register_params_uniform: BASELINE configs "
+                         "1-2 as SURVEY.md states them) or a plan PER KEY, 4 / 1000 distinct (burst, count, period) tiers assigned by a "
+                         "hash of the slot (tc_register_params: the evaluation reads rate_id[] and the plan dictionary)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle replay of the timed batches")
     ap.add_argument("--layout", default="fixed", choices=["wide", "fixed"],
                     help="resident state: 16-byte {tat, expiry} cells, or TC_CFG_FIXED_PARAMS (8-byte TAT column)")
     return ap.parse_args()
@@ -148,6 +153,71 @@ def now_of(now0, i, nows):
 def make_nows(dev, batch, count, now0):
     import torch
     return [torch.arange(batch, dtype=torch.int64, device=dev) + (now0 + b * 1_000_000) for b in range(count)]
+
+
+def plan_tiers(kind, n_keys):
+    """Per-key rate plans: -> (tiers int64[T, 3] of (burst, count, period), tier_of uint16[n_keys]).  Tier 0 is the reference
+    benchmark's plan (store_comparison.rs:17); the others vary burst 20..210, rate and period, all valid on the 8-byte
+    layout (burst >= 2, emission interval and tolerance far below 2^60 ns).  A key's tier is a hash of its slot, so
+    neighbouring slots carry unrelated plans (the worst case for the rate_id[] gather's locality)."""
+    from throttlecrab_amd import workload as W
+    T = {"tiers4": 4, "tiers1000": 1000}[kind]
+    k = np.arange(T, dtype=np.int64)
+    tiers = np.stack([20 + (k * 37) % 191, 100 + 13 * k, np.where(k % 3 == 0, 3600, np.where(k % 3 == 1, 60, 600))], axis=1).astype(np.int64)
+    tiers[0] = W.REF_PARAMS
+    tier_of = (W.splitmix64(np.arange(n_keys, dtype=np.uint64) ^ np.uint64(0x7157)) % np.uint64(T)).astype(np.uint16)
+    return tiers, tier_of
+
+
+def register_plans(eng, plans, n_keys):
+    """one plan for the table, or a plan per key; -> per-slot [n_keys, 3] triples (None: one plan)"""
+    from throttlecrab_amd import workload as W
+    if plans in (None, "one"):
+        eng.register_params_uniform(*W.REF_PARAMS)
+        return None
+    tiers, tier_of = plan_tiers(plans, n_keys)
+    per_slot = tiers[tier_of]
+    eng.register_params(per_slot[:, 0], per_slot[:, 1], per_slot[:, 2])
+    return per_slot
+
+
+def verify_run(snap, host_batches, n_nows, per_slot, n_keys, batch, general):
+    """The checker of the timed run (the oracle is never timed here): replays EVERY batch the engine was given since its
+    creation -- warmup and timed region, same slots, same timestamps -- through the oracle's dense store one request at a
+    time (rate_limiter.rs:147-205 in queue order) and compares (i) the allowed / denied / error counters of the whole run,
+    (ii) the decision bytes of the last batches (the ring of result arrays still holds them) and (iii) the whole resident
+    state (tc_read_state over every key).  -> dict with "ok"."""
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    t0 = time.perf_counter()
+    orc = O.DenseOracle(n_keys)
+    th = O.host_threads()
+    nb = snap["batches"]
+    allowed = 0
+    bytes_ok, bytes_checked = True, 0
+    for i in range(nb):
+        sl = host_batches[i % len(host_batches)]
+        now = W.T0_NS + i * 1_000_000
+        if general:
+            now = W.T0_NS + (i % n_nows) * 1_000_000 + np.arange(batch, dtype=np.int64)
+        if per_slot is None:
+            ref = orc.batch_slots(sl, *W.REF_PARAMS, 1, now, threads=th)
+        else:
+            pr = per_slot[sl]
+            ref = orc.batch_slots(sl, pr[:, 0], pr[:, 1], pr[:, 2], 1, now, threads=th)
+        allowed += int(ref.allowed.sum())
+        if i in snap["ring"]:
+            bytes_checked += 1
+            bytes_ok = bytes_ok and bool(np.array_equal(snap["ring"][i], ref.allowed))
+    c = snap["counters"]
+    counters_ok = (c["allowed"] == allowed and c["denied"] == nb * batch - allowed and c["errors"] == 0 and c["total"] == nb * batch)
+    otat, oexp, occ = orc.dump()
+    tat, exp = snap["state"]
+    state_ok = bool(not exp[~occ].any() and np.array_equal(tat[occ], otat[occ]) and np.array_equal(exp[occ], oexp[occ]))
+    return {"ok": bool(counters_ok and bytes_ok and state_ok and snap["selfcheck"] == 0 and bytes_checked > 0),
+            "batches_replayed": nb, "counters": bool(counters_ok), "decision_bytes_of_last_batches": bool(bytes_ok),
+            "batches_compared_bytewise": bytes_checked, "resident_state_all_keys": state_ok, "selfcheck": snap["selfcheck"],
+            "oracle_allowed": allowed, "engine_allowed": c["allowed"], "seconds": time.perf_counter() - t0}
 
 
 def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",), piped=True, nows=None):
@@ -247,13 +317,15 @@ def roofline_entry(kernel, avg_ms, alg, ms_per_step, traffic, source):
     return r
 
 
-def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, general=False, profile=True):
-    """One engine, one request stream: warmup + timed region (pipelined), then the per-kernel profile.
-    general: every request carries its own timestamp (k_eval_general instead of k_eval_sorted)."""
+def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, general=False, profile=True, plans=None):
+    """One engine, one request stream: warmup + timed region (pipelined), the oracle replay of exactly those batches, then
+    the per-kernel profile.  general: every request carries its own timestamp (k_eval_general instead of k_eval_sorted).
+    plans: None / "one" = one registered plan for the table; "tiers4" / "tiers1000" = a plan per key (plan_tiers)."""
     import torch
+    plans = a.plans if plans is None else plans
     eng = t.Engine(a.keys, a.batch, device=local, fixed_params=(a.layout == "fixed"))
     eng.use_torch_stream()
-    eng.register_params_uniform(*W.REF_PARAMS)
+    per_slot = register_plans(eng, plans, a.keys)
     nb = a.steps + a.warmup
     host_batches = make_batches(stream, a.keys, a.batch, min(nb, 64), seed_shift=seed_shift)
     d_batches = [torch.from_numpy(b.astype(np.int32)).to(dev) for b in host_batches]
@@ -272,15 +344,29 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
     alg = (ALG_BYTES_GENERAL if general else ALG_BYTES_PER_DECISION) * a.batch
     res = {"value": a.steps * a.batch * world / dt, "unit": "decisions/s", "ms_per_step": ms,
            "allowed_fraction": c["allowed"] / max(1, c["total"]), "whole_step_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    if plans not in (None, "one"):
+        res["plans"] = plans
+    if rank == 0 and dist is None and seed_shift == 0 and not a.no_verify and not a.profile_run and not a.in_order and nb <= 400:
+        # what the timed run left behind, taken before anything else touches the engine: counters, the result arrays of the
+        # last batches, the state of every key -- compared with the oracle's replay of the same nb batches
+        snap = {"batches": nb, "counters": c, "selfcheck": eng.selfcheck(), "state": eng.read_state(0, a.keys),
+                "ring": {i: out[i % OUT_RING].allowed.cpu().numpy()[:a.batch].copy() for i in range(max(0, nb - OUT_RING), nb)}}
+        try:
+            res["verified"] = verify_run(snap, host_batches, len(nows) if nows else 0, per_slot, a.keys, a.batch, general)
+        except Exception as ex:  # noqa: BLE001 (the checker must not take the measurement down with it)
+            res["verified"] = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:160]}
+        del snap
+        log(f"  verified: {res['verified']}")
     if rank == 0 and profile and not a.profile_run:
         piped = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True, nows=nows)
         inorder = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False, nows=nows)
         tag = ("general_" if general else "") + stream
+        lay = a.layout + ("" if plans in (None, "one") else "_" + plans)   # (PMC summaries of per-key-plan runs carry the tier count)
         # The critical-path kernel of the pipelined run is the evaluation on the engine's stream (the grouping of later
         # batches runs beside it on the auxiliary streams): its average launch duration as timed in the pipelined
         # configuration is the roofline's avg_ms.
         ev = piped.get("eval") or piped.get("bucket_eval")
-        tr, src = pmc_traffic("eval_general" if general else "eval", tag, a.layout, 1.0)
+        tr, src = pmc_traffic("eval_general" if general else "eval", tag, lay, 1.0)
         if ev:  # (no record: the launch went untimed -- the line then carries no roofline rather than a made-up one)
             # (pipelined, decisions only, every run regular: the evaluation the engine launches is the lean variant)
             kname = "ev::k_eval_general" if general else ("ev::k_eval_sorted_lean" if ev["kernel"] == "ev::k_eval_sorted" else ev["kernel"])
@@ -289,8 +375,8 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
                       "traffic": (src or {}).get("file")}
             res["roofline"] = roofline_entry(kname, ev["avg_ms"], alg, ms, tr, source)
         gated = ("prep", "sort", "eval") if "bucket_eval" in inorder else ()
-        res["detail"] = {"stages": {"pipelined": stage_table(piped, alg, tag, a.layout),
-                                    "in_order": stage_table(inorder, alg, tag, a.layout, gated=gated)},
+        res["detail"] = {"stages": {"pipelined": stage_table(piped, alg, tag, lay),
+                                    "in_order": stage_table(inorder, alg, tag, lay, gated=gated)},
                          "in_order_sum_ms": sum(s["per_batch_ms"] for s in inorder.values()),
                          "traffic_source": src}
     return res, eng, d_batches, dt
@@ -855,6 +941,13 @@ def main():
                    "pipelined": not a.in_order},
         "allowed_fraction": main_res["allowed_fraction"],
     }
+    if a.plans != "one":
+        result["config"]["plans"] = a.plans
+        result["config"]["workload"] += f", a plan per key ({a.plans})"
+    # every leg that was replayed through the oracle: name -> ok; `verified` = all of them
+    verified = {}
+    if "verified" in main_res:
+        verified["headline"] = main_res["verified"]
     detail = {"headline": main_res.pop("detail", None),
               "notes": {"resident_state": {"fixed": "TC_CFG_FIXED_PARAMS: TAT column, 8 B per key + the plan dictionary (emission interval, "
                                                     "tolerance, burst capacity per plan)",
@@ -885,6 +978,8 @@ def main():
                 o_res, held["eng2"], held["ob"], _ = measure_stream(a, t, W, other, dev, local, 0, 0, None, 1)
                 detail[f"{other}_stream"] = o_res.pop("detail", None)
                 result[f"{other}_stream"] = o_res
+                if "verified" in o_res:
+                    verified[f"{other}_stream"] = o_res["verified"]
 
             def other_layout():  # the headline stream on the other resident-state layout
                 a2 = argparse.Namespace(**vars(a))
@@ -893,6 +988,8 @@ def main():
                 eng_l.close()
                 detail[f"{a2.layout}_layout"] = l_res.pop("detail", None)
                 result[f"{a2.layout}_layout"] = l_res
+                if "verified" in l_res:
+                    verified[f"{a2.layout}_layout"] = l_res["verified"]
 
             def general_of(gs):  # what a server's queue looks like: a timestamp per request (k_eval_general)
                 def run():
@@ -900,7 +997,25 @@ def main():
                     eng_g.close()
                     detail[f"general_{gs}"] = g_res.pop("detail", None)
                     result[f"general_{gs}"] = g_res
+                    if "verified" in g_res:
+                        verified[f"general_{gs}"] = g_res["verified"]
                 return run
+
+            def per_key_plans():
+                # the path north_star describes: (burst, count, period) live PER KEY (rate_limiter.rs:102-123 takes them per
+                # call); the evaluation gathers rate_id[slot] and the plan's (emission interval, tolerance) for every request
+                pk = {}
+                for st_ in ("uniform", "zipf"):
+                    for pl in ("tiers4", "tiers1000"):
+                        if a.plans == pl and st_ == stream:
+                            continue
+                        p_res, eng_p, _, _ = measure_stream(a, t, W, st_, dev, local, 0, 0, None, 1, plans=pl)
+                        eng_p.close()
+                        detail[f"per_key_{st_}_{pl}"] = p_res.pop("detail", None)
+                        pk[f"{st_}_{pl}"] = p_res
+                        if "verified" in p_res:
+                            verified[f"per_key_{st_}_{pl}"] = p_res["verified"]
+                result["per_key_plans"] = pk
 
             def output_forms():
                 if "eng2" in held:
@@ -912,6 +1027,7 @@ def main():
                 result["string_keys"] = {k: v for k, v in sk.items() if isinstance(v, dict)}
 
             leg(f"other stream: {other}", other_stream)
+            leg("per-key plans", per_key_plans)
             leg("other layout", other_layout)
             for gs in ("uniform", "zipf"):
                 if not (general and gs == stream):
@@ -927,6 +1043,13 @@ def main():
         if errors:
             detail["errors"] = errors
             result["errors"] = sorted(errors)
+        if verified:
+            detail["verified"] = verified
+            result["verified"] = all(v.get("ok") for v in verified.values())
+            result["verified_legs"] = len(verified)                                        # how many legs were replayed
+            result["verify_failed"] = sorted(k for k, v in verified.items() if not v.get("ok"))   # ... and which of them differ
+        else:
+            result["verified"] = None   # (--no-verify / --profile-run: nothing was replayed)
         emit(result, detail)
     eng.close()
 
@@ -968,7 +1091,8 @@ def compact_line(result):
     baseline, and one number (+ its whole-step roofline fraction) per secondary workload.  Everything else lives in
     bench_detail.json.  Never longer than COMPACT_LIMIT bytes."""
     top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-           "dtype", "data", "config", "allowed_fraction", "imbalance_max_over_mean", "router_ms_per_step", "route", "errors")
+           "dtype", "data", "config", "allowed_fraction", "imbalance_max_over_mean", "router_ms_per_step", "route", "errors",
+           "verified", "verified_legs", "verify_failed")
     c = _pick(result, top)
     rf = result.get("roofline")
     if rf:
@@ -995,6 +1119,14 @@ def compact_line(result):
             if r2 and r2.get("frac") is not None and "invalid" not in r2:
                 c[k]["kernel_frac"] = r2["frac"]
                 c[k]["kernel_ms"] = r2["avg_ms"]
+    if isinstance(result.get("per_key_plans"), dict):
+        c["per_key_plans"] = {}
+        for k, v in result["per_key_plans"].items():
+            c["per_key_plans"][k] = _pick(v, ("value", "ms_per_step"))
+            r2 = v.get("roofline")
+            if r2 and r2.get("frac") is not None and "invalid" not in r2:
+                c["per_key_plans"][k]["kernel_ms"] = r2["avg_ms"]
+                c["per_key_plans"][k]["kernel_frac"] = r2["frac"]
     if isinstance(result.get("string_keys"), dict):
         c["string_keys"] = {k: _pick(v, one + ("launches_per_batch",)) for k, v in result["string_keys"].items() if isinstance(v, dict)}
     if isinstance(result.get("per_gpu"), list):
@@ -1003,7 +1135,7 @@ def compact_line(result):
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > COMPACT_LIMIT:  # shed the optional parts, largest first, rather than break the contract
-        for k in ("per_gpu", "string_keys", "general_uniform", "fixed_layout", "wide_layout", "allowed_fraction"):
+        for k in ("per_gpu", "string_keys", "per_key_plans", "general_uniform", "general_zipf", "fixed_layout", "wide_layout", "allowed_fraction"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= COMPACT_LIMIT:

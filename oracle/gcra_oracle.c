@@ -482,6 +482,15 @@ void tco_dense_peek(const tco_dense* d, uint32_t slot, int64_t* tat, uint64_t* e
     *expiry_sat = c->expiry > (u128)UINT64_MAX ? UINT64_MAX : (uint64_t)c->expiry;
     *occupied = c->occupied;
 }
+/* the same for a range of slots (bulk comparison of the whole resident state at full size) */
+void tco_dense_dump(const tco_dense* d, size_t first, size_t n, int64_t* tat, uint64_t* expiry_sat, uint8_t* occupied) {
+    for (size_t i = 0; i < n && first + i < d->capacity; i++) {
+        const dn_cell* c = &d->cells[first + i];
+        tat[i] = c->val;
+        expiry_sat[i] = c->expiry > (u128)UINT64_MAX ? UINT64_MAX : (uint64_t)c->expiry;
+        occupied[i] = c->occupied;
+    }
+}
 uint64_t tco_dense_sweep(tco_dense* d, int64_t now) {
     uint64_t removed = 0;
     for (size_t i = 0; i < d->capacity; i++) {
@@ -531,6 +540,43 @@ void tco_batch_slots(tco_store* st, const uint32_t* slot, const tco_batch_io* io
         tco_rate_limit(st, k, 4, IO_ARGS(io, i), &r);
         io_store(io, i, &r);
     }
+}
+
+/* The same over `threads` threads (a CHECKER for full-size GPU tests, not a baseline): thread t serves the requests
+ * whose slot is congruent to t, in index order.  Requests of different keys never touch the same cell, so every
+ * key still sees its requests one by one in queue order and the results equal tco_batch_slots'. */
+typedef struct {
+    int tid, threads;
+    tco_store* st;
+    const uint32_t* slot;
+    const tco_batch_io* io;
+} ds_arg;
+static void* ds_worker(void* p) {
+    ds_arg* a = (ds_arg*)p;
+    const tco_batch_io* io = a->io;
+    for (size_t i = 0; i < io->n; i++) {
+        if ((int)(a->slot[i] % (uint32_t)a->threads) != a->tid) continue;
+        tco_result r;
+        uint8_t k[4];
+        memcpy(k, &a->slot[i], 4);
+        tco_rate_limit(a->st, k, 4, IO_ARGS(io, i), &r);
+        io_store(io, i, &r);
+    }
+    return NULL;
+}
+void tco_batch_slots_mt(tco_store* st, const uint32_t* slot, const tco_batch_io* io, int threads) {
+    if (threads <= 1) {
+        tco_batch_slots(st, slot, io);
+        return;
+    }
+    if (threads > 256) threads = 256;
+    pthread_t th[256];
+    ds_arg args[256];
+    for (int t = 0; t < threads; t++) {
+        args[t].tid = t; args[t].threads = threads; args[t].st = st; args[t].slot = slot; args[t].io = io;
+        pthread_create(&th[t], NULL, ds_worker, &args[t]);
+    }
+    for (int t = 0; t < threads; t++) pthread_join(th[t], NULL);
 }
 
 /* ---- hash-sharded multi-thread baseline -----------------------------------

@@ -107,6 +107,8 @@ void tco_dense_free(tco_dense*);
 tco_store tco_dense_as_store(tco_dense*);
 /* raw cell access for differential tests: expiry saturated to u64 */
 void tco_dense_peek(const tco_dense*, uint32_t slot, int64_t* tat, uint64_t* expiry_sat, int* occupied);
+/* ... of slots [first, first + n) at once */
+void tco_dense_dump(const tco_dense*, size_t first, size_t n, int64_t* tat, uint64_t* expiry_sat, uint8_t* occupied);
 /* cleanup(): vacate every cell with expiry <= now; returns how many */
 uint64_t tco_dense_sweep(tco_dense*, int64_t now);
 size_t tco_dense_live(const tco_dense*);
@@ -134,6 +136,8 @@ void tco_batch_keys(tco_store* st, const uint8_t* key_bytes, const uint32_t* key
                     const tco_batch_io* io);
 /* slots: key i is the 4-byte little-endian slot id */
 void tco_batch_slots(tco_store* st, const uint32_t* slot, const tco_batch_io* io);
+/* tco_batch_slots over `threads` threads, requests partitioned by slot (same results; full-size GPU tests) */
+void tco_batch_slots_mt(tco_store*, const uint32_t* slot, const tco_batch_io*, int threads);
 
 /* Hash-sharded multi-thread CPU baseline: T AdaptiveStores, key i handled by
  * thread (hash(key) % T); each thread walks the whole stream in index order

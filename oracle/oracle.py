@@ -84,12 +84,14 @@ def lib():
     L.tco_dense_as_store.restype = _Store
     L.tco_dense_as_store.argtypes = [C.c_void_p]
     L.tco_dense_peek.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_int64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
+    L.tco_dense_dump.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.tco_dense_sweep.restype = C.c_uint64
     L.tco_dense_sweep.argtypes = [C.c_void_p, C.c_int64]
     L.tco_dense_live.restype = C.c_size_t
     L.tco_dense_live.argtypes = [C.c_void_p]
     L.tco_batch_keys.argtypes = [C.POINTER(_Store), C.c_void_p, C.c_void_p, C.POINTER(_BatchIO)]
     L.tco_batch_slots.argtypes = [C.POINTER(_Store), C.c_void_p, C.POINTER(_BatchIO)]
+    L.tco_batch_slots_mt.argtypes = [C.POINTER(_Store), C.c_void_p, C.POINTER(_BatchIO), C.c_int]
     L.tco_batch_keys_mt.restype = C.c_double
     L.tco_batch_keys_mt.argtypes = [C.c_int, C.c_size_t, C.c_uint64, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(_BatchIO)]
     L.tco_reference_shape.restype = C.c_double
@@ -262,10 +264,15 @@ class DenseOracle(_StoreBase):
             lib().tco_dense_free(self._h)
             self._h = None
 
-    def batch_slots(self, slots: np.ndarray, burst, count, period, quantity, now) -> BatchOut:
+    def batch_slots(self, slots: np.ndarray, burst, count, period, quantity, now, threads: int = 1) -> BatchOut:
+        """threads > 1: requests partitioned by slot over that many threads -- same results (keys are independent, a
+        key's requests stay in index order), for the full-size tests"""
         sl = np.ascontiguousarray(slots, dtype=np.uint32)
         io, out, keep = _make_io(len(sl), burst, count, period, quantity, now)
-        lib().tco_batch_slots(C.byref(self._st), sl.ctypes.data, C.byref(io))
+        if threads > 1:
+            lib().tco_batch_slots_mt(C.byref(self._st), sl.ctypes.data, C.byref(io), threads)
+        else:
+            lib().tco_batch_slots(C.byref(self._st), sl.ctypes.data, C.byref(io))
         return out
 
     def peek(self, slot: int):
@@ -273,11 +280,30 @@ class DenseOracle(_StoreBase):
         lib().tco_dense_peek(self._h, slot, C.byref(t), C.byref(e), C.byref(o))
         return t.value, e.value, bool(o.value)
 
+    def dump(self, first: int = 0, n: Optional[int] = None):
+        """-> (tat int64[n], expiry uint64[n] saturated, occupied bool[n]) of slots [first, first + n)"""
+        n = self.capacity - first if n is None else n
+        tat, exp, occ = np.zeros(n, np.int64), np.zeros(n, np.uint64), np.zeros(n, np.uint8)
+        lib().tco_dense_dump(self._h, first, n, tat.ctypes.data, exp.ctypes.data, occ.ctypes.data)
+        return tat, exp, occ.astype(bool)
+
     def sweep(self, now_ns: int) -> int:
         return int(lib().tco_dense_sweep(self._h, now_ns))
 
     def live(self) -> int:
         return int(lib().tco_dense_live(self._h))
+
+
+def host_threads(limit: int = 16) -> int:
+    """threads this process may actually run (CPU set and cgroup quota), at most `limit`"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(float(q) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, limit))
 
 
 def batch_keys_mt(threads: int, capacity_per_thread: int, created_ns: int, key_bytes, key_off,

@@ -25,6 +25,8 @@ def canned():
                    "keys_per_gpu": 10_000_000, "batch": 1 << 20, "stream": "uniform", "resident_state": "fixed", "pipelined": True},
         "allowed_fraction": 0.999, "roofline": rf,
         "zipf_stream": dict(one), "wide_layout": dict(one), "general_uniform": dict(one), "general_zipf": dict(one),
+        "per_key_plans": {f"{st}_{pl}": dict(one, plans=pl) for st in ("uniform", "zipf") for pl in ("tiers4", "tiers1000")},
+        "verified": True, "verified_legs": 9, "verify_failed": [],
         "string_keys": {"key_%d": dict(one, launches_per_batch=6.0), "ascii_32_64": dict(one, launches_per_batch=6.0),
                         "workload": "a long description " * 20},
         "cpu_baseline": {"value": 1.81e6, "unit": "decisions/s", "cores": 1, "kind": "port", "sample": "first 8 batches " * 30,
@@ -99,3 +101,58 @@ def test_stage_table_gives_no_rate_to_partial_launches():
     out = bench.stage_table(st, 37.9e6, "uniform", "fixed")
     assert "achieved_GBs" not in out["bucket_scatter"] and "note" in out["bucket_scatter"]
     assert out["eval"]["achieved_GBs"] > 0
+
+
+def test_compact_line_carries_the_oracle_verdict_and_the_per_key_plan_legs():
+    d = json.loads(bench.compact_line(canned()))
+    assert d["verified"] is True and d["verified_legs"] == 9 and d["verify_failed"] == []
+    pk = d["per_key_plans"]
+    assert set(pk) == {"uniform_tiers4", "uniform_tiers1000", "zipf_tiers4", "zipf_tiers1000"}
+    for v in pk.values():
+        assert v["value"] > 0 and v["ms_per_step"] > 0 and 0 < v["kernel_frac"] <= 1
+
+
+def test_plan_tiers_are_valid_distinct_and_spread():
+    import numpy as np
+    from oracle import oracle as O
+    for kind, T in (("tiers4", 4), ("tiers1000", 1000)):
+        tiers, tier_of = bench.plan_tiers(kind, 200_000)
+        assert tiers.shape == (T, 3) and len({tuple(r) for r in tiers.tolist()}) == T
+        assert tuple(tiers[0]) == (100, 1000, 3600)
+        assert tier_of.max() == T - 1 and np.bincount(tier_of, minlength=T).min() > 0
+        for b, c, p in tiers.tolist():
+            st, ei, dvt = O.derive(b, c, p, 0)
+            assert st == 0 and b >= 2 and 0 < ei <= dvt < 2**60   # what TC_CFG_FIXED_PARAMS asks of a plan (tc::fixed_plan_ok)
+
+
+def test_verify_run_accepts_the_oracle_and_rejects_a_flipped_decision():
+    """the bench's checker itself, fed with an 'engine' that is the oracle (and then with one wrong byte / one wrong TAT)"""
+    import numpy as np
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    keys, batch, nb = 5000, 4096, 6
+    z = W.Zipf(keys)
+    host = [z.slots(batch, start=i * batch) for i in range(4)]          # (the stream wraps: batch i uses host[i % 4])
+    tiers, tier_of = bench.plan_tiers("tiers4", keys)
+    per_slot = tiers[tier_of]
+    orc = O.DenseOracle(keys)
+    ring, allowed = {}, 0
+    for i in range(nb):
+        pr = per_slot[host[i % 4]]
+        r = orc.batch_slots(host[i % 4], pr[:, 0], pr[:, 1], pr[:, 2], 1, W.T0_NS + i * 1_000_000)
+        allowed += int(r.allowed.sum())
+        if i >= nb - 3:
+            ring[i] = r.allowed.copy()
+    tat, exp, occ = orc.dump()
+    exp = np.where(occ, exp, 0).astype(np.uint64)
+    snap = {"batches": nb, "selfcheck": 0, "state": (tat, exp), "ring": ring,
+            "counters": {"allowed": allowed, "denied": nb * batch - allowed, "errors": 0, "total": nb * batch}}
+    v = bench.verify_run(snap, host, 0, per_slot, keys, batch, False)
+    assert v["ok"] and v["batches_compared_bytewise"] == 3 and 0 < v["oracle_allowed"] < nb * batch
+    bad = dict(snap, ring={k: a.copy() for k, a in ring.items()})
+    bad["ring"][nb - 1][17] ^= 1
+    assert not bench.verify_run(bad, host, 0, per_slot, keys, batch, False)["ok"]
+    t2 = tat.copy()
+    t2[int(np.flatnonzero(occ)[0])] += 1
+    assert not bench.verify_run(dict(snap, state=(t2, exp)), host, 0, per_slot, keys, batch, False)["ok"]
+    assert not bench.verify_run(dict(snap, counters=dict(snap["counters"], allowed=allowed - 1)), host, 0, per_slot, keys, batch, False)["ok"]

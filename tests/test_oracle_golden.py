@@ -109,3 +109,27 @@ def test_cleanup_is_not_neutral_when_time_goes_back():
     assert b.rate_limit(b"k", 1, 1, 1, 1, t1)[1] is True
     b.force_cleanup(t1)
     assert b.rate_limit(b"k", 1, 1, 1, 1, t0)[1] is True
+
+
+def test_partitioned_dense_driver_equals_the_sequential_one():
+    """tco_batch_slots_mt (requests partitioned by slot over threads: the checker of the full-size GPU tests) gives the
+    results and the state of the one-by-one pass -- hot keys, per-request timestamps going back, error requests"""
+    import numpy as np
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    cap, n = 3000, 40_000
+    a, b = O.DenseOracle(cap), O.DenseOracle(cap)
+    t0 = KAT["t0_ns"]
+    for rnd in range(4):
+        slots = rng.integers(0, cap + 3, n).astype(np.uint32)            # (a few out of range: status Internal)
+        hot = rng.random(n) < 0.6
+        slots[hot] = rng.integers(0, 4, int(hot.sum()))
+        now = t0 + rnd * 10**9 + rng.integers(-10**8, 10**9, n)
+        q = rng.choice(np.array([0, 1, 1, 2, -1], dtype=np.int64), n)
+        burst = rng.choice(np.array([1, 2, 5, 100, 0], dtype=np.int64), n)
+        ra = a.batch_slots(slots, burst, 10, 60, q, now)
+        rb = b.batch_slots(slots, burst, 10, 60, q, now, threads=7)
+        for f, x in ra.fields().items():
+            assert np.array_equal(x, rb.fields()[f]), (rnd, f)
+    for x, y in zip(a.dump(), b.dump()):
+        assert np.array_equal(x, y)

@@ -7,6 +7,7 @@ TAG=${1:-r02}
 shift
 CONFIGS=${@:-uniform_fixed uniform_wide zipf_fixed string_keys string_keys_long}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
+export TC_GIT_SHA=${TC_GIT_SHA:-$(cat $R/.git_sha 2>/dev/null || echo unknown)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 export TMPDIR=/tmp
@@ -21,6 +22,9 @@ for C in $CONFIGS; do
     uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     uniform_fixed_bucket) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --in-order" ;;
     uniform_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    uniform_fixed_tiers4) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --plans tiers4"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    uniform_fixed_tiers1000) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --plans tiers1000"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    zipf_fixed_tiers1000) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf --plans tiers1000"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload zipf"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     general_uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
