@@ -127,6 +127,25 @@ int engine_alloc(tc_engine* e) {
         TC_HIP(e, hipHostGetDevicePointer(&dv, e->fill_hint_host, 0));
         e->fill_hint_dev = (uint32_t*)dv;
     }
+    {
+        // range path: 256 ranges of the key space; a slot's offset inside its range must fit 16 bits
+        if (const char* d = getenv("TCGPU_RANGE")) e->range_mode = atoi(d);
+        e->range_max_n = (uint32_t)(rs::FIN_CAP * 256ull * 3ull / 4ull); // mean range 3/4 of what a block finishes in LDS
+        if (const char* d = getenv("TCGPU_RANGE_MAX_N")) e->range_max_n = (uint32_t)std::max(atoll(d), 1ll);
+        if (e->range_mode != 0 && cap > 65536 && cap < 0xFFFFFFFFull) {
+            e->range_mul = rs::range_mul((uint32_t)cap);
+            const uint32_t width = rs::range_width(e->range_mul);
+            if (width <= 65536u) {
+                e->range_sub_passes = width <= 256u ? 1 : 2;
+                e->range_ok = true;
+                TC_HIP(e, hipHostMalloc((void**)&e->range_hint_host, 64, hipHostMallocDefault));
+                *e->range_hint_host = 0ull;
+                void* dv = nullptr;
+                TC_HIP(e, hipHostGetDevicePointer(&dv, e->range_hint_host, 0));
+                e->range_hint_dev = (unsigned long long*)dv;
+            }
+        }
+    }
     if (const char* d = getenv("TCGPU_SORT_ITEMS_PIPED")) {
         const int v = atoi(d);
         if (v == 8 || v == 16 || v == 32) e->sort_items_piped = v;
@@ -397,6 +416,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     }
     if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
+    if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
     if (e->poison_host) (void)hipHostFree(e->poison_host);
     if (e->k_done) (void)hipEventDestroy(e->k_done);
     if (e->m_done) (void)hipEventDestroy(e->m_done);

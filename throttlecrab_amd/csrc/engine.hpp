@@ -145,6 +145,14 @@ struct tc_engine {
     bool eval_lean = true;      // k_eval_sorted_lean for decisions-only batches (TCGPU_EVAL_LEAN=0: the general kernel)
     bool stop_events = true;    // events ride on kernels' completion signals instead of marker packets (TCGPU_STOP_EVENTS=0: hipEventRecord)
     bool prefill_on = true;     // TC_B_OUTPUTS_IDLE batches: decision bytes preset on the grouping stream (TCGPU_PREFILL=0: off)
+    // range path (radix_sort.hpp): one partition pass by key range + an in-LDS finish instead of three LSD passes
+    int range_mode = 2;                  // TCGPU_RANGE: 0 off, 1 pipelined batches only, 2 every batch
+    bool range_ok = false;               // the key space fits (more than 65536 keys, widest range <= 65536 slots)
+    uint32_t range_mul = 0;
+    int range_sub_passes = 0;            // 8-bit digits of a slot's offset inside its range
+    uint32_t range_max_n = 0;            // batches above this are sorted (TCGPU_RANGE_MAX_N)
+    unsigned long long* range_hint_host = nullptr; // pinned: n << 32 | largest range of a recent batch, written by the first pass
+    unsigned long long* range_hint_dev = nullptr;
     uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting
     uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
     bool debug_nostore = false; // TCGPU_DEBUG_NO_DECISION_STORE=1: MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)

@@ -64,6 +64,34 @@ struct Workspace {
     unsigned long long* violations; // the engine's invariant counter (a look-back that outlasts tc::SPIN_LIMIT_TICKS)
 };
 
+// ---- the range path (round 4): ONE pass over global memory + one in-LDS finish ------------------------------------
+// A 1 Mi batch over 10 M slots needs 24 key bits = three LSD passes, each a launch with a look-back chain (19 us alone,
+// 25-35 us beside the other streams): the grouping chain, not the evaluation, set the pace of the pipeline.  The range
+// path cuts the key space into 256 equal RANGES (digit = umulhi(slot, mul): monotone in the slot, so range r holds the
+// slots [range_lo(r), range_lo(r + 1))), partitions the batch by range with the same one-sweep kernel (stable: inside a
+// range the requests keep their index order) and lets ONE 1024-thread block per range finish it without leaving the CU:
+// the range's <= FIN_CAP elements are sorted by their offset inside the range (<= 16 bits: two 8-bit passes with ballot
+// ranking) in LDS and written out as the same sorted (slot << 32 | index) array the three passes produce.  No look-back,
+// no status words, two launches fewer.  A range that holds more than FIN_CAP elements (a skewed batch the host did not
+// foresee: it chooses the path from the largest range of a RECENT batch, mirrored into pinned memory) is sorted by its
+// block through global memory, slowly but exactly; streams that are skewed stay on the three LSD passes.
+constexpr int FIN_THREADS = 1024;
+constexpr int FIN_WAVES = FIN_THREADS / 64;
+constexpr int FIN_ITEMS = 8;
+constexpr uint32_t FIN_CAP = FIN_THREADS * FIN_ITEMS; // elements of a range that are finished in LDS
+constexpr uint32_t FIN_POS_BITS = 13;                  // FIN_CAP == 1 << FIN_POS_BITS
+constexpr int FIN_ROW = RADIX + 1;                     // per-wave counter rows, padded against bank conflicts
+constexpr int MSD_ROW = MAX_PASSES - 1;                // histogram row of the range digit when k_hist counts it beside the LSD digits
+static_assert(FIN_CAP == (1u << FIN_POS_BITS), "positions inside a range must fit FIN_POS_BITS");
+
+// digit = umulhi(slot, mul) with mul = floor(256 * 2^32 / (cap + 1)): < 256 for every slot <= cap (cap itself is the
+// sentinel of out-of-range slots).  Needs cap + 1 > 256.
+__host__ __device__ inline uint32_t range_mul(uint32_t cap) { return (uint32_t)((256ull << 32) / ((uint64_t)cap + 1ull)); }
+// smallest slot whose digit is >= d:  slot * mul >= d * 2^32
+__host__ __device__ inline uint32_t range_lo(uint32_t d, uint32_t mul) { return (uint32_t)((((uint64_t)d << 32) + mul - 1u) / mul); }
+// widest range (slots), conservatively
+__host__ __device__ inline uint32_t range_width(uint32_t mul) { return (uint32_t)((1ull << 32) / mul) + 2u; }
+
 __host__ __device__ inline uint32_t groups_of(uint32_t tiles) { return (tiles + GROUP - 1) / GROUP; }
 __host__ __device__ inline size_t pass_status_words(uint32_t max_tiles, uint32_t max_groups) {
     return ((size_t)max_tiles + 2 * (size_t)max_groups) * RADIX;
@@ -100,10 +128,14 @@ __device__ __forceinline__ bool gated_off(const uint32_t* __restrict__ gate, uin
 
 // `fill` (TC_B_OUTPUTS_IDLE batches): the batch's decision bytes, set to fill_value here, ahead of the evaluation,
 // which then only stores the decisions that differ (16-byte stores; the tail bytewise)
+// `msd_mul` != 0: the range digit umulhi(slot, msd_mul) is counted too -- msd_only: INSTEAD of the LSD digits, into row 0
+// (the range path: `passes` is 1, one pass's look-back words are cleared); else beside them, into row MSD_ROW (passes <= 3),
+// from which the first LSD pass mirrors the largest range to the host (the hint the path is chosen by)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
                                                   int passes, Workspace ws, uint32_t tiles, const uint32_t* __restrict__ gate,
-                                                  uint32_t gate_min, uint8_t* __restrict__ fill, uint32_t fill_value) {
+                                                  uint32_t gate_min, uint8_t* __restrict__ fill, uint32_t fill_value,
+                                                  uint32_t msd_mul, int msd_only) {
     __shared__ uint32_t s_h[MAX_PASSES][RADIX];
     if (fill != nullptr) {
         const uint32_t v4 = fill_value * 0x01010101u;
@@ -155,16 +187,28 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t kk = clamp_slot(k[u], cap);
-                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+                if (msd_only) {
+                    atomicAdd(&s_h[0][__umulhi(kk, msd_mul)], 1u);
+                } else {
+                    for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+                    if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
+                }
             }
         }
         for (; i < n; i += stride) {
             const uint32_t kk = clamp_slot(slot[i], cap);
-            for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+            if (msd_only) {
+                atomicAdd(&s_h[0][__umulhi(kk, msd_mul)], 1u);
+            } else {
+                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+                if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
+            }
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < passes * RADIX; i += NT) {
+    for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) {
+        const int row = i / RADIX;
+        if (!(row < passes || (!msd_only && msd_mul && row == MSD_ROW))) continue;
         const uint32_t v = (&s_h[0][0])[i];
         if (v) atomicAdd(&ws.hist[i], v);
     }
@@ -173,11 +217,15 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
 // ---------------------------------------------------------------------------
 // one LSD pass.  FIRST: input is the raw slot column (value = position).
 // ---------------------------------------------------------------------------
-template <int ITEMS, bool FIRST>
+// MSD (with FIRST, pass 0): the digit is the RANGE of the slot, umulhi(slot, msd_mul) -- the partition pass of the range path.
+// `range_hint` (block 0 of a pass that has the range histogram at hand: the MSD pass itself, row 0; the first LSD pass
+// when k_hist counted the ranges beside the LSD digits, row MSD_ROW): n << 32 | largest range, into pinned host memory.
+template <int ITEMS, bool FIRST, bool MSD = false>
 __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict__ slot_in,
                                                       const uint64_t* __restrict__ elem_in,
                                                       uint64_t* __restrict__ elem_out, uint32_t n, uint32_t cap,
-                                                      int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min) {
+                                                      int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min,
+                                                      uint32_t msd_mul, unsigned long long* __restrict__ range_hint) {
     constexpr int TILE = THREADS * ITEMS;
     if (gated_off(gate, gate_min)) return; // (the whole grid: nobody is left waiting in a look-back)
     __shared__ uint32_t s_base[RADIX];          // global exclusive start of each digit
@@ -195,6 +243,17 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
     if (threadIdx.x == 0) s_tile = (gridDim.x <= RESIDENT_TILES) ? blockIdx.x : atomicAdd(&ws.ticket[pass], 1u);
     for (int i = threadIdx.x; i < WAVES * RADIX; i += THREADS) (&s_wave[0][0])[i] = 0;
 
+    if (range_hint != nullptr && blockIdx.x == 0) { // (block-uniform)
+        uint32_t m = ws.hist[(MSD ? 0 : MSD_ROW) * RADIX + threadIdx.x];
+        for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+        if (lane == 0) s_scan[wave] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < WAVES; ++w) m = max(m, s_scan[w]);
+            __hip_atomic_store(range_hint, ((unsigned long long)n << 32) | m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+    }
     // exclusive scan of the batch histogram of this pass's digit (RADIX == THREADS)
     {
         const uint32_t h = ws.hist[pass * RADIX + threadIdx.x];
@@ -243,7 +302,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool valid = (wbase + j * 64) < n;
-        const uint32_t d = (key[j] >> shift) & 255u;
+        const uint32_t d = MSD ? (valid ? __umulhi(key[j], msd_mul) : 255u) : ((key[j] >> shift) & 255u);
         unsigned long long m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -300,7 +359,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if ((wbase + j * 64) < n) {
-            const uint32_t d = (key[j] >> shift) & 255u;
+            const uint32_t d = MSD ? __umulhi(key[j], msd_mul) : ((key[j] >> shift) & 255u);
             s_elem[s_tstart[d] + s_wave[wave][d] + rank[j]] = ((uint64_t)key[j] << 32) | val[j];
         }
     }
@@ -395,10 +454,224 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
         const uint32_t i = j * THREADS + threadIdx.x;
         if (i < nvalid) {
             const uint64_t e = s_elem[i];
-            const uint32_t d = ((uint32_t)(e >> 32) >> shift) & 255u;
+            const uint32_t d = MSD ? __umulhi((uint32_t)(e >> 32), msd_mul) : (((uint32_t)(e >> 32) >> shift) & 255u);
             elem_out[i + s_off[d]] = e;
         }
     }
+}
+
+// ---------------------------------------------------------------------------
+// range path, second half: one block per range sorts the range by the slot's offset inside it
+// ---------------------------------------------------------------------------
+// a load that is served by the L2, not by this CU's vector cache (which may still hold the line from before this block's own
+// stores to it went through)
+__device__ __forceinline__ uint64_t ld_l2(const uint64_t* p) {
+    return __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// rank the digits of one strip-distributed chunk: every wave ranks its own items with ballots against its counter row
+// (as k_onesweep does), then the rows become exclusive prefixes over the waves and s_tot[] the chunk's digit counts.
+// Wave w holds positions [w * strip, (w + 1) * strip) of the chunk, item j of lane l at w * strip + j * 64 + l, so
+// (wave, item, lane) order is position order: the ranks are stable.  Ends with a barrier.
+template <int ITEMS_>
+__device__ __forceinline__ void fin_rank(const uint32_t (&dig)[ITEMS_], const bool (&valid)[ITEMS_], uint32_t (&rank)[ITEMS_],
+                                         uint32_t (*s_cnt)[FIN_ROW], uint32_t* s_tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < FIN_WAVES * FIN_ROW; i += FIN_THREADS) (&s_cnt[0][0])[i] = 0;
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < ITEMS_; ++j) {
+        if (__ballot(valid[j]) == 0ull) { // (wave-uniform: the strip ended)
+            rank[j] = 0;
+            continue;
+        }
+        const uint32_t d = dig[j];
+        unsigned long long m = __ballot(valid[j]);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const uint32_t before = valid[j] ? s_cnt[wave][d] : 0u;
+        rank[j] = before + (uint32_t)__popcll(m & lt);
+        if (valid[j] && (m & lt) == 0ull) s_cnt[wave][d] = before + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier(); // (same-wave LDS operations execute in program order)
+    }
+    __syncthreads();
+    // exclusive prefix over the 16 waves of every digit: 16 consecutive lanes take one digit's column
+#pragma unroll
+    for (int round = 0; round < RADIX / (FIN_THREADS / FIN_WAVES); ++round) {
+        const int d = round * (FIN_THREADS / FIN_WAVES) + (threadIdx.x >> 4), w = threadIdx.x & 15;
+        const uint32_t v = s_cnt[w][d];
+        uint32_t incl = v;
+#pragma unroll
+        for (int off = 1; off < FIN_WAVES; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, FIN_WAVES);
+            if (w >= off) incl += o;
+        }
+        s_cnt[w][d] = incl - v;
+        if (w == FIN_WAVES - 1) s_tot[d] = incl;
+    }
+    __syncthreads();
+}
+
+// exclusive scan of s_tot[RADIX] into s_start[RADIX] (every thread of the block calls it; ends with a barrier)
+__device__ __forceinline__ void fin_scan_digits(const uint32_t* s_tot, uint32_t* s_start, uint32_t* s_part) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t v = 0, incl = 0;
+    if (threadIdx.x < RADIX) {
+        v = s_tot[threadIdx.x];
+        incl = v;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_part[wave] = incl;
+    }
+    __syncthreads();
+    if (threadIdx.x < RADIX) {
+        uint32_t carry = 0;
+        for (int w = 0; w < wave; ++w) carry += s_part[w];
+        s_start[threadIdx.x] = carry + incl - v;
+    }
+    __syncthreads();
+}
+
+// `elem_in`: the partition pass's output (a range's part of it is scratch for a range that does not fit LDS);
+// `elem_out`: the batch sorted by (slot, index).  One block per range; sub_passes = 8-bit digits of the offset
+// inside a range (1 or 2: the host takes this path only when the widest range is at most 65536 slots).
+static __global__ __launch_bounds__(FIN_THREADS) void k_finish(uint64_t* __restrict__ elem_in, uint64_t* __restrict__ elem_out, uint32_t n,
+                                                        Workspace ws, uint32_t msd_mul, int sub_passes) {
+    __shared__ uint32_t s_idx[FIN_CAP];            // request index of position p (never moves)
+    __shared__ uint32_t s_kv[2][FIN_CAP];          // offset inside the range << FIN_POS_BITS | p, in the order reached so far
+    __shared__ uint32_t s_cnt[FIN_WAVES][FIN_ROW];
+    __shared__ uint32_t s_tot[RADIX];
+    __shared__ uint32_t s_start[RADIX];
+    __shared__ uint32_t s_part[RADIX / 64];
+    __shared__ uint32_t s_base, s_count;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t r = blockIdx.x;
+    // where my range starts in the partitioned batch: exclusive scan of the range histogram (k_hist, row 0)
+    {
+        uint32_t h = 0, incl = 0;
+        if (threadIdx.x < RADIX) {
+            h = ws.hist[threadIdx.x];
+            incl = h;
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t o = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += o;
+            }
+            if (lane == 63) s_part[wave] = incl;
+        }
+        __syncthreads();
+        if (threadIdx.x == r) {
+            uint32_t carry = 0;
+            for (int w = 0; w < wave; ++w) carry += s_part[w];
+            s_base = carry + incl - h;
+            s_count = h;
+        }
+        __syncthreads();
+    }
+    const uint32_t c = s_count, base = s_base;
+    if (c == 0u || base + c > n) return; // (the second test cannot fire: the histogram sums to n)
+    const uint32_t lo = range_lo(r, msd_mul);
+    const uint64_t* in = elem_in + base;
+    uint64_t* out = elem_out + base;
+
+    if (c <= FIN_CAP) {
+        // every wave takes an equal strip of whole 64-position rows, so that all 16 waves work on a half-full range too
+        const uint32_t strip = ((c + FIN_THREADS - 1) / FIN_THREADS) * 64u; // <= 64 * FIN_ITEMS
+        uint32_t kv[FIN_ITEMS], dig[FIN_ITEMS], rank[FIN_ITEMS];
+        bool valid[FIN_ITEMS];
+#pragma unroll
+        for (int j = 0; j < FIN_ITEMS; ++j) {
+            const uint32_t p = (uint32_t)wave * strip + (uint32_t)j * 64u + (uint32_t)lane;
+            valid[j] = (uint32_t)j * 64u < strip && p < c;
+            kv[j] = 0;
+            if (valid[j]) {
+                const uint64_t e = in[p];
+                s_idx[p] = (uint32_t)e;
+                kv[j] = (((uint32_t)(e >> 32) - lo) << FIN_POS_BITS) | p;
+            }
+        }
+        for (int ps = 0; ps < sub_passes; ++ps) {
+            if (ps != 0) {
+#pragma unroll
+                for (int j = 0; j < FIN_ITEMS; ++j) {
+                    const uint32_t p = (uint32_t)wave * strip + (uint32_t)j * 64u + (uint32_t)lane;
+                    if (valid[j]) kv[j] = s_kv[(ps - 1) & 1][p];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < FIN_ITEMS; ++j) dig[j] = (kv[j] >> (FIN_POS_BITS + 8u * (uint32_t)ps)) & 255u;
+            fin_rank<FIN_ITEMS>(dig, valid, rank, s_cnt, s_tot);
+            fin_scan_digits(s_tot, s_start, s_part);
+#pragma unroll
+            for (int j = 0; j < FIN_ITEMS; ++j)
+                if (valid[j]) s_kv[ps & 1][s_start[dig[j]] + s_cnt[wave][dig[j]] + rank[j]] = kv[j];
+            __syncthreads();
+        }
+        const uint32_t* fin = s_kv[(sub_passes - 1) & 1];
+        for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) {
+            const uint32_t v = fin[q];
+            out[q] = ((uint64_t)(lo + (v >> FIN_POS_BITS)) << 32) | s_idx[v & (FIN_CAP - 1u)];
+        }
+        return;
+    }
+
+    // A range that does not fit: stable LSD passes over the offset, chunk by chunk through global memory, by this
+    // block alone (in -> out -> in ..., the result copied to `out` if it ends in `in`).  Slow, exact, and rare: the
+    // host leaves skewed streams on the three-pass path.
+    uint64_t* a = elem_in + base;
+    uint64_t* b = out;
+    uint32_t* s_off = s_kv[0]; // [RADIX] running start of every digit in the destination
+    for (int ps = 0; ps < sub_passes; ++ps) {
+        const uint64_t* src = (ps & 1) ? b : a;
+        uint64_t* dst = (ps & 1) ? a : b;
+        const uint32_t shift = 8u * (uint32_t)ps;
+        if (threadIdx.x < RADIX) s_off[threadIdx.x] = 0;
+        __syncthreads();
+        for (uint32_t q0 = 0; q0 < c; q0 += FIN_THREADS) { // histogram of the digit over the whole range
+            const uint32_t q = q0 + threadIdx.x;
+            const bool v = q < c;
+            const uint32_t d = v ? ((((uint32_t)(ld_l2(&src[q]) >> 32) - lo) >> shift) & 255u) : 0u;
+            unsigned long long m = __ballot(v);
+#pragma unroll
+            for (int bt = 0; bt < 8; ++bt) {
+                const unsigned long long bb = __ballot((d >> bt) & 1u);
+                m &= ((d >> bt) & 1u) ? bb : ~bb;
+            }
+            if (v && (m & ((1ull << lane) - 1ull)) == 0ull) atomicAdd(&s_off[d], (uint32_t)__popcll(m)); // one add per distinct digit of the wave
+        }
+        __syncthreads();
+        if (threadIdx.x < RADIX) s_tot[threadIdx.x] = s_off[threadIdx.x];
+        __syncthreads();
+        fin_scan_digits(s_tot, s_off, s_part);
+        for (uint32_t c0 = 0; c0 < c; c0 += FIN_CAP) { // chunks in order: the pass is stable
+            uint64_t el[FIN_ITEMS];
+            uint32_t dig[FIN_ITEMS], rank[FIN_ITEMS];
+            bool valid[FIN_ITEMS];
+#pragma unroll
+            for (int j = 0; j < FIN_ITEMS; ++j) {
+                const uint32_t p = c0 + (uint32_t)wave * (64u * FIN_ITEMS) + (uint32_t)j * 64u + (uint32_t)lane;
+                valid[j] = p < c;
+                el[j] = valid[j] ? ld_l2(&src[p]) : 0ull;
+                dig[j] = (((uint32_t)(el[j] >> 32) - lo) >> shift) & 255u;
+            }
+            fin_rank<FIN_ITEMS>(dig, valid, rank, s_cnt, s_tot);
+#pragma unroll
+            for (int j = 0; j < FIN_ITEMS; ++j)
+                if (valid[j]) dst[s_off[dig[j]] + s_cnt[wave][dig[j]] + rank[j]] = el[j];
+            __syncthreads();
+            if (threadIdx.x < RADIX) s_off[threadIdx.x] += s_tot[threadIdx.x];
+            __syncthreads();
+        }
+        __threadfence(); // this block's stores have reached the L2 before its next pass reads them back (ld_l2)
+        __syncthreads();
+    }
+    if ((sub_passes & 1) == 0)
+        for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) b[q] = ld_l2(&a[q]);
 }
 
 } // namespace rs

@@ -80,32 +80,66 @@ int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_ke
     return TC_E_OK;
 }
 
+// Does this batch take the range path (radix_sort.hpp: one partition pass by key range + an in-LDS finish per range)?
+// The host cannot see the batch; it goes by the largest range of a RECENT batch of the stream, which the first pass of
+// every sort mirrors into pinned memory (never waited for).  No hint yet, a hint that predicts a range beyond what a
+// block finishes in LDS, or a batch too large: the three LSD passes.  A wrong guess costs time, not correctness
+// (k_finish sorts an oversized range through global memory).
+static bool range_applies(const tc_engine* e, uint32_t n, bool piped) {
+    if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return false;
+    if (n < 256u || n > e->range_max_n) return false;
+    const unsigned long long h = *(volatile unsigned long long*)e->range_hint_host;
+    const uint64_t hn = h >> 32, hmax = h & 0xFFFFFFFFull;
+    return hn != 0 && hmax * (uint64_t)n <= hn * (uint64_t)(rs::FIN_CAP / 8u * 7u);
+}
+
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
 // returns the buffer holding the result
 static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
-                                    bool piped, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
+                                    bool piped, bool ranged, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
                                     uint8_t* fill = nullptr, uint32_t fill_value = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
-    const int passes = (bits + 7) / 8;
+    const int passes = ranged ? 1 : (bits + 7) / 8;
     const int items = piped ? e->sort_items_piped : SORT_ITEMS;
     const uint32_t tile = rs::THREADS * (uint32_t)items;
     const uint32_t tiles = (n + tile - 1) / tile;
     rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
     ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
     ss.hist_parity ^= 1u;
+    // the range histogram is counted beside the LSD digits too (one more LDS atomic per request) whenever the key space
+    // admits the range path: it is where the hint comes from
+    const uint32_t msd_mul = e->range_ok ? e->range_mul : 0u;
+    unsigned long long* hint = e->range_ok ? e->range_hint_dev : nullptr;
     prof_begin_m(e, TC_STAGE_PREP, s);
-    TC_LAUNCH_T(e, TC_STAGE_PREP, (hipEvent_t) nullptr, rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value);
+    TC_LAUNCH_T(e, TC_STAGE_PREP, (hipEvent_t) nullptr, rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value, msd_mul, ranged ? 1 : 0);
     prof_end_m(e, s);
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
+    if (ranged) {
+        // partition by range into elem_b, finish every range into elem_a
+        prof_begin_m(e, TC_STAGE_SORT, s);
+#define TC_MSD(IT) \
+    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rs::k_onesweep<IT, true, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot, \
+                (const uint64_t*)nullptr, bufs[1], n, cap, 0, ws, (const uint32_t*)nullptr, 0u, msd_mul, hint)
+        if (items == 32) TC_MSD(32);
+        else if (items == 16) TC_MSD(16);
+        else TC_MSD(8);
+#undef TC_MSD
+        prof_end_m(e, s);
+        prof_begin_m(e, TC_STAGE_SORT, s);
+        hipEvent_t stop = e->prof_on ? nullptr : stop_last;
+        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, bufs[1], bufs[0], n, ws, msd_mul, e->range_sub_passes);
+        prof_end_m(e, s);
+        return bufs[0];
+    }
     const uint64_t* in = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
         prof_begin_m(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
         hipEvent_t stop = (p + 1 == passes && !e->prof_on) ? stop_last : nullptr;
 #define TC_PASS(IT, FI) \
-    TC_LAUNCH_T(e, TC_STAGE_SORT, stop, (rs::k_onesweep<IT, FI>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
-              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min)
+    TC_LAUNCH_T(e, TC_STAGE_SORT, stop, (rs::k_onesweep<IT, FI, false>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
+              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min, 0u, (FI) ? hint : (unsigned long long*)nullptr)
         if (p == 0) {
             if (items == 32) TC_PASS(32, true);
             else if (items == 16) TC_PASS(16, true);
@@ -377,7 +411,10 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
         // A skewed batch pays for the partition and then takes the sort path anyway.  The host cannot wait for the
         // gate, but the device mirrors it into pinned memory: when a recent batch tripped it, the next BP_BACKOFF
         // batches are not partitioned at all (the sort path alone is always correct), then the path is tried again.
-        bool eligible = direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
+        // (round 4: a batch the range path takes is grouped by it alone, in order as well: two grouping launches and the
+        // evaluation, nothing enqueued twice)
+        const bool ranged = range_applies(e, n, piped);
+        bool eligible = !ranged && direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
         if (eligible && e->bp_gate_host && e->bp_backoff_len) {
             const uint32_t seen = *(volatile uint32_t*)e->bp_gate_host;
             if (seen > e->bp_skew && e->bp_backoff == 0) {
@@ -426,7 +463,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
                 fill_value = *(volatile uint32_t*)e->fill_hint_host & 1u;
                 p.flags |= fill_value ? F_PREFILL1 : F_PREFILL0;
             }
-            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value);
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, ranged, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value);
             if (!ride) TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
             ss.grouped_aside = true;
@@ -437,7 +474,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, s, p, &d_slot));
             ss.grouped_aside = false;
             if (bucketed && !bucket_partition(e, ss, s, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
-            sorted = sort_by_slot(e, ss, s, d_slot, n, false, gate, e->bp_skew);
+            sorted = sort_by_slot(e, ss, s, d_slot, n, false, ranged, gate, e->bp_skew);
         }
         if (bucketed) bucket_eval(e, ss, s, p, full);
         prof_begin_m(e, TC_STAGE_EVAL, s);

@@ -18,11 +18,17 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 KNOBS = ("TCGPU_EVAL_LEAN", "TCGPU_STOP_EVENTS", "TCGPU_EVAL_ITEMS", "TCGPU_SORT_ITEMS_PIPED", "TCGPU_DEBUG_NO_DECISION_STORE",
-         "TCGPU_AUX_STREAMS", "TCGPU_PIPE_DEPTH", "TCGPU_AUX_PRIORITY", "TCGPU_PREFILL")
+         "TCGPU_AUX_STREAMS", "TCGPU_PIPE_DEPTH", "TCGPU_AUX_PRIORITY", "TCGPU_PREFILL", "TCGPU_RANGE")
 # "_idle": the batches carry TC_B_OUTPUTS_IDLE (a ring of 8 output arrays instead of one)
 CONFIGS = {
     "default": {"_idle": "1"},
     "default_again": {"_idle": "1"},
+    "range0": {"_idle": "1", "TCGPU_RANGE": "0"},          # three LSD passes (round 3's grouping)
+    "range0_again": {"_idle": "1", "TCGPU_RANGE": "0"},
+    "range_aux2": {"_idle": "1", "TCGPU_AUX_STREAMS": "2"},
+    "range_sort8": {"_idle": "1", "TCGPU_SORT_ITEMS_PIPED": "8"},
+    "range_sort32": {"_idle": "1", "TCGPU_SORT_ITEMS_PIPED": "32"},
+    "range_depth4": {"_idle": "1", "TCGPU_PIPE_DEPTH": "4"},
     "aux2": {"_idle": "1", "TCGPU_AUX_STREAMS": "2"},
     "aux4": {"_idle": "1", "TCGPU_AUX_STREAMS": "4"},
     "depth4": {"_idle": "1", "TCGPU_PIPE_DEPTH": "4"},

@@ -1,4 +1,6 @@
-// sortbench.hip -- times rs::k_hist / rs::k_onesweep alone (with phase ablations via -DRS_ABLATE=N)
+// sortbench.hip -- the grouping kernels alone: rs::k_hist + three rs::k_onesweep LSD passes against the range path
+// (rs::k_hist counting ranges + one partition pass + rs::k_finish), each checked against std::sort and timed with events.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DSB_ITEMS=16] tools/sortbench.hip -o /tmp/sb && /tmp/sb
 #include <hip/hip_runtime.h>
 #include <algorithm>
 #include <cstdint>
@@ -6,45 +8,103 @@
 #include <random>
 #include <vector>
 #include "../throttlecrab_amd/csrc/radix_sort.hpp"
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 #ifndef SB_ITEMS
 #define SB_ITEMS 16
 #endif
-int main(int argc, char** argv) {
-    const uint32_t n = argc > 1 ? (uint32_t)atol(argv[1]) : (1u << 20), cap = 10000000;
-    const int passes = 3;
-    std::mt19937_64 rng(1);
+
+static std::vector<uint32_t> make(const char* dist, uint32_t n, uint32_t cap, uint64_t seed) {
+    std::mt19937_64 rng(seed);
     std::vector<uint32_t> h(n);
-    for (auto& x : h) x = rng() % cap;
-    uint32_t* d_slot; uint64_t *a, *b; uint32_t* wsmem;
-    const uint32_t tile = rs::THREADS * SB_ITEMS, tiles = (n + tile - 1) / tile;
-    const size_t words = rs::workspace_words(tiles);
-    CK(hipMalloc(&d_slot, n * 4)); CK(hipMalloc(&a, n * 8)); CK(hipMalloc(&b, n * 8)); CK(hipMalloc(&wsmem, words * 4));
-    CK(hipMemcpy(d_slot, h.data(), n * 4, hipMemcpyHostToDevice));
+    const std::string d(dist);
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t r = rng();
+        if (d == "uniform") h[i] = r % cap;
+        else if (d == "hot") h[i] = (r % 100 < 40) ? 1234567u % cap : (uint32_t)((r >> 8) % cap);          // one key with 40 % of the batch
+        else if (d == "hot_ranges") h[i] = (r % 100 < 70) ? (uint32_t)(cap / 3 + (r >> 20) % 3000) : (uint32_t)((r >> 8) % cap);  // one RANGE with 70 %, many keys in it
+        else if (d == "same") h[i] = cap - 1;
+        else if (d == "few") h[i] = (uint32_t)((r % 7) * (cap / 7));
+        else if (d == "edges") h[i] = (r & 1) ? (uint32_t)(r % 4 == 1 ? cap + 5 : cap - 1) : (uint32_t)((r >> 8) % 3);             // out-of-range slots (clamped to cap), both ends
+        else h[i] = r % cap;
+    }
+    return h;
+}
+
+int main(int argc, char** argv) {
+    const uint32_t cap = argc > 1 ? (uint32_t)atol(argv[1]) : 10000000u;
+    const int passes = 3;
+    const uint32_t mul = rs::range_mul(cap);
+    const uint32_t width = rs::range_width(mul);
+    const int sub_passes = width <= 256 ? 1 : 2;
+    printf("cap %u  range mul %u  widest range %u slots  sub passes %d  lo(1)=%u lo(255)=%u\n", cap, mul, width, sub_passes, rs::range_lo(1, mul), rs::range_lo(255, mul));
+    if (width > 65536) { printf("key space too wide for the range path\n"); return 1; }
+    const uint32_t NMAX = 1u << 21;
+    uint32_t* d_slot; uint64_t *a, *b; uint32_t* wsmem; unsigned long long* hint;
+    const uint32_t tile = rs::THREADS * SB_ITEMS, max_tiles = (NMAX + tile - 1) / tile;
+    const size_t words = rs::workspace_words(max_tiles);
+    CK(hipMalloc(&d_slot, NMAX * 4)); CK(hipMalloc(&a, NMAX * 8)); CK(hipMalloc(&b, NMAX * 8)); CK(hipMalloc(&wsmem, words * 4));
+    CK(hipHostMalloc((void**)&hint, 64, hipHostMallocDefault));
     CK(hipMemset(wsmem, 0, words * 4));
+    CK(hipDeviceSynchronize());
     hipEvent_t ev[8]; for (auto& evx : ev) CK(hipEventCreate(&evx));
-    float acc[4] = {0, 0, 0, 0}; const int iters = 20; uint32_t parity = 0;
-    for (int it = 0; it < iters + 3; ++it) {
-        const rs::Workspace ws = rs::carve(wsmem, parity, tiles); parity ^= 1;
-        CK(hipEventRecord(ev[0]));
-        hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, 0, d_slot, n, cap, passes, ws, tiles, nullptr, 0u, (uint8_t*)nullptr, 0u);
-        CK(hipEventRecord(ev[1]));
-        hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, true>), dim3(tiles), dim3(rs::THREADS), 0, 0, d_slot, (const uint64_t*)nullptr, a, n, cap, 0, ws, nullptr, 0u);
-        CK(hipEventRecord(ev[2]));
-        hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, 0, (const uint32_t*)nullptr, a, b, n, cap, 1, ws, nullptr, 0u);
-        CK(hipEventRecord(ev[3]));
-        hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, false>), dim3(tiles), dim3(rs::THREADS), 0, 0, (const uint32_t*)nullptr, b, a, n, cap, 2, ws, nullptr, 0u);
-        CK(hipEventRecord(ev[4]));
-        CK(hipEventSynchronize(ev[4]));
-        if (it >= 3) for (int k = 0; k < 4; ++k) { float ms; CK(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += ms; }
-    }
-    printf("n=%u ABLATE=%d ITEMS=%d tiles=%u  hist %.1f us  pass0 %.1f  pass1 %.1f  pass2 %.1f\n", n, RS_ABLATE, SB_ITEMS, tiles,
-           1e3 * acc[0] / iters, 1e3 * acc[1] / iters, 1e3 * acc[2] / iters, 1e3 * acc[3] / iters);
-    if (RS_ABLATE == 0) {
-        std::vector<uint64_t> out(n); CK(hipMemcpy(out.data(), a, n * 8, hipMemcpyDeviceToHost));
-        std::vector<uint64_t> ref(n); for (uint32_t i = 0; i < n; ++i) ref[i] = ((uint64_t)h[i] << 32) | i;
+    uint32_t parity = 0;
+    int bad = 0;
+    struct Case { const char* dist; uint32_t n; };
+    const Case cases[] = {{"uniform", 1u << 20}, {"uniform", 5000}, {"uniform", 300000}, {"uniform", 256}, {"uniform", 1}, {"uniform", 4097},
+                          {"uniform", 1u << 21}, {"hot", 1u << 20}, {"hot_ranges", 1u << 20}, {"same", 200000}, {"same", 70000}, {"few", 1u << 20},
+                          {"edges", 100000}, {"uniform", 1572864}};
+    for (const Case& cs : cases) {
+        const uint32_t n = cs.n;
+        std::vector<uint32_t> h = make(cs.dist, n, cap, 1 + n);
+        CK(hipMemcpy(d_slot, h.data(), n * 4, hipMemcpyHostToDevice));
+        std::vector<uint64_t> ref(n);
+        for (uint32_t i = 0; i < n; ++i) ref[i] = ((uint64_t)std::min(h[i], cap) << 32) | i;
         std::sort(ref.begin(), ref.end());
-        printf("sorted correctly: %s\n", out == ref ? "yes" : "NO");
+        const uint32_t tiles = (n + tile - 1) / tile;
+        float acc[8] = {0};
+        const int iters = 12;
+        std::vector<uint64_t> out(n);
+        for (int mode = 0; mode < 2; ++mode) { // 0: three LSD passes, 1: range path
+            for (int k = 0; k < 8; ++k) acc[k] = 0;
+            for (int it = 0; it < iters + 2; ++it) {
+                const rs::Workspace ws = rs::carve(wsmem, parity, max_tiles); parity ^= 1;
+                CK(hipEventRecord(ev[0]));
+                if (mode == 0) {
+                    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, 0, d_slot, n, cap, passes, ws, tiles, nullptr, 0u, (uint8_t*)nullptr, 0u, mul, 0);
+                    CK(hipEventRecord(ev[1]));
+                    hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, true, false>), dim3(tiles), dim3(rs::THREADS), 0, 0, d_slot, (const uint64_t*)nullptr, a, n, cap, 0, ws, nullptr, 0u, 0u, hint);
+                    CK(hipEventRecord(ev[2]));
+                    hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, false, false>), dim3(tiles), dim3(rs::THREADS), 0, 0, (const uint32_t*)nullptr, a, b, n, cap, 1, ws, nullptr, 0u, 0u, (unsigned long long*)nullptr);
+                    CK(hipEventRecord(ev[3]));
+                    hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, false, false>), dim3(tiles), dim3(rs::THREADS), 0, 0, (const uint32_t*)nullptr, b, a, n, cap, 2, ws, nullptr, 0u, 0u, (unsigned long long*)nullptr);
+                    CK(hipEventRecord(ev[4]));
+                } else {
+                    hipLaunchKernelGGL(rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, 0, d_slot, n, cap, 1, ws, tiles, nullptr, 0u, (uint8_t*)nullptr, 0u, mul, 1);
+                    CK(hipEventRecord(ev[1]));
+                    hipLaunchKernelGGL((rs::k_onesweep<SB_ITEMS, true, true>), dim3(tiles), dim3(rs::THREADS), 0, 0, d_slot, (const uint64_t*)nullptr, b, n, cap, 0, ws, nullptr, 0u, mul, hint);
+                    CK(hipEventRecord(ev[2]));
+                    hipLaunchKernelGGL(rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, 0, b, a, n, ws, mul, sub_passes);
+                    CK(hipEventRecord(ev[3]));
+                    CK(hipEventRecord(ev[4]));
+                }
+                CK(hipEventSynchronize(ev[4]));
+                CK(hipGetLastError());
+                if (it >= 2) for (int k = 0; k < 4; ++k) { float ms; CK(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += ms; }
+            }
+            CK(hipMemcpy(out.data(), a, (size_t)n * 8, hipMemcpyDeviceToHost));
+            const bool ok = out == ref;
+            bad += !ok;
+            const unsigned long long hv = *(volatile unsigned long long*)hint;
+            printf("%-10s n=%8u %-6s hist %5.1f us  p0 %5.1f  %s %5.1f  %s %5.1f  total %6.1f   largest range %u (n %u)  %s\n", cs.dist, n, mode ? "range" : "lsd",
+                   1e3 * acc[0] / iters, 1e3 * acc[1] / iters, mode ? "finish" : "p1", 1e3 * acc[2] / iters, mode ? "-" : "p2", 1e3 * acc[3] / iters,
+                   1e3 * (acc[0] + acc[1] + acc[2] + acc[3]) / iters, (unsigned)(hv & 0xFFFFFFFFu), (unsigned)(hv >> 32), ok ? "sorted" : "WRONG");
+            if (!ok) {
+                uint32_t shown = 0;
+                for (uint32_t i = 0; i < n && shown < 4; ++i)
+                    if (out[i] != ref[i]) { printf("   first differences at %u: got %016llx want %016llx\n", i, (unsigned long long)out[i], (unsigned long long)ref[i]); ++shown; }
+            }
+        }
     }
-    return 0;
+    printf(bad ? "FAILED: %d wrong results\n" : "all sorted correctly (%d)\n", bad);
+    return bad ? 1 : 0;
 }
