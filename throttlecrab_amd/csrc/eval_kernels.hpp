@@ -478,7 +478,7 @@ struct __attribute__((aligned(16))) PendEntry {
 #ifndef TC_EVAL_LEAN_WAVES
 #define TC_EVAL_LEAN_WAVES 8 // waves per SIMD the LEAN variants are compiled for (= 256-thread blocks per CU)
 #endif
-template <bool FULL, bool DIRECT, int ITEMS, bool FIXED, bool LEAN>
+template <bool FULL, bool DIRECT, int ITEMS, bool FIXED, bool LEAN, int BS = BLOCK>
 __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t* __restrict__ sorted,
                                                  PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
                                                  uint32_t* __restrict__ loaded, uint32_t seq,
@@ -486,7 +486,7 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
     if (gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min) return; // this batch took the bucket path (bucket_path.hpp)
     const uint32_t n = p.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t block_start = blockIdx.x * (BLOCK * ITEMS);
+    const uint32_t block_start = blockIdx.x * (BS * ITEMS);
     const bool class_by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS); // uniform over the grid
     const RateClass rc_batch = p.classes[p.uniform_class];                                // (class 0 if there is none)
     uint32_t kk[ITEMS];
@@ -496,7 +496,7 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
     // makes the compiler drain the earlier ones first
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        kk[j] = block_start + j * BLOCK + threadIdx.x;
+        kk[j] = block_start + j * BS + threadIdx.x;
         me[j] = sorted[min(kk[j], n - 1u)];
     }
 #pragma unroll
@@ -539,7 +539,7 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
     }
 
     // run boundaries per row; start of my run by a max-scan of head positions over the block's range
-    __shared__ uint32_t s_rowmax[ITEMS][BLOCK / 64];
+    __shared__ uint32_t s_rowmax[ITEMS][BS / 64];
     __shared__ uint32_t s_start;
     bool head[ITEMS], is_last[ITEMS];
     uint32_t hp[ITEMS];
@@ -581,13 +581,13 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
     uint32_t carry = 0; // latest head position (+1) in the rows before mine
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        for (int w = 0; w < BLOCK / 64; ++w) {
+        for (int w = 0; w < BS / 64; ++w) {
             // rows before (j, wave) in position order: all of the earlier sub-tiles, and waves < mine of this one
             if (w < wave) carry = max(carry, s_rowmax[j][w]);
         }
         const uint32_t h = max(hp[j], carry);
         seg_start[j] = h ? h - 1 : s_start;
-        for (int w = wave; w < BLOCK / 64; ++w) carry = max(carry, s_rowmax[j][w]);
+        for (int w = wave; w < BS / 64; ++w) carry = max(carry, s_rowmax[j][w]);
 
         const uint32_t k = kk[j];
         const bool valid = k < n;
@@ -742,7 +742,7 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
         }
         wave_denied_add(p, slot, denied_here[j]);
     }
-    block_count3(na, nd, ne, p.counters, (LEAN && blockIdx.x == gridDim.x / 2) ? hint : nullptr);
+    block_count3<BS>(na, nd, ne, p.counters, (LEAN && blockIdx.x == gridDim.x / 2) ? hint : nullptr);
 }
 
 template <bool FULL, bool DIRECT, int ITEMS, bool FIXED>
@@ -754,11 +754,13 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
 // decisions only, direct stores, only the `allowed` byte column asked for: at most 80 scalar and 64 vector registers,
 // so that EIGHT blocks fit a CU (k_eval_sorted's 106 SGPRs admit six) -- the kernel waits on random memory, and what
 // hides that is resident waves
-template <int ITEMS, bool FIXED>
-__global__ __launch_bounds__(BLOCK, TC_EVAL_LEAN_WAVES) __attribute__((amdgpu_num_sgpr(80))) void k_eval_sorted_lean(
+// (ITEMS = 4: half as many blocks of twice the work, four per CU -- what skewed streams run fastest on; 512-thread blocks, the
+// same waves per CU in half as many blocks, measured slower on both streams: profiles/r04_v11_eval_block_ab.txt)
+template <int ITEMS, bool FIXED, int BS = BLOCK>
+__global__ __launch_bounds__(BS, (ITEMS <= 2 ? TC_EVAL_LEAN_WAVES : TC_EVAL_LEAN_WAVES / 2)) __attribute__((amdgpu_num_sgpr(80))) void k_eval_sorted_lean(
     Params p, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ loaded, uint32_t seq, const uint32_t* __restrict__ gate,
     uint32_t gate_min, uint32_t* hint) {
-    eval_sorted_body<false, true, ITEMS, FIXED, true>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint);
+    eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint);
 }
 
 // ---------------------------------------------------------------------------

@@ -197,7 +197,7 @@ static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, u
     (void)lean;
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
     if (lean) {
-        if constexpr (ITEMS <= 2) {
+        if constexpr (ITEMS <= 4) {
             TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
             return;
         }
@@ -208,17 +208,21 @@ static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, u
     else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted<false, false, ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->pend, e->pend_count, e->loaded, seq, gate, gate_min);
 }
 
-static int eval_items_of(const tc_engine* e, bool piped) { return e->eval_items ? e->eval_items : (piped ? 2 : 4); }
+// Sorted positions per lane: 2 for a pipelined batch of a stream that looks uniform (the grid of 2048 blocks of 8 per CU hides the
+// random cells best), 4 in order -- and 4 for pipelined batches of a skewed stream (`slim`: the range hint sent the batch to
+// the LSD passes), whose evaluation is lighter and gains more from a grid half as large: Zipf 41.7 -> 38.6 us per batch,
+// uniform 43.7 -> 46.1 (profiles/r04_v8_items4_ab.txt).
+static int eval_items_of(const tc_engine* e, bool piped, bool slim = false) { return e->eval_items ? e->eval_items : ((piped && !slim) ? 2 : 4); }
 
 // LEAN: decisions only, direct stores, nothing asked for but the `allowed` bytes in request order (k_eval_sorted_lean)
 static bool lean_applies(const tc_engine* e, bool full, bool direct, bool piped, const Params& p) {
-    return e->eval_lean && !full && direct && eval_items_of(e, piped) <= 2 && p.allowed && !p.status && !p.limit && !p.order && !p.row_bits;
+    return e->eval_lean && !full && direct && eval_items_of(e, piped) <= 4 && p.allowed && !p.status && !p.limit && !p.order && !p.row_bits;
 }
 
 static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped, uint32_t n, hipStream_t s, const Params& p,
                                const uint64_t* sorted, uint32_t seq, const uint32_t* gate = nullptr, uint32_t gate_min = 0,
-                               hipEvent_t stop = nullptr) {
-    const int items = eval_items_of(e, piped);
+                               hipEvent_t stop = nullptr, bool slim = false) {
+    const int items = eval_items_of(e, piped, slim);
     const bool lean = lean_applies(e, full, direct, piped, p);
     if (e->fixed) {
         switch (items) {
@@ -487,7 +491,9 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             }
             // (direct: the evaluation is the last reader of the set -- `consumed` can ride on its completion signal)
             consumed_rides = direct && e->stop_events && !e->prof_on;
-            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr);
+            // (slim: the stream looked skewed to the range hint -- not merely "no hint yet" or a batch too large for the path)
+            const bool slim = piped && e->range_ok && !ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n;
+            launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr, slim);
             prof_end_m(e, s);
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);

@@ -25,6 +25,8 @@ CONFIGS = {
     "default_again": {"_idle": "1"},
     "range0": {"_idle": "1", "TCGPU_RANGE": "0"},          # three LSD passes (round 3's grouping)
     "range0_again": {"_idle": "1", "TCGPU_RANGE": "0"},
+    "items4": {"_idle": "1", "TCGPU_EVAL_ITEMS": "4"},        # lean evaluation, 1024 blocks of 1024 positions
+    "items4_again": {"_idle": "1", "TCGPU_EVAL_ITEMS": "4"},
     "range_aux2": {"_idle": "1", "TCGPU_AUX_STREAMS": "2"},
     "range_sort8": {"_idle": "1", "TCGPU_SORT_ITEMS_PIPED": "8"},
     "range_sort32": {"_idle": "1", "TCGPU_SORT_ITEMS_PIPED": "32"},

@@ -21,7 +21,7 @@ def main():
     qcol = next((x for x in ("stream_id", "queue_id", "queue") if x in cols), None)
     rows = c.execute(f"select name, start, end, {qcol or '0'} from kernels order by start").fetchall()
     hist = [r for r in rows if "k_hist" in r[0]]
-    sweeps = [r for r in rows if "k_onesweep" in r[0]]
+    sweeps = [r for r in rows if "k_onesweep" in r[0] or "k_finish" in r[0]]   # (range path: partition pass + finish)
     evals = [r for r in rows if "k_eval_sorted" in r[0] or "k_eval_general" in r[0]]
     passes = len(sweeps) // max(1, len(hist))
     print(f"# {len(hist)} k_hist, {len(sweeps)} k_onesweep ({passes} per batch), {len(evals)} evaluations")
