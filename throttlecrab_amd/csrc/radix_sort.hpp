@@ -24,6 +24,16 @@
 #define RS_ABLATE 0 // tools/sortbench.hip sets 1..4 to time the kernel with phases cut off
 #endif
 
+#ifndef RS_TIMING
+#define RS_TIMING 0 // tools/sortbench.hip sets 1: one block of k_tile_ranges / k_finish stamps the 100 MHz wall clock at its phase boundaries
+#endif
+#if RS_TIMING
+__device__ long long g_rs_stamps[2][16];
+#define RS_STAMP(k, i, blk) do { if (threadIdx.x == 0 && blockIdx.x == (blk)) g_rs_stamps[k][i] = wall_clock64(); } while (0)
+#else
+#define RS_STAMP(k, i, blk) do { } while (0)
+#endif
+
 namespace rs {
 
 constexpr int THREADS = 256;
@@ -64,17 +74,23 @@ struct Workspace {
     unsigned long long* violations; // the engine's invariant counter (a look-back that outlasts tc::SPIN_LIMIT_TICKS)
 };
 
-// ---- the range path (round 4): ONE pass over global memory + one in-LDS finish ------------------------------------
-// A 1 Mi batch over 10 M slots needs 24 key bits = three LSD passes, each a launch with a look-back chain (19 us alone,
-// 25-35 us beside the other streams): the grouping chain, not the evaluation, set the pace of the pipeline.  The range
-// path cuts the key space into 256 equal RANGES (digit = umulhi(slot, mul): monotone in the slot, so range r holds the
-// slots [range_lo(r), range_lo(r + 1))), partitions the batch by range with the same one-sweep kernel (stable: inside a
-// range the requests keep their index order) and lets ONE 1024-thread block per range finish it without leaving the CU:
-// the range's <= FIN_CAP elements are sorted by their offset inside the range (<= 16 bits: two 8-bit passes with ballot
-// ranking) in LDS and written out as the same sorted (slot << 32 | index) array the three passes produce.  No look-back,
-// no status words, two launches fewer.  A range that holds more than FIN_CAP elements (a skewed batch the host did not
-// foresee: it chooses the path from the largest range of a RECENT batch, mirrored into pinned memory) is sorted by its
-// block through global memory, slowly but exactly; streams that are skewed stay on the three LSD passes.
+// ---- the range path (round 4): two launches, no histogram pass, no chain between tiles -----------------------------
+// A 1 Mi batch over 10 M slots needs 24 key bits = a histogram launch + three LSD passes, each pass a launch with a
+// look-back chain (19 us alone, 25-35 us beside the other streams).  The range path cuts the key space into 256 equal
+// RANGES (digit = umulhi(slot, mul): monotone in the slot, so range r holds the slots [range_lo(r), range_lo(r + 1))):
+//   k_tile_ranges   every tile of the batch is partitioned by range IN PLACE (tile t's elements stay in [t * TILE, ...),
+//                   grouped by range, index order kept) and writes a 256-entry table row: where each range starts in
+//                   the tile and how many elements it has there.  Tiles do not depend on one another: no histogram
+//                   first, no look-back.
+//   k_finish        one 1024-thread block per range collects the range's pieces from all tiles (tile order = index
+//                   order), sorts its <= FIN_CAP elements by their offset inside the range (<= 16 bits: two 8-bit
+//                   passes with ballot ranking) in LDS and writes them where the range belongs in the sorted batch --
+//                   the same sorted (slot << 32 | index) array the LSD passes produce.  The range's place is the sum
+//                   of the earlier ranges' sizes: every block publishes its size at once and reads the others' (256
+//                   co-resident blocks, one word each).
+// A range that holds more than FIN_CAP elements (a skewed batch the host did not foresee: it chooses the path from the
+// largest range of a RECENT batch, mirrored into pinned memory) is sorted by its block through global memory, slowly but
+// exactly; streams that are skewed stay on the LSD passes.
 constexpr int FIN_THREADS = 1024;
 constexpr int FIN_WAVES = FIN_THREADS / 64;
 constexpr int FIN_ITEMS = 8;
@@ -83,6 +99,12 @@ constexpr uint32_t FIN_POS_BITS = 13;                  // FIN_CAP == 1 << FIN_PO
 constexpr int FIN_ROW = RADIX + 1;                     // per-wave counter rows, padded against bank conflicts
 constexpr int MSD_ROW = MAX_PASSES - 1;                // histogram row of the range digit when k_hist counts it beside the LSD digits
 static_assert(FIN_CAP == (1u << FIN_POS_BITS), "positions inside a range must fit FIN_POS_BITS");
+// k_finish, counting path: ranges of at most CNT_W_MAX slots whose slots hold at most CNT_DUP_MAX elements each are sorted by
+// COUNTING (one LDS atomic per element on a byte counter per slot) instead of two ballot-ranked passes
+constexpr uint32_t CNT_W_MAX = 49152;
+constexpr uint32_t CNT_DUP_MAX = 16;
+constexpr uint32_t FIN_UNION_WORDS = CNT_W_MAX / 4 + CNT_W_MAX / 8 + FIN_CAP; // >= 2 * FIN_CAP + FIN_WAVES * FIN_ROW + 2 * RADIX
+static_assert(FIN_UNION_WORDS >= 2 * FIN_CAP + FIN_WAVES * FIN_ROW + 2 * RADIX, "the ballot path's arrays fit the union");
 
 // digit = umulhi(slot, mul) with mul = floor(256 * 2^32 / (cap + 1)): < 256 for every slot <= cap (cap itself is the
 // sentinel of out-of-range slots).  Needs cap + 1 > 256.
@@ -128,14 +150,13 @@ __device__ __forceinline__ bool gated_off(const uint32_t* __restrict__ gate, uin
 
 // `fill` (TC_B_OUTPUTS_IDLE batches): the batch's decision bytes, set to fill_value here, ahead of the evaluation,
 // which then only stores the decisions that differ (16-byte stores; the tail bytewise)
-// `msd_mul` != 0: the range digit umulhi(slot, msd_mul) is counted too -- msd_only: INSTEAD of the LSD digits, into row 0
-// (the range path: `passes` is 1, one pass's look-back words are cleared); else beside them, into row MSD_ROW (passes <= 3),
-// from which the first LSD pass mirrors the largest range to the host (the hint the path is chosen by)
+// `msd_mul` != 0 (passes <= 3): the range digit umulhi(slot, msd_mul) is counted beside the LSD digits, into row MSD_ROW, from
+// which the first LSD pass mirrors the largest range to the host (the hint the range path is chosen by)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
                                                   int passes, Workspace ws, uint32_t tiles, const uint32_t* __restrict__ gate,
                                                   uint32_t gate_min, uint8_t* __restrict__ fill, uint32_t fill_value,
-                                                  uint32_t msd_mul, int msd_only) {
+                                                  uint32_t msd_mul) {
     __shared__ uint32_t s_h[MAX_PASSES][RADIX];
     if (fill != nullptr) {
         const uint32_t v4 = fill_value * 0x01010101u;
@@ -187,28 +208,20 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t kk = clamp_slot(k[u], cap);
-                if (msd_only) {
-                    atomicAdd(&s_h[0][__umulhi(kk, msd_mul)], 1u);
-                } else {
-                    for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-                    if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
-                }
+                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+                if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
             }
         }
         for (; i < n; i += stride) {
             const uint32_t kk = clamp_slot(slot[i], cap);
-            if (msd_only) {
-                atomicAdd(&s_h[0][__umulhi(kk, msd_mul)], 1u);
-            } else {
-                for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-                if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
-            }
+            for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
+            if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) {
         const int row = i / RADIX;
-        if (!(row < passes || (!msd_only && msd_mul && row == MSD_ROW))) continue;
+        if (!(row < passes || (msd_mul && row == MSD_ROW))) continue;
         const uint32_t v = (&s_h[0][0])[i];
         if (v) atomicAdd(&ws.hist[i], v);
     }
@@ -217,15 +230,14 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
 // ---------------------------------------------------------------------------
 // one LSD pass.  FIRST: input is the raw slot column (value = position).
 // ---------------------------------------------------------------------------
-// MSD (with FIRST, pass 0): the digit is the RANGE of the slot, umulhi(slot, msd_mul) -- the partition pass of the range path.
-// `range_hint` (block 0 of a pass that has the range histogram at hand: the MSD pass itself, row 0; the first LSD pass
-// when k_hist counted the ranges beside the LSD digits, row MSD_ROW): n << 32 | largest range, into pinned host memory.
-template <int ITEMS, bool FIRST, bool MSD = false>
+// `range_hint` (block 0 of the first pass, when k_hist counted the ranges beside the LSD digits: row MSD_ROW):
+// n << 32 | largest range, into pinned host memory.
+template <int ITEMS, bool FIRST>
 __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict__ slot_in,
                                                       const uint64_t* __restrict__ elem_in,
                                                       uint64_t* __restrict__ elem_out, uint32_t n, uint32_t cap,
                                                       int pass, Workspace ws, const uint32_t* __restrict__ gate, uint32_t gate_min,
-                                                      uint32_t msd_mul, unsigned long long* __restrict__ range_hint) {
+                                                      unsigned long long* __restrict__ range_hint) {
     constexpr int TILE = THREADS * ITEMS;
     if (gated_off(gate, gate_min)) return; // (the whole grid: nobody is left waiting in a look-back)
     __shared__ uint32_t s_base[RADIX];          // global exclusive start of each digit
@@ -244,7 +256,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
     for (int i = threadIdx.x; i < WAVES * RADIX; i += THREADS) (&s_wave[0][0])[i] = 0;
 
     if (range_hint != nullptr && blockIdx.x == 0) { // (block-uniform)
-        uint32_t m = ws.hist[(MSD ? 0 : MSD_ROW) * RADIX + threadIdx.x];
+        uint32_t m = ws.hist[MSD_ROW * RADIX + threadIdx.x];
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
         if (lane == 0) s_scan[wave] = m;
         __syncthreads();
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool valid = (wbase + j * 64) < n;
-        const uint32_t d = MSD ? (valid ? __umulhi(key[j], msd_mul) : 255u) : ((key[j] >> shift) & 255u);
+        const uint32_t d = (key[j] >> shift) & 255u;
         unsigned long long m = __ballot(valid);
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         if ((wbase + j * 64) < n) {
-            const uint32_t d = MSD ? __umulhi(key[j], msd_mul) : ((key[j] >> shift) & 255u);
+            const uint32_t d = (key[j] >> shift) & 255u;
             s_elem[s_tstart[d] + s_wave[wave][d] + rank[j]] = ((uint64_t)key[j] << 32) | val[j];
         }
     }
@@ -454,7 +466,7 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
         const uint32_t i = j * THREADS + threadIdx.x;
         if (i < nvalid) {
             const uint64_t e = s_elem[i];
-            const uint32_t d = MSD ? __umulhi((uint32_t)(e >> 32), msd_mul) : (((uint32_t)(e >> 32) >> shift) & 255u);
+            const uint32_t d = ((uint32_t)(e >> 32) >> shift) & 255u;
             elem_out[i + s_off[d]] = e;
         }
     }
@@ -538,48 +550,349 @@ __device__ __forceinline__ void fin_scan_digits(const uint32_t* s_tot, uint32_t*
     __syncthreads();
 }
 
-// `elem_in`: the partition pass's output (a range's part of it is scratch for a range that does not fit LDS);
-// `elem_out`: the batch sorted by (slot, index).  One block per range; sub_passes = 8-bit digits of the offset
-// inside a range (1 or 2: the host takes this path only when the widest range is at most 65536 slots).
-static __global__ __launch_bounds__(FIN_THREADS) void k_finish(uint64_t* __restrict__ elem_in, uint64_t* __restrict__ elem_out, uint32_t n,
-                                                        Workspace ws, uint32_t msd_mul, int sub_passes) {
+// ---------------------------------------------------------------------------
+// range path, first half: every tile partitioned by range in place + its table row
+// ---------------------------------------------------------------------------
+// table[tile * RADIX + r] = (elements of range r in the tile) << 16 | where they start inside the tile.
+// `fill` (TC_B_OUTPUTS_IDLE batches): see k_hist -- the range path has no histogram launch, so the decision bytes are preset here.
+template <int ITEMS>
+__global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restrict__ slot_in, uint64_t* __restrict__ elem_out,
+                                                         uint32_t* __restrict__ table, uint32_t n, uint32_t cap, uint32_t msd_mul,
+                                                         uint8_t* __restrict__ fill, uint32_t fill_value) {
+    constexpr int TILE = THREADS * ITEMS;
+    static_assert(TILE <= 65535, "a tile's starts and counts are packed into 16 bits each");
+    __shared__ uint32_t s_wave[WAVES][RADIX];
+    __shared__ uint32_t s_tstart[RADIX];
+    __shared__ uint64_t s_elem[TILE];
+    __shared__ uint32_t s_scan[WAVES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x;
+    RS_STAMP(0, 0, gridDim.x / 2);
+    uint32_t key[ITEMS], rank[ITEMS];
+    const uint32_t wbase = tile * TILE + wave * 64 * ITEMS + lane; // wave-striped: (wave, item, lane) order is index order
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t pos = wbase + j * 64;
+        key[j] = pos < n ? clamp_slot(slot_in[pos], cap) : 0u;
+    }
+    // every wave clears its own counter row: no block barrier stands between the loads and the ranking, which starts on
+    // the first items while the later ones are still on their way (the loads were 4.6 of the kernel's 11 us)
+#pragma unroll
+    for (int i = 0; i < RADIX / 64; ++i) s_wave[wave][i * 64 + lane] = 0;
+    if (fill != nullptr) {
+        const uint32_t v4 = fill_value * 0x01010101u;
+        const uint32_t head = (uint32_t)((16u - ((uintptr_t)fill & 15u)) & 15u);
+        const uint32_t h = head < n ? head : n;
+        uint4* f16 = reinterpret_cast<uint4*>(fill + h);
+        const uint32_t n16 = (n - h) / 16u;
+        for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < n16; i += gridDim.x * THREADS) f16[i] = make_uint4(v4, v4, v4, v4);
+        if (blockIdx.x == 0) {
+            for (uint32_t i = threadIdx.x; i < h; i += THREADS) fill[i] = (uint8_t)fill_value;
+            for (uint32_t i = h + n16 * 16u + threadIdx.x; i < n; i += THREADS) fill[i] = (uint8_t)fill_value;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    RS_STAMP(0, 1, gridDim.x / 2);
+    RS_STAMP(0, 2, gridDim.x / 2);
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const bool valid = (wbase + j * 64) < n;
+        const uint32_t d = valid ? __umulhi(key[j], msd_mul) : 0u;
+        unsigned long long m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const unsigned long long bb = __ballot((d >> b) & 1u);
+            m &= ((d >> b) & 1u) ? bb : ~bb;
+        }
+        const uint32_t before = valid ? s_wave[wave][d] : 0u;
+        rank[j] = before + (uint32_t)__popcll(m & lt);
+        if (valid && (m & lt) == 0ull) s_wave[wave][d] = before + (uint32_t)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    RS_STAMP(0, 3, gridDim.x / 2);
+    __syncthreads();
+    RS_STAMP(0, 4, gridDim.x / 2);
+    {
+        const int d = threadIdx.x; // RADIX == THREADS
+        uint32_t run = 0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t c = s_wave[w][d];
+            s_wave[w][d] = run;
+            run += c;
+        }
+        uint32_t v = run;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(v, off, 64);
+            if (lane >= off) v += o;
+        }
+        if (lane == 63) s_scan[wave] = v;
+        __syncthreads();
+        uint32_t carry = 0;
+        for (int w = 0; w < wave; ++w) carry += s_scan[w];
+        const uint32_t start = carry + v - run;
+        s_tstart[d] = start;
+        table[(size_t)tile * RADIX + d] = (run << 16) | start;
+    }
+    __syncthreads();
+    RS_STAMP(0, 5, gridDim.x / 2);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t pos = wbase + j * 64;
+        if (pos < n) {
+            const uint32_t d = __umulhi(key[j], msd_mul);
+            s_elem[s_tstart[d] + s_wave[wave][d] + rank[j]] = ((uint64_t)key[j] << 32) | pos;
+        }
+    }
+    __syncthreads();
+    RS_STAMP(0, 6, gridDim.x / 2);
+    const uint32_t tile_first = tile * TILE;
+    const uint32_t nvalid = (n - tile_first) < (uint32_t)TILE ? (n - tile_first) : (uint32_t)TILE;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t i = j * THREADS + threadIdx.x;
+        if (i < nvalid) elem_out[tile_first + i] = s_elem[i];
+    }
+    RS_STAMP(0, 7, gridDim.x / 2);
+}
+
+// ---------------------------------------------------------------------------
+// range path, second half: one block per range
+// ---------------------------------------------------------------------------
+// `tiled`: k_tile_ranges' output (tile size `tile_len`, `tiles` <= FIN_THREADS of them) with its `table`; `elem_out`: the batch
+// sorted by (slot, index); `scratch`: a third array of the batch's size (ranges that do not fit LDS); `look`: RADIX words,
+// seq << 32 | elements of range r, tagged with this launch's sequence number so that nothing has to be cleared;
+// sub_passes = 8-bit digits of the offset inside a range (1 or 2: the host takes this path only when the widest range
+// is at most 65536 slots); `range_hint`: n << 32 | largest range, into pinned host memory (block RADIX - 1).
+static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* __restrict__ tiled, const uint32_t* __restrict__ table,
+                                                               uint64_t* __restrict__ elem_out, uint64_t* __restrict__ scratch,
+                                                               unsigned long long* __restrict__ look, uint32_t seq, uint32_t n,
+                                                               uint32_t tiles, uint32_t tile_len, uint32_t msd_mul, int sub_passes,
+                                                               unsigned long long* __restrict__ range_hint, unsigned long long* violations) {
     __shared__ uint32_t s_idx[FIN_CAP];            // request index of position p (never moves)
-    __shared__ uint32_t s_kv[2][FIN_CAP];          // offset inside the range << FIN_POS_BITS | p, in the order reached so far
-    __shared__ uint32_t s_cnt[FIN_WAVES][FIN_ROW];
-    __shared__ uint32_t s_tot[RADIX];
-    __shared__ uint32_t s_start[RADIX];
-    __shared__ uint32_t s_part[RADIX / 64];
-    __shared__ uint32_t s_base, s_count;
+    __shared__ uint32_t s_u[FIN_UNION_WORDS];      // the two ways of sorting a range share this
+    // ballot path: offset inside the range << FIN_POS_BITS | p in the order reached so far (x2), per-wave digit counters, digit totals / starts
+    uint32_t (*s_kv)[FIN_CAP] = reinterpret_cast<uint32_t (*)[FIN_CAP]>(s_u);
+    uint32_t (*s_cnt)[FIN_ROW] = reinterpret_cast<uint32_t (*)[FIN_ROW]>(s_u + 2 * FIN_CAP);
+    uint32_t* s_tot = s_u + 2 * FIN_CAP + FIN_WAVES * FIN_ROW;
+    uint32_t* s_start = s_tot + RADIX;
+    // counting path: a byte counter per slot of the range, where each word of four counters starts in the sorted range, the sorted range
+    uint32_t* c_cnt = s_u;
+    uint16_t* c_ws = reinterpret_cast<uint16_t*>(s_u + CNT_W_MAX / 4);
+    uint32_t* c_fin = s_u + CNT_W_MAX / 4 + CNT_W_MAX / 8;
+    __shared__ uint32_t s_flag;
+    __shared__ uint32_t s_part[FIN_WAVES];
+    __shared__ uint32_t s_pos[FIN_THREADS + 1];    // where tile t's piece of my range starts among the range's elements
+    __shared__ uint32_t s_st[FIN_THREADS];         // ... and inside the tile
+    __shared__ uint32_t s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = blockIdx.x;
-    // where my range starts in the partitioned batch: exclusive scan of the range histogram (k_hist, row 0)
+    RS_STAMP(1, 0, 128);
+    // my range's pieces: one table word per tile; exclusive scan of the counts over the tiles
+    uint32_t c;
     {
-        uint32_t h = 0, incl = 0;
-        if (threadIdx.x < RADIX) {
-            h = ws.hist[threadIdx.x];
-            incl = h;
-            for (int off = 1; off < 64; off <<= 1) {
-                const uint32_t o = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += o;
-            }
-            if (lane == 63) s_part[wave] = incl;
+        uint32_t w = 0;
+        if (threadIdx.x < tiles) w = table[(size_t)threadIdx.x * RADIX + r];
+        const uint32_t cnt = w >> 16;
+        RS_STAMP(1, 1, 128);
+        if (cnt == 0xFFFFu) s_part[0] = 1; // (RS_TIMING: the table word has landed)
+        RS_STAMP(1, 2, 128);
+        uint32_t incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
         }
+        if (lane == 63) s_part[wave] = incl;
         __syncthreads();
-        if (threadIdx.x == r) {
-            uint32_t carry = 0;
-            for (int w = 0; w < wave; ++w) carry += s_part[w];
-            s_base = carry + incl - h;
-            s_count = h;
+        uint32_t carry = 0, total = 0;
+        for (int q = 0; q < FIN_WAVES; ++q) {
+            if (q < wave) carry += s_part[q];
+            total += s_part[q];
         }
+        s_pos[threadIdx.x] = carry + incl - cnt;
+        s_st[threadIdx.x] = w & 0xFFFFu;
+        if (threadIdx.x == 0) {
+            s_pos[FIN_THREADS] = total;
+            // my size, for the blocks of the later ranges (they read it at the very end of their work)
+            __hip_atomic_store(&look[r], ((unsigned long long)seq << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        c = total;
         __syncthreads();
     }
-    const uint32_t c = s_count, base = s_base;
-    if (c == 0u || base + c > n) return; // (the second test cannot fire: the histogram sums to n)
+    RS_STAMP(1, 3, 128);
+    // where my range goes in the sorted batch: the sizes of the ranges before mine (and, for the last block, the largest one)
+    auto place = [&]() -> uint32_t {
+        uint32_t mine = 0, big = 0;
+        if (threadIdx.x < r || (r == RADIX - 1 && threadIdx.x == r)) {
+            unsigned long long v;
+            tc::SpinGuard guard;
+            while ((uint32_t)((v = __hip_atomic_load(&look[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
+                if (tc::spin_expired(guard)) { // (flagged, never hung: every block publishes before it does anything else)
+                    tc::invariant_failed(violations);
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+            }
+            big = (uint32_t)v;
+            mine = threadIdx.x < r ? big : 0u;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            mine += __shfl_xor(mine, off, 64);
+            big = max(big, __shfl_xor(big, off, 64));
+        }
+        __syncthreads(); // (s_part is free again)
+        if (lane == 0 && wave < RADIX / 64) {
+            s_part[wave] = mine;
+            s_part[RADIX / 64 + wave] = big;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t b0 = 0, m0 = 0;
+            for (int q = 0; q < RADIX / 64; ++q) {
+                b0 += s_part[q];
+                m0 = max(m0, s_part[RADIX / 64 + q]);
+            }
+            s_base = b0;
+            if (r == RADIX - 1 && range_hint != nullptr)
+                __hip_atomic_store(range_hint, ((unsigned long long)n << 32) | m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        return s_base;
+    };
+    if (c == 0u) {
+        if (r == RADIX - 1) (void)place(); // (the hint)
+        return;
+    }
     const uint32_t lo = range_lo(r, msd_mul);
-    const uint64_t* in = elem_in + base;
-    uint64_t* out = elem_out + base;
 
     if (c <= FIN_CAP) {
+        // which tile owns position p of the range
+        auto expand = [&](uint32_t* s_owner) {
+            // tile t's piece is usually a handful of elements (n / 256 / tiles: 16 of a 1 Mi batch): its thread writes them;
+            // a long piece (the range's requests came in a burst) is left to the whole wave
+            constexpr uint32_t LONG_PIECE = 48;
+            const uint32_t t = threadIdx.x;
+            uint32_t p0 = 0, p1 = 0;
+            if (t < tiles) {
+                p0 = s_pos[t];
+                p1 = s_pos[t + 1];
+            }
+            const bool is_long = p1 - p0 > LONG_PIECE;
+            if (!is_long)
+                for (uint32_t p = p0; p < p1; ++p) s_owner[p] = t;
+            unsigned long long lm = __ballot(is_long);
+            while (lm) {
+                const int src = __builtin_ctzll(lm);
+                lm &= lm - 1ull;
+                const uint32_t q0 = __shfl(p0, src, 64), q1 = __shfl(p1, src, 64), tt = (uint32_t)wave * 64u + (uint32_t)src;
+                for (uint32_t p = q0 + (uint32_t)lane; p < q1; p += 64u) s_owner[p] = tt;
+            }
+        };
+        const uint32_t width = range_lo(r + 1u, msd_mul) - lo; // slots of my range (every offset is below it)
+        if (width <= CNT_W_MAX) {
+            // COUNTING: one byte counter per slot, bumped with one LDS atomic per element whose return value is the
+            // element's arrival number among the requests of its slot; a scan over the counters gives every slot's place.
+            // Requests of one slot must end up in index order (= position order p): the few slots with more than one
+            // request sort their members by p (each counts the members before it).  A slot with more than CNT_DUP_MAX
+            // requests (the counter would not even hold 256) sends the whole range to the ballot passes below.
+            const uint32_t nw = (width + 3u) / 4u;
+            for (uint32_t i = threadIdx.x; i < nw; i += FIN_THREADS) c_cnt[i] = 0;
+            if (threadIdx.x == 0) s_flag = 0;
+            uint32_t* s_owner = c_fin; // (free until the sorted range is written)
+            expand(s_owner);
+            __syncthreads();
+            RS_STAMP(1, 4, 128);
+            const uint32_t strip = ((c + FIN_THREADS - 1) / FIN_THREADS) * 64u;
+            uint32_t kv[FIN_ITEMS], arr[FIN_ITEMS];
+            bool valid[FIN_ITEMS], over = false;
+#pragma unroll
+            for (int j = 0; j < FIN_ITEMS; ++j) {
+                const uint32_t p = (uint32_t)wave * strip + (uint32_t)j * 64u + (uint32_t)lane;
+                valid[j] = (uint32_t)j * 64u < strip && p < c;
+                kv[j] = 0;
+                arr[j] = 0;
+                if (valid[j]) {
+                    const uint32_t t = s_owner[p];
+                    const uint64_t e = tiled[(size_t)t * tile_len + s_st[t] + (p - s_pos[t])];
+                    s_idx[p] = (uint32_t)e;
+                    const uint32_t sub = (uint32_t)(e >> 32) - lo;
+                    kv[j] = (sub << FIN_POS_BITS) | p;
+                    const uint32_t sh = 8u * (sub & 3u);
+                    arr[j] = (atomicAdd(&c_cnt[sub >> 2], 1u << sh) >> sh) & 255u;
+                    over |= arr[j] >= CNT_DUP_MAX;
+                }
+            }
+            if (over) s_flag = 1u;
+            __syncthreads();
+            RS_STAMP(1, 5, 128);
+            if (s_flag == 0u) { // (block-uniform)
+                // where every word of four counters starts: each thread sums a run of words, the block scans the sums
+                const uint32_t per = (nw + FIN_THREADS - 1) / FIN_THREADS;
+                const uint32_t w0 = min(threadIdx.x * per, nw), w1 = min(w0 + per, nw);
+                uint32_t mine = 0;
+                for (uint32_t i = w0; i < w1; ++i) mine += (c_cnt[i] * 0x01010101u) >> 24; // (four counters of at most 16: no carry)
+                uint32_t incl = mine;
+                for (int off = 1; off < 64; off <<= 1) {
+                    const uint32_t o = __shfl_up(incl, off, 64);
+                    if (lane >= off) incl += o;
+                }
+                if (lane == 63) s_part[wave] = incl;
+                __syncthreads();
+                uint32_t run = incl - mine;
+                for (int q = 0; q < wave; ++q) run += s_part[q];
+                for (uint32_t i = w0; i < w1; ++i) {
+                    c_ws[i] = (uint16_t)run;
+                    run += (c_cnt[i] * 0x01010101u) >> 24;
+                }
+                __syncthreads();
+                RS_STAMP(1, 6, 128);
+                // place: slots with one request know their position; the members of the others meet in the slot's places first
+                uint32_t q_of[FIN_ITEMS], len[FIN_ITEMS];
+                uint32_t* s_grp = c_fin;
+#pragma unroll
+                for (int j = 0; j < FIN_ITEMS; ++j) {
+                    q_of[j] = 0;
+                    len[j] = 0;
+                    if (valid[j]) {
+                        const uint32_t sub = kv[j] >> FIN_POS_BITS, sh = 8u * (sub & 3u);
+                        const uint32_t w = c_cnt[sub >> 2];
+                        len[j] = (w >> sh) & 255u;
+                        q_of[j] = (uint32_t)c_ws[sub >> 2] + (((w & ((1u << sh) - 1u)) * 0x01010101u) >> 24);
+                        if (len[j] > 1u) s_grp[q_of[j] + arr[j]] = kv[j] & (FIN_CAP - 1u);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < FIN_ITEMS; ++j) {
+                    if (valid[j] && len[j] > 1u) {
+                        const uint32_t p = kv[j] & (FIN_CAP - 1u), g0 = q_of[j];
+                        uint32_t before = 0;
+                        for (uint32_t i = 0; i < len[j]; ++i) before += s_grp[g0 + i] < p ? 1u : 0u;
+                        q_of[j] = g0 + before;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int j = 0; j < FIN_ITEMS; ++j)
+                    if (valid[j]) c_fin[q_of[j]] = kv[j];
+                __syncthreads();
+                RS_STAMP(1, 12, 128);
+                const uint32_t base = place();
+                RS_STAMP(1, 13, 128);
+                uint64_t* out = elem_out + base;
+                for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) {
+                    const uint32_t v = c_fin[q];
+                    out[q] = ((uint64_t)(lo + (v >> FIN_POS_BITS)) << 32) | s_idx[v & (FIN_CAP - 1u)];
+                }
+                RS_STAMP(1, 14, 128);
+                return;
+            }
+            __syncthreads(); // (a slot too popular for its counter: everybody has left the counters before they are reused)
+        }
+        uint32_t* s_owner = s_kv[1]; // (free until the second pass writes it)
+        expand(s_owner);
+        __syncthreads();
         // every wave takes an equal strip of whole 64-position rows, so that all 16 waves work on a half-full range too
         const uint32_t strip = ((c + FIN_THREADS - 1) / FIN_THREADS) * 64u; // <= 64 * FIN_ITEMS
         uint32_t kv[FIN_ITEMS], dig[FIN_ITEMS], rank[FIN_ITEMS];
@@ -590,45 +903,68 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(uint64_t* __restr
             valid[j] = (uint32_t)j * 64u < strip && p < c;
             kv[j] = 0;
             if (valid[j]) {
-                const uint64_t e = in[p];
+                const uint32_t t = s_owner[p];
+                const uint64_t e = tiled[(size_t)t * tile_len + s_st[t] + (p - s_pos[t])];
                 s_idx[p] = (uint32_t)e;
                 kv[j] = (((uint32_t)(e >> 32) - lo) << FIN_POS_BITS) | p;
             }
         }
+        RS_STAMP(1, 5, 128);
         for (int ps = 0; ps < sub_passes; ++ps) {
+            RS_STAMP(1, 6 + 3 * ps, 128);
             if (ps != 0) {
 #pragma unroll
                 for (int j = 0; j < FIN_ITEMS; ++j) {
                     const uint32_t p = (uint32_t)wave * strip + (uint32_t)j * 64u + (uint32_t)lane;
                     if (valid[j]) kv[j] = s_kv[(ps - 1) & 1][p];
                 }
+                __syncthreads(); // (everybody has read s_owner / the previous order before s_kv[ps & 1] is rewritten)
             }
 #pragma unroll
             for (int j = 0; j < FIN_ITEMS; ++j) dig[j] = (kv[j] >> (FIN_POS_BITS + 8u * (uint32_t)ps)) & 255u;
             fin_rank<FIN_ITEMS>(dig, valid, rank, s_cnt, s_tot);
+            RS_STAMP(1, 7 + 3 * ps, 128);
             fin_scan_digits(s_tot, s_start, s_part);
+            RS_STAMP(1, 8 + 3 * ps, 128);
 #pragma unroll
             for (int j = 0; j < FIN_ITEMS; ++j)
                 if (valid[j]) s_kv[ps & 1][s_start[dig[j]] + s_cnt[wave][dig[j]] + rank[j]] = kv[j];
             __syncthreads();
         }
+        RS_STAMP(1, 12, 128);
+        const uint32_t base = place();
+        RS_STAMP(1, 13, 128);
+        uint64_t* out = elem_out + base;
         const uint32_t* fin = s_kv[(sub_passes - 1) & 1];
         for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) {
             const uint32_t v = fin[q];
             out[q] = ((uint64_t)(lo + (v >> FIN_POS_BITS)) << 32) | s_idx[v & (FIN_CAP - 1u)];
         }
+        RS_STAMP(1, 14, 128);
         return;
     }
 
-    // A range that does not fit: stable LSD passes over the offset, chunk by chunk through global memory, by this
-    // block alone (in -> out -> in ..., the result copied to `out` if it ends in `in`).  Slow, exact, and rare: the
-    // host leaves skewed streams on the three-pass path.
-    uint64_t* a = elem_in + base;
-    uint64_t* b = out;
+    // A range that does not fit: collect it, then stable LSD passes over the offset, chunk by chunk through global memory,
+    // by this block alone (out -> scratch -> out; one pass: copied back).  Slow, exact, and rare: the host leaves skewed
+    // streams on the LSD passes.
+    const uint32_t base = place();
+    uint64_t* b = elem_out + base;
+    uint64_t* a = scratch + base;
+    for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) {
+        uint32_t lo_t = 0, hi_t = tiles; // the last tile whose piece starts at or before q
+        while (hi_t - lo_t > 1u) {
+            const uint32_t mid = (lo_t + hi_t) >> 1;
+            if (s_pos[mid] <= q) lo_t = mid;
+            else hi_t = mid;
+        }
+        b[q] = tiled[(size_t)lo_t * tile_len + s_st[lo_t] + (q - s_pos[lo_t])];
+    }
+    __threadfence();
+    __syncthreads();
     uint32_t* s_off = s_kv[0]; // [RADIX] running start of every digit in the destination
     for (int ps = 0; ps < sub_passes; ++ps) {
-        const uint64_t* src = (ps & 1) ? b : a;
-        uint64_t* dst = (ps & 1) ? a : b;
+        const uint64_t* src = (ps & 1) ? a : b;
+        uint64_t* dst = (ps & 1) ? b : a;
         const uint32_t shift = 8u * (uint32_t)ps;
         if (threadIdx.x < RADIX) s_off[threadIdx.x] = 0;
         __syncthreads();
@@ -670,7 +1006,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(uint64_t* __restr
         __threadfence(); // this block's stores have reached the L2 before its next pass reads them back (ld_l2)
         __syncthreads();
     }
-    if ((sub_passes & 1) == 0)
+    if ((sub_passes & 1) != 0)
         for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) b[q] = ld_l2(&a[q]);
 }
 

@@ -80,14 +80,15 @@ int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_ke
     return TC_E_OK;
 }
 
-// Does this batch take the range path (radix_sort.hpp: one partition pass by key range + an in-LDS finish per range)?
-// The host cannot see the batch; it goes by the largest range of a RECENT batch of the stream, which the first pass of
-// every sort mirrors into pinned memory (never waited for).  No hint yet, a hint that predicts a range beyond what a
-// block finishes in LDS, or a batch too large: the three LSD passes.  A wrong guess costs time, not correctness
-// (k_finish sorts an oversized range through global memory).
+// Does this batch take the range path (radix_sort.hpp: every tile partitioned by key range in place + one block per range
+// that collects and finishes it in LDS -- two launches instead of a histogram and three LSD passes)?  The host cannot see
+// the batch; it goes by the largest range of a RECENT batch of the stream, which every grouping mirrors into pinned memory
+// (never waited for).  No hint yet, a hint that predicts a range beyond what a block finishes in LDS, or a batch too large:
+// the LSD passes.  A wrong guess costs time, not correctness (k_finish sorts an oversized range through global memory).
 static bool range_applies(const tc_engine* e, uint32_t n, bool piped) {
     if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return false;
-    if (n < 256u || n > e->range_max_n) return false;
+    const uint32_t tile = rs::THREADS * (uint32_t)(piped ? e->sort_items_piped : SORT_ITEMS);
+    if (n < 256u || n > e->range_max_n || (n + tile - 1) / tile > (uint32_t)rs::FIN_THREADS) return false;
     const unsigned long long h = *(volatile unsigned long long*)e->range_hint_host;
     const uint64_t hn = h >> 32, hmax = h & 0xFFFFFFFFull;
     return hn != 0 && hmax * (uint64_t)n <= hn * (uint64_t)(rs::FIN_CAP / 8u * 7u);
@@ -100,46 +101,50 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
                                     uint8_t* fill = nullptr, uint32_t fill_value = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
-    const int passes = ranged ? 1 : (bits + 7) / 8;
+    const int passes = (bits + 7) / 8;
     const int items = piped ? e->sort_items_piped : SORT_ITEMS;
     const uint32_t tile = rs::THREADS * (uint32_t)items;
     const uint32_t tiles = (n + tile - 1) / tile;
     rs::Workspace ws = rs::carve(ss.ws, ss.hist_parity, e->sort_max_tiles);
     ws.violations = e->counters + (TC_CNT_COUNT + 1) + 3;
-    ss.hist_parity ^= 1u;
-    // the range histogram is counted beside the LSD digits too (one more LDS atomic per request) whenever the key space
-    // admits the range path: it is where the hint comes from
-    const uint32_t msd_mul = e->range_ok ? e->range_mul : 0u;
-    unsigned long long* hint = e->range_ok ? e->range_hint_dev : nullptr;
-    prof_begin_m(e, TC_STAGE_PREP, s);
-    TC_LAUNCH_T(e, TC_STAGE_PREP, (hipEvent_t) nullptr, rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value, msd_mul, ranged ? 1 : 0);
-    prof_end_m(e, s);
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
+    unsigned long long* hint = e->range_ok ? e->range_hint_dev : nullptr;
     if (ranged) {
-        // partition by range into elem_b, finish every range into elem_a
+        // tiles partitioned in place into elem_b (+ the table, in the look-back words of the first LSD pass, which this batch
+        // does not run), every range finished into elem_a.  No histogram launch: the histogram parity stays as it is.
+        uint32_t* table = ws.status;
+        if (++ss.range_seq == 0u) ss.range_seq = 1u;
         prof_begin_m(e, TC_STAGE_SORT, s);
-#define TC_MSD(IT) \
-    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rs::k_onesweep<IT, true, true>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot, \
-                (const uint64_t*)nullptr, bufs[1], n, cap, 0, ws, (const uint32_t*)nullptr, 0u, msd_mul, hint)
-        if (items == 32) TC_MSD(32);
-        else if (items == 16) TC_MSD(16);
-        else TC_MSD(8);
-#undef TC_MSD
+#define TC_TILES(IT) \
+    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rs::k_tile_ranges<IT>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot, bufs[1], table, n, cap, \
+                e->range_mul, fill, fill_value)
+        if (items == 32) TC_TILES(32);
+        else if (items == 16) TC_TILES(16);
+        else TC_TILES(8);
+#undef TC_TILES
         prof_end_m(e, s);
         prof_begin_m(e, TC_STAGE_SORT, s);
         hipEvent_t stop = e->prof_on ? nullptr : stop_last;
-        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, bufs[1], bufs[0], n, ws, msd_mul, e->range_sub_passes);
+        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)table, bufs[0],
+                    ss.elem_c, ss.range_look, ss.range_seq, n, tiles, tile, e->range_mul, e->range_sub_passes, hint, ws.violations);
         prof_end_m(e, s);
         return bufs[0];
     }
+    ss.hist_parity ^= 1u;
+    // the range histogram is counted beside the LSD digits (one more LDS atomic per request) whenever the key space admits
+    // the range path: it is where the hint comes from while a stream is on the LSD passes
+    const uint32_t msd_mul = e->range_ok ? e->range_mul : 0u;
+    prof_begin_m(e, TC_STAGE_PREP, s);
+    TC_LAUNCH_T(e, TC_STAGE_PREP, (hipEvent_t) nullptr, rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value, msd_mul);
+    prof_end_m(e, s);
     const uint64_t* in = nullptr;
     for (int p = 0; p < passes; ++p) {
         uint64_t* out = bufs[p & 1];
         prof_begin_m(e, TC_STAGE_SORT, s); // one record per pass: the stage average is per kernel launch
         hipEvent_t stop = (p + 1 == passes && !e->prof_on) ? stop_last : nullptr;
 #define TC_PASS(IT, FI) \
-    TC_LAUNCH_T(e, TC_STAGE_SORT, stop, (rs::k_onesweep<IT, FI, false>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
-              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min, 0u, (FI) ? hint : (unsigned long long*)nullptr)
+    TC_LAUNCH_T(e, TC_STAGE_SORT, stop, (rs::k_onesweep<IT, FI>), dim3(tiles), dim3(rs::THREADS), 0, s, (FI) ? d_slot : (const uint32_t*)nullptr, \
+              (FI) ? (const uint64_t*)nullptr : in, out, n, cap, p, ws, gate, gate_min, (FI) ? hint : (unsigned long long*)nullptr)
         if (p == 0) {
             if (items == 32) TC_PASS(32, true);
             else if (items == 16) TC_PASS(16, true);
