@@ -165,8 +165,8 @@ int engine_alloc(tc_engine* e) {
         TC_HIP(e, hipMalloc(&ss.elem_b, mb * sizeof(uint64_t)));
         if (e->range_ok) {
             TC_HIP(e, hipMalloc(&ss.elem_c, std::min<uint64_t>(mb, e->range_max_n) * sizeof(uint64_t)));
-            TC_HIP(e, hipMalloc(&ss.range_look, rs::RADIX * sizeof(unsigned long long)));
-            TC_HIP(e, hipMemsetAsync(ss.range_look, 0, rs::RADIX * sizeof(unsigned long long), (hipStream_t)0));
+            TC_HIP(e, hipMalloc(&ss.range_totals, 2 * rs::RADIX * sizeof(uint32_t)));
+            TC_HIP(e, hipMemsetAsync(ss.range_totals, 0, 2 * rs::RADIX * sizeof(uint32_t), (hipStream_t)0));
         }
         TC_HIP(e, hipMalloc(&ss.ws, words * sizeof(uint32_t)));
         TC_HIP(e, hipMemsetAsync(ss.ws, 0, words * sizeof(uint32_t), (hipStream_t)0));
@@ -405,7 +405,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_look, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }

@@ -102,8 +102,8 @@ struct tc_engine {
     struct SortSet {
         uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
         uint64_t* elem_c = nullptr;                    // range path: scratch of a range that does not fit LDS (min(max_batch, range_max_n))
-        unsigned long long* range_look = nullptr;      // range path: RADIX words, seq << 32 | size of range r
-        uint32_t range_seq = 0;
+        uint32_t* range_totals = nullptr;              // range path: 2 x RADIX words, the ranges' sizes of this / the next batch of the set
+        uint32_t range_parity = 0;
         uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
         uint32_t* k_slot = nullptr;                    // key mode: slots resolved for the batch using this set
         uint32_t* h_slot = nullptr;                    // TC_B_ASYNC: the host batch's slot column, staged (lazy)

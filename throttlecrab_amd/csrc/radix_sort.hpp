@@ -553,12 +553,13 @@ __device__ __forceinline__ void fin_scan_digits(const uint32_t* s_tot, uint32_t*
 // ---------------------------------------------------------------------------
 // range path, first half: every tile partitioned by range in place + its table row
 // ---------------------------------------------------------------------------
-// table[tile * RADIX + r] = (elements of range r in the tile) << 16 | where they start inside the tile.
+// table[tile * RADIX + r] = (elements of range r in the tile) << 16 | where they start inside the tile;
+// totals[r] += elements of range r (zero on entry: k_finish of the set's previous batch cleared it).
 // `fill` (TC_B_OUTPUTS_IDLE batches): see k_hist -- the range path has no histogram launch, so the decision bytes are preset here.
 template <int ITEMS>
 __global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restrict__ slot_in, uint64_t* __restrict__ elem_out,
-                                                         uint32_t* __restrict__ table, uint32_t n, uint32_t cap, uint32_t msd_mul,
-                                                         uint8_t* __restrict__ fill, uint32_t fill_value) {
+                                                         uint32_t* __restrict__ table, uint32_t* __restrict__ totals, uint32_t n, uint32_t cap,
+                                                         uint32_t msd_mul, uint8_t* __restrict__ fill, uint32_t fill_value) {
     constexpr int TILE = THREADS * ITEMS;
     static_assert(TILE <= 65535, "a tile's starts and counts are packed into 16 bits each");
     __shared__ uint32_t s_wave[WAVES][RADIX];
@@ -634,6 +635,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restr
         const uint32_t start = carry + v - run;
         s_tstart[d] = start;
         table[(size_t)tile * RADIX + d] = (run << 16) | start;
+        if (run) atomicAdd(&totals[d], run); // the ranges' sizes over the whole batch (k_finish: where every range goes); nothing waits for it
     }
     __syncthreads();
     RS_STAMP(0, 5, gridDim.x / 2);
@@ -661,15 +663,17 @@ __global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restr
 // range path, second half: one block per range
 // ---------------------------------------------------------------------------
 // `tiled`: k_tile_ranges' output (tile size `tile_len`, `tiles` <= FIN_THREADS of them) with its `table`; `elem_out`: the batch
-// sorted by (slot, index); `scratch`: a third array of the batch's size (ranges that do not fit LDS); `look`: RADIX words,
-// seq << 32 | elements of range r, tagged with this launch's sequence number so that nothing has to be cleared;
+// sorted by (slot, index); `scratch`: a third array of the batch's size (ranges that do not fit LDS); `totals`: the ranges' sizes
+// (k_tile_ranges), `totals_next`: the other parity's, cleared here for the set's next batch -- no block waits for another
+// (a first version had every block publish its size and read the others': under load, blocks that had been dispatched
+// early then sat on their CU waiting for the late ones, 41 us per launch in the pipelined run against 14 alone);
 // sub_passes = 8-bit digits of the offset inside a range (1 or 2: the host takes this path only when the widest range
 // is at most 65536 slots); `range_hint`: n << 32 | largest range, into pinned host memory (block RADIX - 1).
 static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* __restrict__ tiled, const uint32_t* __restrict__ table,
                                                                uint64_t* __restrict__ elem_out, uint64_t* __restrict__ scratch,
-                                                               unsigned long long* __restrict__ look, uint32_t seq, uint32_t n,
+                                                               const uint32_t* __restrict__ totals, uint32_t* __restrict__ totals_next, uint32_t n,
                                                                uint32_t tiles, uint32_t tile_len, uint32_t msd_mul, int sub_passes,
-                                                               unsigned long long* __restrict__ range_hint, unsigned long long* violations) {
+                                                               unsigned long long* __restrict__ range_hint) {
     __shared__ uint32_t s_idx[FIN_CAP];            // request index of position p (never moves)
     __shared__ uint32_t s_u[FIN_UNION_WORDS];      // the two ways of sorting a range share this
     // ballot path: offset inside the range << FIN_POS_BITS | p in the order reached so far (x2), per-wave digit counters, digit totals / starts
@@ -714,8 +718,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
         s_st[threadIdx.x] = w & 0xFFFFu;
         if (threadIdx.x == 0) {
             s_pos[FIN_THREADS] = total;
-            // my size, for the blocks of the later ranges (they read it at the very end of their work)
-            __hip_atomic_store(&look[r], ((unsigned long long)seq << 32) | total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            totals_next[r] = 0;
         }
         c = total;
         __syncthreads();
@@ -724,17 +727,8 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
     // where my range goes in the sorted batch: the sizes of the ranges before mine (and, for the last block, the largest one)
     auto place = [&]() -> uint32_t {
         uint32_t mine = 0, big = 0;
-        if (threadIdx.x < r || (r == RADIX - 1 && threadIdx.x == r)) {
-            unsigned long long v;
-            tc::SpinGuard guard;
-            while ((uint32_t)((v = __hip_atomic_load(&look[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 32) != seq) {
-                if (tc::spin_expired(guard)) { // (flagged, never hung: every block publishes before it does anything else)
-                    tc::invariant_failed(violations);
-                    break;
-                }
-                __builtin_amdgcn_s_sleep(2);
-            }
-            big = (uint32_t)v;
+        if (threadIdx.x < RADIX) {
+            big = totals[threadIdx.x];
             mine = threadIdx.x < r ? big : 0u;
         }
         for (int off = 32; off > 0; off >>= 1) {

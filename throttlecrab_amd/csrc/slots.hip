@@ -113,10 +113,12 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
         // tiles partitioned in place into elem_b (+ the table, in the look-back words of the first LSD pass, which this batch
         // does not run), every range finished into elem_a.  No histogram launch: the histogram parity stays as it is.
         uint32_t* table = ws.status;
-        if (++ss.range_seq == 0u) ss.range_seq = 1u;
+        uint32_t* totals = ss.range_totals + (size_t)ss.range_parity * rs::RADIX;         // zero: cleared by the finish of the set's previous batch
+        uint32_t* totals_next = ss.range_totals + (size_t)(ss.range_parity ^ 1u) * rs::RADIX;
+        ss.range_parity ^= 1u;
         prof_begin_m(e, TC_STAGE_SORT, s);
 #define TC_TILES(IT) \
-    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rs::k_tile_ranges<IT>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot, bufs[1], table, n, cap, \
+    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rs::k_tile_ranges<IT>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot, bufs[1], table, totals, n, cap, \
                 e->range_mul, fill, fill_value)
         if (items == 32) TC_TILES(32);
         else if (items == 16) TC_TILES(16);
@@ -126,7 +128,7 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
         prof_begin_m(e, TC_STAGE_SORT, s);
         hipEvent_t stop = e->prof_on ? nullptr : stop_last;
         TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)table, bufs[0],
-                    ss.elem_c, ss.range_look, ss.range_seq, n, tiles, tile, e->range_mul, e->range_sub_passes, hint, ws.violations);
+                    ss.elem_c, (const uint32_t*)totals, totals_next, n, tiles, tile, e->range_mul, e->range_sub_passes, hint);
         prof_end_m(e, s);
         return bufs[0];
     }

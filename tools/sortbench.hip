@@ -43,11 +43,11 @@ int main(int argc, char** argv) {
     printf("cap %u  range mul %u  widest range %u slots  sub passes %d  lo(1)=%u lo(255)=%u\n", cap, mul, width, sub_passes, rs::range_lo(1, mul), rs::range_lo(255, mul));
     if (width > 65536) { printf("key space too wide for the range path\n"); return 1; }
     const uint32_t NMAX = 1u << 21;
-    uint32_t* d_slot; uint64_t *a, *b, *c3; uint32_t* wsmem; unsigned long long *hint, *look, *viol; uint32_t seq = 0;
+    uint32_t* d_slot; uint64_t *a, *b, *c3; uint32_t* wsmem; unsigned long long* hint; uint32_t* totals; uint32_t tpar = 0;
     const uint32_t tile = rs::THREADS * SB_ITEMS, max_tiles = (NMAX + tile - 1) / tile;
     const size_t words = rs::workspace_words(max_tiles);
     CK(hipMalloc(&d_slot, NMAX * 4)); CK(hipMalloc(&a, NMAX * 8)); CK(hipMalloc(&b, NMAX * 8)); CK(hipMalloc(&c3, NMAX * 8)); CK(hipMalloc(&wsmem, words * 4));
-    CK(hipMalloc(&look, 256 * 8)); CK(hipMemset(look, 0, 256 * 8)); CK(hipMalloc(&viol, 64 * 8)); CK(hipMemset(viol, 0, 64 * 8));
+    CK(hipMalloc(&totals, 512 * 4)); CK(hipMemset(totals, 0, 512 * 4));
     CK(hipHostMalloc((void**)&hint, 64, hipHostMallocDefault));
     CK(hipMemset(wsmem, 0, words * 4));
     CK(hipDeviceSynchronize());
@@ -86,10 +86,10 @@ int main(int argc, char** argv) {
                 } else {
                     CK(hipEventRecord(ev[1]));
                     if (tiles > (uint32_t)rs::FIN_THREADS) { printf("(n too large for the range path)\n"); break; }
-                    hipLaunchKernelGGL((rs::k_tile_ranges<SB_ITEMS>), dim3(tiles), dim3(rs::THREADS), 0, 0, d_slot, b, ws.status, n, cap, mul, (uint8_t*)nullptr, 0u);
+                    hipLaunchKernelGGL((rs::k_tile_ranges<SB_ITEMS>), dim3(tiles), dim3(rs::THREADS), 0, 0, d_slot, b, ws.status, totals + 256 * tpar, n, cap, mul, (uint8_t*)nullptr, 0u);
                     CK(hipEventRecord(ev[2]));
-                    ++seq;
-                    hipLaunchKernelGGL(rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, 0, (const uint64_t*)b, (const uint32_t*)ws.status, a, c3, look, seq, n, tiles, tile, mul, sub_passes, hint, viol + 8);
+                    hipLaunchKernelGGL(rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, 0, (const uint64_t*)b, (const uint32_t*)ws.status, a, c3, (const uint32_t*)(totals + 256 * tpar), totals + 256 * (tpar ^ 1u), n, tiles, tile, mul, sub_passes, hint);
+                    tpar ^= 1u;
                     CK(hipEventRecord(ev[3]));
                     CK(hipEventRecord(ev[4]));
                 }
