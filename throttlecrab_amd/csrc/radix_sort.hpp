@@ -572,10 +572,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restr
     uint32_t key[ITEMS], rank[ITEMS];
     const uint32_t wbase = tile * TILE + wave * 64 * ITEMS + lane; // wave-striped: (wave, item, lane) order is index order
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t pos = wbase + j * 64;
-        key[j] = pos < n ? clamp_slot(slot_in[pos], cap) : 0u;
-    }
+    for (int j = 0; j < ITEMS; ++j) key[j] = slot_in[min(wbase + j * 64, n - 1u)]; // (raw: nothing here waits for a load)
     // every wave clears its own counter row: no block barrier stands between the loads and the ranking, which starts on
     // the first items while the later ones are still on their way (the loads were 4.6 of the kernel's 11 us)
 #pragma unroll
@@ -599,6 +596,7 @@ __global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restr
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const bool valid = (wbase + j * 64) < n;
+        key[j] = clamp_slot(key[j], cap);
         const uint32_t d = valid ? __umulhi(key[j], msd_mul) : 0u;
         unsigned long long m = __ballot(valid);
 #pragma unroll
