@@ -20,11 +20,11 @@ def main():
     print("# kernels columns:", cols)
     qcol = next((x for x in ("stream_id", "queue_id", "queue") if x in cols), None)
     rows = c.execute(f"select name, start, end, {qcol or '0'} from kernels order by start").fetchall()
-    hist = [r for r in rows if "k_hist" in r[0]]
-    sweeps = [r for r in rows if "k_onesweep" in r[0] or "k_finish" in r[0]]   # (range path: partition pass + finish)
+    # a batch's grouping chain starts with k_hist (LSD passes) or with k_tile_ranges (range path: + k_finish)
+    hist = [r for r in rows if "k_hist" in r[0] or "k_tile_ranges" in r[0]]
+    sweeps = [r for r in rows if "k_onesweep" in r[0] or "k_finish" in r[0]]
     evals = [r for r in rows if "k_eval_sorted" in r[0] or "k_eval_general" in r[0]]
-    passes = len(sweeps) // max(1, len(hist))
-    print(f"# {len(hist)} k_hist, {len(sweeps)} k_onesweep ({passes} per batch), {len(evals)} evaluations")
+    print(f"# {len(hist)} chain heads (k_hist / k_tile_ranges), {len(sweeps)} k_onesweep / k_finish, {len(evals)} evaluations")
     # the i-th evaluation belongs to the i-th batch; its sort chain is the i-th k_hist (in START order the chains of
     # different streams interleave, so the passes are matched by stream)
     by_q = {}
@@ -37,12 +37,21 @@ def main():
     t0 = rows[0][1]
     used = {q: 0 for q in by_q}
     chain_end = []
+    heads_by_q = {}
+    for h in hist_sorted:
+        heads_by_q.setdefault(h[3], []).append(h)
     for h in hist_sorted:
         q = h[3]
         lst = by_q.get(q, [])
         k = used.get(q, 0)
-        mine = lst[k:k + passes]
-        used[q] = k + passes
+        # the chain's kernels: everything on its stream that starts before the stream's next chain head
+        later = [x for x in heads_by_q[q] if x[1] > h[1]]
+        nxt = later[0][1] if later else float("inf")
+        m = k
+        while m < len(lst) and lst[m][1] < nxt:
+            m += 1
+        mine = lst[k:m]
+        used[q] = m
         chain_end.append((mine[-1][2] if mine else h[2], q, [(m[1], m[2]) for m in mine]))
     print(f"{'batch':>5s} {'q':>6s} {'hist_start':>10s} {'hist':>6s} {'p1':>6s} {'p2':>6s} {'p3':>6s} {'sort_end':>9s} {'eval_start':>10s} {'eval':>6s} "
           f"{'slack':>7s} {'gap':>6s} {'step':>6s}   (us)")
