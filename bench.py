@@ -613,22 +613,20 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     else:
         host = [W.uniform_slots(world * a.keys, B, seed=2, start=i * G + rank * B) for i in range(n_distinct)]
     d_slice = [torch.from_numpy(h.astype(np.int32)).to(dev) for h in host]
-    xr = sharded.ExchangeRank(eng, fab, rank, world, B, route_ring=8)
-    outs = [t.BatchResult(allowed=torch.empty(2 * B, dtype=torch.uint8, device=dev)) for _ in range(OUT_RING)]
+    xr = sharded.ExchangeRank(eng, fab, rank, world, B)
+    # a step's decisions: at most world x B requests may land here (every source's whole slice)
+    outs = [t.BatchResult(allowed=torch.empty(world * B, dtype=torch.uint8, device=dev)) for _ in range(OUT_RING)]
     cnt_view = sharded.device_counter_view(eng)
     gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
     top_gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64, device=dev)
     decided = 0
     # the host never waits in steady state: a slice is routed (straight into the destinations' inboxes) LA_ROUTE steps and
-    # announced LA_POST steps before it is evaluated
+    # announced LA_POST steps before it is evaluated; the three phases of a step are ONE library call (tc_exchange_step)
     LA_ROUTE, LA_POST = 4, 1
 
     def step(i, last=False, metrics=True):
         nonlocal decided
-        xr.timed("route", i + LA_ROUTE, d_slice[(i + LA_ROUTE) % n_distinct])
-        xr.timed("post", i + LA_POST)
-        segs = xr.timed("collect", i)
-        decided += xr.timed("evaluate", i, segs, W.T0_NS + i * 1_000_000, outs)
+        decided += xr.timed("step", i, d_slice[(i + LA_ROUTE) % n_distinct], LA_ROUTE, LA_POST, W.T0_NS + i * 1_000_000, outs)
         if not metrics:
             return
         if i % METRICS_EVERY == METRICS_EVERY - 1 or last:
@@ -658,7 +656,7 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     torch.cuda.synchronize()
     dist.barrier()
     dt_mine = time.perf_counter() - t0
-    host_us = {k_: 1e6 * v / a.steps for k_, v in xr.host_s.items()}   # of the timed region only
+    host_us = {k_: 1e6 * v / a.steps for k_, v in xr.host_s.items() if v}   # of the timed region only
     tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     dt = float(tm.item())
@@ -666,13 +664,21 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     res["route"] = "exchange"
     res["host_us_per_step"] = host_us  # where the host's time goes
     print(f"[bench] rank {rank} host us/step (timed region): {host_us}", file=sys.stderr, flush=True)
-    # roofline of this rank's evaluation: HIP events per kernel (needs no peers: the inboxes of the last steps again)
+    # roofline of this rank's evaluation: HIP events per kernel (needs no peers: the inboxes of the last two steps again, handed
+    # to the engine directly as segmented batches)
     steps_p = min(a.steps, 12)
-    segs_last = [xr.collect(it - 1 - (k % 2)) for k in range(2)]
+    segs_last = [[(fab.inbox(rank, (it - 1 - q) % fab.ring, s_), int(fab.mail[rank, (it - 1 - q) % fab.ring, s_, 0])) for s_ in range(world)]
+                 for q in range(2)]
     eng.profile_enable(True)
     n_prof = 0
     for k in range(steps_p):
-        n_prof += xr.evaluate(it + 100 + k, segs_last[k % 2], W.T0_NS + (it + k) * 1_000_000, outs)
+        sg = segs_last[k % 2]
+        tot = sum(c_ for _, c_ in sg)
+        if tot == 0 or tot > eng.max_batch:
+            continue
+        eng.rate_limit_batch_slots(None, segments=sg, registered=True, quantity=1, now_ns=W.T0_NS + (it + k) * 1_000_000, want=("allowed",),
+                                   out=outs[k % OUT_RING], inputs_ready=True, outputs_idle=True)
+        n_prof += tot
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile_enable(False)
@@ -689,12 +695,14 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     # the inboxes are scratch by now -- once every rank has left its profile steps
     dist.barrier()
     torch.cuda.synchronize()
+    cnt_scratch = [torch.zeros(world, dtype=torch.int32, device=dev) for _ in range(8)]
     t1 = time.perf_counter()
     for k in range(8):
-        eng.route_batch(d_slice[k % n_distinct], world, only=-1, out=(None, None, xr.counts_dev[k % xr.route_ring]), ahead=True, no_readers=True,
+        eng.route_batch(d_slice[k % n_distinct], world, only=-1, out=(None, None, cnt_scratch[k]), ahead=True, no_readers=True,
                         out_dst=[fab.inbox(d, k % fab.ring, rank) for d in range(world)])
     torch.cuda.synchronize()
     res["router_ms_per_step"] = 1e3 * (time.perf_counter() - t1) / 8
+    xr.close()
     dist.barrier()
     eng.close()
     return res

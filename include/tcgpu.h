@@ -66,6 +66,8 @@ enum {
     TC_E_TABLE_FULL = -5,     /* string mode: no free slot / arena space for a new key */
     TC_E_NO_DEVICE = -6,
     TC_E_UNSUPPORTED = -7,
+    TC_E_AGAIN = -9,          /* tc_exchange_* with TC_X_NONBLOCKING: the phase's turn has not come (another rank, or the device,
+                               * has to get further first); nothing was done, call again */
     TC_E_INVARIANT = -8       /* a kernel flagged a broken internal invariant (a wait on another workgroup gave up after
                                * 2 s, a closed form met a state it was proven not to meet): results and resident state
                                * since the last call that returned TC_E_OK from tc_synchronize() are UNDEFINED.  Sticky:
@@ -404,12 +406,57 @@ typedef struct tc_forward {
 } tc_forward;
 int tc_forward_segments(tc_engine* e, const tc_forward* f);
 
+/* ---- the exchange as library calls (one rank's side; `--route exchange` of bench.py) -----------------------------------
+ * Every rank owns `ring` inbox slots per source in its own HBM ([ring][world][seg_cap] u32, shared with the peers through
+ * hipIpcGetMemHandle / hipIpcOpenMemHandle once, at set-up) and the ranks share one small host-memory block: mail
+ * [world][ring][world][2] = (count, step + 1) written by a source once its segment has landed, and done[world] = steps a
+ * destination has evaluated (which frees its inbox slots).  Per step i a rank
+ *   routes   its slice of global step i + route_ahead straight into the owners' inboxes (tc_route_batch, only = -1, out_dst),
+ *   posts    step i + post_ahead: (count, step) into every destination's mailbox once the router's tag is in,
+ *   collects the world mailbox words of step i and
+ *   evaluates the world inboxes as ONE batch whose slot column comes in pieces (sources in rank order).
+ * tc_exchange_step is those four in one call.  No collective, no host synchronisation in steady state (a phase only waits
+ * when its inputs are not there yet).  The caller primes the pipeline: routes 0 .. route_ahead - 1, posts 0 .. post_ahead - 1.
+ * tmpl: outputs, rate plan / quantity / timestamp and flags of the evaluation (device pointers; TC_B_INPUTS_READY is added);
+ * a step larger than the engine's max_batch is evaluated in chunks, each writing behind the previous one.  */
+#define TC_X_NONBLOCKING 0x1u    /* a phase whose turn has not come returns TC_E_AGAIN instead of waiting (ONE thread driving
+                                  * several ranks, as the tests do); a repeated phase of a step already done is a no-op */
+typedef struct tc_exchange tc_exchange;
+typedef struct tc_exchange_config {
+    uint32_t struct_size;      /* = sizeof(tc_exchange_config) */
+    uint32_t rank;             /* this shard */
+    uint32_t world;            /* shards, 1..64 */
+    uint32_t ring;             /* inbox slots per source (>= 2; a source may run ring - 1 steps ahead of a destination) */
+    uint32_t seg_cap;          /* requests one source may send per step (the slice length) */
+    uint32_t flags;            /* TC_X_* */
+    uint64_t keys_per_shard;
+    uint32_t* const* inbox;    /* HOST array [world]: inbox[d] = destination d's [ring][world][seg_cap] array as THIS process
+                                * addresses it (own: device memory; peers: hipIpcOpenMemHandle) */
+    uint32_t* mail;            /* host memory shared by all ranks, zero at set-up: [world][ring][world][2] */
+    int64_t* done;             /* ... [world] */
+} tc_exchange_config;
+int tc_exchange_create(tc_engine* e, const tc_exchange_config* c, tc_exchange** out);
+int tc_exchange_destroy(tc_exchange* x);
+int tc_exchange_route(tc_exchange* x, uint64_t step, const uint32_t* global_id, uint32_t n);
+int tc_exchange_post(tc_exchange* x, uint64_t step);
+int tc_exchange_collect(tc_exchange* x, uint64_t step, uint32_t* counts /* [world] or NULL */);
+int tc_exchange_evaluate(tc_exchange* x, uint64_t step, const tc_batch* tmpl, uint64_t* decided);
+int tc_exchange_step(tc_exchange* x, uint64_t step, const uint32_t* global_id_ahead, uint32_t n_ahead, uint32_t route_ahead,
+                     uint32_t post_ahead, const tc_batch* tmpl, uint64_t* decided);
+/* publish the steps whose evaluation has completed (frees inbox slots for the sources); never waits */
+int tc_exchange_poll(tc_exchange* x);
+
 /* The same map on the host: owner and shard-local slot of n global ids (either output may be NULL), and its
  * inverse (global id of slot `slot` of shard `owner`).  No device needed. */
 int tc_route_host(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* global_id, uint32_t* owner,
                   uint32_t* slot);
 int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* owner, const uint32_t* slot,
                      uint64_t* global_id);
+
+/* String keys across GPUs (README.md:247-249: "client-side sharding by key"): owner[i] = mix64(hash(key i) ^ salt) mod world --
+ * the front door of a sharded deployment of key-mode engines: split a key batch by owner, hand every GPU the keys it owns.
+ * key_off[n + 1] delimits the keys in key_bytes.  Host only. */
+int tc_route_keys_host(uint32_t world, uint64_t n, const uint8_t* key_bytes, const uint32_t* key_off, uint32_t* owner);
 
 /* Number of internal invariant violations the kernels have flagged since creation (always 0
  * unless there is a bug; the parity tests assert it). */

@@ -21,6 +21,7 @@ pub const TC_E_TABLE_FULL: c_int = -5;
 pub const TC_E_NO_DEVICE: c_int = -6;
 pub const TC_E_UNSUPPORTED: c_int = -7;
 pub const TC_E_INVARIANT: c_int = -8;
+pub const TC_E_AGAIN: c_int = -9;
 
 pub const TC_CFG_KEY_MODE: u32 = 0x1;
 pub const TC_CFG_TRACK_DENIED: u32 = 0x2;
@@ -36,6 +37,7 @@ pub const TC_B_OUTPUTS_IDLE: u32 = 0x40;
 
 pub const TC_ROUTE_AHEAD: u32 = 0x1;
 pub const TC_ROUTE_NO_READERS: u32 = 0x2;
+pub const TC_X_NONBLOCKING: u32 = 0x1;
 
 pub const TC_CNT_TOTAL: usize = 0;
 pub const TC_CNT_ALLOWED: usize = 1;
@@ -50,6 +52,26 @@ pub const TC_CNT_COUNT: usize = 8;
 #[repr(C)]
 pub struct tc_engine {
     _private: [u8; 0],
+}
+
+/// one rank's side of the multi-GPU exchange (opaque)
+#[repr(C)]
+pub struct tc_exchange {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct tc_exchange_config {
+    pub struct_size: u32,
+    pub rank: u32,
+    pub world: u32,
+    pub ring: u32,
+    pub seg_cap: u32,
+    pub flags: u32,
+    pub keys_per_shard: u64,
+    pub inbox: *const *mut u32,
+    pub mail: *mut u32,
+    pub done: *mut i64,
 }
 
 #[repr(C)]
@@ -196,6 +218,15 @@ extern "C" {
     pub fn tc_route_batch(e: *mut tc_engine, r: *const tc_route) -> c_int;
     pub fn tc_forward_segments(e: *mut tc_engine, f: *const tc_forward) -> c_int;
     pub fn tc_route_host(world: u32, keys_per_shard: u64, n: u64, global_id: *const u32, owner: *mut u32, slot: *mut u32) -> c_int;
+    pub fn tc_exchange_create(e: *mut tc_engine, c: *const tc_exchange_config, out: *mut *mut tc_exchange) -> c_int;
+    pub fn tc_exchange_destroy(x: *mut tc_exchange) -> c_int;
+    pub fn tc_exchange_route(x: *mut tc_exchange, step: u64, global_id: *const u32, n: u32) -> c_int;
+    pub fn tc_exchange_post(x: *mut tc_exchange, step: u64) -> c_int;
+    pub fn tc_exchange_collect(x: *mut tc_exchange, step: u64, counts: *mut u32) -> c_int;
+    pub fn tc_exchange_evaluate(x: *mut tc_exchange, step: u64, tmpl: *const tc_batch, decided: *mut u64) -> c_int;
+    pub fn tc_exchange_step(x: *mut tc_exchange, step: u64, global_id_ahead: *const u32, n_ahead: u32, route_ahead: u32, post_ahead: u32, tmpl: *const tc_batch, decided: *mut u64) -> c_int;
+    pub fn tc_exchange_poll(x: *mut tc_exchange) -> c_int;
+    pub fn tc_route_keys_host(world: u32, n: u64, key_bytes: *const u8, key_off: *const u32, owner: *mut u32) -> c_int;
     pub fn tc_route_inverse(world: u32, keys_per_shard: u64, n: u64, owner: *const u32, slot: *const u32, global_id: *mut u64) -> c_int;
     pub fn tc_engine_set_stream(e: *mut tc_engine, hip_stream: *mut c_void) -> c_int;
     pub fn tc_register_params(

@@ -252,3 +252,108 @@ def test_forward_segments_copies_every_piece_to_its_destination():
         got = dsts[d].cpu().numpy()
         assert np.array_equal(got[:cnt[d]].astype(np.uint32), segs[d]) and (got[cnt[d]:] == -1).all(), d
     eng.close()
+
+
+def test_exchange_step_is_one_library_call_and_matches_the_single_pass():
+    """tc_exchange_step (route i + 4, post i + 1, collect + evaluate i in ONE call, what bench.py --route exchange times), three
+    shards driven by one thread over a LocalFabric; steps larger than the engine's max_batch are evaluated in chunks."""
+    import torch
+
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    from tests.test_gpu_slots import T0
+    from throttlecrab_amd import sharded
+    from throttlecrab_amd import workload as W
+    world, cap, B, steps, LA_R, LA_P = 3, 5000, 12_000, 14, 4, 1
+    n_glob = world * cap
+    z = W.Zipf(n_glob)
+    glob = [z.slots(world * B, start=i * world * B).astype(np.uint32) for i in range(steps + LA_R)]
+    dev = torch.device("cuda:0")
+    with torch.cuda.stream(torch.cuda.Stream(device=dev)):
+        fab = sharded.LocalFabric(world, B, ring=8, device=dev)
+        engs, ranks = [], []
+        for r in range(world):
+            e = t.Engine(cap, 16_000, fixed_params=True)   # (a hot key's owner gets more than max_batch requests in a step: chunks)
+            e.use_torch_stream()
+            e.register_params_uniform(5, 10, 60)
+            engs.append(e)
+            ranks.append(sharded.ExchangeRank(e, fab, r, world, B))
+        d_slices = [[torch.from_numpy(g[r * B:(r + 1) * B].astype(np.int32)).to(dev) for r in range(world)] for g in glob]
+        outs = [[t.BatchResult(allowed=torch.zeros(world * B, dtype=torch.uint8, device=dev)) for _ in range(steps)] for _ in range(world)]
+        for j in range(LA_R):
+            for r in range(world):
+                ranks[r].route(j, d_slices[j][r])
+        for j in range(LA_P):
+            for r in range(world):
+                ranks[r].post(j)
+        decided = {}
+        for i in range(steps):
+            for r in range(world):
+                decided[(i, r)] = ranks[r].step(i, d_slices[i + LA_R][r], LA_R, LA_P, T0 + i * 300_000_000, outs[r])
+        torch.cuda.synchronize()
+        ref_orc = O.DenseOracle(n_glob)
+        chunked = 0
+        for st in range(steps):
+            g = glob[st]
+            ref = ref_orc.batch_slots(g, 5, 10, 60, 1, T0 + st * 300_000_000)
+            owner, _ = sharded.route(g, world, cap)
+            for r in range(world):
+                idx = np.concatenate([s * B + np.nonzero(owner[s * B:(s + 1) * B] == r)[0] for s in range(world)])
+                assert decided[(st, r)] == len(idx)
+                chunked += len(idx) > 16_000
+                assert np.array_equal(outs[r][st].allowed.cpu().numpy()[:len(idx)], ref.allowed[idx].astype(np.uint8)), (st, r)
+        assert chunked > 0
+        for x in ranks:
+            x.close()
+        for e in engs:
+            assert e.selfcheck() == 0
+            e.close()
+        fab.close()
+
+
+def test_exchange_flow_control_holds_while_the_gpu_is_stalled():
+    """an inbox slot is freed by an event on the stream the ENGINE evaluates on.  With the engine's stream stalled
+    behind a long sleep, a source that is `ring` steps ahead must not be let into the slot (TC_E_AGAIN in non-blocking mode)
+    however the host polls; once the evaluation has run, it is."""
+    import torch
+
+    import throttlecrab_amd as t
+    from tests.test_gpu_slots import T0
+    from throttlecrab_amd import _lib as L
+    from throttlecrab_amd import sharded
+    cap, B, ring = 3000, 4096, 2
+    dev = torch.device("cuda:0")
+    for own_stream in (False, True):   # the engine on torch's stream / on its own stream (torch's default stream current)
+        ctx = torch.cuda.stream(torch.cuda.Stream(device=dev)) if not own_stream else torch.cuda.stream(torch.cuda.default_stream(dev))
+        with ctx:
+            fab = sharded.LocalFabric(1, B, ring=ring, device=dev)
+            eng = t.Engine(cap, B, fixed_params=True)
+            eng.use_torch_stream()
+            eng.register_params_uniform(5, 10, 60)
+            xr = sharded.ExchangeRank(eng, fab, 0, 1, B)
+            ids = torch.from_numpy(np.random.default_rng(1).integers(0, cap, B).astype(np.int32)).to(dev)
+            outs = [t.BatchResult(allowed=torch.zeros(B, dtype=torch.uint8, device=dev)) for _ in range(8)]
+            for st in range(ring):
+                xr.route(st, ids)
+                xr.post(st)
+            eng.synchronize()
+            # stall the stream the engine evaluates on, then enqueue the evaluation of step 0 behind the stall
+            stall_stream = torch.cuda.current_stream(dev)
+            if not own_stream:   # (the engine's private stream cannot be stalled from torch: there, only that the slot is freed in the end)
+                torch.cuda._sleep(int(3e8))   # ~150 ms on the engine's stream
+            xr.evaluate(0, xr.collect(0), T0, outs)
+            rc = xr._lib.tc_exchange_route(xr._h, ring, ids.data_ptr(), B)   # step `ring` wants the slot step 0 still occupies
+            if not own_stream:
+                assert rc == L.TC_E_AGAIN, rc
+                for _ in range(50):
+                    fab.poll()
+                    assert xr._lib.tc_exchange_route(xr._h, ring, ids.data_ptr(), B) == L.TC_E_AGAIN
+            eng.synchronize()
+            stall_stream.synchronize()
+            fab.poll()
+            assert xr._lib.tc_exchange_route(xr._h, ring, ids.data_ptr(), B) == L.TC_E_OK
+            eng.synchronize()
+            xr.close()
+            assert eng.selfcheck() == 0
+            eng.close()
+            fab.close()

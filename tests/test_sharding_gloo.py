@@ -210,3 +210,88 @@ def test_split_segments_is_the_router_with_every_destination():
         for d in range(world):
             pos, slots = sharded.shard_requests(ids, world, d, cap)
             assert np.array_equal(segs[d], slots)
+
+
+# ---- string keys across shards (BASELINE configs[4] sharded; README.md:247-249 shards by KEY) --------------------------------
+T0 = 1_700_000_000 * 10**9
+
+
+def _key_stream():
+    """a stream of string keys with hot keys, `key_<i>` and longer ASCII keys mixed"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(21)
+    n = 40_000
+    ids = rng.integers(0, 6000, n)
+    hot = rng.random(n) < 0.3
+    ids[hot] = rng.integers(0, 12, int(hot.sum()))
+    keys = [(b"key_%d" % i) if i % 3 else (b"tenant:%d:resource/with/a/longer/path/%d" % (i, i * 7919)) for i in ids.tolist()]
+    kb, ko = O.pack_keys(keys)
+    now = T0 + np.arange(n, dtype=np.int64) * 200_000
+    return kb, ko, now
+
+
+def _key_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as O
+    from throttlecrab_amd import sharded
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    kb, ko, now = _key_stream()
+    mine_b, mine_o, pos = sharded.split_keys(kb, ko, world)[rank]   # the front door: this shard's keys, in stream order
+    st = O.AdaptiveOracle(capacity=10_000, created_ns=T0, auto_cleanup=False)
+    res = st.batch_keys(mine_b, mine_o, 5, 50, 60, 1, now[pos])
+    allowed = torch.zeros(len(ko) - 1, dtype=torch.int64)
+    cover = torch.zeros(len(ko) - 1, dtype=torch.int64)
+    allowed[torch.from_numpy(pos)] = torch.from_numpy(res.allowed.astype(np.int64))
+    cover[torch.from_numpy(pos)] = 1
+    dist.all_reduce(allowed)
+    dist.all_reduce(cover)
+    if rank == 0:
+        q.put((allowed.numpy().tolist(), cover.numpy().tolist(), len(pos)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_string_keys_sharded_by_key_match_the_single_pass():
+    """tc_route_keys_host: owner(key) = mix64(hash(key) ^ salt) mod world.  Two shards, each handed the keys it owns (in
+    stream order) with a store of its own: the union of their decisions is the single sequential pass's."""
+    import torch.multiprocessing as mp
+    from oracle import oracle as O
+    from throttlecrab_amd import sharded
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_key_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    allowed, cover, n0 = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    kb, ko, now = _key_stream()
+    ref = O.AdaptiveOracle(capacity=10_000, created_ns=T0, auto_cleanup=False).batch_keys(kb, ko, 5, 50, 60, 1, now)
+    assert all(c == 1 for c in cover), "every request is owned by exactly one shard"
+    assert np.array_equal(np.array(allowed), ref.allowed.astype(np.int64))
+    assert 0 < int(ref.allowed.sum()) < len(allowed)
+    assert 0.3 * len(allowed) < n0 < 0.7 * len(allowed)   # both shards get real work
+
+
+def test_route_keys_is_a_function_of_the_key_bytes_and_spreads():
+    from oracle import oracle as O
+    from throttlecrab_amd import sharded
+    keys = [b"", b"a", b"key_1", b"key_1", b"key_2", "🦀🔥💻".encode(), b"x" * 1000, b"key:with:colons/and/slashes\\and\\backslashes"]
+    kb, ko = O.pack_keys(keys)
+    for world in (1, 2, 8, 64):
+        o = sharded.route_keys(kb, ko, world)
+        assert o.max() < world and o[2] == o[3]
+    kb, ko = O.pack_keys([b"key_%d" % i for i in range(80_000)])
+    cnt = np.bincount(sharded.route_keys(kb, ko, 8), minlength=8)
+    assert cnt.min() > 0.93 * 10_000 and cnt.max() < 1.07 * 10_000
+    with pytest.raises(ValueError):
+        sharded.route_keys(kb, ko, 65)
+    parts = sharded.split_keys(*O.pack_keys(keys), 3)
+    assert sorted(int(p) for _, _, pos in parts for p in pos) == list(range(len(keys)))
+    for b, off, pos in parts:   # every owner's arena holds exactly its keys, in order
+        assert [bytes(b[off[i]:off[i + 1]]) for i in range(len(pos))] == [keys[p] for p in pos]

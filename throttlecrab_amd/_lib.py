@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "libtcgpu.so")
 TC_OK, TC_NEGATIVE_QUANTITY, TC_INVALID_RATE_LIMIT, TC_INTERNAL = 0, 1, 2, 3
 # call-level return codes
 (TC_E_OK, TC_E_INVALID_ARG, TC_E_HIP, TC_E_NOMEM, TC_E_BATCH_TOO_LARGE, TC_E_TABLE_FULL, TC_E_NO_DEVICE,
- TC_E_UNSUPPORTED, TC_E_INVARIANT) = (0, -1, -2, -3, -4, -5, -6, -7, -8)
+ TC_E_UNSUPPORTED, TC_E_INVARIANT, TC_E_AGAIN) = (0, -1, -2, -3, -4, -5, -6, -7, -8, -9)
+TC_X_NONBLOCKING = 0x1
 TC_CFG_KEY_MODE = 0x1
 TC_CFG_TRACK_DENIED = 0x2
 TC_CFG_FIXED_PARAMS = 0x4
@@ -58,6 +59,11 @@ class tc_route(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("world", C.c_uint32), ("keys_per_shard", C.c_uint64), ("n", C.c_uint64),
                 ("global_id", C.c_void_p), ("only", C.c_int32), ("flags", C.c_uint32), ("out_slot", C.c_void_p),
                 ("out_pos", C.c_void_p), ("out_count", C.c_void_p), ("stream", C.c_void_p), ("out_count_host", C.c_void_p), ("tag", C.c_uint32), ("reserved1", C.c_uint32), ("out_dst", C.c_void_p)]
+
+
+class tc_exchange_config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32), ("ring", C.c_uint32), ("seg_cap", C.c_uint32),
+                ("flags", C.c_uint32), ("keys_per_shard", C.c_uint64), ("inbox", C.c_void_p), ("mail", C.c_void_p), ("done", C.c_void_p)]
 
 
 class tc_result(C.Structure):
@@ -106,8 +112,17 @@ SYMBOLS = {
     "tc_snapshot_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_route_batch": (C.c_int, [C.c_void_p, C.POINTER(tc_route)]),
     "tc_forward_segments": (C.c_int, [C.c_void_p, C.POINTER(tc_forward)]),
+    "tc_exchange_create": (C.c_int, [C.c_void_p, C.POINTER(tc_exchange_config), C.POINTER(C.c_void_p)]),
+    "tc_exchange_destroy": (C.c_int, [C.c_void_p]),
+    "tc_exchange_route": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32]),
+    "tc_exchange_post": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "tc_exchange_collect": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
+    "tc_exchange_evaluate": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(tc_batch), C.POINTER(C.c_uint64)]),
+    "tc_exchange_step": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(tc_batch), C.POINTER(C.c_uint64)]),
+    "tc_exchange_poll": (C.c_int, [C.c_void_p]),
     "tc_route_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_route_inverse": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "tc_route_keys_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_slot_keys": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 

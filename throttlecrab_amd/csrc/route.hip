@@ -153,3 +153,17 @@ extern "C" int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_
     }
     return TC_E_OK;
 }
+
+// String keys (BASELINE configs[4] across GPUs; README.md:247-249 shards by KEY): owner(key) = mix64(hash(key) ^ salt) mod world,
+// SURVEY.md section 8(e).  A front end (the actor, a RESP connection handler) splits a key batch by owner with this and hands
+// every GPU's key-mode engine the keys it owns; the engines never see one another's keys.  The salt decorrelates the owner
+// from the placement inside an engine's table (which uses the low bits of the same hash).  Host only: no device needed.
+extern "C" int tc_route_keys_host(uint32_t world, uint64_t n, const uint8_t* key_bytes, const uint32_t* key_off, uint32_t* owner) {
+    if (world == 0 || world > 64 || (n && (!key_bytes || !key_off || !owner))) return TC_E_INVALID_ARG;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (key_off[i + 1] < key_off[i]) return TC_E_INVALID_ARG;
+        const uint64_t h = kt::hash_key(key_bytes + key_off[i], key_off[i + 1] - key_off[i]);
+        owner[i] = (uint32_t)(kt::mix64(h ^ 0xa5a5a5a5a5a5a5a5ull) % world);
+    }
+    return TC_E_OK;
+}

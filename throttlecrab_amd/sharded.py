@@ -102,6 +102,41 @@ def all_gather_counters(local_block, dist, world: int):
     return per_rank, {k: int(tot[i]) for i, k in enumerate(TC_CNT_NAMES)}
 
 
+def route_keys(key_bytes: np.ndarray, key_off: np.ndarray, world: int) -> np.ndarray:
+    """Owner of every string key of an arena (tc_route_keys_host: mix64(hash(key) ^ salt) mod world) -> uint32[n].  The front
+    door of a sharded key-mode deployment; needs no GPU."""
+    from . import _lib as L
+    kb = np.ascontiguousarray(key_bytes, dtype=np.uint8)
+    ko = np.ascontiguousarray(key_off, dtype=np.uint32)
+    owner = np.empty(len(ko) - 1, np.uint32)
+    rc = L.load().tc_route_keys_host(world, len(ko) - 1, kb.ctypes.data, ko.ctypes.data, owner.ctypes.data)
+    if rc != 0:
+        raise ValueError(f"tc_route_keys_host({world}) failed: {rc}")
+    return owner
+
+
+def split_keys(key_bytes: np.ndarray, key_off: np.ndarray, world: int):
+    """-> [(key_bytes_d, key_off_d, positions_d) for d in range(world)]: the arena cut into one arena per owner, the
+    requests of an owner in stream order (so that a key's requests keep their order), + where each came from"""
+    owner = route_keys(key_bytes, key_off, world)
+    ko = np.asarray(key_off, dtype=np.int64)
+    lens = ko[1:] - ko[:-1]
+    out = []
+    for d in range(world):
+        pos = np.nonzero(owner == d)[0]
+        off_d = np.zeros(len(pos) + 1, np.uint32)
+        off_d[1:] = np.cumsum(lens[pos])
+        if len(pos):
+            idx = np.concatenate([np.arange(ko[p], ko[p + 1]) for p in pos]) if lens[pos].sum() else np.zeros(0, np.int64)
+            bytes_d = np.asarray(key_bytes, dtype=np.uint8)[idx]
+        else:
+            bytes_d = np.zeros(0, np.uint8)
+        if bytes_d.size == 0:
+            bytes_d = np.zeros(1, np.uint8)
+        out.append((bytes_d, off_d, pos))
+    return out
+
+
 # ---- the exchange (see the module docstring) -------------------------------------------------------------------------
 def split_segments(global_slice: np.ndarray, world: int, keys_per_shard: int):
     """Host mirror of tc_route_batch(only = -1): what one source rank sends -- [shard-local slots for destination d,
@@ -124,6 +159,9 @@ class LocalFabric:
 
     def inbox(self, dst: int, slot: int, src: int):
         return self._inbox[dst][slot, src]
+
+    def inbox_base(self, dst: int):
+        return self._inbox[dst]
 
     def poll(self):
         """one thread drives every shard: a rank that waits for another rank's progress has to note it itself"""
@@ -167,6 +205,9 @@ class IpcFabric:
     def inbox(self, dst: int, slot: int, src: int):
         return self._inbox[dst][slot, src]
 
+    def inbox_base(self, dst: int):
+        return self._inbox[dst]
+
     def close(self):
         self.mail = self.done = None
         try:
@@ -178,88 +219,110 @@ class IpcFabric:
 
 
 class ExchangeRank:
-    """One rank's side of the exchange.  Per step i (the caller pipelines them: route a few steps ahead of post, post
-    ahead of collect):
-        route(i, slice)   tc_route_batch(only = -1, out_dst = the destinations' inboxes) of this rank's slice on a
-                          grouping stream: routing and forwarding in ONE pass, counts -> pinned memory
-        post(i)           once the router's tag is in (every segment has landed): (count, i + 1) into every
-                          destination's mailbox
-        collect(i)        wait for every source's mailbox word of step i -> the segments to evaluate
-        evaluate(i, ...)  one batch, slot column in pieces, sources in rank order (chunks of at most max_batch)"""
+    """One rank's side of the exchange: a thin wrapper over the library's tc_exchange_* calls (csrc/exchange.hip).  Per step i
+    (the caller pipelines them: route a few steps ahead of post, post ahead of the evaluation):
+        route(i, slice)   this rank's slice routed straight into the destinations' inboxes (one pass, counts -> pinned memory)
+        post(i)           once the router's tag is in: (count, i + 1) into every destination's mailbox
+        collect(i)        every source's mailbox word of step i -> [(inbox tensor, count)]
+        evaluate(i, ...)  the inboxes as ONE batch, slot column in pieces, sources in rank order
+        step(i, ...)      route(i + route_ahead) + post(i + post_ahead) + evaluate(i) in ONE library call (what bench.py times)
+    With a LocalFabric (several ranks driven by one thread) the library runs non-blocking and a phase whose turn has not come
+    is retried after every rank has published its progress."""
 
     def __init__(self, engine, fabric, rank: int, world: int, slice_len: int, route_ring: int = 8):
-        import torch
+        import ctypes as C
+
+        from . import _lib as L
         self.eng, self.fab, self.rank, self.world = engine, fabric, rank, world
-        dev = torch.device(f"cuda:{engine.device}")
-        self.route_ring = route_ring
-        self.counts_dev = [torch.zeros(world, dtype=torch.int32, device=dev) for _ in range(route_ring)]
-        self.counts_host = [engine.host_alloc(world + 1, np.uint32) for _ in range(route_ring)]
-        for c in self.counts_host:
-            c[:] = 0
-        self.eval_events = {}
-        self._event_pool = []
-        if hasattr(fabric, "ranks"):
+        self._lib = engine._lib
+        self.route_ring = route_ring  # (kept for callers that sized buffers by it; the library keeps 8 routers' count blocks)
+        self._single_thread = hasattr(fabric, "ranks")
+        self._ptrs = (C.c_void_p * world)(*[fabric.inbox_base(d).data_ptr() for d in range(world)])
+        cfg = L.tc_exchange_config()
+        cfg.struct_size = C.sizeof(L.tc_exchange_config)
+        cfg.rank, cfg.world, cfg.ring, cfg.seg_cap = rank, world, fabric.ring, fabric.seg_cap
+        cfg.flags = L.TC_X_NONBLOCKING if self._single_thread else 0
+        cfg.keys_per_shard = engine.capacity
+        cfg.inbox = C.cast(self._ptrs, C.c_void_p)
+        cfg.mail = fabric.mail.ctypes.data
+        cfg.done = fabric.done.ctypes.data
+        h = C.c_void_p(0)
+        engine._check(self._lib.tc_exchange_create(engine._h, C.byref(cfg), C.byref(h)))
+        self._h = h
+        self._again = L.TC_E_AGAIN
+        self._counts = (C.c_uint32 * world)()
+        if self._single_thread:
             fabric.ranks.append(self)
-        self.host_s = {"route": 0.0, "post": 0.0, "collect": 0.0, "evaluate": 0.0}  # host seconds per phase (diagnostics)
+        self.host_s = {"route": 0.0, "post": 0.0, "collect": 0.0, "evaluate": 0.0, "step": 0.0}  # host seconds per phase (diagnostics)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tc_exchange_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, fn, *args):
+        while True:
+            rc = fn(self._h, *args)
+            if rc != self._again:
+                self.eng._check(rc)
+                return
+            self.fab.poll()  # (one thread drives every shard: let the others publish what they have finished)
 
     def route(self, step: int, global_slice):
-        r, k = step % self.route_ring, step % self.fab.ring
-        # flow control: a destination's inbox slot is free once it has evaluated step - ring
-        while any(int(self.fab.done[d]) < step - self.fab.ring + 1 for d in range(self.world)):
-            self.fab.poll() if hasattr(self.fab, "poll") else self._publish_done()
         if global_slice.numel() > self.fab.seg_cap:
             raise RuntimeError(f"a slice of {global_slice.numel()} requests exceeds the inbox capacity {self.fab.seg_cap}")
-        # (the router's output goes to the inboxes, never to a batch's slot column: it need not wait for any batch in flight)
-        self.eng.route_batch(global_slice, self.world, only=-1, out=(None, None, self.counts_dev[r]), ahead=True,
-                             host_counts=self.counts_host[r], tag=step + 1, no_readers=True,
-                             out_dst=[self.fab.inbox(d, k, self.rank) for d in range(self.world)])
+        self._keep_slice = global_slice
+        self._call(self._lib.tc_exchange_route, step, global_slice.data_ptr(), global_slice.numel())
 
     def post(self, step: int):
-        r, k = step % self.route_ring, step % self.fab.ring
-        while int(self.counts_host[r][self.world]) != step + 1:  # routed a few steps ago: no wait in steady state
-            pass
-        for d in range(self.world):
-            self.fab.mail[d, k, self.rank, 0] = int(self.counts_host[r][d])
-        for d in range(self.world):   # (count before tag: a reader that sees the tag sees the count)
-            self.fab.mail[d, k, self.rank, 1] = step + 1
+        self._call(self._lib.tc_exchange_post, step)
 
     def collect(self, step: int):
+        self._call(self._lib.tc_exchange_collect, step, self._counts)
         k = step % self.fab.ring
-        mail = self.fab.mail[self.rank, k]
-        while any(int(mail[s, 1]) != step + 1 for s in range(self.world)):
-            pass
-        return [(self.fab.inbox(self.rank, k, s), int(mail[s, 0])) for s in range(self.world)]
+        return [(self.fab.inbox(self.rank, k, s), int(self._counts[s])) for s in range(self.world)]
+
+    def _template(self, n_out, now_ns, outs, step, **kw):
+        """the evaluation's tc_batch: outputs (a result set of its own per step in flight), one timestamp, the registered plans"""
+        import ctypes as C
+        res = outs[step % len(outs)]
+        # TC_B_OUTPUTS_IDLE promises that nothing in flight touches the arrays: only with a ring longer than the pipeline
+        idle = len(outs) >= 8 and kw.pop("outputs_idle", True)
+        kw.pop("outputs_idle", None)
+        b, res, keep = self.eng._prepare(n_out, True, None, None, None, kw.pop("quantity", 1), now_ns, True, False, kw.pop("want", ("allowed",)),
+                                         res, inputs_ready=True, outputs_idle=idle)
+        return b, keep
 
     def evaluate(self, step: int, segments, now_ns: int, outs, **kw):
-        """-> requests decided.  outs: a list of BatchResult to cycle through (one per chunk in flight)."""
-        import torch
-        cap = self.eng.max_batch
-        total = sum(cnt for _, cnt in segments)
-        if total <= cap:
-            pieces = [segments]  # (the common case: no slicing, no copies)
-        else:
-            pieces, chunk, size = [], [], 0
-            for tns, cnt in segments:  # cut the concatenation into chunks of at most max_batch requests
-                at = 0
-                while cnt - at > 0:
-                    take = min(cnt - at, cap - size)
-                    chunk.append((tns[at:] if at else tns, take))
-                    size += take
-                    at += take
-                    if size == cap:
-                        pieces.append(chunk)
-                        chunk, size = [], 0
-            if chunk:
-                pieces.append(chunk)
-        for j, ch in enumerate(pieces):
-            self.eng.rate_limit_batch_slots(None, segments=ch, registered=True, quantity=1, now_ns=now_ns, want=("allowed",),
-                                            out=outs[(step * 4 + j) % len(outs)], inputs_ready=True, outputs_idle=True, **kw)
-        # completion of this step's evaluation frees its inbox slots (events are recycled: creating one costs microseconds)
-        ev = self._event_pool.pop() if self._event_pool else torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.eng.device))
-        self.eval_events[step] = ev
-        self._publish_done()
-        return total
+        """-> requests decided.  outs: a list of BatchResult to cycle through (one per step in flight).  `segments` (what
+        collect() returned) only sizes the result arrays: the library reads the mailboxes itself."""
+        import ctypes as C
+        total = sum(cnt for _, cnt in segments) if segments is not None else self.world * self.fab.seg_cap
+        if total == 0:
+            total = 1  # (an empty step still has to be marked as evaluated: the library does that)
+        b, keep = self._template(total, now_ns, outs, step, **kw)
+        decided = C.c_uint64(0)
+        self._call(self._lib.tc_exchange_evaluate, step, C.byref(b), C.byref(decided))
+        self._keep_eval = keep
+        return int(decided.value)
+
+    def step(self, step: int, slice_ahead, route_ahead: int, post_ahead: int, now_ns: int, outs, **kw):
+        """route(step + route_ahead, slice_ahead) + post(step + post_ahead) + evaluate(step): ONE library call.  The result arrays
+        of `outs` must hold a whole step (world x seg_cap decisions at most)."""
+        import ctypes as C
+        b, keep = self._template(self.world * self.fab.seg_cap, now_ns, outs, step, **kw)
+        decided = C.c_uint64(0)
+        self._keep_slice = slice_ahead
+        self._call(self._lib.tc_exchange_step, step, slice_ahead.data_ptr() if slice_ahead is not None else None,
+                   slice_ahead.numel() if slice_ahead is not None else 0, route_ahead, post_ahead, C.byref(b), C.byref(decided))
+        self._keep_eval = keep
+        return int(decided.value)
 
     def timed(self, name, *args, **kw):
         """run phase `name` and book its host time (bench.py reports where a step's host time goes)"""
@@ -270,9 +333,4 @@ class ExchangeRank:
         return r
 
     def _publish_done(self):
-        """steps whose evaluation has finished free their inbox slots"""
-        for st in sorted(self.eval_events):
-            if not self.eval_events[st].query():
-                break
-            self.fab.done[self.rank] = st + 1
-            self._event_pool.append(self.eval_events.pop(st))
+        self._lib.tc_exchange_poll(self._h)
