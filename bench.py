@@ -649,6 +649,7 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     decided = 0
     for k_ in xr.host_s:
         xr.host_s[k_] = 0.0   # (the warmup holds one-time costs: scratch allocation, the stream probe)
+    xr.wait_us()
     t0 = time.perf_counter()
     for k in range(a.steps):
         step(it, last=(k == a.steps - 1))
@@ -657,6 +658,8 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     dist.barrier()
     dt_mine = time.perf_counter() - t0
     host_us = {k_: 1e6 * v / a.steps for k_, v in xr.host_s.items() if v}   # of the timed region only
+    w_ = xr.wait_us()   # ... of which the library spent waiting (for inbox slots, the router's tag, the other ranks)
+    host_us.update({"waiting_for_inbox_slots": w_[0] / a.steps, "waiting_for_router": w_[1] / a.steps, "waiting_for_sources": w_[2] / a.steps})
     tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
     dt = float(tm.item())
@@ -691,6 +694,7 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
             res["roofline"] = roofline_entry(ev["kernel"], ev["per_batch_ms"], alg, 1e3 * dt / a.steps, None,
                                              {"avg_ms": f"HIP events, rank {rank}, per-step total of the evaluation launches", "traffic": None})
         res["stages"] = stages
+        print(f"[bench] rank {rank} evaluation stages: " + ", ".join(f"{k} {v['avg_ms'] * 1e3:.1f} us x {v['launches_per_batch']:.1f}" for k, v in stages.items()), file=sys.stderr, flush=True)
     # the routing front end alone (this rank's slice routed straight into the inboxes, 8 routers drained), for the record;
     # the inboxes are scratch by now -- once every rank has left its profile steps
     dist.barrier()

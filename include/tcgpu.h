@@ -445,6 +445,9 @@ int tc_exchange_step(tc_exchange* x, uint64_t step, const uint32_t* global_id_ah
                      uint32_t post_ahead, const tc_batch* tmpl, uint64_t* decided);
 /* publish the steps whose evaluation has completed (frees inbox slots for the sources); never waits */
 int tc_exchange_poll(tc_exchange* x);
+/* host time (ns) the calls have spent WAITING since the last call of this function: [0] for free inbox slots (route), [1] for
+ * the router's tag (post), [2] for the sources' mailbox words (collect) -- what tells a host-bound step from a starved one */
+int tc_exchange_wait_ns(tc_exchange* x, uint64_t out[3]);
 
 /* The same map on the host: owner and shard-local slot of n global ids (either output may be NULL), and its
  * inverse (global id of slot `slot` of shard `owner`).  No device needed. */

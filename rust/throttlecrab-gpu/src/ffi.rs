@@ -226,6 +226,7 @@ extern "C" {
     pub fn tc_exchange_evaluate(x: *mut tc_exchange, step: u64, tmpl: *const tc_batch, decided: *mut u64) -> c_int;
     pub fn tc_exchange_step(x: *mut tc_exchange, step: u64, global_id_ahead: *const u32, n_ahead: u32, route_ahead: u32, post_ahead: u32, tmpl: *const tc_batch, decided: *mut u64) -> c_int;
     pub fn tc_exchange_poll(x: *mut tc_exchange) -> c_int;
+    pub fn tc_exchange_wait_ns(x: *mut tc_exchange, out: *mut u64) -> c_int;
     pub fn tc_route_keys_host(world: u32, n: u64, key_bytes: *const u8, key_off: *const u32, owner: *mut u32) -> c_int;
     pub fn tc_route_inverse(world: u32, keys_per_shard: u64, n: u64, owner: *const u32, slot: *const u32, global_id: *mut u64) -> c_int;
     pub fn tc_engine_set_stream(e: *mut tc_engine, hip_stream: *mut c_void) -> c_int;

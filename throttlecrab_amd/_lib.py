@@ -120,6 +120,7 @@ SYMBOLS = {
     "tc_exchange_evaluate": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(tc_batch), C.POINTER(C.c_uint64)]),
     "tc_exchange_step": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(tc_batch), C.POINTER(C.c_uint64)]),
     "tc_exchange_poll": (C.c_int, [C.c_void_p]),
+    "tc_exchange_wait_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_route_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_route_inverse": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_route_keys_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),

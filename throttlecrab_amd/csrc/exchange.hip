@@ -6,9 +6,11 @@
 #include "engine.hpp"
 
 #include <sched.h>
+#include <time.h>
 
 struct tc_exchange {
     tc_engine* e = nullptr;
+    int device = 0;
     uint32_t rank = 0, world = 0, ring = 0, seg_cap = 0, flags = 0;
     uint64_t keys_per_shard = 0;
     std::vector<uint32_t*> inbox;       // [world]: base of destination d's [ring][world][seg_cap] array, as this process maps it
@@ -22,6 +24,7 @@ struct tc_exchange {
     std::vector<uint32_t*> dst;         // scratch: the inboxes of one step
     std::vector<const uint32_t*> seg_ptr;
     std::vector<uint32_t> seg_n;
+    uint64_t wait_ns[3] = {0, 0, 0};    // host time spent waiting: for inbox slots (route), for the router's tag (post), for the sources (collect)
     uint64_t next_route = 0, next_post = 0; // a phase repeated for a step it has already done (a TC_E_AGAIN retry of tc_exchange_step) does nothing
 };
 
@@ -59,6 +62,7 @@ extern "C" int tc_exchange_create(tc_engine* e, const tc_exchange_config* c, tc_
     tc_exchange* x = new (std::nothrow) tc_exchange;
     if (!x) return TC_E_NOMEM;
     x->e = e;
+    x->device = e->device;
     x->rank = c->rank, x->world = c->world, x->ring = c->ring, x->seg_cap = c->seg_cap, x->flags = c->flags;
     x->keys_per_shard = c->keys_per_shard;
     x->inbox.assign(c->inbox, c->inbox + c->world);
@@ -87,7 +91,7 @@ extern "C" int tc_exchange_create(tc_engine* e, const tc_exchange_config* c, tc_
 
 extern "C" int tc_exchange_destroy(tc_exchange* x) {
     if (!x) return TC_E_OK;
-    (void)hipSetDevice(x->e->device);
+    (void)hipSetDevice(x->device); // (the engine may be gone already: nothing of it is touched here)
     for (auto& p : x->evaluated) {
         (void)hipEventSynchronize(p.second);
         (void)hipEventDestroy(p.second);
@@ -99,6 +103,15 @@ extern "C" int tc_exchange_destroy(tc_exchange* x) {
     return TC_E_OK;
 }
 
+extern "C" int tc_exchange_wait_ns(tc_exchange* x, uint64_t out[3]) {
+    if (!x || !out) return TC_E_INVALID_ARG;
+    for (int i = 0; i < 3; ++i) {
+        out[i] = x->wait_ns[i];
+        x->wait_ns[i] = 0;
+    }
+    return TC_E_OK;
+}
+
 extern "C" int tc_exchange_poll(tc_exchange* x) {
     if (!x) return TC_E_INVALID_ARG;
     publish_done(x);
@@ -106,16 +119,25 @@ extern "C" int tc_exchange_poll(tc_exchange* x) {
 }
 
 // a wait of the host on other ranks / on the device: nothing in TC_X_NONBLOCKING mode (the caller comes back)
-#define TC_X_WAIT(x, cond)                                      \
+static inline uint64_t mono_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+#define TC_X_WAIT(x, which, cond)                               \
     do {                                                        \
-        uint32_t _spins = 0;                                    \
-        while (!(cond)) {                                       \
-            publish_done(x);                                    \
-            if ((x)->flags & TC_X_NONBLOCKING) return TC_E_AGAIN; \
-            if ((++_spins & 1023u) == 0u) {                     \
-                TC_CHECK_POISON((x)->e);                        \
-                sched_yield();                                  \
+        if (!(cond)) {                                          \
+            const uint64_t _t0 = mono_ns();                     \
+            uint32_t _spins = 0;                                \
+            while (!(cond)) {                                   \
+                publish_done(x);                                \
+                if ((x)->flags & TC_X_NONBLOCKING) return TC_E_AGAIN; \
+                if ((++_spins & 1023u) == 0u) {                 \
+                    TC_CHECK_POISON((x)->e);                    \
+                    sched_yield();                              \
+                }                                               \
             }                                                   \
+            (x)->wait_ns[which] += mono_ns() - _t0;             \
         }                                                       \
     } while (0)
 
@@ -128,7 +150,7 @@ extern "C" int tc_exchange_route(tc_exchange* x, uint64_t step, const uint32_t* 
     const uint32_t r = (uint32_t)(step % tc_exchange::ROUTES), k = (uint32_t)(step % x->ring);
     // flow control: a destination's inbox slot is free once it has evaluated step - ring
     const int64_t need = (int64_t)step - (int64_t)x->ring + 1;
-    for (uint32_t d = 0; d < x->world; ++d) TC_X_WAIT(x, __atomic_load_n(&x->done[d], __ATOMIC_ACQUIRE) >= need);
+    for (uint32_t d = 0; d < x->world; ++d) TC_X_WAIT(x, 0, __atomic_load_n(&x->done[d], __ATOMIC_ACQUIRE) >= need);
     for (uint32_t d = 0; d < x->world; ++d) x->dst[d] = inbox_of(x, d, k, x->rank);
     tc_route rq;
     memset(&rq, 0, sizeof rq);
@@ -155,7 +177,7 @@ extern "C" int tc_exchange_post(tc_exchange* x, uint64_t step) {
     if (step < x->next_post) return TC_E_OK;
     const uint32_t r = (uint32_t)(step % tc_exchange::ROUTES), k = (uint32_t)(step % x->ring);
     volatile uint32_t* ch = x->counts_host[r];
-    TC_X_WAIT(x, ch[x->world] == (uint32_t)(step + 1)); // the router's tag: every segment has landed (routed a few steps ago: no wait in steady state)
+    TC_X_WAIT(x, 1, ch[x->world] == (uint32_t)(step + 1)); // the router's tag: every segment has landed (routed a few steps ago: no wait in steady state)
     for (uint32_t d = 0; d < x->world; ++d) {
         uint32_t* m = mail_of(x, d, k, x->rank);
         __atomic_store_n(&m[0], ch[d], __ATOMIC_RELAXED);
@@ -171,7 +193,7 @@ extern "C" int tc_exchange_collect(tc_exchange* x, uint64_t step, uint32_t* coun
     const uint32_t k = (uint32_t)(step % x->ring);
     for (uint32_t s = 0; s < x->world; ++s) {
         uint32_t* m = mail_of(x, x->rank, k, s);
-        TC_X_WAIT(x, __atomic_load_n(&m[1], __ATOMIC_ACQUIRE) == (uint32_t)(step + 1));
+        TC_X_WAIT(x, 2, __atomic_load_n(&m[1], __ATOMIC_ACQUIRE) == (uint32_t)(step + 1));
         x->seg_n[s] = __atomic_load_n(&m[0], __ATOMIC_RELAXED);
         x->seg_ptr[s] = inbox_of(x, x->rank, k, s);
         if (counts) counts[s] = x->seg_n[s];

@@ -93,6 +93,7 @@ class Engine:
         self.device = device
         self.key_mode = key_mode
         self.check_on_close = False
+        self._children = []   # objects that hold a pointer to this engine (sharded.ExchangeRank): closed before it
 
     def debug_fail_copy(self, nth: int):
         """test hook: the nth staging copy from now fails (tc_debug_fail_copy)"""
@@ -109,6 +110,9 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None):
+            for ch in list(getattr(self, "_children", ())):
+                ch.close()
+            self._children = []
             if self.check_on_close:
                 bad = self.selfcheck()
                 assert bad == 0, f"engine flagged {bad} internal invariant violations"

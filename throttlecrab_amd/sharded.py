@@ -249,6 +249,7 @@ class ExchangeRank:
         h = C.c_void_p(0)
         engine._check(self._lib.tc_exchange_create(engine._h, C.byref(cfg), C.byref(h)))
         self._h = h
+        engine._children.append(self)   # (the exchange points into the engine: the engine closes it first)
         self._again = L.TC_E_AGAIN
         self._counts = (C.c_uint32 * world)()
         if self._single_thread:
@@ -334,3 +335,10 @@ class ExchangeRank:
 
     def _publish_done(self):
         self._lib.tc_exchange_poll(self._h)
+
+    def wait_us(self):
+        """host microseconds spent waiting inside the library since the last call: (inbox slots, router tag, sources)"""
+        import ctypes as C
+        out = (C.c_uint64 * 3)()
+        self._lib.tc_exchange_wait_ns(self._h, out)
+        return tuple(v / 1e3 for v in out)
