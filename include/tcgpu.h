@@ -332,7 +332,7 @@ int tc_top_denied(tc_engine* e, uint32_t k, uint32_t* slots, uint64_t* counts, u
 int tc_denied_reset(tc_engine* e);
 /* string mode: TopDeniedKeys::get_top (metrics.rs:66-76) -- the k most denied KEYS, most denied first (ties: key
  * bytes ascending), as a key arena (key_off[k + 1]) + counts.  A key's denials follow the key: a sweep that unbinds it
- * moves the count into a side table of 32 768 keys (keys of up to 256 bytes, the reference's MAX_KEY_LENGTH; trimmed
+ * moves the count into a side table of 65 536 keys (keys of up to 256 bytes, the reference's MAX_KEY_LENGTH; trimmed
  * to the 10 000 most denied ones once it passes 30 000, like TopDeniedKeys::cleanup), and binding the key again
  * moves it back.  k is capped at 10 000.  TC_E_INVALID_ARG if key_bytes_cap is too small. */
 int tc_top_denied_keys(tc_engine* e, uint32_t k, uint8_t* key_bytes, size_t key_bytes_cap, uint32_t* key_off, uint64_t* counts,

@@ -153,3 +153,53 @@ def test_top_denied_needs_the_flag():
         eng.top_denied(5)
     assert ei.value.code == -7
     eng.close()
+
+
+def test_retired_keys_survive_tombstone_churn_and_compaction():
+    """the side table of keys that lost their slot is compacted by the host (tombstones out) before probe chains
+    run full -- generations of 9 000 denied keys each retire and come back (every return leaves a tombstone, every retirement
+    claims a record): 45 000 claims pass the statistics' threshold; no denial count may be lost on the way."""
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    n_keys = 9000
+    pool = [b"gen-key-%d" % i for i in range(n_keys)]
+    eng = t.Engine(16384, 40000, key_mode=True, track_denied=True)
+    model = _TopDeniedModel()
+    now = T0
+    kb, ko = O.pack_keys(pool + pool + pool)   # every key three times per batch: burst 2 -> one denial per key per batch
+    for gen in range(6):
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=2, count_per_period=2, period=3600, quantity=1, now_ns=now, want=("allowed", "status"))
+        denied = (res.allowed == 0) & (res.status == 0)
+        assert int(denied.sum()) == n_keys
+        for k in pool:
+            model.update(k)
+        now += 2 * 3600 * 10**9
+        assert eng.sweep_expired(now) == n_keys          # all retire: counts move into the side table (and back next round)
+        assert eng.counters()["live_slots"] == 0
+        assert eng.top_denied(50) == model.get_top(50), gen
+    top = eng.top_denied(10000)
+    assert len(top) == n_keys and all(c == 6 for _, c in top)
+    assert [k for k, _ in top] == sorted(pool)            # equal counts: key bytes ascending
+    eng.close()
+
+
+def test_top_denied_keys_break_ties_at_the_cut_by_key_bytes():
+    """tc_top_denied orders ties by slot, tc_top_denied_keys by key bytes: with 300 keys tied at the cut the k
+    returned must be the smallest keys, not the lowest slots (keys are bound in an order unrelated to their bytes)."""
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    rng = np.random.default_rng(3)
+    names = [b"tie-%05d" % i for i in rng.permutation(300)]          # bound in shuffled order: slot order != key order
+    big = [b"big-%d" % i for i in range(5)]
+    eng = t.Engine(4096, 8192, key_mode=True, track_denied=True)
+    keys = []
+    for nm in names:
+        keys += [nm] * 3                                             # burst 2: one denial each
+    for j, nm in enumerate(big):
+        keys += [nm] * (4 + j)                                       # 2 + j denials
+    kb, ko = O.pack_keys(keys)
+    eng.rate_limit_batch_keys(kb, ko, max_burst=2, count_per_period=2, period=3600, quantity=1, now_ns=T0, want=("allowed",))
+    want = [(b"big-4", 6), (b"big-3", 5), (b"big-2", 4), (b"big-1", 3), (b"big-0", 2)] + [(nm, 1) for nm in sorted(names)]
+    for k in (3, 5, 10, 70, 200, 305, 400):
+        assert eng.top_denied(k) == want[:k], k
+    eng.close()

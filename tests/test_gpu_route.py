@@ -357,3 +357,37 @@ def test_exchange_flow_control_holds_while_the_gpu_is_stalled():
             assert eng.selfcheck() == 0
             eng.close()
             fab.close()
+
+
+def test_routers_on_two_caller_streams_do_not_share_scratch_unordered():
+    """every router off the grouping streams uses scratch lane 0; two of them on different caller streams are now
+    ordered by an event.  Alternate two streams for 60 partitions of different batches and check every one."""
+    import torch
+
+    import throttlecrab_amd as t
+    from throttlecrab_amd import sharded
+    world, cap, n = 4, 50_000, 300_000
+    eng = t.Engine(cap, 1 << 19)
+    eng.use_torch_stream()
+    dev = torch.device("cuda:0")
+    streams = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+    rng = np.random.default_rng(9)
+    ids = [rng.integers(0, world * cap, n).astype(np.uint32) for _ in range(6)]
+    d_ids = [torch.from_numpy(x.astype(np.int32)).to(dev) for x in ids]
+    torch.cuda.synchronize()
+    outs = []
+    for i in range(60):
+        st = streams[i % 2]
+        only = i % world
+        slots = torch.empty(n, dtype=torch.int32, device=dev)
+        counts = torch.zeros(world, dtype=torch.int32, device=dev)
+        eng.route_batch(d_ids[i % 6], world, only=only, out=(slots, None, counts), stream=st)
+        outs.append((i % 6, only, slots, counts))
+    torch.cuda.synchronize()
+    for b, only, slots, counts in outs:
+        owner, slot = sharded.route(ids[b], world, cap)
+        c = counts.cpu().numpy()
+        assert np.array_equal(c, np.bincount(owner, minlength=world))
+        assert np.array_equal(slots.cpu().numpy()[:c[only]].astype(np.uint32), slot[owner == only])
+    assert eng.selfcheck() == 0
+    eng.close()

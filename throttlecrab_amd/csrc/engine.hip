@@ -262,8 +262,8 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     t.retired = nullptr;
     t.denied = e->denied;
     if (e->denied) { // denial counts of keys that lose their slot (kt::RetiredRec)
-        TC_HIP(e, hipMalloc(&e->retired, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec)));
-        TC_HIP(e, hipMemsetAsync(e->retired, 0, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec), (hipStream_t)0));
+        TC_HIP(e, hipMalloc(&e->retired, ((size_t)kt::RETIRED_CAP + 1) * sizeof(kt::RetiredRec))); // (+ the statistics record)
+        TC_HIP(e, hipMemsetAsync(e->retired, 0, ((size_t)kt::RETIRED_CAP + 1) * sizeof(kt::RetiredRec), (hipStream_t)0));
         t.retired = e->retired;
     }
     hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, (hipStream_t)0,
@@ -422,6 +422,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
+    if (e->route_l0_done) (void)hipEventDestroy(e->route_l0_done);
     if (e->poison_host) (void)hipHostFree(e->poison_host);
     if (e->k_done) (void)hipEventDestroy(e->k_done);
     if (e->m_done) (void)hipEventDestroy(e->m_done);

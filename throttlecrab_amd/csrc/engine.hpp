@@ -199,6 +199,9 @@ struct tc_engine {
     size_t route_ws_words = 0;    // words of one of them
     uint32_t next_route = 0;
     uint32_t route_seq = 0;       // sequence number of the one-pass router's look-back words
+    hipEvent_t route_l0_done = nullptr; // the last router that used scratch lane 0 (the caller's stream / the engine's stream) ...
+    hipStream_t route_l0_stream = nullptr; // ... and the stream it ran on: a router on ANOTHER stream waits for it (one scratch)
+    bool route_l0_used = false;
 
     // bucket path (bucket_path.hpp): uniform batches are partitioned by key range and ranked per bucket instead of
     // sorted.  Such a batch is enqueued on BOTH paths; the partition's largest bucket (a word in device memory,

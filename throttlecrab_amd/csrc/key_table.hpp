@@ -67,7 +67,10 @@ struct __attribute__((aligned(128))) KeyRec {
 // counter -- a key's denials are always in exactly one place.  RETIRED_CAP entries (3 x the reference's 10 000-key
 // limit, metrics.rs:17: the host trims to the top 10 000 once the table passes 30 000, like TopDeniedKeys::cleanup);
 // keys over RETIRED_KEY bytes are not kept (the reference ignores keys over 256 bytes, metrics.rs:11,37).
-constexpr uint32_t RETIRED_CAP = 32768u, RETIRED_KEY = 256u, RETIRED_PROBES = 128u;
+// (round 4: 65 536 entries, so that 30 000 keys are a load of 46 %; the record BEHIND the table -- index RETIRED_CAP -- carries the
+// table's statistics: .count = denial counts that found no room within RETIRED_PROBES records, .len = records ever claimed,
+// tombstones included; the host compacts the table -- tombstones out, trimmed like the reference's map -- when either says so)
+constexpr uint32_t RETIRED_CAP = 65536u, RETIRED_KEY = 256u, RETIRED_PROBES = 128u;
 constexpr unsigned long long RT_EMPTY = 0ull, RT_BUSY = 1ull, RT_DELETED = 2ull, RT_VALID = 1ull << 63;
 struct RetiredRec {
     unsigned long long tag; // RT_EMPTY / RT_BUSY / RT_DELETED / hash | RT_VALID
@@ -267,6 +270,7 @@ __device__ inline void retire_denials(const Table& t, uint64_t h, const uint8_t*
         if (tag == RT_EMPTY || tag == RT_DELETED) {
             unsigned long long expected = tag;
             if (__hip_atomic_compare_exchange_strong(&r->tag, &expected, RT_BUSY, __ATOMIC_ACQUIRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                if (tag == RT_EMPTY) atomicAdd(&t.retired[RETIRED_CAP].len, 1u);
                 r->count = count;
                 r->len = len;
                 for (uint32_t b = 0; b < len; ++b) r->bytes[b] = key[b];
@@ -277,7 +281,9 @@ __device__ inline void retire_denials(const Table& t, uint64_t h, const uint8_t*
             pos = (pos + RETIRED_CAP - 1u) & (RETIRED_CAP - 1u);
         }
     }
-    // no room within RETIRED_PROBES records: the count is dropped (the reference's capped map forgets keys too)
+    // no room within RETIRED_PROBES records: the count is dropped (the reference's capped map forgets keys too) -- and counted, so
+    // that the host compacts the table before more are
+    atomicAdd(&t.retired[RETIRED_CAP].count, 1u);
 }
 // bind side: a key that gets a slot again takes its retired denials along
 __device__ inline void resurrect_denials(const Table& t, uint64_t h, const uint8_t* key, uint32_t len, uint32_t slot) {

@@ -1,6 +1,65 @@
 // maint.hip -- maintenance: AdaptiveStore::cleanup (tc_sweep_expired), top denied keys, raw state for differential tests
 #include "engine.hpp"
 
+// everything that may touch the table of retired keys has run: key stages on the key stream (k_bind: resurrect_denials), sweeps
+// and everything else on the engine's stream
+static int drain_key_work(tc_engine* e) {
+    hipStream_t s = cur_stream(e);
+    if (e->k_busy) {
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        e->k_busy = false;
+    }
+    TC_HIP(e, hipStreamSynchronize(s));
+    return TC_E_OK;
+}
+
+static bool by_count_then_key(const std::pair<std::string, uint64_t>& a, const std::pair<std::string, uint64_t>& b) {
+    return a.second != b.second ? a.second > b.second : a.first < b.first;
+}
+
+// The table of retired keys, rewritten from the host without its tombstones -- and, past 3 x the reference's limit, trimmed to
+// the `limit` most denied keys (TopDeniedKeys::cleanup, metrics.rs:52-64).  `force`: whatever the statistics say.  The engine
+// is drained first.  `out` (optional): the keys the table holds afterwards.
+static int compact_retired(tc_engine* e, bool force, std::vector<std::pair<std::string, uint64_t>>* out) {
+    TC_TRY(drain_key_work(e));
+    hipStream_t s = cur_stream(e);
+    kt::RetiredRec stats;
+    TC_HIP(e, hipMemcpyAsync(&stats, e->retired + kt::RETIRED_CAP, sizeof stats, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    const bool due = stats.count != 0u || stats.len > kt::RETIRED_CAP / 2u;
+    if (!due && !force && !out) return TC_E_OK;
+    std::vector<kt::RetiredRec> rt(kt::RETIRED_CAP);
+    TC_HIP(e, hipMemcpyAsync(rt.data(), e->retired, rt.size() * sizeof(kt::RetiredRec), hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipStreamSynchronize(s));
+    std::vector<std::pair<std::string, uint64_t>> keep;
+    for (const kt::RetiredRec& r : rt)
+        if ((r.tag & kt::RT_VALID) && r.count) keep.emplace_back(std::string((const char*)r.bytes, r.len), (uint64_t)r.count);
+    const bool trim = keep.size() > 3u * TOPK_MAX;
+    if (trim) {
+        std::sort(keep.begin(), keep.end(), by_count_then_key);
+        keep.resize(TOPK_MAX);
+    }
+    if (due || force || trim) {
+        std::fill(rt.begin(), rt.end(), kt::RetiredRec{});
+        for (const auto& kv : keep) {
+            const uint64_t h = kt::hash_key((const uint8_t*)kv.first.data(), (uint32_t)kv.first.size());
+            uint32_t pos = (uint32_t)(h >> 17) & (kt::RETIRED_CAP - 1u);
+            while (rt[pos].tag != kt::RT_EMPTY) pos = (pos + 1u) & (kt::RETIRED_CAP - 1u);
+            rt[pos].tag = h | kt::RT_VALID;
+            rt[pos].count = (uint32_t)kv.second;
+            rt[pos].len = (uint32_t)kv.first.size();
+            memcpy(rt[pos].bytes, kv.first.data(), kv.first.size());
+        }
+        stats = kt::RetiredRec{};
+        stats.len = (uint32_t)keep.size();
+        TC_HIP(e, hipMemcpyAsync(e->retired, rt.data(), rt.size() * sizeof(kt::RetiredRec), hipMemcpyHostToDevice, s));
+        TC_HIP(e, hipMemcpyAsync(e->retired + kt::RETIRED_CAP, &stats, sizeof stats, hipMemcpyHostToDevice, s));
+        TC_HIP(e, hipStreamSynchronize(s));
+    }
+    if (out) *out = std::move(keep);
+    return TC_E_OK;
+}
+
 extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed) {
     if (!e) return TC_E_INVALID_ARG;
     TC_CHECK_POISON(e);
@@ -36,6 +95,8 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
     *removed = r;
+    // a synchronous sweep is where the table of retired keys is looked after (the sweep is what fills it)
+    if (e->key_mode && e->retired) TC_TRY(compact_retired(e, false, nullptr));
     return TC_E_OK;
 }
 
@@ -143,8 +204,9 @@ extern "C" int tc_denied_reset(tc_engine* e) {
     if (!e) return TC_E_INVALID_ARG;
     if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
     TC_HIP(e, hipSetDevice(e->device));
+    if (e->retired) TC_TRY(drain_key_work(e)); // (a bind kernel on the key stream may be moving counts out of the table)
     TC_HIP(e, hipMemsetAsync(e->denied, 0, e->capacity * sizeof(uint32_t), cur_stream(e)));
-    if (e->retired) TC_HIP(e, hipMemsetAsync(e->retired, 0, (size_t)kt::RETIRED_CAP * sizeof(kt::RetiredRec), cur_stream(e)));
+    if (e->retired) TC_HIP(e, hipMemsetAsync(e->retired, 0, ((size_t)kt::RETIRED_CAP + 1) * sizeof(kt::RetiredRec), cur_stream(e)));
     return TC_E_OK;
 }
 
@@ -159,54 +221,37 @@ extern "C" int tc_top_denied_keys(tc_engine* e, uint32_t k, uint8_t* key_bytes, 
     key_off[0] = 0;
     if (k == 0) return TC_E_OK;
     if (k > TOPK_MAX) k = TOPK_MAX;
-    // keys that hold a slot
-    // (keys over 256 bytes are not tracked by the reference, metrics.rs:36-39: they are filtered out below, so a few
-    // more candidates than k are fetched)
-    const uint32_t k_live = std::min<uint32_t>(k + 64u, TOPK_MAX);
-    std::vector<uint32_t> slots(k_live);
-    std::vector<uint64_t> cnt(k_live);
-    uint32_t n_live = 0;
-    TC_TRY(tc_top_denied(e, k_live, slots.data(), cnt.data(), &n_live));
+    // keys that hold a slot.  Keys over 256 bytes are not tracked by the reference (metrics.rs:36-39) and are filtered out, and
+    // ties at the cut are broken by KEY bytes while tc_top_denied breaks them by slot: candidates are fetched until every
+    // slot whose count reaches the k-th eligible count is among them (or all counted slots are).
     std::vector<std::pair<std::string, uint64_t>> all;
-    if (n_live) {
-        std::vector<uint32_t> off(n_live + 1);
-        std::vector<uint8_t> bytes(std::max<size_t>(1, (size_t)n_live * 64));
-        int rc;
-        while ((rc = tc_slot_keys(e, n_live, slots.data(), bytes.data(), bytes.size(), off.data())) == TC_E_INVALID_ARG && bytes.size() < ((size_t)1 << 31))
-            bytes.resize(bytes.size() * 4);
-        if (rc != TC_E_OK) return rc;
-        for (uint32_t i = 0; i < n_live; ++i)
-            if (off[i + 1] - off[i] <= kt::RETIRED_KEY) all.emplace_back(std::string((const char*)bytes.data() + off[i], off[i + 1] - off[i]), cnt[i]);
-    }
-    // keys that lost theirs (a key's denials are in exactly one place: see kt::RetiredRec)
-    std::vector<kt::RetiredRec> rt(kt::RETIRED_CAP);
-    hipStream_t s = cur_stream(e);
-    TC_HIP(e, hipMemcpyAsync(rt.data(), e->retired, rt.size() * sizeof(kt::RetiredRec), hipMemcpyDeviceToHost, s));
-    TC_HIP(e, hipStreamSynchronize(s));
-    std::vector<std::pair<std::string, uint64_t>> retired;
-    for (const kt::RetiredRec& r : rt)
-        if ((r.tag & kt::RT_VALID) && r.count) retired.emplace_back(std::string((const char*)r.bytes, r.len), (uint64_t)r.count);
-    auto by_count = [](const std::pair<std::string, uint64_t>& a, const std::pair<std::string, uint64_t>& b) {
-        return a.second != b.second ? a.second > b.second : a.first < b.first;
-    };
-    if (retired.size() > 3u * TOPK_MAX) {
-        // TopDeniedKeys::cleanup (metrics.rs:52-64): past 3 x the limit only the most denied `limit` keys are kept.
-        // The table is rewritten from the host (the engine is drained: this is a synchronous call).
-        std::sort(retired.begin(), retired.end(), by_count);
-        retired.resize(TOPK_MAX);
-        std::fill(rt.begin(), rt.end(), kt::RetiredRec{});
-        for (const auto& kv : retired) {
-            const uint64_t h = kt::hash_key((const uint8_t*)kv.first.data(), (uint32_t)kv.first.size());
-            uint32_t pos = (uint32_t)(h >> 17) & (kt::RETIRED_CAP - 1u);
-            while (rt[pos].tag != kt::RT_EMPTY) pos = (pos + 1u) & (kt::RETIRED_CAP - 1u);
-            rt[pos].tag = h | kt::RT_VALID;
-            rt[pos].count = (uint32_t)kv.second;
-            rt[pos].len = (uint32_t)kv.first.size();
-            memcpy(rt[pos].bytes, kv.first.data(), kv.first.size());
+    for (uint32_t k_live = std::min<uint32_t>(k + 64u, TOPK_MAX);;) {
+        std::vector<uint32_t> slots(k_live);
+        std::vector<uint64_t> cnt(k_live);
+        uint32_t n_live = 0;
+        TC_TRY(tc_top_denied(e, k_live, slots.data(), cnt.data(), &n_live));
+        all.clear();
+        if (n_live) {
+            std::vector<uint32_t> off(n_live + 1);
+            std::vector<uint8_t> bytes(std::max<size_t>(1, (size_t)n_live * 64));
+            int rc;
+            while ((rc = tc_slot_keys(e, n_live, slots.data(), bytes.data(), bytes.size(), off.data())) == TC_E_INVALID_ARG && bytes.size() < ((size_t)1 << 31))
+                bytes.resize(bytes.size() * 4);
+            if (rc != TC_E_OK) return rc;
+            for (uint32_t i = 0; i < n_live; ++i)
+                if (off[i + 1] - off[i] <= kt::RETIRED_KEY) all.emplace_back(std::string((const char*)bytes.data() + off[i], off[i + 1] - off[i]), cnt[i]);
         }
-        TC_HIP(e, hipMemcpyAsync(e->retired, rt.data(), rt.size() * sizeof(kt::RetiredRec), hipMemcpyHostToDevice, s));
-        TC_HIP(e, hipStreamSynchronize(s));
+        const bool everything = n_live < k_live || k_live >= TOPK_MAX;
+        // (tc_top_denied returns its candidates most denied first: cnt[n_live - 1] is the smallest count fetched)
+        const bool cut_is_clean = all.size() >= k && n_live && cnt[n_live - 1] < all[k - 1].second;
+        if (everything || cut_is_clean) break;
+        k_live = std::min<uint32_t>(k_live * 2u, TOPK_MAX);
     }
+    // keys that lost theirs (a key's denials are in exactly one place: see kt::RetiredRec); the table is compacted on the way
+    // if its statistics ask for it (it is drained against the key stream first)
+    std::vector<std::pair<std::string, uint64_t>> retired;
+    TC_TRY(compact_retired(e, false, &retired));
+    auto by_count = by_count_then_key;
     all.insert(all.end(), retired.begin(), retired.end());
     std::sort(all.begin(), all.end(), by_count);
     if (all.size() > k) all.resize(k);

@@ -62,8 +62,8 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
             e->route_ws = nullptr;
             e->route_ws_words = 0;
         }
-        // one scratch per stream a router may run on (the caller's / the engine's, each grouping stream): routers on
-        // different streams never wait for one another
+        // one scratch per grouping stream + one (lane 0) for every other stream a router may run on: routers on different
+        // grouping streams never wait for one another, lane 0's users are ordered by an event
         const size_t each = (words * 2 + 1) & ~(size_t)1;
         TC_HIP(e, hipMalloc(&e->route_ws, each * (1 + AUX_MAX) * sizeof(uint32_t)));
         // (hipMemset on device memory returns before the fill has run, and the fill runs on the NULL stream, which the
@@ -72,6 +72,12 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
         TC_HIP(e, hipMemset(e->route_ws, 0, each * (1 + AUX_MAX) * sizeof(uint32_t)));
         TC_HIP(e, hipDeviceSynchronize());
         e->route_ws_words = each;
+    }
+    if (lane == 0) {
+        // every router off the grouping streams shares scratch lane 0: two of them on DIFFERENT streams (a caller's stream and
+        // the engine's, or two callers' streams) are ordered by an event instead of racing on the tile counts
+        if (!e->route_l0_done) TC_HIP(e, hipEventCreateWithFlags(&e->route_l0_done, hipEventDisableTiming));
+        if (e->route_l0_used && e->route_l0_stream != s) TC_HIP(e, hipStreamWaitEvent(s, e->route_l0_done, 0));
     }
     rt::Work w;
     uint32_t* scratch = e->route_ws + (size_t)lane * e->route_ws_words;
@@ -104,6 +110,11 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     }
     if (r.out_count_host) hipLaunchKernelGGL(rt::k_route_publish, dim3(1), dim3(rt::MAX_WORLD), 0, s, w, r.world);
     TC_HIP(e, hipGetLastError());
+    if (lane == 0) {
+        TC_HIP(e, hipEventRecord(e->route_l0_done, s));
+        e->route_l0_stream = s;
+        e->route_l0_used = true;
+    }
     return TC_E_OK;
 }
 
