@@ -784,7 +784,8 @@ struct __attribute__((aligned(32))) ChainRec {
                                     // resident state when it reaches me" (published before the wave waits); strong: "...
                                     // whatever state reaches me" (see k_eval_general)
     uint32_t dirty;
-    uint32_t pad;
+    uint32_t slot;                  // the key whose state this is (valid with fin): a wave that finds the record further back than its
+                                    // direct predecessor knows by it whether the record still belongs to ITS segment
 };
 
 // (general batches, decisions only, TC_B_OUTPUTS_IDLE: the bytes were preset on the grouping stream like the lean
@@ -875,7 +876,18 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         uint32_t in_dirty = 0;
         bool direct = false;    // speculation failed: only an exact hand-over will do
         bool skipped_weak = false; // a weakly transparent wave lies between me and the records being examined
+        bool walking = false;      // the search has passed open records: whatever it finds is an EARLIER state, not the one that reaches me
         uint32_t base = 0;      // records gw-1-base-lane are examined
+        // EARLIER-STATE transparency (round 4; decisions only, TC_CFG_FIXED_PARAMS, the segment runs through this whole wave): the
+        // argument that makes a wave strongly transparent under the RESIDENT state holds for ANY earlier state S of its own
+        // segment -- the key's TAT only grows inside a batch and a live state stays live, so a request that finds S live and is
+        // denied under S is denied under whatever state reaches the wave.  While the records between a wave and the nearest
+        // published state of its segment (same slot) are still open, the wave tries that state: if it denies every lane, the
+        // wave is final, says so (strong) and waits for nobody.  A key that enters a batch fresh -- resident state vacant, which
+        // no wave can be transparent under -- and is drained by its first waves no longer chains the hundreds of waves behind
+        // them one by one (the first Zipf batch on an empty table: one key, 1 800 waves, 4.7 ms).
+        const bool may_try_earlier = !FULL && (p.flags & F_FIXED) != 0u && through;
+        constexpr uint32_t WALK_LIMIT = 48u * 64u; // waves a search for an earlier state walks back before it starts over
         tc::SpinGuard guard;
         while (!strong_wave) {
             if (tc::spin_expired(guard)) { // (see tc::SpinGuard: flagged, never hung; this wave goes on from c0)
@@ -894,41 +906,79 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             const unsigned long long fm = __ballot(is_fin), sm = __ballot(is_spec), tm = __ballot(is_strong);
             // the nearest record that carries a state, and what lies between it and me
             int d = -1;
-            bool exact = false;
+            bool exact = false, earlier = false;
             if (fm) {
                 const int f = __builtin_ctzll(fm);
                 const unsigned long long below = f ? ((1ull << f) - 1ull) : 0ull;
-                if ((~tm & below) == 0ull && !skipped_weak) {
+                if ((~tm & below) == 0ull && !skipped_weak && !walking) {
                     d = f;        // only strongly transparent waves in between: that state IS the one that reaches me
                     exact = true;
-                } else if (!direct && (~sm & below) == 0ull) {
+                } else if (!direct && !walking && (~sm & below) == 0ull) {
                     d = f;        // transparent if the state is still c0: to be checked
+                } else if (may_try_earlier) {
+                    d = f;        // an earlier state of (maybe) my segment: to be tried
+                    earlier = true;
                 }
-            } else if (~tm == 0ull) {
+            } else if (~tm == 0ull && !walking) {
                 base += 64; // 64 strongly transparent waves: look further back
                 continue;
-            } else if (!direct && ~sm == 0ull) {
+            } else if (!direct && !walking && ~sm == 0ull) {
                 skipped_weak = true;
                 base += 64; // 64 transparent waves: look further back
+                continue;
+            } else if (may_try_earlier && base + 64u <= WALK_LIMIT && (long long)gw - 1 - (long long)base - 63 > 0) {
+                walking = true; // open records in this window: walk on, looking for ANY state of my segment
+                base += 64;
                 continue;
             }
             if (d < 0) {
                 base = 0; // something in between is not ready: look again from the nearest record
                 skipped_weak = false;
+                walking = false;
                 __builtin_amdgcn_s_sleep(2);
                 continue;
             }
             long long vt = 0;
             unsigned long long vx = 0;
-            uint32_t vd = 0;
+            uint32_t vd = 0, vs = 0;
             if (lane == d) {
                 vt = (long long)__hip_atomic_load(&chain[j].tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 vx = __hip_atomic_load(&chain[j].expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 vd = __hip_atomic_load(&chain[j].dirty, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vs = __hip_atomic_load(&chain[j].slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             vt = __shfl(vt, d, 64);
             vx = __shfl(vx, d, 64);
             vd = __shfl(vd, d, 64);
+            vs = __shfl(vs, d, 64);
+            if (earlier) {
+                // (every lane of this wave is a request of one slot: `through`)
+                bool final_here = false;
+                if (vs == __shfl(slot, 0, 64)) {
+                    bool allow_s = false, dead_s = false;
+                    if (ok) {
+                        Cell ts;
+                        ts.tat = vt;
+                        ts.expiry = vx;
+                        dead_s = !(vx > (uint64_t)r.now);
+                        allow_s = tc::gcra_step<false>(ts, r.ei, r.dvt, r.q, r.now).allowed;
+                    }
+                    final_here = __ballot(allow_s || dead_s) == 0ull;
+                }
+                if (final_here) {
+                    strong_wave = true; // denied under an earlier LIVE state of my segment: denied under the one that reaches me
+                    in_tat = vt;        // (the lanes are judged against it below: all denied)
+                    in_exp = vx;
+                    if (lane == 0)
+                        __hip_atomic_store(&chain[gw].spec, (seq << 1) | 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                base = 0; // not (yet) decisive: wait for the records in between like everybody else
+                skipped_weak = false;
+                walking = false;
+                __builtin_amdgcn_s_sleep(2);
+                continue;
+            }
             if (exact || (vt == c0_tat && vx == c0_exp)) { // (the weakly transparent waves in between were right)
                 in_tat = vt;
                 in_exp = vx;
@@ -1009,6 +1059,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             __hip_atomic_store(&o->tat, (unsigned long long)out.tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&o->expiry, (unsigned long long)out.expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&o->dirty, out_dirty ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->slot, slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // the record must be performed at agent scope before the flag that announces it
             __atomic_signal_fence(__ATOMIC_SEQ_CST);
             __builtin_amdgcn_s_waitcnt(0);
