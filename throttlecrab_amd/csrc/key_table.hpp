@@ -848,17 +848,9 @@ static __global__ void k_overflow_swap(Table t, const unsigned long long* __rest
 }
 
 // Rebuild (tombstones lengthen probe chains; inserts recycle the ones on their own chain, the rest stays): decided ON THE DEVICE so that
-// a sweep never waits for the host -- k_rebuild_decide latches "tombstones > 1/4 of the table" into
-// a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (three near-empty
-// launches, ~10 us, when no rebuild is due).
-static __global__ void k_rebuild_decide(Table t, uint32_t* __restrict__ flag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        uint32_t tombs = 0; // (the shards wrap around individually; their sum is the count)
-        for (uint32_t s = 0; s < TOMB_SHARDS; ++s) tombs += t.tombs[s];
-        *flag = (uint64_t)tombs > (t.nb_mask + 1) / 4 ? 1u : 0u;
-    }
-}
-
+// a sweep never waits for the host -- mk::k_sweep_decide latches "tombstones (with the keys just unbound) > 1/4 of the
+// table" into a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (near-empty launches when no
+// rebuild is due).
 static __global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32_t* __restrict__ flag) {
     if (*flag == 0u) return;
     // 32-byte entries as two 16-byte stores per thread

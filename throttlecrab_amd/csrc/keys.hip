@@ -72,13 +72,16 @@ int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool inser
     return TC_E_OK;
 }
 
-// rebuild the key table if tombstones fill more than 1/4 of it (checked on the device)
+// the table side of a key-mode sweep, behind k_sweep_keys on the engine's stream: decide whether the table is rebuilt (checked
+// on the device: tombstones + the keys just unbound > 1/4 of it), else turn the unbound keys' entries into tombstones
 int rebuild_key_table_if_due(tc_engine* e) {
     kt::Table& t = e->kt;
     hipStream_t s = cur_stream(e);
     uint32_t* flag = t.error_flag + 1; // spare word of the table's misc block
+    const int* top_save = reinterpret_cast<const int*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 40); // (k_sweep_mark_top)
     const dim3 grid(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block(kt::THREADS);
-    hipLaunchKernelGGL(kt::k_rebuild_decide, dim3(1), dim3(64), 0, s, t, flag);
+    hipLaunchKernelGGL(mk::k_sweep_decide, dim3(1), dim3(64), 0, s, t, top_save, flag);
+    hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(2048), dim3(BLOCK), 0, s, t, top_save, (const uint32_t*)flag);
     hipLaunchKernelGGL(kt::k_rebuild_clear, grid, block, 0, s, t, flag);
     hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, flag);
     // ... and compact the overflow arena (keys longer than 48 bytes) once more than half of it is handed out

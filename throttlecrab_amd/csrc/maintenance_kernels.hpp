@@ -106,7 +106,7 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restric
 // Every block owns a contiguous range of slots, collects the slots it unbinds in
 // LDS and pushes them with ONE stack reservation per SWEEP_BUF slots (an atomic on
 // the stack top costs ~12 ns and serialises: one per 256 slots was most of the kernel).
-constexpr int SWEEP_BUF = 4096;
+constexpr int SWEEP_BUF = 4096; // (>= 2 rounds of BLOCK * SWEEP_ITEMS slots)
 static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
                                                       unsigned long long* counters, unsigned long long* removed_out,
                                                       uint32_t* __restrict__ denied) {
@@ -124,28 +124,63 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
         fill = 0;
     };
     uint32_t unbound_total = 0;
-    for (uint64_t base = first; base < last; base += BLOCK) {
-        const uint64_t i = base + threadIdx.x;
-        bool unbind = false;
-        if (i < last && t.bound[i]) {
-            Cell c = cells[i];
-            if (!(c.expiry > (uint64_t)now)) {
-                if (c.expiry != 0) removed++; // the reference's map only ever held written entries
-                c.tat = 0;
-                c.expiry = 0;
-                cells[i] = c;
-                unbind = true;
-            } else {
-                live++;
+    // SWEEP_ITEMS slots per thread and round: their `bound` bytes, then their cells, are all requested before anything is
+    // looked at, and the block ranks the slots it unbinds once per round (round 4: one slot per thread and two barriers per
+    // 256 slots kept the sweep at 0.9 TB/s -- 180-200 us per sweep of an 11.5 M-slot table, a fifth of configs[4]'s step)
+    constexpr int SWEEP_ITEMS = 4;
+    __shared__ uint32_t s_cnt[BLOCK / 64];
+    for (uint64_t base = first; base < last; base += (uint64_t)BLOCK * SWEEP_ITEMS) {
+        uint8_t bnd[SWEEP_ITEMS];
+        Cell c[SWEEP_ITEMS];
+        bool unbind[SWEEP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SWEEP_ITEMS; ++j) {
+            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+            bnd[j] = i < last ? t.bound[i] : (uint8_t)0;
+        }
+#pragma unroll
+        for (int j = 0; j < SWEEP_ITEMS; ++j) {
+            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+            c[j] = cells[bnd[j] ? i : first]; // (unconditional: a load under a branch drains the earlier ones first)
+        }
+        uint32_t mine = 0;
+#pragma unroll
+        for (int j = 0; j < SWEEP_ITEMS; ++j) {
+            unbind[j] = false;
+            if (bnd[j]) {
+                if (!(c[j].expiry > (uint64_t)now)) {
+                    if (c[j].expiry != 0) removed++; // the reference's map only ever held written entries
+                    unbind[j] = true;
+                    mine++;
+                } else {
+                    live++;
+                }
             }
         }
-        uint32_t total = 0;
-        const uint32_t rank = kt::block_rank<BLOCK>(unbind, total); // one barrier
-        if (fill + total > (uint32_t)SWEEP_BUF) flush();
-        if (unbind) {
-            const uint32_t pos = t.rec[i].pos;
-            t.ktab[pos].w = (t.ktab[pos].w & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
-            t.bound[i] = 0;
+        // rank of my unbound slots among the block's (any order will do: the free stack is a pool)
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        uint32_t incl = mine;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_cnt[wave] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine, total = 0;
+        for (int w = 0; w < BLOCK / 64; ++w) {
+            if (w < wave) before += s_cnt[w];
+            total += s_cnt[w];
+        }
+        if (fill + total > (uint32_t)SWEEP_BUF) flush(); // (uniform over the block; SWEEP_BUF >= 2 rounds)
+#pragma unroll
+        for (int j = 0; j < SWEEP_ITEMS; ++j) {
+            if (!unbind[j]) continue;
+            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+            Cell z;
+            z.tat = 0;
+            z.expiry = 0;
+            cells[i] = z;
+            t.bound[i] = 0; // (the key's table entry is dealt with by k_sweep_tombstones -- or by the rebuild, all at once)
             if (denied) {
                 // the slot will serve another key; its denials stay with the key it served (kt::RetiredRec)
                 const uint32_t dc = denied[i];
@@ -155,14 +190,15 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
                     denied[i] = 0;
                 }
             }
-            s_buf[fill + rank] = (uint32_t)i;
+            s_buf[fill + before] = (uint32_t)i;
+            ++before;
         }
         fill += total;
         unbound_total += total;
-        __syncthreads(); // block_rank's scratch is reused next round
+        __syncthreads(); // s_cnt is reused next round; flush() reads s_buf
     }
     if (fill) flush();
-    if (threadIdx.x == 0 && unbound_total) atomicAdd(&t.tombs[blockIdx.x % kt::TOMB_SHARDS], unbound_total);
+    (void)unbound_total;
     __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
         removed += __shfl_down(removed, off, 64);
@@ -185,6 +221,37 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
         }
         if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
     }
+}
+
+// A key-mode sweep in four steps (round 4): k_sweep_mark_top remembers where the free stack stood; k_sweep_keys vacates the
+// expired cells, unbinds their keys and pushes the slots; k_sweep_decide latches "the table will be rebuilt" (the tombstones it
+// has + the keys just unbound would fill more than 1/4 of it); k_sweep_tombstones then turns the unbound keys' entries into
+// tombstones -- one line read for the entry's position, one entry written, per key -- UNLESS the rebuild is due, which clears
+// the whole table and re-enters the bound keys anyway.  (The first sweep of configs[4] unbinds 9 M of 10.5 M keys: 9 M record
+// lines read and 9 M entries written only to be cleared by the rebuild that followed, a third of that sweep's 1 GB.)
+static __global__ void k_sweep_mark_top(kt::Table t, int* __restrict__ top_save) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) *top_save = *t.free_top;
+}
+static __global__ void k_sweep_decide(kt::Table t, const int* __restrict__ top_save, uint32_t* __restrict__ flag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        uint32_t tombs = 0; // (the shards wrap around individually; their sum is the count)
+        for (uint32_t s = 0; s < kt::TOMB_SHARDS; ++s) tombs += t.tombs[s];
+        const int freed = *t.free_top - *top_save;
+        *flag = (uint64_t)tombs + (uint64_t)(freed > 0 ? freed : 0) > (t.nb_mask + 1) / 4 ? 1u : 0u;
+    }
+}
+static __global__ __launch_bounds__(BLOCK) void k_sweep_tombstones(kt::Table t, const int* __restrict__ top_save, const uint32_t* __restrict__ flag) {
+    if (*flag != 0u) return; // the rebuild that follows drops every entry of an unbound key by itself
+    const int lo = *top_save, hi = *t.free_top;
+    uint32_t mine = 0;
+    for (int k = lo + (int)(blockIdx.x * BLOCK + threadIdx.x); k < hi; k += (int)(gridDim.x * BLOCK)) {
+        const uint32_t slot = t.free_slots[k];
+        const uint32_t pos = t.rec[slot].pos;
+        t.ktab[pos].w = (t.ktab[pos].w & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
+        ++mine;
+    }
+    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&t.tombs[(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % kt::TOMB_SHARDS], mine);
 }
 
 // ---------------------------------------------------------------------------
