@@ -473,6 +473,14 @@ int tc_debug_fail_copy(tc_engine* e, uint32_t nth);
  * engine is poisoned (TC_E_INVARIANT).  Not for production use. */
 int tc_debug_break_wait(tc_engine* e, uint32_t on);
 
+/* Test hook (forward progress): a FILLER kernel -- `blocks` workgroups of 256 threads, `lds_bytes` of LDS each, every one of
+ * which stays resident for `microseconds` -- enqueued on a stream of its own that is restricted to the compute units of
+ * cu_mask (8 words, bit i = CU i as hipExtStreamCreateWithCUMask counts them; NULL: every CU).  Returns at once.  The
+ * kernels that wait for other workgroups (radix look-back, direct stores, the general path's chain, the one-pass router)
+ * wait only for workgroups dispatched EARLIER, so taking wave slots, LDS or whole CUs away from them must only ever make them
+ * slower: tests/test_gpu_robustness.py runs them against fillers and checks results and watchdog.  Not for production use. */
+int tc_debug_occupy(tc_engine* e, const uint32_t* cu_mask, uint32_t blocks, uint32_t lds_bytes, uint64_t microseconds);
+
 /* Checkpoint / restore of everything resident (state cells, rate plans, denial counters, in
  * string mode the key table, plus the counter block).  The reference keeps its state in memory
  * only and loses it on restart; here a snapshot is a few device-to-host copies.  Load needs an

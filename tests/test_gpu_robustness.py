@@ -5,8 +5,9 @@
 * The engine's wait loops (radix look-back, direct stores of k_eval_sorted, hand-over chain of k_eval_general)
   each wait only for blocks dispatched earlier.  Two processes drive two engines on ONE device with the
   batches that lean on those waits hardest (hot keys with runs of 100 000 allowed requests crossing ~1 600
-  waves, per-request timestamps, skewed uniform batches), so that their kernels contend for the same CUs;
-  every result is checked against the oracle and the spin watchdog (tc_selfcheck) must stay silent."""
+  waves, per-request timestamps, skewed uniform batches), so that their kernels contend for the same CUs -- and, round 4,
+  against FILLER kernels (tc_debug_occupy) that sit on half of the CUs, on every other CU, or on every CU's LDS while the
+  batches run; every result is checked against the oracle and the spin watchdog (tc_selfcheck) must stay silent."""
 import os
 import socket
 import sys
@@ -140,8 +141,16 @@ def _contender(rank, seconds, q):
     host_counts = eng.host_alloc(3, np.uint32)
     host_counts[:] = 0
     t_end, rounds, bad = time.time() + seconds, 0, 0
+    # fillers take wave slots, LDS and whole CUs away from the kernels that wait for other workgroups: half of the
+    # CUs for 3 ms, every other CU, or every CU's LDS -- launched just before a batch, still resident while its kernels run
+    fillers = os.environ.get("TC_STRESS_FILLERS", "1") == "1"
+    masks = [[0xFFFFFFFF] * 4 + [0] * 4, [0x55555555] * 8, None]
     while time.time() < t_end:
         kind = rounds % 4
+        if fillers and rounds % 3 != 2:
+            m = masks[(rounds // 4) % 3]
+            eng.debug_occupy(blocks=256 if m is None else 1024, microseconds=3000 if m is not None else 800, cu_mask=m,
+                             lds_bytes=96 * 1024 if m is None else 0)
         if kind == 3:
             # a global batch of 2 shards routed on the grouping streams (one-pass router: tiles chained by look-back),
             # the count polled from pinned memory, what this shard owns evaluated as a pipelined batch
@@ -245,3 +254,65 @@ def test_a_tripped_watchdog_fails_the_engine_loudly(sync_batch):
     e2.register_params_uniform(5, 10, 60)
     assert e2.rate_limit_batch_slots(np.arange(10, dtype=np.uint32), registered=True, quantity=1, now_ns=T0, want=("allowed",)).allowed.all()
     e2.close()
+
+
+@pytest.mark.parametrize("filler", ["half_the_cus", "every_other_cu", "all_lds", "oversubscribed"])
+def test_waiting_kernels_make_progress_beside_fillers(filler):
+    """the look-back of the LSD passes, the direct stores of k_eval_sorted, the chain of k_eval_general and the
+    one-pass router wait for workgroups dispatched EARLIER -- an assumption about the dispatcher, not a promise of HIP.  What
+    can be tested is that starving them does not break it: a filler kernel (tc_debug_occupy) holds half of the CUs, every other
+    CU, most of every CU's LDS, or more workgroups than the chip has room for, for milliseconds, while batches with a run of
+    ~105 000 allowed requests of one key (1 600 rows behind one owner), per-request timestamps (the chain) and a skewed slot
+    column (LSD passes) run pipelined.  Results == oracle, watchdog silent."""
+    import torch
+
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    from throttlecrab_amd import sharded
+    cap, n = 200_000, 1 << 18
+    rng = np.random.default_rng(41)
+    eng, orc = t.Engine(cap, n), O.DenseOracle(cap)
+    eng.use_torch_stream()
+    eng.register_params_uniform(200_000, 10**9, 1)
+    tt = lambda a: torch.from_numpy(np.asarray(a).astype(np.int64)).cuda()
+    spec = {"half_the_cus": dict(blocks=2048, microseconds=4000, cu_mask=[0xFFFFFFFF] * 4 + [0] * 4),
+            "every_other_cu": dict(blocks=2048, microseconds=4000, cu_mask=[0x55555555] * 8),
+            "all_lds": dict(blocks=256, microseconds=4000, lds_bytes=128 * 1024),
+            "oversubscribed": dict(blocks=8192, microseconds=600)}[filler]
+    host_counts = eng.host_alloc(3, np.uint32)
+    host_counts[:] = 0
+    pending = []
+    for rnd in range(8):
+        slots = rng.integers(0, cap, n).astype(np.uint32)
+        slots[rng.random(n) < 0.4] = 11
+        base = T0 + rnd * 10**9
+        d = torch.from_numpy(slots.astype(np.int32)).cuda()
+        torch.cuda.synchronize()
+        eng.debug_occupy(**spec)                      # resident while the batch's kernels are dispatched
+        if rnd % 4 == 0:
+            now = base + np.sort(rng.integers(0, 10**6, n))
+            ref = orc.batch_slots(slots, 200_000, 10**9, 1, 1, now)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=tt(now), want=("allowed", "remaining"), inputs_ready=True)
+        elif rnd % 4 == 3:
+            gids = rng.integers(0, 2 * cap, n).astype(np.uint32)
+            owner, slot = sharded.route(gids, 2, cap)
+            want = slot[owner == 0]
+            ref = orc.batch_slots(want, 200_000, 10**9, 1, 1, base)
+            g = torch.from_numpy(gids.astype(np.int32)).cuda()
+            torch.cuda.synchronize()
+            slots_d, _, _ = eng.route_batch(g, 2, only=0, ahead=True, host_counts=host_counts, tag=rnd + 1)
+            while int(host_counts[2]) != rnd + 1:
+                pass
+            mine = int(host_counts[0])
+            assert mine == len(want)
+            res = eng.rate_limit_batch_slots(slots_d[:mine], registered=True, quantity=1, now_ns=base, want=("allowed", "remaining"), inputs_ready=True)
+        else:
+            ref = orc.batch_slots(slots, 200_000, 10**9, 1, 1, base)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=base, want=("allowed", "remaining"), inputs_ready=bool(rnd % 2))
+        pending.append((res, ref, d))
+    torch.cuda.synchronize()
+    for rnd, (res, ref, _) in enumerate(pending):
+        assert np.array_equal(res.allowed.cpu().numpy(), ref.allowed), (filler, rnd)
+        assert np.array_equal(res.remaining.cpu().numpy(), ref.remaining), (filler, rnd)
+    assert eng.selfcheck() == 0, "the spin watchdog fired"
+    eng.close()

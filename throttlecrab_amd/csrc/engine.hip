@@ -423,6 +423,10 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
     if (e->route_l0_done) (void)hipEventDestroy(e->route_l0_done);
+    for (uint32_t k = 0; k < e->debug_fillers; ++k) {
+        (void)hipStreamSynchronize(e->debug_filler[k]);
+        (void)hipStreamDestroy(e->debug_filler[k]);
+    }
     if (e->poison_host) (void)hipHostFree(e->poison_host);
     if (e->k_done) (void)hipEventDestroy(e->k_done);
     if (e->m_done) (void)hipEventDestroy(e->m_done);
@@ -596,6 +600,35 @@ extern "C" int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]) {
     TC_HIP(e, hipMemcpyAsync(out, e->counters, TC_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     out[TC_CNT_BATCHES] = e->batches;
+    return TC_E_OK;
+}
+
+// ---- tc_debug_occupy: fillers for the forward-progress tests --------------------------------------------------------------
+static __global__ void k_filler(long long ticks) { // every thread stays for `ticks` of the 100 MHz wall clock
+    extern __shared__ uint32_t s_fill[];
+    if (threadIdx.x == 0) s_fill[0] = 1u; // (keeps the dynamic LDS allocated)
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+
+extern "C" int tc_debug_occupy(tc_engine* e, const uint32_t* cu_mask, uint32_t blocks, uint32_t lds_bytes, uint64_t microseconds) {
+    if (!e || blocks == 0 || blocks > 65536 || lds_bytes > 160 * 1024 || microseconds > 2000000ull) return TC_E_INVALID_ARG;
+    TC_HIP(e, hipSetDevice(e->device));
+    uint32_t mask[8];
+    for (int i = 0; i < 8; ++i) mask[i] = cu_mask ? cu_mask[i] : 0xFFFFFFFFu;
+    uint32_t at = e->debug_fillers;
+    for (uint32_t k = 0; k < e->debug_fillers; ++k)
+        if (memcmp(e->debug_filler_mask[k], mask, sizeof mask) == 0) at = k;
+    if (at == e->debug_fillers) {
+        if (at == 4) return fail(e, TC_E_INVALID_ARG, "tc_debug_occupy: at most 4 distinct CU masks per engine");
+        TC_HIP(e, hipExtStreamCreateWithCUMask(&e->debug_filler[at], 8, mask));
+        memcpy(e->debug_filler_mask[at], mask, sizeof mask);
+        e->debug_fillers++;
+    }
+    if (lds_bytes > 64 * 1024)
+        TC_HIP(e, hipFuncSetAttribute(reinterpret_cast<const void*>(k_filler), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(k_filler, dim3(blocks), dim3(256), lds_bytes < 4 ? 4 : lds_bytes, e->debug_filler[at], (long long)(microseconds * 100ull));
+    TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
 

@@ -194,6 +194,9 @@ struct tc_engine {
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
     uint32_t* poison_host = nullptr; // pinned: raised by tc::invariant_failed; every ABI call checks it (TC_E_INVARIANT)
     bool debug_break_wait = false;   // tc_debug_break_wait
+    hipStream_t debug_filler[4] = {};    // tc_debug_occupy: filler streams, one per distinct CU mask seen (up to 4)
+    uint32_t debug_filler_mask[4][8] = {};
+    uint32_t debug_fillers = 0;
     uint32_t fault_countdown = 0; // tc_debug_fail_copy: the n-th staging copy from now fails (error-path tests)
     uint32_t* route_ws = nullptr; // tc_route_batch scratch (lazy): per stream it may run on: tile counts per destination
     size_t route_ws_words = 0;    // words of one of them

@@ -103,6 +103,14 @@ class Engine:
         """test hook: the next uniform batch withholds one cross-row announcement (tc_debug_break_wait)"""
         self._check(self._lib.tc_debug_break_wait(self._h, 1 if on else 0))
 
+    def debug_occupy(self, blocks: int, microseconds: int, cu_mask=None, lds_bytes: int = 0):
+        """test hook: a filler kernel of `blocks` workgroups that stay resident for `microseconds` each, on a stream limited to
+        the CUs of `cu_mask` (8 uint32 words; None: all) -- tc_debug_occupy; returns at once"""
+        m = None
+        if cu_mask is not None:
+            m = (C.c_uint32 * 8)(*[int(w) & 0xFFFFFFFF for w in cu_mask])
+        self._check(self._lib.tc_debug_occupy(self._h, m, blocks, lds_bytes, microseconds))
+
     def selfcheck(self) -> int:
         v = C.c_uint64(0)
         self._check(self._lib.tc_selfcheck(self._h, C.byref(v)))
