@@ -888,9 +888,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         // them one by one (the first Zipf batch on an empty table: one key, 1 800 waves, 4.7 ms).
         const bool may_try_earlier = !FULL && (p.flags & F_FIXED) != 0u && through;
         constexpr uint32_t WALK_LIMIT = 48u * 64u; // waves a search for an earlier state walks back before it starts over
-        unsigned long long pf[4] = {0ull, 0ull, 0ull, 0ull}; // the flag words of four windows, requested together
-        uint32_t pf_base = 0;
-        bool pf_valid = false;
         tc::SpinGuard guard;
         while (!strong_wave) {
             if (tc::spin_expired(guard)) { // (see tc::SpinGuard: flagged, never hung; this wave goes on from c0)
@@ -899,23 +896,11 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
                 in_exp = c0_exp;
                 break;
             }
-            // four windows of 64 records are requested at once (a walk over the 1 800 strongly transparent waves of a hot
-            // key's run is a chain of round trips: 28 of them one window at a time); they are looked at nearest first, and
-            // whatever makes the search start over (base = 0) reads the records afresh
-            if (base < pf_base || base >= pf_base + 4u * 64u || !pf_valid) {
-                pf_base = base;
-                pf_valid = true;
-#pragma unroll
-                for (int w = 0; w < 4; ++w) {
-                    const long long jw = (long long)gw - 1 - (long long)(base + 64u * (uint32_t)w) - lane;
-                    pf[w] = jw >= 0 ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&chain[jw].fin), __ATOMIC_RELAXED,
-                                                        __HIP_MEMORY_SCOPE_AGENT)
-                                    : 0ull;
-                }
-            }
             const long long j = (long long)gw - 1 - (long long)base - lane;
-            const uint32_t wsel = (base - pf_base) >> 6; // (wave-uniform)
-            const unsigned long long fl = wsel == 0u ? pf[0] : (wsel == 1u ? pf[1] : (wsel == 2u ? pf[2] : pf[3]));
+            unsigned long long fl = 0ull;
+            if (j >= 0)
+                fl = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(&chain[j].fin), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t sp = (uint32_t)(fl >> 32);
             const bool is_fin = (uint32_t)fl == seq, is_spec = (sp >> 1) == seq, is_strong = is_spec && (sp & 1u);
             const unsigned long long fm = __ballot(is_fin), sm = __ballot(is_spec), tm = __ballot(is_strong);
@@ -948,7 +933,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             }
             if (d < 0) {
                 base = 0; // something in between is not ready: look again from the nearest record
-                pf_valid = false;
                 skipped_weak = false;
                 walking = false;
                 __builtin_amdgcn_s_sleep(2);
@@ -990,7 +974,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
                     break;
                 }
                 base = 0; // not (yet) decisive: wait for the records in between like everybody else
-                pf_valid = false;
                 skipped_weak = false;
                 walking = false;
                 __builtin_amdgcn_s_sleep(2);
@@ -1004,7 +987,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             }
             direct = true; // the state changed on the way: no shortcut through weakly transparent waves
             base = 0;
-            pf_valid = false;
             skipped_weak = false;
         }
         if (continued) {
