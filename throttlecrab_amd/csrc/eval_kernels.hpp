@@ -26,6 +26,7 @@ constexpr uint32_t F_FIXED = 4u;         // TC_CFG_FIXED_PARAMS engine: 8-byte T
 constexpr uint32_t F_PREFILL0 = 16u;     // TC_B_OUTPUTS_IDLE batch whose `allowed` bytes were all set to 0 ahead of the evaluation
 constexpr uint32_t F_PREFILL1 = 32u;     // ... to 1: the evaluation only stores the decisions that differ from the fill
 constexpr uint32_t F_DEBUG_NO_ANNOUNCE = 64u; // tc_debug_break_wait: row 0 never announces (the watchdog's test)
+constexpr uint32_t F_NO_EARLIER = 128u;  // TCGPU_GENERAL_EARLIER=0 (A/B): k_eval_general without the earlier-state rule
 constexpr uint32_t F_DEBUG_NOSTORE = 8u; // measurement only (TCGPU_DEBUG_NO_DECISION_STORE): the lean kernel skips its decision bytes
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
 constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
@@ -886,7 +887,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         // wave is final, says so (strong) and waits for nobody.  A key that enters a batch fresh -- resident state vacant, which
         // no wave can be transparent under -- and is drained by its first waves no longer chains the hundreds of waves behind
         // them one by one (the first Zipf batch on an empty table: one key, 1 800 waves, 4.7 ms).
-        const bool may_try_earlier = !FULL && (p.flags & F_FIXED) != 0u && through;
+        const bool may_try_earlier = !FULL && (p.flags & (F_FIXED | F_NO_EARLIER)) == F_FIXED && through;
         constexpr uint32_t WALK_LIMIT = 48u * 64u; // waves a search for an earlier state walks back before it starts over
         tc::SpinGuard guard;
         while (!strong_wave) {
