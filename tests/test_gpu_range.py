@@ -1,0 +1,121 @@
+"""The range path of the grouping stage (csrc/radix_sort.hpp: k_tile_ranges + k_finish) through the C ABI: streams that switch
+between uniform and skewed batches (the host chooses the path from a HINT about recent batches: a skewed batch on the range
+path must still come out exact -- k_finish sorts an oversized range through global memory), key spaces at the edges of what the
+path takes, batches that are tiny, ragged or larger than the path takes, duplicates beyond the counting path's byte counters.
+Everything against the oracle applying the requests one by one (rate_limiter.rs:147-205 in queue order)."""
+import numpy as np
+import pytest
+
+from tests.test_gpu_slots import T0, _oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cap, batches, piped, fixed=True, plan=(5, 50, 60), general=False):
+    import torch
+
+    import throttlecrab_amd as t
+    eng = t.Engine(cap, max(len(b) for b in batches), fixed_params=fixed)
+    eng.use_torch_stream()
+    eng.register_params_uniform(*plan)
+    orc = _oracle(cap)
+    held = []
+    rng = np.random.default_rng(len(batches))
+    for i, slots in enumerate(batches):
+        now = T0 + i * 700_000_000
+        d = torch.from_numpy(slots.astype(np.int32)).cuda()
+        if general:
+            nowc = now + np.sort(rng.integers(0, 10**6, len(slots)))
+            ref = orc.batch_slots(slots, *plan, 1, nowc)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=torch.from_numpy(nowc).cuda(), want=("allowed", "status"), inputs_ready=piped)
+        else:
+            ref = orc.batch_slots(slots, *plan, 1, now)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=now, want=("allowed", "remaining", "status"), inputs_ready=piped)
+        held.append((res, ref, d))
+        if not piped or i % 3 == 2:
+            torch.cuda.synchronize()   # (lets the hint of the batches so far reach the host: the next call may change path)
+    torch.cuda.synchronize()
+    for i, (res, ref, _) in enumerate(held):
+        assert np.array_equal(res.allowed.cpu().numpy(), ref.allowed), f"batch {i}: decisions differ"
+        assert np.array_equal(res.status.cpu().numpy(), ref.status), f"batch {i}: statuses differ"
+        if not general:
+            assert np.array_equal(res.remaining.cpu().numpy(), ref.remaining), f"batch {i}: remaining differs"
+    assert eng.selfcheck() == 0
+    c = eng.counters()
+    eng.close()
+    return c
+
+
+def _uniform(rng, cap, n):
+    return rng.integers(0, cap, n).astype(np.uint32)
+
+
+def _skewed(rng, cap, n, share=0.45, keys=3):
+    s = rng.integers(0, cap, n).astype(np.uint32)
+    hot = rng.random(n) < share
+    s[hot] = rng.integers(0, keys, int(hot.sum())) * (cap // 7) + 5
+    return s
+
+
+@pytest.mark.parametrize("piped", [True, False], ids=["pipelined", "in_order"])
+def test_a_stream_that_switches_between_uniform_and_skewed_batches(piped):
+    """uniform batches put the engine on the range path; the skewed batches that follow are grouped by it until the hint has
+    caught up (oversized ranges: k_finish's pass through global memory), then by the LSD passes; then uniform again"""
+    rng = np.random.default_rng(5)
+    cap, n = 400_000, 150_000
+    kinds = "uuuuuu" + "ssssssss" + "uuuuuuuuuu" + "sususususu" + "uuuuuuuuuuuu"
+    batches = [(_uniform if k == "u" else _skewed)(rng, cap, n) for k in kinds]
+    c = _run(cap, batches, piped)
+    assert 0 < c["denied"] < c["total"]
+
+
+def test_skew_inside_one_range_many_keys():
+    """70 % of a batch in ONE range but spread over 3 000 keys: the oversized range is a real sort, not one run"""
+    rng = np.random.default_rng(6)
+    cap, n = 400_000, 120_000
+    batches = []
+    for i in range(14):
+        s = _uniform(rng, cap, n)
+        if i >= 6:
+            m = rng.random(n) < 0.7
+            s[m] = cap // 3 + rng.integers(0, 3000, int(m.sum()))
+        batches.append(s)
+    _run(cap, batches, True)
+    _run(cap, batches, False, fixed=False)
+
+
+@pytest.mark.parametrize("cap", [65_537, 70_001, 1_000_003, 16_000_000, 16_777_215, 20_000_000])
+def test_key_spaces_at_the_edges_of_the_range_path(cap):
+    """65 536 keys and fewer, or ranges wider than 65 536 slots (> 16.7 M keys), are sorted by the LSD passes; everything in
+    between takes the range path -- with one digit of the offset (ranges of at most 256 slots) or two"""
+    rng = np.random.default_rng(cap % 1000)
+    n = 60_000
+    batches = [_uniform(rng, cap, n) for _ in range(6)]
+    batches[3][: n // 2] = cap - 1          # the last slot, many times
+    batches[4][::3] = 0
+    _run(cap, batches, True)
+
+
+def test_batch_sizes_tiny_ragged_and_beyond_the_path():
+    rng = np.random.default_rng(8)
+    cap = 300_000
+    sizes = [1, 255, 256, 257, 4095, 4096, 4097, 70_001, 1, 300_000, 2_000_000, 1_600_000, 100_000, 100_000]
+    batches = [_uniform(rng, cap, n) for n in sizes]
+    _run(cap, batches, True)
+    _run(cap, batches, False)
+
+
+def test_slots_with_more_requests_than_a_byte_counter_holds():
+    """the counting path of k_finish keeps a byte per slot and gives up at 16 requests of one slot in a range (ballot passes
+    instead): slots with 17, 100, 300 and 5 000 requests among uniform ones, below the share that sends the stream to the LSD passes"""
+    rng = np.random.default_rng(9)
+    cap, n = 2_000_000, 400_000
+    batches = []
+    for i in range(10):
+        s = _uniform(rng, cap, n)
+        for j, cnt in enumerate((17, 100, 300, 5000 if i % 2 else 16)):
+            at = rng.integers(0, n, cnt)
+            s[at] = 123_457 * (j + 1) + i
+        batches.append(s)
+    _run(cap, batches, True, plan=(100, 1000, 3600))
+    _run(cap, batches, True, general=True)

@@ -85,13 +85,20 @@ int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_ke
 // the batch; it goes by the largest range of a RECENT batch of the stream, which every grouping mirrors into pinned memory
 // (never waited for).  No hint yet, a hint that predicts a range beyond what a block finishes in LDS, or a batch too large:
 // the LSD passes.  A wrong guess costs time, not correctness (k_finish sorts an oversized range through global memory).
-static bool range_applies(const tc_engine* e, uint32_t n, bool piped) {
+static bool range_applies(tc_engine* e, uint32_t n, bool piped) {
     if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return false;
-    const uint32_t tile = rs::THREADS * (uint32_t)(piped ? e->sort_items_piped : SORT_ITEMS);
-    if (n < 256u || n > e->range_max_n || (n + tile - 1) / tile > (uint32_t)rs::FIN_THREADS) return false;
     const unsigned long long h = *(volatile unsigned long long*)e->range_hint_host;
     const uint64_t hn = h >> 32, hmax = h & 0xFFFFFFFFull;
-    return hn != 0 && hmax * (uint64_t)n <= hn * (uint64_t)(rs::FIN_CAP / 8u * 7u);
+    // the share of a batch its largest range took (x 2^20), of the last RANGE_HINTS looks at the hint: a stream that
+    // alternates between uniform and skewed batches stays on the LSD passes (a skewed batch on the range path costs a
+    // block's slow pass over its oversized range: ~0.5 ms for a Zipf(1.1) batch)
+    if (hn == 0) return false; // (no grouping of this engine has run yet)
+    e->range_share[e->range_looks++ % tc_engine::RANGE_HINTS] = (uint32_t)std::min<uint64_t>((hmax << 20) / hn, 0xFFFFFFFFull);
+    const uint32_t tile = rs::THREADS * (uint32_t)(piped ? e->sort_items_piped : SORT_ITEMS);
+    if (n < 256u || n > e->range_max_n || (n + tile - 1) / tile > (uint32_t)rs::FIN_THREADS) return false;
+    uint32_t worst = 0;
+    for (uint32_t k = 0; k < tc_engine::RANGE_HINTS; ++k) worst = std::max(worst, e->range_share[k]);
+    return (((uint64_t)worst * n) >> 20) <= (uint64_t)(rs::FIN_CAP / 8u * 7u);
 }
 
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
