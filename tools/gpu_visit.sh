@@ -27,7 +27,6 @@ for S in $STEPS; do
     dist1prof) cd /tmp; export TMPDIR=/tmp
            RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 MASTER_ADDR=127.0.0.1 MASTER_PORT=29535 TC_BENCH_FORCE_DIST=1 timeout 120 rocprofv3 --kernel-trace --stats -d $O/x_stats -o s -- python $R/bench.py --gpus 1 --steps 40 --warmup 10 --route exchange > $O/x_stats.log 2>&1; echo "rc=$?"
            cd $R; python tools/trace_seq.py $O/x_stats -520 160 > $O/trace_seq.txt 2>&1; python tools/summarize_prof.py ${TAG}_exchange_1rank $O/x_stats > /dev/null 2>&1; head -24 profiles/${TAG}_exchange_1rank.txt; mkdir -p $O/profiles; cp profiles/${TAG}_exchange_1rank* $O/profiles/; rm -rf $O/x_stats ;;
-    segab) timeout 120 python tools/seg_ab.py 2>&1 | grep -v amdgpu.ids ;;
     keysprof) bash tools/gpu_round.sh $TAG string_keys string_keys_long ;;
     keysq) timeout 200 python tools/keys_only.py 2>/dev/null | tail -1 ;;
     keys) timeout 200 python tools/keys_only.py 2>/dev/null | tail -1
