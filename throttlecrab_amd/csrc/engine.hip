@@ -121,7 +121,6 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_DEBUG_NO_DECISION_STORE")) e->debug_nostore = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_GENERAL_EARLIER")) e->general_earlier = atoi(d) != 0;
-    if (const char* d = getenv("TCGPU_CARRY_NOW")) e->carry_now = atoi(d) != 0;
     {
         TC_HIP(e, hipHostMalloc((void**)&e->fill_hint_host, 64, hipHostMallocDefault));
         *e->fill_hint_host = 1u;
@@ -167,7 +166,6 @@ int engine_alloc(tc_engine* e) {
         TC_HIP(e, hipMalloc(&ss.elem_b, mb * sizeof(uint64_t)));
         if (e->range_ok) {
             TC_HIP(e, hipMalloc(&ss.elem_c, std::min<uint64_t>(mb, e->range_max_n) * sizeof(uint64_t)));
-            TC_HIP(e, hipMalloc(&ss.carry, std::min<uint64_t>(mb, e->range_max_n) * sizeof(int64_t)));
             TC_HIP(e, hipMalloc(&ss.range_totals, 2 * rs::RADIX * sizeof(uint32_t)));
             TC_HIP(e, hipMemsetAsync(ss.range_totals, 0, 2 * rs::RADIX * sizeof(uint32_t), (hipStream_t)0));
         }
@@ -408,7 +406,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.carry, ss.range_totals, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }

@@ -102,7 +102,6 @@ struct tc_engine {
     struct SortSet {
         uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
         uint64_t* elem_c = nullptr;                    // range path: scratch of a range that does not fit LDS (min(max_batch, range_max_n))
-        int64_t* carry = nullptr;                      // range path, general batches: the per-request timestamps in sorted order (same size)
         uint32_t* range_totals = nullptr;              // range path: 2 x RADIX words, the ranges' sizes of this / the next batch of the set
         uint32_t range_parity = 0;
         uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
@@ -162,7 +161,6 @@ struct tc_engine {
     uint32_t range_looks = 0;
     uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting
     uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
-    bool carry_now = true;           // TCGPU_CARRY_NOW=0: k_eval_general gathers the timestamps by request index on the range path too (A/B)
     bool general_earlier = true;     // TCGPU_GENERAL_EARLIER=0: k_eval_general without the earlier-state rule (A/B)
     bool debug_nostore = false; // TCGPU_DEBUG_NO_DECISION_STORE=1: MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)
     uint32_t loaded_seq = 0;

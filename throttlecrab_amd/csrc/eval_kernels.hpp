@@ -71,11 +71,10 @@ struct Req {
 };
 
 // Request i against `slot`: arguments, derived rate and status (rate_limiter.rs:111-123).
-// `now_sorted`: the request's timestamp when the grouping stage carried the `now` column along (k_finish), else nullptr
-__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot, const int64_t* now_sorted = nullptr, uint32_t k = 0) {
+__device__ __forceinline__ Req make_req(const Params& p, uint32_t i, uint32_t slot) {
     Req r;
     r.q = p.q ? p.q[i] : p.q_s;
-    r.now = now_sorted ? now_sorted[k] : (p.now ? p.now[i] : p.now_s);
+    r.now = p.now ? p.now[i] : p.now_s;
     r.ei = r.dvt = r.limit = 0;
     if (slot >= p.capacity) {
         r.status = tc::ST_INTERNAL;
@@ -804,8 +803,7 @@ __device__ __forceinline__ void write_out_general(const Params& p, uint32_t i, c
 
 template <bool FULL>
 __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t* __restrict__ sorted,
-                                                        ChainRec* __restrict__ chain, uint32_t seq, uint32_t* hint,
-                                                        const int64_t* __restrict__ now_sorted) {
+                                                        ChainRec* __restrict__ chain, uint32_t seq, uint32_t* hint) {
     const uint32_t n = p.n;
     const uint32_t k = blockIdx.x * BLOCK + threadIdx.x;
     const int lane = threadIdx.x & 63;
@@ -825,7 +823,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     Req r;
     r.ei = r.dvt = r.q = r.now = r.limit = 0;
     r.status = tc::ST_INTERNAL;
-    if (valid) r = make_req(p, idx, slot, now_sorted, k); // (now_sorted: a coalesced read instead of a gather by request index)
+    if (valid) r = make_req(p, idx, slot);
     const bool ok = valid && r.status == tc::ST_OK;
 
     // my piece = lanes [pstart, pend] of this wave that belong to my segment

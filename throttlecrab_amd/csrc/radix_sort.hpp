@@ -681,18 +681,11 @@ __global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restr
 // early then sat on their CU waiting for the late ones, 41 us per launch in the pipelined run against 14 alone);
 // sub_passes = 8-bit digits of the offset inside a range (1 or 2: the host takes this path only when the widest range
 // is at most 65536 slots); `range_hint`: n << 32 | largest range, into pinned host memory (block RADIX - 1).
-// CARRY: a column of one 8-byte value per request (the per-request timestamps of a general batch) is brought into sorted
-// order on the way: carry_out[k] = carry_in[index of sorted element k].  The gather by request index that k_eval_general
-// would do on the critical stream (1 Mi random 8-byte loads: 2 x 63 MB fetched, most of that kernel's traffic) is issued
-// here right after the elements have arrived and is not looked at before the range is sorted -- sixteen waves per CU and
-// two sort phases hide it (round 3 carried the column through the last LSD pass, four waves per CU: the pass got 20 us slower).
-template <bool CARRY>
 static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* __restrict__ tiled, const uint32_t* __restrict__ table,
                                                                uint64_t* __restrict__ elem_out, uint64_t* __restrict__ scratch,
                                                                const uint32_t* __restrict__ totals, uint32_t* __restrict__ totals_next, uint32_t n,
                                                                uint32_t tiles, uint32_t tile_len, uint32_t msd_mul, int sub_passes,
-                                                               unsigned long long* __restrict__ range_hint,
-                                                               const int64_t* __restrict__ carry_in, int64_t* __restrict__ carry_out) {
+                                                               unsigned long long* __restrict__ range_hint) {
     __shared__ uint32_t s_idx[FIN_CAP];            // request index of position p (never moves)
     __shared__ uint32_t s_u[FIN_UNION_WORDS];      // the two ways of sorting a range share this
     // ballot path: offset inside the range << FIN_POS_BITS | p in the order reached so far (x2), per-wave digit counters, digit totals / starts
@@ -820,7 +813,6 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
             RS_STAMP(1, 4, 128);
             const uint32_t strip = ((c + FIN_THREADS - 1) / FIN_THREADS) * 64u;
             uint32_t kv[FIN_ITEMS], arr[FIN_ITEMS];
-            int64_t cv[CARRY ? FIN_ITEMS : 1];
             bool valid[FIN_ITEMS], over = false;
 #pragma unroll
             for (int j = 0; j < FIN_ITEMS; ++j) {
@@ -834,7 +826,6 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                     s_idx[p] = (uint32_t)e;
                     const uint32_t sub = (uint32_t)(e >> 32) - lo;
                     kv[j] = (sub << FIN_POS_BITS) | p;
-                    if (CARRY) cv[j] = carry_in[(uint32_t)e];
                     const uint32_t sh = 8u * (sub & 3u);
                     arr[j] = (atomicAdd(&c_cnt[sub >> 2], 1u << sh) >> sh) & 255u;
                     over |= arr[j] >= CNT_DUP_MAX;
@@ -901,11 +892,6 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) {
                     const uint32_t v = c_fin[q];
                     out[q] = ((uint64_t)(lo + (v >> FIN_POS_BITS)) << 32) | s_idx[v & (FIN_CAP - 1u)];
-                }
-                if (CARRY) {
-#pragma unroll
-                    for (int j = 0; j < FIN_ITEMS; ++j)
-                        if (valid[j]) carry_out[base + q_of[j]] = cv[j]; // (the range's 32 KB of the column: this block writes all of it)
                 }
                 RS_STAMP(1, 14, 128);
                 return;
@@ -1030,11 +1016,6 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
     }
     if ((sub_passes & 1) != 0)
         for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) b[q] = ld_l2(&a[q]);
-    if (CARRY) {
-        __threadfence();
-        __syncthreads();
-        for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) carry_out[base + q] = carry_in[(uint32_t)ld_l2(&b[q])];
-    }
 }
 
 } // namespace rs

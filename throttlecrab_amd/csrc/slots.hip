@@ -105,7 +105,7 @@ static bool range_applies(tc_engine* e, uint32_t n, bool piped) {
 // returns the buffer holding the result
 static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
                                     bool piped, bool ranged, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
-                                    uint8_t* fill = nullptr, uint32_t fill_value = 0, const int64_t* carry_in = nullptr) {
+                                    uint8_t* fill = nullptr, uint32_t fill_value = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
     const int passes = (bits + 7) / 8;
@@ -134,13 +134,8 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
         prof_end_m(e, s);
         prof_begin_m(e, TC_STAGE_SORT, s);
         hipEvent_t stop = e->prof_on ? nullptr : stop_last;
-        // (carry_in: the per-request timestamps of a general batch, brought into sorted order on the way -- ss.carry)
-        if (carry_in)
-            TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish<true>, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)table, bufs[0],
-                        ss.elem_c, (const uint32_t*)totals, totals_next, n, tiles, tile, e->range_mul, e->range_sub_passes, hint, carry_in, ss.carry);
-        else
-            TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish<false>, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)table, bufs[0],
-                        ss.elem_c, (const uint32_t*)totals, totals_next, n, tiles, tile, e->range_mul, e->range_sub_passes, hint, (const int64_t*)nullptr, (int64_t*)nullptr);
+        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)table, bufs[0],
+                    ss.elem_c, (const uint32_t*)totals, totals_next, n, tiles, tile, e->range_mul, e->range_sub_passes, hint);
         prof_end_m(e, s);
         return bufs[0];
     }
@@ -459,9 +454,6 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             if (!b.allowed) p.allowed = nullptr;
         }
         const uint32_t* gate = bucketed ? ss.bpw.maxb : nullptr;
-        // a general batch with a timestamp per request on the range path: k_finish brings the column into sorted order
-        // (TCGPU_CARRY_NOW=0: the evaluation gathers it by request index, as on the LSD passes)
-        const bool carry = ranged && !uniform && e->carry_now && ss.carry != nullptr && (p.now != nullptr || (hin && hin->col[4] != nullptr));
         const uint64_t* sorted;
         const uint32_t* d_slot = b.slot;
         if (!hin && !b.n_segments) {
@@ -477,7 +469,6 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
             if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, ax, p, &d_slot));
             if (bucketed && !bucket_partition(e, ss, ax, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
-            const int64_t* carry_now = carry ? p.now : nullptr; // (a host batch's column has been staged by now: p.now is the device copy)
             const bool ride = e->stop_events && !e->prof_on; // `sorted` rides on the last pass's own completion signal
             // TC_B_OUTPUTS_IDLE: nothing enqueued earlier touches this call's `allowed` bytes, so they are preset here, on
             // the grouping stream, to what most decisions of a recent batch were, and the evaluation only stores the
@@ -491,7 +482,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
                 fill_value = *(volatile uint32_t*)e->fill_hint_host & 1u;
                 p.flags |= fill_value ? F_PREFILL1 : F_PREFILL0;
             }
-            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, ranged, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value, carry_now);
+            sorted = sort_by_slot(e, ss, ax, d_slot, n, true, ranged, gate, e->bp_skew, ride ? ss.sorted : nullptr, fill, fill_value);
             if (!ride) TC_HIP(e, hipEventRecord(ss.sorted, ax));
             TC_HIP(e, hipStreamWaitEvent(s, ss.sorted, 0));
             ss.grouped_aside = true;
@@ -500,10 +491,9 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // and every auxiliary sort was joined into `s` before its evaluation
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, s, p, &d_slot));
             if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, s, p, &d_slot));
-            const int64_t* carry_now = carry ? p.now : nullptr;
             ss.grouped_aside = false;
             if (bucketed && !bucket_partition(e, ss, s, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
-            sorted = sort_by_slot(e, ss, s, d_slot, n, false, ranged, gate, e->bp_skew, nullptr, nullptr, 0, carry_now);
+            sorted = sort_by_slot(e, ss, s, d_slot, n, false, ranged, gate, e->bp_skew);
         }
         if (bucketed) bucket_eval(e, ss, s, p, full);
         prof_begin_m(e, TC_STAGE_EVAL, s);
@@ -530,9 +520,8 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // (the evaluation is the last reader of the set: `consumed` rides on its completion signal)
             consumed_rides = e->stop_events && !e->prof_on;
             hipEvent_t stop = consumed_rides ? ss.consumed : nullptr;
-            const int64_t* now_sorted = carry ? ss.carry : nullptr;
-            if (full) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev, now_sorted);
-            else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev, now_sorted);
+            if (full) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
+            else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
             prof_end_m(e, s);
         }
         e->wait_before_sort = nullptr;

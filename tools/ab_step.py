@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 KNOBS = ("TCGPU_EVAL_LEAN", "TCGPU_STOP_EVENTS", "TCGPU_EVAL_ITEMS", "TCGPU_SORT_ITEMS_PIPED", "TCGPU_DEBUG_NO_DECISION_STORE",
-         "TCGPU_AUX_STREAMS", "TCGPU_PIPE_DEPTH", "TCGPU_AUX_PRIORITY", "TCGPU_PREFILL", "TCGPU_RANGE", "TCGPU_GENERAL_EARLIER", "TCGPU_CARRY_NOW")
+         "TCGPU_AUX_STREAMS", "TCGPU_PIPE_DEPTH", "TCGPU_AUX_PRIORITY", "TCGPU_PREFILL", "TCGPU_RANGE", "TCGPU_GENERAL_EARLIER")
 # "_idle": the batches carry TC_B_OUTPUTS_IDLE (a ring of 8 output arrays instead of one)
 CONFIGS = {
     "default": {"_idle": "1"},
@@ -27,8 +27,6 @@ CONFIGS = {
     "range0_again": {"_idle": "1", "TCGPU_RANGE": "0"},
     "items4": {"_idle": "1", "TCGPU_EVAL_ITEMS": "4"},        # lean evaluation, 1024 blocks of 1024 positions
     "items4_again": {"_idle": "1", "TCGPU_EVAL_ITEMS": "4"},
-    "no_carry": {"_idle": "1", "TCGPU_CARRY_NOW": "0"},           # (AB_GENERAL=1) timestamps gathered by the evaluation instead of carried by k_finish
-    "no_carry_again": {"_idle": "1", "TCGPU_CARRY_NOW": "0"},
     "no_earlier": {"_idle": "1", "TCGPU_GENERAL_EARLIER": "0"},   # (AB_GENERAL=1) k_eval_general without the earlier-state rule
     "no_earlier_again": {"_idle": "1", "TCGPU_GENERAL_EARLIER": "0"},
     "range_aux2": {"_idle": "1", "TCGPU_AUX_STREAMS": "2"},
