@@ -435,6 +435,7 @@ typedef struct tc_exchange_config {
     uint32_t* mail;            /* host memory shared by all ranks, zero at set-up: [world][ring][world][2] */
     int64_t* done;             /* ... [world] */
 } tc_exchange_config;
+/* (an exchange points into its engine: destroy it first.  A step may be routed at most 8 steps ahead of its post.) */
 int tc_exchange_create(tc_engine* e, const tc_exchange_config* c, tc_exchange** out);
 int tc_exchange_destroy(tc_exchange* x);
 int tc_exchange_route(tc_exchange* x, uint64_t step, const uint32_t* global_id, uint32_t n);

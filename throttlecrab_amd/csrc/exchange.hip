@@ -147,6 +147,8 @@ extern "C" int tc_exchange_route(tc_exchange* x, uint64_t step, const uint32_t* 
     TC_CHECK_POISON(e);
     if (n == 0 || n > x->seg_cap) return fail(e, TC_E_INVALID_ARG, "tc_exchange_route: a slice holds 1..seg_cap requests");
     if (step < x->next_route) return TC_E_OK;
+    // (a router's count block is reused every ROUTES steps: its counts must have been posted by then)
+    if (step >= x->next_post + tc_exchange::ROUTES) return fail(e, TC_E_INVALID_ARG, "tc_exchange_route: more than 8 steps ahead of tc_exchange_post");
     const uint32_t r = (uint32_t)(step % tc_exchange::ROUTES), k = (uint32_t)(step % x->ring);
     // flow control: a destination's inbox slot is free once it has evaluated step - ring
     const int64_t need = (int64_t)step - (int64_t)x->ring + 1;
