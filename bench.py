@@ -452,8 +452,8 @@ def keys_bench(a, dev):
         tr, src = pmc_traffic(dom, "string_keys" + ("_long" if long else ""), "wide", d["launches_per_batch"])
         r["whole_step_frac"] = alg / (dt / steps) / 1e9 / HBM_PEAK_GBS
         r["algorithmic_bytes_per_decision"] = alg / B
-        # kernels per batch: the key stage is ONE profiled stage of four launches (k_probe, k_claim_scan, k_bind, k_follow)
-        r["launches_per_batch"] = sum(st_["launches_per_batch"] * (4 if k_ == "hash" else 1) for k_, st_ in stages.items())
+        # kernels per batch: the key stage is ONE profiled stage of three launches (k_probe, k_bind, k_follow)
+        r["launches_per_batch"] = sum(st_["launches_per_batch"] * (3 if k_ == "hash" else 1) for k_, st_ in stages.items())
         # the dominant stage's kernels as ONE roofline entry (per-batch total of the stage: the key stage is several launches)
         r["roofline"] = roofline_entry(d["kernel"], d["per_batch_ms"], alg, 1e3 * dt / steps, tr,
                                        {"avg_ms": "HIP events, per-batch total of the stage's launches, pipelined profile steps "

@@ -22,8 +22,11 @@
 //   bound[cap]      u8 1 = slot has a key (the compact column the expiry sweep scans:
 //                   walking the 128-byte records would read 128x the bytes)
 //   free_slots[cap] stack of unbound slots, free_top = number of free slots
+//   pos_col[cap]    the ktab position of each bound slot's entry (KeyRec::pos as a column of its own: the sweep turns the
+//                   entries of ~1 M freed slots into tombstones, and a 4-byte column read in slot order costs a sixteenth of
+//                   one record line per key)
 //
-// Inserting inside a batch is a three-kernel protocol without spinning (a wave
+// Inserting inside a batch is a three-kernel protocol (k_probe, k_bind, k_follow) without spinning (a wave
 // cannot wait for its own lanes): k_probe claims an empty entry with the
 // REQUEST INDEX, duplicates of the same new key find that claim and compare
 // against the claimant's key bytes in the input arena; k_bind (claimants)
@@ -89,6 +92,7 @@ struct Table {
     unsigned long long* overflow_used; // bytes handed out in the current half
     uint32_t* overflow_half;           // 0 / 1
     uint32_t* free_slots;
+    uint32_t* pos_col;      // [capacity] KeyRec::pos again, as a compact column: what the sweep reads to find the entries of the slots it freed
     int* free_top;
     uint32_t* tombs;        // [TOMB_SHARDS] tombstones currently in ktab, as shards that sum to the count (wrap-around arithmetic)
     uint32_t* error_flag;   // != 0: a key could not be bound (no slot / no overflow space)
@@ -585,6 +589,7 @@ __device__ __forceinline__ uint32_t bind_claimant(const Table& t, const uint8_t*
         kr.hash = h;
         kr.len = len;
         kr.pos = pos;
+        t.pos_col[slot] = pos;
         t.bound[slot] = 1;
         Entry* en = &t.ktab[pos];
         uint64_t k0 = 0, k1 = 0;
@@ -609,50 +614,35 @@ __device__ __forceinline__ void release_claim(const Table& t, const uint32_t* __
     atomicExch(t.error_flag, 1u);
 }
 
-// claim_cnt[b] (claimants of k_probe's block b) -> claimants in the blocks before b; claim_cnt[n_blocks] = all of them.
-// One block: a batch has at most a few thousand probe blocks.
-static __global__ __launch_bounds__(1024) void k_claim_scan(uint32_t* __restrict__ claim_cnt, uint32_t n_blocks) {
-    __shared__ uint32_t s_w[16];
-    __shared__ uint32_t s_carry;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_blocks; base += 1024) {
-        const uint32_t j = base + threadIdx.x;
-        const uint32_t c = j < n_blocks ? claim_cnt[j] : 0u;
-        uint32_t v = c;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(v, off, 64);
-            if (lane >= off) v += o;
-        }
-        if (lane == 63) s_w[wave] = v;
-        __syncthreads();
-        uint32_t before = s_carry;
-        for (int k = 0; k < wave; ++k) before += s_w[k];
-        if (j < n_blocks) claim_cnt[j] = before + v - c;
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry = before + v;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) claim_cnt[n_blocks] = s_carry;
-}
-
 // claimants: take a slot, store the key, publish the binding.  Claimant number R of the batch (in request
-// order: k_probe left the number of claimants per block in claim_cnt[], k_claim_scan made them offsets) takes free_slots[top - 1 - R]; the
-// stack pointer itself moves once, in k_follow.  No atomics: one on a single address costs ~12 ns and
-// serialises (a per-wave pop was 197 us of a 225 us kernel, a per-1024-block pop still 12 us).
+// order) takes free_slots[top - 1 - R]: k_probe left the number of claimants per block in claim_cnt[], and a block here sums
+// the counts of the blocks before it itself -- 256 lanes over at most a few thousand words that sit in L2 (round 4: the
+// one-block k_claim_scan between the two kernels was 7-9 us and a launch on the key stage's chain).  The last block leaves
+// the batch's total behind the counts; the stack pointer itself moves once, in k_follow.  No atomics: one on a single
+// address costs ~12 ns and serialises (a per-wave pop was 197 us of a 225 us kernel, a per-1024-block pop still 12 us).
 static __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
                                                   const uint32_t* __restrict__ key_off, uint32_t n,
                                                   uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ state,
                                                   const uint32_t* __restrict__ aux, const uint64_t* __restrict__ hash_in,
-                                                  const uint32_t* __restrict__ claim_cnt) {
+                                                  uint32_t* __restrict__ claim_cnt) {
+    __shared__ uint32_t s_part[THREADS / 64];
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     const uint32_t st = i < n ? state[i] : ST_FOUND;
     const bool want = st == ST_CLAIMANT;
     uint32_t total = 0;
     const uint32_t rank = block_rank<THREADS>(want, total);
+    const bool last = blockIdx.x == gridDim.x - 1;
+    uint32_t before = 0;
+    if (total != 0u || last) { // (block-uniform)
+        uint32_t part = 0;
+        for (uint32_t j = threadIdx.x; j < blockIdx.x; j += THREADS) part += claim_cnt[j];
+        for (int off = 32; off > 0; off >>= 1) part += __shfl_down(part, off, 64);
+        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = part;
+        __syncthreads();
+        for (int w = 0; w < THREADS / 64; ++w) before += s_part[w];
+        if (last && threadIdx.x == 0) claim_cnt[gridDim.x] = before + total; // (k_follow)
+    }
     if (want) {
-        const uint32_t before = claim_cnt[blockIdx.x]; // claimants in the blocks before mine (k_claim_scan)
         const int top = *t.free_top; // moves in k_follow, not here
         slot_out[i] = bind_claimant(t, key_bytes, key_off, n, i, aux[i], hash_in[i], slot_out[i], top - 1 - (int)(before + rank));
     } else if (st == ST_NOSPACE) {
@@ -671,7 +661,7 @@ static __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t*
     if (i < n && state[i] == ST_FOLLOWER) slot_out[i] = slot_out[aux[i]];
     if (blockIdx.x == 0) {
         if (threadIdx.x == 0) {
-            const uint32_t total = claim_cnt[n_blocks]; // (k_claim_scan)
+            const uint32_t total = claim_cnt[n_blocks]; // (k_bind's last block)
             const int top = *t.free_top;
             const int got = top < 0 ? 0 : (top < (int)total ? top : (int)total);
             *t.free_top = top - got;
@@ -747,6 +737,7 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
             kr.hash = h;
             kr.len = len;
             kr.pos = (uint32_t)target;
+            t.pos_col[slot] = (uint32_t)target;
             t.bound[slot] = 1;
             Entry* en = &t.ktab[target];
             en->hash = h;
@@ -769,19 +760,18 @@ __device__ inline uint32_t find_or_bind_one(Table& t, const uint8_t* key, uint32
 // Overflow arena (keys longer than 48 bytes).  Space is handed out by a bump pointer and a swept key's bytes
 // are not given back one by one; instead the sweep compacts: once more than half of the current half is
 // handed out, every bound long key is copied into the other half (fresh bump pointer) and the halves swap.
-// Decided and done ON THE DEVICE (the asynchronous sweep never waits for the host); three near-empty
-// launches when nothing is due.  flag[0] = compact now, flag[1] = bytes handed out in the new half.
-static __global__ void k_overflow_decide(Table t, unsigned long long* __restrict__ flag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        flag[0] = *t.overflow_used > t.overflow_bytes / 2 ? 1ull : 0ull;
-        flag[1] = 0ull;
-    }
+// Decided and done ON THE DEVICE (the asynchronous sweep never waits for the host).
+// flag[0] = compact now, flag[1] = bytes handed out in the new half.
+// (the decision itself is taken by mk::k_sweep_decide, together with the rebuild's)
+__device__ __forceinline__ void overflow_decide(const Table& t, unsigned long long* __restrict__ flag) {
+    flag[0] = *t.overflow_used > t.overflow_bytes / 2 ? 1ull : 0ull;
+    flag[1] = 0ull;
 }
 // (one reservation per block and 2048 slots: a returning atomicAdd per copied key on the new half's cursor -- one
 // word -- serialised the kernel: 1.7 ms for the ~3 M long keys of the configs[4] stream)
 constexpr int COMPACT_ITEMS = 8;
-static __global__ __launch_bounds__(THREADS) void k_overflow_compact(Table t, unsigned long long* __restrict__ flag) {
-    if (flag[0] == 0ull) return;
+__device__ __forceinline__ void overflow_compact(const Table& t, unsigned long long* __restrict__ flag) {
+    if (flag[0] == 0ull) return; // (uniform over the grid)
     __shared__ uint32_t s_w[THREADS / 64];
     __shared__ unsigned long long s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -840,8 +830,8 @@ static __global__ __launch_bounds__(THREADS) void k_overflow_compact(Table t, un
         }
     }
 }
-static __global__ void k_overflow_swap(Table t, const unsigned long long* __restrict__ flag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0 && flag[0] != 0ull) {
+__device__ __forceinline__ void overflow_swap(const Table& t, const unsigned long long* __restrict__ flag) { // (one thread, the kernel after)
+    if (flag[0] != 0ull) {
         *t.overflow_used = flag[1];
         *t.overflow_half ^= 1u;
     }
@@ -849,19 +839,24 @@ static __global__ void k_overflow_swap(Table t, const unsigned long long* __rest
 
 // Rebuild (tombstones lengthen probe chains; inserts recycle the ones on their own chain, the rest stays): decided ON THE DEVICE so that
 // a sweep never waits for the host -- mk::k_sweep_decide latches "tombstones (with the keys just unbound) > 1/4 of the
-// table" into a flag word, k_rebuild_clear and k_reinsert do nothing unless it is set (near-empty launches when no
-// rebuild is due).
-static __global__ __launch_bounds__(THREADS) void k_rebuild_clear(Table t, const uint32_t* __restrict__ flag) {
-    if (*flag == 0u) return;
-    // 32-byte entries as two 16-byte stores per thread
-    ulonglong2* raw = reinterpret_cast<ulonglong2*>(t.ktab);
-    const uint64_t n16 = (t.nb_mask + 1) * 2;
-    for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * THREADS)
-        raw[i] = make_ulonglong2(0ull, 0ull);
+// table" into a flag word, the two kernels below do nothing unless it is set.
+// Two launches do the rare work behind a sweep, near-empty when nothing is due (round 4: they were five): k_table_clear_compact
+// clears the table for a rebuild and / or copies the long keys into the arena's other half (independent of each other);
+// k_table_reinsert flips the arena's halves and re-enters every bound slot into the cleared table.
+static __global__ __launch_bounds__(THREADS) void k_table_clear_compact(Table t, const uint32_t* __restrict__ flag, unsigned long long* __restrict__ oflag) {
+    if (*flag != 0u) {
+        // 32-byte entries as two 16-byte stores per thread
+        ulonglong2* raw = reinterpret_cast<ulonglong2*>(t.ktab);
+        const uint64_t n16 = (t.nb_mask + 1) * 2;
+        for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * THREADS)
+            raw[i] = make_ulonglong2(0ull, 0ull);
+    }
+    overflow_compact(t, oflag);
 }
 
 // re-enter every bound slot into the cleared table
-static __global__ __launch_bounds__(THREADS) void k_reinsert(Table t, const uint32_t* __restrict__ flag) {
+static __global__ __launch_bounds__(THREADS) void k_table_reinsert(Table t, const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ oflag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) overflow_swap(t, oflag); // (nothing below looks at the arena)
     if (*flag == 0u) return;
     if (blockIdx.x == 0 && threadIdx.x < TOMB_SHARDS) t.tombs[threadIdx.x] = 0u;
     for (uint32_t s = blockIdx.x * THREADS + threadIdx.x; s < t.capacity; s += gridDim.x * THREADS) {
@@ -883,6 +878,7 @@ static __global__ __launch_bounds__(THREADS) void k_reinsert(Table t, const uint
                 en->key[1] = k1;
                 en->w = meta | (unsigned long long)(s + 2u);
                 t.rec[s].pos = (uint32_t)pos;
+                t.pos_col[s] = (uint32_t)pos;
                 break;
             }
             pos = (pos + 1) & t.nb_mask;

@@ -12,15 +12,17 @@ int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_
         if (e->k_busy) TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
     }
     const dim3 grid(nblocks(n)), block(kt::THREADS);
+    bool carried = false;
     prof_begin(e, TC_STAGE_HASH, s);
     if (insert) {
         hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux,
                            e->k_hash, e->k_claim);
-        hipLaunchKernelGGL(kt::k_claim_scan, dim3(1), dim3(1024), 0, s, e->k_claim, grid.x);
         hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_hash,
                            e->k_claim);
-        hipLaunchKernelGGL(kt::k_follow, grid, block, 0, s, n, out_slot, e->k_state, e->k_aux, e->kt, e->k_claim, grid.x,
-                           e->counters + TC_CNT_KEYS_INSERTED);
+        // (the stage's completion event rides on its last kernel: an event record of its own is one more packet on the chain)
+        carried = !e->prof_on;
+        TC_LAUNCH(carried ? (on_key_stream ? e->k_done : e->m_done) : (hipEvent_t) nullptr, kt::k_follow, grid, block, 0, s, n, out_slot,
+                  e->k_state, e->k_aux, e->kt, e->k_claim, grid.x, e->counters + TC_CNT_KEYS_INSERTED);
     } else {
         hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state,
                            e->k_aux, e->k_hash, (uint32_t*)nullptr);
@@ -28,11 +30,11 @@ int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_
     prof_end(e, s);
     TC_HIP(e, hipGetLastError());
     if (on_key_stream) {
-        TC_HIP(e, hipEventRecord(e->k_done, s));
+        if (!carried) TC_HIP(e, hipEventRecord(e->k_done, s));
         e->k_busy = true;
         e->m_busy = false;
     } else {
-        TC_HIP(e, hipEventRecord(e->m_done, s));
+        if (!carried) TC_HIP(e, hipEventRecord(e->m_done, s));
         e->m_busy = true;
         e->k_busy = false;
     }
@@ -78,17 +80,15 @@ int rebuild_key_table_if_due(tc_engine* e) {
     kt::Table& t = e->kt;
     hipStream_t s = cur_stream(e);
     uint32_t* flag = t.error_flag + 1; // spare word of the table's misc block
-    const int* top_save = reinterpret_cast<const int*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 40); // (k_sweep_mark_top)
+    const int* top_save = reinterpret_cast<const int*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 48); // (k_sweep_mark_top)
     const dim3 grid(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block(kt::THREADS);
-    hipLaunchKernelGGL(mk::k_sweep_decide, dim3(1), dim3(64), 0, s, t, top_save, flag);
-    hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(2048), dim3(BLOCK), 0, s, t, top_save, (const uint32_t*)flag);
-    hipLaunchKernelGGL(kt::k_rebuild_clear, grid, block, 0, s, t, flag);
-    hipLaunchKernelGGL(kt::k_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, flag);
-    // ... and compact the overflow arena (keys longer than 48 bytes) once more than half of it is handed out
+    // ... and the overflow arena (keys longer than 112 bytes) is compacted once more than half of it is handed out
     unsigned long long* oflag = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 32);
-    hipLaunchKernelGGL(kt::k_overflow_decide, dim3(1), dim3(64), 0, s, t, oflag);
-    hipLaunchKernelGGL(kt::k_overflow_compact, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, oflag);
-    hipLaunchKernelGGL(kt::k_overflow_swap, dim3(1), dim3(64), 0, s, t, oflag);
+    hipLaunchKernelGGL(mk::k_sweep_decide, dim3(1), dim3(64), 0, s, t, top_save, flag, oflag);
+    hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(1024), dim3(BLOCK), 0, s, t, top_save, (const uint32_t*)flag);
+    hipLaunchKernelGGL(kt::k_table_clear_compact, grid, block, 0, s, t, (const uint32_t*)flag, oflag);
+    hipLaunchKernelGGL(kt::k_table_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, (const uint32_t*)flag,
+                       (const unsigned long long*)oflag);
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }

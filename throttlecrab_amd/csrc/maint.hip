@@ -70,10 +70,13 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
         TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
         e->k_busy = false;
     }
-    TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s));
-    TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), s));
+    if (!e->key_mode) {
+        TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s));
+        TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), s));
+    }
     if (e->key_mode) {
-        hipLaunchKernelGGL(k_sweep_mark_top, dim3(1), dim3(64), 0, s, e->kt, reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(e->kt.overflow_used) + 40));
+        hipLaunchKernelGGL(k_sweep_mark_top, dim3(1), dim3(64), 0, s, e->kt, reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(e->kt.overflow_used) + 48),
+                           scratch, e->counters + TC_CNT_LIVE_SLOTS);
         hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
                            e->cells, e->kt, now_ns, e->counters, scratch, e->denied);
     }

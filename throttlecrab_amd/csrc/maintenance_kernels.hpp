@@ -223,32 +223,49 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
     }
 }
 
-// A key-mode sweep in four steps (round 4): k_sweep_mark_top remembers where the free stack stood; k_sweep_keys vacates the
+// A key-mode sweep in four steps (round 4): k_sweep_mark_top remembers where the free stack stood (and zeroes the sweep's counters); k_sweep_keys vacates the
 // expired cells, unbinds their keys and pushes the slots; k_sweep_decide latches "the table will be rebuilt" (the tombstones it
 // has + the keys just unbound would fill more than 1/4 of it); k_sweep_tombstones then turns the unbound keys' entries into
 // tombstones -- one line read for the entry's position, one entry written, per key -- UNLESS the rebuild is due, which clears
 // the whole table and re-enters the bound keys anyway.  (The first sweep of configs[4] unbinds 9 M of 10.5 M keys: 9 M record
 // lines read and 9 M entries written only to be cleared by the rebuild that followed, a third of that sweep's 1 GB.)
-static __global__ void k_sweep_mark_top(kt::Table t, int* __restrict__ top_save) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) *top_save = *t.free_top;
+static __global__ void k_sweep_mark_top(kt::Table t, int* __restrict__ top_save, unsigned long long* __restrict__ removed_scratch,
+                                        unsigned long long* __restrict__ live_counter) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *top_save = *t.free_top;
+        *removed_scratch = 0ull; // (two memset launches before)
+        *live_counter = 0ull;
+    }
 }
-static __global__ void k_sweep_decide(kt::Table t, const int* __restrict__ top_save, uint32_t* __restrict__ flag) {
+static __global__ void k_sweep_decide(kt::Table t, const int* __restrict__ top_save, uint32_t* __restrict__ flag, unsigned long long* __restrict__ oflag) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         uint32_t tombs = 0; // (the shards wrap around individually; their sum is the count)
         for (uint32_t s = 0; s < kt::TOMB_SHARDS; ++s) tombs += t.tombs[s];
         const int freed = *t.free_top - *top_save;
         *flag = (uint64_t)tombs + (uint64_t)(freed > 0 ? freed : 0) > (t.nb_mask + 1) / 4 ? 1u : 0u;
+        kt::overflow_decide(t, oflag);
     }
 }
+// (four keys per thread in flight; the entry's position comes from the compact column, not from the key's 128-byte record;
+// the tombstone is a 4-byte store into the binding word's low half -- nobody reads a tombstone's tag: 72-100 -> ~20 us per
+// 1.2 M keys)
+constexpr int TOMB_ITEMS = 4;
 static __global__ __launch_bounds__(BLOCK) void k_sweep_tombstones(kt::Table t, const int* __restrict__ top_save, const uint32_t* __restrict__ flag) {
     if (*flag != 0u) return; // the rebuild that follows drops every entry of an unbound key by itself
     const int lo = *top_save, hi = *t.free_top;
     uint32_t mine = 0;
-    for (int k = lo + (int)(blockIdx.x * BLOCK + threadIdx.x); k < hi; k += (int)(gridDim.x * BLOCK)) {
-        const uint32_t slot = t.free_slots[k];
-        const uint32_t pos = t.rec[slot].pos;
-        t.ktab[pos].w = (t.ktab[pos].w & 0xFFFFFFFF00000000ull) | kt::VAL_TOMB;
-        ++mine;
+    for (int k0 = lo + (int)(blockIdx.x * BLOCK * TOMB_ITEMS + threadIdx.x); k0 < hi; k0 += (int)(gridDim.x * BLOCK * TOMB_ITEMS)) {
+        uint32_t slot[TOMB_ITEMS], pos[TOMB_ITEMS];
+#pragma unroll
+        for (int j = 0; j < TOMB_ITEMS; ++j) slot[j] = k0 + j * BLOCK < hi ? t.free_slots[k0 + j * BLOCK] : kt::NO_SLOT;
+#pragma unroll
+        for (int j = 0; j < TOMB_ITEMS; ++j) pos[j] = t.pos_col[slot[j] != kt::NO_SLOT ? slot[j] : 0u];
+#pragma unroll
+        for (int j = 0; j < TOMB_ITEMS; ++j)
+            if (slot[j] != kt::NO_SLOT) {
+                *reinterpret_cast<uint32_t*>(&t.ktab[pos[j]].w) = kt::VAL_TOMB; // (little-endian: the `val` half)
+                ++mine;
+            }
     }
     for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&t.tombs[(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % kt::TOMB_SHARDS], mine);

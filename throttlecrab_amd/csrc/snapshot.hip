@@ -13,7 +13,7 @@ struct SnapHeader {
     uint64_t payload_bytes; // everything after the header
     uint64_t checksum;      // FNV-1a 64 over the payload: a truncated, corrupt or foreign file is refused BEFORE the engine is touched
 };
-constexpr uint32_t SNAP_VERSION = 5; // 3: sharded tombstone count; 4: 128-byte key records, table of retired keys (denial counts); 5: 65 536 retired keys + statistics record
+constexpr uint32_t SNAP_VERSION = 6; // 3: sharded tombstone count; 4: 128-byte key records, table of retired keys (denial counts); 5: 65 536 retired keys + statistics record; 6: entry positions as a column
 // FNV-1a over 8-byte words of the byte stream (a byte-wise FNV over gigabytes of state would take seconds);
 // independent of how the stream is cut into pieces
 struct StreamSum {
@@ -65,6 +65,7 @@ std::vector<Section> snapshot_sections(tc_engine* e) {
         v.push_back({t.free_slots, (size_t)t.capacity * 4});
         v.push_back({t.overflow_used, 64}); // overflow_used | free_top | error_flag | overflow_half
         v.push_back({t.tombs, kt::TOMB_SHARDS * 4});
+        v.push_back({t.pos_col, (size_t)t.capacity * 4});
         if (e->retired) v.push_back({e->retired, ((size_t)kt::RETIRED_CAP + 1) * sizeof(kt::RetiredRec)});
     }
     return v;
