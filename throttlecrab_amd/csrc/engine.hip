@@ -277,10 +277,9 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     for (uint32_t si = 0; si < e->depth; ++si) TC_HIP(e, hipMalloc(&e->sets[si].k_slot, mb * 4));
     TC_HIP(e, hipEventCreateWithFlags(&e->k_done, hipEventDisableTiming));
     TC_HIP(e, hipEventCreateWithFlags(&e->m_done, hipEventDisableTiming));
-    TC_HIP(e, hipMalloc(&e->k_state, mb * 4));
+    TC_HIP(e, hipMalloc(&e->k_state, mb));
     TC_HIP(e, hipMalloc(&e->k_aux, mb * 4));
     TC_HIP(e, hipMalloc(&e->k_claim, ((size_t)nblocks(mb) + 1) * 4));
-    TC_HIP(e, hipMalloc(&e->k_hash, mb * 8));
     TC_HIP(e, hipMalloc(&e->k_stage_off, (mb + 1) * 4));
     TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
     e->key_mode = true;
@@ -435,7 +434,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
         if (ss.k_slot) (void)hipFree(ss.k_slot);
-    void* kptrs[] = {e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_hash, e->k_stage_bytes, e->k_stage_off};
+    void* kptrs[] = {e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_stage_bytes, e->k_stage_off};
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
     if (e->small_io) (void)hipHostFree(e->small_io);

@@ -230,9 +230,9 @@ struct tc_engine {
     kt::Table kt;
     void* kt_block = nullptr;        // one allocation backing every kt.* array
     kt::RetiredRec* retired = nullptr; // key mode + TC_CFG_TRACK_DENIED: denial counts of keys without a slot
-    uint32_t *k_slot = nullptr, *k_state = nullptr, *k_aux = nullptr; // max_batch each
-    uint32_t* k_claim = nullptr;     // keys first seen in the batch, per k_probe block
-    uint64_t* k_hash = nullptr;
+    uint32_t *k_slot = nullptr, *k_aux = nullptr; // max_batch each
+    uint8_t* k_state = nullptr;      // max_batch
+    uint32_t* k_claim = nullptr;     // keys first seen in the batch, per k_probe block (+ the batch's total behind them)
     // Key stages mutate the key table and share the scratch above, so they run one after another in
     // call order: on the key stream for TC_B_INPUTS_READY device batches (overlapping the grouping and
     // evaluation of earlier batches), else on the main stream; the two events hand the order across.

@@ -327,6 +327,18 @@ __device__ __forceinline__ uint64_t load_and_hash(const uint8_t* __restrict__ ke
     return hash_short(k0, k1, len);
 }
 
+// the hash of request i's key, exactly as probe_request computes it
+__device__ __forceinline__ uint64_t request_hash(const uint8_t* __restrict__ key_bytes, const uint32_t* __restrict__ key_off, uint32_t n, uint32_t i) {
+    const uint32_t off = key_off[i], len = key_off[i + 1] - off, arena = key_off[n];
+    if (len > ENTRY_KEY && len <= 8u * KEY_WORDS) {
+        uint64_t kw[KEY_WORDS];
+        load_words(key_bytes + off, len, (uint64_t)arena - off, kw);
+        return hash_words(kw, len);
+    }
+    uint64_t k0, k1;
+    return load_and_hash(key_bytes, off, len, arena, k0, k1);
+}
+
 // ---------------------------------------------------------------------------
 // probe: one lane per request.  INSERT: unseen keys claim an entry.
 // Request i of a batch of n: returns its state; `slot` (found: the slot; claimant of a long key: the
@@ -498,13 +510,12 @@ __device__ __forceinline__ void reserve_overflow(const Table& t, bool live, uint
     }
 }
 
-// outputs: slot_out[i], state[i], aux[i], hash_out[i] as probe_request leaves them; claim_cnt[block]
+// outputs: slot_out[i], state[i], aux[i] as probe_request leaves them; claim_cnt[block]
 template <bool INSERT>
 __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __restrict__ key_bytes,
                                                    const uint32_t* __restrict__ key_off, uint32_t n,
-                                                   uint32_t* __restrict__ slot_out, uint32_t* __restrict__ state,
-                                                   uint32_t* __restrict__ aux, uint64_t* __restrict__ hash_out,
-                                                   uint32_t* __restrict__ claim_cnt) {
+                                                   uint32_t* __restrict__ slot_out, uint8_t* __restrict__ state,
+                                                   uint32_t* __restrict__ aux, uint32_t* __restrict__ claim_cnt) {
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     uint32_t st = ST_MISSING;
     uint32_t slot = NO_SLOT, ax = 0;
@@ -515,10 +526,10 @@ __global__ __launch_bounds__(THREADS) void k_probe(Table t, const uint8_t* __res
     }
     if (INSERT) tombs_sub<THREADS>(t, recycled);
     if (INSERT) reserve_overflow<THREADS>(t, i < n, i < n ? key_off[i + 1] - key_off[i] : 0u, st, slot);
-    if (i < n) {
-        hash_out[i] = h;
+    if (i < n) { // (round 4: the hash is not handed on -- a claimant hashes its key again in k_bind, from words it loads anyway -- and the
+                 // state is a byte: 20 -> 9 MB of scratch columns per 1 Mi keys)
         slot_out[i] = slot;
-        state[i] = st;
+        state[i] = (uint8_t)st;
         aux[i] = ax;
     }
     if (INSERT) {
@@ -622,9 +633,8 @@ __device__ __forceinline__ void release_claim(const Table& t, const uint32_t* __
 // address costs ~12 ns and serialises (a per-wave pop was 197 us of a 225 us kernel, a per-1024-block pop still 12 us).
 static __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t* __restrict__ key_bytes,
                                                   const uint32_t* __restrict__ key_off, uint32_t n,
-                                                  uint32_t* __restrict__ slot_out, const uint32_t* __restrict__ state,
-                                                  const uint32_t* __restrict__ aux, const uint64_t* __restrict__ hash_in,
-                                                  uint32_t* __restrict__ claim_cnt) {
+                                                  uint32_t* __restrict__ slot_out, const uint8_t* __restrict__ state,
+                                                  const uint32_t* __restrict__ aux, uint32_t* __restrict__ claim_cnt) {
     __shared__ uint32_t s_part[THREADS / 64];
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;
     const uint32_t st = i < n ? state[i] : ST_FOUND;
@@ -644,9 +654,10 @@ static __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t*
     }
     if (want) {
         const int top = *t.free_top; // moves in k_follow, not here
-        slot_out[i] = bind_claimant(t, key_bytes, key_off, n, i, aux[i], hash_in[i], slot_out[i], top - 1 - (int)(before + rank));
+        slot_out[i] = bind_claimant(t, key_bytes, key_off, n, i, aux[i], request_hash(key_bytes, key_off, n, i), slot_out[i],
+                                    top - 1 - (int)(before + rank));
     } else if (st == ST_NOSPACE) {
-        release_claim(t, key_off, i, aux[i], hash_in[i]);
+        release_claim(t, key_off, i, aux[i], request_hash(key_bytes, key_off, n, i));
         slot_out[i] = NO_SLOT;
     }
 }
@@ -654,7 +665,7 @@ static __global__ __launch_bounds__(THREADS) void k_bind(Table t, const uint8_t*
 // duplicates of a key first seen in this batch take the claimant's slot; block 0 also moves the free
 // stack's pointer past the slots k_bind handed out and counts the insertions
 static __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t* __restrict__ slot_out,
-                                                    const uint32_t* __restrict__ state, const uint32_t* __restrict__ aux, Table t,
+                                                    const uint8_t* __restrict__ state, const uint32_t* __restrict__ aux, Table t,
                                                     const uint32_t* __restrict__ claim_cnt, uint32_t n_blocks,
                                                     unsigned long long* inserted_counter) {
     const uint32_t i = blockIdx.x * THREADS + threadIdx.x;

@@ -15,17 +15,17 @@ int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_
     bool carried = false;
     prof_begin(e, TC_STAGE_HASH, s);
     if (insert) {
-        hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux,
-                           e->k_hash, e->k_claim);
-        hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_hash,
-                           e->k_claim);
+        hipLaunchKernelGGL(kt::k_probe<true>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state, e->k_aux, e->k_claim);
+        hipLaunchKernelGGL(kt::k_bind, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, (const uint8_t*)e->k_state,
+                           (const uint32_t*)e->k_aux, e->k_claim);
         // (the stage's completion event rides on its last kernel: an event record of its own is one more packet on the chain)
         carried = !e->prof_on;
         TC_LAUNCH(carried ? (on_key_stream ? e->k_done : e->m_done) : (hipEvent_t) nullptr, kt::k_follow, grid, block, 0, s, n, out_slot,
-                  e->k_state, e->k_aux, e->kt, e->k_claim, grid.x, e->counters + TC_CNT_KEYS_INSERTED);
+                  (const uint8_t*)e->k_state, (const uint32_t*)e->k_aux, e->kt, (const uint32_t*)e->k_claim, grid.x,
+                  e->counters + TC_CNT_KEYS_INSERTED);
     } else {
         hipLaunchKernelGGL(kt::k_probe<false>, grid, block, 0, s, e->kt, d_bytes, d_off, n, out_slot, e->k_state,
-                           e->k_aux, e->k_hash, (uint32_t*)nullptr);
+                           e->k_aux, (uint32_t*)nullptr);
     }
     prof_end(e, s);
     TC_HIP(e, hipGetLastError());

@@ -127,29 +127,28 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
     // SWEEP_ITEMS slots per thread and round: their `bound` bytes, then their cells, are all requested before anything is
     // looked at, and the block ranks the slots it unbinds once per round (round 4: one slot per thread and two barriers per
     // 256 slots kept the sweep at 0.9 TB/s -- 180-200 us per sweep of an 11.5 M-slot table, a fifth of configs[4]'s step)
-    constexpr int SWEEP_ITEMS = 4;
+    // (later in round 4: eight slots, and the cells' expiry words are requested together with the `bound` bytes instead of
+    // behind them -- nearly every 128-byte line of the cells holds a bound slot anyway, and the second round trip per round was
+    // half of the kernel: 93 -> ~55 us)
+    constexpr int SWEEP_ITEMS = 8;
     __shared__ uint32_t s_cnt[BLOCK / 64];
     for (uint64_t base = first; base < last; base += (uint64_t)BLOCK * SWEEP_ITEMS) {
         uint8_t bnd[SWEEP_ITEMS];
-        Cell c[SWEEP_ITEMS];
+        uint64_t exp_[SWEEP_ITEMS];
         bool unbind[SWEEP_ITEMS];
 #pragma unroll
         for (int j = 0; j < SWEEP_ITEMS; ++j) {
             const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
             bnd[j] = i < last ? t.bound[i] : (uint8_t)0;
-        }
-#pragma unroll
-        for (int j = 0; j < SWEEP_ITEMS; ++j) {
-            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-            c[j] = cells[bnd[j] ? i : first]; // (unconditional: a load under a branch drains the earlier ones first)
+            exp_[j] = cells[i < last ? i : first].expiry;
         }
         uint32_t mine = 0;
 #pragma unroll
         for (int j = 0; j < SWEEP_ITEMS; ++j) {
             unbind[j] = false;
             if (bnd[j]) {
-                if (!(c[j].expiry > (uint64_t)now)) {
-                    if (c[j].expiry != 0) removed++; // the reference's map only ever held written entries
+                if (!(exp_[j] > (uint64_t)now)) {
+                    if (exp_[j] != 0) removed++; // the reference's map only ever held written entries
                     unbind[j] = true;
                     mine++;
                 } else {
