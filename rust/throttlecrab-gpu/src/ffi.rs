@@ -252,6 +252,7 @@ extern "C" {
     pub fn tc_debug_fail_copy(e: *mut tc_engine, nth: u32) -> c_int;
     pub fn tc_debug_break_wait(e: *mut tc_engine, on: u32) -> c_int;
     pub fn tc_debug_occupy(e: *mut tc_engine, cu_mask: *const u32, blocks: u32, lds_bytes: u32, microseconds: u64) -> c_int;
+    pub fn tc_debug_check_keys(e: *mut tc_engine, inconsistencies: *mut u64) -> c_int;
     pub fn tc_snapshot_save(e: *mut tc_engine, path: *const c_char) -> c_int;
     pub fn tc_snapshot_load(e: *mut tc_engine, path: *const c_char) -> c_int;
 }

@@ -55,6 +55,9 @@ def test_config4_at_spec_10m_keys(key_set):
             removed = eng.sweep_expired(now)
             assert removed == before - len(orc), (s, removed, before, len(orc))
             assert eng.counters()["live_slots"] == len(orc)
+            # entries, key records, position column and free stack agree (tc_debug_check_keys), after the rebuild (s == 3) and
+            # after a sweep that wrote tombstones
+            assert eng.debug_check_keys() == 0, s
             if s == 3:
                 assert removed > 8 * B  # the prefilled keys
         last_ids = ids
@@ -65,6 +68,7 @@ def test_config4_at_spec_10m_keys(key_set):
     for i in range(len(sample)):
         key = bytes(kb[ko[i]:ko[i + 1]])
         assert eng.get(key, t_end) == orc.get(key, t_end), key
+    assert eng.debug_check_keys() == 0
     eng.close()
 
 
@@ -96,6 +100,7 @@ def test_tombstones_are_recycled_and_failed_binds_do_not_pile_up():
     kb, ko = W.string_keys(np.arange(2 * 10**6, 2 * 10**6 + cap))
     ref = orc.batch_keys(kb, ko, 5, 10, 60, 1, T0 + 10**12 + 1)
     assert_same(eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=T0 + 10**12 + 1), ref, "refill")
+    assert eng.debug_check_keys() == 0
     eng.close()
 
 
@@ -121,4 +126,5 @@ def test_overflow_arena_is_reclaimed_by_the_sweep():
         orc.force_cleanup(now)
         assert eng.sweep_expired(now) == n
         assert eng.counters()["live_slots"] == len(orc) == 0
+        assert eng.debug_check_keys() == 0, gen
     eng.close()

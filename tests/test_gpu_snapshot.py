@@ -66,6 +66,7 @@ def test_snapshot_string_mode(tmp_path):
     a.snapshot_save(path)
     b = t.Engine(8192, 20000, key_mode=True)
     b.snapshot_load(path)
+    assert a.debug_check_keys() == 0 and b.debug_check_keys() == 0  # (the loaded table is consistent in itself, position column included)
     for i, (kb, ko) in enumerate(batches[3:]):
         now = T0 + (3 + i) * 10**9
         _same(a.rate_limit_batch_keys(kb, ko, max_burst=4, count_per_period=10, period=60, quantity=1, now_ns=now),
@@ -75,6 +76,7 @@ def test_snapshot_string_mode(tmp_path):
         assert a.get(k, t_end) == b.get(k, t_end) and a.lookup_slot(k) == b.lookup_slot(k), k
     assert a.counters() == b.counters()
     assert a.sweep_expired(T0 + 10**12) == b.sweep_expired(T0 + 10**12)
+    assert a.debug_check_keys() == 0 and b.debug_check_keys() == 0
     a.close()
     b.close()
 

@@ -108,6 +108,7 @@ SYMBOLS = {
     "tc_debug_fail_copy": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tc_debug_break_wait": (C.c_int, [C.c_void_p, C.c_uint32]),
     "tc_debug_occupy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
+    "tc_debug_check_keys": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_snapshot_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_snapshot_load": (C.c_int, [C.c_void_p, C.c_char_p]),

@@ -271,3 +271,30 @@ extern "C" int tc_top_denied_keys(tc_engine* e, uint32_t k, uint8_t* key_bytes, 
     *n_out = (uint32_t)all.size();
     return TC_E_OK;
 }
+
+extern "C" int tc_debug_check_keys(tc_engine* e, uint64_t* inconsistencies) {
+    if (!e || !inconsistencies) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "tc_debug_check_keys: engine was created without TC_CFG_KEY_MODE");
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_TRY(drain_key_work(e));
+    hipStream_t s = cur_stream(e);
+    unsigned long long* bad = nullptr;
+    TC_HIP(e, hipMalloc(&bad, 2 * sizeof(unsigned long long)));
+    unsigned long long host[2] = {0, 0};
+    int top = 0;
+    hipError_t rc = hipMemsetAsync(bad, 0, sizeof host, s);
+    if (rc == hipSuccess) {
+        hipLaunchKernelGGL(k_check_keys, dim3(2048), dim3(BLOCK), 0, s, e->kt, 0, bad);
+        hipLaunchKernelGGL(k_check_keys, dim3(2048), dim3(BLOCK), 0, s, e->kt, 1, bad);
+        rc = hipGetLastError();
+    }
+    if (rc == hipSuccess) rc = hipMemcpyAsync(host, bad, sizeof host, hipMemcpyDeviceToHost, s);
+    if (rc == hipSuccess) rc = hipMemcpyAsync(&top, e->kt.free_top, sizeof top, hipMemcpyDeviceToHost, s);
+    if (rc == hipSuccess) rc = hipStreamSynchronize(s);
+    (void)hipFree(bad);
+    TC_HIP(e, rc);
+    *inconsistencies = host[0] + (host[1] + (uint64_t)(top < 0 ? 0 : top) == e->capacity ? 0u : 1u);
+    return TC_E_OK;
+}
+

@@ -270,6 +270,45 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_tombstones(kt::Table t, 
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&t.tombs[(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % kt::TOMB_SHARDS], mine);
 }
 
+// tc_debug_check_keys: the table seen from the slots (pass 0) and from the entries (pass 1); bad[0] = inconsistencies,
+// bad[1] = bound slots
+static __global__ __launch_bounds__(BLOCK) void k_check_keys(kt::Table t, int pass, unsigned long long* __restrict__ bad) {
+    uint32_t wrong = 0, bound = 0;
+    if (pass == 0) {
+        for (uint64_t s = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; s < t.capacity; s += (uint64_t)gridDim.x * BLOCK) {
+            if (!t.bound[s]) continue;
+            ++bound;
+            const uint32_t pos = t.pos_col[s];
+            const kt::KeyRec& kr = t.rec[s];
+            if (kr.len == kt::NO_SLOT || kr.pos != pos || pos > t.nb_mask) {
+                ++wrong;
+                continue;
+            }
+            const kt::Entry& en = t.ktab[pos];
+            if ((uint32_t)en.w != (uint32_t)s + 2u || en.hash != kr.hash || (en.w & 0xFFFFFFFF00000000ull) != kt::entry_meta(kr.hash, kr.len)) ++wrong;
+        }
+    } else {
+        for (uint64_t p = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; p <= t.nb_mask; p += (uint64_t)gridDim.x * BLOCK) {
+            const uint32_t val = (uint32_t)t.ktab[p].w;
+            if (val == kt::VAL_EMPTY || val == kt::VAL_TOMB) continue;
+            if (val & kt::VAL_PENDING) {
+                ++wrong; // a claim nobody bound
+                continue;
+            }
+            const uint32_t s = val - 2u;
+            if (s >= t.capacity || !t.bound[s] || t.pos_col[s] != (uint32_t)p) ++wrong;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        wrong += __shfl_down(wrong, off, 64);
+        bound += __shfl_down(bound, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        if (wrong) atomicAdd(&bad[0], (unsigned long long)wrong);
+        if (bound) atomicAdd(&bad[1], (unsigned long long)bound);
+    }
+}
+
 // ---------------------------------------------------------------------------
 // top denied keys (metrics.rs:24-76 keeps a capped HashMap on the host; here the counts are
 // exact, one u32 per slot, and the top K are selected on demand: radix select of the K-th

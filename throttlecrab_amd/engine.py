@@ -111,6 +111,13 @@ class Engine:
             m = (C.c_uint32 * 8)(*[int(w) & 0xFFFFFFFF for w in cu_mask])
         self._check(self._lib.tc_debug_occupy(self._h, m, blocks, lds_bytes, microseconds))
 
+    def debug_check_keys(self) -> int:
+        """test hook (string keys): number of inconsistencies between the key table's entries, records, position column and free
+        stack (tc_debug_check_keys); 0 on a healthy table"""
+        v = C.c_uint64(0)
+        self._check(self._lib.tc_debug_check_keys(self._h, C.byref(v)))
+        return int(v.value)
+
     def selfcheck(self) -> int:
         v = C.c_uint64(0)
         self._check(self._lib.tc_selfcheck(self._h, C.byref(v)))
