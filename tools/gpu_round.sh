@@ -29,8 +29,8 @@ for C in $CONFIGS; do
     zipf_wide) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout wide --workload zipf"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     general_uniform_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     general_zipf_fixed) CMD="python $R/bench.py --profile-run --steps 20 --warmup 3 --layout fixed --workload general_zipf"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
-    string_keys) CMD="python $R/tools/profile_keys.py short 8" ;;
-    string_keys_long) CMD="python $R/tools/profile_keys.py long 8" ;;
+    string_keys) CMD="python $R/tools/profile_keys.py short 8"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
+    string_keys_long) CMD="python $R/tools/profile_keys.py long 8"; PMCENV="TCGPU_ASSUME_CONCURRENT=1" ;;
     *) echo "unknown config $C"; continue ;;
   esac
   cd /tmp
