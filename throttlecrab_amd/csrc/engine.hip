@@ -239,7 +239,8 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
         return at;
     };
     const size_t o_ktab = take(nb * sizeof(kt::Entry)), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(2 * overflow),
-                 o_free = take(cap * 4), o_misc = take(64), o_tombs = take(kt::TOMB_SHARDS * 4), o_pos = take(cap * 4);
+                 o_free = take(cap * 4), o_misc = take(64), o_tombs = take(kt::TOMB_SHARDS * 4), o_pos = take(cap * 4),
+                 o_swlist = take((cap + mk::SWEEP_GRID * BLOCK) * 4), o_swpart = take(3 * mk::SWEEP_GRID * 4), o_swoff = take(mk::SWEEP_GRID * 4);
     TC_HIP(e, hipMalloc(&e->kt_block, off));
     uint8_t* base = (uint8_t*)e->kt_block;
     TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * sizeof(kt::Entry), (hipStream_t)0));
@@ -259,6 +260,9 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     t.overflow_half = (uint32_t*)(base + o_misc + 24);
     // (+32, +40: the overflow compaction's flag words; +48: where the free stack stood when the sweep began)
     t.free_slots = (uint32_t*)(base + o_free);
+    e->sweep_work.list = (uint32_t*)(base + o_swlist); // (a block's stretch starts at its first slot; the last one's may reach past the capacity)
+    e->sweep_work.part = (uint32_t*)(base + o_swpart);
+    e->sweep_work.off = (uint32_t*)(base + o_swoff);
     t.pos_col = (uint32_t*)(base + o_pos);
     TC_HIP(e, hipMemsetAsync(t.pos_col, 0, cap * 4, (hipStream_t)0));
     t.capacity = (uint32_t)cap;

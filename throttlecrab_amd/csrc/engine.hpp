@@ -230,6 +230,7 @@ struct tc_engine {
     kt::Table kt;
     void* kt_block = nullptr;        // one allocation backing every kt.* array
     kt::RetiredRec* retired = nullptr; // key mode + TC_CFG_TRACK_DENIED: denial counts of keys without a slot
+    mk::SweepWork sweep_work{};                   // key-mode sweep: the unbound slots per block, counts, offsets
     uint32_t *k_slot = nullptr, *k_aux = nullptr; // max_batch each
     uint8_t* k_state = nullptr;      // max_batch
     uint32_t* k_claim = nullptr;     // keys first seen in the batch, per k_probe block (+ the batch's total behind them)
@@ -344,7 +345,7 @@ inline int stage_need(tc_engine* e, T*& p, size_t count) {
 int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert, uint32_t* out_slot, bool on_key_stream);
 int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n, const uint8_t** d_bytes, const uint32_t** d_off);
 int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint32_t* slot);
-int rebuild_key_table_if_due(tc_engine* e);
+int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_scratch);
 
 inline void prof_begin_m(tc_engine* e, int stage, hipStream_t s) {
     if (e->prof_markers) prof_begin(e, stage, s);

@@ -74,22 +74,27 @@ int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool inser
     return TC_E_OK;
 }
 
-// the table side of a key-mode sweep, behind k_sweep_keys on the engine's stream: decide whether the table is rebuilt (checked
-// on the device: tombstones + the keys just unbound > 1/4 of it), else turn the unbound keys' entries into tombstones
-int rebuild_key_table_if_due(tc_engine* e) {
+// a key-mode sweep on the engine's stream (maintenance_kernels.hpp: k_sweep_keys, k_sweep_decide, k_sweep_tombstones), then the
+// rare work: the table rebuilt once tombstones + the keys just unbound exceed 1/4 of it, the overflow arena (keys longer than
+// 112 bytes) compacted once more than half of it is handed out -- both decided on the device, near-empty launches otherwise
+int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_scratch) {
     kt::Table& t = e->kt;
     hipStream_t s = cur_stream(e);
     uint32_t* flag = t.error_flag + 1; // spare word of the table's misc block
-    const int* top_save = reinterpret_cast<const int*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 48); // (k_sweep_mark_top)
-    const dim3 grid(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block(kt::THREADS);
-    // ... and the overflow arena (keys longer than 112 bytes) is compacted once more than half of it is handed out
+    int* top_save = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 48);
     unsigned long long* oflag = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 32);
-    hipLaunchKernelGGL(mk::k_sweep_decide, dim3(1), dim3(64), 0, s, t, top_save, flag, oflag);
-    hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(1024), dim3(BLOCK), 0, s, t, top_save, (const uint32_t*)flag);
-    hipLaunchKernelGGL(kt::k_table_clear_compact, grid, block, 0, s, t, (const uint32_t*)flag, oflag);
-    hipLaunchKernelGGL(kt::k_table_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, (const uint32_t*)flag,
-                       (const unsigned long long*)oflag);
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(nblocks(e->capacity), mk::SWEEP_GRID);
+    const dim3 block(kt::THREADS);
+    hipLaunchKernelGGL(mk::k_sweep_keys, dim3(blocks), dim3(BLOCK), 0, s, e->cells, t, now_ns, e->sweep_work, e->denied);
+    hipLaunchKernelGGL(mk::k_sweep_decide, dim3(1), dim3(mk::DECIDE_THREADS), 0, s, t, e->sweep_work, blocks, top_save, flag, oflag,
+                       removed_scratch, e->counters);
+    hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(blocks), dim3(BLOCK), 0, s, t, e->sweep_work, (const int*)top_save, (const uint32_t*)flag);
+    hipLaunchKernelGGL(kt::k_table_clear_compact, dim3(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block, 0, s, t, (const uint32_t*)flag, oflag);
+    // (the sweep's completion event -- later key stages on the key stream wait for it -- rides on its last kernel)
+    TC_LAUNCH(e->m_done, kt::k_table_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, (const uint32_t*)flag,
+              (const unsigned long long*)oflag);
     TC_HIP(e, hipGetLastError());
+    e->m_busy = true;
     return TC_E_OK;
 }
 

@@ -70,30 +70,18 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
         TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
         e->k_busy = false;
     }
-    if (!e->key_mode) {
+    if (e->key_mode) {
+        TC_TRY(sweep_keys_device(e, now_ns, scratch)); // (records m_done: the sweep, and a rebuild, change the key table)
+    } else {
         TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s));
         TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), s));
-    }
-    if (e->key_mode) {
-        hipLaunchKernelGGL(k_sweep_mark_top, dim3(1), dim3(64), 0, s, e->kt, reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(e->kt.overflow_used) + 48),
-                           scratch, e->counters + TC_CNT_LIVE_SLOTS);
-        hipLaunchKernelGGL(k_sweep_keys, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
-                           e->cells, e->kt, now_ns, e->counters, scratch, e->denied);
-    }
-    else if (e->fixed)
-        hipLaunchKernelGGL(k_sweep_fixed, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s, e->tat8, e->rate_id,
-                           e->classes, (uint32_t)e->uniform_id, e->capacity, now_ns, e->counters, scratch);
-    else
-        hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
-                           e->cells, e->capacity, now_ns, e->counters, scratch);
-    TC_HIP(e, hipGetLastError());
-    if (e->key_mode) {
-        // tombstones lengthen probe chains: rebuild the table once they fill 1/4 of it
-        int rc = rebuild_key_table_if_due(e);
-        if (rc != TC_E_OK) return rc;
-        // the sweep (and a rebuild) changed the key table: later key stages on the key stream wait for it
-        TC_HIP(e, hipEventRecord(e->m_done, s));
-        e->m_busy = true;
+        if (e->fixed)
+            hipLaunchKernelGGL(k_sweep_fixed, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s, e->tat8, e->rate_id,
+                               e->classes, (uint32_t)e->uniform_id, e->capacity, now_ns, e->counters, scratch);
+        else
+            hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
+                               e->cells, e->capacity, now_ns, e->counters, scratch);
+        TC_HIP(e, hipGetLastError());
     }
     if (!removed) return TC_E_OK; // asynchronous: the count goes to TC_CNT_SWEPT
     unsigned long long r = 0;

@@ -101,35 +101,41 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restric
     }
 }
 
-// Key-mode sweep: same retain rule, and an expired (or never written) bound slot
-// also loses its key: tombstone in the hash table, slot back on the free stack.
-// Every block owns a contiguous range of slots, collects the slots it unbinds in
-// LDS and pushes them with ONE stack reservation per SWEEP_BUF slots (an atomic on
-// the stack top costs ~12 ns and serialises: one per 256 slots was most of the kernel).
-constexpr int SWEEP_BUF = 4096; // (>= 2 rounds of BLOCK * SWEEP_ITEMS slots)
-static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now,
-                                                      unsigned long long* counters, unsigned long long* removed_out,
+// Key-mode sweep: same retain rule, and an expired (or never written) bound slot also loses its key: slot back on the free
+// stack, tombstone in the hash table.  Three kernels without a single contended atomic (later in round 4: every block of the
+// old k_sweep_keys reserved its stretch of the free stack with a returning atomicAdd on the stack pointer and added to three
+// counters when it was done -- 2 048 blocks that finish together, ~12.8 ns per block on one word: a quarter of the kernel,
+// measured by its grid size, gpurun_out/r04_v51/sweepgrid.txt):
+//   k_sweep_keys        every block owns a contiguous range of slots; the slots it unbinds go into ITS stretch of a list that
+//                       is as long as the table (work.list[first ...]), its counts into work.part[]
+//   k_sweep_decide      one block: scans the blocks' counts (-> where each stretch goes on the free stack), moves the stack
+//                       pointer, sums the counters, latches "the table will be rebuilt" (the tombstones it has + the keys just
+//                       unbound would fill more than 1/4 of it) and the overflow arena's compaction
+//   k_sweep_tombstones  block b copies stretch b onto the stack and -- UNLESS the rebuild is due, which clears the whole table
+//                       and re-enters the bound keys anyway -- turns the unbound keys' entries into tombstones: four keys per
+//                       thread in flight, the entry's position from the compact column pos_col[] (not from the key's 128-byte
+//                       record), a 4-byte store into the binding word's low half (nobody reads a tombstone's tag).
+//                       (The first sweep of configs[4] unbinds 9 M of 10.5 M keys: 9 M entries written only to be cleared by the
+//                       rebuild that followed were a third of that sweep's 1 GB.)
+constexpr uint32_t SWEEP_GRID = 2048; // blocks of k_sweep_keys at most (work.part, work.off)
+struct SweepWork {
+    uint32_t* list; // [capacity]
+    uint32_t* part; // [3][SWEEP_GRID]: unbound, removed, live per block
+    uint32_t* off;  // [SWEEP_GRID]: unbound slots of the blocks before
+};
+__host__ __device__ __forceinline__ uint64_t sweep_per_block(uint64_t capacity, uint32_t blocks) {
+    return ((capacity + blocks - 1) / blocks + BLOCK - 1) / BLOCK * BLOCK;
+}
+
+static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now, SweepWork work,
                                                       uint32_t* __restrict__ denied) {
-    __shared__ uint32_t s_buf[SWEEP_BUF];
-    __shared__ int s_base;
     uint32_t removed = 0, live = 0, fill = 0; // fill is uniform over the block
-    const uint64_t per_block = (((uint64_t)t.capacity + gridDim.x - 1) / gridDim.x + BLOCK - 1) / BLOCK * BLOCK;
+    const uint64_t per_block = sweep_per_block(t.capacity, gridDim.x);
     const uint64_t first = (uint64_t)blockIdx.x * per_block;
     const uint64_t last = first + per_block < t.capacity ? first + per_block : t.capacity;
-    auto flush = [&]() {
-        if (threadIdx.x == 0) s_base = atomicAdd(t.free_top, (int)fill);
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < fill; j += BLOCK) t.free_slots[s_base + (int)j] = s_buf[j];
-        __syncthreads();
-        fill = 0;
-    };
-    uint32_t unbound_total = 0;
-    // SWEEP_ITEMS slots per thread and round: their `bound` bytes, then their cells, are all requested before anything is
-    // looked at, and the block ranks the slots it unbinds once per round (round 4: one slot per thread and two barriers per
-    // 256 slots kept the sweep at 0.9 TB/s -- 180-200 us per sweep of an 11.5 M-slot table, a fifth of configs[4]'s step)
-    // (later in round 4: eight slots, and the cells' expiry words are requested together with the `bound` bytes instead of
-    // behind them -- nearly every 128-byte line of the cells holds a bound slot anyway, and the second round trip per round was
-    // half of the kernel: 93 -> ~55 us)
+    uint32_t* __restrict__ mine_list = work.list + first;
+    // eight slots per thread and round: their `bound` bytes and their cells' expiry words are all requested before anything is
+    // looked at, and the block ranks the slots it unbinds once per round
     constexpr int SWEEP_ITEMS = 8;
     __shared__ uint32_t s_cnt[BLOCK / 64];
     for (uint64_t base = first; base < last; base += (uint64_t)BLOCK * SWEEP_ITEMS) {
@@ -170,7 +176,6 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
             if (w < wave) before += s_cnt[w];
             total += s_cnt[w];
         }
-        if (fill + total > (uint32_t)SWEEP_BUF) flush(); // (uniform over the block; SWEEP_BUF >= 2 rounds)
 #pragma unroll
         for (int j = 0; j < SWEEP_ITEMS; ++j) {
             if (!unbind[j]) continue;
@@ -189,15 +194,12 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
                     denied[i] = 0;
                 }
             }
-            s_buf[fill + before] = (uint32_t)i;
+            mine_list[fill + before] = (uint32_t)i; // (fill + before < the slots looked at so far <= per_block)
             ++before;
         }
         fill += total;
-        unbound_total += total;
-        __syncthreads(); // s_cnt is reused next round; flush() reads s_buf
+        __syncthreads(); // s_cnt is reused next round
     }
-    if (fill) flush();
-    (void)unbound_total;
     __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
         removed += __shfl_down(removed, off, 64);
@@ -214,60 +216,83 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
             r += s_r[w];
             l += s_l[w];
         }
-        if (r) {
-            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)r);
-            atomicAdd(removed_out, (unsigned long long)r);
-        }
-        if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
+        work.part[blockIdx.x] = fill;
+        work.part[SWEEP_GRID + blockIdx.x] = r;
+        work.part[2 * SWEEP_GRID + blockIdx.x] = l;
     }
 }
 
-// A key-mode sweep in four steps (round 4): k_sweep_mark_top remembers where the free stack stood (and zeroes the sweep's counters); k_sweep_keys vacates the
-// expired cells, unbinds their keys and pushes the slots; k_sweep_decide latches "the table will be rebuilt" (the tombstones it
-// has + the keys just unbound would fill more than 1/4 of it); k_sweep_tombstones then turns the unbound keys' entries into
-// tombstones -- one line read for the entry's position, one entry written, per key -- UNLESS the rebuild is due, which clears
-// the whole table and re-enters the bound keys anyway.  (The first sweep of configs[4] unbinds 9 M of 10.5 M keys: 9 M record
-// lines read and 9 M entries written only to be cleared by the rebuild that followed, a third of that sweep's 1 GB.)
-static __global__ void k_sweep_mark_top(kt::Table t, int* __restrict__ top_save, unsigned long long* __restrict__ removed_scratch,
-                                        unsigned long long* __restrict__ live_counter) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *top_save = *t.free_top;
-        *removed_scratch = 0ull; // (two memset launches before)
-        *live_counter = 0ull;
+constexpr int DECIDE_THREADS = 1024;
+static __global__ __launch_bounds__(DECIDE_THREADS) void k_sweep_decide(kt::Table t, SweepWork work, uint32_t blocks, int* __restrict__ top_save,
+                                                                        uint32_t* __restrict__ flag, unsigned long long* __restrict__ oflag,
+                                                                        unsigned long long* __restrict__ removed_out, unsigned long long* counters) {
+    static_assert(SWEEP_GRID == 2 * DECIDE_THREADS, "two blocks of k_sweep_keys per thread");
+    __shared__ uint32_t s_w[DECIDE_THREADS / 64][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t b0 = 2u * threadIdx.x, b1 = b0 + 1u;
+    const uint32_t c0 = b0 < blocks ? work.part[b0] : 0u, c1 = b1 < blocks ? work.part[b1] : 0u;
+    uint32_t removed = (b0 < blocks ? work.part[SWEEP_GRID + b0] : 0u) + (b1 < blocks ? work.part[SWEEP_GRID + b1] : 0u);
+    uint32_t live = (b0 < blocks ? work.part[2 * SWEEP_GRID + b0] : 0u) + (b1 < blocks ? work.part[2 * SWEEP_GRID + b1] : 0u);
+    uint32_t incl = c0 + c1;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
     }
-}
-static __global__ void k_sweep_decide(kt::Table t, const int* __restrict__ top_save, uint32_t* __restrict__ flag, unsigned long long* __restrict__ oflag) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (int off = 32; off > 0; off >>= 1) {
+        removed += __shfl_down(removed, off, 64);
+        live += __shfl_down(live, off, 64);
+    }
+    if (lane == 63) s_w[wave][0] = incl;
+    if (lane == 0) {
+        s_w[wave][1] = removed;
+        s_w[wave][2] = live;
+    }
+    __syncthreads();
+    uint32_t before = incl - (c0 + c1), total = 0, r = 0, l = 0;
+    for (int w = 0; w < DECIDE_THREADS / 64; ++w) {
+        if (w < wave) before += s_w[w][0];
+        total += s_w[w][0];
+        r += s_w[w][1];
+        l += s_w[w][2];
+    }
+    if (b0 < blocks) work.off[b0] = before;
+    if (b1 < blocks) work.off[b1] = before + c0;
+    if (threadIdx.x == 0) {
+        const int top = *t.free_top;
+        *top_save = top; // (k_sweep_tombstones pushes above it)
+        *t.free_top = top + (int)total;
         uint32_t tombs = 0; // (the shards wrap around individually; their sum is the count)
         for (uint32_t s = 0; s < kt::TOMB_SHARDS; ++s) tombs += t.tombs[s];
-        const int freed = *t.free_top - *top_save;
-        *flag = (uint64_t)tombs + (uint64_t)(freed > 0 ? freed : 0) > (t.nb_mask + 1) / 4 ? 1u : 0u;
+        *flag = (uint64_t)tombs + (uint64_t)total > (t.nb_mask + 1) / 4 ? 1u : 0u;
         kt::overflow_decide(t, oflag);
+        *removed_out = r;
+        counters[TC_CNT_SWEPT] += r;
+        counters[TC_CNT_LIVE_SLOTS] = l;
     }
 }
-// (four keys per thread in flight; the entry's position comes from the compact column, not from the key's 128-byte record;
-// the tombstone is a 4-byte store into the binding word's low half -- nobody reads a tombstone's tag: 72-100 -> ~20 us per
-// 1.2 M keys)
+
 constexpr int TOMB_ITEMS = 4;
-static __global__ __launch_bounds__(BLOCK) void k_sweep_tombstones(kt::Table t, const int* __restrict__ top_save, const uint32_t* __restrict__ flag) {
-    if (*flag != 0u) return; // the rebuild that follows drops every entry of an unbound key by itself
-    const int lo = *top_save, hi = *t.free_top;
-    uint32_t mine = 0;
-    for (int k0 = lo + (int)(blockIdx.x * BLOCK * TOMB_ITEMS + threadIdx.x); k0 < hi; k0 += (int)(gridDim.x * BLOCK * TOMB_ITEMS)) {
+static __global__ __launch_bounds__(BLOCK) void k_sweep_tombstones(kt::Table t, SweepWork work, const int* __restrict__ top_save,
+                                                                   const uint32_t* __restrict__ flag) {
+    const uint32_t cnt = work.part[blockIdx.x];
+    if (cnt == 0u) return;
+    const bool tomb = *flag == 0u; // (else: the rebuild that follows drops every entry of an unbound key by itself)
+    const uint32_t* __restrict__ src = work.list + (uint64_t)blockIdx.x * sweep_per_block(t.capacity, gridDim.x);
+    uint32_t* __restrict__ dst = t.free_slots + *top_save + work.off[blockIdx.x];
+    for (uint32_t k0 = threadIdx.x; k0 < cnt; k0 += BLOCK * TOMB_ITEMS) {
         uint32_t slot[TOMB_ITEMS], pos[TOMB_ITEMS];
 #pragma unroll
-        for (int j = 0; j < TOMB_ITEMS; ++j) slot[j] = k0 + j * BLOCK < hi ? t.free_slots[k0 + j * BLOCK] : kt::NO_SLOT;
+        for (int j = 0; j < TOMB_ITEMS; ++j) slot[j] = k0 + j * BLOCK < cnt ? src[k0 + j * BLOCK] : kt::NO_SLOT;
 #pragma unroll
-        for (int j = 0; j < TOMB_ITEMS; ++j) pos[j] = t.pos_col[slot[j] != kt::NO_SLOT ? slot[j] : 0u];
+        for (int j = 0; j < TOMB_ITEMS; ++j) pos[j] = tomb && slot[j] != kt::NO_SLOT ? t.pos_col[slot[j]] : 0u;
 #pragma unroll
         for (int j = 0; j < TOMB_ITEMS; ++j)
             if (slot[j] != kt::NO_SLOT) {
-                *reinterpret_cast<uint32_t*>(&t.ktab[pos[j]].w) = kt::VAL_TOMB; // (little-endian: the `val` half)
-                ++mine;
+                dst[k0 + j * BLOCK] = slot[j];
+                if (tomb) *reinterpret_cast<uint32_t*>(&t.ktab[pos[j]].w) = kt::VAL_TOMB; // (little-endian: the `val` half)
             }
     }
-    for (int off = 32; off > 0; off >>= 1) mine += __shfl_down(mine, off, 64);
-    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(&t.tombs[(blockIdx.x * (BLOCK / 64) + (threadIdx.x >> 6)) % kt::TOMB_SHARDS], mine);
+    if (tomb && threadIdx.x == 0) atomicAdd(&t.tombs[blockIdx.x % kt::TOMB_SHARDS], cnt);
 }
 
 // tc_debug_check_keys: the table seen from the slots (pass 0) and from the entries (pass 1); bad[0] = inconsistencies,
