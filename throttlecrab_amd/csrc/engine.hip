@@ -217,6 +217,7 @@ int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipMalloc(&e->pend_count, 2 * sizeof(uint32_t)));
     TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
+    TC_HIP(e, hipMalloc(&e->sweep_part, 3 * (size_t)SWEEP_GRID * sizeof(uint32_t)));
     TC_HIP(e, hipMalloc(&e->op_result, sizeof(StoreOpResult)));
     TC_HIP(e, hipMalloc(&e->one_result, sizeof(OneResult)));
     TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
@@ -240,7 +241,7 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     };
     const size_t o_ktab = take(nb * sizeof(kt::Entry)), o_rec = take(cap * sizeof(kt::KeyRec)), o_bound = take(cap), o_ovf = take(2 * overflow),
                  o_free = take(cap * 4), o_misc = take(64), o_tombs = take(kt::TOMB_SHARDS * 4), o_pos = take(cap * 4),
-                 o_swlist = take((cap + mk::SWEEP_GRID * BLOCK) * 4), o_swpart = take(3 * mk::SWEEP_GRID * 4), o_swoff = take(mk::SWEEP_GRID * 4);
+                 o_swlist = take((cap + mk::SWEEP_GRID * BLOCK) * 4), o_swoff = take(mk::SWEEP_GRID * 4);
     TC_HIP(e, hipMalloc(&e->kt_block, off));
     uint8_t* base = (uint8_t*)e->kt_block;
     TC_HIP(e, hipMemsetAsync(base + o_ktab, 0, nb * sizeof(kt::Entry), (hipStream_t)0));
@@ -261,7 +262,7 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     // (+32, +40: the overflow compaction's flag words; +48: where the free stack stood when the sweep began)
     t.free_slots = (uint32_t*)(base + o_free);
     e->sweep_work.list = (uint32_t*)(base + o_swlist); // (a block's stretch starts at its first slot; the last one's may reach past the capacity)
-    e->sweep_work.part = (uint32_t*)(base + o_swpart);
+    e->sweep_work.part = e->sweep_part;
     e->sweep_work.off = (uint32_t*)(base + o_swoff);
     t.pos_col = (uint32_t*)(base + o_pos);
     TC_HIP(e, hipMemsetAsync(t.pos_col, 0, cap * 4, (hipStream_t)0));
@@ -438,7 +439,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
         if (ss.k_slot) (void)hipFree(ss.k_slot);
-    void* kptrs[] = {e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_stage_bytes, e->k_stage_off};
+    void* kptrs[] = {e->sweep_part, e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_stage_bytes, e->k_stage_off};
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
     if (e->small_io) (void)hipHostFree(e->small_io);

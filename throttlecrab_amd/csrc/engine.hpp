@@ -230,7 +230,8 @@ struct tc_engine {
     kt::Table kt;
     void* kt_block = nullptr;        // one allocation backing every kt.* array
     kt::RetiredRec* retired = nullptr; // key mode + TC_CFG_TRACK_DENIED: denial counts of keys without a slot
-    mk::SweepWork sweep_work{};                   // key-mode sweep: the unbound slots per block, counts, offsets
+    uint32_t* sweep_part = nullptr;               // [3][SWEEP_GRID] per-block counts of a sweep (every mode)
+    mk::SweepWork sweep_work{};                   // key-mode sweep: the unbound slots per block, those counts, offsets
     uint32_t *k_slot = nullptr, *k_aux = nullptr; // max_batch each
     uint8_t* k_state = nullptr;      // max_batch
     uint32_t* k_claim = nullptr;     // keys first seen in the batch, per k_probe block (+ the batch's total behind them)

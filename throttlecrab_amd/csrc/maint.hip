@@ -73,14 +73,13 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     if (e->key_mode) {
         TC_TRY(sweep_keys_device(e, now_ns, scratch)); // (records m_done: the sweep, and a rebuild, change the key table)
     } else {
-        TC_HIP(e, hipMemsetAsync(scratch, 0, sizeof(unsigned long long), s));
-        TC_HIP(e, hipMemsetAsync(e->counters + TC_CNT_LIVE_SLOTS, 0, sizeof(unsigned long long), s));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(nblocks(e->capacity), SWEEP_GRID);
         if (e->fixed)
-            hipLaunchKernelGGL(k_sweep_fixed, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s, e->tat8, e->rate_id,
-                               e->classes, (uint32_t)e->uniform_id, e->capacity, now_ns, e->counters, scratch);
+            hipLaunchKernelGGL(k_sweep_fixed, dim3(blocks), dim3(BLOCK), 0, s, e->tat8, e->rate_id, e->classes, (uint32_t)e->uniform_id, e->capacity,
+                               now_ns, e->sweep_part);
         else
-            hipLaunchKernelGGL(k_sweep, dim3(std::min<uint64_t>(nblocks(e->capacity), 2048)), dim3(BLOCK), 0, s,
-                               e->cells, e->capacity, now_ns, e->counters, scratch);
+            hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(BLOCK), 0, s, e->cells, e->capacity, now_ns, e->sweep_part);
+        hipLaunchKernelGGL(k_sweep_fold, dim3(1), dim3(1024), 0, s, (const uint32_t*)e->sweep_part, blocks, scratch, e->counters);
         TC_HIP(e, hipGetLastError());
     }
     if (!removed) return TC_E_OK; // asynchronous: the count goes to TC_CNT_SWEPT

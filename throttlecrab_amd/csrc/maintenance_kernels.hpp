@@ -19,22 +19,11 @@ using tc::Cell;
 // ---------------------------------------------------------------------------
 // K4: expiry sweep == AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203)
 // ---------------------------------------------------------------------------
-static __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint64_t capacity, int64_t now,
-                                                 unsigned long long* counters, unsigned long long* removed_out) {
-    uint32_t removed = 0, live = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        Cell c = cells[i];
-        if (c.expiry != 0) {
-            if (!(c.expiry > (uint64_t)now)) { // retain(|exp| *exp > now)
-                c.tat = 0;
-                c.expiry = 0;
-                cells[i] = c;
-                removed++;
-            } else {
-                live++;
-            }
-        }
-    }
+// (later in round 4: four cells per thread in flight, and a block leaves its two counts in part[] for k_sweep_fold instead
+// of adding them to the counters itself -- 2 048 blocks that finish together on three words, ~12.8 ns each on one word)
+constexpr uint32_t SWEEP_GRID = 2048; // blocks of a sweep kernel at most
+constexpr int SWEEP_UNROLL = 4;
+__device__ __forceinline__ void sweep_block_counts(uint32_t removed, uint32_t live, uint32_t* __restrict__ part) {
     __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
     for (int off = 32; off > 0; off >>= 1) {
         removed += __shfl_down(removed, off, 64);
@@ -51,53 +40,87 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells
             r += s_r[w];
             l += s_l[w];
         }
-        if (r) {
-            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)r);
-            atomicAdd(removed_out, (unsigned long long)r);
-        }
-        if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
+        part[SWEEP_GRID + blockIdx.x] = r;
+        part[2 * SWEEP_GRID + blockIdx.x] = l;
     }
+}
+static __global__ __launch_bounds__(BLOCK) void k_sweep(Cell* __restrict__ cells, uint64_t capacity, int64_t now, uint32_t* __restrict__ part) {
+    uint32_t removed = 0, live = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < capacity; i0 += stride * SWEEP_UNROLL) {
+        uint64_t ex[SWEEP_UNROLL];
+#pragma unroll
+        for (int j = 0; j < SWEEP_UNROLL; ++j) ex[j] = i0 + j * stride < capacity ? cells[i0 + j * stride].expiry : 0ull;
+#pragma unroll
+        for (int j = 0; j < SWEEP_UNROLL; ++j) {
+            if (ex[j] == 0) continue;
+            if (!(ex[j] > (uint64_t)now)) { // retain(|exp| *exp > now)
+                Cell c;
+                c.tat = 0;
+                c.expiry = 0;
+                cells[i0 + j * stride] = c;
+                removed++;
+            } else {
+                live++;
+            }
+        }
+    }
+    sweep_block_counts(removed, live, part);
 }
 
 // TC_CFG_FIXED_PARAMS layout: expiry == tat + dvt of the key's plan (tc::fixed_cell); vacant == TAT_VACANT
 static __global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restrict__ tat8, const uint16_t* __restrict__ rate_id,
                                                        const tc::RateClass* __restrict__ classes, uint32_t uniform_class, uint64_t capacity,
-                                                       int64_t now, unsigned long long* counters, unsigned long long* removed_out) {
+                                                       int64_t now, uint32_t* __restrict__ part) {
     uint32_t removed = 0, live = 0;
     const int64_t dvt_all = classes[uniform_class].dvt;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < capacity; i += (uint64_t)gridDim.x * BLOCK) {
-        const int64_t t = tat8[i];
-        if (t != tc::TAT_VACANT) {
-            const int64_t dvt = uniform_class ? dvt_all : classes[rate_id[i]].dvt;
-            if (!(tc::fixed_cell(t, dvt).expiry > (uint64_t)now)) { // retain(|exp| *exp > now)
-                tat8[i] = tc::TAT_VACANT;
+    const uint64_t stride = (uint64_t)gridDim.x * BLOCK;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i0 < capacity; i0 += stride * SWEEP_UNROLL) {
+        int64_t tt[SWEEP_UNROLL];
+#pragma unroll
+        for (int j = 0; j < SWEEP_UNROLL; ++j) tt[j] = i0 + j * stride < capacity ? tat8[i0 + j * stride] : tc::TAT_VACANT;
+#pragma unroll
+        for (int j = 0; j < SWEEP_UNROLL; ++j) {
+            if (tt[j] == tc::TAT_VACANT) continue;
+            const int64_t dvt = uniform_class ? dvt_all : classes[rate_id[i0 + j * stride]].dvt;
+            if (!(tc::fixed_cell(tt[j], dvt).expiry > (uint64_t)now)) { // retain(|exp| *exp > now)
+                tat8[i0 + j * stride] = tc::TAT_VACANT;
                 removed++;
             } else {
                 live++;
             }
         }
     }
-    __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
+    sweep_block_counts(removed, live, part);
+}
+// the blocks' counts -> the counters (one block behind a slot-mode sweep; key mode: k_sweep_decide)
+static __global__ __launch_bounds__(1024) void k_sweep_fold(const uint32_t* __restrict__ part, uint32_t blocks, unsigned long long* __restrict__ removed_out,
+                                                            unsigned long long* counters) {
+    __shared__ uint32_t s_w[16][2];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t removed = 0, live = 0;
+    for (uint32_t b = threadIdx.x; b < blocks; b += 1024) {
+        removed += part[SWEEP_GRID + b];
+        live += part[2 * SWEEP_GRID + b];
+    }
     for (int off = 32; off > 0; off >>= 1) {
         removed += __shfl_down(removed, off, 64);
         live += __shfl_down(live, off, 64);
     }
-    if ((threadIdx.x & 63) == 0) {
-        s_r[threadIdx.x >> 6] = removed;
-        s_l[threadIdx.x >> 6] = live;
+    if (lane == 0) {
+        s_w[wave][0] = removed;
+        s_w[wave][1] = live;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t r = 0, l = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) {
-            r += s_r[w];
-            l += s_l[w];
+        for (int w = 0; w < 16; ++w) {
+            r += s_w[w][0];
+            l += s_w[w][1];
         }
-        if (r) {
-            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)r);
-            atomicAdd(removed_out, (unsigned long long)r);
-        }
-        if (l) atomicAdd(&counters[TC_CNT_LIVE_SLOTS], (unsigned long long)l);
+        *removed_out = r;
+        counters[TC_CNT_SWEPT] += r;
+        counters[TC_CNT_LIVE_SLOTS] = l;
     }
 }
 
@@ -117,7 +140,6 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_fixed(int64_t* __restric
 //                       record), a 4-byte store into the binding word's low half (nobody reads a tombstone's tag).
 //                       (The first sweep of configs[4] unbinds 9 M of 10.5 M keys: 9 M entries written only to be cleared by the
 //                       rebuild that followed were a third of that sweep's 1 GB.)
-constexpr uint32_t SWEEP_GRID = 2048; // blocks of k_sweep_keys at most (work.part, work.off)
 struct SweepWork {
     uint32_t* list; // [capacity]
     uint32_t* part; // [3][SWEEP_GRID]: unbound, removed, live per block
@@ -200,26 +222,8 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
         fill += total;
         __syncthreads(); // s_cnt is reused next round
     }
-    __shared__ uint32_t s_r[BLOCK / 64], s_l[BLOCK / 64];
-    for (int off = 32; off > 0; off >>= 1) {
-        removed += __shfl_down(removed, off, 64);
-        live += __shfl_down(live, off, 64);
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_r[threadIdx.x >> 6] = removed;
-        s_l[threadIdx.x >> 6] = live;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t r = 0, l = 0;
-        for (int w = 0; w < BLOCK / 64; ++w) {
-            r += s_r[w];
-            l += s_l[w];
-        }
-        work.part[blockIdx.x] = fill;
-        work.part[SWEEP_GRID + blockIdx.x] = r;
-        work.part[2 * SWEEP_GRID + blockIdx.x] = l;
-    }
+    sweep_block_counts(removed, live, work.part);
+    if (threadIdx.x == 0) work.part[blockIdx.x] = fill;
 }
 
 constexpr int DECIDE_THREADS = 1024;
