@@ -128,3 +128,40 @@ def test_overflow_arena_is_reclaimed_by_the_sweep():
         assert eng.counters()["live_slots"] == len(orc) == 0
         assert eng.debug_check_keys() == 0, gen
     eng.close()
+
+
+@pytest.mark.parametrize("cap", [257, 5000, 70001, 600_000])
+def test_sweep_cycles_at_odd_capacities(cap):
+    """The key-mode sweep in three kernels (k_sweep_keys: a stretch of the list per block; k_sweep_decide: one block scans the
+    blocks' counts; k_sweep_tombstones: pushes the stretches onto the free stack, writes the tombstones) at capacities that are
+    not multiples of anything: one block, a few, a ragged last one, the full grid of 2 048.  Six generations of keys, half of
+    each generation refreshed before the sweep so that every sweep unbinds some keys and keeps others; removed / live counts
+    and every result against the AdaptiveStore port, the table checked from both sides after every sweep."""
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    n = cap // 3
+    eng = _engine(cap, max(n, 256))
+    orc = O.AdaptiveOracle(capacity=2 * cap, created_ns=T0, auto_cleanup=False)
+    now = T0
+    for gen in range(6):
+        ids = np.arange(gen * n, (gen + 1) * n)
+        kb, ko = W.string_keys(ids)
+        ref = orc.batch_keys(kb, ko, 5, 10, 60, 1, now)
+        assert_same(eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=now), ref, f"gen {gen}")
+        # every second key of the generation is asked for again 50 s later: its entry lives 50 s longer than its neighbours'
+        kb2, ko2 = W.string_keys(ids[::2])
+        ref = orc.batch_keys(kb2, ko2, 5, 10, 60, 1, now + 50 * 10**9)
+        assert_same(eng.rate_limit_batch_keys(kb2, ko2, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=now + 50 * 10**9), ref, f"gen {gen} again")
+        now += 70 * 10**9  # the untouched half has expired, the refreshed half has not
+        before = len(orc)
+        orc.force_cleanup(now)
+        removed = eng.sweep_expired(now)
+        assert removed == before - len(orc) and removed > 0, (gen, removed, before, len(orc))
+        assert eng.counters()["live_slots"] == len(orc)
+        assert eng.debug_check_keys() == 0, gen
+    # the survivors of every generation still answer like the reference's
+    kb, ko = W.string_keys(np.arange(0, 6 * n, 7))
+    ref = orc.batch_keys(kb, ko, 5, 10, 60, 1, now + 1)
+    assert_same(eng.rate_limit_batch_keys(kb, ko, max_burst=5, count_per_period=10, period=60, quantity=1, now_ns=now + 1), ref, "survivors")
+    assert eng.debug_check_keys() == 0
+    eng.close()
