@@ -482,9 +482,9 @@ int tc_debug_break_wait(tc_engine* e, uint32_t on);
  * slower: tests/test_gpu_robustness.py runs them against fillers and checks results and watchdog.  Not for production use. */
 int tc_debug_occupy(tc_engine* e, const uint32_t* cu_mask, uint32_t blocks, uint32_t lds_bytes, uint64_t microseconds);
 /* Test hook (string keys): walks the key table both ways after draining the engine -- every bound slot must be reachable
- * through the entry its position column names (the entry binds that slot and carries the hash of the slot's key record;
- * record and column agree), every binding entry must name a bound slot that points back at it, no claim may be left
- * pending, and bound slots + free slots must add up to the capacity.  *inconsistencies = how many of these fail (0 on a
+ * through the entry its position column names (the entry binds that slot and carries the hash of the slot's key record),
+ * every binding entry must name a bound slot that points back at it, no claim may be left pending, and bound slots + free
+ * slots must add up to the capacity.  *inconsistencies = how many of these fail (0 on a
  * healthy table).  TC_E_UNSUPPORTED without TC_CFG_KEY_MODE.  Not for production use (two passes over the table). */
 int tc_debug_check_keys(tc_engine* e, uint64_t* inconsistencies);
 

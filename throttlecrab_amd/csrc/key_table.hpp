@@ -16,7 +16,7 @@
 //                   A key of up to 16 bytes ("user:123", "key_1234567") is therefore found and CONFIRMED
 //                   with one 32-byte access; longer keys are confirmed against their slot's KeyRec.
 //   rec[cap]        one 128-byte KeyRec per slot (ONE memory line): full hash, key length, position of the slot's
-//                   ktab entry (for unbinding) and the key bytes inline (<= 112 B; a longer key keeps an 8-byte
+//                   ktab entry at binding time and the key bytes inline (<= 112 B; a longer key keeps an 8-byte
 //                   offset into the overflow arena).  A confirm requests the length word and the key words of
 //                   the line together, so a hit on a 17..112-byte key costs the entry line + this line.
 //   bound[cap]      u8 1 = slot has a key (the compact column the expiry sweep scans:
@@ -60,7 +60,7 @@ struct __attribute__((aligned(32))) Entry {
 struct __attribute__((aligned(128))) KeyRec {
     uint64_t hash;
     uint32_t len; // NO_SLOT = slot not bound
-    uint32_t pos;
+    uint32_t pos; // the entry's position WHEN THE KEY WAS BOUND (a rebuild moves entries: Table::pos_col[] is the one that is kept current)
     uint8_t bytes[INLINE_KEY];
 };
 
@@ -913,8 +913,8 @@ static __global__ __launch_bounds__(THREADS) void k_table_reinsert(Table t, cons
                     en->key[0] = k0;
                     en->key[1] = k1;
                     en->w = meta | (unsigned long long)(s + 2u);
-                    t.rec[s].pos = (uint32_t)pos;
-                    t.pos_col[s] = (uint32_t)pos;
+                    t.pos_col[s] = (uint32_t)pos; // (KeyRec::pos stays what it was at binding: writing it dirtied every bound key's
+                                                  // record line, a quarter of the rebuild's 0.77 GB)
                     break;
                 }
                 pos = (pos + 1) & t.nb_mask;
