@@ -159,6 +159,7 @@ struct tc_engine {
     static constexpr uint32_t RANGE_HINTS = 8;       // looks at the hint the path goes by (the worst of them)
     uint32_t range_share[RANGE_HINTS] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t range_looks = 0;
+    uint32_t range_relook = 0; // in-order batches the range path turned down (every 32nd goes through the sort path, which writes a hint)
     uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting
     uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
     bool general_earlier = true;     // TCGPU_GENERAL_EARLIER=0: k_eval_general without the earlier-state rule (A/B)

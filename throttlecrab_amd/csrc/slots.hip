@@ -433,7 +433,16 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
         // (round 4: a batch the range path takes is grouped by it alone, in order as well: two grouping launches and the
         // evaluation, nothing enqueued twice)
         const bool ranged = range_applies(e, n, piped);
-        bool eligible = !ranged && direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
+        // The range hint is written by the grouping kernels of the sort paths (k_hist's range row, k_finish).  An in-order batch
+        // on the bucket path leaves none: an engine that only ever sees in-order batches would stay on the bucket path for
+        // good -- 84 us per 1 Mi batch where the range path takes 63, found by tools/batch_sizes.py; bench.py's in-order
+        // figures had pipelined batches before them -- and a stream that turns uniform would never be noticed.  So the first
+        // in-order batch of an engine, and every 32nd that the range path turned down, is grouped by the sort path alone,
+        // which looks.
+        bool look = false;
+        if (!ranged && !piped && e->range_ok && (e->range_mode >= 2) && n >= 256u && n <= e->range_max_n)
+            look = (*(volatile unsigned long long*)e->range_hint_host >> 32) == 0ull || (++e->range_relook & 31u) == 0u;
+        bool eligible = !ranged && !look && direct && e->bp_ok && n >= e->bp_min_n && n <= e->bp_max_n && !p.order && (!piped || e->bp_piped);
         if (eligible && e->bp_gate_host && e->bp_backoff_len) {
             const uint32_t seen = *(volatile uint32_t*)e->bp_gate_host;
             if (seen > e->bp_skew && e->bp_backoff == 0) {
