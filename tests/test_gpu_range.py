@@ -119,3 +119,53 @@ def test_slots_with_more_requests_than_a_byte_counter_holds():
         batches.append(s)
     _run(cap, batches, True, plan=(100, 1000, 3600))
     _run(cap, batches, True, general=True)
+
+
+def test_fresh_in_order_engine_reaches_the_range_path_and_leaves_it_again():
+    """The range hint is written by the grouping kernels of the sort paths; the bucket path, which in-order batches of 16 Ki
+    requests or more take when the range path turns them down, writes none.  An engine that is only ever handed in-order batches
+    (the ABI's default) therefore never got a hint and never left the bucket path.  Now its first batch, and every 32nd one the
+    range path turned down, is grouped by the sort path alone.  Here: which kernels a fresh engine's in-order batches run
+    (the engine's per-stage profile), uniform batches first, then skewed ones, then uniform again -- every batch exact."""
+    import torch
+
+    import throttlecrab_amd as t
+    cap, n, plan = 2_000_000, 1 << 16, (5, 50, 60)
+    eng = t.Engine(cap, n, fixed_params=True)
+    eng.use_torch_stream()
+    eng.register_params_uniform(*plan)
+    orc = _oracle(cap)
+    rng = np.random.default_rng(11)
+    step = [0]
+
+    def run(slots):
+        now = T0 + step[0] * 300_000_000
+        step[0] += 1
+        ref = orc.batch_slots(slots, *plan, 1, now)
+        res = eng.rate_limit_batch_slots(torch.from_numpy(slots.astype(np.int32)).cuda(), registered=True, quantity=1, now_ns=now,
+                                         want=("allowed", "remaining"))
+        torch.cuda.synchronize()
+        assert np.array_equal(res.allowed.cpu().numpy(), ref.allowed) and np.array_equal(res.remaining.cpu().numpy(), ref.remaining), step[0]
+
+    def stages(batches):
+        eng.profile_enable(True)
+        for b in batches:
+            run(b)
+        pr = {k: calls for k, (ms, calls) in eng.profile_read().items() if calls}
+        eng.profile_enable(False)
+        return pr
+
+    for _ in range(3):
+        run(_uniform(rng, cap, n))
+    pr = stages([_uniform(rng, cap, n) for _ in range(4)])
+    assert pr.get("sort") == 8 and not any(k.startswith("bucket") for k in pr), pr          # k_tile_ranges + k_finish per batch
+    for _ in range(10):   # a skewed stream: the worst of the last eight looks keeps it off the range path
+        run(_skewed(rng, cap, n))
+    pr = stages([_skewed(rng, cap, n) for _ in range(4)])
+    assert pr.get("sort", 0) != 8 or any(k.startswith("bucket") for k in pr), pr
+    for _ in range(80):   # uniform again: noticed within 32 batches (+ eight looks), although the bucket path writes no hint
+        run(_uniform(rng, cap, n))
+    pr = stages([_uniform(rng, cap, n) for _ in range(4)])
+    assert pr.get("sort") == 8 and not any(k.startswith("bucket") for k in pr), pr
+    assert eng.selfcheck() == 0
+    eng.close()
