@@ -316,3 +316,50 @@ def test_waiting_kernels_make_progress_beside_fillers(filler):
         assert np.array_equal(res.remaining.cpu().numpy(), ref.remaining), (filler, rnd)
     assert eng.selfcheck() == 0, "the spin watchdog fired"
     eng.close()
+
+
+def test_pipelined_batches_do_not_depend_on_what_the_process_did_before():
+    """Which hardware queue -- and which dispatch pipe -- a HIP stream lands on depends on everything the process created before.
+    With GPU work on the caller's stream BEFORE the engine creates its grouping streams (any real application; not bench.py),
+    the third grouping stream used to land on the main stream's pipe: its kernels were held back while an evaluation still
+    handed out blocks, and pipelined 1 Mi batches took 104 us instead of 42 -- slower than in order (64).  The engine now drops
+    candidates that collide with the main stream (k_probe_occupy / k_probe_stamp).  Here: after such work, pipelined batches
+    must beat in-order ones on a fresh engine each (a ratio, not a time: 0.66 when healthy, 1.6 when not), results exact."""
+    import time
+
+    import torch
+
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    N, B = 4_000_000, 1 << 20
+    dev = torch.device("cuda:0")
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        torch.zeros(1 << 20, device=dev).sum().item()   # the caller's stream takes its queue first
+        host = [W.uniform_slots(N, B, seed=2, start=i * B) for i in range(4)]
+        d = [torch.from_numpy(h.astype(np.int32)).to(dev) for h in host]
+        per = {}
+        for piped in (True, False):
+            eng = t.Engine(N, B, fixed_params=True)
+            eng.use_torch_stream()
+            eng.register_params_uniform(*W.REF_PARAMS)
+            outs = [t.BatchResult(allowed=torch.empty(B, dtype=torch.uint8, device=dev)) for _ in range(8)]
+            run = lambda i: eng.rate_limit_batch_slots(d[i % 4], registered=True, now_ns=W.T0_NS + i * 1000, want=("allowed",), out=outs[i % 8],
+                                                       inputs_ready=piped, outputs_idle=piped)
+            for i in range(12):
+                run(i)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(60):
+                run(12 + i)
+            torch.cuda.synchronize()
+            per[piped] = (time.perf_counter() - t0) / 60
+            if piped:   # the last batch's decisions against the oracle applying all 72 batches
+                orc = O.DenseOracle(N)
+                for i in range(72):
+                    ref = orc.batch_slots(host[i % 4], *W.REF_PARAMS, 1, W.T0_NS + i * 1000)
+                assert np.array_equal(outs[71 % 8].allowed.cpu().numpy(), ref.allowed)
+            assert eng.selfcheck() == 0
+            eng.close()
+    assert per[True] < 0.9 * per[False], per

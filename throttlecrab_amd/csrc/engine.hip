@@ -159,6 +159,8 @@ int engine_alloc(tc_engine* e) {
     e->n_aux_want = e->n_aux;
     e->aux_priority = aux_high ? prio_hi : prio_lo;
     TC_HIP(e, hipMalloc(&e->probe_ws, 2 * sizeof(uint32_t)));
+    TC_HIP(e, hipMalloc(&e->probe_stamps, 2 * sizeof(long long)));
+    if (const char* pp = getenv("TCGPU_PIPE_PROBE")) e->pipe_probe = atoi(pp) != 0;
     // (the grouping streams themselves are created by ensure_side_streams, against the actual main stream)
     for (uint32_t si = 0; si < e->depth; ++si) {
         tc_engine::SortSet& ss = e->sets[si];
@@ -307,11 +309,39 @@ static int streams_concurrent(tc_engine* e, hipStream_t a, hipStream_t b, bool* 
     return TC_E_OK;
 }
 
+// true if a kernel on `b` is held back while a kernel on `a` still hands out blocks (same dispatch pipe; see k_probe_occupy).
+// PIPE_REPS tries: the collision shows in some of them only.  ~50 us per try.
+static int streams_collide(tc_engine* e, hipStream_t a, hipStream_t b, bool* out) {
+    constexpr int PIPE_REPS = 10;
+    constexpr long long ROUND_TICKS = 800; // 8 us per round of blocks
+    hipDeviceProp_t prop;
+    TC_HIP(e, hipGetDeviceProperties(&prop, e->device));
+    const uint32_t resident = (uint32_t)std::max(1, prop.multiProcessorCount) * 8u; // 256-thread blocks the chip holds
+    long long* stamps = reinterpret_cast<long long*>(e->probe_stamps);
+    *out = false;
+    for (int rep = 0; rep < PIPE_REPS && !*out; ++rep) {
+        hipLaunchKernelGGL(k_probe_occupy, dim3(4 * resident), dim3(256), 0, a, ROUND_TICKS, stamps);
+        hipLaunchKernelGGL(k_probe_stamp, dim3(1), dim3(64), 0, b, stamps + 1);
+        TC_HIP(e, hipGetLastError());
+        TC_HIP(e, hipStreamSynchronize(a));
+        TC_HIP(e, hipStreamSynchronize(b));
+        long long h[2] = {0, 0};
+        TC_HIP(e, hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost));
+        // (the stamp normally lands one round after the start -- when the first blocks leave; behind a colliding kernel, four)
+        if (h[1] - h[0] > 5 * ROUND_TICKS / 2) *out = true;
+    }
+    return TC_E_OK;
+}
+
 // The grouping streams (and the key stream) must not share a hardware queue with the main stream or
 // with each other: two active streams on one queue serialise, which costs the pipeline half its
 // throughput.  Which queue a new stream lands on depends on everything the
 // process created before (torch, RCCL, other engines), so candidates are created and PROBED against
 // the main stream in use; the ones that do not run concurrently are dropped.  ~0.5 ms, once per main stream.
+// (Late in round 4: nor a dispatch pipe with the main stream.  With the process's streams created in another order than
+// bench.py's -- any GPU work on the caller's stream before the engine's first pipelined batch -- the third grouping stream
+// landed four queues behind the main stream, and pipelined batches took 104 us instead of 42: tools/batch_sizes.py BS_PRE=1,
+// tools/pipeprobe.hip.  Candidates that collide with the main stream are dropped like the ones that share its queue.)
 int ensure_side_streams(tc_engine* e) {
     hipStream_t m = cur_stream(e);
     if (e->side_ready && e->side_for == m) return TC_E_OK;
@@ -342,6 +372,11 @@ int ensure_side_streams(tc_engine* e) {
         if (assume) ok = true;
         else if (rc == TC_E_OK) rc = streams_concurrent(e, m, s, &ok);
         for (size_t g = 0; !assume && rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
+        if (!assume && rc == TC_E_OK && ok && e->pipe_probe) {
+            bool collide = false;
+            rc = streams_collide(e, m, s, &collide);
+            ok = !collide;
+        }
         if (rc != TC_E_OK) {
             if (s) (void)hipStreamDestroy(s);
             for (hipStream_t x : good) (void)hipStreamDestroy(x);
@@ -416,7 +451,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
-    void* ptrs[] = {e->route_ws, e->bp_park, e->cells, e->tat8, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
+    void* ptrs[] = {e->route_ws, e->bp_park, e->cells, e->tat8, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->probe_stamps, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
                     e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};

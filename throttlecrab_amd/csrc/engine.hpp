@@ -138,6 +138,8 @@ struct tc_engine {
     bool side_ready = false;
     int aux_priority = 0;
     uint32_t* probe_ws = nullptr;        // {flag, saw}
+    void* probe_stamps = nullptr;        // {start of k_probe_occupy, k_probe_stamp's clock}
+    bool pipe_probe = true;              // TCGPU_PIPE_PROBE=0: keep candidates that share a dispatch pipe with the main stream
     uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
     PendEntry* pend = nullptr;

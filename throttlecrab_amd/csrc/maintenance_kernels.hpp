@@ -458,6 +458,19 @@ static __global__ void k_probe_spin(uint32_t* flag, uint32_t* saw, long long tim
         __builtin_amdgcn_s_sleep(8);
     *saw = v;
 }
+// Two streams on different hardware queues can still share a dispatch PIPE: a kernel on the one then is not handed out while
+// a kernel on the other still has blocks to hand out (tools/pipeprobe.hip: with 8 queues, the stream created four after
+// another one; intermittently).  k_probe_occupy (a grid four times what the chip holds, every block staying `ticks`) stamps
+// its start; a one-block k_probe_stamp on the other stream stamps when it ran: one round of blocks later if the two do not
+// collide, four rounds later if they do.
+static __global__ void k_probe_occupy(long long ticks, long long* start) {
+    const long long t0 = wall_clock64();
+    if (blockIdx.x == 0 && threadIdx.x == 0) *start = t0;
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+static __global__ void k_probe_stamp(long long* out) {
+    if (threadIdx.x == 0) *out = wall_clock64();
+}
 static __global__ void k_probe_set(uint32_t* flag) {
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

@@ -17,7 +17,7 @@ import throttlecrab_amd as t  # noqa: E402
 from throttlecrab_amd import workload as W  # noqa: E402
 
 N_KEYS, MAXB = 10_000_000, 1 << 20
-SIZES = [256, 1024, 4096, 16384, 65536, 262144, 1 << 20]
+SIZES = [int(x) for x in os.environ["BS_SIZES"].split(",")] if os.environ.get("BS_SIZES") else [256, 1024, 4096, 16384, 65536, 262144, 1 << 20]
 dev = torch.device("cuda:0")
 stream = torch.cuda.Stream()
 print(f"{'batch':>9} | {'pipelined us':>12} {'G/s':>7} | {'in order us':>11} {'G/s':>7} | {'host sync us':>12} {'G/s':>7}")
@@ -25,7 +25,9 @@ with torch.cuda.stream(stream):
     for n in SIZES:
         steps = max(50, min(2000, (1 << 24) // n))
         row = []
-        for mode in ("piped", "inorder", "host"):
+        for mode in (os.environ["BS_MODES"].split(",") if os.environ.get("BS_MODES") else ("piped", "inorder", "host")):
+            if os.environ.get("BS_PRE"):  # (GPU work on torch's stream BEFORE the engine creates its streams)
+                torch.zeros(1 << 20, device=dev).sum().item()
             eng = t.Engine(N_KEYS, MAXB, fixed_params=True)
             eng.use_torch_stream()
             eng.register_params_uniform(*W.REF_PARAMS)
@@ -63,4 +65,6 @@ with torch.cuda.stream(stream):
                 print(f"   {mode} n={n}: " + ", ".join(f"{k} {1e3 * ms / calls:.1f} us x{calls / 20:.1f}" for k, (ms, calls) in pr.items() if calls))
             assert eng.selfcheck() == 0
             eng.close()
+        while len(row) < 3:
+            row.append((0.0, 0.0))
         print(f"{n:>9} | {row[0][0]:>12.1f} {row[0][1]:>7.3f} | {row[1][0]:>11.1f} {row[1][1]:>7.3f} | {row[2][0]:>12.1f} {row[2][1]:>7.3f}", flush=True)
