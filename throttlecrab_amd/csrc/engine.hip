@@ -360,7 +360,7 @@ int ensure_side_streams(tc_engine* e) {
     const uint32_t want = e->n_aux_want + (e->key_mode ? 1u : 0u);
     const char* as = getenv("TCGPU_ASSUME_CONCURRENT");
     const bool assume = as && atoi(as) != 0;
-    std::vector<hipStream_t> good, bad;
+    std::vector<hipStream_t> good, bad, soft;
     for (int c = 0; c < 16 && good.size() < want; ++c) {
         hipStream_t s = nullptr;
         int rc = TC_E_OK;
@@ -372,19 +372,36 @@ int ensure_side_streams(tc_engine* e) {
         if (assume) ok = true;
         else if (rc == TC_E_OK) rc = streams_concurrent(e, m, s, &ok);
         for (size_t g = 0; !assume && rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
+        bool second_best = false; // concurrent with everything, off the main stream's pipe, but on the pipe of a stream already kept
         if (!assume && rc == TC_E_OK && ok && e->pipe_probe) {
             bool collide = false;
             rc = streams_collide(e, m, s, &collide);
             ok = !collide;
+            for (size_t g = 0; rc == TC_E_OK && ok && !second_best && g < good.size(); ++g) {
+                rc = streams_collide(e, good[g], s, &collide);
+                second_best = collide;
+            }
         }
         if (rc != TC_E_OK) {
             if (s) (void)hipStreamDestroy(s);
             for (hipStream_t x : good) (void)hipStreamDestroy(x);
             for (hipStream_t x : bad) (void)hipStreamDestroy(x);
+            for (hipStream_t x : soft) (void)hipStreamDestroy(x);
             return rc;
         }
+        if (ok && second_best) soft.push_back(s);
+        else (ok ? good : bad).push_back(s);
+    }
+    // (four pipes: main + three streams of their own pipe each is what there is; whoever wants more takes the second best)
+    while (good.size() < want && !soft.empty()) {
+        hipStream_t s = soft.front();
+        soft.erase(soft.begin());
+        bool ok = true; // (streams kept after it were not probed against it)
+        for (size_t g = 0; ok && g < good.size(); ++g)
+            if (streams_concurrent(e, good[g], s, &ok) != TC_E_OK) ok = false;
         (ok ? good : bad).push_back(s);
     }
+    for (hipStream_t s : soft) (void)hipStreamDestroy(s);
     for (hipStream_t s : bad) (void)hipStreamDestroy(s);
     size_t gi = 0;
     if (e->key_mode && !good.empty()) e->key_stream = good[gi++];
