@@ -337,7 +337,7 @@ static int streams_collide(tc_engine* e, hipStream_t a, hipStream_t b, bool* out
 // with each other: two active streams on one queue serialise, which costs the pipeline half its
 // throughput.  Which queue a new stream lands on depends on everything the
 // process created before (torch, RCCL, other engines), so candidates are created and PROBED against
-// the main stream in use; the ones that do not run concurrently are dropped.  ~0.5 ms, once per main stream.
+// the main stream in use; the ones that do not run concurrently are dropped.  A few ms, once per main stream.
 // (Late in round 4: nor a dispatch pipe with the main stream.  With the process's streams created in another order than
 // bench.py's -- any GPU work on the caller's stream before the engine's first pipelined batch -- the third grouping stream
 // landed four queues behind the main stream, and pipelined batches took 104 us instead of 42: tools/batch_sizes.py BS_PRE=1,
