@@ -54,7 +54,7 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
         }
     }
     const uint32_t n = (uint32_t)r.n, tiles = (n + rt::TILE - 1) / rt::TILE;
-    const size_t words = (size_t)tiles * r.world + 4 + 2 * (size_t)rt::ONE_PASS_TILES;
+    const size_t words = 2 * (size_t)tiles * r.world + 4 + 2 * (size_t)rt::ONE_PASS_TILES; // (tile_cnt: u32, or the split router's u64 words)
     if (words > e->route_ws_words) {
         if (e->route_ws) {
             TC_HIP(e, hipDeviceSynchronize()); // (whatever streams earlier routers ran on)
@@ -102,6 +102,11 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
                                status, e->route_seq, r.out_slot, r.out_pos, viol);
         }
         hipLaunchKernelGGL(rt::k_route_scan, dim3(r.world), dim3(rt::THREADS), 0, s, w); // (the totals)
+    } else if (r.out_dst && r.only < 0 && tiles <= rt::ONE_PASS_TILES && !getenv("TCGPU_ROUTE_3PASS")) {
+        // every destination into its own buffer (the exchange): one pass as well
+        if (++e->route_seq == 0u) e->route_seq = 1u;
+        hipLaunchKernelGGL(rt::k_route_split_one, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w,
+                           reinterpret_cast<unsigned long long*>(w.tile_cnt), e->route_seq, split, e->counters + (TC_CNT_COUNT + 1) + 3);
     } else {
         hipLaunchKernelGGL(rt::k_route_count, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w);
         hipLaunchKernelGGL(rt::k_route_scan, dim3(r.world), dim3(rt::THREADS), 0, s, w);

@@ -318,6 +318,96 @@ __global__ __launch_bounds__(THREADS) void k_route_one(const uint32_t* __restric
         }
 }
 
+// ---------------------------------------------------------------------------
+// EVERY destination into a buffer of its own (the exchange: out_dst) in ONE pass over the ids -- count | scan | scatter were
+// three launches on the stream that also groups batches.  A request's place in its destination's buffer is the number of
+// requests for that destination in the tiles before + in the waves of this tile before + in this wave before: the first of
+// the three is a running sum per destination over the tiles.  Every tile publishes its `world` counts in tagged words (the
+// call's sequence number: nothing to clear) and sums the words of the tiles before it directly -- wave k takes destinations
+// k, k + 4, ..., its lanes the tiles, spinning on words that are not there yet (lower-numbered tiles only, which the
+// dispatcher started earlier; the watchdog as everywhere).  The last tile leaves the totals for k_route_publish.
+// status: [world][tiles] words of seq << 32 | count.
+// ---------------------------------------------------------------------------
+static __global__ __launch_bounds__(THREADS) void k_route_split_one(const uint32_t* __restrict__ id, uint32_t n, Map m, Work w,
+                                                             unsigned long long* __restrict__ status, uint32_t seq, SplitOut dst,
+                                                             unsigned long long* __restrict__ violations) {
+    __shared__ uint32_t s_wave[THREADS / 64][MAX_WORLD]; // per-wave counts -> exclusive prefix over the waves
+    __shared__ uint32_t s_before[MAX_WORLD];             // this destination's requests in the tiles before
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t tile = blockIdx.x, tiles = gridDim.x;
+    for (uint32_t i = threadIdx.x; i < (THREADS / 64) * MAX_WORLD; i += THREADS) (&s_wave[0][0])[i] = 0;
+    __syncthreads();
+    // wave-striped: step j of wave k covers requests tile*TILE + k*1024 + j*64 + lane (request order inside a wave)
+    const uint32_t first = tile * TILE + wave * (64 * ITEMS) + lane;
+    uint32_t dest[ITEMS], slot[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t pos = first + j * 64;
+        route_of(m, pos < n ? id[pos] : 0u, dest[j], slot[j]);
+        if (pos >= n) dest[j] = 0xFFFFFFFFu;
+    }
+    const unsigned long long lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        rank[j] = 0;
+        for (uint32_t d = 0; d < m.world; ++d) { // (wave-uniform loop: `world` ballots per step)
+            const unsigned long long mm = __ballot(dest[j] == d);
+            if (dest[j] == d) rank[j] = s_wave[wave][d] + (uint32_t)__popcll(mm & lt);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0 && mm) s_wave[wave][d] += (uint32_t)__popcll(mm);
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    __syncthreads();
+    const unsigned long long tagged = (unsigned long long)seq << 32;
+    if (threadIdx.x < m.world) {
+        uint32_t run = 0;
+        for (int k = 0; k < THREADS / 64; ++k) {
+            const uint32_t c = s_wave[k][threadIdx.x];
+            s_wave[k][threadIdx.x] = run;
+            run += c;
+        }
+        __hip_atomic_store(&status[(size_t)threadIdx.x * tiles + tile], tagged | run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_before[threadIdx.x] = run; // (this tile's own count for now: the last tile adds it to the sum below)
+    }
+    __syncthreads();
+    {
+        tc::SpinGuard guard;
+        bool gave_up = false;
+        for (uint32_t d = wave; d < m.world && !gave_up; d += THREADS / 64) {
+            const unsigned long long* row = status + (size_t)d * tiles;
+            uint32_t sum = 0;
+            for (uint32_t t0 = 0; t0 < tile && !gave_up; t0 += 64) {
+                const uint32_t t = t0 + lane;
+                unsigned long long sv = t < tile ? __hip_atomic_load(&row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : tagged;
+                while ((uint32_t)(sv >> 32) != seq) { // a tile dispatched before mine that has not counted yet
+                    if (tc::spin_expired(guard)) { // (flagged, never hung)
+                        tc::invariant_failed(violations);
+                        gave_up = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                    sv = __hip_atomic_load(&row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                gave_up = __any(gave_up);
+                sum += (uint32_t)sv;
+            }
+            for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+            if (lane == 0) {
+                const uint32_t own = s_before[d];
+                s_before[d] = sum;
+                if (tile == tiles - 1) __hip_atomic_store(&w.totals[d], sum + own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (k_route_publish)
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const uint32_t pos = first + j * 64, d = dest[j];
+        if (pos < n) dst.ptr[d][s_before[d] + s_wave[wave][d] + rank[j]] = slot[j];
+    }
+}
+
 // A caller that polls host memory instead of synchronising: behind the scatter on the same stream, the totals and,
 // after them, the caller's tag.  (A ticket taken by every tile of the scatter kernel -- "the last one publishes" --
 // cost 100 ns per tile: 2048 device-scope atomics on one word are 0.2 ms.)
