@@ -39,6 +39,17 @@ def test_device_partition_equals_host_mirror(world, n, passes, monkeypatch):
         assert np.array_equal(pos[at:at + len(want)], want), dest          # stable: request order
         assert np.array_equal(slots[at:at + len(want)], slot[want]), dest
         at += len(want)
+    # every destination into a buffer of its own (what the exchange does with the inboxes): one pass (k_route_split_one) /
+    # three kernels
+    bufs = [torch.full((n + 1,), -7, dtype=torch.int32, device="cuda") for _ in range(world)]
+    _, _, c3 = eng.route_batch(d, world, only=-1, out_dst=bufs)
+    torch.cuda.synchronize()
+    assert np.array_equal(c3.cpu().numpy(), counts)
+    for dest in range(world):
+        want = np.nonzero(owner == dest)[0]
+        got = bufs[dest].cpu().numpy()
+        assert np.array_equal(got[: len(want)].astype(np.uint32), slot[want]), dest   # stable: request order
+        assert (got[len(want):] == -7).all(), dest                                      # and nothing behind the segment
     # one destination only
     for dest in sorted({0, world - 1, world // 2}):
         s2, p2, c2 = eng.route_batch(d, world, only=dest, want_pos=True)
@@ -389,5 +400,33 @@ def test_routers_on_two_caller_streams_do_not_share_scratch_unordered():
         c = counts.cpu().numpy()
         assert np.array_equal(c, np.bincount(owner, minlength=world))
         assert np.array_equal(slots.cpu().numpy()[:c[only]].astype(np.uint32), slot[owner == only])
+    assert eng.selfcheck() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("n,world", [(1024 * 4096, 8), (1024 * 4096 + 1, 8), (1_500_000, 64), (2_000_003, 5)])
+def test_split_router_at_its_grid_limit(n, world):
+    """k_route_split_one takes grids of at most 1 024 tiles of 4 096 ids (the tagged count words of a call: [world][tiles]);
+    one id more and the three kernels take over.  Every destination's buffer against the host mirror."""
+    import torch
+    import throttlecrab_amd as t
+    from throttlecrab_amd import sharded
+    cap = 1_000_000
+    rng = np.random.default_rng(n % 1000 + world)
+    ids = rng.integers(0, min(world * cap, 2**31 - 1), n).astype(np.uint32)
+    owner, slot = sharded.route(ids, world, cap)
+    eng = t.Engine(cap, 1 << 16)
+    eng.use_torch_stream()
+    d = torch.from_numpy(ids.astype(np.int32)).cuda()
+    counts = np.bincount(owner, minlength=world)
+    bufs = [torch.full((int(counts[k]) + 1,), -7, dtype=torch.int32, device="cuda") for k in range(world)]
+    for rep in range(2):  # (twice: the words of the first call are still there, tagged with another sequence number)
+        _, _, c = eng.route_batch(d, world, only=-1, out_dst=bufs)
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy(), counts)
+        for dest in range(world):
+            got = bufs[dest].cpu().numpy()
+            assert np.array_equal(got[:-1].astype(np.uint32), slot[owner == dest]), (rep, dest)
+            assert got[-1] == -7
     assert eng.selfcheck() == 0
     eng.close()
