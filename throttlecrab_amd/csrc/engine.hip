@@ -310,9 +310,9 @@ static int streams_concurrent(tc_engine* e, hipStream_t a, hipStream_t b, bool* 
 }
 
 // true if a kernel on `b` is held back while a kernel on `a` still hands out blocks (same dispatch pipe; see k_probe_occupy).
-// PIPE_REPS tries: the collision shows in some of them only.  ~50 us per try.
+// PIPE_REPS tries: the collision shows in some of them only (one in five in tools/pipeprobe.hip).  ~50 us per try.
 static int streams_collide(tc_engine* e, hipStream_t a, hipStream_t b, bool* out) {
-    constexpr int PIPE_REPS = 10;
+    constexpr int PIPE_REPS = 16;
     constexpr long long ROUND_TICKS = 800; // 8 us per round of blocks
     hipDeviceProp_t prop;
     TC_HIP(e, hipGetDeviceProperties(&prop, e->device));
