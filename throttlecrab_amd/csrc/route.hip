@@ -90,6 +90,7 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     // one destination: count, offset and scatter in ONE pass over the ids for grids of at most ONE_PASS_TILES (tiles of 4096
     // or 8192 ids); every destination, or a bigger batch: count | scan | scatter
     const uint32_t tiles32 = (n + 2 * rt::TILE - 1) / (2 * rt::TILE);
+    bool published = false;
     if (r.only >= 0 && tiles32 <= rt::ONE_PASS_TILES && !getenv("TCGPU_ROUTE_3PASS")) {
         if (++e->route_seq == 0u) e->route_seq = 1u;
         unsigned long long* viol = e->counters + (TC_CNT_COUNT + 1) + 3;
@@ -101,7 +102,9 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
             hipLaunchKernelGGL((rt::k_route_one<2 * rt::ITEMS>), dim3(tiles32), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (uint32_t)r.only,
                                status, e->route_seq, r.out_slot, r.out_pos, viol);
         }
-        hipLaunchKernelGGL(rt::k_route_scan, dim3(r.world), dim3(rt::THREADS), 0, s, w); // (the totals)
+        // (the totals of every destination, and the host's copy + tag, in one launch)
+        hipLaunchKernelGGL(rt::k_route_totals, dim3(r.world), dim3(rt::THREADS), 0, s, w, r.world, scratch + e->route_ws_words - 2);
+        published = true;
     } else if (r.out_dst && r.only < 0 && tiles <= rt::ONE_PASS_TILES && !getenv("TCGPU_ROUTE_3PASS")) {
         // every destination into its own buffer (the exchange): one pass as well
         if (++e->route_seq == 0u) e->route_seq = 1u;
@@ -113,7 +116,7 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
         if (r.out_dst) hipLaunchKernelGGL(rt::k_route_scatter<true>, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos, split);
         else hipLaunchKernelGGL(rt::k_route_scatter<false>, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, (int)r.only, r.out_slot, r.out_pos, split);
     }
-    if (r.out_count_host) hipLaunchKernelGGL(rt::k_route_publish, dim3(1), dim3(rt::MAX_WORLD), 0, s, w, r.world);
+    if (r.out_count_host && !published) hipLaunchKernelGGL(rt::k_route_publish, dim3(1), dim3(rt::MAX_WORLD), 0, s, w, r.world);
     TC_HIP(e, hipGetLastError());
     if (lane == 0) {
         TC_HIP(e, hipEventRecord(e->route_l0_done, s));

@@ -408,6 +408,35 @@ static __global__ __launch_bounds__(THREADS) void k_route_split_one(const uint32
     }
 }
 
+// Behind the one-pass router of ONE destination: the totals of every destination (block d sums row d of the tile counts) and,
+// for a caller that polls host memory, the totals and then the tag -- written by whichever block is the last to finish
+// (`world` <= 64 arrivals on one word), so that the tag follows every total.  One launch where k_route_scan + k_route_publish
+// were two; the exclusive prefixes k_route_scan also leaves in tile_cnt are for k_route_scatter, which does not run here.
+static __global__ __launch_bounds__(THREADS) void k_route_totals(Work w, uint32_t world, uint32_t* __restrict__ arrivals) {
+    __shared__ uint32_t s_part[THREADS / 64];
+    const uint32_t* row = w.tile_cnt + (size_t)blockIdx.x * w.tiles;
+    uint32_t sum = 0;
+    for (uint32_t t = threadIdx.x; t < w.tiles; t += THREADS) sum += __hip_atomic_load(&row[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int k = 0; k < THREADS / 64; ++k) total += s_part[k];
+        __hip_atomic_store(&w.totals[blockIdx.x], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w.host_totals) {
+            w.host_totals[blockIdx.x] = total;
+            __threadfence_system();
+            const uint32_t before = __hip_atomic_fetch_add(arrivals, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            if (before + 1u == world) {
+                __hip_atomic_store(arrivals, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // (for the next call on this scratch)
+                w.host_totals[world] = w.tag;
+                __threadfence_system();
+            }
+        }
+    }
+}
+
 // A caller that polls host memory instead of synchronising: behind the scatter on the same stream, the totals and,
 // after them, the caller's tag.  (A ticket taken by every tile of the scatter kernel -- "the last one publishes" --
 // cost 100 ns per tile: 2048 device-scope atomics on one word are 0.2 ms.)
