@@ -773,9 +773,19 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     host_s = {"route": 0.0, "poll": 0.0, "evaluate": 0.0}   # where the host's time goes (diagnostics, stderr + detail)
     ROUTE_AHEAD = os.environ.get("TC_BENCH_ROUTE_AHEAD", "1") == "1"
 
+    # (diagnostics, one rank only: TC_BENCH_SKIP_ROUTER=1 hands the global batch to the engine as it is -- with one shard an id is
+    # its slot -- so that what the router costs a step can be told from what the rest of this path costs)
+    SKIP_ROUTER = world == 1 and os.environ.get("TC_BENCH_SKIP_ROUTER", "0") == "1"
+
     def route(i):
         r = i % RING
         t_ = time.perf_counter()
+        if SKIP_ROUTER:
+            ring[r] = (d_global[i % n_distinct], None, ring[r][2])
+            counts_host[r][rank] = G
+            counts_host[r][world] = i + 1
+            host_s["route"] += time.perf_counter() - t_
+            return
         eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r], ahead=ROUTE_AHEAD, host_counts=counts_host[r], tag=i + 1)
         host_s["route"] += time.perf_counter() - t_
 
