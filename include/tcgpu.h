@@ -221,7 +221,8 @@ enum {
     TC_CNT_SWEPT = 4,    /* entries removed by tc_sweep_expired */
     TC_CNT_BATCHES = 5,
     TC_CNT_KEYS_INSERTED = 6,
-    TC_CNT_LIVE_SLOTS = 7, /* occupied slots (refreshed by tc_sweep_expired) */
+    TC_CNT_LIVE_SLOTS = 7, /* the store's size, AdaptiveStore::len(): string mode -- the keys that hold a slot, exact in tc_counters();
+                            * slot mode (and the device-resident block) -- occupied slots as of the last tc_sweep_expired */
     TC_CNT_COUNT = 8
 };
 
@@ -275,6 +276,64 @@ int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, int64_t max_
  * expiry <= now.  Decision-neutral.  removed == NULL: the sweep is only enqueued on the
  * engine's stream (no host wait; the number removed is added to TC_CNT_SWEPT). */
 int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed);
+
+/* ---- self-cleaning: AdaptiveStore::maybe_clean_expired behind the engine's own calls -----------------------------------
+ * The reference's stores clean THEMSELVES: every compare_and_swap_with_ttl / set_if_not_exists_with_ttl first runs
+ * maybe_clean_expired (adaptive_cleanup.rs:205-211,229,262; periodic.rs:128-142; probabilistic.rs:110-125), so a
+ * `RateLimiter<AdaptiveStore>` never fills up with expired keys.  With a policy set, the engine does the same in front of
+ * every mutating call (tc_rate_limit, tc_rate_limit_batch_keys / _slots, tc_store_compare_and_swap_with_ttl,
+ * tc_store_set_if_not_exists_with_ttl): it counts the reference's operations (one per allowed request / store call), looks
+ * at the call's timestamp and at the store's size and, when the reference's should_clean would say yes, enqueues
+ * tc_sweep_expired at that timestamp in front of the call -- on the engine's stream, nothing waits.  A batch is one step:
+ * the trigger is evaluated once per call with the call's first timestamp, where the reference evaluates it per request.
+ * Cleanup never changes a decision while timestamps do not decrease, so results stay bit-exact.
+ * String mode adds what a fixed-size table needs where the reference's HashMap would grow:
+ *   - room: a key batch that might not find n free slots is preceded by a sweep (and, if the numbers the host holds are
+ *     older than that sweep, by one wait for fresh ones);
+ *   - retry: a SYNCHRONOUS call that still ran out of slots (TC_E_TABLE_FULL) sweeps at the newest timestamp of the call and
+ *     applies the rejected requests once more, in order, before it reports the error.
+ * Without a policy (the default of tc_engine_create) the engine never cleans by itself: tc_sweep_expired is the
+ * caller's.  The host mirrors (throttlecrab_gpu.hpp GpuStore, rust/throttlecrab-gpu) set TC_SWEEP_ADAPTIVE with the
+ * server's defaults (throttlecrab-server/src/config.rs:285-304) when they create their engine. */
+enum {
+    TC_SWEEP_NONE = 0,
+    TC_SWEEP_ADAPTIVE = 1,      /* adaptive_cleanup.rs:138-211 */
+    TC_SWEEP_PERIODIC = 2,      /* periodic.rs:128-142 */
+    TC_SWEEP_PROBABILISTIC = 3  /* probabilistic.rs:110-125 */
+};
+typedef struct tc_sweep_policy {
+    uint32_t struct_size;         /* = sizeof(tc_sweep_policy) */
+    uint32_t kind;                /* TC_SWEEP_* */
+    int64_t created_ns;           /* the store's creation time (`SystemTime::now()` in with_capacity): the first time-based
+                                   * cleanup is due one interval later (adaptive: 5 s, DEFAULT_CLEANUP_INTERVAL_SECS) */
+    int64_t min_interval_ns;      /* adaptive; 0 = 1 s (MIN_CLEANUP_INTERVAL_SECS; the server's default is 5 s) */
+    int64_t max_interval_ns;      /* adaptive; 0 = 300 s */
+    int64_t interval_ns;          /* periodic; 0 = 60 s */
+    uint64_t max_operations;      /* adaptive; 0 = 100 000 (MAX_OPERATIONS_BEFORE_CLEANUP; the server's default is 1 000 000) */
+    uint64_t map_capacity;        /* adaptive: the `capacity` of AdaptiveStore::with_capacity -- the memory-pressure trigger
+                                   * fires above 3/4 of 1.3 x this many entries; 0 = the engine's capacity / 1.3, i.e. the
+                                   * trigger fires when 3/4 of the engine's slots are taken */
+    uint64_t cleanup_probability; /* probabilistic; 0 = 1000 */
+} tc_sweep_policy;
+/* p == NULL or kind == TC_SWEEP_NONE: the engine stops cleaning by itself. */
+int tc_set_sweep_policy(tc_engine* e, const tc_sweep_policy* p);
+typedef struct tc_sweep_info {
+    uint32_t struct_size;          /* = sizeof(tc_sweep_info), set by the caller */
+    uint32_t kind;                 /* the policy in force */
+    uint64_t sweeps;               /* sweeps the engine started by itself since the policy was set ... */
+    uint64_t sweeps_by_time;       /* ... because the interval had passed (adaptive_cleanup.rs:140, periodic.rs:129) */
+    uint64_t sweeps_by_operations; /* ... the operation count (:145) or the probabilistic draw (probabilistic.rs:116) */
+    uint64_t sweeps_by_size;       /* ... the size of the store (:150-168) */
+    uint64_t sweeps_for_room;      /* ... a key batch that might not have found free slots */
+    uint64_t retries;              /* synchronous calls that ran out of slots, swept and applied the rejected requests again */
+    uint64_t feed_waits;           /* times a call waited for fresh numbers from the device (room checks only) */
+    uint64_t operations;           /* operations counted since the last cleanup */
+    uint64_t entries;              /* the store's size as the host last saw it (string mode: bound keys) */
+    uint64_t last_removed;         /* entries the last cleanup the host has heard of removed */
+    int64_t current_interval_ns;   /* adaptive: current_cleanup_interval */
+    int64_t next_cleanup_ns;       /* adaptive / periodic: next_cleanup */
+} tc_sweep_info;
+int tc_sweep_stats(tc_engine* e, tc_sweep_info* out);
 
 /* Copy the counter block to host (refreshes it first). */
 int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]);

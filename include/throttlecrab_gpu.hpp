@@ -68,13 +68,55 @@ struct Request {
     SystemTime now;
 };
 
+// WHEN the store cleans itself: the cadence of one of the reference's three stores (tcgpu.h: tc_set_sweep_policy).  The
+// reference's stores run maybe_clean_expired inside every compare_and_swap_with_ttl / set_if_not_exists_with_ttl
+// (adaptive_cleanup.rs:205-211,229,262); the engine does the same in front of its own mutating calls once a policy is set.
+struct CleanupPolicy {
+    uint32_t kind = TC_SWEEP_ADAPTIVE;
+    SystemTime created = std::chrono::time_point_cast<Duration>(std::chrono::system_clock::now()); // `SystemTime::now()` in with_capacity
+    Duration min_interval{0}, max_interval{0}; // adaptive (0: the reference's 1 s / 300 s)
+    Duration interval{0};                      // periodic (0: 60 s)
+    uint64_t max_operations = 0;               // adaptive (0: 100 000)
+    uint64_t map_capacity = 0;                 // adaptive: `capacity` of with_capacity (0: the engine's own table)
+    uint64_t cleanup_probability = 0;          // probabilistic (0: 1000)
+    // AdaptiveStore::with_capacity / builder defaults (adaptive_cleanup.rs:12-16)
+    static CleanupPolicy adaptive() { return CleanupPolicy{}; }
+    // the server's adaptive store (throttlecrab-server/src/config.rs:285-304: 5 s .. 300 s, 1 000 000 operations)
+    static CleanupPolicy server_defaults() {
+        CleanupPolicy p;
+        p.min_interval = std::chrono::seconds(5), p.max_interval = std::chrono::seconds(300), p.max_operations = 1000000;
+        return p;
+    }
+    static CleanupPolicy periodic(Duration every = std::chrono::seconds(60)) {
+        CleanupPolicy p;
+        p.kind = TC_SWEEP_PERIODIC, p.interval = every;
+        return p;
+    }
+    static CleanupPolicy probabilistic(uint64_t one_in = 1000) {
+        CleanupPolicy p;
+        p.kind = TC_SWEEP_PROBABILISTIC, p.cleanup_probability = one_in;
+        return p;
+    }
+    static CleanupPolicy none() { // the owner calls cleanup() itself
+        CleanupPolicy p;
+        p.kind = TC_SWEEP_NONE;
+        return p;
+    }
+    CleanupPolicy& created_at(SystemTime t) {
+        created = t;
+        return *this;
+    }
+};
+
 // The GPU-resident store; plays the role of AdaptiveStore (adaptive_cleanup.rs) and
 // implements the Store trait's three operations.
 class GpuStore {
   public:
     // AdaptiveStore::with_capacity (adaptive_cleanup.rs:93-106); max_batch bounds rate_limit_batch
     // track_denied: keep a denial counter per key for Metrics' top denied keys (metrics.rs:24-76)
-    explicit GpuStore(uint64_t capacity = 1000, uint64_t max_batch = 1 << 16, int device = 0, bool track_denied = false) {
+    // policy: the store cleans itself like AdaptiveStore by default (CleanupPolicy::none(): only when cleanup() is called)
+    explicit GpuStore(uint64_t capacity = 1000, uint64_t max_batch = 1 << 16, int device = 0, bool track_denied = false,
+                      const CleanupPolicy& policy = CleanupPolicy::adaptive()) {
         tc_config cfg{};
         cfg.struct_size = sizeof cfg;
         cfg.flags = TC_CFG_KEY_MODE | (track_denied ? TC_CFG_TRACK_DENIED : 0u);
@@ -85,6 +127,34 @@ class GpuStore {
         e_ = tc_engine_create(&cfg, &err);
         if (!e_) throw std::runtime_error("tc_engine_create failed: " + std::to_string(err));
         max_batch_ = max_batch;
+        try {
+            set_cleanup_policy(policy);
+        } catch (...) {
+            tc_engine_destroy(e_);
+            throw;
+        }
+    }
+    void set_cleanup_policy(const CleanupPolicy& p) {
+        tc_sweep_policy c{};
+        c.struct_size = sizeof c;
+        c.kind = p.kind;
+        c.created_ns = to_ns(p.created);
+        c.min_interval_ns = p.min_interval.count(), c.max_interval_ns = p.max_interval.count(), c.interval_ns = p.interval.count();
+        c.max_operations = p.max_operations, c.map_capacity = p.map_capacity, c.cleanup_probability = p.cleanup_probability;
+        check(tc_set_sweep_policy(e_, &c));
+    }
+    // what the store's own cleanups have done (sweeps by trigger, retries after a full table, the policy's state)
+    tc_sweep_info cleanup_stats() {
+        tc_sweep_info r{};
+        r.struct_size = sizeof r;
+        check(tc_sweep_stats(e_, &r));
+        return r;
+    }
+    // AdaptiveStore::len(): entries in the store, expired ones that no cleanup has removed yet included
+    uint64_t len() {
+        uint64_t c[TC_CNT_COUNT];
+        check(tc_counters(e_, c));
+        return c[TC_CNT_LIVE_SLOTS]; // (string mode: the keys that hold a slot right now)
     }
     GpuStore(const GpuStore&) = delete;
     GpuStore& operator=(const GpuStore&) = delete;
@@ -108,7 +178,7 @@ class GpuStore {
         check(tc_store_set_if_not_exists_with_ttl(e_, bytes(key), key.size(), value, (uint64_t)ttl.count(), to_ns(now), &ok));
         return ok != 0;
     }
-    // AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203), explicit instead of heuristic
+    // AdaptiveStore::cleanup (adaptive_cleanup.rs:173-203), called explicitly (the store also runs it by itself: CleanupPolicy)
     uint64_t cleanup(SystemTime now) {
         uint64_t removed = 0;
         check(tc_sweep_expired(e_, to_ns(now), &removed));

@@ -39,6 +39,12 @@ pub const TC_ROUTE_AHEAD: u32 = 0x1;
 pub const TC_ROUTE_NO_READERS: u32 = 0x2;
 pub const TC_X_NONBLOCKING: u32 = 0x1;
 
+// tc_sweep_policy.kind: which of the reference's stores the engine cleans like
+pub const TC_SWEEP_NONE: u32 = 0;
+pub const TC_SWEEP_ADAPTIVE: u32 = 1;
+pub const TC_SWEEP_PERIODIC: u32 = 2;
+pub const TC_SWEEP_PROBABILISTIC: u32 = 3;
+
 pub const TC_CNT_TOTAL: usize = 0;
 pub const TC_CNT_ALLOWED: usize = 1;
 pub const TC_CNT_DENIED: usize = 2;
@@ -58,6 +64,40 @@ pub struct tc_engine {
 #[repr(C)]
 pub struct tc_exchange {
     _private: [u8; 0],
+}
+
+/// tc_set_sweep_policy: maybe_clean_expired (adaptive_cleanup.rs:205-211) inside the engine's own mutating calls
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct tc_sweep_policy {
+    pub struct_size: u32,
+    pub kind: u32,
+    pub created_ns: i64,
+    pub min_interval_ns: i64,
+    pub max_interval_ns: i64,
+    pub interval_ns: i64,
+    pub max_operations: u64,
+    pub map_capacity: u64,
+    pub cleanup_probability: u64,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct tc_sweep_info {
+    pub struct_size: u32,
+    pub kind: u32,
+    pub sweeps: u64,
+    pub sweeps_by_time: u64,
+    pub sweeps_by_operations: u64,
+    pub sweeps_by_size: u64,
+    pub sweeps_for_room: u64,
+    pub retries: u64,
+    pub feed_waits: u64,
+    pub operations: u64,
+    pub entries: u64,
+    pub last_removed: u64,
+    pub current_interval_ns: i64,
+    pub next_cleanup_ns: i64,
 }
 
 #[repr(C)]
@@ -194,6 +234,8 @@ extern "C" {
         out: *mut tc_result,
     ) -> c_int;
     pub fn tc_sweep_expired(e: *mut tc_engine, now_ns: i64, removed: *mut u64) -> c_int;
+    pub fn tc_set_sweep_policy(e: *mut tc_engine, p: *const tc_sweep_policy) -> c_int;
+    pub fn tc_sweep_stats(e: *mut tc_engine, out: *mut tc_sweep_info) -> c_int;
     pub fn tc_counters(e: *mut tc_engine, out: *mut u64) -> c_int;
     pub fn tc_store_get(e: *mut tc_engine, key: *const u8, key_len: usize, now_ns: i64, value: *mut i64, found: *mut c_int) -> c_int;
     pub fn tc_store_compare_and_swap_with_ttl(

@@ -45,7 +45,41 @@ impl GpuStore {
         Self::new(capacity, 1 << 20, 0)
     }
 
+    /// The store cleans itself like `AdaptiveStore` (adaptive_cleanup.rs:138-211): the engine runs the reference's
+    /// `should_clean` in front of every mutating call and sweeps when it says so (tcgpu.h: tc_set_sweep_policy), so a
+    /// `RateLimiter<GpuStore>` does not fill up with expired keys.  Intervals and the operation limit are the server's
+    /// defaults (throttlecrab-server/src/config.rs:285-304); `with_sweep_policy` changes them, `TC_SWEEP_NONE` switches
+    /// the behaviour off (`cleanup` is then the owner's to call).
     pub fn new(capacity: usize, max_batch: usize, device_id: i32) -> Self {
+        let mut s = Self::new_without_policy(capacity, max_batch, device_id);
+        let p = ffi::tc_sweep_policy {
+            struct_size: std::mem::size_of::<ffi::tc_sweep_policy>() as u32,
+            kind: ffi::TC_SWEEP_ADAPTIVE,
+            created_ns: ns(SystemTime::now()).max(0),
+            min_interval_ns: 5_000_000_000,
+            max_interval_ns: 300_000_000_000,
+            interval_ns: 0,
+            max_operations: 1_000_000,
+            map_capacity: 0, // the engine's own table: clean when 3/4 of its slots are taken
+            cleanup_probability: 0,
+        };
+        s.with_sweep_policy(&p).expect("tc_set_sweep_policy");
+        s
+    }
+
+    pub fn with_sweep_policy(&mut self, p: &ffi::tc_sweep_policy) -> Result<(), String> {
+        let rc = unsafe { ffi::tc_set_sweep_policy(self.e, p) };
+        if rc == 0 { Ok(()) } else { Err(call_error(self.e, rc)) }
+    }
+
+    /// What the engine's own cleanups have done so far (sweeps by trigger, retries after a full table, the policy's state).
+    pub fn sweep_stats(&mut self) -> Result<ffi::tc_sweep_info, String> {
+        let mut out = ffi::tc_sweep_info { struct_size: std::mem::size_of::<ffi::tc_sweep_info>() as u32, ..Default::default() };
+        let rc = unsafe { ffi::tc_sweep_stats(self.e, &mut out) };
+        if rc == 0 { Ok(out) } else { Err(call_error(self.e, rc)) }
+    }
+
+    pub fn new_without_policy(capacity: usize, max_batch: usize, device_id: i32) -> Self {
         let cfg = ffi::tc_config {
             struct_size: std::mem::size_of::<ffi::tc_config>() as u32,
             flags: ffi::TC_CFG_KEY_MODE,
@@ -61,7 +95,7 @@ impl GpuStore {
         GpuStore { e, max_batch }
     }
 
-    /// `AdaptiveStore::cleanup` (adaptive_cleanup.rs:173-203), explicitly: the engine never cleans on its own.
+    /// `AdaptiveStore::cleanup` (adaptive_cleanup.rs:173-203), explicitly (the store also cleans by itself: see `new`).
     pub fn cleanup(&mut self, now: SystemTime) -> Result<u64, String> {
         let mut removed = 0u64;
         let rc = unsafe { ffi::tc_sweep_expired(self.e, ns(now), &mut removed) };
@@ -244,7 +278,8 @@ impl GpuRateLimiter {
             out.extend((0..n).map(|_| Err(CellError::Internal(msg.clone()))));
             return;
         }
-        // TC_E_TABLE_FULL: the keys that fit were applied, the others carry status Internal
+        // TC_E_TABLE_FULL: the keys that fit were applied, the others carry status Internal (with the store's cleanup policy
+        // on, the engine has already swept and applied them once more before it reports this: the table is full of LIVE keys)
         out.extend((0..n).map(|i| decode(&dec[i], burst[i], qty[i])));
     }
 }

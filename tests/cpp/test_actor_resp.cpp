@@ -280,7 +280,54 @@ static void test_throttle_many() {
     CHECK(allowed.load() == 10 * 20);
 }
 
+// the drop-in cleans itself.  A store of 4 096 slots behind the actor, 3 x that many distinct keys whose
+// entries live 0.1 s ((2, 10, 1 s)), stream time advancing one second per group: the reference's AdaptiveStore cleans inside
+// its own set_if_not_exists / compare_and_swap (adaptive_cleanup.rs:205-211,229,262) and never holds more than a few groups;
+// here the engine's policy (GpuStore's default: CleanupPolicy::adaptive) has to keep the fixed table from filling up.
+// Not one reply may be an internal error; groups go through the pipelined TC_B_ASYNC path (2 000 > 1 024 requests), the
+// single requests in between through the one-launch path and tc_rate_limit.
+static void test_store_cleans_itself_behind_the_actor() {
+    const size_t capacity = 4096, group = 2000, groups = 7; // 14 000 distinct keys = 3.4 x the table
+    GpuStore store(capacity, 1 << 12, 0, false, CleanupPolicy::adaptive().created_at(now0()));
+    auto limiter = std::make_shared<RateLimiter>(std::move(store));
+    RateLimiterHandle h = BasicRateLimiterActor<RateLimiter>::spawn(1 << 14, limiter, 1 << 12);
+    size_t serial = 0, allowed = 0;
+    for (size_t g = 0; g < groups; ++g) {
+        const SystemTime t = now0() + std::chrono::seconds(g);
+        std::vector<ThrottleRequest> reqs;
+        for (size_t i = 0; i < group; ++i) reqs.push_back(ThrottleRequest{"short:" + std::to_string(serial++), 2, 10, 1, 1, t + std::chrono::microseconds(i)});
+        for (auto& r : h.throttle_many(std::move(reqs))) {
+            CHECK(is_ok(r)); // "Rate limit check failed: internal error: ..." is what a full table would answer
+            allowed += std::get<0>(r).allowed;
+        }
+        for (int i = 0; i < 5; ++i) { // lightly loaded moments: single requests
+            auto r = h.throttle(ThrottleRequest{"short:" + std::to_string(serial++), 2, 10, 1, 1, t + std::chrono::milliseconds(500)});
+            CHECK(is_ok(r) && std::get<0>(r).allowed);
+        }
+    }
+    CHECK(allowed == groups * group); // every key was new
+    h = RateLimiterHandle();          // the actor exits; the limiter is ours again
+    const tc_sweep_info st = limiter->store().cleanup_stats();
+    CHECK(st.kind == TC_SWEEP_ADAPTIVE && st.sweeps >= 2 && st.retries == 0);
+    CHECK(limiter->store().len() <= capacity);
+    uint64_t c[TC_CNT_COUNT];
+    CHECK(tc_counters(limiter->store().handle(), c) == TC_E_OK && c[TC_CNT_ERRORS] == 0 && c[TC_CNT_ALLOWED] == groups * (group + 5));
+    // a store WITHOUT a policy runs full on the same stream: that is what the policy is for
+    RateLimiter bare(GpuStore(capacity, 1 << 12, 0, false, CleanupPolicy::none()));
+    size_t internal = 0;
+    serial = 0;
+    for (size_t g = 0; g < 3; ++g) {
+        std::vector<Request> reqs;
+        std::vector<std::string> keys;
+        for (size_t i = 0; i < group; ++i) keys.push_back("short:" + std::to_string(serial++));
+        for (size_t i = 0; i < group; ++i) reqs.push_back(Request{keys[i], 2, 10, 1, 1, now0() + std::chrono::seconds(g)});
+        for (auto& o : bare.rate_limit_batch(reqs)) internal += !throttlecrab::is_ok(o);
+    }
+    CHECK(internal == 3 * group - capacity);
+}
+
 int main() {
+    test_store_cleans_itself_behind_the_actor();
     test_pipelined_submit_collect();
     test_throttle_many();
     test_basic_rate_limiting();

@@ -1,0 +1,296 @@
+"""The drop-in cleans itself (round 5): AdaptiveStore::maybe_clean_expired runs inside every
+compare_and_swap_with_ttl / set_if_not_exists_with_ttl (adaptive_cleanup.rs:205-211,229,262), so a reference user never sees a
+store full of expired keys.  With tc_set_sweep_policy the engine does the same in front of its own mutating calls.  Here:
+the reference's cleanup tests (store/cleanup_test.rs:8-107, store/tests.rs:59-84) WITHOUT an explicit sweep, decisions that
+stay bit-exact while the engine sweeps on its own, a table a third the size of the key stream that never answers Internal,
+and the retry of a synchronous call that ran out of slots."""
+import numpy as np
+import pytest
+
+from tests import kat
+
+pytestmark = pytest.mark.gpu
+
+KAT = kat.load()
+T0 = KAT["t0_ns"]
+S = 10**9
+FIELDS = ("allowed", "limit", "remaining", "reset_after_ns", "retry_after_ns", "status")
+CLEANUP_CASES = [c for c in KAT["store_contract"] if c["source"].startswith("throttlecrab/src/core/store/cleanup_test.rs")
+                 or c["name"] == "memory_store_ttl"]
+
+
+def _engine(capacity, max_batch=1 << 16, key_mode=True, **kw):
+    import throttlecrab_amd as t
+    e = t.Engine(capacity, max_batch, key_mode=key_mode, **kw)
+    e.check_on_close = True
+    return e
+
+
+def _oracle(capacity=100000):
+    from oracle import oracle as O
+    return O.AdaptiveOracle(capacity=capacity, created_ns=T0, auto_cleanup=False)
+
+
+def assert_same(res, ref, ctx=""):
+    for f in FIELDS:
+        got = getattr(res, f)
+        if not isinstance(got, np.ndarray):
+            got = got.cpu().numpy()
+        exp = getattr(ref, f)
+        bad = np.nonzero(got.astype(np.int64) != exp.astype(np.int64))[0]
+        assert bad.size == 0, f"{ctx}: field {f} differs at {bad[:8]} got {got[bad[:8]]} want {exp[bad[:8]]}"
+
+
+class _SelfCleaningStore:
+    """the engine behind the reference's Store surface, with NO cleanup entry point: what cleans is the engine"""
+
+    def __init__(self, eng):
+        self.eng = eng
+        for name in ("get", "compare_and_swap_with_ttl", "set_if_not_exists_with_ttl"):
+            setattr(self, name, getattr(eng, name))
+
+    def live_count(self):  # AdaptiveStore::len()
+        return self.eng.counters()["live_slots"]
+
+
+@pytest.mark.parametrize("kind", ["periodic", "adaptive"])
+@pytest.mark.parametrize("case", CLEANUP_CASES, ids=[c["name"] for c in CLEANUP_CASES])
+def test_reference_cleanup_tests_without_an_explicit_sweep(case, kind):
+    """cleanup_test.rs drives a PeriodicStore (60 s); AdaptiveStore's first interval is 5 s: the operation at +61 s trips both"""
+    eng = _engine(2048, 64)
+    eng.set_sweep_policy(kind, created_ns=T0)
+    assert any(op[0] == "sweep" for op in case["ops"]) or case["name"] == "memory_store_ttl"
+    kat.replay_store_contract(case, _SelfCleaningStore(eng), T0, explicit_sweeps=False)
+    st = eng.sweep_stats()
+    assert st["kind"] == kind
+    if case["name"].startswith("cleanup_"):  # the trigger at +61 s cleaned, by time
+        assert st["sweeps"] == 1 and st["sweeps_by_time"] == 1, st
+    if case["name"] == "no_cleanup_without_triggers":
+        assert st["sweeps"] == 0, st
+    assert eng.debug_check_keys() == 0
+    eng.close()
+
+
+def test_policy_off_is_the_default_and_can_be_switched_back():
+    eng = _engine(256, 64)
+    assert eng.sweep_stats()["kind"] == "none"
+    for i in range(100):
+        assert eng.set_if_not_exists_with_ttl(b"k%d" % i, i, 1 * S, T0)
+    assert eng.set_if_not_exists_with_ttl(b"late", 1, 1 * S, T0 + 100 * S)
+    assert eng.counters()["live_slots"] == 101          # nobody cleaned
+    eng.set_sweep_policy("adaptive", created_ns=T0)
+    assert eng.set_if_not_exists_with_ttl(b"later", 1, 1 * S, T0 + 200 * S)
+    assert eng.counters()["live_slots"] == 1 and eng.sweep_stats()["sweeps_by_time"] == 1
+    eng.set_sweep_policy(None)
+    assert eng.set_if_not_exists_with_ttl(b"latest", 1, 1 * S, T0 + 900 * S)
+    assert eng.counters()["live_slots"] == 2 and eng.sweep_stats()["kind"] == "none"
+    eng.close()
+
+
+def test_adaptive_triggers_and_interval_adaptation():
+    """should_clean's operation-count trigger and cleanup()'s interval adaptation (adaptive_cleanup.rs:145,186-196) as the engine runs them"""
+    eng = _engine(4096, 64)
+    eng.set_sweep_policy("adaptive", created_ns=T0, max_operations=50, min_interval_ns=1 * S, max_interval_ns=20 * S)
+    st = eng.sweep_stats()
+    assert st["current_interval_ns"] == 5 * S and st["next_cleanup_ns"] == T0 + 5 * S
+    # 60 store operations inside the first interval: the 50th is counted, finds 50 and cleans (adaptive_cleanup.rs:206,145;
+    # nothing to remove: the interval doubles)
+    for i in range(60):
+        eng.set_if_not_exists_with_ttl(b"a%d" % i, i, 3600 * S, T0 + 1000 + i)
+    st = eng.sweep_stats()
+    assert st["sweeps"] == 1 and st["sweeps_by_operations"] == 1 and st["last_removed"] == 0, st
+    assert st["current_interval_ns"] == 10 * S, st
+    # rate_limit counts one operation per ALLOWED request: burst 2 -> two allowed, the rest denied
+    eng2 = _engine(4096, 64)
+    eng2.set_sweep_policy("adaptive", created_ns=T0, max_operations=1000)
+    for i in range(10):
+        eng2.rate_limit(b"one", 2, 10, 3600, 1, T0 + i)
+    eng2.rate_limit(b"two", 2, 10, 3600, 1, T0 + 100)
+    assert eng2.sweep_stats()["operations"] == 3, eng2.sweep_stats()
+    eng2.rate_limit(b"two", 2, 10, 3600, 1, T0 + 101)
+    assert eng2.sweep_stats()["operations"] == 4
+    eng2.rate_limit(b"two", 2, 10, 3600, 1, T0 + 102)              # denied: no store operation
+    assert eng2.sweep_stats()["operations"] == 4
+    eng2.close()
+    # a productive cleanup (more than half removed) halves the interval
+    for i in range(100):
+        eng.set_if_not_exists_with_ttl(b"s%d" % i, i, 1 * S, T0 + 2 * S)
+    # (those 100 operations tripped the operation trigger twice more, with nothing to remove: 20 s, the cap)
+    assert eng.sweep_stats()["current_interval_ns"] == 20 * S
+    eng.rate_limit(b"tick", 5, 10, 60, 1, T0 + 3700 * S)  # by now the 60 long-lived keys have expired, too
+    eng.rate_limit(b"tock", 5, 10, 60, 1, T0 + 3701 * S)
+    st = eng.sweep_stats()
+    assert st["last_removed"] == 160 and st["current_interval_ns"] == 10 * S, st
+    assert eng.counters()["live_slots"] == 2
+    eng.close()
+
+
+@pytest.mark.parametrize("n", [500, 6000])  # one launch (k_small_batch) / the pipeline
+def test_three_times_the_table_in_short_lived_keys_never_answers_internal(n):
+    """4 x capacity distinct keys whose entries live 0.1 s, one second of stream time per batch, through the synchronous
+    host-pointer call (what rust/throttlecrab-gpu's rate_limit_batch issues): the reference's map would hold a few of them at
+    a time; a fixed table has to be cleaned in time.  Zero Internal statuses, decisions identical to the oracle's."""
+    from oracle import oracle as O
+    cap = 2 * n
+    eng, orc = _engine(cap, 1 << 14), _oracle()
+    eng.set_sweep_policy("adaptive", created_ns=T0)
+    rng = np.random.default_rng(n)
+    serial = 0
+    for b in range(8):  # 8 n distinct keys in all = 4 x the table
+        keys = [b"key_%d" % (serial + i) for i in range(n)]
+        serial += n
+        kb, ko = O.pack_keys(keys)
+        now = T0 + b * S + np.sort(rng.integers(0, 10**8, n))
+        ref = orc.batch_keys(kb, ko, 2, 10, 1, 1, now)
+        res = eng.rate_limit_batch_keys(kb, ko, max_burst=np.full(n, 2), count_per_period=np.full(n, 10), period=np.full(n, 1),
+                                        quantity=np.ones(n, np.int64), now_ns=now, want=FIELDS)
+        assert_same(res, ref, f"batch {b}")
+        assert not np.any(res.status), "a request was turned away"
+    st = eng.sweep_stats()
+    assert st["sweeps"] >= 2 and st["retries"] == 0, st  # cleaned in FRONT of the batches: nothing had to be applied twice
+    assert eng.counters()["errors"] == 0 and eng.debug_check_keys() == 0
+    eng.close()
+
+
+@pytest.mark.parametrize("n_new", [300, 3000])  # one launch / the pipeline
+def test_a_synchronous_call_that_runs_out_of_slots_sweeps_and_applies_the_rest(n_new):
+    """(2, 10, 1 s): an entry lives 0.1 s.  The retry: the room check is quiet (its last sweep found nothing to remove, the clock has not moved an interval), the
+    old keys have expired meanwhile, the batch of new keys finds no slot -- and comes back complete"""
+    from oracle import oracle as O
+    cap = 4 * n_new
+    eng, orc = _engine(cap, 1 << 14), _oracle()
+    # (map_capacity: the size trigger -- 3/4 of the map -- out of the way; this is about the room check and the retry)
+    eng.set_sweep_policy("adaptive", created_ns=T0, min_interval_ns=10 * S, max_interval_ns=300 * S, map_capacity=100 * cap)
+
+    def run(keys, now, ctx, expect_full=False):
+        kb, ko = O.pack_keys(keys)
+        n = len(keys)
+        cols = dict(max_burst=np.full(n, 2), count_per_period=np.full(n, 10), period=np.full(n, 1), quantity=np.ones(n, np.int64),
+                    now_ns=np.full(n, now, np.int64))
+        import throttlecrab_amd as t
+        if expect_full:
+            with pytest.raises(t.TcError) as ei:
+                eng.rate_limit_batch_keys(kb, ko, want=FIELDS, **cols)
+            assert ei.value.code == -5
+            return None
+        res = eng.rate_limit_batch_keys(kb, ko, want=FIELDS, **cols)
+        ref = orc.batch_keys(kb, ko, 2, 10, 1, 1, cols["now_ns"])
+        assert_same(res, ref, ctx)
+        return res
+
+    old = [b"old_%d" % i for i in range(cap - n_new // 2)]   # the table nearly full of keys that live 0.1 s
+    for at in range(0, len(old), 8000):
+        run(old[at:at + 8000], T0 + 1 * S, "fill")
+    # the time trigger (5 s after creation) has not fired; free slots: n_new / 2
+    first = [b"new_a%d" % i for i in range(n_new)]
+    # at +1.05 s the old keys are still alive: the room sweep removes nothing, half the batch finds no slot even after the retry
+    run(first, T0 + 1 * S + 5 * 10**7, "full", expect_full=True)
+    st = eng.sweep_stats()
+    assert st["sweeps_for_room"] == 1 and st["retries"] == 1, st
+    orc_keys = first[: n_new // 2]  # (what the engine applied: the first keys in index order got the free slots)
+    kb, ko = O.pack_keys(orc_keys)
+    orc.batch_keys(kb, ko, 2, 10, 1, 1, np.full(len(orc_keys), T0 + 1 * S + 5 * 10**7, np.int64))
+    # one second later everything has expired; the room check stays quiet (10 s), the batch runs out of slots and is retried
+    second = [b"new_b%d" % i for i in range(n_new)]
+    res = run(second, T0 + 2 * S + 5 * 10**7, "retried")
+    assert not np.any(res.status)
+    st = eng.sweep_stats()
+    assert st["sweeps_for_room"] == 1 and st["retries"] == 2, st
+    c = eng.counters()
+    assert c["errors"] == n_new - n_new // 2, c  # only the requests that were really turned away count as errors
+    assert c["live_slots"] == n_new and eng.debug_check_keys() == 0
+    # single requests and store operations retry the same way
+    eng2 = _engine(64, 64)
+    eng2.set_sweep_policy("adaptive", created_ns=T0, min_interval_ns=10 * S, map_capacity=10000)
+    for i in range(64):
+        assert eng2.rate_limit(b"f%d" % i, 2, 10, 1, 1, T0 + 1 * S)[:2] == (0, True)
+    import throttlecrab_amd as t
+    with pytest.raises(t.TcError):
+        eng2.rate_limit(b"one more", 2, 10, 1, 1, T0 + 1 * S + 1)           # full of live keys: honest
+    assert eng2.rate_limit(b"one more", 2, 10, 1, 1, T0 + 2 * S)[:2] == (0, True)  # expired by now: swept, applied
+    assert eng2.set_if_not_exists_with_ttl(b"and a store op", 7, 1 * S, T0 + 2 * S) is True
+    assert eng2.counters()["live_slots"] == 2 and eng2.counters()["errors"] == 1
+    eng2.close()
+    eng.close()
+
+
+@pytest.mark.parametrize("mode", ["device", "async"])
+def test_pipelined_key_batches_stay_exact_and_bounded_while_the_engine_sweeps(mode):
+    """batches nobody waits for (device pointers on the key stream / TC_B_ASYNC host arrays): the policy goes by the feed the
+    device writes into pinned memory; 4 x the table in distinct keys, decisions == the oracle's, no request turned away"""
+    import torch
+    from oracle import oracle as O
+    n, cap = 20000, 50000
+    eng, orc = _engine(cap, 1 << 15), _oracle()
+    eng.set_sweep_policy("periodic", created_ns=T0, interval_ns=2 * S)
+    eng.use_torch_stream()
+    rng = np.random.default_rng(3)
+    keep, refs, serial = [], [], 0
+    for b in range(10):
+        fresh = [b"key_%d" % (serial + i) for i in range(n // 2)]
+        serial += n // 2
+        hot = [b"hot_%d" % int(h) for h in rng.integers(0, 200, n - n // 2)]  # recurring keys: denials
+        order = rng.permutation(n)
+        keys = [(fresh + hot)[i] for i in order]
+        kb, ko = O.pack_keys(keys)
+        now = T0 + b * S
+        refs.append(orc.batch_keys(kb, ko, 3, 10, 1, 1, now))
+        if mode == "device":
+            res = eng.rate_limit_batch_keys(torch.from_numpy(kb).cuda(), torch.from_numpy(ko.astype(np.int32)).cuda(), max_burst=3,
+                                            count_per_period=10, period=1, quantity=1, now_ns=now, inputs_ready=True)
+        else:
+            hb, ho = eng.host_alloc(kb.size, np.uint8), eng.host_alloc(ko.size, np.uint32)
+            hb[:], ho[:] = kb, ko
+            out = __import__("throttlecrab_amd").BatchResult(**{f: eng.host_alloc(n, np.uint8 if f in ("allowed", "status") else np.int64) for f in FIELDS})
+            res = eng.rate_limit_batch_keys(hb, ho, max_burst=3, count_per_period=10, period=1, quantity=1, now_ns=now, async_=True, out=out)
+        keep.append(res)
+    eng.wait_batches(0)
+    torch.cuda.synchronize()
+    for b, (res, ref) in enumerate(zip(keep, refs)):
+        assert_same(res, ref, f"{mode} batch {b}")
+        st = res.status if isinstance(res.status, np.ndarray) else res.status.cpu().numpy()
+        assert not st.any()
+    st = eng.sweep_stats()
+    assert st["sweeps_by_time"] >= 3 and st["retries"] == 0, st
+    assert eng.counters()["live_slots"] < cap and eng.debug_check_keys() == 0
+    eng.close()
+
+
+def test_a_store_full_of_live_keys_is_not_swept_in_front_of_every_call():
+    """between 3/4 full and full the reference's map has grown out of the size trigger (adaptive_cleanup.rs:166: len > 3/4 of
+    capacity(), and capacity() doubles once len passes it); the engine's virtual map follows, the sweep count stays put"""
+    eng = _engine(1000, 64)
+    eng.set_sweep_policy("adaptive", created_ns=T0)
+    for i in range(900):
+        assert eng.set_if_not_exists_with_ttl(b"live%d" % i, i, 3600 * S, T0 + i)
+    st = eng.sweep_stats()
+    assert st["sweeps_by_size"] == 1 and st["sweeps"] == 1 and st["last_removed"] == 0, st   # once, at the 752nd key
+    for i in range(50):
+        assert eng.rate_limit(b"live%d" % i, 5, 10, 60, 1, T0 + 1000 + i)[0] == 0
+    assert eng.sweep_stats()["sweeps"] == 1 and eng.counters()["live_slots"] == 900
+    eng.close()
+
+
+def test_slot_mode_engines_clean_themselves_too():
+    """no key table to run out of, but the same cadence: the time and operation triggers vacate expired slots; decisions and
+    the resident state stay those of the oracle"""
+    from oracle import oracle as O
+    cap, n = 20000, 30000
+    eng = _engine(cap, 1 << 15, key_mode=False)
+    eng.set_sweep_policy("adaptive", created_ns=T0, max_operations=40000)
+    orc = O.DenseOracle(cap)
+    rng = np.random.default_rng(9)
+    for b in range(12):
+        slots = rng.integers(0, cap, n).astype(np.uint32)
+        now = T0 + b * S // 2   # (the first time trigger is due at +5 s; 40 000 allowed requests come sooner)
+        ref = orc.batch_slots(slots, 5, 10, 1, 1, now)
+        res = eng.rate_limit_batch_slots(slots, max_burst=5, count_per_period=10, period=1, quantity=1, now_ns=now)
+        assert_same(res, ref, f"batch {b}")
+    st = eng.sweep_stats()
+    assert st["sweeps"] >= 3 and st["sweeps_by_time"] >= 1 and st["sweeps_by_operations"] >= 1, st
+    assert eng.counters()["swept"] > 0
+    t_end = T0 + 100 * S
+    orc.sweep(t_end)
+    eng.sweep_expired(t_end)
+    assert eng.counters()["live_slots"] == orc.live() == 0
+    eng.close()

@@ -15,7 +15,7 @@ C_SCALARS = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": 
              "int64_t": "i64", "size_t": "usize", "int": "c_int", "char": "c_char", "void": "c_void", "double": "f64",
              "tc_engine": "tc_engine", "tc_config": "tc_config", "tc_batch": "tc_batch", "tc_result": "tc_result",
              "tc_decision": "tc_decision", "tc_route": "tc_route", "tc_forward": "tc_forward", "tc_exchange": "tc_exchange",
-             "tc_exchange_config": "tc_exchange_config"}
+             "tc_exchange_config": "tc_exchange_config", "tc_sweep_policy": "tc_sweep_policy", "tc_sweep_info": "tc_sweep_info"}
 
 
 def strip_comments(c):
@@ -63,7 +63,8 @@ def rust_structs():
 
 def test_repr_c_structs_match_the_header():
     c, r = c_structs(), rust_structs()
-    for name in ("tc_config", "tc_batch", "tc_decision", "tc_result", "tc_route", "tc_forward", "tc_exchange_config"):
+    for name in ("tc_config", "tc_batch", "tc_decision", "tc_result", "tc_route", "tc_forward", "tc_exchange_config", "tc_sweep_policy",
+                 "tc_sweep_info"):
         assert name in c and name in r, name
         assert r[name] == c[name], f"{name}: rust {r[name]} != header {c[name]}"
     assert r["tc_engine"] == [("_private", "[u8; 0]")] and r["tc_exchange"] == [("_private", "[u8; 0]")]  # opaque
@@ -98,7 +99,7 @@ def test_constants_match_the_header():
         assert k in c, f"{k} is not in tcgpu.h"
         assert c[k] == v, f"{k}: rust {v} != header {c[k]}"
     for k in c:  # every flag and status of the header is bound
-        if k.startswith(("TC_B_", "TC_CFG_", "TC_E_", "TC_CNT_")) or k in ("TC_OK", "TC_NEGATIVE_QUANTITY", "TC_INVALID_RATE_LIMIT", "TC_INTERNAL"):
+        if k.startswith(("TC_B_", "TC_CFG_", "TC_E_", "TC_CNT_", "TC_SWEEP_")) or k in ("TC_OK", "TC_NEGATIVE_QUANTITY", "TC_INVALID_RATE_LIMIT", "TC_INTERNAL"):
             assert k in rust, f"{k} of tcgpu.h is missing in ffi.rs"
 
 
@@ -149,3 +150,12 @@ def test_store_trait_surface():
         assert sig in LIB, sig
     assert re.search(r"pub fn rate_limit\(\s*&mut self,\s*key: &str,\s*max_burst: i64,\s*count_per_period: i64,\s*period: i64,\s*quantity: i64,\s*now: SystemTime,?\s*\) -> Result<\(bool, RateLimitResult\), CellError>", LIB)
     assert "pub fn rate_limit_batch(&mut self, reqs: &[Request]) -> Vec<Result<(bool, RateLimitResult), CellError>>" in LIB
+
+
+def test_the_store_cleans_itself():
+    """GpuStore::new hands the engine AdaptiveStore's policy with the server's defaults (config.rs:285-304): the drop-in
+    cleans inside its own compare_and_swap / set_if_not_exists, like adaptive_cleanup.rs:229,262"""
+    new = LIB[LIB.index("pub fn new(capacity"):LIB.index("pub fn with_sweep_policy")]
+    assert "kind: ffi::TC_SWEEP_ADAPTIVE" in new and "min_interval_ns: 5_000_000_000" in new and "max_interval_ns: 300_000_000_000" in new
+    assert "max_operations: 1_000_000" in new and "with_sweep_policy(&p)" in new
+    assert "ffi::tc_set_sweep_policy(self.e, p)" in LIB

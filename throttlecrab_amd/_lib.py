@@ -66,6 +66,22 @@ class tc_exchange_config(C.Structure):
                 ("flags", C.c_uint32), ("keys_per_shard", C.c_uint64), ("inbox", C.c_void_p), ("mail", C.c_void_p), ("done", C.c_void_p)]
 
 
+TC_SWEEP_NONE, TC_SWEEP_ADAPTIVE, TC_SWEEP_PERIODIC, TC_SWEEP_PROBABILISTIC = 0, 1, 2, 3
+
+
+class tc_sweep_policy(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_uint32), ("created_ns", C.c_int64), ("min_interval_ns", C.c_int64),
+                ("max_interval_ns", C.c_int64), ("interval_ns", C.c_int64), ("max_operations", C.c_uint64),
+                ("map_capacity", C.c_uint64), ("cleanup_probability", C.c_uint64)]
+
+
+class tc_sweep_info(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kind", C.c_uint32), ("sweeps", C.c_uint64), ("sweeps_by_time", C.c_uint64),
+                ("sweeps_by_operations", C.c_uint64), ("sweeps_by_size", C.c_uint64), ("sweeps_for_room", C.c_uint64),
+                ("retries", C.c_uint64), ("feed_waits", C.c_uint64), ("operations", C.c_uint64), ("entries", C.c_uint64),
+                ("last_removed", C.c_uint64), ("current_interval_ns", C.c_int64), ("next_cleanup_ns", C.c_int64)]
+
+
 class tc_result(C.Structure):
     _fields_ = [("limit", C.c_int64), ("remaining", C.c_int64), ("reset_after_ns", C.c_int64),
                 ("retry_after_ns", C.c_int64), ("allowed", C.c_uint8), ("status", C.c_uint8)]
@@ -89,6 +105,8 @@ SYMBOLS = {
     "tc_rate_limit": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int64, C.c_int64,
                                 C.c_int64, C.POINTER(tc_result)]),
     "tc_sweep_expired": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(C.c_uint64)]),
+    "tc_set_sweep_policy": (C.c_int, [C.c_void_p, C.POINTER(tc_sweep_policy)]),
+    "tc_sweep_stats": (C.c_int, [C.c_void_p, C.POINTER(tc_sweep_info)]),
     "tc_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_counters_refresh": (C.c_int, [C.c_void_p]),
     "tc_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -487,6 +487,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         (void)hipStreamDestroy(e->debug_filler[k]);
     }
     if (e->poison_host) (void)hipHostFree(e->poison_host);
+    if (e->as.feed_host) (void)hipHostFree(e->as.feed_host);
     if (e->k_done) (void)hipEventDestroy(e->k_done);
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
@@ -656,9 +657,18 @@ extern "C" int tc_counters(tc_engine* e, uint64_t out[TC_CNT_COUNT]) {
     TC_CHECK_POISON(e);
     int rc = tc_counters_refresh(e);
     if (rc != TC_E_OK) return rc;
+    int top = 0;
+    if (e->key_mode) { // string mode: the store's size is the number of keys that hold a slot (key stages in flight come first)
+        if (e->k_busy) {
+            TC_HIP(e, hipStreamWaitEvent(cur_stream(e), e->k_done, 0));
+            e->k_busy = false;
+        }
+        TC_HIP(e, hipMemcpyAsync(&top, e->kt.free_top, sizeof top, hipMemcpyDeviceToHost, cur_stream(e)));
+    }
     TC_HIP(e, hipMemcpyAsync(out, e->counters, TC_CNT_COUNT * sizeof(uint64_t), hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     out[TC_CNT_BATCHES] = e->batches;
+    if (e->key_mode) out[TC_CNT_LIVE_SLOTS] = e->capacity - std::min<uint64_t>(e->capacity, (uint64_t)std::max(top, 0));
     return TC_E_OK;
 }
 

@@ -7,6 +7,7 @@
 //   maint.hip     sweep, top denied keys, state introspection
 //   snapshot.hip  tc_snapshot_save / load
 //   route.hip     multi-GPU: tc_route_batch, tc_forward_segments, the host mirror of the map
+//   autosweep.hip self-cleaning: tc_set_sweep_policy, the policy feed, auto_sweep_before / auto_sweep_after
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -22,6 +23,7 @@
 #include <vector>
 
 #include "../../include/tcgpu.h"
+#include "../../include/throttlecrab_sweep.hpp"
 #include "gcra_math.hpp"
 #include "key_table.hpp"
 #include "radix_sort.hpp"
@@ -192,11 +194,40 @@ struct tc_engine {
     uint8_t* small_io = nullptr;  // host address
     uint8_t* small_io_dev = nullptr; // the same block as the device addresses it
     size_t small_io_bytes = 0;
+    size_t small_slots_at = 0;    // key mode: where the last small batch's resolved slots are in it (retry of rejected requests)
     bool small_off = false;       // TCGPU_NO_SMALL_BATCH=1: always take the big pipeline
 
     // TC_B_ASYNC host batches still in flight, oldest first: one event per batch, recorded behind its last copy
     std::deque<hipEvent_t> async_done;
     std::vector<hipEvent_t> async_pool;
+
+    // self-cleaning (autosweep.hip): AdaptiveStore::maybe_clean_expired in front of the engine's own mutating calls
+    struct AutoSweep {
+        uint32_t kind = TC_SWEEP_NONE;
+        throttlecrab::sweep::AdaptiveSweep adaptive{0, 0};
+        throttlecrab::sweep::PeriodicSweep periodic{0};
+        throttlecrab::sweep::ProbabilisticSweep probabilistic{1000};
+        // the feed: what the device tells the host after every mutating call, in pinned memory, never waited for (mk::PolicyFeed)
+        void* feed_host = nullptr;
+        void* feed_dev = nullptr;
+        uint64_t issued = 0;              // feeds enqueued so far (the feed of call k carries seq k)
+        uint64_t seen = 0;                // seq of the newest feed the host has read
+        uint64_t allowed_accounted = 0;   // device total of allowed requests already handed to the policy as operations
+        uint64_t swept_accounted = 0;     // device total of removed entries already handed to the policy
+        uint64_t host_ops = 0;            // operations only the host knows of (tc_store_* calls: one each), not yet handed over
+        uint64_t entries = 0;             // the store's size as of feed `seen` (string mode: bound keys; slot mode: live slots of the last sweep)
+        uint64_t free_slots = 0;          // string mode: free slots as of feed `seen`
+        int64_t last_now = 0;             // newest timestamp the engine has been shown (a call's own, or the feed's for device columns)
+        std::deque<std::pair<uint64_t, uint64_t>> keys_after; // (seq, n) of the key batches issued: those > seen may have taken n slots each
+        // a sweep the engine started whose result the host has not heard yet
+        bool pending = false;
+        uint64_t pending_seq = 0;         // the first feed that reflects it
+        uint64_t pending_entries = 0;     // the store's size when it was started
+        tc_sweep_info stats{};
+        bool in_retry = false;            // a rejected sub-batch is being applied again: no second retry
+        int64_t min_interval_ns = 0;
+        int64_t room_quiet_until = INT64_MIN; // an unproductive room sweep is not repeated before the stream's clock gets here
+    } as;
 
     uint64_t batches = 0; // TC_CNT_BATCHES is kept on the host
     uint32_t* poison_host = nullptr; // pinned: raised by tc::invariant_failed; every ABI call checks it (TC_E_INVARIANT)
@@ -345,6 +376,20 @@ inline int stage_need(tc_engine* e, T*& p, size_t count) {
     if (!p) TC_HIP(e, hipMalloc(&p, count * sizeof(T)));
     return TC_E_OK;
 }
+// autosweep.hip
+// in front of a mutating call: n requests (key_batch: each may take a free slot), first timestamp `now_ns` (now_known false: the
+// timestamps are a device column -- the newest one the feed has shown stands in).  ops_now: operations the call itself is known
+// to be (tc_store_* calls: one, counted BEFORE should_clean like adaptive_cleanup.rs:206; the allowed requests of a batch are
+// only known afterwards and reach the policy through the feed).  May enqueue a sweep on the engine's stream.
+int auto_sweep_before(tc_engine* e, uint64_t n, bool key_batch, bool now_known, int64_t now_ns, uint64_t ops_now = 0);
+// behind it: enqueue the feed on the engine's stream (now_last: device address of the call's last timestamp, or nullptr and
+// now_scalar)
+int auto_sweep_after(tc_engine* e, uint64_t n, bool key_batch, const int64_t* now_last_dev, int64_t now_scalar);
+// a synchronous call ran out of slots: sweep at now_ns and wait (the caller applies the rejected requests again)
+int auto_sweep_for_retry(tc_engine* e, int64_t now_ns);
+inline bool auto_sweep_on(const tc_engine* e) { return e->as.kind != TC_SWEEP_NONE; }
+// maint.hip
+int sweep_enqueue(tc_engine* e, int64_t now_ns); // tc_sweep_expired without the wait
 // keys.hip
 int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert, uint32_t* out_slot, bool on_key_stream);
 int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n, const uint8_t** d_bytes, const uint32_t** d_off);

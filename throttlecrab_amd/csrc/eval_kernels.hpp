@@ -345,7 +345,7 @@ static __global__ void k_rate_limit_one(Params p, kt::Table t, int key_mode, Inl
 constexpr int SMALL_MAX = 1024;
 static __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::Table t, int key_mode, const uint8_t* __restrict__ key_bytes,
                                                            const uint32_t* __restrict__ key_off, uint32_t* __restrict__ table_full,
-                                                           unsigned long long* inserted) {
+                                                           unsigned long long* inserted, uint32_t* __restrict__ slot_out) {
     __shared__ uint64_t s_key[SMALL_MAX]; // slot << 32 | request index; padding = ~0
     __shared__ uint32_t s_slot[SMALL_MAX];
     const uint32_t i = threadIdx.x, n = p.n;
@@ -377,6 +377,7 @@ static __global__ __launch_bounds__(SMALL_MAX) void k_small_batch(Params p, kt::
         }
         if (i < n && st == kt::ST_FOLLOWER) slot = s_slot[ax];
         if (i < n && slot == kt::NO_SLOT) *table_full = 1u; // (same value from every lane that gets here)
+        if (i < n && slot_out != nullptr) slot_out[i] = slot; // (which requests were turned away: the host may apply them again)
     } else if (i < n) {
         slot = p.slot[i];
     }

@@ -110,6 +110,13 @@ static int check_key_errors(tc_engine* e) {
     return TC_E_OK;
 }
 
+// requests that were turned away for want of a slot were counted as errors (status Internal); they are about to be applied again
+static int forget_errors(tc_engine* e, uint64_t k) {
+    hipLaunchKernelGGL(mk::k_counter_add, dim3(1), dim3(1), 0, cur_stream(e), e->counters + (TC_CNT_COUNT + 1) + 2, 0ull - (unsigned long long)k);
+    TC_HIP(e, hipGetLastError());
+    return TC_E_OK;
+}
+
 // TC_B_ASYNC key batch: key arena and offsets are staged on the key stream (SDMA), resolved there, grouped on
 // an auxiliary stream, evaluated in order, results copied back behind the evaluation; nothing waits.  A full
 // key table shows as status Internal on the affected requests; the TC_E_TABLE_FULL return code is delivered
@@ -150,25 +157,9 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     return finish_async(e, b);
 }
 
-extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
-    if (!e || !bp || bp->struct_size < offsetof(tc_batch, n_segments)) return TC_E_INVALID_ARG;
-    TC_CHECK_POISON(e);
-    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
-    tc_batch b;
-    memset(&b, 0, sizeof b);
-    memcpy(&b, bp, std::min<size_t>(bp->struct_size, sizeof b));
-    if (b.n_segments) return fail(e, TC_E_INVALID_ARG, "segments belong to slot batches");
-    if (b.n == 0) return TC_E_OK;
-    if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
-    if (!b.key_bytes || !b.key_off) return fail(e, TC_E_INVALID_ARG, "key_bytes/key_off is NULL");
-    if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
-    if (b.flags & (TC_B_REGISTERED_PARAMS | TC_B_UNIQUE_SLOTS))
-        return fail(e, TC_E_INVALID_ARG, "registered params / unique-slot promise do not apply to string keys");
-    TC_HIP(e, hipSetDevice(e->device));
-    if (b.flags & TC_B_ASYNC) {
-        if (b.flags & TC_B_DEVICE_PTRS) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
-        return run_keys_host_async(e, b);
-    }
+// a validated key batch through the path its flags name
+static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
+    if (b.flags & TC_B_ASYNC) return run_keys_host_async(e, b);
     const uint8_t* d_bytes = b.key_bytes;
     const uint32_t* d_off = b.key_off;
     const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
@@ -208,6 +199,117 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     return check_key_errors(e);
 }
 
+// A SYNCHRONOUS host-pointer key batch came back with TC_E_TABLE_FULL while the engine cleans by itself: where the reference's
+// HashMap would simply have grown, drop what has expired by the call's newest timestamp and apply the requests that were
+// turned away once more.  They are exactly the requests whose key got no slot -- every request of such a key, so the
+// sub-batch, in index order, IS the tail of those keys' sequences (keys are independent) -- and they touched no state.
+// `small`: the batch went through k_small_batch (its resolved slots are in the pinned block), else through the pipeline (e->k_slot).
+static int retry_rejected(tc_engine* e, const tc_batch& b, bool small) {
+    const size_t n = b.n;
+    std::vector<uint32_t> slots(n);
+    if (small) {
+        memcpy(slots.data(), e->small_io + e->small_slots_at, n * sizeof(uint32_t));
+    } else {
+        TC_HIP(e, hipMemcpyAsync(slots.data(), e->k_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost, cur_stream(e)));
+        TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    }
+    std::vector<uint32_t> idx;
+    for (size_t i = 0; i < n; ++i)
+        if (slots[i] == kt::NO_SLOT) idx.push_back((uint32_t)i);
+    if (idx.empty()) return TC_E_TABLE_FULL; // (the flag was an earlier asynchronous batch's)
+    const size_t m = idx.size();
+    int64_t newest = b.now_ns ? INT64_MIN : b.now_ns_scalar;
+    if (b.now_ns)
+        for (uint32_t i : idx) newest = std::max(newest, b.now_ns[i]);
+    TC_TRY(forget_errors(e, m));
+    TC_TRY(auto_sweep_for_retry(e, newest));
+    std::vector<uint8_t> arena;
+    std::vector<uint32_t> off(m + 1, 0u);
+    for (size_t k = 0; k < m; ++k) {
+        const uint32_t i = idx[k];
+        arena.insert(arena.end(), b.key_bytes + b.key_off[i], b.key_bytes + b.key_off[i + 1]);
+        off[k + 1] = (uint32_t)arena.size();
+    }
+    if (arena.empty()) arena.push_back(0);
+    const int64_t* in_cols[5] = {b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns};
+    std::vector<int64_t> sub_in[5];
+    for (int j = 0; j < 5; ++j)
+        if (in_cols[j]) {
+            sub_in[j].resize(m);
+            for (size_t k = 0; k < m; ++k) sub_in[j][k] = in_cols[j][idx[k]];
+        }
+    tc_batch sub = b;
+    sub.n = m;
+    sub.key_bytes = arena.data();
+    sub.key_off = off.data();
+    sub.max_burst = in_cols[0] ? sub_in[0].data() : nullptr;
+    sub.count_per_period = in_cols[1] ? sub_in[1].data() : nullptr;
+    sub.period = in_cols[2] ? sub_in[2].data() : nullptr;
+    sub.quantity = in_cols[3] ? sub_in[3].data() : nullptr;
+    sub.now_ns = in_cols[4] ? sub_in[4].data() : nullptr;
+    std::vector<uint8_t> o_allowed(b.allowed || b.allowed_bits ? m : 0), o_status(b.status ? m : 0);
+    int64_t* const want[4] = {b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns};
+    std::vector<int64_t> o_col[4], o_r4(b.result4 ? 4 * m : 0);
+    for (int j = 0; j < 4; ++j) o_col[j].resize(want[j] ? m : 0);
+    std::vector<tc_decision> o_dec(b.decisions ? m : 0);
+    sub.allowed = o_allowed.empty() ? nullptr : o_allowed.data();
+    sub.allowed_bits = nullptr;
+    sub.status = b.status ? o_status.data() : nullptr;
+    sub.limit = want[0] ? o_col[0].data() : nullptr;
+    sub.remaining = want[1] ? o_col[1].data() : nullptr;
+    sub.reset_after_ns = want[2] ? o_col[2].data() : nullptr;
+    sub.retry_after_ns = want[3] ? o_col[3].data() : nullptr;
+    sub.result4 = b.result4 ? o_r4.data() : nullptr;
+    sub.decisions = b.decisions ? o_dec.data() : nullptr;
+    e->as.in_retry = true;
+    const int rc = tc_rate_limit_batch_keys(e, &sub);
+    e->as.in_retry = false;
+    if (rc != TC_E_OK && rc != TC_E_TABLE_FULL) return rc; // (nothing more was applied; the first pass's results stand)
+    e->batches--; // one batch, as far as the caller is concerned
+    for (size_t k = 0; k < m; ++k) {
+        const uint32_t i = idx[k];
+        if (b.allowed) b.allowed[i] = o_allowed[k];
+        if (b.allowed_bits) b.allowed_bits[i >> 6] = (b.allowed_bits[i >> 6] & ~(1ull << (i & 63u))) | ((uint64_t)(o_allowed[k] & 1u) << (i & 63u));
+        if (b.status) b.status[i] = o_status[k];
+        for (int j = 0; j < 4; ++j)
+            if (want[j]) want[j][i] = o_col[j][k];
+        if (b.result4) memcpy(b.result4 + 4 * (size_t)i, o_r4.data() + 4 * k, 4 * sizeof(int64_t));
+        if (b.decisions) b.decisions[i] = o_dec[k];
+    }
+    return rc;
+}
+
+extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
+    if (!e || !bp || bp->struct_size < offsetof(tc_batch, n_segments)) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
+    tc_batch b;
+    memset(&b, 0, sizeof b);
+    memcpy(&b, bp, std::min<size_t>(bp->struct_size, sizeof b));
+    if (b.n_segments) return fail(e, TC_E_INVALID_ARG, "segments belong to slot batches");
+    if (b.n == 0) return TC_E_OK;
+    if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
+    if (!b.key_bytes || !b.key_off) return fail(e, TC_E_INVALID_ARG, "key_bytes/key_off is NULL");
+    if ((b.flags & TC_B_GROUPED_OUTPUT) && !b.order) return fail(e, TC_E_INVALID_ARG, "TC_B_GROUPED_OUTPUT needs `order`");
+    if (b.flags & (TC_B_REGISTERED_PARAMS | TC_B_UNIQUE_SLOTS))
+        return fail(e, TC_E_INVALID_ARG, "registered params / unique-slot promise do not apply to string keys");
+    if ((b.flags & TC_B_ASYNC) && (b.flags & TC_B_DEVICE_PTRS))
+        return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
+    TC_HIP(e, hipSetDevice(e->device));
+    if (!auto_sweep_on(e)) return keys_batch_dispatch(e, b);
+    // the engine cleans by itself (tc_set_sweep_policy): maybe_clean_expired in front of the batch, the feed behind it
+    const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
+    const bool now_known = !dev || !b.now_ns;
+    TC_TRY(auto_sweep_before(e, b.n, true, now_known, (!dev && b.now_ns) ? b.now_ns[0] : b.now_ns_scalar));
+    const bool small = !dev && !(b.flags & TC_B_ASYNC) && small_batch_applies(e, b);
+    int rc = keys_batch_dispatch(e, b);
+    if (rc == TC_E_TABLE_FULL && !dev && !(b.flags & (TC_B_ASYNC | TC_B_GROUPED_OUTPUT)) && !e->as.in_retry) rc = retry_rejected(e, b, small);
+    if (rc != TC_E_OK && rc != TC_E_TABLE_FULL) return rc;
+    const int rc2 = auto_sweep_after(e, b.n, true, (dev && b.now_ns) ? b.now_ns + (b.n - 1) : nullptr,
+                                     (!dev && b.now_ns) ? b.now_ns[b.n - 1] : b.now_ns_scalar);
+    return rc2 != TC_E_OK ? rc2 : rc;
+}
+
 extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, int64_t max_burst,
                              int64_t count_per_period, int64_t period, int64_t quantity, int64_t now_ns,
                              tc_result* out) {
@@ -216,6 +318,8 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
     if (key_len > 0x7FFFFFFFull) return fail(e, TC_E_INVALID_ARG, "key too long");
     if (e->fixed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: single calls carry their own rate; use a registered batch");
     TC_HIP(e, hipSetDevice(e->device));
+    // maybe_clean_expired (adaptive_cleanup.rs:205-211) in front of the call, when the engine cleans by itself
+    TC_TRY(auto_sweep_before(e, 1, true, true, now_ns));
     hipStream_t s = cur_stream(e);
     uint32_t slot = 0;
     InlineKey ik;
@@ -264,6 +368,7 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
         TC_HIP(e, hipEventRecord(e->m_done, s));
         e->m_busy = true;
     }
+    TC_TRY(auto_sweep_after(e, 1, true, nullptr, now_ns));
     OneResult r;
     TC_HIP(e, hipMemcpyAsync(&r, e->one_result, sizeof r, hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
@@ -272,6 +377,17 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
         uint32_t zero = 0;
         TC_HIP(e, hipMemcpyAsync(e->kt.error_flag, &zero, sizeof zero, hipMemcpyHostToDevice, s));
         TC_HIP(e, hipStreamSynchronize(s));
+        if (auto_sweep_on(e) && !e->as.in_retry) {
+            // where the reference's map would have grown: drop what has expired by now and apply the request once more
+            // (the first attempt touched no state and was counted as an error: taken back)
+            TC_TRY(forget_errors(e, 1));
+            TC_TRY(auto_sweep_for_retry(e, now_ns));
+            e->as.in_retry = true;
+            const int rc2 = tc_rate_limit(e, key, key_len, max_burst, count_per_period, period, quantity, now_ns, out);
+            e->as.in_retry = false;
+            e->batches--;
+            return rc2;
+        }
         return fail(e, TC_E_TABLE_FULL, "key table full: the key got status Internal (raise capacity or sweep)");
     }
     out->allowed = r.d.allowed;
@@ -304,13 +420,15 @@ static int store_slot_of(tc_engine* e, const uint8_t* key, size_t key_len, bool 
     return TC_E_OK;
 }
 
+// feed: a mutating operation while the engine cleans by itself -- the policy feed goes out behind the kernel, in front of the wait
 static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, uint64_t ttl, int64_t now,
-                    StoreOpResult* r) {
+                    StoreOpResult* r, bool feed = false, bool key_batch = false) {
     if (e->fixed) return fail(e, TC_E_UNSUPPORTED, "TC_CFG_FIXED_PARAMS: the 8-byte layout cannot hold a free ttl (Store operations need the 16-byte cell)");
     if (now < 0) return fail(e, TC_E_INVALID_ARG, "now_ns < 0");
     TC_HIP(e, hipSetDevice(e->device));
     hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, cur_stream(e), e->cells, slot, op, a, b, ttl, now, e->op_result);
     TC_HIP(e, hipGetLastError());
+    if (feed) TC_TRY(auto_sweep_after(e, 1, key_batch, nullptr, now));
     TC_HIP(e, hipMemcpyAsync(r, e->op_result, sizeof *r, hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     return TC_E_OK;
@@ -339,6 +457,8 @@ extern "C" int tc_store_compare_and_swap_with_ttl(tc_engine* e, const uint8_t* k
                                                   int64_t new_value, uint64_t ttl_ns, int64_t now_ns, int* swapped) {
     if (!e || !swapped) return TC_E_INVALID_ARG;
     TC_CHECK_POISON(e);
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_TRY(auto_sweep_before(e, 1, false, true, now_ns, 1)); // adaptive_cleanup.rs:229: self.maybe_clean_expired(now)
     uint64_t slot;
     int rc = store_slot_of(e, key, key_len, false, &slot);
     if (rc != TC_E_OK) return rc;
@@ -347,7 +467,7 @@ extern "C" int tc_store_compare_and_swap_with_ttl(tc_engine* e, const uint8_t* k
         return TC_E_OK;
     }
     StoreOpResult r;
-    rc = store_op(e, slot, 1, old_value, new_value, ttl_ns, now_ns, &r);
+    rc = store_op(e, slot, 1, old_value, new_value, ttl_ns, now_ns, &r, true, false);
     if (rc != TC_E_OK) return rc;
     *swapped = r.flag;
     return TC_E_OK;
@@ -357,11 +477,17 @@ extern "C" int tc_store_set_if_not_exists_with_ttl(tc_engine* e, const uint8_t* 
                                                    uint64_t ttl_ns, int64_t now_ns, int* was_set) {
     if (!e || !was_set) return TC_E_INVALID_ARG;
     TC_CHECK_POISON(e);
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_TRY(auto_sweep_before(e, 1, true, true, now_ns, 1)); // adaptive_cleanup.rs:262: self.maybe_clean_expired(now)
     uint64_t slot;
     int rc = store_slot_of(e, key, key_len, true, &slot);
+    if (rc == TC_E_TABLE_FULL && auto_sweep_on(e)) { // the reference's map would have grown: drop what has expired, once more
+        TC_TRY(auto_sweep_for_retry(e, now_ns));
+        rc = store_slot_of(e, key, key_len, true, &slot);
+    }
     if (rc != TC_E_OK) return rc;
     StoreOpResult r;
-    rc = store_op(e, slot, 2, value, 0, ttl_ns, now_ns, &r);
+    rc = store_op(e, slot, 2, value, 0, ttl_ns, now_ns, &r, true, true);
     if (rc != TC_E_OK) return rc;
     *was_set = r.flag;
     return TC_E_OK;

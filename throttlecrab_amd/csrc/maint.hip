@@ -60,10 +60,10 @@ static int compact_retired(tc_engine* e, bool force, std::vector<std::pair<std::
     return TC_E_OK;
 }
 
-extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed) {
-    if (!e) return TC_E_INVALID_ARG;
-    TC_CHECK_POISON(e);
-    TC_HIP(e, hipSetDevice(e->device));
+// AdaptiveStore::cleanup at now_ns, enqueued on the engine's stream (tc_sweep_expired without the wait; the engine's own
+// cleanups, autosweep.hip, come through here too).  The number removed lands in counters[TC_CNT_COUNT] (scratch) and is added
+// to TC_CNT_SWEPT.
+int sweep_enqueue(tc_engine* e, int64_t now_ns) {
     hipStream_t s = cur_stream(e);
     unsigned long long* scratch = e->counters + TC_CNT_COUNT;
     if (e->k_busy) { // key stages still in flight on the key stream come first
@@ -82,9 +82,18 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
         hipLaunchKernelGGL(k_sweep_fold, dim3(1), dim3(1024), 0, s, (const uint32_t*)e->sweep_part, blocks, scratch, e->counters);
         TC_HIP(e, hipGetLastError());
     }
+    return TC_E_OK;
+}
+
+extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed) {
+    if (!e) return TC_E_INVALID_ARG;
+    TC_CHECK_POISON(e);
+    TC_HIP(e, hipSetDevice(e->device));
+    TC_TRY(sweep_enqueue(e, now_ns));
     if (!removed) return TC_E_OK; // asynchronous: the count goes to TC_CNT_SWEPT
+    hipStream_t s = cur_stream(e);
     unsigned long long r = 0;
-    TC_HIP(e, hipMemcpyAsync(&r, scratch, sizeof r, hipMemcpyDeviceToHost, s));
+    TC_HIP(e, hipMemcpyAsync(&r, e->counters + TC_CNT_COUNT, sizeof r, hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
     *removed = r;
     // a synchronous sweep is where the table of retired keys is looked after (the sweep is what fills it)

@@ -535,4 +535,55 @@ static __global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, c
     }
 }
 
+// ---------------------------------------------------------------------------
+// The policy feed (autosweep.hip): what the host-side cleanup policy (AdaptiveStore::should_clean, adaptive_cleanup.rs:138-171)
+// needs to know about the device -- how many requests were allowed so far (the reference counts one operation per mutating
+// store call), how many entries the store holds, how many a sweep removed, the newest timestamp of a device column -- written
+// into PINNED host memory behind every mutating call while a policy is set.  The host reads it without ever waiting: the
+// record is bracketed by two copies of its sequence number (begin first, end last, system-scope fences between), a reader that
+// finds them different reads again later.
+// ---------------------------------------------------------------------------
+static __global__ void k_counter_add(unsigned long long* word, unsigned long long delta) { atomicAdd(word, delta); }
+
+struct PolicyFeed {
+    unsigned long long seq_end;   // written last
+    unsigned long long allowed;   // TC_CNT_ALLOWED, folded from the shards
+    unsigned long long swept;     // TC_CNT_SWEPT
+    unsigned long long entries;   // string mode: bound keys (capacity - free slots); slot mode: TC_CNT_LIVE_SLOTS (as of the last sweep)
+    unsigned long long free_slots; // string mode
+    long long last_now;           // the call's last timestamp
+    unsigned long long seq_begin; // written first
+    unsigned long long pad;
+};
+static __global__ __launch_bounds__(ev::NSHARD) void k_policy_feed(const unsigned long long* __restrict__ counters, PolicyFeed* __restrict__ feed,
+                                                                   unsigned long long seq, const int64_t* __restrict__ now_last, int64_t now_scalar,
+                                                                   const int* __restrict__ free_top, uint64_t capacity) {
+    __shared__ unsigned long long s[ev::NSHARD / 64];
+    const unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + threadIdx.x * ev::SHARD_WORDS;
+    unsigned long long v = __hip_atomic_load(shard, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    unsigned long long allowed = 0;
+    for (int w = 0; w < ev::NSHARD / 64; ++w) allowed += s[w];
+    volatile PolicyFeed* f = feed;
+    f->seq_begin = seq;
+    __threadfence_system();
+    f->allowed = allowed;
+    f->swept = counters[TC_CNT_SWEPT];
+    if (free_top != nullptr) {
+        const int top = *free_top;
+        const unsigned long long fr = top < 0 ? 0ull : (unsigned long long)top;
+        f->free_slots = fr;
+        f->entries = capacity - (fr < capacity ? fr : capacity);
+    } else {
+        f->free_slots = 0;
+        f->entries = counters[TC_CNT_LIVE_SLOTS];
+    }
+    f->last_now = now_last != nullptr ? (long long)*now_last : (long long)now_scalar;
+    __threadfence_system();
+    f->seq_end = seq;
+}
+
 } // namespace mk

@@ -625,7 +625,7 @@ bool small_batch_applies(const tc_engine* e, const tc_batch& b) {
 int run_small_batch(tc_engine* e, const tc_batch& b) {
     const size_t n = b.n;
     if (!e->small_io) {
-        const size_t bytes = 64 + SMALL_KEY_BYTES + (size_t)SMALL_MAX * (4 + 4 + 5 * 8 + 1 + 1 + 4 * 8 + 32 + 32) + 16 * 16;
+        const size_t bytes = 64 + SMALL_KEY_BYTES + (size_t)SMALL_MAX * (4 + 4 + 4 + 5 * 8 + 1 + 1 + 4 * 8 + 32 + 32) + 16 * 16;
         TC_HIP(e, hipHostMalloc((void**)&e->small_io, bytes, hipHostMallocDefault));
         void* dv = nullptr;
         TC_HIP(e, hipHostGetDevicePointer(&dv, e->small_io, 0));
@@ -646,9 +646,12 @@ int run_small_batch(tc_engine* e, const tc_batch& b) {
     p.n = (uint32_t)n;
     const uint8_t* d_key_bytes = nullptr;
     const uint32_t* d_key_off = nullptr;
+    uint32_t* d_slot_out = nullptr;
     if (e->key_mode) {
         const size_t total = b.key_off[n];
         const size_t o_off = take((n + 1) * 4), o_bytes = take(total + 16);
+        e->small_slots_at = take(n * 4);
+        d_slot_out = (uint32_t*)(d + e->small_slots_at);
         std::memcpy(h + o_off, b.key_off, (n + 1) * 4);
         if (total) std::memcpy(h + o_bytes, b.key_bytes, total);
         d_key_off = (const uint32_t*)(d + o_off);
@@ -711,7 +714,7 @@ int run_small_batch(tc_engine* e, const tc_batch& b) {
     }
     prof_begin(e, TC_STAGE_EVAL, s);
     hipLaunchKernelGGL(k_small_batch, dim3(1), dim3(SMALL_MAX), 0, s, p, e->kt, e->key_mode ? 1 : 0, d_key_bytes, d_key_off,
-                       (uint32_t*)d, e->counters + TC_CNT_KEYS_INSERTED);
+                       (uint32_t*)d, e->counters + TC_CNT_KEYS_INSERTED, d_slot_out);
     prof_end(e, s);
     TC_HIP(e, hipGetLastError());
     if (e->key_mode) { // the key table may have changed: later key stages on the key stream wait for this
@@ -759,8 +762,11 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     }
     TC_HIP(e, hipSetDevice(e->device));
     int rc;
-    if (b.flags & TC_B_DEVICE_PTRS) {
-        if (b.flags & TC_B_ASYNC) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
+    const bool dev_ptrs = (b.flags & TC_B_DEVICE_PTRS) != 0;
+    if (dev_ptrs && (b.flags & TC_B_ASYNC)) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
+    // the engine cleans by itself (tc_set_sweep_policy): maybe_clean_expired in front of the batch (autosweep.hip)
+    if (auto_sweep_on(e)) TC_TRY(auto_sweep_before(e, b.n, false, !dev_ptrs || !b.now_ns, (!dev_ptrs && b.now_ns) ? b.now_ns[0] : b.now_ns_scalar));
+    if (dev_ptrs) {
         rc = run_slots_device(e, b);
     } else if (b.flags & TC_B_ASYNC) {
         rc = run_slots_host_async(e, b);
@@ -775,6 +781,8 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     // fixed layout: once a request has been decided the plans can no longer change (a batch that was rejected, or
     // whose staging failed, applied nothing and seals nothing)
     if (e->fixed && rc == TC_E_OK) e->sealed = true;
+    if (rc == TC_E_OK && auto_sweep_on(e))
+        rc = auto_sweep_after(e, b.n, false, (dev_ptrs && b.now_ns) ? b.now_ns + (b.n - 1) : nullptr, (!dev_ptrs && b.now_ns) ? b.now_ns[b.n - 1] : b.now_ns_scalar);
     return rc;
 }
 

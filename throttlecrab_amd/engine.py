@@ -443,6 +443,30 @@ class Engine:
         self._check(self._lib.tc_sweep_expired(self._h, now_ns, C.byref(removed)))
         return int(removed.value)
 
+    def set_sweep_policy(self, kind="adaptive", created_ns: int = 0, min_interval_ns: int = 0, max_interval_ns: int = 0,
+                         interval_ns: int = 0, max_operations: int = 0, map_capacity: int = 0, cleanup_probability: int = 0):
+        """tc_set_sweep_policy: the engine cleans by itself in front of its own mutating calls, when the reference's store of
+        that kind would (adaptive_cleanup.rs:138-211 / periodic.rs:128-142 / probabilistic.rs:110-125).  kind: "adaptive" |
+        "periodic" | "probabilistic" | None (off, the default of a fresh engine).  Zeros mean the reference's defaults."""
+        if kind is None or kind == "none":
+            self._check(self._lib.tc_set_sweep_policy(self._h, None))
+            return
+        p = L.tc_sweep_policy()
+        p.struct_size = C.sizeof(L.tc_sweep_policy)
+        p.kind = {"adaptive": L.TC_SWEEP_ADAPTIVE, "periodic": L.TC_SWEEP_PERIODIC, "probabilistic": L.TC_SWEEP_PROBABILISTIC}[kind]
+        p.created_ns, p.min_interval_ns, p.max_interval_ns, p.interval_ns = created_ns, min_interval_ns, max_interval_ns, interval_ns
+        p.max_operations, p.map_capacity, p.cleanup_probability = max_operations, map_capacity, cleanup_probability
+        self._check(self._lib.tc_set_sweep_policy(self._h, C.byref(p)))
+
+    def sweep_stats(self) -> dict:
+        """tc_sweep_stats: what the engine's own cleanups did (sweeps by trigger, retries, the policy's state)."""
+        r = L.tc_sweep_info()
+        r.struct_size = C.sizeof(L.tc_sweep_info)
+        self._check(self._lib.tc_sweep_stats(self._h, C.byref(r)))
+        d = {k: int(getattr(r, k)) for k, _ in L.tc_sweep_info._fields_ if k != "struct_size"}
+        d["kind"] = ("none", "adaptive", "periodic", "probabilistic")[r.kind]
+        return d
+
     def counters(self) -> dict:
         arr = (C.c_uint64 * L.TC_CNT_COUNT)()
         self._check(self._lib.tc_counters(self._h, arr))
