@@ -107,7 +107,11 @@ def log(msg):
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks (one per GPU).  Started plainly -- `python bench.py --gpus N`, no torchrun around it -- bench.py "
+                         "launches the N ranks itself (torch.distributed.run on 127.0.0.1) and fails if the node has fewer GPUs; under "
+                         "torchrun it must agree with WORLD_SIZE.  Default: WORLD_SIZE, else 1")
+    ap.add_argument("--plan-only", action="store_true", help="print what --gpus N would launch, as JSON, and exit (no GPU touched)")
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="uniform", choices=["uniform", "zipf", "general", "general_zipf"],
@@ -870,14 +874,51 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     return res
 
 
+def launch_plan(a, argv, env):
+    """What `--gpus N` means for THIS process: ("run", world) -- go on as rank RANK of `world` -- or ("launch", cmd) -- this is a
+    plain `python bench.py --gpus N` with N > 1: start the N ranks (one per GPU, RCCL over 127.0.0.1), which is what the driver's
+    torchrun line does (README.md:247-249: the reference's scale-out is sharding by key; BASELINE configs[3]) -- or
+    ("error", message).  Pure: no GPU, no torch."""
+    under_torchrun = "WORLD_SIZE" in env
+    if under_torchrun:
+        world = int(env["WORLD_SIZE"])
+        if a.gpus is not None and a.gpus != world:
+            return "error", f"--gpus {a.gpus} but torchrun started {world} rank(s) (WORLD_SIZE): the line would claim GPUs that did no work"
+        return "run", world
+    gpus = 1 if a.gpus is None else a.gpus
+    if gpus < 1:
+        return "error", f"--gpus {gpus}"
+    if gpus == 1:
+        return "run", 1
+    port = env.get("MASTER_PORT") or str(29400 + os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + [x for x in argv if x != "--plan-only"]
+    return "launch", cmd
+
+
 def main():
     a = parse()
+    kind, plan = launch_plan(a, sys.argv[1:], os.environ)
+    if a.plan_only:
+        print(json.dumps({"action": kind, "world" if kind == "run" else ("cmd" if kind == "launch" else "error"): plan}))
+        return
+    if kind == "error":
+        sys.exit(f"bench.py: {plan}")
+    if kind == "launch":
+        if os.environ.get("TC_BENCH_ONE_DEVICE") != "1":  # (that switch puts every rank on GPU 0, over gloo: what a 1-GPU box can test)
+            import torch
+            have = torch.cuda.device_count()
+            if have < a.gpus:
+                sys.exit(f"bench.py: --gpus {a.gpus} but this node shows {have} GPU(s); nothing was measured")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        sys.stdout.flush()
+        os.execv(plan[0], plan)  # the ranks' rank 0 prints the line
     import torch
 
     import throttlecrab_amd as t
     from throttlecrab_amd import workload as W
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = plan
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
@@ -927,9 +968,13 @@ def main():
             else:
                 sh = run_sharded(a, t, W, dev, local, rank, world, dist)
             torch.cuda.synchronize()
+        # n_gpus of the line = the ranks the collective actually reached, not what a flag or an environment variable says
+        seen = torch.ones(1, dtype=torch.int64, device=dev)
+        dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+        ranks_seen = int(seen.item())
         if rank == 0:
             res = {
-                "metric": "GCRA decisions/sec, 10M keys per GPU", "value": sh["value"], "unit": "decisions/s", "n_gpus": world,
+                "metric": "GCRA decisions/sec, 10M keys per GPU", "value": sh["value"], "unit": "decisions/s", "n_gpus": ranks_seen,
                 "steps": a.steps, "warmup": a.warmup, "ms_per_step": sh["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "int64", "data": "synthetic",
                 "config": {"workload": f"configs[3]: {world} x {a.keys} keys hash-sharded across {world} GPU(s), ONE global {a.workload} "

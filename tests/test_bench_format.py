@@ -156,3 +156,34 @@ def test_verify_run_accepts_the_oracle_and_rejects_a_flipped_decision():
     t2[int(np.flatnonzero(occ)[0])] += 1
     assert not bench.verify_run(dict(snap, state=(t2, exp)), host, 0, per_slot, keys, batch, False)["ok"]
     assert not bench.verify_run(dict(snap, counters=dict(snap["counters"], allowed=allowed - 1)), host, 0, per_slot, keys, batch, False)["ok"]
+
+
+def test_gpus_flag_launches_the_ranks_itself():
+    """`--gpus N` was parsed and ignored (ranks came from torchrun's environment only, so a plain
+    `python bench.py --gpus 8` ran one rank and said n_gpus: 1).  Now: a plain start with N > 1 launches the N ranks
+    (torch.distributed.run on 127.0.0.1), under torchrun the flag must agree with WORLD_SIZE, and the line's n_gpus is what the
+    collective reached.  The plan is a pure function: checked here without a GPU (the real launch: tests/test_gpu_sharding.py)."""
+    import argparse
+    import subprocess
+
+    def plan(gpus, argv, env):
+        return bench.launch_plan(argparse.Namespace(gpus=gpus), argv, env)
+
+    kind, cmd = plan(8, ["--gpus", "8", "--steps", "20", "--warmup", "5"], {})
+    assert kind == "launch"
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=8" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[-6:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"] and cmd[-7].endswith("bench.py")
+    assert plan(1, ["--gpus", "1"], {}) == ("run", 1) and plan(None, [], {}) == ("run", 1)
+    assert plan(8, ["--gpus", "8"], {"WORLD_SIZE": "8"}) == ("run", 8)       # the driver's torchrun line
+    assert plan(None, [], {"WORLD_SIZE": "4"}) == ("run", 4)
+    assert plan(8, [], {"WORLD_SIZE": "1"})[0] == "error" and plan(0, [], {})[0] == "error"
+    assert plan(2, [], {"MASTER_PORT": "31234"})[1][cmd.index("--master-port") + 1] == "31234"
+    # ... and through the command line (no GPU is touched by --plan-only)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plan-only", "--steps", "2"], capture_output=True,
+                         text=True, timeout=120, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["action"] == "launch" and "--nproc-per-node=2" in d["cmd"] and "--plan-only" not in d["cmd"]
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3"], capture_output=True, text=True, timeout=120,
+                         env=dict(os.environ, WORLD_SIZE="2"))
+    assert bad.returncode != 0 and "torchrun started 2" in bad.stderr

@@ -87,3 +87,32 @@ def test_two_engines_two_processes_match_single_pass():
     assert np.array_equal(allowed, ref)
     assert totals["total"] == nb * n and totals["allowed"] == int(ref.sum())
     assert per_rank[0][0] + per_rank[1][0] == nb * n and min(per_rank[0][0], per_rank[1][0]) > 0.2 * nb * n
+
+
+def _bench_line(args, env_extra, timeout=600):
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("route", ["replicate", "exchange"])
+def test_bench_gpus_flag_launches_that_many_ranks(route):
+    """a plain `python bench.py --gpus 2` (no torchrun around it) must run TWO ranks and say so.  The box has one
+    GPU: TC_BENCH_ONE_DEVICE=1 puts both ranks on it with gloo for the metrics -- the launcher, the process group, the router,
+    the per-GPU table and the summary are the ones a real node runs."""
+    d = _bench_line(["--gpus", "2", "--steps", "3", "--warmup", "2", "--no-cpu", "--keys", "200000", "--batch", "65536", "--route", route],
+                    {"TC_BENCH_ONE_DEVICE": "1", "MASTER_PORT": str(_free_port())})
+    assert d["n_gpus"] == 2 and len(d["per_gpu"]) == 2 and d["scaling"] == "weak" and d["steps"] == 3
+    assert d["config"]["batch"] == 2 * 65536 and d["value"] > 0
+    assert abs(sum(g["share_of_traffic"] for g in d["per_gpu"]) - 1.0) < 1e-6 and min(g["share_of_traffic"] for g in d["per_gpu"]) > 0.3
+
+
+def test_bench_gpus_1_prints_the_single_gpu_line():
+    d = _bench_line(["--gpus", "1", "--steps", "3", "--warmup", "2", "--no-cpu", "--no-also", "--keys", "200000", "--batch", "65536"], {})
+    assert d["n_gpus"] == 1 and "per_gpu" not in d and d["config"]["batch"] == 65536 and d["verified"] is True
+    for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in d, k
