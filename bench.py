@@ -473,6 +473,165 @@ def keys_bench(a, dev):
     return out
 
 
+def abi_shape_stream(n_keys, n, seed, now0):
+    """One batch of the call a reference-side caller makes (rate_limiter.rs:102-110 per request, stamped by its transport,
+    throttlecrab-server/src/transport/http.rs:128): string keys `key_<id>` (id uniform over the table), the key's own
+    (burst, count, period) -- one of four plans by a hash of the id, handed over with EVERY request as the reference's API
+    does --, quantity 1 or 2, a timestamp per request that is NOT monotone inside the batch (arrival order != stamp order).
+    -> dict of host arrays."""
+    from throttlecrab_amd import workload as W
+    ids = W.uniform_slots(n_keys, n, seed=seed)
+    h = W.splitmix64(ids.astype(np.uint64) ^ np.uint64(0xAB1))
+    plans = np.array([(100, 1000, 3600), (20, 100, 60), (50, 600, 600), (10, 100, 60)], dtype=np.int64)
+    pl = plans[(h % np.uint64(4)).astype(np.int64)]
+    r = W.splitmix64(np.arange(n, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B9))
+    kb, ko = W.string_keys(ids)
+    return {"ids": ids, "key_bytes": kb, "key_off": ko, "max_burst": pl[:, 0].copy(), "count_per_period": pl[:, 1].copy(),
+            "period": pl[:, 2].copy(), "quantity": (1 + (r >> np.uint64(60)) % np.uint64(2)).astype(np.int64),
+            "now_ns": (now0 + (np.arange(n, dtype=np.int64) * 900) // max(1, n // 1000) + ((r >> np.uint64(20)) % np.uint64(200_000)).astype(np.int64))}
+
+
+ABI_COLS = ("max_burst", "count_per_period", "period", "quantity", "now_ns")
+
+
+def abi_shape_bench(a, dev):
+    """the reference-shaped call, timed.  `tc_rate_limit_batch_keys` exactly as rust/throttlecrab-gpu's
+    `GpuRateLimiter::rate_limit_batch` issues it -- HOST pointers, string keys, per-request (burst, count, period), quantity
+    and timestamp, `tc_decision` records out, flags 0, the store's own cleanup policy on (GpuStore::new: adaptive, the server's
+    defaults) -- at 4 Ki, 64 Ki and 1 Mi requests over a table that holds `--keys` keys; the same from pinned buffers
+    (tc_host_alloc), and from a ring of 4 pinned sets with TC_B_ASYNC.  PCIe-inclusive by construction (never `value`).
+    Every call's decisions are compared with the oracle's replay of the same requests in the same order (the dense store keyed
+    by the id inside `key_<id>`: keys and ids correspond one to one, the Store semantics are the same)."""
+    import torch
+
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    S = 10**9
+    n_keys, B = a.keys, a.batch
+    eng = t.Engine(n_keys + B, B, device=dev.index or 0, key_mode=True)
+    eng.set_sweep_policy("adaptive", created_ns=W.T0_NS, min_interval_ns=5 * S, max_interval_ns=300 * S, max_operations=1_000_000)
+    orc = O.DenseOracle(n_keys)
+    th = O.host_threads()
+    # the table: every key seen once (device-pointer batches: not what is measured), with its own plan
+    t_fill = time.perf_counter()
+    for at in range(0, n_keys, B):
+        ids = np.arange(at, min(at + B, n_keys), dtype=np.uint32)
+        kb, ko = W.string_keys(ids)
+        hh = W.splitmix64(ids.astype(np.uint64) ^ np.uint64(0xAB1))
+        plans = np.array([(100, 1000, 3600), (20, 100, 60), (50, 600, 600), (10, 100, 60)], dtype=np.int64)
+        pl = plans[(hh % np.uint64(4)).astype(np.int64)]
+        cols = [torch.from_numpy(pl[:, j].copy()).to(dev) for j in range(3)]
+        eng.rate_limit_batch_keys(torch.from_numpy(kb).to(dev), torch.from_numpy(ko.astype(np.int32)).to(dev), max_burst=cols[0],
+                                  count_per_period=cols[1], period=cols[2], quantity=1, now_ns=W.T0_NS, want=("allowed",))
+        eng.synchronize()
+        orc.batch_slots(ids, pl[:, 0], pl[:, 1], pl[:, 2], 1, W.T0_NS, threads=th)
+    fill_s = time.perf_counter() - t_fill
+    out = {"table_keys": n_keys, "prefill_seconds": fill_s}
+    ok_all, calls_checked, step_no = True, 0, 0
+
+    def check(batch, dec_np, ctx):
+        nonlocal ok_all, calls_checked
+        ref = orc.batch_slots(batch["ids"], batch["max_burst"], batch["count_per_period"], batch["period"], batch["quantity"], batch["now_ns"], threads=th)
+        d = t.Engine.unpack_decisions(dec_np)
+        good = all(np.array_equal(d[f].astype(np.int64), getattr(ref, f).astype(np.int64)) for f in ("allowed", "status", "remaining", "reset_after_ns", "retry_after_ns"))
+        ok_all = ok_all and good
+        calls_checked += 1
+        if not good:
+            log(f"  abi_shape: {ctx} differs from the oracle")
+
+    # The first ~20 TC_B_ASYNC calls of a process each stall the submitting thread for 5-7 ms, once (calls 1, 5, 11, 19 on
+    # every box looked at, whatever the batch size: the runtime growing its pools; tools/abi_stall.py) -- a server pays that
+    # at start-up, a measurement of 8 calls must not: 32 small calls first.
+    wb = abi_shape_stream(n_keys, 4096, 999, W.T0_NS + S // 2)
+    wp = {c: eng.host_alloc(wb[c].size, wb[c].dtype) for c in ("key_bytes", "key_off") + ABI_COLS}
+    for c in wp:
+        wp[c][:] = wb[c]
+    wres = [t.BatchResult(decisions=eng.host_alloc(4 * 4096, np.int64)) for _ in range(4)]
+    for i in range(32):
+        eng.wait_batches(3)
+        eng.rate_limit_batch_keys(wp["key_bytes"], wp["key_off"], **{c: wp[c] for c in ABI_COLS}, want=("decisions",), out=wres[i % 4], async_=True)
+        orc.batch_slots(wb["ids"], wb["max_burst"], wb["count_per_period"], wb["period"], wb["quantity"], wb["now_ns"], threads=th)
+    eng.wait_batches(0)
+    for n, calls in ((4096, 48), (65536, 24), (B, 8)):
+        if n > B:
+            continue
+        distinct = 4
+        batches = []
+        for k in range(distinct):
+            batches.append(abi_shape_stream(n_keys, n, 1000 + step_no, W.T0_NS + S + step_no * 1_000_000))
+            step_no += 1
+        bytes_in = sum(int(batches[0][c].nbytes) for c in ("key_bytes", "key_off") + ABI_COLS) / n
+        leg = {"requests": n, "bytes_in_per_request": bytes_in, "bytes_out_per_request": 32}
+        # (i) pageable host arrays, synchronous: GpuRateLimiter::rate_limit_batch verbatim
+        res = [t.BatchResult(decisions=np.zeros(4 * n, np.int64)) for _ in range(distinct)]
+        for k in range(2):  # warm: staging allocations, the first sweep
+            eng.rate_limit_batch_keys(batches[k]["key_bytes"], batches[k]["key_off"], **{c: batches[k][c] for c in ABI_COLS}, want=("decisions",), out=res[k])
+            check(batches[k], res[k].decisions, f"{n} warm")
+        t0 = time.perf_counter()
+        for i in range(calls):
+            k = i % distinct
+            eng.rate_limit_batch_keys(batches[k]["key_bytes"], batches[k]["key_off"], **{c: batches[k][c] for c in ABI_COLS}, want=("decisions",), out=res[k])
+            if i >= calls - distinct or i < distinct:
+                pass
+        dt = time.perf_counter() - t0
+        leg["sync_pageable"] = {"value": calls * n / dt, "unit": "decisions/s", "us_per_call": 1e6 * dt / calls, "calls": calls}
+        # the oracle follows in call order (the engine's results of the last `distinct` calls are still in `res`)
+        for i in range(calls):
+            k = i % distinct
+            if i >= calls - distinct:
+                check(batches[k], res[k].decisions, f"{n} sync call {i}")
+            else:
+                orc.batch_slots(batches[k]["ids"], batches[k]["max_burst"], batches[k]["count_per_period"], batches[k]["period"], batches[k]["quantity"], batches[k]["now_ns"], threads=th)
+        # (ii) the same arrays in pinned memory (tc_host_alloc), synchronous; (iii) TC_B_ASYNC over a ring of 4 pinned sets
+        pinned = []
+        for k in range(distinct):
+            pb = {c: eng.host_alloc(batches[k][c].size, batches[k][c].dtype) for c in ("key_bytes", "key_off") + ABI_COLS}
+            for c in pb:
+                pb[c][:] = batches[k][c]
+            pinned.append((pb, t.BatchResult(decisions=eng.host_alloc(4 * n, np.int64))))
+        for mode in ("sync_pinned", "async_pinned_ring4"):
+            asy = mode.startswith("async")
+            # warm: a freshly pinned array stalls the submitting thread for 5-7 ms the first few times a transfer touches it
+            # (tools/abi_stall.py: calls 1, 5, 11, 19 of a ring of 4 sets, then never again) -- a server's staging buffers live
+            # as long as the server; here every leg pins new ones, so each set is used six times before the clock starts
+            n_warm = 6 * distinct if mode == "sync_pinned" or asy else 0
+            for i in range(n_warm):
+                pb, r_ = pinned[i % distinct]
+                if asy:
+                    eng.wait_batches(distinct - 1)
+                eng.rate_limit_batch_keys(pb["key_bytes"], pb["key_off"], **{c: pb[c] for c in ABI_COLS}, want=("decisions",), out=r_, async_=asy)
+            eng.wait_batches(0)
+            for i in range(n_warm):
+                k = i % distinct
+                orc.batch_slots(batches[k]["ids"], batches[k]["max_burst"], batches[k]["count_per_period"], batches[k]["period"], batches[k]["quantity"], batches[k]["now_ns"], threads=th)
+            t0 = time.perf_counter()
+            for i in range(calls):
+                pb, r_ = pinned[i % distinct]
+                if asy:
+                    eng.wait_batches(distinct - 1)  # the oldest set of the ring is free again
+                eng.rate_limit_batch_keys(pb["key_bytes"], pb["key_off"], **{c: pb[c] for c in ABI_COLS}, want=("decisions",), out=r_, async_=asy)
+            if asy:
+                eng.wait_batches(0)
+            dt = time.perf_counter() - t0
+            leg[mode] = {"value": calls * n / dt, "unit": "decisions/s", "us_per_call": 1e6 * dt / calls, "calls": calls}
+            for i in range(calls):
+                k = i % distinct
+                if i >= calls - distinct:
+                    check(batches[k], pinned[k][1].decisions, f"{n} {mode} call {i}")
+                else:
+                    orc.batch_slots(batches[k]["ids"], batches[k]["max_burst"], batches[k]["count_per_period"], batches[k]["period"], batches[k]["quantity"], batches[k]["now_ns"], threads=th)
+        out[str(n)] = leg
+        del pinned, res, batches
+    c = eng.counters()
+    st = eng.sweep_stats()
+    out["verified"] = {"ok": bool(ok_all and c["errors"] == 0 and eng.selfcheck() == 0), "calls_compared_with_the_oracle": calls_checked,
+                       "note": "the last 4 calls of every leg field by field; the oracle replays every call in between to stay in step"}
+    out["store_cleanups"] = {k: st[k] for k in ("sweeps", "sweeps_by_time", "sweeps_by_operations", "sweeps_by_size", "sweeps_for_room", "retries", "feed_waits")}
+    eng.close()
+    return out
+
+
 def cpu_baseline(kind, n_keys, batch, n_batches):
     """The oracle (a port of RateLimiter<AdaptiveStore>, string keys "key_<slot>") timed on this box's host cores:
     (i) one thread over the first n_batches of the same stream == the reference's one actor task
@@ -1030,7 +1189,11 @@ def main():
         # recorded under "errors" and the headline line is still printed -- the driver's record depends on that line.
         errors = {}
 
+        only = [x for x in os.environ.get("TC_BENCH_LEGS", "").split(",") if x]  # (iteration aid: run only the legs whose name contains one of these)
+
         def leg(name, fn):
+            if only and not any(o in name for o in only):
+                return
             log(name)
             try:
                 fn()
@@ -1104,6 +1267,15 @@ def main():
             if "eng2" in held:
                 leg("close second engine", held["eng2"].close)
             leg("string keys", string_keys)
+
+            def abi_shape():
+                ab = abi_shape_bench(a, dev)
+                detail["abi_shape"] = ab
+                result["abi_shape"] = {k: {m: _pick(v[m], ("value", "us_per_call")) for m in ("sync_pageable", "sync_pinned", "async_pinned_ring4")}
+                                       for k, v in ab.items() if isinstance(v, dict) and "requests" in v}
+                result["abi_shape"]["verified"] = ab["verified"]["ok"]
+                verified["abi_shape"] = ab["verified"]
+            leg("abi shape (host pointers, string keys, per-request parameters)", abi_shape)
         if not a.no_cpu and not a.profile_run:
             def cpu():
                 result["cpu_baseline"] = cpu_baseline(stream, a.keys, a.batch, a.cpu_sample_batches)
@@ -1199,11 +1371,13 @@ def compact_line(result):
         c["string_keys"] = {k: _pick(v, one + ("launches_per_batch",)) for k, v in result["string_keys"].items() if isinstance(v, dict)}
     if isinstance(result.get("per_gpu"), list):
         c["per_gpu"] = [_pick(g, ("rank", "share_of_traffic", "decisions_per_s")) for g in result["per_gpu"]][:8]
+    if isinstance(result.get("abi_shape"), dict):  # requests per call -> decisions/s by mode (PCIe-inclusive)
+        c["abi_shape"] = {k: ({m: vv.get("value") for m, vv in v.items()} if isinstance(v, dict) else v) for k, v in result["abi_shape"].items()}
     c["detail"] = DETAIL_PATH
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > COMPACT_LIMIT:  # shed the optional parts, largest first, rather than break the contract
-        for k in ("per_gpu", "string_keys", "per_key_plans", "general_uniform", "general_zipf", "fixed_layout", "wide_layout", "allowed_fraction"):
+        for k in ("per_gpu", "string_keys", "per_key_plans", "abi_shape", "general_uniform", "general_zipf", "fixed_layout", "wide_layout", "allowed_fraction"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= COMPACT_LIMIT:

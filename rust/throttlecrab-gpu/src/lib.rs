@@ -152,6 +152,7 @@ pub struct Request<'a> {
 /// `RateLimiter<GpuStore>` with the decision on the device.
 pub struct GpuRateLimiter {
     store: GpuStore,
+    staging: Staging,
 }
 
 fn decode(r: &ffi::tc_decision, limit: i64, quantity: i64) -> Result<(bool, RateLimitResult), CellError> {
@@ -171,9 +172,12 @@ fn decode(r: &ffi::tc_decision, limit: i64, quantity: i64) -> Result<(bool, Rate
     }
 }
 
+// single owner, like the store (the pinned staging is plain memory owned by this value)
+unsafe impl Send for GpuRateLimiter {}
+
 impl GpuRateLimiter {
     pub fn new(store: GpuStore) -> Self {
-        GpuRateLimiter { store }
+        GpuRateLimiter { store, staging: Staging::new() }
     }
 
     pub fn store_mut(&mut self) -> &mut GpuStore {
@@ -223,34 +227,39 @@ impl GpuRateLimiter {
         if n == 0 {
             return;
         }
-        let mut arena: Vec<u8> = Vec::with_capacity(reqs.iter().map(|r| r.key.len()).sum());
-        let mut off: Vec<u32> = Vec::with_capacity(n + 1);
-        off.push(0);
-        for r in reqs {
-            arena.extend_from_slice(r.key.as_bytes());
-            off.push(arena.len() as u32);
+        // The request columns are marshalled straight into PINNED staging (tc_host_alloc) that lives as long as the limiter:
+        // the engine's transfers to and from pinned memory run at PCIe speed, and a large batch from pinned arrays is
+        // pipelined in chunks (its inputs cross the link while earlier chunks are evaluated and their results go back);
+        // pageable `Vec`s would be staged once more by the runtime, with the caller blocked meanwhile.
+        let key_bytes: usize = reqs.iter().map(|r| r.key.len()).sum();
+        self.staging.reserve(n, key_bytes.max(1));
+        let st = &mut self.staging;
+        let mut at = 0usize;
+        unsafe {
+            *st.off.ptr = 0;
+            for (i, r) in reqs.iter().enumerate() {
+                std::ptr::copy_nonoverlapping(r.key.as_ptr(), st.arena.ptr.add(at), r.key.len());
+                at += r.key.len();
+                *st.off.ptr.add(i + 1) = at as u32;
+                *st.burst.ptr.add(i) = r.max_burst;
+                *st.count.ptr.add(i) = r.count_per_period;
+                *st.period.ptr.add(i) = r.period;
+                *st.qty.ptr.add(i) = r.quantity;
+                *st.now.ptr.add(i) = ns(r.now);
+            }
         }
-        if arena.is_empty() {
-            arena.push(0); // (a non-null arena pointer even when every key is empty)
-        }
-        let burst: Vec<i64> = reqs.iter().map(|r| r.max_burst).collect();
-        let count: Vec<i64> = reqs.iter().map(|r| r.count_per_period).collect();
-        let period: Vec<i64> = reqs.iter().map(|r| r.period).collect();
-        let qty: Vec<i64> = reqs.iter().map(|r| r.quantity).collect();
-        let now: Vec<i64> = reqs.iter().map(|r| ns(r.now)).collect();
-        let mut dec = vec![ffi::tc_decision::default(); n];
         let b = ffi::tc_batch {
             struct_size: std::mem::size_of::<ffi::tc_batch>() as u32,
             flags: 0,
             n: n as u64,
             slot: std::ptr::null(),
-            key_bytes: arena.as_ptr(),
-            key_off: off.as_ptr(),
-            max_burst: burst.as_ptr(),
-            count_per_period: count.as_ptr(),
-            period: period.as_ptr(),
-            quantity: qty.as_ptr(),
-            now_ns: now.as_ptr(),
+            key_bytes: st.arena.ptr,
+            key_off: st.off.ptr,
+            max_burst: st.burst.ptr,
+            count_per_period: st.count.ptr,
+            period: st.period.ptr,
+            quantity: st.qty.ptr,
+            now_ns: st.now.ptr,
             max_burst_scalar: 0,
             count_per_period_scalar: 0,
             period_scalar: 0,
@@ -264,7 +273,7 @@ impl GpuRateLimiter {
             retry_after_ns: std::ptr::null_mut(),
             status: std::ptr::null_mut(),
             result4: std::ptr::null_mut(),
-            decisions: dec.as_mut_ptr(),
+            decisions: st.dec.ptr,
             order: std::ptr::null_mut(),
             n_segments: 0,
             reserved_seg: 0,
@@ -280,6 +289,65 @@ impl GpuRateLimiter {
         }
         // TC_E_TABLE_FULL: the keys that fit were applied, the others carry status Internal (with the store's cleanup policy
         // on, the engine has already swept and applied them once more before it reports this: the table is full of LIVE keys)
-        out.extend((0..n).map(|i| decode(&dec[i], burst[i], qty[i])));
+        out.extend((0..n).map(|i| unsafe { decode(&*st.dec.ptr.add(i), *st.burst.ptr.add(i), *st.qty.ptr.add(i)) }));
+    }
+}
+
+/// One pinned host array (tc_host_alloc / tc_host_free), grown by doubling and kept across calls.
+struct Pinned<T> {
+    ptr: *mut T,
+    cap: usize,
+}
+
+impl<T> Pinned<T> {
+    const fn new() -> Self {
+        Pinned { ptr: std::ptr::null_mut(), cap: 0 }
+    }
+    fn reserve(&mut self, n: usize) {
+        if n <= self.cap {
+            return;
+        }
+        let cap = n.next_power_of_two().max(1024);
+        unsafe {
+            ffi::tc_host_free(self.ptr as *mut std::os::raw::c_void);
+            self.ptr = ffi::tc_host_alloc(cap * std::mem::size_of::<T>()) as *mut T;
+        }
+        assert!(!self.ptr.is_null(), "tc_host_alloc failed");
+        self.cap = cap;
+    }
+}
+
+impl<T> Drop for Pinned<T> {
+    fn drop(&mut self) {
+        unsafe { ffi::tc_host_free(self.ptr as *mut std::os::raw::c_void) }
+    }
+}
+
+/// The marshalling buffers of `rate_limit_batch`: key arena, offsets, the five request columns, the decision records.
+struct Staging {
+    arena: Pinned<u8>,
+    off: Pinned<u32>,
+    burst: Pinned<i64>,
+    count: Pinned<i64>,
+    period: Pinned<i64>,
+    qty: Pinned<i64>,
+    now: Pinned<i64>,
+    dec: Pinned<ffi::tc_decision>,
+}
+
+impl Staging {
+    const fn new() -> Self {
+        Staging { arena: Pinned::new(), off: Pinned::new(), burst: Pinned::new(), count: Pinned::new(), period: Pinned::new(), qty: Pinned::new(),
+                  now: Pinned::new(), dec: Pinned::new() }
+    }
+    fn reserve(&mut self, n: usize, key_bytes: usize) {
+        self.arena.reserve(key_bytes);
+        self.off.reserve(n + 1);
+        self.burst.reserve(n);
+        self.count.reserve(n);
+        self.period.reserve(n);
+        self.qty.reserve(n);
+        self.now.reserve(n);
+        self.dec.reserve(n);
     }
 }

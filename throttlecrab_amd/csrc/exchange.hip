@@ -26,6 +26,7 @@ struct tc_exchange {
     std::vector<uint32_t> seg_n;
     uint64_t wait_ns[3] = {0, 0, 0};    // host time spent waiting: for inbox slots (route), for the router's tag (post), for the sources (collect)
     uint64_t next_route = 0, next_post = 0; // a phase repeated for a step it has already done (a TC_E_AGAIN retry of tc_exchange_step) does nothing
+    uint64_t wait_limit_ns = 30ull * 1000000000ull; // a blocking wait on a peer / the device gives up after this long (TCGPU_EXCHANGE_WAIT_S)
 };
 
 static inline uint32_t* inbox_of(const tc_exchange* x, uint32_t d, uint32_t k, uint32_t s) {
@@ -85,6 +86,10 @@ extern "C" int tc_exchange_create(tc_engine* e, const tc_exchange_config* c, tc_
         memset(x->counts_host[r], 0, (c->world + 1) * sizeof(uint32_t));
     }
     TC_HIP(e, hipDeviceSynchronize());
+    if (const char* ws = getenv("TCGPU_EXCHANGE_WAIT_S")) {
+        const double sec = atof(ws);
+        if (sec > 0) x->wait_limit_ns = (uint64_t)(sec * 1e9);
+    }
     *out = x;
     return TC_E_OK;
 }
@@ -134,6 +139,9 @@ static inline uint64_t mono_ns() {
                 if ((x)->flags & TC_X_NONBLOCKING) return TC_E_AGAIN; \
                 if ((++_spins & 1023u) == 0u) {                 \
                     TC_CHECK_POISON((x)->e);                    \
+                    /* (a dead peer or a mis-set pipeline must not hang the caller for good) */ \
+                    if (mono_ns() - _t0 > (x)->wait_limit_ns)   \
+                        return fail((x)->e, TC_E_AGAIN, "tc_exchange: gave up waiting for a peer rank / the device (TCGPU_EXCHANGE_WAIT_S); the step was not done"); \
                     sched_yield();                              \
                 }                                               \
             }                                                   \
@@ -221,6 +229,10 @@ extern "C" int tc_exchange_evaluate(tc_exchange* x, uint64_t step, const tc_batc
     uint64_t total = 0;
     for (uint32_t s = 0; s < x->world; ++s) total += x->seg_n[s];
     const uint64_t cap = e->max_batch;
+    // (checked BEFORE any chunk is issued -- ADVICE r4: found while building the second chunk, the first had already changed
+    // the resident state and the step's completion was never recorded)
+    if (total > cap && (b.flags & TC_B_GROUPED_OUTPUT)) return fail(e, TC_E_UNSUPPORTED, "tc_exchange_evaluate: grouped output of a step larger than max_batch");
+    if (total > cap && b.allowed_bits) return fail(e, TC_E_UNSUPPORTED, "tc_exchange_evaluate: allowed_bits of a step larger than max_batch");
     // cut the concatenation into chunks of at most max_batch requests (the common case: one chunk, nothing copied)
     const uint32_t* piece_ptr[2 * TC_MAX_SEGMENTS];
     uint32_t piece_n[2 * TC_MAX_SEGMENTS];
@@ -251,9 +263,7 @@ extern "C" int tc_exchange_evaluate(tc_exchange* x, uint64_t step, const tc_batc
         c.seg_slot = piece_ptr;
         c.seg_n = piece_n;
         if (at) { // later chunks write behind the earlier ones
-            if (b.flags & TC_B_GROUPED_OUTPUT) return fail(e, TC_E_UNSUPPORTED, "tc_exchange_evaluate: grouped output of a step larger than max_batch");
             if (c.allowed) c.allowed += at;
-            if (c.allowed_bits) return fail(e, TC_E_UNSUPPORTED, "tc_exchange_evaluate: allowed_bits of a step larger than max_batch");
             if (c.limit) c.limit += at;
             if (c.remaining) c.remaining += at;
             if (c.reset_after_ns) c.reset_after_ns += at;
@@ -264,7 +274,16 @@ extern "C" int tc_exchange_evaluate(tc_exchange* x, uint64_t step, const tc_batc
             c.flags &= ~TC_B_OUTPUTS_IDLE; // (only the chunk that starts the arrays may preset them)
         }
         rc = tc_rate_limit_batch_slots(e, &c);
-        if (rc != TC_E_OK) return rc;
+        if (rc != TC_E_OK) {
+            // a chunk failed with earlier chunks of the step already applied: the step cannot be completed, and sources that
+            // wait for its inbox slots must not spin on a `done` word that never moves -- the engine is poisoned (sticky
+            // TC_E_INVARIANT on this rank; the peers' waits run into their limit)
+            if (at) {
+                *e->poison_host = 1u;
+                e->err += " (tc_exchange_evaluate: a later chunk of the step failed after earlier ones were applied: engine poisoned)";
+            }
+            return rc;
+        }
         at += size;
     }
     // completion of this step's evaluation frees its inbox slots: an event on the stream the ENGINE evaluates on
@@ -286,6 +305,9 @@ extern "C" int tc_exchange_evaluate(tc_exchange* x, uint64_t step, const tc_batc
 extern "C" int tc_exchange_step(tc_exchange* x, uint64_t step, const uint32_t* d_global_id_ahead, uint32_t n_ahead, uint32_t route_ahead,
                                 uint32_t post_ahead, const tc_batch* tmpl, uint64_t* decided) {
     if (!x) return TC_E_INVALID_ARG;
+    // a source may run ring - 1 steps ahead of a destination, and a router's count block comes round every ROUTES steps
+    if (route_ahead >= x->ring || post_ahead > route_ahead || route_ahead - post_ahead >= tc_exchange::ROUTES)
+        return fail(x->e, TC_E_INVALID_ARG, "tc_exchange_step: need post_ahead <= route_ahead < ring and route_ahead - post_ahead < 8");
     int rc;
     if (d_global_id_ahead && (rc = tc_exchange_route(x, step + route_ahead, d_global_id_ahead, n_ahead)) != TC_E_OK) return rc;
     if ((rc = tc_exchange_post(x, step + post_ahead)) != TC_E_OK) return rc;

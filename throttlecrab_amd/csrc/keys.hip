@@ -128,7 +128,11 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     const bool piped = e->key_stream != nullptr && e->n_aux != 0;
     tc_engine::SortSet& ss = e->sets[e->next_set];
     hipStream_t ks = piped ? e->key_stream : cur_stream(e);
-    const size_t total = b.key_off[n];
+    // (the chunk of a larger batch: its offsets start at `base`, not 0 -- only its own bytes are staged, and the kernels are
+    // handed the staging pointer moved back by `base`, so that bytes + key_off[i] lands where it should)
+    const size_t base = b.key_off[0];
+    if (b.key_off[n] < base) return fail(e, TC_E_INVALID_ARG, "key_off must not decrease");
+    const size_t total = b.key_off[n] - base;
     if (total > ss.h_key_cap) { // grow (hipFree waits for everything that may still read the old buffer)
         if (ss.h_key_bytes) (void)hipFree(ss.h_key_bytes);
         ss.h_key_bytes = nullptr;
@@ -140,9 +144,12 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     if (!ss.h_key_off) TC_HIP(e, hipMalloc(&ss.h_key_off, (e->max_batch + 1) * sizeof(uint32_t)));
     // the key stage and the evaluation that last used this set's staging and slot column are done
     if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ks, ss.consumed, 0));
-    if (total) TC_HIP(e, copy_async(e, ss.h_key_bytes, b.key_bytes, total, hipMemcpyHostToDevice, ks));
+    if (total) TC_HIP(e, copy_async(e, ss.h_key_bytes, b.key_bytes + base, total, hipMemcpyHostToDevice, ks));
     TC_HIP(e, copy_async(e, ss.h_key_off, b.key_off, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ks));
-    TC_TRY(resolve_keys_device(e, ss.h_key_bytes, ss.h_key_off, n, true, ss.k_slot, piped));
+    TC_TRY(resolve_keys_device(e, ss.h_key_bytes - base, ss.h_key_off, n, true, ss.k_slot, piped));
+    // (the engine cleans by itself: a synchronous caller may have to apply rejected requests again -- it needs the slots)
+    if (e->as.chunk_slots_at != UINT64_MAX)
+        TC_HIP(e, hipMemcpyAsync(e->k_slot + e->as.chunk_slots_at, ss.k_slot, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToDevice, ks));
     tc_batch d = b;
     d.flags = (b.flags & ~(TC_B_ASYNC | TC_B_INPUTS_READY)) | TC_B_DEVICE_PTRS | (piped ? TC_B_INPUTS_READY : 0u);
     d.slot = ss.k_slot;
@@ -157,9 +164,35 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     return finish_async(e, b);
 }
 
+// a large synchronous host-pointer key batch, pipelined in chunks (engine.hpp: HOST_CHUNK_MIN)
+static int run_keys_host_chunked(tc_engine* e, const tc_batch& b) {
+    size_t mine = 0;
+    int rc = TC_E_OK;
+    uint64_t at = 0;
+    for (const uint64_t cn : host_chunk_plan(e, b.n)) {
+        if (rc != TC_E_OK) break;
+        tc_batch c;
+        host_sub_batch(b, at, cn, c);
+        e->as.chunk_slots_at = auto_sweep_on(e) ? at : UINT64_MAX;
+        rc = run_keys_host_async(e, c);
+        e->as.chunk_slots_at = UINT64_MAX;
+        if (rc == TC_E_OK) ++mine;
+        else if (at) e->err += " (a later chunk of a pipelined host batch: the " + std::to_string(at) + " requests before it were applied)";
+        at += cn;
+    }
+    e->batches -= mine ? mine - 1 : 0; // one batch, as far as the caller is concerned
+    const int wrc = wait_own_async(e, mine);
+    if (rc != TC_E_OK) return rc;
+    if (wrc != TC_E_OK) return wrc;
+    // (the slot copies behind the key stages -- what retry_rejected reads -- are the last thing on the key stream)
+    if (auto_sweep_on(e) && e->key_stream) TC_HIP(e, hipStreamSynchronize(e->key_stream));
+    return check_key_errors(e);
+}
+
 // a validated key batch through the path its flags name
 static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
     if (b.flags & TC_B_ASYNC) return run_keys_host_async(e, b);
+    if (host_chunking_applies(e, b)) return run_keys_host_chunked(e, b);
     const uint8_t* d_bytes = b.key_bytes;
     const uint32_t* d_off = b.key_off;
     const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
@@ -194,9 +227,14 @@ static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
     // slot column already on the device
     TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
     TC_HIP(e, hipMemcpyAsync(e->stage.slot, e->k_slot, b.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, cur_stream(e)));
-    rc = run_slots_host_staged(e, b);
+    uint32_t flag = 0;
+    rc = run_slots_host_staged(e, b, &flag);
     if (rc != TC_E_OK) return rc;
-    return check_key_errors(e);
+    if (flag) {
+        TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, cur_stream(e)));
+        return fail(e, TC_E_TABLE_FULL, "key table full: some keys got status Internal (raise capacity or sweep)");
+    }
+    return TC_E_OK;
 }
 
 // A SYNCHRONOUS host-pointer key batch came back with TC_E_TABLE_FULL while the engine cleans by itself: where the reference's

@@ -41,15 +41,25 @@ static int compact_retired(tc_engine* e, bool force, std::vector<std::pair<std::
     }
     if (due || force || trim) {
         std::fill(rt.begin(), rt.end(), kt::RetiredRec{});
+        // most denied first, and no key further from its home than the device looks (RETIRED_PROBES records: retire_denials /
+        // resurrect_denials stop there -- a key placed beyond would be invisible to them, then duplicated or its count lost;
+        // ADVICE r4).  A key that does not fit is dropped like the keys TopDeniedKeys::cleanup drops (the least denied go first).
+        std::sort(keep.begin(), keep.end(), by_count_then_key);
+        size_t kept = 0;
         for (const auto& kv : keep) {
             const uint64_t h = kt::hash_key((const uint8_t*)kv.first.data(), (uint32_t)kv.first.size());
             uint32_t pos = (uint32_t)(h >> 17) & (kt::RETIRED_CAP - 1u);
-            while (rt[pos].tag != kt::RT_EMPTY) pos = (pos + 1u) & (kt::RETIRED_CAP - 1u);
+            uint32_t probes = 0;
+            while (rt[pos].tag != kt::RT_EMPTY && probes < kt::RETIRED_PROBES) pos = (pos + 1u) & (kt::RETIRED_CAP - 1u), ++probes;
+            if (probes >= kt::RETIRED_PROBES) continue;
+            if (kept != (size_t)(&kv - keep.data())) keep[kept] = kv; // (compacts `keep` in place: what the table holds afterwards)
+            ++kept;
             rt[pos].tag = h | kt::RT_VALID;
             rt[pos].count = (uint32_t)kv.second;
             rt[pos].len = (uint32_t)kv.first.size();
             memcpy(rt[pos].bytes, kv.first.data(), kv.first.size());
         }
+        keep.resize(kept);
         stats = kt::RetiredRec{};
         stats.len = (uint32_t)keep.size();
         TC_HIP(e, hipMemcpyAsync(e->retired, rt.data(), rt.size() * sizeof(kt::RetiredRec), hipMemcpyHostToDevice, s));

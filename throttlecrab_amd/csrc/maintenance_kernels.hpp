@@ -553,7 +553,7 @@ struct PolicyFeed {
     unsigned long long free_slots; // string mode
     long long last_now;           // the call's last timestamp
     unsigned long long seq_begin; // written first
-    unsigned long long pad;
+    unsigned long long inserted;  // TC_CNT_KEYS_INSERTED: keys bound so far (string mode)
 };
 static __global__ __launch_bounds__(ev::NSHARD) void k_policy_feed(const unsigned long long* __restrict__ counters, PolicyFeed* __restrict__ feed,
                                                                    unsigned long long seq, const int64_t* __restrict__ now_last, int64_t now_scalar,
@@ -582,6 +582,7 @@ static __global__ __launch_bounds__(ev::NSHARD) void k_policy_feed(const unsigne
         f->entries = counters[TC_CNT_LIVE_SLOTS];
     }
     f->last_now = now_last != nullptr ? (long long)*now_last : (long long)now_scalar;
+    f->inserted = __hip_atomic_load(&counters[TC_CNT_KEYS_INSERTED], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __threadfence_system();
     f->seq_end = seq;
 }

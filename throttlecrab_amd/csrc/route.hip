@@ -54,8 +54,14 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
         }
     }
     const uint32_t n = (uint32_t)r.n, tiles = (n + rt::TILE - 1) / rt::TILE;
-    const size_t words = 2 * (size_t)tiles * r.world + 4 + 2 * (size_t)rt::ONE_PASS_TILES; // (tile_cnt: u32, or the split router's u64 words)
-    if (words > e->route_ws_words) {
+    // One scratch lane: [ look-back words of k_route_one: ONE_PASS_TILES x u64 | tile_cnt: u32 [world][tiles] of the count / scan /
+    // scatter routers and of k_route_one | ... FIRST HALF ends | the split router's tagged u64 words [world][tiles] | ticket: 2 ].
+    // The split router's words are validated by the call's sequence number in their high half and never cleared, so no router
+    // that writes plain u32 counts may ever touch them (they used to share tile_cnt's place, and a stale
+    // odd-indexed count equal to a later call's small sequence number read as "this tile has published"): they have the
+    // second half of the lane to themselves, at a place that does not move while the allocation stands.
+    const size_t half_need = 2 * (size_t)rt::ONE_PASS_TILES + 2 * (size_t)tiles * r.world + 2;
+    if (2 * half_need > e->route_ws_words) {
         if (e->route_ws) {
             TC_HIP(e, hipDeviceSynchronize()); // (whatever streams earlier routers ran on)
             (void)hipFree(e->route_ws);
@@ -64,7 +70,7 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
         }
         // one scratch per grouping stream + one (lane 0) for every other stream a router may run on: routers on different
         // grouping streams never wait for one another, lane 0's users are ordered by an event
-        const size_t each = (words * 2 + 1) & ~(size_t)1;
+        const size_t each = 4 * half_need; // (room to grow: a reallocation drains the device)
         TC_HIP(e, hipMalloc(&e->route_ws, each * (1 + AUX_MAX) * sizeof(uint32_t)));
         // (hipMemset on device memory returns before the fill has run, and the fill runs on the NULL stream, which the
         // engine's non-blocking streams are not ordered behind: without the wait the fill could land on top of the
@@ -83,6 +89,7 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     uint32_t* scratch = e->route_ws + (size_t)lane * e->route_ws_words;
     unsigned long long* status = reinterpret_cast<unsigned long long*>(scratch); // [ONE_PASS_TILES] look-back words of the one-pass router
     w.tile_cnt = scratch + 2 * (size_t)rt::ONE_PASS_TILES;
+    unsigned long long* split_status = reinterpret_cast<unsigned long long*>(scratch + e->route_ws_words / 2); // (route_ws_words is a multiple of 4)
     w.totals = r.out_count;
     w.tiles = tiles;
     w.host_totals = r.out_count_host;
@@ -108,8 +115,8 @@ extern "C" int tc_route_batch(tc_engine* e, const tc_route* rp) {
     } else if (r.out_dst && r.only < 0 && tiles <= rt::ONE_PASS_TILES && !getenv("TCGPU_ROUTE_3PASS")) {
         // every destination into its own buffer (the exchange): one pass as well
         if (++e->route_seq == 0u) e->route_seq = 1u;
-        hipLaunchKernelGGL(rt::k_route_split_one, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w,
-                           reinterpret_cast<unsigned long long*>(w.tile_cnt), e->route_seq, split, e->counters + (TC_CNT_COUNT + 1) + 3);
+        hipLaunchKernelGGL(rt::k_route_split_one, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w, split_status, e->route_seq, split,
+                           e->counters + (TC_CNT_COUNT + 1) + 3);
     } else {
         hipLaunchKernelGGL(rt::k_route_count, dim3(tiles), dim3(rt::THREADS), 0, s, r.global_id, n, m, w);
         hipLaunchKernelGGL(rt::k_route_scan, dim3(r.world), dim3(rt::THREADS), 0, s, w);

@@ -474,8 +474,10 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             hipStream_t ax = e->aux[e->next_aux];
             e->next_aux = (e->next_aux + 1) % e->n_aux;
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
-            if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
+            // (the request columns do not depend on the key stage: their transfer goes out before the wait for it -- round 5: it
+            // used to sit behind that wait, so that a chunk's columns only started to cross PCIe once its keys were resolved)
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
+            if (e->wait_before_sort) TC_HIP(e, hipStreamWaitEvent(ax, e->wait_before_sort, 0)); // its key stage
             if (b.n_segments) TC_TRY(gather_segments(e, ss, b, n, ax, p, &d_slot));
             if (bucketed && !bucket_partition(e, ss, ax, d_slot, n)) return fail(e, TC_E_HIP, "bucket partition launch failed");
             const bool ride = e->stop_events && !e->prof_on; // `sorted` rides on the last pass's own completion signal
@@ -550,7 +552,9 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
 
 // Host-pointer batch whose slot column is already in e->stage.slot: stage the
 // other inputs, run, copy the outputs back, synchronise.
-int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
+// key_error_flag: a key batch -- "did a key fail to get a slot" comes back with the results, behind the same wait (it used to be
+// a copy and a wait of its own behind this one: ~25 us of a 4 Ki-request call's 200)
+int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag) {
     const uint64_t n = b.n;
     hipStream_t s = cur_stream(e);
     tc_batch d = b;
@@ -571,6 +575,7 @@ int run_slots_host_staged(tc_engine* e, const tc_batch& b) {
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d));
     TC_TRY(copy_outputs_back(e, b, s));
+    if (key_error_flag) TC_HIP(e, hipMemcpyAsync(key_error_flag, e->kt.error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
     return poisoned(e); // (a synchronous batch whose kernels flagged an invariant fails itself, not the next call)
 }
@@ -607,6 +612,68 @@ static int run_slots_host_async(tc_engine* e, const tc_batch& b) {
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d, &hin));
     return finish_async(e, b);
+}
+
+bool host_arrays_pinned(const tc_batch& b) {
+    const void* arrays[] = {b.slot, b.key_bytes, b.key_off, b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns, b.allowed, b.allowed_bits,
+                            b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns, b.status, b.result4, b.decisions};
+    for (const void* a : arrays)
+        if (a && !device_view_of_host(a)) return false;
+    return true;
+}
+
+void host_sub_batch(const tc_batch& b, uint64_t at, uint64_t cn, tc_batch& c) {
+    c = b;
+    c.n = cn;
+    c.flags |= TC_B_ASYNC;
+    if (c.slot) c.slot += at;
+    if (c.key_off) c.key_off += at; // (offsets stay absolute into key_bytes: the staging copies the chunk's byte range only)
+    if (c.max_burst) c.max_burst += at;
+    if (c.count_per_period) c.count_per_period += at;
+    if (c.period) c.period += at;
+    if (c.quantity) c.quantity += at;
+    if (c.now_ns) c.now_ns += at;
+    if (c.allowed) c.allowed += at;
+    if (c.allowed_bits) c.allowed_bits += at / 64;
+    if (c.limit) c.limit += at;
+    if (c.remaining) c.remaining += at;
+    if (c.reset_after_ns) c.reset_after_ns += at;
+    if (c.retry_after_ns) c.retry_after_ns += at;
+    if (c.status) c.status += at;
+    if (c.result4) c.result4 += 4 * at;
+    if (c.decisions) c.decisions += at;
+}
+
+int wait_own_async(tc_engine* e, size_t mine) {
+    if (mine == 0 || e->async_done.empty()) return poisoned(e);
+    // completion is in issue order: the newest one done means all of them are (earlier TC_B_ASYNC batches of the caller's stay
+    // in the queue -- complete, but the caller's to collect with tc_wait_batches)
+    TC_HIP(e, hipEventSynchronize(e->async_done.back()));
+    for (size_t k = 0; k < mine && !e->async_done.empty(); ++k) {
+        e->async_pool.push_back(e->async_done.back());
+        e->async_done.pop_back();
+    }
+    return poisoned(e);
+}
+
+static int run_slots_host_async(tc_engine* e, const tc_batch& b);
+// a large synchronous host-pointer slot batch, pipelined in chunks (engine.hpp: HOST_CHUNK_MIN)
+static int run_slots_host_chunked(tc_engine* e, const tc_batch& b) {
+    size_t mine = 0;
+    int rc = TC_E_OK;
+    uint64_t at = 0;
+    for (const uint64_t cn : host_chunk_plan(e, b.n)) {
+        if (rc != TC_E_OK) break;
+        tc_batch c;
+        host_sub_batch(b, at, cn, c);
+        rc = run_slots_host_async(e, c);
+        if (rc == TC_E_OK) ++mine;
+        else if (at) e->err += " (a later chunk of a pipelined host batch: the " + std::to_string(at) + " requests before it were applied)";
+        at += cn;
+    }
+    e->batches -= mine ? mine - 1 : 0; // one batch, as far as the caller is concerned
+    const int wrc = wait_own_async(e, mine);
+    return rc != TC_E_OK ? rc : wrc;
 }
 
 // ---- small host-pointer batches: one launch (k_small_batch) ----------------------------------------
@@ -772,6 +839,8 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
         rc = run_slots_host_async(e, b);
     } else if (small_batch_applies(e, b)) {
         rc = run_small_batch(e, b);
+    } else if (host_chunking_applies(e, b)) {
+        rc = run_slots_host_chunked(e, b);
     } else {
         // host pointers: stage in, run, stage out, synchronise
         TC_TRY(stage_need(e, e->stage.slot, e->max_batch));

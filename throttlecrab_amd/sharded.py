@@ -267,12 +267,24 @@ class ExchangeRank:
         except Exception:
             pass
 
+    RETRY_SECONDS = 60.0  # one thread driving several ranks: how long a phase is retried before the pipeline is declared stuck
+
     def _call(self, fn, *args):
+        import time
+        deadline = None
         while True:
             rc = fn(self._h, *args)
             if rc != self._again:
                 self.eng._check(rc)
                 return
+            # TC_E_AGAIN: with TC_X_NONBLOCKING "not this phase's turn yet" -- retried, but not for ever (a mis-set pipeline, e.g.
+            # post_ahead = 0 with one thread driving all ranks, never gets its turn: ADVICE r4); from a blocking exchange it
+            # means the library itself gave up waiting for a peer
+            if deadline is None:
+                deadline = time.monotonic() + self.RETRY_SECONDS
+            if not self._single_thread or time.monotonic() > deadline:
+                from .engine import TcError
+                raise TcError(rc, "exchange phase never got its turn (a peer rank is gone, or route_ahead / post_ahead do not fit the ring)")
             self.fab.poll()  # (one thread drives every shard: let the others publish what they have finished)
 
     def route(self, step: int, global_slice):
@@ -296,8 +308,17 @@ class ExchangeRank:
         # TC_B_OUTPUTS_IDLE promises that nothing in flight touches the arrays: only with a ring longer than the pipeline
         idle = len(outs) >= 8 and kw.pop("outputs_idle", True)
         kw.pop("outputs_idle", None)
-        b, res, keep = self.eng._prepare(n_out, True, None, None, None, kw.pop("quantity", 1), now_ns, True, False, kw.pop("want", ("allowed",)),
-                                         res, inputs_ready=True, outputs_idle=idle)
+        quantity, want = kw.pop("quantity", 1), kw.pop("want", ("allowed",))
+        if kw:  # (max_burst= / grouped= ... used to be dropped without a word)
+            raise TypeError(f"exchange evaluation: unsupported options {sorted(kw)} (the registered plans, one timestamp, quantity, want, outputs_idle)")
+        for name in want:
+            # a result set may still be written by an earlier step that cycles through it: never reallocated behind its back
+            cur = getattr(res, name)
+            need = (n_out + 63) // 64 if name == "allowed_bits" else (4 * n_out if name in ("result4", "decisions") else n_out)
+            if cur is not None and cur.numel() < need:
+                raise ValueError(f"exchange evaluation: outs[{step % len(outs)}].{name} holds {cur.numel()} entries, the step may need {need} "
+                                 "(it is not reallocated here: an earlier step may still be writing it)")
+        b, res, keep = self.eng._prepare(n_out, True, None, None, None, quantity, now_ns, True, False, want, res, inputs_ready=True, outputs_idle=idle)
         return b, keep
 
     def evaluate(self, step: int, segments, now_ns: int, outs, **kw):
