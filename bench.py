@@ -344,10 +344,12 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
         gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
     dt, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, a.warmup, dist, cnt_view, gathered, piped=not a.in_order, nows=nows)
     c = eng.counters()
+    engine_info = eng.info()   # (did the pipelined batches really overlap -- side streams kept, probe verdicts, grouping path)
     ms = 1e3 * dt / a.steps
     alg = (ALG_BYTES_GENERAL if general else ALG_BYTES_PER_DECISION) * a.batch
     res = {"value": a.steps * a.batch * world / dt, "unit": "decisions/s", "ms_per_step": ms,
-           "allowed_fraction": c["allowed"] / max(1, c["total"]), "whole_step_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+           "allowed_fraction": c["allowed"] / max(1, c["total"]), "whole_step_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+           "pipelining_degraded": bool(engine_info["pipelining_degraded"]), "engine_info": engine_info}
     if plans not in (None, "one"):
         res["plans"] = plans
     if rank == 0 and dist is None and seed_shift == 0 and not a.no_verify and not a.profile_run and not a.in_order and nb <= 400:
@@ -1166,7 +1168,7 @@ def main():
                                ", decisions only",
                    "keys_per_gpu": a.keys, "batch": a.batch, "stream": a.workload, "resident_state": a.layout,
                    "pipelined": not a.in_order},
-        "allowed_fraction": main_res["allowed_fraction"],
+        "allowed_fraction": main_res["allowed_fraction"], "pipelining_degraded": main_res.get("pipelining_degraded"),
     }
     if a.plans != "one":
         result["config"]["plans"] = a.plans
@@ -1175,7 +1177,7 @@ def main():
     verified = {}
     if "verified" in main_res:
         verified["headline"] = main_res["verified"]
-    detail = {"headline": main_res.pop("detail", None),
+    detail = {"headline": main_res.pop("detail", None), "engine_info": main_res.pop("engine_info", None),
               "notes": {"resident_state": {"fixed": "TC_CFG_FIXED_PARAMS: TAT column, 8 B per key + the plan dictionary (emission interval, "
                                                     "tolerance, burst capacity per plan)",
                                            "wide": "{tat, expiry} cell, 16 B per key + plan id column + the plan dictionary"},
@@ -1207,7 +1209,7 @@ def main():
 
             def other_stream():  # the other BASELINE stream (configs[1] <-> configs[2]), measured the same way
                 o_res, held["eng2"], held["ob"], _ = measure_stream(a, t, W, other, dev, local, 0, 0, None, 1)
-                detail[f"{other}_stream"] = o_res.pop("detail", None)
+                detail[f"{other}_stream"] = (o_res.pop("engine_info", None), o_res.pop("detail", None))[1]
                 result[f"{other}_stream"] = o_res
                 if "verified" in o_res:
                     verified[f"{other}_stream"] = o_res["verified"]
@@ -1217,7 +1219,7 @@ def main():
                 a2.layout = "fixed" if a.layout == "wide" else "wide"
                 l_res, eng_l, _, _ = measure_stream(a2, t, W, stream, dev, local, 0, 0, None, 1, general=general)
                 eng_l.close()
-                detail[f"{a2.layout}_layout"] = l_res.pop("detail", None)
+                detail[f"{a2.layout}_layout"] = (l_res.pop("engine_info", None), l_res.pop("detail", None))[1]
                 result[f"{a2.layout}_layout"] = l_res
                 if "verified" in l_res:
                     verified[f"{a2.layout}_layout"] = l_res["verified"]
@@ -1226,7 +1228,7 @@ def main():
                 def run():
                     g_res, eng_g, _, _ = measure_stream(a, t, W, gs, dev, local, 0, 0, None, 1, general=True)
                     eng_g.close()
-                    detail[f"general_{gs}"] = g_res.pop("detail", None)
+                    detail[f"general_{gs}"] = (g_res.pop("engine_info", None), g_res.pop("detail", None))[1]
                     result[f"general_{gs}"] = g_res
                     if "verified" in g_res:
                         verified[f"general_{gs}"] = g_res["verified"]
@@ -1242,7 +1244,7 @@ def main():
                             continue
                         p_res, eng_p, _, _ = measure_stream(a, t, W, st_, dev, local, 0, 0, None, 1, plans=pl)
                         eng_p.close()
-                        detail[f"per_key_{st_}_{pl}"] = p_res.pop("detail", None)
+                        detail[f"per_key_{st_}_{pl}"] = (p_res.pop("engine_info", None), p_res.pop("detail", None))[1]
                         pk[f"{st_}_{pl}"] = p_res
                         if "verified" in p_res:
                             verified[f"per_key_{st_}_{pl}"] = p_res["verified"]
@@ -1332,7 +1334,7 @@ def compact_line(result):
     bench_detail.json.  Never longer than COMPACT_LIMIT bytes."""
     top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
            "dtype", "data", "config", "allowed_fraction", "imbalance_max_over_mean", "router_ms_per_step", "route", "errors",
-           "verified", "verified_legs", "verify_failed")
+           "verified", "verified_legs", "verify_failed", "pipelining_degraded")
     c = _pick(result, top)
     rf = result.get("roofline")
     if rf:

@@ -521,6 +521,35 @@ int tc_route_inverse(uint32_t world, uint64_t keys_per_shard, uint64_t n, const 
  * key_off[n + 1] delimits the keys in key_bytes.  Host only. */
 int tc_route_keys_host(uint32_t world, uint64_t n, const uint8_t* key_bytes, const uint32_t* key_off, uint32_t* owner);
 
+/* ---- pipeline health --------------------------------------------------------------------------------------------------------
+ * Pipelined batches (TC_B_INPUTS_READY, TC_B_ASYNC, pinned host batches in chunks) are fast because their grouping runs on
+ * internal streams BESIDE the evaluation of earlier batches.  Which hardware queue and dispatch pipe a stream lands on depends on
+ * everything the process did with the GPU before, so the engine probes candidates against its main stream
+ * and keeps those that really run concurrently -- and when it finds none (GPU_MAX_HW_QUEUES too small, a process full of streams)
+ * the batches still give the same results, in order on the main stream, 1.5-2.5 x slower, without any error.  This call says
+ * which of the two it is. */
+typedef struct tc_engine_info {
+    uint32_t struct_size;          /* = sizeof(tc_engine_info), set by the caller */
+    uint32_t side_streams_probed;  /* 0: no pipelined batch yet on the current main stream -- nothing below is known */
+    uint32_t grouping_streams_wanted;
+    uint32_t grouping_streams;     /* kept after the probe; 0: pipelined batches run in order on the main stream */
+    uint32_t key_stream;           /* string mode: 1 if key stages have a stream of their own */
+    uint32_t candidates_tried;     /* streams created and probed */
+    uint32_t rejected_same_queue;  /* ... that did not run while the main stream (or a kept stream) was running */
+    uint32_t rejected_same_pipe;   /* ... that ran, but were handed out behind the main stream's workgroups */
+    uint32_t kept_second_best;     /* kept although they share a dispatch pipe with ANOTHER kept stream (never with the main one) */
+    uint32_t probes_assumed;       /* 1: TCGPU_ASSUME_CONCURRENT -- candidates taken unprobed (profiler counter passes) */
+    uint32_t pipelining_degraded;  /* 1: fewer grouping streams than wanted (or no key stream): expect the slower figures */
+    uint32_t scratch_sets;         /* batches whose grouping may be in flight at once */
+    uint32_t grouping_path;        /* of the last batch: 0 none yet, 1 range path (2 launches), 2 LSD passes, 3 bucket path, 4 small batch / unique */
+    uint32_t range_path_possible;  /* the key space admits the range path */
+    uint64_t range_hint_requests;  /* the range hint the next batch goes by: requests of the batch it came from ... */
+    uint64_t range_hint_largest;   /* ... and its largest key range (a block finishes up to 8 192 requests in LDS) */
+    uint64_t host_chunk_requests;  /* pinned synchronous host batches of at least twice this many requests are pipelined in chunks; 0: never */
+    uint64_t batches;              /* batches decided so far */
+} tc_engine_info;
+int tc_engine_info_get(tc_engine* e, tc_engine_info* out);
+
 /* Number of internal invariant violations the kernels have flagged since creation (always 0
  * unless there is a bug; the parity tests assert it). */
 int tc_selfcheck(tc_engine* e, uint64_t* violations);

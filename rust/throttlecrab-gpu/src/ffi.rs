@@ -100,6 +100,30 @@ pub struct tc_sweep_info {
     pub next_cleanup_ns: i64,
 }
 
+/// tc_engine_info_get: do pipelined batches overlap, and which grouping path is in use
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct tc_engine_info {
+    pub struct_size: u32,
+    pub side_streams_probed: u32,
+    pub grouping_streams_wanted: u32,
+    pub grouping_streams: u32,
+    pub key_stream: u32,
+    pub candidates_tried: u32,
+    pub rejected_same_queue: u32,
+    pub rejected_same_pipe: u32,
+    pub kept_second_best: u32,
+    pub probes_assumed: u32,
+    pub pipelining_degraded: u32,
+    pub scratch_sets: u32,
+    pub grouping_path: u32,
+    pub range_path_possible: u32,
+    pub range_hint_requests: u64,
+    pub range_hint_largest: u64,
+    pub host_chunk_requests: u64,
+    pub batches: u64,
+}
+
 #[repr(C)]
 pub struct tc_exchange_config {
     pub struct_size: u32,
@@ -234,6 +258,7 @@ extern "C" {
         out: *mut tc_result,
     ) -> c_int;
     pub fn tc_sweep_expired(e: *mut tc_engine, now_ns: i64, removed: *mut u64) -> c_int;
+    pub fn tc_engine_info_get(e: *mut tc_engine, out: *mut tc_engine_info) -> c_int;
     pub fn tc_set_sweep_policy(e: *mut tc_engine, p: *const tc_sweep_policy) -> c_int;
     pub fn tc_sweep_stats(e: *mut tc_engine, out: *mut tc_sweep_info) -> c_int;
     pub fn tc_counters(e: *mut tc_engine, out: *mut u64) -> c_int;

@@ -363,3 +363,49 @@ def test_pipelined_batches_do_not_depend_on_what_the_process_did_before():
             assert eng.selfcheck() == 0
             eng.close()
     assert per[True] < 0.9 * per[False], per
+
+
+_INFO_CHILD = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["TC_ROOT"])
+import numpy as np, torch
+import throttlecrab_amd as t
+from oracle import oracle as O
+from throttlecrab_amd import workload as W
+cap, n = 200_000, 1 << 16
+eng, orc = t.Engine(cap, n, fixed_params=True), O.DenseOracle(cap)
+eng.use_torch_stream()
+eng.register_params_uniform(*W.REF_PARAMS)
+before = eng.info()
+ok = True
+for b in range(6):
+    sl = W.uniform_slots(cap, n, seed=5, start=b * n)
+    ref = orc.batch_slots(sl, *W.REF_PARAMS, 1, W.T0_NS + b * 10**6)
+    res = eng.rate_limit_batch_slots(torch.from_numpy(sl.astype(np.int32)).cuda(), registered=True, quantity=1, now_ns=W.T0_NS + b * 10**6,
+                                     want=("allowed",), inputs_ready=True)
+    torch.cuda.synchronize()
+    ok = ok and bool(np.array_equal(res.allowed.cpu().numpy(), ref.allowed))
+print(json.dumps({"before": before, "after": eng.info(), "exact": ok, "selfcheck": eng.selfcheck()}))
+"""
+
+
+@pytest.mark.parametrize("queues", ["8", "2"])
+def test_the_engine_says_when_its_pipeline_is_degraded(queues):
+    """with too few hardware queues the side streams cannot run beside the main stream; pipelined batches then run
+    in order -- same results, 1.5-2.5 x slower, no error.  tc_engine_info_get must say so (and say "healthy" when it is)."""
+    import json
+    import subprocess
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=queues, TC_ROOT=ROOT)
+    out = subprocess.run([sys.executable, "-c", _INFO_CHILD], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout[-1000:] + out.stderr[-3000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["exact"] and d["selfcheck"] == 0
+    assert d["before"]["side_streams_probed"] == 0 and d["before"]["grouping_path"] == "none yet"
+    a = d["after"]
+    assert a["side_streams_probed"] == 1 and a["grouping_streams_wanted"] == 3 and a["batches"] == 6 and a["scratch_sets"] == 6
+    assert a["grouping_path"] in ("range path", "LSD passes") and a["range_path_possible"] == 1 and a["range_hint_requests"] == 1 << 16
+    assert a["candidates_tried"] >= a["grouping_streams"]
+    if queues == "8":
+        assert a["grouping_streams"] == 3 and a["pipelining_degraded"] == 0, a
+    else:   # main + one more queue at most: not three grouping streams that run beside the main stream
+        assert a["grouping_streams"] < 3 and a["pipelining_degraded"] == 1 and a["rejected_same_queue"] + a["rejected_same_pipe"] > 0, a

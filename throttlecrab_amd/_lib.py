@@ -82,6 +82,15 @@ class tc_sweep_info(C.Structure):
                 ("last_removed", C.c_uint64), ("current_interval_ns", C.c_int64), ("next_cleanup_ns", C.c_int64)]
 
 
+class tc_engine_info(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("side_streams_probed", C.c_uint32), ("grouping_streams_wanted", C.c_uint32),
+                ("grouping_streams", C.c_uint32), ("key_stream", C.c_uint32), ("candidates_tried", C.c_uint32),
+                ("rejected_same_queue", C.c_uint32), ("rejected_same_pipe", C.c_uint32), ("kept_second_best", C.c_uint32),
+                ("probes_assumed", C.c_uint32), ("pipelining_degraded", C.c_uint32), ("scratch_sets", C.c_uint32),
+                ("grouping_path", C.c_uint32), ("range_path_possible", C.c_uint32), ("range_hint_requests", C.c_uint64),
+                ("range_hint_largest", C.c_uint64), ("host_chunk_requests", C.c_uint64), ("batches", C.c_uint64)]
+
+
 class tc_result(C.Structure):
     _fields_ = [("limit", C.c_int64), ("remaining", C.c_int64), ("reset_after_ns", C.c_int64),
                 ("retry_after_ns", C.c_int64), ("allowed", C.c_uint8), ("status", C.c_uint8)]
@@ -128,6 +137,7 @@ SYMBOLS = {
     "tc_debug_occupy": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64]),
     "tc_debug_check_keys": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_selfcheck": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "tc_engine_info_get": (C.c_int, [C.c_void_p, C.POINTER(tc_engine_info)]),
     "tc_snapshot_save": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_snapshot_load": (C.c_int, [C.c_void_p, C.c_char_p]),
     "tc_route_batch": (C.c_int, [C.c_void_p, C.POINTER(tc_route)]),

@@ -363,7 +363,10 @@ int ensure_side_streams(tc_engine* e) {
     const char* as = getenv("TCGPU_ASSUME_CONCURRENT");
     const bool assume = as && atoi(as) != 0;
     std::vector<hipStream_t> good, bad, soft;
+    e->probe_tried = e->probe_same_queue = e->probe_same_pipe = e->probe_second_best = 0;
+    e->probe_assumed = assume;
     for (int c = 0; c < 16 && good.size() < want; ++c) {
+        ++e->probe_tried;
         hipStream_t s = nullptr;
         int rc = TC_E_OK;
         if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, e->aux_priority) != hipSuccess) rc = fail(e, TC_E_HIP, "hipStreamCreateWithPriority failed");
@@ -374,11 +377,13 @@ int ensure_side_streams(tc_engine* e) {
         if (assume) ok = true;
         else if (rc == TC_E_OK) rc = streams_concurrent(e, m, s, &ok);
         for (size_t g = 0; !assume && rc == TC_E_OK && ok && g < good.size(); ++g) rc = streams_concurrent(e, good[g], s, &ok);
+        if (rc == TC_E_OK && !ok) ++e->probe_same_queue;
         bool second_best = false; // concurrent with everything, off the main stream's pipe, but on the pipe of a stream already kept
         if (!assume && rc == TC_E_OK && ok && e->pipe_probe) {
             bool collide = false;
             rc = streams_collide(e, m, s, &collide);
             ok = !collide;
+            if (collide) ++e->probe_same_pipe;
             for (size_t g = 0; rc == TC_E_OK && ok && !second_best && g < good.size(); ++g) {
                 rc = streams_collide(e, good[g], s, &collide);
                 second_best = collide;
@@ -402,6 +407,7 @@ int ensure_side_streams(tc_engine* e) {
         for (size_t g = 0; ok && g < good.size(); ++g)
             if (streams_concurrent(e, good[g], s, &ok) != TC_E_OK) ok = false;
         (ok ? good : bad).push_back(s);
+        if (ok) ++e->probe_second_best;
     }
     for (hipStream_t s : soft) (void)hipStreamDestroy(s);
     for (hipStream_t s : bad) (void)hipStreamDestroy(s);
@@ -760,6 +766,38 @@ extern "C" int tc_debug_fail_copy(tc_engine* e, uint32_t nth) {
 
 // Internal invariant violations seen so far (0 unless there is a bug): runs that turned out
 // irregular in a batch the host had proved regular (k_eval_sorted<DIRECT>).
+extern "C" int tc_engine_info_get(tc_engine* e, tc_engine_info* out) {
+    if (!e || !out || out->struct_size < sizeof(tc_engine_info)) return TC_E_INVALID_ARG;
+    tc_engine_info r;
+    memset(&r, 0, sizeof r);
+    r.struct_size = sizeof r;
+    const bool probed = e->side_ready && e->side_for == cur_stream(e);
+    r.side_streams_probed = probed ? 1u : 0u;
+    r.grouping_streams_wanted = e->n_aux_want;
+    if (probed) {
+        r.grouping_streams = e->n_aux;
+        r.key_stream = e->key_stream ? 1u : 0u;
+        r.candidates_tried = e->probe_tried;
+        r.rejected_same_queue = e->probe_same_queue;
+        r.rejected_same_pipe = e->probe_same_pipe;
+        r.kept_second_best = e->probe_second_best;
+        r.probes_assumed = e->probe_assumed ? 1u : 0u;
+        r.pipelining_degraded = (e->n_aux < e->n_aux_want || (e->key_mode && !e->key_stream)) ? 1u : 0u;
+    }
+    r.scratch_sets = e->depth;
+    r.grouping_path = e->last_grouping_path;
+    r.range_path_possible = e->range_ok ? 1u : 0u;
+    if (e->range_hint_host) {
+        const unsigned long long h = *(volatile unsigned long long*)e->range_hint_host;
+        r.range_hint_requests = h >> 32;
+        r.range_hint_largest = h & 0xFFFFFFFFull;
+    }
+    r.host_chunk_requests = e->host_chunk;
+    r.batches = e->batches;
+    *out = r;
+    return TC_E_OK;
+}
+
 extern "C" int tc_selfcheck(tc_engine* e, uint64_t* violations) {
     if (!e || !violations) return TC_E_INVALID_ARG;
     TC_HIP(e, hipSetDevice(e->device));

@@ -142,6 +142,10 @@ struct tc_engine {
     uint32_t* probe_ws = nullptr;        // {flag, saw}
     void* probe_stamps = nullptr;        // {start of k_probe_occupy, k_probe_stamp's clock}
     bool pipe_probe = true;              // TCGPU_PIPE_PROBE=0: keep candidates that share a dispatch pipe with the main stream
+    // what the last probe found (tc_engine_info_get)
+    uint32_t probe_tried = 0, probe_same_queue = 0, probe_same_pipe = 0, probe_second_best = 0;
+    bool probe_assumed = false;
+    uint32_t last_grouping_path = 0;     // 1 range path, 2 LSD passes, 3 bucket path, 4 no grouping (small batch / unique slots)
     uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
     PendEntry* pend = nullptr;

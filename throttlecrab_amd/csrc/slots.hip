@@ -385,6 +385,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
     bool bits_in_kernel = false;
 
     if (b.flags & TC_B_UNIQUE_SLOTS) {
+        e->last_grouping_path = 4u;
         if (hin) {
             // (a set's staging columns are only read by work that this stream has already been ordered behind)
             tc_engine::SortSet& ss = e->sets[e->next_set];
@@ -455,6 +456,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             }
         }
         const bool bucketed = eligible;
+        e->last_grouping_path = ranged ? 1u : (bucketed ? 3u : 2u); // (bucketed: decided on the device in the end -- tc_engine_info says what was enqueued)
         // Grouped rows + a bitmask of them, every run regular: the evaluation's waves hold 64 consecutive rows each and
         // pack their decisions with one ballot (no byte column, no k_pack_bits launch).
         if (b.allowed_bits && p.order && direct) {

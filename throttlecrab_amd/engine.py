@@ -118,6 +118,18 @@ class Engine:
         self._check(self._lib.tc_debug_check_keys(self._h, C.byref(v)))
         return int(v.value)
 
+    GROUPING_PATHS = ("none yet", "range path", "LSD passes", "bucket path", "no grouping")
+
+    def info(self) -> dict:
+        """tc_engine_info_get: the pipeline's health -- side streams wanted / kept, what the probe rejected and why, whether
+        pipelined batches currently overlap (pipelining_degraded), the grouping path of the last batch and the range hint"""
+        r = L.tc_engine_info()
+        r.struct_size = C.sizeof(L.tc_engine_info)
+        self._check(self._lib.tc_engine_info_get(self._h, C.byref(r)))
+        d = {k: int(getattr(r, k)) for k, _ in L.tc_engine_info._fields_ if k != "struct_size"}
+        d["grouping_path"] = self.GROUPING_PATHS[min(r.grouping_path, 4)]
+        return d
+
     def selfcheck(self) -> int:
         v = C.c_uint64(0)
         self._check(self._lib.tc_selfcheck(self._h, C.byref(v)))
