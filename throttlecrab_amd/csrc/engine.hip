@@ -278,8 +278,9 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
         TC_HIP(e, hipMemsetAsync(e->retired, 0, ((size_t)kt::RETIRED_CAP + 1) * sizeof(kt::RetiredRec), (hipStream_t)0));
         t.retired = e->retired;
     }
+    if (const char* d = getenv("TCGPU_SPREAD_FREE")) e->spread_free = atoi(d) != 0;
     hipLaunchKernelGGL(kt::k_init_free, dim3(std::min<uint64_t>(nblocks(cap), 2048)), dim3(kt::THREADS), 0, (hipStream_t)0,
-                       t.free_slots, t.bound, (uint32_t)cap);
+                       t.free_slots, t.bound, (uint32_t)cap, e->spread_free ? 1u : 0u);
     const int top = (int)cap;
     TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->k_slot, mb * 4));

@@ -273,6 +273,8 @@ struct tc_engine {
 
     // string-key mode (TC_CFG_KEY_MODE): device hash table + per-batch resolution scratch
     bool key_mode = false;
+    bool spread_free = false;        // TCGPU_SPREAD_FREE=1: the free stack hands out slots from all over the key space (kt::spread_position), so that key
+                                     // batches can take the range path -- measured slower on configs[4] (profiles/r05_v9_spread_free_ab.txt): off
     kt::Table kt;
     void* kt_block = nullptr;        // one allocation backing every kt.* array
     kt::RetiredRec* retired = nullptr; // key mode + TC_CFG_TRACK_DENIED: denial counts of keys without a slot

@@ -681,9 +681,33 @@ static __global__ __launch_bounds__(THREADS) void k_follow(uint32_t n, uint32_t*
     }
 }
 
-static __global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint8_t* bound, uint32_t capacity) {
+// Where the p-th of m items goes when the items (given in slot order) are to LEAVE in an order that visits the whole slot range
+// again and again: the items are cut into rows of `cols` consecutive ones and handed out column by column.  A bijection of
+// [0, m).  The free stack is popped from the top down, so that consecutive pops -- the new keys of one batch -- get slots from
+// all over the key space and the batch's slots stay spread evenly enough for the range path (radix_sort.hpp: two grouping
+// launches instead of a histogram and three LSD passes).  Round 4 pushed freed slots in slot order: neighbouring records for
+// k_bind, but a fifth of every configs[4] batch in one narrow slot range, and with it the LSD passes for every key batch.
+// (in RUNS of SPREAD_RUN consecutive items: a batch's claimants -- consecutive pops -- still bind neighbouring slots run by run,
+// so that their `bound` bytes, position words and denial counters share memory lines; one slot at a time k_bind took 65 instead of
+// 45 us and the sweep's push 77 instead of 40)
+constexpr uint32_t SPREAD_RUN = 64;
+__host__ __device__ inline uint32_t spread_position(uint32_t g, uint32_t m, uint32_t cols) {
+    const uint32_t runs = m / SPREAD_RUN;                      // whole runs; the items behind them stay where they are
+    const uint32_t run = g / SPREAD_RUN, in_run = g - run * SPREAD_RUN;
+    if (run >= runs) return g;
+    const uint32_t rows_full = runs / cols, rem = runs - rows_full * cols; // the last row holds `rem` runs
+    const uint32_t row = run / cols, c = run - row * cols;
+    return (c * rows_full + (c < rem ? c : rem) + row) * SPREAD_RUN + in_run;
+}
+__host__ __device__ inline uint32_t spread_cols(uint32_t m) { return m / SPREAD_RUN / 256u + 1u; } // ~256 rows: one per key range of the range path
+
+// spread: slot order in, the order above out (slot 0 is still the first one handed out: it sits on top)
+static __global__ __launch_bounds__(THREADS) void k_init_free(uint32_t* free_slots, uint8_t* bound, uint32_t capacity, uint32_t spread) {
+    const uint32_t cols = spread_cols(capacity);
     for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < capacity; i += gridDim.x * THREADS) {
-        free_slots[i] = capacity - 1u - i; // slot 0 is handed out first
+        // item i (= slot i) is popped spread_position-th: the stack is popped from its top, entry capacity - 1, down
+        const uint32_t pop = spread ? spread_position(i, capacity, cols) : i;
+        free_slots[capacity - 1u - pop] = i;
         bound[i] = 0;
     }
 }

@@ -88,7 +88,8 @@ int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_
     hipLaunchKernelGGL(mk::k_sweep_keys, dim3(blocks), dim3(BLOCK), 0, s, e->cells, t, now_ns, e->sweep_work, e->denied);
     hipLaunchKernelGGL(mk::k_sweep_decide, dim3(1), dim3(mk::DECIDE_THREADS), 0, s, t, e->sweep_work, blocks, top_save, flag, oflag,
                        removed_scratch, e->counters);
-    hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(blocks), dim3(BLOCK), 0, s, t, e->sweep_work, (const int*)top_save, (const uint32_t*)flag);
+    hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(blocks), dim3(BLOCK), 0, s, t, e->sweep_work, (const int*)top_save, (const uint32_t*)flag,
+                       e->spread_free ? 1u : 0u);
     hipLaunchKernelGGL(kt::k_table_clear_compact, dim3(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block, 0, s, t, (const uint32_t*)flag, oflag);
     // (the sweep's completion event -- later key stages on the key stream wait for it -- rides on its last kernel)
     TC_LAUNCH(e->m_done, kt::k_table_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, (const uint32_t*)flag,

@@ -277,12 +277,16 @@ static __global__ __launch_bounds__(DECIDE_THREADS) void k_sweep_decide(kt::Tabl
 
 constexpr int TOMB_ITEMS = 4;
 static __global__ __launch_bounds__(BLOCK) void k_sweep_tombstones(kt::Table t, SweepWork work, const int* __restrict__ top_save,
-                                                                   const uint32_t* __restrict__ flag) {
+                                                                   const uint32_t* __restrict__ flag, uint32_t spread) {
     const uint32_t cnt = work.part[blockIdx.x];
     if (cnt == 0u) return;
     const bool tomb = *flag == 0u; // (else: the rebuild that follows drops every entry of an unbound key by itself)
     const uint32_t* __restrict__ src = work.list + (uint64_t)blockIdx.x * sweep_per_block(t.capacity, gridDim.x);
-    uint32_t* __restrict__ dst = t.free_slots + *top_save + work.off[blockIdx.x];
+    // the sweep's m freed slots, in slot order, are the stack entries [top_save, top_save + m); spread (kt::spread_position):
+    // the g-th of them is the one popped spread_position(g)-th, i.e. entry top_save + m - 1 - that
+    const uint32_t first = work.off[blockIdx.x];
+    const uint32_t m = (uint32_t)(*t.free_top - *top_save), cols = kt::spread_cols(m);
+    uint32_t* __restrict__ base = t.free_slots + *top_save;
     for (uint32_t k0 = threadIdx.x; k0 < cnt; k0 += BLOCK * TOMB_ITEMS) {
         uint32_t slot[TOMB_ITEMS], pos[TOMB_ITEMS];
 #pragma unroll
@@ -292,7 +296,8 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_tombstones(kt::Table t, 
 #pragma unroll
         for (int j = 0; j < TOMB_ITEMS; ++j)
             if (slot[j] != kt::NO_SLOT) {
-                dst[k0 + j * BLOCK] = slot[j];
+                const uint32_t g = first + k0 + j * BLOCK;
+                base[spread ? m - 1u - kt::spread_position(g, m, cols) : g] = slot[j];
                 if (tomb) *reinterpret_cast<uint32_t*>(&t.ktab[pos[j]].w) = kt::VAL_TOMB; // (little-endian: the `val` half)
             }
     }

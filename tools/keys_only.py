@@ -14,3 +14,7 @@ a = bench.parse()
 torch.cuda.set_device(0)
 r = bench.keys_bench(a, torch.device("cuda:0"))
 print(json.dumps({k: ({kk: v[kk] for kk in ("value", "ms_per_step", "steps") if kk in v} if isinstance(v, dict) else v) for k, v in r.items()}))
+if os.environ.get("KEYS_DETAIL"):
+    for k, v in r.items():
+        if isinstance(v, dict):
+            print(k, {st: (round(1e3 * x["avg_ms"], 1), round(x["launches_per_batch"], 2)) for st, x in v["detail"]["stages"]["pipelined"].items()}, v.get("grouping_path"))
