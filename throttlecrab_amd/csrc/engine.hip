@@ -121,6 +121,7 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_DEBUG_NO_DECISION_STORE")) e->debug_nostore = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_GENERAL_EARLIER")) e->general_earlier = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_GENERAL_RUNS")) e->general_runs = atoi(d) != 0;
     {
         TC_HIP(e, hipHostMalloc((void**)&e->fill_hint_host, 64, hipHostMallocDefault));
         *e->fill_hint_host = 1u;

@@ -27,6 +27,7 @@ constexpr uint32_t F_PREFILL0 = 16u;     // TC_B_OUTPUTS_IDLE batch whose `allow
 constexpr uint32_t F_PREFILL1 = 32u;     // ... to 1: the evaluation only stores the decisions that differ from the fill
 constexpr uint32_t F_DEBUG_NO_ANNOUNCE = 64u; // tc_debug_break_wait: row 0 never announces (the watchdog's test)
 constexpr uint32_t F_NO_EARLIER = 128u;  // TCGPU_GENERAL_EARLIER=0 (A/B): k_eval_general without the earlier-state rule
+constexpr uint32_t F_GENERAL_RUNS = 256u; // k_eval_general settles a run of allowed requests in one round (TCGPU_GENERAL_RUNS=0: one per round)
 constexpr uint32_t F_DEBUG_NOSTORE = 8u; // measurement only (TCGPU_DEBUG_NO_DECISION_STORE): the lean kernel skips its decision bytes
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
 constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
@@ -1048,6 +1049,56 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
             c.tat = nt;
             c.expiry = nx;
             dirty = true;
+        }
+        // Round 5 -- a RUN of allowed requests in one round.  One round per allowed request is what a key costs while it still has
+        // tokens: a piece of 60 allowed requests keeps its wave for 60 rounds, and the first ~25 batches of a Zipf stream -- all a
+        // 20-batch measurement sees -- are full of such pieces (98 us per batch there, 74 once the keys are
+        // drained).  If the requests behind the one just allowed carry the same increment and tolerance and are all allowed as well,
+        // the state in front of the k-th of them is the state just left + k increments: every open lane runs the REAL step on
+        // that predicted state and checks that it is allowed and leaves exactly the next predicted state (the clamp was a no-op,
+        // the entry live, nothing saturated); the run ends in front of the first lane that fails, and everything before it is
+        // final -- exact by induction, no special cases.  (Round 3's general version -- a max-plus prefix scan in every round --
+        // cost more registers and instructions than it saved once the keys were drained; this one is an arithmetic progression,
+        // and it is only entered when some piece still has open lanes behind an allowed request: wave-uniform.)
+        if ((p.flags & F_GENERAL_RUNS) != 0u && __ballot(!fin && first < 64) != 0ull) {
+            const long long inc_me = tc::sat_mul(r.ei, r.q);
+            const long long inc_f = __shfl(inc_me, src, 64), dvt_f = __shfl((long long)r.dvt, src, 64);
+            const bool cand = !fin && first < 64; // (an open lane behind the allowed request of its piece)
+            const unsigned long long behind = __ballot(cand) & piece & ~((2ull << (first & 63)) - 1ull); // ... of MY piece
+            const uint32_t kk = (uint32_t)__popcll(behind & ((1ull << lane) - 1ull)); // open lanes of my piece between `first` and me
+            Cell sk;
+            sk.tat = nt + (long long)kk * inc_f;
+            sk.expiry = (unsigned long long)(sk.tat + dvt_f);
+            const long long want_tat = sk.tat + inc_f;
+            bool good = cand && inc_me == inc_f && r.dvt == dvt_f && inc_f > 0 && inc_f < (1ll << 40) && nt > -(1ll << 61) && nt < (1ll << 61) &&
+                        dvt_f >= 0 && dvt_f < (1ll << 61) && nx == (unsigned long long)(nt + dvt_f);
+            Cell s2 = sk;
+            if (good) {
+                good = tc::gcra_step<false>(s2, r.ei, r.dvt, r.q, r.now).allowed && s2.tat == want_tat && s2.expiry == (unsigned long long)(want_tat + dvt_f);
+            }
+            const unsigned long long bad = __ballot(cand && !good) & behind;
+            const int stop = bad ? __builtin_ctzll(bad) : 64; // the first lane of my piece the progression does not hold for
+            const unsigned long long run = stop < 64 ? (behind & ((1ull << stop) - 1ull)) : behind;
+            if (cand && ((run >> lane) & 1ull)) { // allowed against the predicted state: final
+                Decision d;
+                if (FULL) {
+                    Cell tmp = sk;
+                    d = tc::gcra_step<true>(tmp, r.ei, r.dvt, r.q, r.now);
+                } else {
+                    d.allowed = true;
+                    d.remaining = d.reset_after = d.retry_after = 0;
+                }
+                write_out_general<FULL>(p, orow, r, d);
+                na = 1;
+                was_allowed = true;
+                mine = s2;
+                fin = true;
+            } else if (first < 64 && lane > first && run != 0ull) {
+                // behind the run: go on from the state it leaves.  (Every lane of the piece behind `first`, settled or not: an
+                // error request at the end of a piece owns the state the piece hands on, like any last lane.)
+                c.tat = nt + (long long)__popcll(run) * inc_f;
+                c.expiry = (unsigned long long)(c.tat + dvt_f);
+            }
         }
     }
     // the last lane of the piece owns the state the piece leaves

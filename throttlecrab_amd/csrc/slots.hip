@@ -364,6 +364,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
     if (e->fixed) p.flags |= F_FIXED;
     if (e->debug_nostore) p.flags |= F_DEBUG_NOSTORE;
     if (!e->general_earlier) p.flags |= F_NO_EARLIER;
+    if (e->general_runs) p.flags |= F_GENERAL_RUNS;
     if (e->debug_break_wait) {
         p.flags |= F_DEBUG_NO_ANNOUNCE;
         e->debug_break_wait = false; // one batch
