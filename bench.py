@@ -960,58 +960,30 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     else:
         host = [W.uniform_slots(world * a.keys, G, seed=2, start=i * G) for i in range(n_distinct)]
     d_global = [torch.from_numpy(h.astype(np.int32)).to(dev) for h in host]
-    RING = 8  # routed slot columns stay untouched while up to pipeline-depth batches are in flight
-    ring = [(torch.empty(G, dtype=torch.int32, device=dev), None, torch.zeros(world, dtype=torch.int32, device=dev)) for _ in range(RING)]
-    counts_host = [eng.host_alloc(world + 1, np.uint32) for _ in range(RING)]   # pinned: counts, then the batch's tag
-    for c in counts_host:
-        c[:] = 0
-    # every batch in flight writes its decisions to an array of its own (as the N = 1 run does): TC_B_OUTPUTS_IDLE
-    outs = [t.BatchResult(allowed=torch.empty(cap_batch, dtype=torch.uint8, device=dev)) for _ in range(OUT_RING)]
-    n_calls = 0
+    # every batch in flight writes its decisions to an array of its own (as the N = 1 run does): TC_B_OUTPUTS_IDLE; an array holds
+    # a rank's whole share of a global batch (the owner of a hot key gets more than 1 / world of it)
+    outs = [t.BatchResult(allowed=torch.empty(G, dtype=torch.uint8, device=dev)) for _ in range(OUT_RING)]
     cnt_view = sharded.device_counter_view(eng)
     gathered = torch.zeros(world * cnt_view.numel(), dtype=torch.int64, device=dev)
     top_gathered = torch.zeros(world * sharded.TOPK, 2, dtype=torch.int64, device=dev)
     decided = 0
-
-    # TC_ROUTE_AHEAD: the router runs on the engine's grouping streams, beside the evaluations of earlier batches (it
-    # only reads the global batch and writes a ring entry whose last reader is already on the engine's stream), and
-    # its last block writes the counts + the batch's tag into pinned host memory: the host learns how many requests
-    # it owns by polling that word -- no event, no stream synchronisation on the way.
-    host_s = {"route": 0.0, "poll": 0.0, "evaluate": 0.0}   # where the host's time goes (diagnostics, stderr + detail)
-    ROUTE_AHEAD = os.environ.get("TC_BENCH_ROUTE_AHEAD", "1") == "1"
-
-    # (diagnostics, one rank only: TC_BENCH_SKIP_ROUTER=1 hands the global batch to the engine as it is -- with one shard an id is
-    # its slot -- so that what the router costs a step can be told from what the rest of this path costs)
-    SKIP_ROUTER = world == 1 and os.environ.get("TC_BENCH_SKIP_ROUTER", "0") == "1"
+    LOOKAHEAD = 4
+    # The rank's side of `replicate` is library code (csrc/shard.hip): tc_shard_step routes global batch i + 4 on the
+    # engine's grouping streams (beside the evaluations; the router's last block leaves the counts + the batch's tag in pinned host
+    # memory), polls the tag of batch i -- routed four steps ago: no wait in steady state, no event, no stream synchronisation --
+    # and decides the rank's share in chunks of at most max_batch: ONE call per step (round 4: route_batch + a poll + a batch call
+    # per chunk from Python, 26-38 us of host time per step).
+    xr = sharded.ShardRank(eng, rank, world, G, ring=LOOKAHEAD + 4)
+    host_s = {"step": 0.0}   # where the host's time goes (diagnostics, stderr + detail)
 
     def route(i):
-        r = i % RING
-        t_ = time.perf_counter()
-        if SKIP_ROUTER:
-            ring[r] = (d_global[i % n_distinct], None, ring[r][2])
-            counts_host[r][rank] = G
-            counts_host[r][world] = i + 1
-            host_s["route"] += time.perf_counter() - t_
-            return
-        eng.route_batch(d_global[i % n_distinct], world, only=rank, out=ring[r], ahead=ROUTE_AHEAD, host_counts=counts_host[r], tag=i + 1)
-        host_s["route"] += time.perf_counter() - t_
+        xr.route(i, d_global[i % n_distinct])
 
     def evaluate(i, last=False, metrics=True):
-        nonlocal decided, n_calls
-        r = i % RING
+        nonlocal decided
         t_ = time.perf_counter()
-        while int(counts_host[r][world]) != i + 1:   # routed LOOKAHEAD steps ago: no wait in steady state
-            pass
-        mine = int(counts_host[r][rank])
-        t2_ = time.perf_counter()
-        host_s["poll"] += t2_ - t_
-        for lo in range(0, mine, cap_batch):
-            hi = min(mine, lo + cap_batch)
-            eng.rate_limit_batch_slots(ring[r][0][lo:hi], registered=True, quantity=1, now_ns=W.T0_NS + i * 1_000_000,
-                                       want=("allowed",), out=outs[n_calls % OUT_RING], inputs_ready=True, outputs_idle=True)
-            n_calls += 1
-        host_s["evaluate"] += time.perf_counter() - t2_
-        decided += mine
+        decided += xr.step(i, d_global[(i + LOOKAHEAD) % n_distinct], LOOKAHEAD, W.T0_NS + i * 1_000_000, outs)
+        host_s["step"] += time.perf_counter() - t_
         if not metrics:
             return
         if i % METRICS_EVERY == METRICS_EVERY - 1 or last:
@@ -1023,12 +995,10 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
 
     # The router runs LOOKAHEAD global batches ahead of the evaluation: the host needs a batch's count (how many of
     # its requests this rank owns) before it can enqueue the evaluation, and that read must not drain the stream.
-    LOOKAHEAD = 4
     it = 0
     for j in range(LOOKAHEAD):
         route(j)
     for _ in range(a.warmup):
-        route(it + LOOKAHEAD)
         evaluate(it)
         it += 1
     dist.barrier()
@@ -1036,15 +1006,16 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     decided = 0
     for k_ in host_s:
         host_s[k_] = 0.0   # (the warmup holds one-time costs: scratch allocation, the stream probe)
+    xr.wait_us()
     t0 = time.perf_counter()
     for k in range(a.steps):
-        route(it + LOOKAHEAD)   # (the last LOOKAHEAD of them are routed for nothing: inside the timing, against us)
-        evaluate(it, last=(k == a.steps - 1))
+        evaluate(it, last=(k == a.steps - 1))   # (routes batch it + LOOKAHEAD too: the last LOOKAHEAD of them for nothing, inside the timing, against us)
         it += 1
     torch.cuda.synchronize()
     dist.barrier()
     dt_mine = time.perf_counter() - t0
     host_us = {k_: 1e6 * v / a.steps for k_, v in host_s.items()}   # of the timed region only
+    host_us["of_it_waiting_for_the_router"] = xr.wait_us() / a.steps
     print(f"[bench] rank {rank} host us/step (timed region): {host_us}", file=sys.stderr, flush=True)
     tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
     dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -1057,7 +1028,6 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     decided = 0
     eng.profile_enable(True)
     for _ in range(steps_p):
-        route(it + LOOKAHEAD)
         evaluate(it, metrics=False)
         it += 1
     torch.cuda.synchronize()
@@ -1130,6 +1100,10 @@ def main():
     if world > 1 or os.environ.get("TC_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if "RANK" not in os.environ:   # TC_BENCH_FORCE_DIST=1 started plainly: a process group of one
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 2000))
         if os.environ.get("TC_BENCH_ONE_DEVICE") == "1":  # several ranks on ONE GPU (what a 1-GPU box can test of the N > 1 path)
             local = 0
         torch.cuda.set_device(local)

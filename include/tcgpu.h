@@ -509,6 +509,34 @@ int tc_exchange_poll(tc_exchange* x);
  * the router's tag (post), [2] for the sources' mailbox words (collect) -- what tells a host-bound step from a starved one */
 int tc_exchange_wait_ns(tc_exchange* x, uint64_t out[3]);
 
+/* ---- `replicate` mode as library calls (one rank's side; bench.py --route replicate) -------------------------------------------
+ * Every rank is handed the WHOLE global batch; per step i it
+ *   routes    global step i + route_ahead: keeps what it owns as shard-local slots (tc_route_batch, one destination) on one of the
+ *             engine's grouping streams, beside the evaluations, into one of `ring` columns of its own; the router's last block
+ *             leaves the counts and the step's tag in pinned host memory,
+ *   evaluates step i: polls that tag (routed a few steps ago: no wait in steady state), and decides its share -- in batches of
+ *             at most max_batch, each writing its outputs behind the previous one's.
+ * tc_shard_step is both in one call: a rank's host cost per step is one call (round 4: four Python calls, 26-38 us).  The caller
+ * primes the pipeline: routes steps 0 .. route_ahead - 1.  tmpl: as for tc_exchange_evaluate.  No collective, no peer memory. */
+typedef struct tc_shard tc_shard;
+typedef struct tc_shard_config {
+    uint32_t struct_size;     /* = sizeof(tc_shard_config) */
+    uint32_t rank;            /* this shard */
+    uint32_t world;           /* shards, 1..64 */
+    uint32_t ring;            /* routed batches kept (>= route_ahead + 2, at most 64) */
+    uint64_t keys_per_shard;  /* the engines' capacity */
+    uint64_t max_global;      /* requests of the largest global batch */
+} tc_shard_config;
+/* (a shard points into its engine: destroy it first) */
+int tc_shard_create(tc_engine* e, const tc_shard_config* c, tc_shard** out);
+int tc_shard_destroy(tc_shard* x);
+int tc_shard_route(tc_shard* x, uint64_t step, const uint32_t* global_id, uint64_t n);
+int tc_shard_evaluate(tc_shard* x, uint64_t step, const tc_batch* tmpl, uint64_t* decided);
+int tc_shard_step(tc_shard* x, uint64_t step, const uint32_t* global_id_ahead, uint64_t n_ahead, uint32_t route_ahead, const tc_batch* tmpl,
+                  uint64_t* decided);
+/* host time (ns) the calls have spent waiting for a router's tag since the last call of this function */
+int tc_shard_wait_ns(tc_shard* x, uint64_t* out);
+
 /* The same map on the host: owner and shard-local slot of n global ids (either output may be NULL), and its
  * inverse (global id of slot `slot` of shard `owner`).  No device needed. */
 int tc_route_host(uint32_t world, uint64_t keys_per_shard, uint64_t n, const uint32_t* global_id, uint32_t* owner,

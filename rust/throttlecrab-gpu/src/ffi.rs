@@ -124,6 +124,22 @@ pub struct tc_engine_info {
     pub batches: u64,
 }
 
+/// one rank's side of `replicate` mode (opaque)
+#[repr(C)]
+pub struct tc_shard {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+pub struct tc_shard_config {
+    pub struct_size: u32,
+    pub rank: u32,
+    pub world: u32,
+    pub ring: u32,
+    pub keys_per_shard: u64,
+    pub max_global: u64,
+}
+
 #[repr(C)]
 pub struct tc_exchange_config {
     pub struct_size: u32,
@@ -258,6 +274,20 @@ extern "C" {
         out: *mut tc_result,
     ) -> c_int;
     pub fn tc_sweep_expired(e: *mut tc_engine, now_ns: i64, removed: *mut u64) -> c_int;
+    pub fn tc_shard_create(e: *mut tc_engine, c: *const tc_shard_config, out: *mut *mut tc_shard) -> c_int;
+    pub fn tc_shard_destroy(x: *mut tc_shard) -> c_int;
+    pub fn tc_shard_route(x: *mut tc_shard, step: u64, global_id: *const u32, n: u64) -> c_int;
+    pub fn tc_shard_evaluate(x: *mut tc_shard, step: u64, tmpl: *const tc_batch, decided: *mut u64) -> c_int;
+    pub fn tc_shard_step(
+        x: *mut tc_shard,
+        step: u64,
+        global_id_ahead: *const u32,
+        n_ahead: u64,
+        route_ahead: u32,
+        tmpl: *const tc_batch,
+        decided: *mut u64,
+    ) -> c_int;
+    pub fn tc_shard_wait_ns(x: *mut tc_shard, out: *mut u64) -> c_int;
     pub fn tc_engine_info_get(e: *mut tc_engine, out: *mut tc_engine_info) -> c_int;
     pub fn tc_set_sweep_policy(e: *mut tc_engine, p: *const tc_sweep_policy) -> c_int;
     pub fn tc_sweep_stats(e: *mut tc_engine, out: *mut tc_sweep_info) -> c_int;

@@ -430,3 +430,55 @@ def test_split_router_at_its_grid_limit(n, world):
             assert got[-1] == -7
     assert eng.selfcheck() == 0
     eng.close()
+
+
+@pytest.mark.parametrize("stream_kind", ["uniform", "zipf"])
+def test_replicate_mode_as_one_library_call_per_step(stream_kind):
+    """tc_shard_step (csrc/shard.hip): route step i + 3 on the grouping streams, poll the router's tag, evaluate the
+    rank's share of step i in chunks of at most max_batch -- three ranks of one world stepped in one loop, each seeing the WHOLE
+    global stream; the union of their decisions == one sequential pass of the oracle keyed by the global id."""
+    import torch
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    from tests.test_gpu_slots import T0
+    from throttlecrab_amd import sharded, workload as W
+    world, cap, G, steps, LA = 3, 40_000, 90_000, 10, 3
+    rng = np.random.default_rng(5)
+    z = W.Zipf(world * cap)
+    glob = [(z.slots(G, start=i * G) if stream_kind == "zipf" else rng.integers(0, world * cap, G)).astype(np.uint32) for i in range(steps)]
+    d = [torch.from_numpy(g.astype(np.int32)).cuda() for g in glob]
+    engs, ranks, outs = [], [], []
+    for r in range(world):
+        e = t.Engine(cap, 20_000, fixed_params=True)   # (max_batch below a rank's share: every step is evaluated in chunks)
+        e.use_torch_stream()
+        e.register_params_uniform(5, 10, 60)
+        engs.append(e)
+        ranks.append(sharded.ShardRank(e, r, world, G, ring=LA + 2))
+        outs.append([t.BatchResult(allowed=torch.zeros(G, dtype=torch.uint8, device="cuda"), status=torch.zeros(G, dtype=torch.uint8, device="cuda"))
+                     for _ in range(steps)])
+    torch.cuda.synchronize()
+    decided = {}
+    for r in range(world):
+        for j in range(LA):
+            ranks[r].route(j, d[j])
+    for i in range(steps):
+        for r in range(world):
+            ahead = d[i + LA] if i + LA < steps else None
+            decided[(i, r)] = ranks[r].step(i, ahead, LA, T0 + i * 300_000_000, outs[r], want=("allowed", "status"))
+    torch.cuda.synchronize()
+    orc = O.DenseOracle(world * cap)
+    for i in range(steps):
+        ref = orc.batch_slots(glob[i], 5, 10, 60, 1, T0 + i * 300_000_000)
+        owner, _ = sharded.route(glob[i], world, cap)
+        for r in range(world):
+            mine = owner == r
+            assert decided[(i, r)] == int(mine.sum()), (i, r)
+            k = decided[(i, r)]
+            assert np.array_equal(outs[r][i].allowed.cpu().numpy()[:k], ref.allowed[mine].astype(np.uint8)), (i, r)
+            assert not outs[r][i].status.cpu().numpy()[:k].any()
+    for r in range(world):
+        assert engs[r].selfcheck() == 0
+        assert ranks[r].wait_us() >= 0.0
+        with pytest.raises(t.TcError):
+            ranks[r].step(steps, None, LA + 5, T0, outs[r])   # a look-ahead the ring cannot hold
+        engs[r].close()

@@ -15,7 +15,7 @@ C_SCALARS = {"uint8_t": "u8", "uint16_t": "u16", "uint32_t": "u32", "uint64_t": 
              "int64_t": "i64", "size_t": "usize", "int": "c_int", "char": "c_char", "void": "c_void", "double": "f64",
              "tc_engine": "tc_engine", "tc_config": "tc_config", "tc_batch": "tc_batch", "tc_result": "tc_result",
              "tc_decision": "tc_decision", "tc_route": "tc_route", "tc_forward": "tc_forward", "tc_exchange": "tc_exchange",
-             "tc_exchange_config": "tc_exchange_config", "tc_sweep_policy": "tc_sweep_policy", "tc_sweep_info": "tc_sweep_info", "tc_engine_info": "tc_engine_info"}
+             "tc_exchange_config": "tc_exchange_config", "tc_sweep_policy": "tc_sweep_policy", "tc_sweep_info": "tc_sweep_info", "tc_engine_info": "tc_engine_info", "tc_shard": "tc_shard", "tc_shard_config": "tc_shard_config"}
 
 
 def strip_comments(c):
@@ -64,10 +64,10 @@ def rust_structs():
 def test_repr_c_structs_match_the_header():
     c, r = c_structs(), rust_structs()
     for name in ("tc_config", "tc_batch", "tc_decision", "tc_result", "tc_route", "tc_forward", "tc_exchange_config", "tc_sweep_policy",
-                 "tc_sweep_info", "tc_engine_info"):
+                 "tc_sweep_info", "tc_engine_info", "tc_shard_config"):
         assert name in c and name in r, name
         assert r[name] == c[name], f"{name}: rust {r[name]} != header {c[name]}"
-    assert r["tc_engine"] == [("_private", "[u8; 0]")] and r["tc_exchange"] == [("_private", "[u8; 0]")]  # opaque
+    assert r["tc_engine"] == [("_private", "[u8; 0]")] and r["tc_exchange"] == [("_private", "[u8; 0]")] and r["tc_shard"] == [("_private", "[u8; 0]")]  # opaque
 
 
 def c_constants():

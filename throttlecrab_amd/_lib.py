@@ -91,6 +91,11 @@ class tc_engine_info(C.Structure):
                 ("range_hint_largest", C.c_uint64), ("host_chunk_requests", C.c_uint64), ("batches", C.c_uint64)]
 
 
+class tc_shard_config(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("rank", C.c_uint32), ("world", C.c_uint32), ("ring", C.c_uint32), ("keys_per_shard", C.c_uint64),
+                ("max_global", C.c_uint64)]
+
+
 class tc_result(C.Structure):
     _fields_ = [("limit", C.c_int64), ("remaining", C.c_int64), ("reset_after_ns", C.c_int64),
                 ("retry_after_ns", C.c_int64), ("allowed", C.c_uint8), ("status", C.c_uint8)]
@@ -151,6 +156,12 @@ SYMBOLS = {
     "tc_exchange_step": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(tc_batch), C.POINTER(C.c_uint64)]),
     "tc_exchange_poll": (C.c_int, [C.c_void_p]),
     "tc_exchange_wait_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "tc_shard_create": (C.c_int, [C.c_void_p, C.POINTER(tc_shard_config), C.POINTER(C.c_void_p)]),
+    "tc_shard_destroy": (C.c_int, [C.c_void_p]),
+    "tc_shard_route": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]),
+    "tc_shard_evaluate": (C.c_int, [C.c_void_p, C.c_uint64, C.POINTER(tc_batch), C.POINTER(C.c_uint64)]),
+    "tc_shard_step": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint32, C.POINTER(tc_batch), C.POINTER(C.c_uint64)]),
+    "tc_shard_wait_ns": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
     "tc_route_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_route_inverse": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),
     "tc_route_keys_host": (C.c_int, [C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]),

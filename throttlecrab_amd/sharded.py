@@ -21,6 +21,9 @@ from __future__ import annotations
 
 import numpy as np
 
+import ctypes as C
+
+from . import _lib as L
 from . import workload as W
 from ._lib import TC_CNT_COUNT, TC_CNT_NAMES
 
@@ -363,3 +366,73 @@ class ExchangeRank:
         out = (C.c_uint64 * 3)()
         self._lib.tc_exchange_wait_ns(self._h, out)
         return tuple(v / 1e3 for v in out)
+
+
+class ShardRank:
+    """One rank's side of `replicate` mode as library calls (csrc/shard.hip: tc_shard_*): the rank is handed every global batch,
+    routes it `route_ahead` steps ahead of the evaluation on the engine's grouping streams and decides what it owns -- one call
+    per step (step()).  outs: a list of BatchResult to cycle through, one per step in flight, whose arrays hold the rank's
+    largest share of a global batch."""
+
+    def __init__(self, engine, rank: int, world: int, max_global: int, ring: int = 8):
+        self.eng, self.rank, self.world = engine, rank, world
+        self._lib = engine._lib
+        cfg = L.tc_shard_config()
+        cfg.struct_size = C.sizeof(L.tc_shard_config)
+        cfg.rank, cfg.world, cfg.ring, cfg.keys_per_shard, cfg.max_global = rank, world, ring, engine.capacity, max_global
+        h = C.c_void_p(0)
+        engine._check(self._lib.tc_shard_create(engine._h, C.byref(cfg), C.byref(h)))
+        self._h = h
+        engine._children.append(self)   # (the shard points into the engine: the engine closes it first)
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.tc_shard_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _template(self, now_ns, outs, step, **kw):
+        res = outs[step % len(outs)]
+        idle = len(outs) >= 8 and kw.pop("outputs_idle", True)
+        kw.pop("outputs_idle", None)
+        quantity, want = kw.pop("quantity", 1), kw.pop("want", ("allowed",))
+        if kw:
+            raise TypeError(f"shard evaluation: unsupported options {sorted(kw)} (the registered plans, one timestamp, quantity, want, outputs_idle)")
+        n_out = min(getattr(res, name).numel() // (4 if name in ("result4", "decisions") else 1) for name in want if getattr(res, name) is not None) if any(
+            getattr(res, name) is not None for name in want) else 0
+        if n_out == 0:
+            raise ValueError("shard evaluation: the result arrays of `outs` must be allocated by the caller (they hold a rank's largest share)")
+        b, res, keep = self.eng._prepare(n_out, True, None, None, None, quantity, now_ns, True, False, want, res, inputs_ready=True, outputs_idle=idle)
+        return b, keep
+
+    def route(self, step: int, global_ids):
+        self._keep_ids = global_ids
+        self.eng._check(self._lib.tc_shard_route(self._h, step, global_ids.data_ptr(), global_ids.numel()))
+
+    def evaluate(self, step: int, now_ns: int, outs, **kw) -> int:
+        b, keep = self._template(now_ns, outs, step, **kw)
+        decided = C.c_uint64(0)
+        self.eng._check(self._lib.tc_shard_evaluate(self._h, step, C.byref(b), C.byref(decided)))
+        self._keep = keep
+        return int(decided.value)
+
+    def step(self, step: int, ids_ahead, route_ahead: int, now_ns: int, outs, **kw) -> int:
+        """route(step + route_ahead, ids_ahead) + evaluate(step): ONE library call -> requests this rank decided"""
+        b, keep = self._template(now_ns, outs, step, **kw)
+        decided = C.c_uint64(0)
+        self._keep_ids = ids_ahead
+        self.eng._check(self._lib.tc_shard_step(self._h, step, ids_ahead.data_ptr() if ids_ahead is not None else None,
+                                                ids_ahead.numel() if ids_ahead is not None else 0, route_ahead, C.byref(b), C.byref(decided)))
+        self._keep = keep
+        return int(decided.value)
+
+    def wait_us(self) -> float:
+        out = C.c_uint64(0)
+        self._lib.tc_shard_wait_ns(self._h, C.byref(out))
+        return out.value / 1e3
