@@ -224,12 +224,12 @@ def verify_run(snap, host_batches, n_nows, per_slot, n_keys, batch, general):
             "oracle_allowed": allowed, "engine_allowed": c["allowed"], "seconds": time.perf_counter() - t0}
 
 
-def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",), piped=True, nows=None):
+def run_gpu(eng, d_batches, out, now0, steps, warmup, dist, cnt_view, gathered, want=("allowed",), piped=True, nows=None, it0=0):
     """warmup + timed region; returns seconds for `steps` batches (max over ranks).  (With `nows` the columns repeat
     after len(nows) batches: timestamps then go back by that many ms once per cycle, which the general path takes
     like any other non-monotone clock.)"""
     import torch
-    it = 0
+    it = it0   # (batches already given to the engine: the stream and its clock go on from there)
 
     # every batch in flight writes its results to arrays of its own (a ring of OUT_RING result sets, as a consumer that
     # reads them later needs anyway); decisions-only pipelined batches say so with TC_B_OUTPUTS_IDLE
@@ -363,6 +363,14 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
             res["verified"] = {"ok": False, "error": f"{type(ex).__name__}: {ex}"[:160]}
         del snap
         log(f"  verified: {res['verified']}")
+    if rank == 0 and dist is None and seed_shift == 0 and not a.profile_run and not a.in_order and os.environ.get("TC_BENCH_REPEATS", "1") != "0":
+        # the timed region is 20 x 44 us = 0.9 ms -- four more regions of the same length right behind it (the
+        # stream goes on), so that a 3 % difference between two rounds can be told from noise.  `value` is the FIRST region's.
+        reps = [ms]
+        for _ in range(4):
+            dt_r, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, 0, None, None, None, piped=True, nows=nows, it0=it)
+            reps.append(1e3 * dt_r / a.steps)
+        res["repeats"] = {"ms_per_step": reps, "median": float(np.median(reps)), "min": min(reps), "max": max(reps)}
     if rank == 0 and profile and not a.profile_run:
         piped = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True, nows=nows)
         inorder = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False, nows=nows)
@@ -1186,6 +1194,9 @@ def main():
                    "pipelined": not a.in_order},
         "allowed_fraction": main_res["allowed_fraction"], "pipelining_degraded": main_res.get("pipelining_degraded"),
     }
+    if "repeats" in main_res:
+        result["ms_per_step_median5"] = main_res["repeats"]["median"]
+        result["ms_per_step_range5"] = [main_res["repeats"]["min"], main_res["repeats"]["max"]]
     if a.plans != "one":
         result["config"]["plans"] = a.plans
         result["config"]["workload"] += f", a plan per key ({a.plans})"
@@ -1353,7 +1364,7 @@ def compact_line(result):
     bench_detail.json.  Never longer than COMPACT_LIMIT bytes."""
     top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
            "dtype", "data", "config", "allowed_fraction", "imbalance_max_over_mean", "router_ms_per_step", "route", "errors",
-           "verified", "verified_legs", "verify_failed", "pipelining_degraded")
+           "verified", "verified_legs", "verify_failed", "pipelining_degraded", "ms_per_step_median5", "ms_per_step_range5")
     c = _pick(result, top)
     rf = result.get("roofline")
     if rf:
@@ -1372,6 +1383,11 @@ def compact_line(result):
             c["cpu_baseline"]["reference_shape"] = _pick(cb["reference_shape"], ("value",))
     else:
         c["cpu_baseline"] = None
+    # (north_star states its target on the Zipf stream -- its roofline object beside the headline's)
+    for k in ("zipf_stream", "uniform_stream"):
+        r2 = (result.get(k) or {}).get("roofline") if isinstance(result.get(k), dict) else None
+        if r2 and r2.get("frac") is not None and "invalid" not in r2:
+            c["roofline_" + k.split("_")[0]] = _pick(r2, ("kernel", "avg_ms", "achieved", "frac", "traffic", "whole_step_frac"))
     one = ("value", "ms_per_step", "whole_step_frac")
     for k in ("zipf_stream", "uniform_stream", "wide_layout", "fixed_layout", "general_uniform", "general_zipf"):
         if isinstance(result.get(k), dict):
@@ -1398,7 +1414,7 @@ def compact_line(result):
     c = _r(c)
     line = json.dumps(c, separators=(",", ":"))
     if len(line) > COMPACT_LIMIT:  # shed the optional parts, largest first, rather than break the contract
-        for k in ("per_gpu", "string_keys", "per_key_plans", "abi_shape", "general_uniform", "general_zipf", "fixed_layout", "wide_layout", "allowed_fraction"):
+        for k in ("per_gpu", "roofline_zipf", "roofline_uniform", "string_keys", "per_key_plans", "abi_shape", "general_uniform", "general_zipf", "fixed_layout", "wide_layout", "allowed_fraction"):
             c.pop(k, None)
             line = json.dumps(c, separators=(",", ":"))
             if len(line) <= COMPACT_LIMIT:
