@@ -647,7 +647,7 @@ def abi_shape_bench(a, dev):
             # warm: a freshly pinned array stalls the submitting thread for 5-7 ms the first few times a transfer touches it
             # (tools/abi_stall.py: calls 1, 5, 11, 19 of a ring of 4 sets, then never again) -- a server's staging buffers live
             # as long as the server; here every leg pins new ones, so each set is used six times before the clock starts
-            n_warm = 6 * distinct if mode == "sync_pinned" or asy else 0
+            n_warm = (6 if n >= (1 << 18) else 16) * distinct if mode == "sync_pinned" or asy else 0
             for i in range(n_warm):
                 pb, r_ = pinned[i % distinct]
                 if asy:

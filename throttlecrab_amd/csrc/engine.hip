@@ -153,6 +153,7 @@ int engine_alloc(tc_engine* e) {
         if (v == 8 || v == 16 || v == 32) e->sort_items_piped = v;
     }
     if (const char* d = getenv("TCGPU_NO_SMALL_BATCH")) e->small_off = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_COPY_KERNEL")) e->copy_kernel_off = atoi(d) == 0;
     e->host_chunk = HOST_CHUNK_DEFAULT;
     if (const char* d = getenv("TCGPU_HOST_CHUNK")) e->host_chunk = (uint64_t)std::max(0ll, atoll(d)) / 64 * 64;
     const char* pe = getenv("TCGPU_AUX_PRIORITY");

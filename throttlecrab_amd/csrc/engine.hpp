@@ -201,6 +201,7 @@ struct tc_engine {
     size_t small_io_bytes = 0;
     size_t small_slots_at = 0;    // key mode: where the last small batch's resolved slots are in it (retry of rejected requests)
     bool small_off = false;       // TCGPU_NO_SMALL_BATCH=1: always take the big pipeline
+    bool copy_kernel_off = false; // TCGPU_COPY_KERNEL=0: pinned host inputs of synchronous batches by hipMemcpyAsync, one array at a time (A/B)
     uint64_t host_chunk = 0;      // requests per chunk of a pipelined synchronous host batch (HOST_CHUNK_DEFAULT; TCGPU_HOST_CHUNK, 0: never;
                                   // a multiple of 64: packed decision bits are written in whole words)
 
@@ -406,10 +407,13 @@ inline bool host_chunking_applies(const tc_engine* e, const tc_batch& b) {
 void host_sub_batch(const tc_batch& b, uint64_t at, uint64_t cn, tc_batch& c);
 // wait for the last `mine` TC_B_ASYNC batches (the ones this call issued) and hand their events back to the pool
 int wait_own_async(tc_engine* e, size_t mine);
+// host arrays -> device staging on stream s: ONE copy kernel (mk::k_copy_multi) when every source is pinned host memory, else one
+// hipMemcpyAsync each (count <= 8; a failed copy -- tc_debug_fail_copy -- fails the call before anything was applied, as before)
+int stage_in_multi(tc_engine* e, const void* const* src, void* const* dst, const size_t* bytes, uint32_t count, hipStream_t s);
 int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d);
 int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_kernel = false);
 int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin = nullptr);
-int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag = nullptr);
+int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag = nullptr, const uint32_t* d_slot = nullptr);
 int finish_async(tc_engine* e, const tc_batch& b);
 bool small_batch_applies(const tc_engine* e, const tc_batch& b);
 int run_small_batch(tc_engine* e, const tc_batch& b);

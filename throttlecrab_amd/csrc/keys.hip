@@ -52,8 +52,10 @@ int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, 
         TC_HIP(e, hipMalloc(&e->k_stage_bytes, want));
         e->k_stage_bytes_cap = want;
     }
-    if (total) TC_HIP(e, copy_async(e, e->k_stage_bytes, key_bytes, total, hipMemcpyHostToDevice, cur_stream(e)));
-    TC_HIP(e, copy_async(e, e->k_stage_off, key_off, (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, cur_stream(e)));
+    const void* c_src[2] = {key_bytes, key_off};
+    void* c_dst[2] = {e->k_stage_bytes, e->k_stage_off};
+    const size_t c_bytes[2] = {total, (n + 1) * sizeof(uint32_t)};
+    TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, 2, cur_stream(e)));
     *d_bytes = e->k_stage_bytes ? e->k_stage_bytes : (const uint8_t*)e->k_stage_off;
     *d_off = e->k_stage_off;
     return TC_E_OK;
@@ -224,12 +226,9 @@ static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
     }
     int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, e->k_slot, false);
     if (rc != TC_E_OK) return rc;
-    // host pointers for everything else: reuse the slot path's staging, with the
-    // slot column already on the device
-    TC_TRY(stage_need(e, e->stage.slot, e->max_batch));
-    TC_HIP(e, hipMemcpyAsync(e->stage.slot, e->k_slot, b.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, cur_stream(e)));
+    // host pointers for everything else: the slot path's staging, with the slot column where the key stage left it
     uint32_t flag = 0;
-    rc = run_slots_host_staged(e, b, &flag);
+    rc = run_slots_host_staged(e, b, &flag, e->k_slot);
     if (rc != TC_E_OK) return rc;
     if (flag) {
         TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, cur_stream(e)));

@@ -540,6 +540,38 @@ static __global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, c
     }
 }
 
+// Several such copies in ONE launch (blockIdx.y = the segment): the input columns of a synchronous host batch from PINNED memory.
+// Seven hipMemcpyAsync calls on one stream cost ~10-18 us each before the first byte moves (a 4 Ki-request reference-shaped
+// call spent 70 of its 200 us there); one launch reads them all over PCIe side by side.
+struct CopySegs {
+    const void* src[8];
+    void* dst[8];
+    size_t bytes[8];
+};
+static __global__ __launch_bounds__(BLOCK) void k_copy_multi(CopySegs sg) {
+    const void* __restrict__ src = sg.src[blockIdx.y];
+    void* __restrict__ dst = sg.dst[blockIdx.y];
+    const size_t bytes = sg.bytes[blockIdx.y];
+    const size_t tid = (size_t)blockIdx.x * BLOCK + threadIdx.x, nthreads = (size_t)gridDim.x * BLOCK;
+    if ((((uintptr_t)dst | (uintptr_t)src) & 15u) == 0) {
+        const size_t n16 = bytes / 16;
+        const uint4* s = static_cast<const uint4*>(src);
+        uint4* d = static_cast<uint4*>(dst);
+        size_t i = tid;
+        for (; i + 3 * nthreads < n16; i += 4 * nthreads) {
+            const uint4 a = s[i], b = s[i + nthreads], c = s[i + 2 * nthreads], e = s[i + 3 * nthreads];
+            d[i] = a;
+            d[i + nthreads] = b;
+            d[i + 2 * nthreads] = c;
+            d[i + 3 * nthreads] = e;
+        }
+        for (; i < n16; i += nthreads) d[i] = s[i];
+        for (i = n16 * 16 + tid; i < bytes; i += nthreads) static_cast<uint8_t*>(dst)[i] = static_cast<const uint8_t*>(src)[i];
+    } else {
+        for (size_t i = tid; i < bytes; i += nthreads) static_cast<uint8_t*>(dst)[i] = static_cast<const uint8_t*>(src)[i];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // The policy feed (autosweep.hip): what the host-side cleanup policy (AdaptiveStore::should_clean, adaptive_cleanup.rs:138-171)
 // needs to know about the device -- how many requests were allowed so far (the reference counts one operation per mutating

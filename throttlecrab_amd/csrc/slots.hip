@@ -33,6 +33,37 @@ static int copy_back_async(tc_engine* e, void* host, const void* dev, size_t byt
     return TC_E_OK;
 }
 
+int stage_in_multi(tc_engine* e, const void* const* src, void* const* dst, const size_t* bytes, uint32_t count, hipStream_t s) {
+    mk::CopySegs sg;
+    memset(&sg, 0, sizeof sg);
+    bool pinned = count != 0 && count <= 8 && !e->fault_countdown && !e->copy_kernel_off;
+    size_t largest = 0;
+    uint32_t used = 0;
+    for (uint32_t i = 0; pinned && i < count; ++i) {
+        if (!bytes[i]) continue;
+        void* hv = device_view_of_host(src[i]);
+        if (!hv) {
+            pinned = false;
+            break;
+        }
+        sg.src[used] = hv;
+        sg.dst[used] = dst[i];
+        sg.bytes[used] = bytes[i];
+        largest = std::max(largest, bytes[i]);
+        ++used;
+    }
+    if (pinned && used) {
+        // (few blocks per segment: the transfer is bound by the link, not by the number of waves waiting on it)
+        const uint32_t bx = (uint32_t)std::min<size_t>((largest / 16 + BLOCK - 1) / BLOCK + 1, 32);
+        hipLaunchKernelGGL(mk::k_copy_multi, dim3(bx, used), dim3(BLOCK), 0, s, sg);
+        TC_HIP(e, hipGetLastError());
+        return TC_E_OK;
+    }
+    for (uint32_t i = 0; i < count; ++i)
+        if (bytes[i]) TC_HIP(e, copy_async(e, dst[i], src[i], bytes[i], hipMemcpyHostToDevice, s));
+    return TC_E_OK;
+}
+
 // output staging for the arrays `b` asks for; `d` gets the device pointers
 int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d) {
     const uint64_t mb = e->max_batch;
@@ -557,24 +588,31 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
 // other inputs, run, copy the outputs back, synchronise.
 // key_error_flag: a key batch -- "did a key fail to get a slot" comes back with the results, behind the same wait (it used to be
 // a copy and a wait of its own behind this one: ~25 us of a 4 Ki-request call's 200)
-int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag) {
+// d_slot: the slot column where it already is in device memory (a key batch's resolved slots), else e->stage.slot
+int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag, const uint32_t* d_slot) {
     const uint64_t n = b.n;
     hipStream_t s = cur_stream(e);
     tc_batch d = b;
     d.flags |= TC_B_DEVICE_PTRS;
     d.flags &= ~(TC_B_INPUTS_READY | TC_B_ASYNC);
-    d.slot = e->stage.slot;
+    d.slot = d_slot ? d_slot : e->stage.slot;
     d.key_bytes = nullptr;
     d.key_off = nullptr;
     const int64_t* hin[5] = {b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns};
     const int64_t** din[5] = {&d.max_burst, &d.count_per_period, &d.period, &d.quantity, &d.now_ns};
+    const void* c_src[5];
+    void* c_dst[5];
+    size_t c_bytes[5];
+    uint32_t c_n = 0;
     for (int j = 0; j < 5; ++j) {
         if (hin[j]) {
             TC_TRY(stage_need(e, e->stage.in[j], e->max_batch));
-            TC_HIP(e, copy_async(e, e->stage.in[j], hin[j], n * sizeof(int64_t), hipMemcpyHostToDevice, s));
+            c_src[c_n] = hin[j], c_dst[c_n] = e->stage.in[j], c_bytes[c_n] = n * sizeof(int64_t);
+            ++c_n;
             *din[j] = e->stage.in[j];
         }
     }
+    TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, s)); // (the request columns: one launch from pinned arrays, else a copy each)
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d));
     TC_TRY(copy_outputs_back(e, b, s));
