@@ -399,9 +399,22 @@ inline std::vector<uint64_t> host_chunk_plan(const tc_engine* e, uint64_t n) {
     return plan;
 }
 bool host_arrays_pinned(const tc_batch& b); // slots.hip: every array the batch names is device-visible host memory
+// bytes that cross PCIe per request of a host batch, both ways.  Chunking pays by what it overlaps: the reference-shaped call
+// (87 B) gains 370 us per 1 Mi requests, a slot batch that asks for `allowed` only (5 B) LOSES 30 (217 us against 187, tools/
+// host_slots.py: four enqueues for 5 MB of transfers) -- so only batches that move at least HOST_CHUNK_MIN_BYTES per request.
+constexpr uint64_t HOST_CHUNK_MIN_BYTES = 16;
+inline uint64_t host_bytes_per_request(const tc_batch& b) {
+    uint64_t in = b.slot ? 4 : 0;
+    if (b.key_off && b.key_bytes && b.n) in += 4 + (uint64_t(b.key_off[b.n]) - b.key_off[0]) / b.n;
+    for (const void* c : {(const void*)b.max_burst, (const void*)b.count_per_period, (const void*)b.period, (const void*)b.quantity, (const void*)b.now_ns})
+        in += c ? 8 : 0;
+    uint64_t out = (b.allowed ? 1 : 0) + (b.status ? 1 : 0) + (b.result4 ? 32 : 0) + (b.decisions ? 32 : 0);
+    for (const void* c : {(const void*)b.limit, (const void*)b.remaining, (const void*)b.reset_after_ns, (const void*)b.retry_after_ns}) out += c ? 8 : 0;
+    return in + out;
+}
 inline bool host_chunking_applies(const tc_engine* e, const tc_batch& b) {
     return e->host_chunk && b.n >= 2 * e->host_chunk && !(b.flags & (TC_B_DEVICE_PTRS | TC_B_ASYNC | TC_B_GROUPED_OUTPUT | TC_B_UNIQUE_SLOTS)) &&
-           host_arrays_pinned(b);
+           host_arrays_pinned(b) && host_bytes_per_request(b) >= HOST_CHUNK_MIN_BYTES;
 }
 // requests [at, at + cn) of host batch b as a batch of their own (every column and output advanced; key_off stays absolute)
 void host_sub_batch(const tc_batch& b, uint64_t at, uint64_t cn, tc_batch& c);
