@@ -184,3 +184,112 @@ def test_fuzz_string_mode(seed):
     for k in keys[::11]:
         assert eng.get(k, now) == orc.get(k, now)
     eng.close()
+
+
+SHORT_PLANS = [(5, 10, 1), (2, 60, 60), (10, 100, 60), (3, 7, 60), (1, 1, 1)]   # entries live 0.6 .. 34 s
+
+
+@pytest.mark.parametrize("seed", range(N_KEYS))
+def test_fuzz_string_mode_while_the_engine_cleans_itself(seed):
+    """Round 5: the same interleavings with a cleanup policy set (tc_set_sweep_policy) and NO explicit sweep -- the engine decides
+    when to clean (time, operation count, size), in front of synchronous, pipelined and TC_B_ASYNC batches, single requests and
+    store operations.  Time only moves forward (under which cleanup is decision-neutral, adaptive_cleanup.rs:248): every decision
+    must be the oracle's, which never cleans; at the end one explicit sweep on both sides must leave the same number of entries."""
+    import torch
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    rng = np.random.default_rng(3000 + seed)
+    keys = [b"k%d" % i for i in range(1500)] + [b"", b"\xf0\x9f\xa6\x80"] + [b"L" * 100 + b"%d" % i for i in range(30)]
+    eng = t.Engine(2048, 5000, key_mode=True, track_denied=True)
+    eng.check_on_close = True
+    eng.use_torch_stream()
+    kind = ("adaptive", "adaptive", "periodic", "probabilistic")[seed % 4]
+    if kind == "adaptive":
+        eng.set_sweep_policy("adaptive", created_ns=T0, min_interval_ns=10**9, max_interval_ns=8 * 10**9,
+                             max_operations=int(rng.integers(200, 3000)), map_capacity=int(rng.choice([0, 512])))
+    elif kind == "periodic":
+        eng.set_sweep_policy("periodic", created_ns=T0, interval_ns=2 * 10**9)
+    else:
+        eng.set_sweep_policy("probabilistic", cleanup_probability=7)
+    orc = O.AdaptiveOracle(capacity=100000, created_ns=T0, auto_cleanup=False)
+    now = T0
+    pending = []   # TC_B_ASYNC batches not yet waited for: (result, reference, context)
+
+    def drain():
+        eng.wait_batches()
+        for res, ref, ctx, _keep in pending:   # (_keep: the input arrays of a TC_B_ASYNC call live until it was waited for)
+            _same(res, ref, ctx)
+        pending.clear()
+
+    for step in range(50):
+        now += int(rng.integers(0, 4 * 10**9))
+        op = rng.choice(["uniform", "general", "async", "single", "store"], p=[0.35, 0.25, 0.15, 0.1, 0.15])
+        n = int(rng.integers(1, 5000))
+        idx = np.minimum(rng.zipf(1.25, n) - 1, len(keys) - 1) if rng.random() < 0.6 else rng.integers(0, len(keys), n)
+        kb, ko = O.pack_keys([keys[i] for i in idx])
+        ko = ko.astype(np.uint32)
+        if op != "async":
+            drain()
+        if op == "uniform":
+            b, c, p = SHORT_PLANS[rng.integers(0, len(SHORT_PLANS))]
+            ref = orc.batch_keys(kb, ko, b, c, p, 1, now)
+            if rng.random() < 0.5:
+                dkb, dko = torch.from_numpy(kb).cuda(), torch.from_numpy(ko.astype(np.int32)).cuda()
+                torch.cuda.synchronize()
+                res = eng.rate_limit_batch_keys(dkb, dko, max_burst=b, count_per_period=c, period=p, quantity=1, now_ns=now,
+                                                inputs_ready=bool(rng.random() < 0.7))
+                torch.cuda.synchronize()
+            else:
+                res = eng.rate_limit_batch_keys(kb, ko, max_burst=b, count_per_period=c, period=p, quantity=1, now_ns=now)
+            _same(res, ref, f"seed {seed} step {step} uniform keys ({kind})")
+        elif op in ("general", "async"):
+            pl = np.array(SHORT_PLANS, dtype=object)[rng.integers(0, len(SHORT_PLANS), n)]
+            b, c, p = (np.array([x[k] for x in pl], dtype=np.int64) for k in range(3))
+            q = rng.choice(np.array([0, 1, 1, 3, -1], dtype=np.int64), n)
+            nows = now + np.sort(rng.integers(0, 10**9, n)).astype(np.int64)   # ascending in index order: time never runs back
+            ref = orc.batch_keys(kb, ko, b, c, p, q, nows)
+            if op == "async":
+                out = t.BatchResult(**{f: eng.host_alloc(n, np.uint8 if f in ("allowed", "status") else np.int64) for f in FIELDS})
+                cols = dict(max_burst=b, count_per_period=c, period=p, quantity=q, now_ns=nows)
+                keep = (kb, ko, cols)
+                res = eng.rate_limit_batch_keys(kb, ko, want=FIELDS, out=out, async_=True, **cols)
+                pending.append((res, ref, f"seed {seed} step {step} async keys ({kind})", keep))
+                if len(pending) >= 3:
+                    drain()
+            else:
+                res = eng.rate_limit_batch_keys(kb, ko, max_burst=b, count_per_period=c, period=p, quantity=q, now_ns=nows)
+                _same(res, ref, f"seed {seed} step {step} general keys ({kind})")
+            now = int(nows.max())
+        elif op == "single":
+            for _ in range(10):
+                key = keys[int(rng.integers(0, len(keys)))]
+                b, c, p = SHORT_PLANS[rng.integers(0, len(SHORT_PLANS))]
+                now += int(rng.integers(0, 10**8))
+                k1, o1 = O.pack_keys([key])
+                ref = orc.batch_keys(k1, o1, b, c, p, 1, now)
+                st, allowed, limit, remaining, reset, retry = eng.rate_limit(key, b, c, p, 1, now)
+                assert (st, int(allowed), limit, remaining, reset, retry) == (int(ref.status[0]), int(ref.allowed[0]), int(ref.limit[0]),
+                        int(ref.remaining[0]), int(ref.reset_after_ns[0]), int(ref.retry_after_ns[0])), (seed, step, key)
+        else:
+            for _ in range(15):
+                key = keys[int(rng.integers(0, len(keys)))]
+                v = int(rng.choice(EXTREME))
+                ttl = int(rng.choice([0, 10**9, 5 * 10**9]))
+                kindop = rng.integers(0, 3)
+                if kindop == 0:
+                    assert eng.get(key, now) == orc.get(key, now)
+                elif kindop == 1:
+                    assert eng.set_if_not_exists_with_ttl(key, v, ttl, now) == orc.set_if_not_exists_with_ttl(key, v, ttl, now)
+                else:
+                    cur = orc.get(key, now)
+                    old = cur if (cur is not None and rng.random() < 0.7) else v
+                    assert eng.compare_and_swap_with_ttl(key, old, v, ttl, now) == orc.compare_and_swap_with_ttl(key, old, v, ttl, now)
+    drain()
+    st = eng.sweep_stats()
+    assert st["kind"] == kind and st["sweeps"] > 0, st
+    for k in keys[::11]:
+        assert eng.get(k, now) == orc.get(k, now)
+    orc.force_cleanup(now)
+    eng.sweep_expired(now)
+    assert eng.counters()["live_slots"] == len(orc) and eng.debug_check_keys() == 0, (st, eng.counters(), len(orc))
+    eng.close()
