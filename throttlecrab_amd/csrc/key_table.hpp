@@ -881,69 +881,122 @@ __device__ __forceinline__ void overflow_swap(const Table& t, const unsigned lon
 static __global__ __launch_bounds__(THREADS) void k_table_clear_compact(Table t, const uint32_t* __restrict__ flag, unsigned long long* __restrict__ oflag) {
     if (*flag != 0u) {
         // 32-byte entries as two 16-byte stores per thread
-        ulonglong2* raw = reinterpret_cast<ulonglong2*>(t.ktab);
+        typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+        v2u64* raw = reinterpret_cast<v2u64*>(t.ktab);
         const uint64_t n16 = (t.nb_mask + 1) * 2;
+        const v2u64 z = {0ull, 0ull};
         for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * THREADS)
-            raw[i] = make_ulonglong2(0ull, 0ull);
+            __builtin_nontemporal_store(z, &raw[i]);
     }
     overflow_compact(t, oflag);
 }
 
 // re-enter every bound slot into the cleared table
+// Round 5: the bound slots of a tile of 4 096 are first gathered into LDS, then entered with every lane busy.  A rebuild follows a sweep
+// that unbound most keys (configs[4]'s first: 1.5 M of 10.5 M stay), and the kernel used to walk the slots lane by lane: one lane in
+// eight had a key to enter, and so that no load sat under a branch the others fetched a record line anyway -- 2.9 M of those against
+// 1.5 M useful ones, 349 us.  Now a thread reads 16 `bound` bytes at once, the block ranks its bound slots (one LDS atomic per wave),
+// and the list is worked off four keys per thread: four records requested, four claims issued, then the fills.
+constexpr int RE_PER = 16;                        // slots per thread and tile
+constexpr uint32_t RE_TILE = THREADS * RE_PER;    // 4 096 slots: 16 KB of LDS for the list
 static __global__ __launch_bounds__(THREADS) void k_table_reinsert(Table t, const uint32_t* __restrict__ flag, const unsigned long long* __restrict__ oflag) {
     if (blockIdx.x == 0 && threadIdx.x == 0) overflow_swap(t, oflag); // (nothing below looks at the arena)
     if (*flag == 0u) return;
     if (blockIdx.x == 0 && threadIdx.x < TOMB_SHARDS) t.tombs[threadIdx.x] = 0u;
-    // four slots per thread and round: their `bound` bytes, then hash, length and the first 16 key bytes of the bound ones'
-    // records, are all requested before anything is looked at (one slot per round left three dependent round trips per bound
-    // slot in the open: 339 us for the 1.5 M keys that survive configs[4]'s first sweep)
-    constexpr int RI = 4;
-    const uint32_t stride = gridDim.x * THREADS;
-    for (uint32_t s0 = blockIdx.x * THREADS + threadIdx.x; s0 < t.capacity; s0 += stride * RI) {
-        uint8_t bnd[RI];
-        uint64_t h[RI], a[RI], b[RI];
-        uint32_t len[RI];
+    __shared__ uint32_t s_list[RE_TILE];
+    __shared__ uint32_t s_fill;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t tile0 = (uint64_t)blockIdx.x * RE_TILE; tile0 < t.capacity; tile0 += (uint64_t)gridDim.x * RE_TILE) {
+        if (threadIdx.x == 0) s_fill = 0u;
+        __syncthreads();
+        const uint64_t mine0 = tile0 + (uint64_t)threadIdx.x * RE_PER;
+        uint32_t w[RE_PER / 4];
+        if (mine0 + RE_PER <= t.capacity) { // (hipMalloc aligns `bound`, tiles and threads start at multiples of 16)
+            const uint4 v = *reinterpret_cast<const uint4*>(t.bound + mine0);
+            w[0] = v.x, w[1] = v.y, w[2] = v.z, w[3] = v.w;
+        } else {
 #pragma unroll
-        for (int j = 0; j < RI; ++j) {
-            const uint64_t s = (uint64_t)s0 + (uint64_t)j * stride;
-            bnd[j] = s < t.capacity ? t.bound[s] : (uint8_t)0;
-        }
-#pragma unroll
-        for (int j = 0; j < RI; ++j) {
-            const KeyRec& kr = t.rec[bnd[j] ? s0 + j * stride : s0]; // (unconditional: a load under a branch drains the earlier ones first)
-            h[j] = kr.hash;
-            len[j] = kr.len;
-            __builtin_memcpy(&a[j], kr.bytes, 8);
-            __builtin_memcpy(&b[j], kr.bytes + 8, 8);
-        }
-#pragma unroll
-        for (int j = 0; j < RI; ++j) {
-            if (!bnd[j]) continue;
-            const uint32_t s = s0 + j * stride;
-            const unsigned long long meta = entry_meta(h[j], len[j]);
-            uint64_t k0 = 0, k1 = 0;
-            if (len[j] <= ENTRY_KEY) {
-                k0 = keep_bytes(a[j], len[j] < 8u ? len[j] : 8u);
-                k1 = len[j] > 8u ? keep_bytes(b[j], len[j] - 8u) : 0ull;
-            }
-            uint64_t pos = h[j] & t.nb_mask;
-            while (true) {
-                // claim with the pending pattern (nobody probes during a rebuild), fill, publish
-                unsigned long long expected = 0ull;
-                if (__hip_atomic_compare_exchange_strong(&t.ktab[pos].w, &expected, meta | (unsigned long long)VAL_PENDING,
-                                                         __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    Entry* en = &t.ktab[pos];
-                    en->hash = h[j];
-                    en->key[0] = k0;
-                    en->key[1] = k1;
-                    en->w = meta | (unsigned long long)(s + 2u);
-                    t.pos_col[s] = (uint32_t)pos; // (KeyRec::pos stays what it was at binding: writing it dirtied every bound key's
-                                                  // record line, a quarter of the rebuild's 0.77 GB)
-                    break;
+            for (int q = 0; q < RE_PER / 4; ++q) {
+                w[q] = 0u;
+                for (int b = 0; b < 4; ++b) {
+                    const uint64_t s = mine0 + (uint64_t)q * 4 + b;
+                    if (s < t.capacity && t.bound[s]) w[q] |= 1u << (8 * b);
                 }
-                pos = (pos + 1) & t.nb_mask;
             }
         }
+        uint32_t cnt = 0;
+#pragma unroll
+        for (int q = 0; q < RE_PER / 4; ++q)
+            for (int b = 0; b < 4; ++b) cnt += ((w[q] >> (8 * b)) & 0xFFu) != 0u;
+        uint32_t incl = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        uint32_t base = 0;
+        if (lane == 63) base = atomicAdd(&s_fill, incl); // (any order will do)
+        base = __shfl(base, 63, 64);
+        uint32_t at = base + incl - cnt;
+#pragma unroll
+        for (int q = 0; q < RE_PER / 4; ++q)
+            for (int b = 0; b < 4; ++b)
+                if ((w[q] >> (8 * b)) & 0xFFu) s_list[at++] = (uint32_t)(mine0 + (uint64_t)q * 4 + b);
+        __syncthreads();
+        const uint32_t total = s_fill;
+        constexpr int RI = 4;
+        for (uint32_t k0 = threadIdx.x; k0 < total; k0 += THREADS * RI) {
+            uint32_t s[RI], len[RI];
+            uint64_t h[RI], a[RI], b[RI], pos[RI];
+            unsigned long long meta[RI];
+            bool have[RI], taken[RI];
+#pragma unroll
+            for (int j = 0; j < RI; ++j) {
+                have[j] = k0 + j * THREADS < total;
+                s[j] = s_list[have[j] ? k0 + j * THREADS : k0];
+            }
+#pragma unroll
+            for (int j = 0; j < RI; ++j) {
+                const KeyRec& kr = t.rec[s[j]];
+                h[j] = kr.hash;
+                len[j] = kr.len;
+                __builtin_memcpy(&a[j], kr.bytes, 8);
+                __builtin_memcpy(&b[j], kr.bytes + 8, 8);
+            }
+#pragma unroll
+            for (int j = 0; j < RI; ++j) { // claim with the pending pattern (nobody probes during a rebuild): four claims in flight
+                meta[j] = entry_meta(h[j], len[j]);
+                pos[j] = h[j] & t.nb_mask;
+                taken[j] = false;
+                if (have[j]) {
+                    unsigned long long expected = 0ull;
+                    taken[j] = !__hip_atomic_compare_exchange_strong(&t.ktab[pos[j]].w, &expected, meta[j] | (unsigned long long)VAL_PENDING, __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RI; ++j) {
+                if (!have[j]) continue;
+                while (taken[j]) { // the next entry of the chain
+                    pos[j] = (pos[j] + 1) & t.nb_mask;
+                    unsigned long long expected = 0ull;
+                    taken[j] = !__hip_atomic_compare_exchange_strong(&t.ktab[pos[j]].w, &expected, meta[j] | (unsigned long long)VAL_PENDING, __ATOMIC_RELAXED,
+                                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                uint64_t k0b = 0, k1b = 0;
+                if (len[j] <= ENTRY_KEY) {
+                    k0b = keep_bytes(a[j], len[j] < 8u ? len[j] : 8u);
+                    k1b = len[j] > 8u ? keep_bytes(b[j], len[j] - 8u) : 0ull;
+                }
+                Entry* en = &t.ktab[pos[j]];
+                en->hash = h[j];
+                en->key[0] = k0b;
+                en->key[1] = k1b;
+                en->w = meta[j] | (unsigned long long)(s[j] + 2u);
+                t.pos_col[s[j]] = (uint32_t)pos[j]; // (KeyRec::pos stays what it was at binding: writing it dirtied every bound key's
+                                                    // record line, a quarter of the rebuild's 0.77 GB)
+            }
+        }
+        __syncthreads(); // the list is reused by the next tile
     }
 }
 

@@ -94,7 +94,7 @@ int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_
                        e->spread_free ? 1u : 0u);
     hipLaunchKernelGGL(kt::k_table_clear_compact, dim3(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block, 0, s, t, (const uint32_t*)flag, oflag);
     // (the sweep's completion event -- later key stages on the key stream wait for it -- rides on its last kernel)
-    TC_LAUNCH(e->m_done, kt::k_table_reinsert, dim3(std::min<uint64_t>(nblocks(t.capacity), 2048)), block, 0, s, t, (const uint32_t*)flag,
+    TC_LAUNCH(e->m_done, kt::k_table_reinsert, dim3(std::min<uint64_t>((t.capacity + kt::RE_TILE - 1) / kt::RE_TILE, 2048)), block, 0, s, t, (const uint32_t*)flag,
               (const unsigned long long*)oflag);
     TC_HIP(e, hipGetLastError());
     e->m_busy = true;
