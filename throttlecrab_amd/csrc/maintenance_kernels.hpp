@@ -168,7 +168,13 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
         for (int j = 0; j < SWEEP_ITEMS; ++j) {
             const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
             bnd[j] = i < last ? t.bound[i] : (uint8_t)0;
-            exp_[j] = cells[i < last ? i : first].expiry;
+        }
+        // (only the bound slots' cells: between sweeps a quarter of configs[4]'s slots are bound, and free slots come in stretches --
+        // the others all ask for the block's first cell, one line)
+#pragma unroll
+        for (int j = 0; j < SWEEP_ITEMS; ++j) {
+            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+            exp_[j] = cells[bnd[j] ? i : first].expiry;
         }
         uint32_t mine = 0;
 #pragma unroll
