@@ -30,6 +30,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <tuple>
 #include <utility>
 #include <variant>
 #include <vector>
@@ -99,6 +100,10 @@ struct Channel {
 
     // statistics of the drain loop (how well the queue batches)
     uint64_t batches = 0, requests = 0, largest_batch = 0;
+    // where the actor thread's time goes (ns; written by the actor thread only, read through RateLimiterHandle::loop_ns):
+    // handing batches to the limiter, answering (of which: collect_batch, i.e. waiting for the GPU + the outcomes), releasing
+    // answered messages
+    uint64_t ns_submit = 0, ns_answer = 0, ns_collect = 0, ns_release = 0;
 };
 } // namespace detail
 
@@ -151,6 +156,9 @@ class RateLimiterHandle {
         std::lock_guard<std::mutex> lk(ch_->mu);
         return {ch_->batches, ch_->requests, ch_->largest_batch};
     }
+
+    // (submit, answer, of which collect_batch, release) nanoseconds of the actor thread so far -- a diagnostic, read without a lock
+    std::tuple<uint64_t, uint64_t, uint64_t, uint64_t> loop_ns() const { return {ch_->ns_submit, ch_->ns_answer, ch_->ns_collect, ch_->ns_release}; }
 
   private:
     template <class L>
@@ -216,6 +224,7 @@ class BasicRateLimiterActor {
     }
 
   private:
+    static uint64_t clock_ns() { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
     // actor.rs:217-236, draining the queue instead of taking one message -- and pipelined: a drained batch
     // is only SUBMITTED (RateLimiter::submit_batch: marshalled into pinned buffers, transfers and evaluation
     // enqueued); while the GPU works on it the loop drains and marshals the next one, and the replies of
@@ -259,12 +268,18 @@ class BasicRateLimiterActor {
             const bool took = !msgs.empty();
             if (took) {
                 ch.not_full.notify_all();
+                const uint64_t t0 = clock_ns();
                 if (submit_throttle_batch(limiter, msgs)) flying.push_back(std::move(msgs));
+                ch.ns_submit += clock_ns() - t0;
             }
             // answer the oldest batch when the pipeline is full or the queue had nothing to add
             if (!flying.empty() && (flying.size() >= Limiter::FLIGHTS || !took)) {
-                answer_throttle_batch(limiter, flying.front());
+                const uint64_t t0 = clock_ns();
+                answer_throttle_batch(limiter, flying.front(), &ch.ns_collect);
+                const uint64_t t1 = clock_ns();
                 flying.pop_front();
+                ch.ns_answer += t1 - t0;
+                ch.ns_release += clock_ns() - t1;
             }
         }
     }
@@ -306,10 +321,12 @@ class BasicRateLimiterActor {
 
     // second half: the replies; send errors are ignored like in the reference (the receiver may have given
     // up, actor.rs:229-230)
-    static void answer_throttle_batch(Limiter& limiter, std::deque<RateLimiterMessage>& msgs) {
+    static void answer_throttle_batch(Limiter& limiter, std::deque<RateLimiterMessage>& msgs, uint64_t* ns_collect) {
         std::vector<RateLimitOutcome> out;
         try {
+            const uint64_t t0 = clock_ns();
             out = limiter.collect_batch();
+            *ns_collect += clock_ns() - t0;
         } catch (const std::exception& ex) {
             answer_all(msgs, std::string("Rate limit check failed: internal error: ") + ex.what());
             return;
@@ -329,7 +346,11 @@ class BasicRateLimiterActor {
                 const size_t k = m.many->requests.size();
                 std::vector<Result<ThrottleResponse>> rs;
                 rs.reserve(k);
-                for (size_t i = 0; i < k; ++i) rs.push_back(reply(out[at++]));
+                for (size_t i = 0; i < k; ++i) { // (in place: a temporary variant would be moved through its visitor)
+                    const RateLimitOutcome& o = out[at++];
+                    if (const auto* ok = std::get_if<0>(&o)) rs.emplace_back(std::in_place_index<0>, ThrottleResponse::from(ok->first, ok->second));
+                    else rs.push_back(reply(o));
+                }
                 m.many->tx.set_value(std::move(rs));
             }
         }

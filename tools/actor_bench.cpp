@@ -80,5 +80,9 @@ int main(int argc, char** argv) {
     std::printf("actor: %d producers x %d requests, window %d, group %d: %.2f M requests/s  (%llu batches, avg %.0f, largest %llu; failed %llu)\n",
                 producers, per, window, group, producers * (double)per / dt / 1e6, (unsigned long long)(b1 - b0),
                 (double)(r1 - r0) / (double)(b1 - b0 ? b1 - b0 : 1), (unsigned long long)l1, (unsigned long long)failed.load());
+    const auto [ns_s, ns_a, ns_c, ns_r] = handle.loop_ns();
+    std::printf("  actor thread, ns per request (warm-up included): submit %.1f, answer %.1f (of which collect_batch = waiting for the GPU + the outcomes: %.1f), "
+                "release %.1f; wall %.1f\n",
+                (double)ns_s / (double)r1, (double)ns_a / (double)r1, (double)ns_c / (double)r1, (double)ns_r / (double)r1, 1e9 * dt / (producers * (double)per));
     return 0;
 }
