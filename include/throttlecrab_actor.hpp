@@ -22,6 +22,7 @@
 // a send after shutdown fails with "Rate limiter actor has shut down" (actor.rs:77).
 #pragma once
 
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -87,15 +88,29 @@ struct RateLimiterMessage {
 };
 
 namespace detail {
-// bounded multi-producer single-consumer channel + the actor thread that drains it
-struct Channel {
+// bounded multi-producer single-consumer channel + the actor thread that drains it.
+// Round 5: the queue is SHARDED.  One deque under one mutex carried ~1 M messages/s however many threads sent (16 producers
+// handing the lock to each other through the kernel -- tools/actor_bench.cpp, single requests: the reference's own message
+// shape); now every handle sends into the shard it was given when it was made (round robin), under that shard's lock, and the
+// actor drains all shards in turn.  What a channel guarantees is kept: the messages of ONE handle are evaluated in the order
+// they were sent (one handle, one shard, FIFO); messages of different handles were never ordered against each other by
+// anything but the race for the lock.  The bound on queued requests, senders blocking while it is reached, and the actor
+// sleeping on an empty channel go through one counter and one mutex that is only taken to sleep or to wake somebody.
+constexpr size_t SHARDS = 16;
+struct alignas(64) Shard {
     std::mutex mu;
-    std::condition_variable not_empty, not_full;
     std::deque<RateLimiterMessage> queue;
-    size_t queued_requests = 0; // requests in `queue` (a message may carry many)
+};
+struct Channel {
+    Shard shard[SHARDS];
+    std::atomic<size_t> queued_requests{0}; // requests in the shards or about to be pushed (a message may carry many)
+    std::atomic<uint32_t> next_shard{0};
+    std::atomic<bool> closed{false}, actor_sleeping{false};
+    std::atomic<uint32_t> senders_waiting{0};
     size_t buffer_size = 1;
+    std::mutex mu; // sleeping and waking, the sender count, the statistics
+    std::condition_variable not_empty, not_full;
     size_t senders = 0;
-    bool closed = false;
     std::thread actor;
 
     // statistics of the drain loop (how well the queue batches)
@@ -112,10 +127,11 @@ class RateLimiterHandle {
   public:
     using request_type = ThrottleRequest;
     RateLimiterHandle() = default;
-    RateLimiterHandle(const RateLimiterHandle& o) : ch_(o.ch_) { retain(); }
-    RateLimiterHandle(RateLimiterHandle&& o) noexcept : ch_(std::move(o.ch_)) {}
+    RateLimiterHandle(const RateLimiterHandle& o) : ch_(o.ch_) { retain(); } // (a copy is another sender: it gets a shard of its own)
+    RateLimiterHandle(RateLimiterHandle&& o) noexcept : ch_(std::move(o.ch_)), shard_(o.shard_) {}
     RateLimiterHandle& operator=(RateLimiterHandle o) {
         std::swap(ch_, o.ch_);
+        std::swap(shard_, o.shard_);
         return *this;
     }
     ~RateLimiterHandle() { release(); }
@@ -168,19 +184,40 @@ class RateLimiterHandle {
     // larger than the whole buffer is let in when the buffer is empty).
     bool send(RateLimiterMessage& msg) {
         if (!ch_) return false;
+        detail::Channel& ch = *ch_;
         const size_t n = msg.size();
-        std::unique_lock<std::mutex> lk(ch_->mu);
-        ch_->not_full.wait(lk, [&] { return ch_->closed || ch_->queued_requests == 0 || ch_->queued_requests + n <= ch_->buffer_size; });
-        if (ch_->closed) return false;
-        const bool was_empty = ch_->queue.empty();
-        ch_->queue.push_back(std::move(msg));
-        ch_->queued_requests += n;
-        lk.unlock();
-        if (was_empty) ch_->not_empty.notify_one(); // (the actor only ever sleeps on an empty queue)
+        // room first (tokio's bounded mpsc: a permit, then the value)
+        size_t q = ch.queued_requests.load();
+        while (true) {
+            if (ch.closed.load()) return false;
+            if (q == 0 || q + n <= ch.buffer_size) {
+                if (ch.queued_requests.compare_exchange_weak(q, q + n)) break;
+                continue;
+            }
+            std::unique_lock<std::mutex> lk(ch.mu);
+            ch.senders_waiting.fetch_add(1);
+            ch.not_full.wait(lk, [&] {
+                q = ch.queued_requests.load();
+                return ch.closed.load() || q == 0 || q + n <= ch.buffer_size;
+            });
+            ch.senders_waiting.fetch_sub(1);
+        }
+        {
+            detail::Shard& sh = ch.shard[shard_];
+            std::lock_guard<std::mutex> lk(sh.mu);
+            sh.queue.push_back(std::move(msg));
+        }
+        // the actor only ever sleeps on an empty channel, and says so first: either it sees the request counted above, or
+        // this load sees its flag (both sequentially consistent)
+        if (ch.actor_sleeping.load()) {
+            std::lock_guard<std::mutex> lk(ch.mu);
+            ch.not_empty.notify_one();
+        }
         return true;
     }
     void retain() {
         if (!ch_) return;
+        shard_ = ch_->next_shard.fetch_add(1) % detail::SHARDS;
         std::lock_guard<std::mutex> lk(ch_->mu);
         ++ch_->senders;
     }
@@ -190,7 +227,7 @@ class RateLimiterHandle {
         {
             std::lock_guard<std::mutex> lk(ch_->mu);
             last = --ch_->senders == 0;
-            if (last) ch_->closed = true; // all senders dropped: rx.recv() returns None (actor.rs:222)
+            if (last) ch_->closed.store(true); // all senders dropped: rx.recv() returns None (actor.rs:222)
         }
         if (last) {
             ch_->not_empty.notify_all();
@@ -200,6 +237,7 @@ class RateLimiterHandle {
         ch_.reset();
     }
     std::shared_ptr<detail::Channel> ch_;
+    uint32_t shard_ = 0;
 };
 
 // actor.rs:88-168 (spawn_periodic / spawn_probabilistic / spawn_adaptive differ only in the
@@ -233,41 +271,60 @@ class BasicRateLimiterActor {
     static void run_actor(detail::Channel& ch, Limiter& limiter, size_t max_batch, std::chrono::microseconds linger,
                           size_t min_batch) {
         std::deque<std::deque<RateLimiterMessage>> flying; // submitted batches, oldest first
+        size_t first_shard = 0; // the drain starts one shard further every turn
         while (true) {
             std::deque<RateLimiterMessage> msgs;
-            {
-                std::unique_lock<std::mutex> lk(ch.mu);
-                if (flying.empty()) { // nothing to answer meanwhile: wait for work
-                    ch.not_empty.wait(lk, [&] { return ch.closed || !ch.queue.empty(); });
-                    if (ch.queue.empty()) break; // closed and drained
-                    if (linger.count() > 0 && ch.queued_requests < min_batch && !ch.closed) {
-                        // (senders only signal an empty queue: poll in slices of the linger time)
-                        const auto until = std::chrono::steady_clock::now() + linger;
-                        while (!ch.closed && ch.queued_requests < min_batch && std::chrono::steady_clock::now() < until)
-                            ch.not_empty.wait_for(lk, linger / 8 + std::chrono::microseconds(1));
+            if (flying.empty()) { // nothing to answer meanwhile: wait for work
+                if (ch.queued_requests.load() == 0) {
+                    std::unique_lock<std::mutex> lk(ch.mu);
+                    ch.actor_sleeping.store(true);
+                    ch.not_empty.wait(lk, [&] { return ch.closed.load() || ch.queued_requests.load() != 0; });
+                    ch.actor_sleeping.store(false);
+                }
+                if (ch.queued_requests.load() == 0 && ch.closed.load()) break; // closed and drained
+                if (linger.count() > 0 && ch.queued_requests.load() < min_batch && !ch.closed.load()) {
+                    // (senders only signal a sleeping actor: poll in slices of the linger time)
+                    const auto until = std::chrono::steady_clock::now() + linger;
+                    std::unique_lock<std::mutex> lk(ch.mu);
+                    while (!ch.closed.load() && ch.queued_requests.load() < min_batch && std::chrono::steady_clock::now() < until)
+                        ch.not_empty.wait_for(lk, linger / 8 + std::chrono::microseconds(1));
+                }
+            }
+            size_t take = 0; // requests
+            bool limit = false;
+            for (size_t k = 0; k < detail::SHARDS && !limit; ++k) {
+                detail::Shard& sh = ch.shard[(first_shard + k) % detail::SHARDS];
+                std::lock_guard<std::mutex> lk(sh.mu);
+                if (sh.queue.empty()) continue;
+                if (msgs.empty() && ch.queued_requests.load() <= max_batch) { // O(1) under the lock the senders need
+                    // (queued_requests >= what the shards hold: everything there is fits)
+                    msgs.swap(sh.queue);
+                    for (const RateLimiterMessage& m : msgs) take += m.size();
+                    continue;
+                }
+                while (!sh.queue.empty()) {
+                    if (take != 0 && take + sh.queue.front().size() > max_batch) {
+                        limit = true;
+                        break;
                     }
+                    take += sh.queue.front().size();
+                    msgs.push_back(std::move(sh.queue.front()));
+                    sh.queue.pop_front();
                 }
-                size_t take = 0; // requests
-                if (ch.queued_requests <= max_batch) { // the whole queue: O(1) under the lock the senders need
-                    take = ch.queued_requests;
-                    msgs.swap(ch.queue);
-                } else {
-                    while (!ch.queue.empty() && (take == 0 || take + ch.queue.front().size() <= max_batch)) {
-                        take += ch.queue.front().size();
-                        msgs.push_back(std::move(ch.queue.front()));
-                        ch.queue.pop_front();
-                    }
-                }
-                ch.queued_requests -= take;
-                if (take) {
-                    ch.batches += 1;
-                    ch.requests += take;
-                    if (take > ch.largest_batch) ch.largest_batch = take;
-                }
+            }
+            first_shard = (first_shard + 1) % detail::SHARDS;
+            if (take) {
+                ch.queued_requests.fetch_sub(take);
+                std::lock_guard<std::mutex> lk(ch.mu);
+                ch.batches += 1;
+                ch.requests += take;
+                if (take > ch.largest_batch) ch.largest_batch = take;
+                if (ch.senders_waiting.load() != 0) ch.not_full.notify_all();
+            } else if (flying.empty()) {
+                std::this_thread::yield(); // (a sender has counted its request and is about to push it)
             }
             const bool took = !msgs.empty();
             if (took) {
-                ch.not_full.notify_all();
                 const uint64_t t0 = clock_ns();
                 if (submit_throttle_batch(limiter, msgs)) flying.push_back(std::move(msgs));
                 ch.ns_submit += clock_ns() - t0;
