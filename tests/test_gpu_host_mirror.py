@@ -8,10 +8,20 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _stale(exe, *sources):
+    """the program is missing, or older than its source, a header under include/ or libtcgpu.so (the tree travels with its built
+    programs: one built before the last header change must not be what is tested)"""
+    import glob
+    if not os.path.exists(exe):
+        return True
+    deps = list(sources) + glob.glob(os.path.join(ROOT, "include", "*")) + [os.path.join(ROOT, "throttlecrab_amd", "libtcgpu.so")]
+    return any(os.path.exists(d) and os.path.getmtime(d) > os.path.getmtime(exe) for d in deps)
+
+
 @pytest.mark.gpu
 def test_cpp_host_mirror_program():
     exe = os.path.join(ROOT, "tests", "cpp", "test_host_mirror")
-    if not os.path.exists(exe):
+    if _stale(exe, exe + ".cpp"):
         import __graft_entry__ as g
         g.build_host_mirror_test()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
@@ -23,7 +33,7 @@ def test_cpp_host_mirror_program():
 def test_cpp_actor_and_resp_pipeline_program():
     """Batch-draining actor (actor.rs mirror) and the RESP THROTTLE pipeline on the GPU."""
     exe = os.path.join(ROOT, "tests", "cpp", "test_actor_resp")
-    if not os.path.exists(exe):
+    if _stale(exe, exe + ".cpp"):
         import __graft_entry__ as g
         g.build_actor_resp_tests()
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
