@@ -224,8 +224,17 @@ int engine_alloc(tc_engine* e) {
     TC_HIP(e, hipMemsetAsync(e->pend_count, 0, 2 * sizeof(uint32_t), (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->allowed_tmp, mb));
     TC_HIP(e, hipMalloc(&e->sweep_part, 3 * (size_t)SWEEP_GRID * sizeof(uint32_t)));
-    TC_HIP(e, hipMalloc(&e->op_result, sizeof(StoreOpResult)));
-    TC_HIP(e, hipMalloc(&e->one_result, sizeof(OneResult)));
+    {
+        static_assert(sizeof(OneResult) <= 64 && sizeof(StoreOpResult) <= 64, "one cache line each");
+        TC_HIP(e, hipHostMalloc((void**)&e->host_results, 256, hipHostMallocDefault));
+        memset(e->host_results, 0, 256);
+        void* dv = nullptr;
+        TC_HIP(e, hipHostGetDevicePointer(&dv, e->host_results, 0));
+        uint8_t* d = static_cast<uint8_t*>(dv);
+        e->one_result = reinterpret_cast<OneResult*>(d), e->one_result_host = reinterpret_cast<const OneResult*>(e->host_results);
+        e->op_result = reinterpret_cast<StoreOpResult*>(d + 64), e->op_result_host = reinterpret_cast<const StoreOpResult*>(e->host_results + 64);
+        e->one_slot = reinterpret_cast<uint32_t*>(d + 128), e->one_slot_host = reinterpret_cast<const uint32_t*>(e->host_results + 128);
+    }
     TC_HIP(e, hipStreamSynchronize((hipStream_t)0)); // set-up runs on the null stream: no private stream yet
     return TC_E_OK;
 }
@@ -480,7 +489,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
             if (p) (void)hipFree(p);
     }
     void* ptrs[] = {e->route_ws, e->bp_park, e->cells, e->tat8, e->rate_id, e->classes, e->denied, e->topk_ws, e->probe_ws, e->probe_stamps, e->counters, e->pend, e->chain, e->loaded, e->pend_count,
-                    e->allowed_tmp, e->op_result, e->one_result, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
+                    e->allowed_tmp, e->stage.slot, e->stage.in[0], e->stage.in[1], e->stage.in[2],
                     e->stage.in[3], e->stage.in[4], e->stage.allowed, e->stage.bits, e->stage.out[0],
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};
     for (void* p : ptrs)
@@ -490,6 +499,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
         (void)hipStreamDestroy(e->key_stream);
     }
     if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
+    if (e->host_results) (void)hipHostFree(e->host_results);
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
     if (e->route_l0_done) (void)hipEventDestroy(e->route_l0_done);

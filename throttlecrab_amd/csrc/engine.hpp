@@ -178,8 +178,16 @@ struct tc_engine {
     int64_t cls_min_ei = INT64_MAX, cls_max_ei = 0, cls_min_dvt = INT64_MAX, cls_max_dvt = 0;
     uint32_t* pend_count = nullptr;
     uint8_t* allowed_tmp = nullptr;
-    StoreOpResult* op_result = nullptr;
-    OneResult* one_result = nullptr; // tc_rate_limit: the single request's result
+    // Results of the single-request calls land in PINNED host memory, written by the kernel itself (round 5: they used to be
+    // fetched with a copy behind the kernel -- a second launch, 7 us after the first: 12-15 of a call's 33 us).  The *_result
+    // pointers are the device's view of the block (what the kernels are given), *_host the caller's.
+    uint8_t* host_results = nullptr;       // hipHostMalloc: OneResult | StoreOpResult | one resolved slot
+    StoreOpResult* op_result = nullptr;    // (device view)
+    OneResult* one_result = nullptr;       // (device view) tc_rate_limit: the single request's result
+    uint32_t* one_slot = nullptr;          // (device view) resolve_one_key
+    const StoreOpResult* op_result_host = nullptr;
+    const OneResult* one_result_host = nullptr;
+    const uint32_t* one_slot_host = nullptr;
 
     // staging for host-pointer batches (lazy)
     struct Stage {

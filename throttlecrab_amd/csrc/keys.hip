@@ -69,10 +69,10 @@ int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool inser
     const uint32_t* d_off;
     int rc = stage_keys(e, key, off, 1, &d_bytes, &d_off);
     if (rc != TC_E_OK) return rc;
-    rc = resolve_keys_device(e, d_bytes, d_off, 1, insert, e->k_slot, false);
+    rc = resolve_keys_device(e, d_bytes, d_off, 1, insert, e->one_slot, false); // (the slot lands in pinned memory: no copy behind it)
     if (rc != TC_E_OK) return rc;
-    TC_HIP(e, hipMemcpyAsync(slot, e->k_slot, sizeof(uint32_t), hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    *slot = *(volatile const uint32_t*)e->one_slot_host;
     return TC_E_OK;
 }
 
@@ -407,9 +407,9 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
         e->m_busy = true;
     }
     TC_TRY(auto_sweep_after(e, 1, true, nullptr, now_ns));
-    OneResult r;
-    TC_HIP(e, hipMemcpyAsync(&r, e->one_result, sizeof r, hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
+    OneResult r;
+    memcpy(&r, (const void*)e->one_result_host, sizeof r); // (written by the kernel into pinned memory)
     e->batches++;
     if (r.table_full) {
         uint32_t zero = 0;
@@ -467,8 +467,8 @@ static int store_op(tc_engine* e, uint64_t slot, int op, int64_t a, int64_t b, u
     hipLaunchKernelGGL(k_store_op, dim3(1), dim3(64), 0, cur_stream(e), e->cells, slot, op, a, b, ttl, now, e->op_result);
     TC_HIP(e, hipGetLastError());
     if (feed) TC_TRY(auto_sweep_after(e, 1, key_batch, nullptr, now));
-    TC_HIP(e, hipMemcpyAsync(r, e->op_result, sizeof *r, hipMemcpyDeviceToHost, cur_stream(e)));
     TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
+    memcpy(r, (const void*)e->op_result_host, sizeof *r); // (written by the kernel into pinned memory)
     return TC_E_OK;
 }
 

@@ -22,3 +22,16 @@ for key_mode in (False, True):
     dt = time.perf_counter() - t0
     print(f"{'string' if key_mode else 'slot  '} mode: tc_rate_limit {1e6 * dt / len(keys):7.1f} us per call")
     eng.close()
+
+# a handful of requests through the batch call (host arrays, string keys, every result field): one launch (k_small_batch)
+eng = t.Engine(1_000_000, 1 << 16, key_mode=True)
+for n in (1, 16, 256, 1024):
+    arenas = [W.string_keys(np.arange(i * n, (i + 1) * n) % 50_000) for i in range(64)]
+    for kb, ko in arenas[:16]:
+        eng.rate_limit_batch_keys(kb, ko, max_burst=10, count_per_period=100, period=60, quantity=1, now_ns=W.T0_NS)
+    t0 = time.perf_counter()
+    for i, (kb, ko) in enumerate(arenas):
+        eng.rate_limit_batch_keys(kb, ko, max_burst=10, count_per_period=100, period=60, quantity=1, now_ns=W.T0_NS + i)
+    dt = time.perf_counter() - t0
+    print(f"string mode: tc_rate_limit_batch_keys, {n:4d} requests {1e6 * dt / len(arenas):7.1f} us per call")
+eng.close()
