@@ -111,6 +111,63 @@ int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_ke
     return TC_E_OK;
 }
 
+// every output of a synchronous host batch (+ the key table's error word, into the pinned result block) behind the evaluation in
+// one or two k_copy_multi launches; false: not applicable (an output in pageable memory, a failed copy being simulated, too many
+// bytes: TCGPU_SYNC_COPY_MAX, default 64 MB -- 0 switches this off) and nothing was enqueued
+static bool outputs_back_in_one_launch(tc_engine* e, const tc_batch& b, hipStream_t s, bool with_flag, bool* flag_done) {
+    if (e->fault_countdown || e->copy_kernel_off) return false;
+    const uint64_t n = b.n;
+    const tc_engine::Stage& st = e->stage;
+    struct Seg {
+        void* host;
+        const void* dev;
+        size_t bytes;
+    } segs[12];
+    uint32_t k = 0;
+    auto add = [&](void* host, const void* dev, size_t bytes) {
+        if (host && bytes) segs[k++] = Seg{host, dev, bytes};
+    };
+    add(b.allowed, st.allowed, n);
+    add(b.allowed_bits, st.bits, ((n + 63) / 64) * sizeof(uint64_t));
+    int64_t* hout[4] = {b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns};
+    for (int j = 0; j < 4; ++j) add(hout[j], st.out[j], n * sizeof(int64_t));
+    add(b.status, st.status, n);
+    add(b.result4, st.result4, n * 4 * sizeof(int64_t));
+    add(b.decisions, st.decisions, n * sizeof(tc_decision));
+    if (b.flags & TC_B_GROUPED_OUTPUT) add(b.order, st.order, n * sizeof(uint32_t));
+    size_t total = 0;
+    mk::CopySegs sg[2];
+    memset(sg, 0, sizeof sg);
+    size_t largest[2] = {0, 0};
+    uint32_t used[2] = {0, 0};
+    for (uint32_t i = 0; i < k; ++i) {
+        void* hv = device_view_of_host(segs[i].host);
+        if (!hv) return false;
+        total += segs[i].bytes;
+        const uint32_t g = i / 8;
+        sg[g].src[used[g]] = segs[i].dev, sg[g].dst[used[g]] = hv, sg[g].bytes[used[g]] = segs[i].bytes;
+        largest[g] = std::max(largest[g], segs[i].bytes);
+        ++used[g];
+    }
+    static const size_t limit = [] { const char* v = getenv("TCGPU_SYNC_COPY_MAX"); return v ? (size_t)strtoull(v, nullptr, 10) : (size_t)(64u << 20); }();
+    if (total > limit) return false;
+    if (with_flag) { // (the last group has room: at most 10 outputs + the word)
+        const uint32_t g = used[0] < 8 ? 0 : 1;
+        void* dv = nullptr;
+        if (hipHostGetDevicePointer(&dv, e->host_results, 0) != hipSuccess) return false;
+        sg[g].src[used[g]] = e->kt.error_flag, sg[g].dst[used[g]] = static_cast<uint8_t*>(dv) + 192, sg[g].bytes[used[g]] = sizeof(uint32_t);
+        largest[g] = std::max(largest[g], sizeof(uint32_t));
+        ++used[g];
+        *flag_done = true;
+    }
+    for (uint32_t g = 0; g < 2; ++g) {
+        if (!used[g]) continue;
+        const uint32_t bx = (uint32_t)std::min<size_t>((largest[g] / 16 + BLOCK - 1) / BLOCK + 1, 48);
+        hipLaunchKernelGGL(mk::k_copy_multi, dim3(bx, used[g]), dim3(BLOCK), 0, s, sg[g]);
+    }
+    return true;
+}
+
 // Does this batch take the range path (radix_sort.hpp: every tile partitioned by key range in place + one block per range
 // that collects and finishes it in LDS -- two launches instead of a histogram and three LSD passes)?  The host cannot see
 // the batch; it goes by the largest range of a RECENT batch of the stream, which every grouping mirrors into pinned memory
@@ -615,9 +672,17 @@ int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_f
     TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, s)); // (the request columns: one launch from pinned arrays, else a copy each)
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d));
-    TC_TRY(copy_outputs_back(e, b, s));
-    if (key_error_flag) TC_HIP(e, hipMemcpyAsync(key_error_flag, e->kt.error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    // Results back.  Round 5: into pinned arrays ONE copy launch behind the evaluation takes every output and the key-error word
+    // with it -- hipMemcpyAsync to pinned memory started 16 us after the evaluation had ended, and the word was a second copy
+    // behind the first (25 of a 4 Ki-request call's 103 us on the device, tools/trace_seq.py): the reference-shaped call of
+    // 4 Ki / 64 Ki / 256 Ki requests 106 -> 84, 240 -> 201, 563 -> 537 us.
+    bool flag_by_kernel = false;
+    if (!outputs_back_in_one_launch(e, b, s, key_error_flag != nullptr, &flag_by_kernel)) {
+        TC_TRY(copy_outputs_back(e, b, s));
+        if (key_error_flag) TC_HIP(e, hipMemcpyAsync(key_error_flag, e->kt.error_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, s));
+    }
     TC_HIP(e, hipStreamSynchronize(s));
+    if (key_error_flag && flag_by_kernel) *key_error_flag = *(volatile const uint32_t*)(e->host_results + 192);
     return poisoned(e); // (a synchronous batch whose kernels flagged an invariant fails itself, not the next call)
 }
 
