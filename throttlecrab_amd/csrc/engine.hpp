@@ -434,7 +434,7 @@ int stage_in_multi(tc_engine* e, const void* const* src, void* const* dst, const
 int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d);
 int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_kernel = false);
 int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin = nullptr);
-int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag = nullptr, const uint32_t* d_slot = nullptr);
+int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag = nullptr, const uint32_t* d_slot = nullptr, bool columns_staged = false);
 int finish_async(tc_engine* e, const tc_batch& b);
 bool small_batch_applies(const tc_engine* e, const tc_batch& b);
 int run_small_batch(tc_engine* e, const tc_batch& b);
@@ -460,7 +460,8 @@ inline bool auto_sweep_on(const tc_engine* e) { return e->as.kind != TC_SWEEP_NO
 int sweep_enqueue(tc_engine* e, int64_t now_ns); // tc_sweep_expired without the wait
 // keys.hip
 int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert, uint32_t* out_slot, bool on_key_stream);
-int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n, const uint8_t** d_bytes, const uint32_t** d_off);
+int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n, const uint8_t** d_bytes, const uint32_t** d_off,
+               const tc_batch* cols = nullptr);
 int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint32_t* slot);
 int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_scratch);
 

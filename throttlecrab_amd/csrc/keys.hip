@@ -42,8 +42,9 @@ int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_
 }
 
 // host key arena -> staged on device
+// cols (optional): the batch whose request columns travel in the same launch (run_slots_host_staged's staging: e->stage.in[j])
 int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n,
-                      const uint8_t** d_bytes, const uint32_t** d_off) {
+                      const uint8_t** d_bytes, const uint32_t** d_off, const tc_batch* cols) {
     const size_t total = key_off[n];
     if (total > e->k_stage_bytes_cap) {
         if (e->k_stage_bytes) (void)hipFree(e->k_stage_bytes);
@@ -52,10 +53,20 @@ int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, 
         TC_HIP(e, hipMalloc(&e->k_stage_bytes, want));
         e->k_stage_bytes_cap = want;
     }
-    const void* c_src[2] = {key_bytes, key_off};
-    void* c_dst[2] = {e->k_stage_bytes, e->k_stage_off};
-    const size_t c_bytes[2] = {total, (n + 1) * sizeof(uint32_t)};
-    TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, 2, cur_stream(e)));
+    const void* c_src[7] = {key_bytes, key_off};
+    void* c_dst[7] = {e->k_stage_bytes, e->k_stage_off};
+    size_t c_bytes[7] = {total, (n + 1) * sizeof(uint32_t)};
+    uint32_t c_n = 2;
+    if (cols) {
+        const int64_t* hin[5] = {cols->max_burst, cols->count_per_period, cols->period, cols->quantity, cols->now_ns};
+        for (int j = 0; j < 5; ++j) {
+            if (!hin[j]) continue;
+            TC_TRY(stage_need(e, e->stage.in[j], e->max_batch));
+            c_src[c_n] = hin[j], c_dst[c_n] = e->stage.in[j], c_bytes[c_n] = n * sizeof(int64_t);
+            ++c_n;
+        }
+    }
+    TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, cur_stream(e)));
     *d_bytes = e->k_stage_bytes ? e->k_stage_bytes : (const uint8_t*)e->k_stage_off;
     *d_off = e->k_stage_off;
     return TC_E_OK;
@@ -200,8 +211,8 @@ static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
     const uint32_t* d_off = b.key_off;
     const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
     if (!dev && small_batch_applies(e, b)) return run_small_batch(e, b);
-    if (!dev) {
-        int rc = stage_keys(e, b.key_bytes, b.key_off, b.n, &d_bytes, &d_off);
+    if (!dev) { // (round 5: keys, offsets and the request columns in ONE launch when they are all pinned -- one launch less on the chain)
+        int rc = stage_keys(e, b.key_bytes, b.key_off, b.n, &d_bytes, &d_off, &b);
         if (rc != TC_E_OK) return rc;
     }
     tc_batch s = b;
@@ -228,7 +239,7 @@ static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
     if (rc != TC_E_OK) return rc;
     // host pointers for everything else: the slot path's staging, with the slot column where the key stage left it
     uint32_t flag = 0;
-    rc = run_slots_host_staged(e, b, &flag, e->k_slot);
+    rc = run_slots_host_staged(e, b, &flag, e->k_slot, true);
     if (rc != TC_E_OK) return rc;
     if (flag) {
         TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, cur_stream(e)));

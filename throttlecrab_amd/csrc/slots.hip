@@ -646,7 +646,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
 // key_error_flag: a key batch -- "did a key fail to get a slot" comes back with the results, behind the same wait (it used to be
 // a copy and a wait of its own behind this one: ~25 us of a 4 Ki-request call's 200)
 // d_slot: the slot column where it already is in device memory (a key batch's resolved slots), else e->stage.slot
-int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag, const uint32_t* d_slot) {
+int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag, const uint32_t* d_slot, bool columns_staged) {
     const uint64_t n = b.n;
     hipStream_t s = cur_stream(e);
     tc_batch d = b;
@@ -669,7 +669,8 @@ int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_f
             *din[j] = e->stage.in[j];
         }
     }
-    TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, s)); // (the request columns: one launch from pinned arrays, else a copy each)
+    // (the request columns: one launch from pinned arrays, else a copy each -- a key batch has sent them with its keys already)
+    if (!columns_staged) TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, s));
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d));
     // Results back.  Round 5: into pinned arrays ONE copy launch behind the evaluation takes every output and the key-error word
