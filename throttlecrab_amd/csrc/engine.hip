@@ -156,6 +156,7 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_COPY_KERNEL")) e->copy_kernel_off = atoi(d) == 0;
     e->host_chunk = HOST_CHUNK_DEFAULT;
     if (const char* d = getenv("TCGPU_HOST_CHUNK")) e->host_chunk = (uint64_t)std::max(0ll, atoll(d)) / 64 * 64;
+    if (const char* d = getenv("TCGPU_ASYNC_COPY_KERNEL_N")) e->async_copy_kernel_n = (uint32_t)std::max(0ll, atoll(d));
     const char* pe = getenv("TCGPU_AUX_PRIORITY");
     const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
     // the evaluation kernel on the main stream is the critical path of the pipeline: grouping runs at

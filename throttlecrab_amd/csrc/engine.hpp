@@ -181,6 +181,7 @@ struct tc_engine {
     // Results of the single-request calls land in PINNED host memory, written by the kernel itself (round 5: they used to be
     // fetched with a copy behind the kernel -- a second launch, 7 us after the first: 12-15 of a call's 33 us).  The *_result
     // pointers are the device's view of the block (what the kernels are given), *_host the caller's.
+    uint32_t async_copy_kernel_n = 32768;  // TC_B_ASYNC host batches up to this many requests are staged by one copy launch (TCGPU_ASYNC_COPY_KERNEL_N)
     uint8_t* host_results = nullptr;       // hipHostMalloc: OneResult | StoreOpResult | one resolved slot
     StoreOpResult* op_result = nullptr;    // (device view)
     OneResult* one_result = nullptr;       // (device view) tc_rate_limit: the single request's result

@@ -158,8 +158,15 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     if (!ss.h_key_off) TC_HIP(e, hipMalloc(&ss.h_key_off, (e->max_batch + 1) * sizeof(uint32_t)));
     // the key stage and the evaluation that last used this set's staging and slot column are done
     if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ks, ss.consumed, 0));
-    if (total) TC_HIP(e, copy_async(e, ss.h_key_bytes, b.key_bytes + base, total, hipMemcpyHostToDevice, ks));
-    TC_HIP(e, copy_async(e, ss.h_key_off, b.key_off, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ks));
+    if (n <= e->async_copy_kernel_n) { // (a small batch: one copy launch when the arrays are pinned -- slots.hip: stage_host_inputs)
+        const void* c_src[2] = {b.key_bytes + base, b.key_off};
+        void* c_dst[2] = {ss.h_key_bytes, ss.h_key_off};
+        const size_t c_bytes[2] = {total, ((size_t)n + 1) * sizeof(uint32_t)};
+        TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, 2, ks));
+    } else {
+        if (total) TC_HIP(e, copy_async(e, ss.h_key_bytes, b.key_bytes + base, total, hipMemcpyHostToDevice, ks));
+        TC_HIP(e, copy_async(e, ss.h_key_off, b.key_off, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, ks));
+    }
     TC_TRY(resolve_keys_device(e, ss.h_key_bytes - base, ss.h_key_off, n, true, ss.k_slot, piped));
     // (the engine cleans by itself: a synchronous caller may have to apply rejected requests again -- it needs the slots)
     if (e->as.chunk_slots_at != UINT64_MAX)

@@ -386,9 +386,21 @@ static void bucket_eval(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, con
 static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn& hin, uint32_t n, hipStream_t st, Params& p,
                              const uint32_t** d_slot) {
     const uint64_t mb = e->max_batch;
+    // A SMALL batch (up to async_copy_kernel_n requests: what an actor's queue yields) is bound by the number of things enqueued
+    // for it, not by the link: its columns cross in one copy launch when they are pinned (stage_in_multi).  A large one goes
+    // through the SDMA engines, a copy each: they do not take the link's latency out on the kernels running beside them.
+    // Measured (tools/abi_probe.py, ring of 4 pinned sets, us per reference-shaped call, copies / one launch): 4 Ki requests 164-168 /
+    // 53-55, 16 Ki 72-171 / 64-65, 32 Ki 186-285 / 73-74 (the copies' times jump about: the runtime's bookkeeping for a pinned
+    // source), 64 Ki 117 / 126 and in bench.py's leg 112-129 / 148: one launch up to 32 Ki.
+    const bool one_launch = n <= e->async_copy_kernel_n;
+    const void* c_src[6];
+    void* c_dst[6];
+    size_t c_bytes[6];
+    uint32_t c_n = 0;
     if (hin.slot) { // (key batches arrive with their slots already resolved on the device)
         if (!ss.h_slot) TC_HIP(e, hipMalloc(&ss.h_slot, mb * sizeof(uint32_t)));
-        TC_HIP(e, copy_async(e, ss.h_slot, hin.slot, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st)); // SDMA when pinned
+        if (one_launch) c_src[c_n] = hin.slot, c_dst[c_n] = ss.h_slot, c_bytes[c_n] = (size_t)n * sizeof(uint32_t), ++c_n;
+        else TC_HIP(e, copy_async(e, ss.h_slot, hin.slot, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st)); // SDMA when pinned
         *d_slot = ss.h_slot;
         p.slot = ss.h_slot;
     }
@@ -396,9 +408,11 @@ static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn&
     for (int j = 0; j < 5; ++j) {
         if (!hin.col[j]) continue;
         if (!ss.h_in[j]) TC_HIP(e, hipMalloc(&ss.h_in[j], mb * sizeof(int64_t)));
-        TC_HIP(e, copy_async(e, ss.h_in[j], hin.col[j], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
+        if (one_launch) c_src[c_n] = hin.col[j], c_dst[c_n] = ss.h_in[j], c_bytes[c_n] = (size_t)n * sizeof(int64_t), ++c_n;
+        else TC_HIP(e, copy_async(e, ss.h_in[j], hin.col[j], (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, st));
         *dst[j] = ss.h_in[j];
     }
+    if (c_n) TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, st));
     return TC_E_OK;
 }
 
