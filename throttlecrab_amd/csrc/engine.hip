@@ -156,6 +156,7 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_COPY_KERNEL")) e->copy_kernel_off = atoi(d) == 0;
     e->host_chunk = HOST_CHUNK_DEFAULT;
     if (const char* d = getenv("TCGPU_HOST_CHUNK")) e->host_chunk = (uint64_t)std::max(0ll, atoll(d)) / 64 * 64;
+    if (const char* d = getenv("TCGPU_BOUNCE_MAX")) e->bounce_max = (size_t)std::max(0ll, atoll(d));
     if (const char* d = getenv("TCGPU_ASYNC_COPY_KERNEL_N")) e->async_copy_kernel_n = (uint32_t)std::max(0ll, atoll(d));
     const char* pe = getenv("TCGPU_AUX_PRIORITY");
     const bool aux_high = pe && atoi(pe) != 0; // default: lowest priority (measured ~1 % better: the evaluation kernel is the critical path)
@@ -501,6 +502,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     }
     if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
     if (e->host_results) (void)hipHostFree(e->host_results);
+    if (e->bounce) (void)hipHostFree(e->bounce);
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
     if (e->route_l0_done) (void)hipEventDestroy(e->route_l0_done);

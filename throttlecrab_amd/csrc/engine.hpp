@@ -181,6 +181,11 @@ struct tc_engine {
     // Results of the single-request calls land in PINNED host memory, written by the kernel itself (round 5: they used to be
     // fetched with a copy behind the kernel -- a second launch, 7 us after the first: 12-15 of a call's 33 us).  The *_result
     // pointers are the device's view of the block (what the kernels are given), *_host the caller's.
+    // A synchronous host batch in PAGEABLE memory, small enough to be bound by latency: the engine copies the arrays through a pinned
+    // block of its own and takes the pinned path (slots.hip: bounce_in / bounce_out).  bounce_max = most bytes, in + out, that go
+    // this way (TCGPU_BOUNCE_MAX; 0: never)
+    uint8_t* bounce = nullptr;
+    size_t bounce_max = 4u << 20;
     uint32_t async_copy_kernel_n = 32768;  // TC_B_ASYNC host batches up to this many requests are staged by one copy launch (TCGPU_ASYNC_COPY_KERNEL_N)
     uint8_t* host_results = nullptr;       // hipHostMalloc: OneResult | StoreOpResult | one resolved slot
     StoreOpResult* op_result = nullptr;    // (device view)
@@ -432,6 +437,18 @@ int wait_own_async(tc_engine* e, size_t mine);
 // host arrays -> device staging on stream s: ONE copy kernel (mk::k_copy_multi) when every source is pinned host memory, else one
 // hipMemcpyAsync each (count <= 8; a failed copy -- tc_debug_fail_copy -- fails the call before anything was applied, as before)
 int stage_in_multi(tc_engine* e, const void* const* src, void* const* dst, const size_t* bytes, uint32_t count, hipStream_t s);
+struct Bounced {
+    tc_batch bb;
+    struct Out {
+        void* user;
+        const void* pinned;
+        size_t bytes;
+    } outs[12];
+    int n_out = 0;
+    bool on = false;
+};
+bool bounce_in(tc_engine* e, const tc_batch& b, Bounced& bo); // false: does not apply (bo.on stays false), the batch runs as it is
+void bounce_out(const Bounced& bo);                          // the results, from the pinned block into the caller's arrays
 int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d);
 int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_kernel = false);
 int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin = nullptr);

@@ -218,6 +218,24 @@ static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
     const uint32_t* d_off = b.key_off;
     const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;
     if (!dev && small_batch_applies(e, b)) return run_small_batch(e, b);
+    if (!dev) { // (a small batch in pageable memory: through the engine's pinned block -- slots.hip: bounce_in)
+        Bounced bo;
+        if (bounce_in(e, b, bo)) {
+            int rc = stage_keys(e, bo.bb.key_bytes, bo.bb.key_off, bo.bb.n, &d_bytes, &d_off, &bo.bb);
+            if (rc != TC_E_OK) return rc;
+            rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, e->k_slot, false);
+            if (rc != TC_E_OK) return rc;
+            uint32_t flag = 0;
+            rc = run_slots_host_staged(e, bo.bb, &flag, e->k_slot, true);
+            if (rc != TC_E_OK) return rc;
+            bounce_out(bo);
+            if (flag) {
+                TC_HIP(e, hipMemsetAsync(e->kt.error_flag, 0, sizeof flag, cur_stream(e)));
+                return fail(e, TC_E_TABLE_FULL, "key table full: some keys got status Internal (raise capacity or sweep)");
+            }
+            return TC_E_OK;
+        }
+    }
     if (!dev) { // (round 5: keys, offsets and the request columns in ONE launch when they are all pinned -- one launch less on the chain)
         int rc = stage_keys(e, b.key_bytes, b.key_off, b.n, &d_bytes, &d_off, &b);
         if (rc != TC_E_OK) return rc;
