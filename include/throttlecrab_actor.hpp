@@ -118,7 +118,7 @@ struct Channel {
     // where the actor thread's time goes (ns; written by the actor thread only, read through RateLimiterHandle::loop_ns):
     // handing batches to the limiter, answering (of which: collect_batch, i.e. waiting for the GPU + the outcomes), releasing
     // answered messages
-    uint64_t ns_submit = 0, ns_answer = 0, ns_collect = 0, ns_release = 0;
+    std::atomic<uint64_t> ns_submit{0}, ns_answer{0}, ns_collect{0}, ns_release{0};
 };
 } // namespace detail
 
@@ -173,8 +173,11 @@ class RateLimiterHandle {
         return {ch_->batches, ch_->requests, ch_->largest_batch};
     }
 
-    // (submit, answer, of which collect_batch, release) nanoseconds of the actor thread so far -- a diagnostic, read without a lock
-    std::tuple<uint64_t, uint64_t, uint64_t, uint64_t> loop_ns() const { return {ch_->ns_submit, ch_->ns_answer, ch_->ns_collect, ch_->ns_release}; }
+    // (submit, answer, of which collect_batch, release) nanoseconds of the actor thread so far -- a diagnostic
+    std::tuple<uint64_t, uint64_t, uint64_t, uint64_t> loop_ns() const {
+        return {ch_->ns_submit.load(std::memory_order_relaxed), ch_->ns_answer.load(std::memory_order_relaxed), ch_->ns_collect.load(std::memory_order_relaxed),
+                ch_->ns_release.load(std::memory_order_relaxed)};
+    }
 
   private:
     template <class L>
@@ -378,7 +381,7 @@ class BasicRateLimiterActor {
 
     // second half: the replies; send errors are ignored like in the reference (the receiver may have given
     // up, actor.rs:229-230)
-    static void answer_throttle_batch(Limiter& limiter, std::deque<RateLimiterMessage>& msgs, uint64_t* ns_collect) {
+    static void answer_throttle_batch(Limiter& limiter, std::deque<RateLimiterMessage>& msgs, std::atomic<uint64_t>* ns_collect) {
         std::vector<RateLimitOutcome> out;
         try {
             const uint64_t t0 = clock_ns();

@@ -241,7 +241,7 @@ static bool outputs_back_in_one_launch(tc_engine* e, const tc_batch& b, hipStrea
         const uint32_t bx = (uint32_t)std::min<size_t>((largest[g] / 16 + BLOCK - 1) / BLOCK + 1, 48);
         hipLaunchKernelGGL(mk::k_copy_multi, dim3(bx, used[g]), dim3(BLOCK), 0, s, sg[g]);
     }
-    return true;
+    return hipGetLastError() == hipSuccess; // (false: the caller's copies follow and report what is wrong with the stream)
 }
 
 // Does this batch take the range path (radix_sort.hpp: every tile partitioned by key range in place + one block per range
