@@ -234,14 +234,15 @@ static bool outputs_back_in_one_launch(tc_engine* e, const tc_batch& b, hipStrea
         sg[g].src[used[g]] = e->kt.error_flag, sg[g].dst[used[g]] = static_cast<uint8_t*>(dv) + 192, sg[g].bytes[used[g]] = sizeof(uint32_t);
         largest[g] = std::max(largest[g], sizeof(uint32_t));
         ++used[g];
-        *flag_done = true;
     }
     for (uint32_t g = 0; g < 2; ++g) {
         if (!used[g]) continue;
         const uint32_t bx = (uint32_t)std::min<size_t>((largest[g] / 16 + BLOCK - 1) / BLOCK + 1, 48);
         hipLaunchKernelGGL(mk::k_copy_multi, dim3(bx, used[g]), dim3(BLOCK), 0, s, sg[g]);
     }
-    return hipGetLastError() == hipSuccess; // (false: the caller's copies follow and report what is wrong with the stream)
+    const bool ok = hipGetLastError() == hipSuccess; // (false: the caller's copies follow and report what is wrong with the stream)
+    *flag_done = ok && with_flag;
+    return ok;
 }
 
 // Does this batch take the range path (radix_sort.hpp: every tile partitioned by key range in place + one block per range
