@@ -165,11 +165,57 @@ static void test_linger_collects_a_batch() {
     CHECK(requests == 64 && batches <= 3 && largest >= 32); // the loop waited for the queue to fill instead of taking 1, 1, 1 ...
 }
 
+// Round 5: the channel is sharded by handle.  40 handles (more than there are shards: some share one) send numbered requests for a key
+// of their own from their own threads, singly and in groups, through a small buffer: every handle's requests must be evaluated in the
+// order it sent them (the limiter's sequence numbers grow along each handle's stream), nothing lost, nothing answered twice.
+static void test_per_handle_order_across_shards() {
+    auto lim = std::make_shared<FakeLimiter>();
+    lim->collect_delay = std::chrono::microseconds(50);
+    RateLimiterHandle h = FakeActor::spawn(512, lim, 256);
+    std::atomic<int> answered{0};
+    std::vector<std::thread> th;
+    for (int p = 0; p < 40; ++p)
+        th.emplace_back([&, p] {
+            RateLimiterHandle mine = h; // (a copy: its own shard)
+            const std::string key = "h" + std::to_string(p);
+            int64_t last = -1;
+            std::deque<std::future<Result<ThrottleResponse>>> q;
+            auto reap = [&] {
+                auto r = q.front().get();
+                q.pop_front();
+                CHECK(is_ok(r) && std::get<0>(r).remaining > last);
+                last = std::get<0>(r).remaining;
+                ++answered;
+            };
+            for (int i = 0; i < 600; ++i) {
+                if (i % 50 == 49) { // a group in between: it must fall into place behind what was sent before it
+                    while (!q.empty()) reap();
+                    std::vector<ThrottleRequest> g(7, ThrottleRequest{key, 1 << 30, 1, 1, 1, now0()});
+                    for (auto& r : mine.throttle_many(std::move(g))) {
+                        CHECK(is_ok(r) && std::get<0>(r).remaining > last);
+                        last = std::get<0>(r).remaining;
+                        ++answered;
+                    }
+                    continue;
+                }
+                if (q.size() >= 32) reap();
+                q.push_back(mine.throttle_async(ThrottleRequest{key, 1 << 30, 1, 1, 1, now0()}));
+            }
+            while (!q.empty()) reap();
+        });
+    for (auto& t : th) t.join();
+    CHECK(answered.load() == 40 * (588 + 12 * 7));
+    auto [batches, requests, largest] = h.drain_stats();
+    CHECK(requests == (uint64_t)answered.load() && batches > 0 && largest <= 256 + 6);
+    CHECK(lim->max_in_flight <= FakeLimiter::FLIGHTS);
+}
+
 int main() {
     test_order_and_matching();
     test_pipeline_depth_and_backpressure();
     test_limiter_errors_and_shutdown();
     test_linger_collects_a_batch();
+    test_per_handle_order_across_shards();
     std::puts("all tests passed");
     return 0;
 }
