@@ -133,3 +133,42 @@ def test_a_chunked_key_batch_that_runs_out_of_slots_is_retried():
     st = eng.sweep_stats()
     assert st["retries"] == 2 and eng.counters()["live_slots"] == n and eng.debug_check_keys() == 0, st
     eng.close()
+
+
+@pytest.mark.parametrize("pinned", [False, True])
+@pytest.mark.parametrize("n", [1500, 3000, 20_000])
+def test_every_output_of_a_synchronous_key_batch_comes_back_in_the_copy_launches(n, pinned):
+    """Round 5: a synchronous host batch's results go back in one k_copy_multi launch per eight arrays, the key-error word with them
+    (slots.hip: outputs_back_in_one_launch), and a batch in pageable memory reaches that path through the engine's pinned block
+    (bounce_in).  All nine output forms at once = two launches; keys that recur; per-request columns; against the oracle."""
+    import throttlecrab_amd as t
+    from oracle import oracle as O
+    from throttlecrab_amd import workload as W
+    rng = np.random.default_rng(n + pinned)
+    eng = t.Engine(50_000, 1 << 16, key_mode=True)
+    eng.check_on_close = True
+    orc = O.AdaptiveOracle(capacity=200_000, created_ns=T0, auto_cleanup=False)
+    want = FIELDS + ("allowed_bits", "result4", "decisions")
+    for rnd in range(3):
+        ids = rng.integers(0, 4000, n)
+        kb, ko = W.string_keys(ids)
+        ko = ko.astype(np.uint32)
+        cols = dict(max_burst=(2 + ids % 5).astype(np.int64), count_per_period=np.full(n, 10, np.int64), period=np.full(n, 60, np.int64),
+                    quantity=rng.integers(-1, 3, n).astype(np.int64), now_ns=(T0 + rnd * S + np.sort(rng.integers(0, S, n))).astype(np.int64))
+        ref = orc.batch_keys(kb, ko, cols["max_burst"], 10, 60, cols["quantity"], cols["now_ns"])
+        if pinned:
+            out = t.BatchResult(**{f: eng.host_alloc({"allowed_bits": (n + 63) // 64, "result4": 4 * n, "decisions": 4 * n}.get(f, n),
+                                                     np.uint8 if f in ("allowed", "status") else (np.uint64 if f == "allowed_bits" else np.int64)) for f in want})
+            res = eng.rate_limit_batch_keys(pinned_copy(eng, kb), pinned_copy(eng, ko), want=want, out=out, **{k: pinned_copy(eng, v) for k, v in cols.items()})
+        else:
+            res = eng.rate_limit_batch_keys(kb, ko, want=want, **cols)
+        assert_same(res, ref, f"n={n} pinned={pinned} round {rnd}")
+        assert np.array_equal(np.unpackbits(res.allowed_bits.view(np.uint8), bitorder="little")[:n], ref.allowed)
+        r4 = np.asarray(res.result4).reshape(-1, 4)
+        ok = ref.status == 0
+        for j, f in enumerate(("limit", "remaining", "reset_after_ns", "retry_after_ns")):
+            assert np.array_equal(r4[ok, j], getattr(ref, f)[ok]), f
+        d = t.Engine.unpack_decisions(res.decisions)
+        assert np.array_equal(d["allowed"], ref.allowed) and np.array_equal(d["remaining"], ref.remaining) and np.array_equal(d["status"], ref.status)
+    assert eng.debug_check_keys() == 0
+    eng.close()
