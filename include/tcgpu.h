@@ -262,7 +262,10 @@ int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* b);
  * throttlecrab-server/src/actor.rs:217-236; this is what lets a batch-draining actor fill the next
  * batch while the previous ones are in flight.) */
 int tc_wait_batches(tc_engine* e, uint32_t max_in_flight);
-/* Pinned host memory for TC_B_ASYNC batches (hipHostMalloc / hipHostFree behind a C signature). */
+/* Pinned host memory (hipHostMalloc / hipHostFree behind a C signature): what TC_B_ASYNC batches need, and what makes a
+ * synchronous host-pointer batch fastest -- its arrays cross PCIe in one copy launch each way, and from 512 Ki requests on the
+ * batch is pipelined in chunks.  Arrays in pageable memory are always correct: up to 4 MB of them per call go through a pinned
+ * block of the engine's own (two memcpys by the calling thread), larger ones through the runtime's staging copies. */
 void* tc_host_alloc(size_t bytes);
 void tc_host_free(void* p);
 
