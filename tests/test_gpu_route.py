@@ -432,8 +432,9 @@ def test_split_router_at_its_grid_limit(n, world):
     eng.close()
 
 
+@pytest.mark.parametrize("world", [3, 8])   # (8: BASELINE configs[3]'s world, every rank of it on this one GPU)
 @pytest.mark.parametrize("stream_kind", ["uniform", "zipf"])
-def test_replicate_mode_as_one_library_call_per_step(stream_kind):
+def test_replicate_mode_as_one_library_call_per_step(stream_kind, world):
     """tc_shard_step (csrc/shard.hip): route step i + 3 on the grouping streams, poll the router's tag, evaluate the
     rank's share of step i in chunks of at most max_batch -- three ranks of one world stepped in one loop, each seeing the WHOLE
     global stream; the union of their decisions == one sequential pass of the oracle keyed by the global id."""
@@ -442,7 +443,7 @@ def test_replicate_mode_as_one_library_call_per_step(stream_kind):
     from oracle import oracle as O
     from tests.test_gpu_slots import T0
     from throttlecrab_amd import sharded, workload as W
-    world, cap, G, steps, LA = 3, 40_000, 90_000, 10, 3
+    cap, G, steps, LA = 40_000, 30_000 * world, 10, 3
     rng = np.random.default_rng(5)
     z = W.Zipf(world * cap)
     glob = [(z.slots(G, start=i * G) if stream_kind == "zipf" else rng.integers(0, world * cap, G)).astype(np.uint32) for i in range(steps)]
