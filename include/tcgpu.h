@@ -572,12 +572,15 @@ typedef struct tc_engine_info {
     uint32_t probes_assumed;       /* 1: TCGPU_ASSUME_CONCURRENT -- candidates taken unprobed (profiler counter passes) */
     uint32_t pipelining_degraded;  /* 1: fewer grouping streams than wanted (or no key stream): expect the slower figures */
     uint32_t scratch_sets;         /* batches whose grouping may be in flight at once */
-    uint32_t grouping_path;        /* of the last batch: 0 none yet, 1 range path (2 launches), 2 LSD passes, 3 bucket path, 4 small batch / unique */
+    uint32_t grouping_path;        /* of the last batch: 0 none yet, 1 range path (2 launches), 2 LSD passes, 3 bucket path, 4 small batch / unique,
+                                    * 5 range path with the hot slots peeled out (3 launches; skewed streams, round 6) */
     uint32_t range_path_possible;  /* the key space admits the range path */
     uint64_t range_hint_requests;  /* the range hint the next batch goes by: requests of the batch it came from ... */
-    uint64_t range_hint_largest;   /* ... and its largest key range (a block finishes up to 8 192 requests in LDS) */
+    uint64_t range_hint_largest;   /* ... and its largest key range (a block finishes up to 4 096 requests in LDS) */
     uint64_t host_chunk_requests;  /* pinned synchronous host batches of at least twice this many requests are pipelined in chunks; 0: never */
     uint64_t batches;              /* batches decided so far */
+    uint64_t hot_slots;            /* slots on the hot list right now (made from the evaluations' notes on long runs; 0: none) */
+    uint64_t hot_batches;          /* batches grouped with the hot slots peeled out so far */
 } tc_engine_info;
 int tc_engine_info_get(tc_engine* e, tc_engine_info* out);
 

@@ -122,6 +122,8 @@ pub struct tc_engine_info {
     pub range_hint_largest: u64,
     pub host_chunk_requests: u64,
     pub batches: u64,
+    pub hot_slots: u64,
+    pub hot_batches: u64,
 }
 
 /// one rank's side of `replicate` mode (opaque)

@@ -169,3 +169,59 @@ def test_fresh_in_order_engine_reaches_the_range_path_and_leaves_it_again():
     assert pr.get("sort") == 8 and not any(k.startswith("bucket") for k in pr), pr
     assert eng.selfcheck() == 0
     eng.close()
+
+
+def _zipf_like(rng, cap, n, hot_keys=400, s=1.1):
+    """a stream with a Zipf(s) head of `hot_keys` scattered keys taking ~2/3 of the requests, the rest uniform"""
+    w = np.arange(1, hot_keys + 1, dtype=np.float64) ** (-s)
+    head = (np.arange(hot_keys, dtype=np.int64) * 7_919 + 13) % cap
+    out = rng.integers(0, cap, n).astype(np.uint32)
+    m = rng.random(n) < 0.66
+    out[m] = head[rng.choice(hot_keys, int(m.sum()), p=w / w.sum())]
+    return out
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["one_timestamp", "timestamp_per_request"])
+def test_hot_slots_are_peeled_out_of_the_range_partition(general):
+    """Round 6 (csrc/range_part.hpp): a stream whose skew is a few hot keys takes the range path with those keys' requests
+    gathered behind the ranges.  Who is hot comes from the evaluations' notes on long runs, through pinned memory -- so the
+    first batches go through the LSD passes, and the engine must say when it changed over.  Every batch exact, both evaluation
+    kernels; then the hot keys MOVE (the list is made afresh) and finally the stream turns uniform (the list empties)."""
+    import torch
+
+    import throttlecrab_amd as t
+    rng = np.random.default_rng(21)
+    cap, n, plan = 3_000_000, 200_000, (20, 100, 60)
+    eng = t.Engine(cap, n, fixed_params=True)
+    eng.use_torch_stream()
+    eng.register_params_uniform(*plan)
+    orc = _oracle(cap)
+    paths, held = [], []
+    streams = [lambda: _zipf_like(rng, cap, n)] * 30 + [lambda: (_zipf_like(rng, cap, n) + 1_000_003) % cap] * 30 + [lambda: _uniform(rng, cap, n)] * 60
+    for i, mk in enumerate(streams):
+        slots = mk().astype(np.uint32)
+        now = T0 + i * 50_000_000
+        d = torch.from_numpy(slots.astype(np.int32)).cuda()
+        if general:
+            nowc = now + np.sort(rng.integers(0, 10**6, n))
+            ref = orc.batch_slots(slots, *plan, 1, nowc)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=torch.from_numpy(nowc).cuda(), want=("allowed",), inputs_ready=True)
+        else:
+            ref = orc.batch_slots(slots, *plan, 1, now)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=now, want=("allowed", "remaining"), inputs_ready=True)
+        paths.append(eng.info()["grouping_path"])
+        held.append((res, ref, d))
+        if i % 2 == 1:
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    for i, (res, ref, _) in enumerate(held):
+        assert np.array_equal(res.allowed.cpu().numpy(), ref.allowed), f"batch {i} ({paths[i]}): decisions differ"
+        if not general:
+            assert np.array_equal(res.remaining.cpu().numpy(), ref.remaining), f"batch {i} ({paths[i]}): remaining differs"
+    info = eng.info()
+    assert eng.selfcheck() == 0
+    eng.close()
+    hot = "range path, hot slots peeled"
+    assert paths[:30].count(hot) >= 15 and paths[30:60].count(hot) >= 10, paths
+    assert paths[-8:] == ["range path"] * 8 and info["hot_slots"] == 0, (paths[-20:], info)
+    assert info["hot_batches"] >= 25

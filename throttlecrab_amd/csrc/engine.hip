@@ -130,9 +130,9 @@ int engine_alloc(tc_engine* e) {
         e->fill_hint_dev = (uint32_t*)dv;
     }
     {
-        // range path: 256 ranges of the key space; a slot's offset inside its range must fit 16 bits
+        // range path: rs::NRANGE ranges of the key space; a slot's offset inside its range must fit 16 bits
         if (const char* d = getenv("TCGPU_RANGE")) e->range_mode = atoi(d);
-        e->range_max_n = (uint32_t)(rs::FIN_CAP * 256ull * 3ull / 4ull); // mean range 3/4 of what a block finishes in LDS
+        e->range_max_n = (uint32_t)(rs::FIN_CAP * (uint64_t)rs::NRANGE * 3ull / 4ull); // mean range 3/4 of what a block finishes in LDS
         if (const char* d = getenv("TCGPU_RANGE_MAX_N")) e->range_max_n = (uint32_t)std::max(atoll(d), 1ll);
         if (e->range_mode != 0 && cap > 65536 && cap < 0xFFFFFFFFull) {
             e->range_mul = rs::range_mul((uint32_t)cap);
@@ -145,6 +145,20 @@ int engine_alloc(tc_engine* e) {
                 void* dv = nullptr;
                 TC_HIP(e, hipHostGetDevicePointer(&dv, e->range_hint_host, 0));
                 e->range_hint_dev = (unsigned long long*)dv;
+                // round 6: hot slots (range_part.hpp)
+                if (const char* d = getenv("TCGPU_HOT")) e->hot.on = atoi(d) != 0;
+                if (const char* d = getenv("TCGPU_HOT_MIN")) e->hot.heavy_min = (uint32_t)std::max(atoi(d), 2);
+                if (e->hot.on) {
+                    const size_t words = (size_t)ev::HEAVY_SLOTS + 8;
+                    TC_HIP(e, hipMalloc(&e->hot.notes_dev, words * sizeof(unsigned long long)));
+                    TC_HIP(e, hipMemsetAsync(e->hot.notes_dev, 0, words * sizeof(unsigned long long), (hipStream_t)0));
+                    TC_HIP(e, hipHostMalloc((void**)&e->hot.notes_host, words * sizeof(unsigned long long) + 64, hipHostMallocDefault));
+                    memset(e->hot.notes_host, 0, words * sizeof(unsigned long long) + 64);
+                    TC_HIP(e, hipHostGetDevicePointer(&dv, e->hot.notes_host, 0));
+                    e->hot.notes_host_dev = (unsigned long long*)dv;
+                    e->hot.hint_cold_host = e->hot.notes_host + words; // (a line of its own behind the notes)
+                    e->hot.hint_cold_dev = e->hot.notes_host_dev + words;
+                }
             }
         }
     }
@@ -174,8 +188,12 @@ int engine_alloc(tc_engine* e) {
         TC_HIP(e, hipMalloc(&ss.elem_b, mb * sizeof(uint64_t)));
         if (e->range_ok) {
             TC_HIP(e, hipMalloc(&ss.elem_c, std::min<uint64_t>(mb, e->range_max_n) * sizeof(uint64_t)));
-            TC_HIP(e, hipMalloc(&ss.range_totals, 2 * rs::RADIX * sizeof(uint32_t)));
-            TC_HIP(e, hipMemsetAsync(ss.range_totals, 0, 2 * rs::RADIX * sizeof(uint32_t), (hipStream_t)0));
+            TC_HIP(e, hipMalloc(&ss.range_totals, 2 * rp::NB_HOT * sizeof(uint32_t)));
+            TC_HIP(e, hipMemsetAsync(ss.range_totals, 0, 2 * rp::NB_HOT * sizeof(uint32_t), (hipStream_t)0));
+            const uint64_t tiles = (std::min<uint64_t>(mb, e->range_max_n) + rp::PT_TILE - 1) / rp::PT_TILE;
+            TC_HIP(e, hipMalloc(&ss.part_table, tiles * rp::NB_HOT * sizeof(uint32_t)));
+            TC_HIP(e, hipMalloc(&ss.hot_dev, sizeof(rp::HotDev)));
+            TC_HIP(e, hipMemsetAsync(ss.hot_dev, 0, sizeof(rp::HotDev), (hipStream_t)0));
         }
         TC_HIP(e, hipMalloc(&ss.ws, words * sizeof(uint32_t)));
         TC_HIP(e, hipMemsetAsync(ss.ws, 0, words * sizeof(uint32_t), (hipStream_t)0));
@@ -486,7 +504,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.part_table, ss.hot_dev, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
@@ -505,6 +523,8 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->bounce) (void)hipHostFree(e->bounce);
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
+    if (e->hot.notes_host) (void)hipHostFree(e->hot.notes_host);
+    if (e->hot.notes_dev) (void)hipFree(e->hot.notes_dev);
     if (e->route_l0_done) (void)hipEventDestroy(e->route_l0_done);
     for (uint32_t k = 0; k < e->debug_fillers; ++k) {
         (void)hipStreamSynchronize(e->debug_filler[k]);
@@ -810,6 +830,8 @@ extern "C" int tc_engine_info_get(tc_engine* e, tc_engine_info* out) {
     }
     r.host_chunk_requests = e->host_chunk;
     r.batches = e->batches;
+    r.hot_slots = e->hot.slots.size();
+    r.hot_batches = e->hot.batches_hot;
     *out = r;
     return TC_E_OK;
 }

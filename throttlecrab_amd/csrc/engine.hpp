@@ -27,6 +27,7 @@
 #include "gcra_math.hpp"
 #include "key_table.hpp"
 #include "radix_sort.hpp"
+#include "range_part.hpp"
 
 #include "eval_kernels.hpp"
 #include "bucket_path.hpp"
@@ -104,8 +105,11 @@ struct tc_engine {
     struct SortSet {
         uint64_t *elem_a = nullptr, *elem_b = nullptr; // max_batch each
         uint64_t* elem_c = nullptr;                    // range path: scratch of a range that does not fit LDS (min(max_batch, range_max_n))
-        uint32_t* range_totals = nullptr;              // range path: 2 x RADIX words, the ranges' sizes of this / the next batch of the set
+        uint32_t* range_totals = nullptr;              // range path: 2 x rp::NB_HOT words, the buckets' sizes (ranges, then hot ids) of this / the next batch of the set
         uint32_t range_parity = 0;
+        uint32_t* part_table = nullptr;                // round 6: rp::k_tile_part's table, rp::NB_HOT words per tile of rp::PT_TILE requests
+        rp::HotDev* hot_dev = nullptr;                 // ... and the set's hot table, as of list version hot_version (0: none installed)
+        uint32_t hot_version = 0;
         uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
         uint32_t* k_slot = nullptr;                    // key mode: slots resolved for the batch using this set
         uint32_t* h_slot = nullptr;                    // TC_B_ASYNC: the host batch's slot column, staged (lazy)
@@ -145,7 +149,7 @@ struct tc_engine {
     // what the last probe found (tc_engine_info_get)
     uint32_t probe_tried = 0, probe_same_queue = 0, probe_same_pipe = 0, probe_second_best = 0;
     bool probe_assumed = false;
-    uint32_t last_grouping_path = 0;     // 1 range path, 2 LSD passes, 3 bucket path, 4 no grouping (small batch / unique slots)
+    uint32_t last_grouping_path = 0;     // 1 range path, 2 LSD passes, 3 bucket path, 4 no grouping (small batch / unique slots), 5 range path with hot slots peeled
     uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
     PendEntry* pend = nullptr;
@@ -168,6 +172,25 @@ struct tc_engine {
     uint32_t range_share[RANGE_HINTS] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t range_looks = 0;
     uint32_t range_relook = 0; // in-order batches the range path turned down (every 32nd goes through the sort path, which writes a hint)
+    // round 6: hot slots peeled out of the range partition (range_part.hpp), so that skewed streams take the range path too
+    struct Hot {
+        bool on = true;                  // TCGPU_HOT=0: skewed streams stay on the LSD passes
+        unsigned long long* notes_dev = nullptr;      // ev::HEAVY_SLOTS notes of the evaluations (ev::heavy_note)
+        unsigned long long* notes_host = nullptr;     // pinned: a copy of them + the copy's sequence word (mk::k_heavy_publish)
+        unsigned long long* notes_host_dev = nullptr; // (the same block as the device addresses it)
+        uint64_t seq_seen = 0;           // the copy the list below was made from
+        uint64_t published = 0;          // copies enqueued so far
+        uint64_t evals = 0;              // evaluations that took notes
+        uint32_t heavy_min = 32;         // a run of at least this many requests is noted (TCGPU_HOT_MIN)
+        std::vector<uint32_t> slots;     // the hot list, heaviest first (<= rp::HOT_MAX)
+        uint32_t version = 0;            // bumped whenever the list changes (the sets install it when they next need it)
+        uint32_t backoff = 0;            // batches left during which the hot form is not tried (peeling did not make the ranges fit)
+        unsigned long long* hint_cold_host = nullptr; // pinned: n << 32 | largest range of a recent batch grouped in the hot form (without its hot slots)
+        unsigned long long* hint_cold_dev = nullptr;
+        uint64_t batches_hot = 0;        // batches grouped in the hot form so far
+        uint32_t stable_looks = 0;       // looks in a row that kept the list
+        std::vector<unsigned long long> scratch, found; // hot_refresh's workspace
+    } hot;
     uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting
     uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
     bool general_earlier = true;     // TCGPU_GENERAL_EARLIER=0: k_eval_general without the earlier-state rule (A/B)

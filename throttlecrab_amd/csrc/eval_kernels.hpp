@@ -64,7 +64,52 @@ struct Params {
     uint32_t* denied; // per-slot denial counters (TC_CFG_TRACK_DENIED) or nullptr
     uint64_t* row_bits; // TC_B_GROUPED_OUTPUT + allowed_bits on a batch whose runs are all regular: the evaluation packs
                         // the decisions of its 64-row waves itself (one ballot, one 8-byte store), no byte column
+    // round 6: runs of at least heavy_min requests are noted in heavy[] (heavy_note below); heavy_min == 0: nothing is
+    unsigned long long* heavy = nullptr;
+    uint32_t heavy_min = 0, heavy_tag = 0;
 };
+
+// Which slots are HOT?  The grouping wants to know (range_part.hpp: a slot that takes thousands of a batch's requests is peeled
+// out of the range partition), the host decides, and the evaluation is where every run's length is in a register anyway: the
+// lane holding the LAST request of a run of at least heavy_min requests leaves slot << 32 | min(length, 2^20 - 1) << 12 | tag in
+// a small table in device memory, at a place hashed from the slot and the batch's tag (so that two slots that collide in one
+// batch do not in the next).  One 8-byte store per heavy run, nothing waits, nothing is counted; entries are overwritten at
+// will and validated by their tag on the host, which gets a copy now and then (mk::k_heavy_publish).
+constexpr uint32_t HEAVY_BITS = 12, HEAVY_SLOTS = 1u << HEAVY_BITS;
+constexpr uint32_t HEAVY_TAG_BITS = 12, HEAVY_LEN_MAX = (1u << 20) - 1u;
+__device__ __forceinline__ void heavy_note(const Params& p, uint32_t slot, uint32_t len) {
+    const uint32_t at = ((slot * 0x9E3779B1u) ^ (p.heavy_tag * 0x85EBCA6Bu)) >> (32 - HEAVY_BITS);
+    p.heavy[at] = ((unsigned long long)slot << 32) | ((unsigned long long)(len < HEAVY_LEN_MAX ? len : HEAVY_LEN_MAX) << HEAVY_TAG_BITS) |
+                  (p.heavy_tag & ((1u << HEAVY_TAG_BITS) - 1u));
+}
+
+// First position of the run of `slot` that position k belongs to, given that position k - 1 holds the same slot.  Gallops back
+// over equal slots, then bisects: all it assumes is that a slot's requests are CONTIGUOUS in `sorted` -- true of a sorted batch
+// and of a batch whose hot slots were gathered behind the sorted rest (range_part.hpp) -- and it costs 2 log2(run so far) loads
+// instead of log2(k).
+__device__ __forceinline__ uint32_t run_start_of(const uint64_t* __restrict__ sorted, uint32_t k, uint32_t slot) {
+    uint32_t hi = k, lo, step = 1;
+    for (;;) {
+        if (hi < step) {
+            if ((uint32_t)(sorted[0] >> 32) == slot) return 0u;
+            lo = 0u;
+            break;
+        }
+        const uint32_t q = hi - step;
+        if ((uint32_t)(sorted[q] >> 32) != slot) {
+            lo = q;
+            break;
+        }
+        hi = q;
+        step <<= 1;
+    }
+    while (hi - lo > 1u) { // sorted[lo] is another slot, sorted[hi] is mine
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((uint32_t)(sorted[mid] >> 32) == slot) hi = mid;
+        else lo = mid;
+    }
+    return hi;
+}
 
 struct Req {
     int64_t ei, dvt, q, now, limit;
@@ -565,15 +610,8 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
         if (lane == 63) s_rowmax[j][wave] = v;
     }
     if (threadIdx.x == 0 && kk[0] < n && !head[0]) {
-        // the run of the block's first position began in an earlier block: lower_bound on the slot
-        const uint32_t slot = (uint32_t)(me[0] >> 32);
-        uint32_t lo = 0, hi = block_start;
-        while (lo < hi) {
-            const uint32_t mid = lo + ((hi - lo) >> 1);
-            if ((uint32_t)(sorted[mid] >> 32) < slot) lo = mid + 1;
-            else hi = mid;
-        }
-        s_start = lo;
+        // the run of the block's first position began in an earlier block
+        s_start = run_start_of(sorted, kk[0], (uint32_t)(me[0] >> 32));
     }
     __syncthreads();
 
@@ -604,6 +642,7 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
         bool bit = false; // my decision (every valid lane of a DIRECT batch writes its own outputs exactly once)
         if (valid) {
             const uint32_t r = k - seg_start[j];
+            if (is_last[j] && p.heavy_min != 0u && r + 1u >= p.heavy_min) heavy_note(p, slot, r + 1u);
             const Req rq = make_req_rc(p, slot, rc[j]);
             Decision d;
             d.allowed = false;
@@ -837,6 +876,10 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     const int pend = lb ? lane + __builtin_ctzll(lb) : 63;
     const unsigned long long piece =
         (pend == 63 ? ~0ull : ((2ull << pend) - 1ull)) & ~((1ull << pstart) - 1ull);
+    if (p.heavy_min != 0u && is_last && slot < p.capacity) { // (round 6: heavy_note)
+        const uint32_t first = continued ? run_start_of(sorted, k - (uint32_t)lane, slot) : k - (uint32_t)(lane - pstart);
+        if (k - first + 1u >= p.heavy_min) heavy_note(p, slot, k - first + 1u);
+    }
 
     // State my piece starts from: the resident cell, or what the previous wave hands over.
     // A hot key's segment crosses hundreds of waves; waiting wave by wave would serialise

@@ -546,6 +546,17 @@ static __global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, c
     }
 }
 
+// Round 6: the evaluation's notes on heavy runs (ev::heavy_note) -> pinned host memory, the batch tag of the copy behind them.
+// One block; the notes are 8-byte words that the host validates one by one, so a copy taken while an evaluation is writing is as
+// good as any.  Enqueued now and then (slots.hip), never waited for.
+static __global__ __launch_bounds__(1024) void k_heavy_publish(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src,
+                                                               uint32_t words, unsigned long long seq) {
+    for (uint32_t i = threadIdx.x; i < words; i += 1024) dst[i] = __builtin_nontemporal_load(&src[i]);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&dst[words], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Several such copies in ONE launch (blockIdx.y = the segment): the input columns of a synchronous host batch from PINNED memory.
 // Seven hipMemcpyAsync calls on one stream cost ~10-18 us each before the first byte moves (a 4 Ki-request reference-shaped
 // call spent 70 of its 200 us there); one launch reads them all over PCIe side by side.

@@ -42,6 +42,9 @@ constexpr int HIST_THREADS = 1024; // k_hist: few big blocks -> few global atomi
 constexpr int HIST_BLOCKS = 128;
 constexpr int RADIX = 256;
 constexpr int MAX_PASSES = 4;
+constexpr int NRANGE = 512;                         // key ranges of the range path (round 6: was 256 = RADIX)
+constexpr int HIST_ROWS = MAX_PASSES + NRANGE / RADIX; // histogram rows of a batch: one per LSD digit + the range digit's (k_hist counts it beside them)
+constexpr int HIST_WORDS = HIST_ROWS * RADIX;
 constexpr int GROUP = 16;          // tiles per look-back group
 constexpr int GROUP_WINDOW = 16;   // predecessor groups examined per look-back round trip
 constexpr uint32_t RESIDENT_TILES = 1024; // <= this many tiles are co-resident on 256 CUs (>= 4 blocks/CU)
@@ -65,7 +68,7 @@ constexpr uint32_t GACC_SUM_MASK = (1u << GACC_SHIFT) - 1u;
 // flight) and, walking backwards over whole groups, complete gacc words until it
 // meets a published gincl (big grids: the first window) or runs out of groups.
 struct Workspace {
-    uint32_t* hist;      // [MAX_PASSES][RADIX] digit histograms of this batch (zero on entry)
+    uint32_t* hist;      // [HIST_ROWS][RADIX] digit histograms of this batch (zero on entry): the LSD digits' rows, then the range digit's NRANGE words
     uint32_t* hist_next; // the other parity's histograms: cleared here for the next batch
     uint32_t* ticket;    // [MAX_PASSES] dynamic tile ids (forward progress for the look-back)
     uint32_t* status;    // [MAX_PASSES] x { part[max_tiles] | gacc[max_groups] | gincl[max_groups] } x RADIX
@@ -91,24 +94,29 @@ struct Workspace {
 // A range that holds more than FIN_CAP elements (a skewed batch the host did not foresee: it chooses the path from the
 // largest range of a RECENT batch, mirrored into pinned memory) is sorted by its block through global memory, slowly but
 // exactly; streams that are skewed stay on the LSD passes.
-constexpr int FIN_THREADS = 1024;
+// Round 6: 512 ranges finished by 512-thread blocks of HALF the LDS (73 KB against 147): two of them share a CU, or one shares it
+// with a block of the partition (rp::k_tile_part, 42-76 KB).  With one 147 KB block per CU, no other grouping kernel could run
+// beside a k_finish on ANY CU: the grouping chains of the three streams took turns (tools/host_bound.py: the device, not the
+// host, held a Zipf batch at 54 us).
+constexpr int FIN_THREADS = 512;
 constexpr int FIN_WAVES = FIN_THREADS / 64;
 constexpr int FIN_ITEMS = 8;
 constexpr uint32_t FIN_CAP = FIN_THREADS * FIN_ITEMS; // elements of a range that are finished in LDS
-constexpr uint32_t FIN_POS_BITS = 13;                  // FIN_CAP == 1 << FIN_POS_BITS
+constexpr uint32_t FIN_POS_BITS = 12;                  // FIN_CAP == 1 << FIN_POS_BITS
 constexpr int FIN_ROW = RADIX + 1;                     // per-wave counter rows, padded against bank conflicts
-constexpr int MSD_ROW = MAX_PASSES - 1;                // histogram row of the range digit when k_hist counts it beside the LSD digits
+constexpr int MSD_ROW = MAX_PASSES;                    // first histogram row of the range digit (NRANGE / RADIX rows) when k_hist counts it beside the LSD digits
+static_assert(NRANGE == FIN_THREADS, "k_finish: one thread per range when the ranges' sizes are summed");
 static_assert(FIN_CAP == (1u << FIN_POS_BITS), "positions inside a range must fit FIN_POS_BITS");
 // k_finish, counting path: ranges of at most CNT_W_MAX slots whose slots hold at most CNT_DUP_MAX elements each are sorted by
 // COUNTING (one LDS atomic per element on a byte counter per slot) instead of two ballot-ranked passes
-constexpr uint32_t CNT_W_MAX = 49152;
-constexpr uint32_t CNT_DUP_MAX = 16;
+constexpr uint32_t CNT_W_MAX = 24576;
+constexpr uint32_t CNT_DUP_MAX = 255; // (round 6: was 16 -- behind the hot slots of a skewed stream come slots with dozens of requests each; the four counters of a word are summed with v_sad_u8, which does not care whether the sum fits a byte)
 constexpr uint32_t FIN_UNION_WORDS = CNT_W_MAX / 4 + CNT_W_MAX / 8 + FIN_CAP; // >= 2 * FIN_CAP + FIN_WAVES * FIN_ROW + 2 * RADIX
 static_assert(FIN_UNION_WORDS >= 2 * FIN_CAP + FIN_WAVES * FIN_ROW + 2 * RADIX, "the ballot path's arrays fit the union");
 
-// digit = umulhi(slot, mul) with mul = floor(256 * 2^32 / (cap + 1)): < 256 for every slot <= cap (cap itself is the
-// sentinel of out-of-range slots).  Needs cap + 1 > 256.
-__host__ __device__ inline uint32_t range_mul(uint32_t cap) { return (uint32_t)((256ull << 32) / ((uint64_t)cap + 1ull)); }
+// digit = umulhi(slot, mul) with mul = floor(NRANGE * 2^32 / (cap + 1)): < NRANGE for every slot <= cap (cap itself is the
+// sentinel of out-of-range slots).  Needs cap + 1 > NRANGE.
+__host__ __device__ inline uint32_t range_mul(uint32_t cap) { return (uint32_t)(((uint64_t)NRANGE << 32) / ((uint64_t)cap + 1ull)); }
 // smallest slot whose digit is >= d:  slot * mul >= d * 2^32
 __host__ __device__ inline uint32_t range_lo(uint32_t d, uint32_t mul) { return (uint32_t)((((uint64_t)d << 32) + mul - 1u) / mul); }
 // widest range (slots), conservatively
@@ -120,13 +128,13 @@ __host__ __device__ inline size_t pass_status_words(uint32_t max_tiles, uint32_t
 }
 // words of the whole workspace (two histogram parities | tickets | status)
 inline size_t workspace_words(uint32_t max_tiles) {
-    return (size_t)2 * MAX_PASSES * RADIX + MAX_PASSES + (size_t)MAX_PASSES * pass_status_words(max_tiles, groups_of(max_tiles));
+    return (size_t)2 * HIST_WORDS + MAX_PASSES + (size_t)MAX_PASSES * pass_status_words(max_tiles, groups_of(max_tiles));
 }
 inline Workspace carve(uint32_t* base, uint32_t parity, uint32_t max_tiles) {
     Workspace ws;
-    ws.hist = base + (size_t)parity * MAX_PASSES * RADIX;
-    ws.hist_next = base + (size_t)(parity ^ 1u) * MAX_PASSES * RADIX;
-    ws.ticket = base + (size_t)2 * MAX_PASSES * RADIX;
+    ws.hist = base + (size_t)parity * HIST_WORDS;
+    ws.hist_next = base + (size_t)(parity ^ 1u) * HIST_WORDS;
+    ws.ticket = base + (size_t)2 * HIST_WORDS;
     ws.status = ws.ticket + MAX_PASSES;
     ws.max_tiles = max_tiles;
     ws.max_groups = groups_of(max_tiles);
@@ -150,14 +158,14 @@ __device__ __forceinline__ bool gated_off(const uint32_t* __restrict__ gate, uin
 
 // `fill` (TC_B_OUTPUTS_IDLE batches): the batch's decision bytes, set to fill_value here, ahead of the evaluation,
 // which then only stores the decisions that differ (16-byte stores; the tail bytewise)
-// `msd_mul` != 0 (passes <= 3): the range digit umulhi(slot, msd_mul) is counted beside the LSD digits, into row MSD_ROW, from
+// `msd_mul` != 0: the range digit umulhi(slot, msd_mul) is counted beside the LSD digits, into the rows from MSD_ROW on, from
 // which the first LSD pass mirrors the largest range to the host (the hint the range path is chosen by)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, uint32_t n, uint32_t cap,
                                                   int passes, Workspace ws, uint32_t tiles, const uint32_t* __restrict__ gate,
                                                   uint32_t gate_min, uint8_t* __restrict__ fill, uint32_t fill_value,
                                                   uint32_t msd_mul) {
-    __shared__ uint32_t s_h[MAX_PASSES][RADIX];
+    __shared__ uint32_t s_h[HIST_ROWS][RADIX];
     if (fill != nullptr) {
         const uint32_t v4 = fill_value * 0x01010101u;
         const uint32_t head = (uint32_t)((16u - ((uintptr_t)fill & 15u)) & 15u); // bytes before the first aligned 16
@@ -172,10 +180,10 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
     }
     if (gated_off(gate, gate_min)) {
         if (blockIdx.x == 0)
-            for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) ws.hist_next[i] = 0;
+            for (int i = threadIdx.x; i < HIST_WORDS; i += NT) ws.hist_next[i] = 0;
         return;
     }
-    for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) (&s_h[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < HIST_WORDS; i += NT) (&s_h[0][0])[i] = 0;
     // clear the look-back words this sort will use (every pass: part | gacc | gincl) + tickets
     {
         const uint32_t groups = groups_of(tiles);
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
     }
     if (blockIdx.x == 0) {
         if (threadIdx.x < MAX_PASSES) ws.ticket[threadIdx.x] = 0;
-        for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) ws.hist_next[i] = 0;
+        for (int i = threadIdx.x; i < HIST_WORDS; i += NT) ws.hist_next[i] = 0;
     }
     __syncthreads();
     {
@@ -209,19 +217,19 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
             for (int u = 0; u < 4; ++u) {
                 const uint32_t kk = clamp_slot(k[u], cap);
                 for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-                if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
+                if (msd_mul) atomicAdd(&(&s_h[MSD_ROW][0])[__umulhi(kk, msd_mul)], 1u); // (NRANGE words: rows MSD_ROW ..)
             }
         }
         for (; i < n; i += stride) {
             const uint32_t kk = clamp_slot(slot[i], cap);
             for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-            if (msd_mul) atomicAdd(&s_h[MSD_ROW][__umulhi(kk, msd_mul)], 1u);
+            if (msd_mul) atomicAdd(&(&s_h[MSD_ROW][0])[__umulhi(kk, msd_mul)], 1u); // (NRANGE words: rows MSD_ROW ..)
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < MAX_PASSES * RADIX; i += NT) {
+    for (int i = threadIdx.x; i < HIST_WORDS; i += NT) {
         const int row = i / RADIX;
-        if (!(row < passes || (msd_mul && row == MSD_ROW))) continue;
+        if (!(row < passes || (msd_mul && row >= MSD_ROW))) continue;
         const uint32_t v = (&s_h[0][0])[i];
         if (v) atomicAdd(&ws.hist[i], v);
     }
@@ -259,7 +267,8 @@ __global__ __launch_bounds__(THREADS) void k_onesweep(const uint32_t* __restrict
     for (int i = 0; i < RADIX / 64; ++i) s_wave[wave][i * 64 + lane] = 0;
 
     if (range_hint != nullptr && blockIdx.x == 0) { // (block-uniform)
-        uint32_t m = ws.hist[MSD_ROW * RADIX + threadIdx.x];
+        uint32_t m = 0;
+        for (int i = threadIdx.x; i < NRANGE; i += THREADS) m = max(m, ws.hist[MSD_ROW * RADIX + i]);
         for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
         if (lane == 0) s_scan[wave] = m;
         __syncthreads();
@@ -525,10 +534,11 @@ __device__ __forceinline__ void fin_rank(const uint32_t (&dig)[ITEMS_], const bo
         __builtin_amdgcn_wave_barrier(); // (same-wave LDS operations execute in program order)
     }
     __syncthreads();
-    // exclusive prefix over the 16 waves of every digit: 16 consecutive lanes take one digit's column
+    // exclusive prefix over the FIN_WAVES waves of every digit: FIN_WAVES consecutive lanes take one digit's column
+    static_assert(FIN_WAVES == 8, "the column mapping below: threadIdx.x >> 3, & 7");
 #pragma unroll
     for (int round = 0; round < RADIX / (FIN_THREADS / FIN_WAVES); ++round) {
-        const int d = round * (FIN_THREADS / FIN_WAVES) + (threadIdx.x >> 4), w = threadIdx.x & 15;
+        const int d = round * (FIN_THREADS / FIN_WAVES) + (threadIdx.x >> 3), w = threadIdx.x & (FIN_WAVES - 1);
         const uint32_t v = s_cnt[w][d];
         uint32_t incl = v;
 #pragma unroll
@@ -565,127 +575,22 @@ __device__ __forceinline__ void fin_scan_digits(const uint32_t* s_tot, uint32_t*
 }
 
 // ---------------------------------------------------------------------------
-// range path, first half: every tile partitioned by range in place + its table row
-// ---------------------------------------------------------------------------
-// table[tile * RADIX + r] = (elements of range r in the tile) << 16 | where they start inside the tile;
-// totals[r] += elements of range r (zero on entry: k_finish of the set's previous batch cleared it).
-// `fill` (TC_B_OUTPUTS_IDLE batches): see k_hist -- the range path has no histogram launch, so the decision bytes are preset here.
-template <int ITEMS>
-__global__ __launch_bounds__(THREADS) void k_tile_ranges(const uint32_t* __restrict__ slot_in, uint64_t* __restrict__ elem_out,
-                                                         uint32_t* __restrict__ table, uint32_t* __restrict__ totals, uint32_t n, uint32_t cap,
-                                                         uint32_t msd_mul, uint8_t* __restrict__ fill, uint32_t fill_value) {
-    constexpr int TILE = THREADS * ITEMS;
-    static_assert(TILE <= 65535, "a tile's starts and counts are packed into 16 bits each");
-    __shared__ uint32_t s_wave[WAVES][RADIX];
-    __shared__ uint32_t s_tstart[RADIX];
-    __shared__ uint64_t s_elem[TILE];
-    __shared__ uint32_t s_scan[WAVES];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t tile = blockIdx.x;
-    RS_STAMP(0, 0, gridDim.x / 2);
-    uint32_t key[ITEMS], rank[ITEMS];
-    const uint32_t wbase = tile * TILE + wave * 64 * ITEMS + lane; // wave-striped: (wave, item, lane) order is index order
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) key[j] = slot_in[min(wbase + j * 64, n - 1u)]; // (raw: nothing here waits for a load)
-    // every wave clears its own counter row: no block barrier stands between the loads and the ranking, which starts on
-    // the first items while the later ones are still on their way (the loads were 4.6 of the kernel's 11 us)
-#pragma unroll
-    for (int i = 0; i < RADIX / 64; ++i) s_wave[wave][i * 64 + lane] = 0;
-    if (fill != nullptr) {
-        const uint32_t v4 = fill_value * 0x01010101u;
-        const uint32_t head = (uint32_t)((16u - ((uintptr_t)fill & 15u)) & 15u);
-        const uint32_t h = head < n ? head : n;
-        uint4* f16 = reinterpret_cast<uint4*>(fill + h);
-        const uint32_t n16 = (n - h) / 16u;
-        for (uint32_t i = blockIdx.x * THREADS + threadIdx.x; i < n16; i += gridDim.x * THREADS) f16[i] = make_uint4(v4, v4, v4, v4);
-        if (blockIdx.x == 0) {
-            for (uint32_t i = threadIdx.x; i < h; i += THREADS) fill[i] = (uint8_t)fill_value;
-            for (uint32_t i = h + n16 * 16u + threadIdx.x; i < n; i += THREADS) fill[i] = (uint8_t)fill_value;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    RS_STAMP(0, 1, gridDim.x / 2);
-    RS_STAMP(0, 2, gridDim.x / 2);
-    const unsigned long long lt = (1ull << lane) - 1ull;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const bool valid = (wbase + j * 64) < n;
-        key[j] = clamp_slot(key[j], cap);
-        const uint32_t d = valid ? __umulhi(key[j], msd_mul) : 0u;
-        unsigned long long m = __ballot(valid);
-#pragma unroll
-        for (int b = 0; b < 8; ++b) {
-            const unsigned long long bb = __ballot((d >> b) & 1u);
-            m &= ((d >> b) & 1u) ? bb : ~bb;
-        }
-        const uint32_t before = valid ? s_wave[wave][d] : 0u;
-        rank[j] = before + (uint32_t)__popcll(m & lt);
-        if (valid && (m & lt) == 0ull) s_wave[wave][d] = before + (uint32_t)__popcll(m);
-        __builtin_amdgcn_wave_barrier();
-    }
-    RS_STAMP(0, 3, gridDim.x / 2);
-    __syncthreads();
-    RS_STAMP(0, 4, gridDim.x / 2);
-    {
-        const int d = threadIdx.x; // RADIX == THREADS
-        uint32_t run = 0;
-#pragma unroll
-        for (int w = 0; w < WAVES; ++w) {
-            const uint32_t c = s_wave[w][d];
-            s_wave[w][d] = run;
-            run += c;
-        }
-        uint32_t v = run;
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t o = __shfl_up(v, off, 64);
-            if (lane >= off) v += o;
-        }
-        if (lane == 63) s_scan[wave] = v;
-        __syncthreads();
-        uint32_t carry = 0;
-        for (int w = 0; w < wave; ++w) carry += s_scan[w];
-        const uint32_t start = carry + v - run;
-        s_tstart[d] = start;
-        table[(size_t)tile * RADIX + d] = (run << 16) | start;
-        if (run) atomicAdd(&totals[d], run); // the ranges' sizes over the whole batch (k_finish: where every range goes); nothing waits for it
-    }
-    __syncthreads();
-    RS_STAMP(0, 5, gridDim.x / 2);
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t pos = wbase + j * 64;
-        if (pos < n) {
-            const uint32_t d = __umulhi(key[j], msd_mul);
-            s_elem[s_tstart[d] + s_wave[wave][d] + rank[j]] = ((uint64_t)key[j] << 32) | pos;
-        }
-    }
-    __syncthreads();
-    RS_STAMP(0, 6, gridDim.x / 2);
-    const uint32_t tile_first = tile * TILE;
-    const uint32_t nvalid = (n - tile_first) < (uint32_t)TILE ? (n - tile_first) : (uint32_t)TILE;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const uint32_t i = j * THREADS + threadIdx.x;
-        if (i < nvalid) elem_out[tile_first + i] = s_elem[i];
-    }
-    RS_STAMP(0, 7, gridDim.x / 2);
-}
-
-// ---------------------------------------------------------------------------
 // range path, second half: one block per range
 // ---------------------------------------------------------------------------
-// `tiled`: k_tile_ranges' output (tile size `tile_len`, `tiles` <= FIN_THREADS of them) with its `table`; `elem_out`: the batch
+// `tiled`: k_tile_ranges' / rp::k_tile_part's output (tile size `tile_len`, `tiles` <= FIN_THREADS of them) with its `table` (rows of
+// `stride` words: the ranges first; totals likewise, `totals_words` of them); `elem_out`: the batch
 // sorted by (slot, index); `scratch`: a third array of the batch's size (ranges that do not fit LDS); `totals`: the ranges' sizes
 // (k_tile_ranges), `totals_next`: the other parity's, cleared here for the set's next batch -- no block waits for another
 // (a first version had every block publish its size and read the others': under load, blocks that had been dispatched
 // early then sat on their CU waiting for the late ones, 41 us per launch in the pipelined run against 14 alone);
 // sub_passes = 8-bit digits of the offset inside a range (1 or 2: the host takes this path only when the widest range
-// is at most 65536 slots); `range_hint`: n << 32 | largest range, into pinned host memory (block RADIX - 1).
+// is at most 65536 slots); `range_hint`: n << 32 | largest range, into pinned host memory (block NRANGE - 1).
 static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* __restrict__ tiled, const uint32_t* __restrict__ table,
                                                                uint64_t* __restrict__ elem_out, uint64_t* __restrict__ scratch,
                                                                const uint32_t* __restrict__ totals, uint32_t* __restrict__ totals_next, uint32_t n,
                                                                uint32_t tiles, uint32_t tile_len, uint32_t msd_mul, int sub_passes,
-                                                               unsigned long long* __restrict__ range_hint) {
+                                                               unsigned long long* __restrict__ range_hint, uint32_t stride,
+                                                               uint32_t totals_words) {
     __shared__ uint32_t s_idx[FIN_CAP];            // request index of position p (never moves)
     __shared__ uint32_t s_u[FIN_UNION_WORDS];      // the two ways of sorting a range share this
     // ballot path: offset inside the range << FIN_POS_BITS | p in the order reached so far (x2), per-wave digit counters, digit totals / starts
@@ -698,7 +603,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
     uint16_t* c_ws = reinterpret_cast<uint16_t*>(s_u + CNT_W_MAX / 4);
     uint32_t* c_fin = s_u + CNT_W_MAX / 4 + CNT_W_MAX / 8;
     __shared__ uint32_t s_flag;
-    __shared__ uint32_t s_part[FIN_WAVES];
+    __shared__ uint32_t s_part[2 * FIN_WAVES];
     __shared__ uint32_t s_pos[FIN_THREADS + 1];    // where tile t's piece of my range starts among the range's elements
     __shared__ uint32_t s_st[FIN_THREADS];         // ... and inside the tile
     __shared__ uint32_t s_base;
@@ -711,8 +616,8 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
     uint32_t c, tot_early = 0;
     {
         uint32_t w = 0;
-        if (threadIdx.x < tiles) w = table[(size_t)threadIdx.x * RADIX + r];
-        if (threadIdx.x < RADIX) tot_early = totals[threadIdx.x];
+        if (threadIdx.x < tiles) w = table[(size_t)threadIdx.x * stride + r];
+        tot_early = totals[threadIdx.x]; // (NRANGE == FIN_THREADS: a range's size per thread)
         // (while the two words are on their way: the counting path's counters)
         if (width <= CNT_W_MAX)
             for (uint32_t i = threadIdx.x; i < (width + 3u) / 4u; i += FIN_THREADS) c_cnt[i] = 0;
@@ -736,7 +641,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
         s_st[threadIdx.x] = w & 0xFFFFu;
         if (threadIdx.x == 0) {
             s_pos[FIN_THREADS] = total;
-            totals_next[r] = 0;
+            for (uint32_t i = r; i < totals_words; i += NRANGE) totals_next[i] = 0; // (round 6: the hot buckets' sizes lie behind the ranges')
         }
         c = total;
         __syncthreads();
@@ -745,35 +650,33 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
     // where my range goes in the sorted batch: the sizes of the ranges before mine (and, for the last block, the largest one)
     auto place = [&]() -> uint32_t {
         uint32_t mine = 0, big = 0;
-        if (threadIdx.x < RADIX) {
-            big = tot_early;
-            mine = threadIdx.x < r ? big : 0u;
-        }
+        big = tot_early;
+        mine = threadIdx.x < r ? big : 0u;
         for (int off = 32; off > 0; off >>= 1) {
             mine += __shfl_xor(mine, off, 64);
             big = max(big, __shfl_xor(big, off, 64));
         }
         __syncthreads(); // (s_part is free again)
-        if (lane == 0 && wave < RADIX / 64) {
+        if (lane == 0) {
             s_part[wave] = mine;
-            s_part[RADIX / 64 + wave] = big;
+            s_part[FIN_WAVES + wave] = big;
         }
         __syncthreads();
         if (threadIdx.x == 0) {
             uint32_t b0 = 0, m0 = 0;
-            for (int q = 0; q < RADIX / 64; ++q) {
+            for (int q = 0; q < FIN_WAVES; ++q) {
                 b0 += s_part[q];
-                m0 = max(m0, s_part[RADIX / 64 + q]);
+                m0 = max(m0, s_part[FIN_WAVES + q]);
             }
             s_base = b0;
-            if (r == RADIX - 1 && range_hint != nullptr)
+            if (r == NRANGE - 1 && range_hint != nullptr)
                 __hip_atomic_store(range_hint, ((unsigned long long)n << 32) | m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __syncthreads();
         return s_base;
     };
     if (c == 0u) {
-        if (r == RADIX - 1) (void)place(); // (the hint)
+        if (r == NRANGE - 1) (void)place(); // (the hint)
         return;
     }
     if (c <= FIN_CAP) {
@@ -839,7 +742,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 const uint32_t per = (nw + FIN_THREADS - 1) / FIN_THREADS;
                 const uint32_t w0 = min(threadIdx.x * per, nw), w1 = min(w0 + per, nw);
                 uint32_t mine = 0;
-                for (uint32_t i = w0; i < w1; ++i) mine += (c_cnt[i] * 0x01010101u) >> 24; // (four counters of at most 16: no carry)
+                for (uint32_t i = w0; i < w1; ++i) mine += __builtin_amdgcn_sad_u8(c_cnt[i], 0u, 0u); // (the sum of the word's four counters)
                 uint32_t incl = mine;
                 for (int off = 1; off < 64; off <<= 1) {
                     const uint32_t o = __shfl_up(incl, off, 64);
@@ -851,7 +754,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 for (int q = 0; q < wave; ++q) run += s_part[q];
                 for (uint32_t i = w0; i < w1; ++i) {
                     c_ws[i] = (uint16_t)run;
-                    run += (c_cnt[i] * 0x01010101u) >> 24;
+                    run += __builtin_amdgcn_sad_u8(c_cnt[i], 0u, 0u);
                 }
                 __syncthreads();
                 RS_STAMP(1, 6, 128);
@@ -866,7 +769,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                         const uint32_t sub = kv[j] >> FIN_POS_BITS, sh = 8u * (sub & 3u);
                         const uint32_t w = c_cnt[sub >> 2];
                         len[j] = (w >> sh) & 255u;
-                        q_of[j] = (uint32_t)c_ws[sub >> 2] + (((w & ((1u << sh) - 1u)) * 0x01010101u) >> 24);
+                        q_of[j] = (uint32_t)c_ws[sub >> 2] + __builtin_amdgcn_sad_u8(w & ((1u << sh) - 1u), 0u, 0u);
                         if (len[j] > 1u) s_grp[q_of[j] + arr[j]] = kv[j] & (FIN_CAP - 1u);
                     }
                 }

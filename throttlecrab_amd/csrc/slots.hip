@@ -245,31 +245,118 @@ static bool outputs_back_in_one_launch(tc_engine* e, const tc_batch& b, hipStrea
     return ok;
 }
 
-// Does this batch take the range path (radix_sort.hpp: every tile partitioned by key range in place + one block per range
-// that collects and finishes it in LDS -- two launches instead of a histogram and three LSD passes)?  The host cannot see
-// the batch; it goes by the largest range of a RECENT batch of the stream, which every grouping mirrors into pinned memory
-// (never waited for).  No hint yet, a hint that predicts a range beyond what a block finishes in LDS, or a batch too large:
-// the LSD passes.  A wrong guess costs time, not correctness (k_finish sorts an oversized range through global memory).
-static bool range_applies(tc_engine* e, uint32_t n, bool piped) {
-    if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return false;
+// Round 6: the hot list (range_part.hpp).  The evaluations note every run of at least hot.heavy_min requests in a small device
+// table, a copy of which reaches pinned memory now and then; whenever a NEW copy has arrived the list is made afresh from the
+// notes of the last HOT_NOTE_AGE evaluations (two copies' worth: a stream that stops being skewed empties the list soon): the (up to) rp::HOT_MAX slots with the longest runs, heaviest first (the order the gather's
+// units are cut for).  Never waits; a stream without heavy runs leaves the list empty.
+constexpr uint32_t HOT_NOTE_AGE = 16;
+static void hot_refresh(tc_engine* e) {
+    tc_engine::Hot& h = e->hot;
+    if (!h.on || !h.notes_host) return;
+    const unsigned long long seq = *(volatile unsigned long long*)(h.notes_host + ev::HEAVY_SLOTS);
+    if (seq == h.seq_seen) return;
+    h.seq_seen = seq;
+    const uint32_t tag_mask = (1u << ev::HEAVY_TAG_BITS) - 1u, tag_now = (uint32_t)seq & tag_mask;
+    // one note per slot (the longest run), through a scratch hash: 4 096 notes at most, no sort of them all (this runs on the
+    // caller's thread between two enqueues: a first version sorted the notes twice and cost the pipeline 0.3 ms every 8th batch)
+    constexpr uint32_t SCR = 2u * ev::HEAVY_SLOTS;
+    if (h.scratch.size() != SCR) h.scratch.assign(SCR, 0ull);
+    else std::fill(h.scratch.begin(), h.scratch.end(), 0ull);
+    auto probe = [&](uint32_t slot) -> unsigned long long& { // entry: (slot + 1) << 32 | length
+        uint32_t at = (slot * 0x9E3779B1u) >> (32 - (ev::HEAVY_BITS + 1));
+        while (h.scratch[at] != 0ull && (uint32_t)(h.scratch[at] >> 32) != slot + 1u) at = (at + 1u) & (SCR - 1u);
+        return h.scratch[at];
+    };
+    std::vector<unsigned long long>& found = h.found; // length << 32 | ~slot: descending = longest first, then by slot
+    found.clear();
+    for (uint32_t i = 0; i < ev::HEAVY_SLOTS; ++i) {
+        const unsigned long long v = ((volatile unsigned long long*)h.notes_host)[i];
+        const uint32_t len = (uint32_t)(v >> ev::HEAVY_TAG_BITS) & ev::HEAVY_LEN_MAX, slot = (uint32_t)(v >> 32);
+        if (len < h.heavy_min || slot >= e->capacity || ((tag_now - (uint32_t)v) & tag_mask) >= HOT_NOTE_AGE) continue;
+        unsigned long long& en = probe(slot);
+        if ((uint32_t)en < len) en = ((unsigned long long)(slot + 1u) << 32) | len;
+    }
+    for (const unsigned long long en : h.scratch)
+        if (en) found.push_back(((unsigned long long)(uint32_t)en << 32) | (0xFFFFFFFFu - ((uint32_t)(en >> 32) - 1u)));
+    if (found.size() > rp::HOT_MAX) {
+        std::nth_element(found.begin(), found.begin() + rp::HOT_MAX, found.end(), std::greater<unsigned long long>());
+        found.resize(rp::HOT_MAX);
+    }
+    std::sort(found.begin(), found.end(), std::greater<unsigned long long>());
+    std::vector<uint32_t> now(found.size());
+    for (size_t i = 0; i < found.size(); ++i) now[i] = 0xFFFFFFFFu - (uint32_t)found[i];
+    // Keep the installed tables while the list is nearly the same: who is among the heaviest 8 / 64 (the gather's single-id
+    // units, rp::HG_SINGLES) and nine in ten of the rest.  The tail of a skewed stream's list changes with every look (slots
+    // around heavy_min requests per batch come and go); a slot that stays on the list for nothing costs an empty bucket.
+    auto as_set = [](const std::vector<uint32_t>& v, size_t k) {
+        std::vector<uint32_t> c(v.begin(), v.begin() + std::min(k, v.size()));
+        std::sort(c.begin(), c.end());
+        return c;
+    };
+    bool same = !h.slots.empty() && as_set(now, rp::HG_A_IDS) == as_set(h.slots, rp::HG_A_IDS) && as_set(now, rp::HG_B_END) == as_set(h.slots, rp::HG_B_END);
+    if (same) {
+        size_t both = 0;
+        for (const uint32_t sl : h.slots) both += probe(sl) != 0ull ? 1u : 0u; // (noted at all: on the new list or just below its cut)
+        same = both * 10u >= h.slots.size() * 9u && now.size() * 10u <= h.slots.size() * 12u + 100u;
+    }
+    if (now.empty() && h.slots.empty()) same = true;
+    if (same) {
+        h.stable_looks++;
+        return;
+    }
+    h.stable_looks = 0;
+    h.slots.swap(now);
+    if (++h.version == 0u) h.version = 1u;
+    h.backoff = 0;
+    *(volatile unsigned long long*)h.hint_cold_host = 0ull; // (what the old list left of the ranges says nothing about the new one)
+}
+
+// How is this batch grouped?  GROUP_RANGE: the range path (radix_sort.hpp / range_part.hpp: every tile partitioned by key range
+// in place + one block per range that collects and finishes it in LDS -- two launches instead of a histogram and three LSD
+// passes); GROUP_RANGE_HOT: the same with the slots of the hot list peeled out of the partition and gathered behind the ranges
+// (three launches); GROUP_LSD: the passes.  The host cannot see the batch; it goes by the largest range of a RECENT batch of the
+// stream, which every grouping mirrors into pinned memory (never waited for).  No hint yet, a hint that predicts a range beyond
+// what a block finishes in LDS and no hot list that could explain it, or a batch too large: the LSD passes.  A wrong guess costs
+// time, not correctness (k_finish sorts an oversized range through global memory).
+enum { GROUP_LSD = 0, GROUP_RANGE = 1, GROUP_RANGE_HOT = 2 };
+static int range_applies(tc_engine* e, uint32_t n, bool piped, bool hot_allowed) {
+    if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return GROUP_LSD;
+    hot_refresh(e);
     const unsigned long long h = *(volatile unsigned long long*)e->range_hint_host;
     const uint64_t hn = h >> 32, hmax = h & 0xFFFFFFFFull;
     // the share of a batch its largest range took (x 2^20), of the last RANGE_HINTS looks at the hint: a stream that
     // alternates between uniform and skewed batches stays on the LSD passes (a skewed batch on the range path costs a
     // block's slow pass over its oversized range: ~0.5 ms for a Zipf(1.1) batch)
-    if (hn == 0) return false; // (no grouping of this engine has run yet)
+    if (hn == 0) return GROUP_LSD; // (no grouping of this engine has run yet)
     e->range_share[e->range_looks++ % tc_engine::RANGE_HINTS] = (uint32_t)std::min<uint64_t>((hmax << 20) / hn, 0xFFFFFFFFull);
-    const uint32_t tile = rs::THREADS * (uint32_t)(piped ? e->sort_items_piped : SORT_ITEMS);
-    if (n < 256u || n > e->range_max_n || (n + tile - 1) / tile > (uint32_t)rs::FIN_THREADS) return false;
+    const uint32_t tile = rp::PT_TILE;
+    if (n < 256u || n > e->range_max_n || (n + tile - 1) / tile > (uint32_t)rs::FIN_THREADS) return GROUP_LSD;
     uint32_t worst = 0;
     for (uint32_t k = 0; k < tc_engine::RANGE_HINTS; ++k) worst = std::max(worst, e->range_share[k]);
-    return (((uint64_t)worst * n) >> 20) <= (uint64_t)(rs::FIN_CAP / 8u * 7u);
+    const uint64_t fits = (uint64_t)(rs::FIN_CAP / 8u * 7u);
+    if ((((uint64_t)worst * n) >> 20) <= fits) return GROUP_RANGE;
+    // Skewed as a whole -- but is it a few slots that make it so?  With a hot list, the batch is grouped without them; what the
+    // largest range then held comes back in a word of its own (the plain hint keeps saying "skewed": nobody counts the whole
+    // batch by range while the stream is grouped this way).  If peeling did not help, the passes, for a while.
+    tc_engine::Hot& hs = e->hot;
+    if (!hot_allowed || !hs.on || hs.slots.empty() || n < 16384u) return GROUP_LSD;
+    if (hs.backoff) {
+        --hs.backoff;
+        return GROUP_LSD;
+    }
+    const unsigned long long hc = *(volatile unsigned long long*)hs.hint_cold_host;
+    if ((hc >> 32) != 0ull && ((hc & 0xFFFFFFFFull) * n) / (hc >> 32) > fits) {
+        hs.backoff = 64;
+        *(volatile unsigned long long*)hs.hint_cold_host = 0ull;
+        return GROUP_LSD;
+    }
+    return GROUP_RANGE_HOT;
 }
 
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
 // returns the buffer holding the result
 static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStream_t s, const uint32_t* d_slot, uint32_t n,
-                                    bool piped, bool ranged, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
+                                    bool piped, int ranged, const uint32_t* gate = nullptr, uint32_t gate_min = 0, hipEvent_t stop_last = nullptr,
                                     uint8_t* fill = nullptr, uint32_t fill_value = 0) {
     const uint32_t cap = (uint32_t)e->capacity;
     const int bits = std::max(1, bit_width_u64(e->capacity)); // the sentinel key `capacity` must fit
@@ -282,25 +369,39 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     uint64_t* bufs[2] = {ss.elem_a, ss.elem_b};
     unsigned long long* hint = e->range_ok ? e->range_hint_dev : nullptr;
     if (ranged) {
-        // tiles partitioned in place into elem_b (+ the table, in the look-back words of the first LSD pass, which this batch
-        // does not run), every range finished into elem_a.  No histogram launch: the histogram parity stays as it is.
-        uint32_t* table = ws.status;
-        uint32_t* totals = ss.range_totals + (size_t)ss.range_parity * rs::RADIX;         // zero: cleared by the finish of the set's previous batch
-        uint32_t* totals_next = ss.range_totals + (size_t)(ss.range_parity ^ 1u) * rs::RADIX;
+        // round 6 (range_part.hpp): tiles of 4 096 requests on 1 024 threads, partitioned in place into elem_b by key range -- and,
+        // in the hot form, by hot id: those buckets are gathered behind the ranges' elements, every range is finished into elem_a
+        const bool hotm = ranged == GROUP_RANGE_HOT;
+        const uint32_t ptiles = (n + rp::PT_TILE - 1) / rp::PT_TILE, stride = hotm ? rp::NB_HOT : rp::NR;
+        uint32_t* totals = ss.range_totals + (size_t)ss.range_parity * rp::NB_HOT;         // zero: cleared by the finish of the set's previous batch
+        uint32_t* totals_next = ss.range_totals + (size_t)(ss.range_parity ^ 1u) * rp::NB_HOT;
         ss.range_parity ^= 1u;
+        if (hotm && ss.hot_version != e->hot.version) {
+            rp::HotList hl;
+            hl.count = (uint32_t)std::min<size_t>(e->hot.slots.size(), rp::HOT_MAX);
+            memcpy(hl.slot, e->hot.slots.data(), hl.count * sizeof(uint32_t));
+            hipLaunchKernelGGL(rp::k_hot_install, dim3(1), dim3(rp::PT_THREADS), 0, s, hl, ss.hot_dev);
+            ss.hot_version = e->hot.version;
+        }
         prof_begin_m(e, TC_STAGE_SORT, s);
-#define TC_TILES(IT) \
-    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rs::k_tile_ranges<IT>), dim3(tiles), dim3(rs::THREADS), 0, s, d_slot, bufs[1], table, totals, n, cap, \
-                e->range_mul, fill, fill_value)
-        if (items == 32) TC_TILES(32);
-        else if (items == 16) TC_TILES(16);
-        else TC_TILES(8);
-#undef TC_TILES
+        if (hotm) TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<true>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap,
+                              e->range_mul, fill, fill_value, (const rp::HotDev*)ss.hot_dev);
+        else TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<false>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap,
+                         e->range_mul, fill, fill_value, (const rp::HotDev*)nullptr);
         prof_end_m(e, s);
+        if (hotm) {
+            const uint32_t hb = rp::hg_grid(n, (uint32_t)std::min<size_t>(e->hot.slots.size(), rp::HOT_MAX), rp::hg_group(ptiles));
+            prof_begin_m(e, TC_STAGE_SORT, s);
+            TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, rp::k_hot_gather, dim3(hb), dim3(rp::HG_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)ss.part_table, stride,
+                        (const uint32_t*)totals, bufs[0], ptiles, rp::PT_TILE, (const rp::HotDev*)ss.hot_dev);
+            prof_end_m(e, s);
+            e->hot.batches_hot++;
+        }
         prof_begin_m(e, TC_STAGE_SORT, s);
         hipEvent_t stop = e->prof_on ? nullptr : stop_last;
-        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::RADIX), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)table, bufs[0],
-                    ss.elem_c, (const uint32_t*)totals, totals_next, n, tiles, tile, e->range_mul, e->range_sub_passes, hint);
+        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::NRANGE), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)ss.part_table, bufs[0],
+                    ss.elem_c, (const uint32_t*)totals, totals_next, n, ptiles, rp::PT_TILE, e->range_mul, e->range_sub_passes, hotm ? e->hot.hint_cold_dev : hint, stride,
+                    rp::NB_HOT);
         prof_end_m(e, s);
         return bufs[0];
     }
@@ -553,6 +654,13 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
     p.uniform_class = e->uniform_id;
     p.denied = e->denied;
     p.row_bits = nullptr;
+    // round 6: the evaluation notes its heavy runs for the host's hot list (hot_refresh); batches too small to care are left out
+    const bool notes = e->hot.on && e->hot.notes_dev != nullptr && n >= 16384u && !(b.flags & TC_B_UNIQUE_SLOTS);
+    if (notes) {
+        p.heavy = e->hot.notes_dev;
+        p.heavy_min = e->hot.heavy_min;
+        p.heavy_tag = (uint32_t)(e->hot.evals & ((1u << ev::HEAVY_TAG_BITS) - 1u));
+    }
     p.capacity = e->capacity;
     p.counters = e->counters;
     if (b.flags & TC_B_REGISTERED_PARAMS) {
@@ -613,7 +721,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
         // batches are not partitioned at all (the sort path alone is always correct), then the path is tried again.
         // (round 4: a batch the range path takes is grouped by it alone, in order as well: two grouping launches and the
         // evaluation, nothing enqueued twice)
-        const bool ranged = range_applies(e, n, piped);
+        const int ranged = range_applies(e, n, piped, !p.order);
         // The range hint is written by the grouping kernels of the sort paths (k_hist's range row, k_finish).  An in-order batch
         // on the bucket path leaves none: an engine that only ever sees in-order batches would stay on the bucket path for
         // good -- 84 us per 1 Mi batch where the range path takes 63, found by tools/batch_sizes.py; bench.py's in-order
@@ -636,7 +744,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             }
         }
         const bool bucketed = eligible;
-        e->last_grouping_path = ranged ? 1u : (bucketed ? 3u : 2u); // (bucketed: decided on the device in the end -- tc_engine_info says what was enqueued)
+        e->last_grouping_path = ranged == GROUP_RANGE_HOT ? 5u : (ranged ? 1u : (bucketed ? 3u : 2u)); // (bucketed: decided on the device in the end -- tc_engine_info says what was enqueued)
         // Grouped rows + a bitmask of them, every run regular: the evaluation's waves hold 64 consecutive rows each and
         // pack their decisions with one ballot (no byte column, no k_pack_bits launch).
         if (b.allowed_bits && p.order && direct) {
@@ -700,7 +808,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // (direct: the evaluation is the last reader of the set -- `consumed` can ride on its completion signal)
             consumed_rides = direct && e->stop_events && !e->prof_on;
             // (slim: the stream looked skewed to the range hint -- not merely "no hint yet" or a batch too large for the path)
-            const bool slim = piped && e->range_ok && !ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n;
+            const bool slim = piped && e->range_ok && (ranged == GROUP_RANGE_HOT || (!ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n));
             launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr, slim);
             prof_end_m(e, s);
             if (!direct) {
@@ -718,6 +826,15 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             prof_end_m(e, s);
         }
         e->wait_before_sort = nullptr;
+        if (notes) {
+            // a copy of the notes for the host behind the first few evaluations, then behind every eighth (one block, ~3 us of
+            // the engine's stream; the host never waits for it)
+            const uint64_t k = ++e->hot.evals;
+            if (k <= 4 || ((k & 7u) == 0u && (e->hot.stable_looks < 4u || (k & 31u) == 0u))) { // (a list that has settled is looked at every 32nd batch)
+                const unsigned long long seq = ((unsigned long long)(++e->hot.published) << ev::HEAVY_TAG_BITS) | p.heavy_tag;
+                hipLaunchKernelGGL(mk::k_heavy_publish, dim3(1), dim3(1024), 0, s, e->hot.notes_host_dev, (const unsigned long long*)e->hot.notes_dev, ev::HEAVY_SLOTS, seq);
+            }
+        }
         // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream
         if (!consumed_rides) TC_HIP(e, hipEventRecord(ss.consumed, s));
         ss.in_use = true;

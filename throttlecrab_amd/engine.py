@@ -118,7 +118,7 @@ class Engine:
         self._check(self._lib.tc_debug_check_keys(self._h, C.byref(v)))
         return int(v.value)
 
-    GROUPING_PATHS = ("none yet", "range path", "LSD passes", "bucket path", "no grouping")
+    GROUPING_PATHS = ("none yet", "range path", "LSD passes", "bucket path", "no grouping", "range path, hot slots peeled")
 
     def info(self) -> dict:
         """tc_engine_info_get: the pipeline's health -- side streams wanted / kept, what the probe rejected and why, whether
@@ -127,7 +127,7 @@ class Engine:
         r.struct_size = C.sizeof(L.tc_engine_info)
         self._check(self._lib.tc_engine_info_get(self._h, C.byref(r)))
         d = {k: int(getattr(r, k)) for k, _ in L.tc_engine_info._fields_ if k != "struct_size"}
-        d["grouping_path"] = self.GROUPING_PATHS[min(r.grouping_path, 4)]
+        d["grouping_path"] = self.GROUPING_PATHS[min(r.grouping_path, 5)]
         return d
 
     def selfcheck(self) -> int:
