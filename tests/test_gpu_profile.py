@@ -12,7 +12,7 @@ T0 = kat.load()["t0_ns"]
 PLAN = (5, 10, 60)
 
 
-def _run(fixed, general, piped, monkeypatch=None, markers=False, n_keys=200_000, n=1 << 17, batches=6):
+def _run(fixed, general, piped, monkeypatch=None, markers=False, n_keys=200_000, n=1 << 17, batches=6, hot=False):
     import torch
 
     import throttlecrab_amd as t
@@ -20,6 +20,8 @@ def _run(fixed, general, piped, monkeypatch=None, markers=False, n_keys=200_000,
     if markers:
         monkeypatch.setenv("TCGPU_PROF_MARKERS", "1")
     monkeypatch.setenv("TCGPU_BUCKET", "0")  # (in-order batches stay on the sort path: the launches counted below)
+    if not hot:
+        monkeypatch.setenv("TCGPU_HOT", "0")  # (... and the skewed batches on the LSD passes: round 6's hot form is counted below)
     eng = t.Engine(n_keys, n, fixed_params=fixed)
     eng.check_on_close = True
     eng.use_torch_stream()
@@ -44,6 +46,8 @@ def _run(fixed, general, piped, monkeypatch=None, markers=False, n_keys=200_000,
         eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=now_arg, want=("allowed",), out=outs[b],
                                    inputs_ready=piped, outputs_idle=piped)
         alive.append((d, now_arg))  # (the columns stay untouched until the results are ready)
+        if hot and b % 4 == 3:
+            torch.cuda.synchronize()  # (the evaluations' notes reach the host: the next batches are grouped in the hot form)
     torch.cuda.synchronize()
     prof = eng.profile_read()
     eng.profile_enable(False)
@@ -51,6 +55,13 @@ def _run(fixed, general, piped, monkeypatch=None, markers=False, n_keys=200_000,
         got = outs[b].allowed.cpu().numpy()[:n]
         assert (got == refs[b].allowed.astype(np.uint8)).all(), f"batch {b}: profiling changed a decision"
     passes = 3 if n_keys >= (1 << 16) else 2
+    if hot:
+        # a batch is grouped by the LSD passes (k_hist + 3) until the host has a hot list, then in the hot form: the partition,
+        # the gather unless the batch is lean (the rank form), the finish
+        lsd = prof["prep"][1]
+        assert 1 <= lsd < batches and prof["sort"][1] == passes * lsd + (3 if general else 2) * (batches - lsd) and prof["eval"][1] == batches, prof
+        eng.close()
+        return prof
     assert prof["prep"][1] == batches and prof["sort"][1] == passes * batches and prof["eval"][1] == batches, prof
     for stage in ("prep", "sort", "eval"):
         ms, calls = prof[stage]
@@ -64,6 +75,11 @@ def _run(fixed, general, piped, monkeypatch=None, markers=False, n_keys=200_000,
 @pytest.mark.parametrize("fixed", [False, True], ids=["wide", "fixed"])
 def test_profiling_counts_every_launch_and_changes_nothing(fixed, general, piped, monkeypatch):
     _run(fixed, general, piped, monkeypatch)
+
+
+@pytest.mark.parametrize("general", [False, True], ids=["rank_form", "gather_form"])
+def test_profiling_counts_the_hot_forms_launches(general, monkeypatch):
+    _run(True, general, True, monkeypatch, batches=24, hot=True)
 
 
 def test_marker_event_fallback(monkeypatch):

@@ -181,18 +181,22 @@ def _zipf_like(rng, cap, n, hot_keys=400, s=1.1):
     return out
 
 
-@pytest.mark.parametrize("general", [False, True], ids=["one_timestamp", "timestamp_per_request"])
-def test_hot_slots_are_peeled_out_of_the_range_partition(general):
+@pytest.mark.parametrize("kind", ["decisions_only", "full_results", "timestamp_per_request", "decisions_only_wide"])
+def test_hot_slots_are_peeled_out_of_the_range_partition(kind):
     """Round 6 (csrc/range_part.hpp): a stream whose skew is a few hot keys takes the range path with those keys' requests
     gathered behind the ranges.  Who is hot comes from the evaluations' notes on long runs, through pinned memory -- so the
-    first batches go through the LSD passes, and the engine must say when it changed over.  Every batch exact, both evaluation
-    kernels; then the hot keys MOVE (the list is made afresh) and finally the stream turns uniform (the list empties)."""
+    first batches go through the LSD passes, and the engine must say when it changed over.  Every batch exact: decisions only
+    (the RANK form: the hot slots' requests are not even gathered, the evaluation's hot role ranks them where they stand and a
+    commit kernel stores the cells it parked -- on both layouts), full results and a timestamp per request (the GATHER form,
+    both evaluation kernels); then the hot keys MOVE (the list is made afresh) and finally the stream turns uniform (the
+    list empties).  The resident state is compared at the end."""
+    general, lean = kind == "timestamp_per_request", kind.startswith("decisions_only")
     import torch
 
     import throttlecrab_amd as t
     rng = np.random.default_rng(21)
     cap, n, plan = 3_000_000, 200_000, (20, 100, 60)
-    eng = t.Engine(cap, n, fixed_params=True)
+    eng = t.Engine(cap, n, fixed_params=kind != "decisions_only_wide")
     eng.use_torch_stream()
     eng.register_params_uniform(*plan)
     orc = _oracle(cap)
@@ -208,7 +212,7 @@ def test_hot_slots_are_peeled_out_of_the_range_partition(general):
             res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=torch.from_numpy(nowc).cuda(), want=("allowed",), inputs_ready=True)
         else:
             ref = orc.batch_slots(slots, *plan, 1, now)
-            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=now, want=("allowed", "remaining"), inputs_ready=True)
+            res = eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=now, want=("allowed",) if lean else ("allowed", "remaining"), inputs_ready=True)
         paths.append(eng.info()["grouping_path"])
         held.append((res, ref, d))
         if i % 2 == 1:
@@ -216,9 +220,17 @@ def test_hot_slots_are_peeled_out_of_the_range_partition(general):
     torch.cuda.synchronize()
     for i, (res, ref, _) in enumerate(held):
         assert np.array_equal(res.allowed.cpu().numpy(), ref.allowed), f"batch {i} ({paths[i]}): decisions differ"
-        if not general:
+        if not general and not lean:
             assert np.array_equal(res.remaining.cpu().numpy(), ref.remaining), f"batch {i} ({paths[i]}): remaining differs"
     info = eng.info()
+    # the resident state after the last batch: one more request per slot of the first batch, full results
+    probe = np.unique(streams[0]().astype(np.uint32))[:50_000]
+    now = T0 + len(streams) * 50_000_000
+    ref = orc.batch_slots(probe, *plan, 1, now)
+    res = eng.rate_limit_batch_slots(torch.from_numpy(probe.astype(np.int32)).cuda(), registered=True, quantity=1, now_ns=now, want=("allowed", "remaining", "reset_after_ns"))
+    torch.cuda.synchronize()
+    assert np.array_equal(res.allowed.cpu().numpy(), ref.allowed) and np.array_equal(res.remaining.cpu().numpy(), ref.remaining)
+    assert np.array_equal(res.reset_after_ns.cpu().numpy(), ref.reset_after_ns)
     assert eng.selfcheck() == 0
     eng.close()
     hot = "range path, hot slots peeled"

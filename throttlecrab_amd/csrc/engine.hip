@@ -148,6 +148,7 @@ int engine_alloc(tc_engine* e) {
                 // round 6: hot slots (range_part.hpp)
                 if (const char* d = getenv("TCGPU_HOT")) e->hot.on = atoi(d) != 0;
                 if (const char* d = getenv("TCGPU_HOT_MIN")) e->hot.heavy_min = (uint32_t)std::max(atoi(d), 2);
+                if (const char* d = getenv("TCGPU_HOT_RANK")) e->hot.rank_on = atoi(d) != 0;
                 if (e->hot.on) {
                     const size_t words = (size_t)ev::HEAVY_SLOTS + 8;
                     TC_HIP(e, hipMalloc(&e->hot.notes_dev, words * sizeof(unsigned long long)));
@@ -158,6 +159,9 @@ int engine_alloc(tc_engine* e) {
                     e->hot.notes_host_dev = (unsigned long long*)dv;
                     e->hot.hint_cold_host = e->hot.notes_host + words; // (a line of its own behind the notes)
                     e->hot.hint_cold_dev = e->hot.notes_host_dev + words;
+                    TC_HIP(e, hipMalloc(&e->hot.pend, (rp::HOT_MAX + 1) * sizeof(ev::PendHot)));
+                    TC_HIP(e, hipMemsetAsync(e->hot.pend, 0, (rp::HOT_MAX + 1) * sizeof(ev::PendHot), (hipStream_t)0));
+                    e->hot.done = reinterpret_cast<uint32_t*>(e->hot.pend + rp::HOT_MAX);
                 }
             }
         }
@@ -194,6 +198,11 @@ int engine_alloc(tc_engine* e) {
             TC_HIP(e, hipMalloc(&ss.part_table, tiles * rp::NB_HOT * sizeof(uint32_t)));
             TC_HIP(e, hipMalloc(&ss.hot_dev, sizeof(rp::HotDev)));
             TC_HIP(e, hipMemsetAsync(ss.hot_dev, 0, sizeof(rp::HotDev), (hipStream_t)0));
+            if (e->hot.on && e->hot.rank_on) {
+                TC_HIP(e, hipMalloc(&ss.hot_info, std::min<uint64_t>(mb, e->range_max_n) * sizeof(uint32_t)));
+                TC_HIP(e, hipMalloc(&ss.hot_P, tiles * rp::HOT_MAX * sizeof(uint32_t)));
+                TC_HIP(e, hipMalloc(&ss.hot_n, (rp::HOT_MAX + 8) * sizeof(uint32_t)));
+            }
         }
         TC_HIP(e, hipMalloc(&ss.ws, words * sizeof(uint32_t)));
         TC_HIP(e, hipMemsetAsync(ss.ws, 0, words * sizeof(uint32_t), (hipStream_t)0));
@@ -504,7 +513,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.part_table, ss.hot_dev, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.part_table, ss.hot_dev, ss.hot_info, ss.hot_P, ss.hot_n, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
@@ -525,6 +534,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
     if (e->hot.notes_host) (void)hipHostFree(e->hot.notes_host);
     if (e->hot.notes_dev) (void)hipFree(e->hot.notes_dev);
+    if (e->hot.pend) (void)hipFree(e->hot.pend);
     if (e->route_l0_done) (void)hipEventDestroy(e->route_l0_done);
     for (uint32_t k = 0; k < e->debug_fillers; ++k) {
         (void)hipStreamSynchronize(e->debug_filler[k]);

@@ -71,16 +71,20 @@ struct Params {
 
 // Which slots are HOT?  The grouping wants to know (range_part.hpp: a slot that takes thousands of a batch's requests is peeled
 // out of the range partition), the host decides, and the evaluation is where every run's length is in a register anyway: the
-// lane holding the LAST request of a run of at least heavy_min requests leaves slot << 32 | min(length, 2^20 - 1) << 12 | tag in
-// a small table in device memory, at a place hashed from the slot and the batch's tag (so that two slots that collide in one
-// batch do not in the next).  One 8-byte store per heavy run, nothing waits, nothing is counted; entries are overwritten at
-// will and validated by their tag on the host, which gets a copy now and then (mk::k_heavy_publish).
-constexpr uint32_t HEAVY_BITS = 12, HEAVY_SLOTS = 1u << HEAVY_BITS;
+// lane holding the LAST request of a run of at least heavy_min requests notes min(length, 2^20 - 1) << 44 | tag << 32 | slot in a
+// small table in device memory -- with atomicMax, at TWO places hashed from the slot (one in each half of the table): where two
+// slots meet, the longer run stays, so the heaviest slots of a stream are never the ones that get lost (a first version stored
+// plainly at one place hashed from slot and batch: every copy missed one of the eight heaviest keys of a Zipf stream now and
+// then, and the batch grouped without it paid k_finish's pass through global memory).  Two atomics per heavy run, nothing
+// waits.  mk::k_heavy_publish copies the table to pinned host memory now and then and clears it: a copy holds the longest
+// runs since the one before.
+constexpr uint32_t HEAVY_BITS = 12, HEAVY_HALF = 1u << HEAVY_BITS, HEAVY_SLOTS = 2u * HEAVY_HALF;
 constexpr uint32_t HEAVY_TAG_BITS = 12, HEAVY_LEN_MAX = (1u << 20) - 1u;
 __device__ __forceinline__ void heavy_note(const Params& p, uint32_t slot, uint32_t len) {
-    const uint32_t at = ((slot * 0x9E3779B1u) ^ (p.heavy_tag * 0x85EBCA6Bu)) >> (32 - HEAVY_BITS);
-    p.heavy[at] = ((unsigned long long)slot << 32) | ((unsigned long long)(len < HEAVY_LEN_MAX ? len : HEAVY_LEN_MAX) << HEAVY_TAG_BITS) |
-                  (p.heavy_tag & ((1u << HEAVY_TAG_BITS) - 1u));
+    const unsigned long long v = ((unsigned long long)(len < HEAVY_LEN_MAX ? len : HEAVY_LEN_MAX) << 44) |
+                                 ((unsigned long long)(p.heavy_tag & ((1u << HEAVY_TAG_BITS) - 1u)) << 32) | slot;
+    atomicMax(&p.heavy[(slot * 0x9E3779B1u) >> (32 - HEAVY_BITS)], v);
+    atomicMax(&p.heavy[HEAVY_HALF + ((slot * 0x85EBCA6Bu + 0x27D4EB2Fu) >> (32 - HEAVY_BITS))], v);
 }
 
 // First position of the run of `slot` that position k belongs to, given that position k - 1 holds the same slot.  Gallops back
@@ -530,11 +534,13 @@ template <bool FULL, bool DIRECT, int ITEMS, bool FIXED, bool LEAN, int BS = BLO
 __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t* __restrict__ sorted,
                                                  PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
                                                  uint32_t* __restrict__ loaded, uint32_t seq,
-                                                 const uint32_t* __restrict__ gate, uint32_t gate_min, uint32_t* hint = nullptr) {
+                                                 const uint32_t* __restrict__ gate, uint32_t gate_min, uint32_t* hint, uint32_t bid, uint32_t n,
+                                                 uint32_t grid) {
+    // (bid, n, grid: this block's number among the `grid` blocks of the sorted part and the part's length -- blockIdx.x, p.n and
+    // gridDim.x unless the kernel also runs the hot role, k_eval_sorted_lean)
     if (gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min) return; // this batch took the bucket path (bucket_path.hpp)
-    const uint32_t n = p.n;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t block_start = blockIdx.x * (BS * ITEMS);
+    const uint32_t block_start = bid * (BS * ITEMS);
     const bool class_by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS); // uniform over the grid
     const RateClass rc_batch = p.classes[p.uniform_class];                                // (class 0 if there is none)
     uint32_t kk[ITEMS];
@@ -784,25 +790,161 @@ __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t
         }
         wave_denied_add(p, slot, denied_here[j]);
     }
-    block_count3<BS>(na, nd, ne, p.counters, (LEAN && blockIdx.x == gridDim.x / 2) ? hint : nullptr);
+    block_count3<BS>(na, nd, ne, p.counters, (LEAN && bid == grid / 2) ? hint : nullptr);
 }
 
 template <bool FULL, bool DIRECT, int ITEMS, bool FIXED>
 __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t* __restrict__ sorted, PendEntry* __restrict__ pend,
                                                        uint32_t* __restrict__ pend_count, uint32_t* __restrict__ loaded, uint32_t seq,
                                                        const uint32_t* __restrict__ gate, uint32_t gate_min) {
-    eval_sorted_body<FULL, DIRECT, ITEMS, FIXED, false>(p, sorted, pend, pend_count, loaded, seq, gate, gate_min);
+    eval_sorted_body<FULL, DIRECT, ITEMS, FIXED, false>(p, sorted, pend, pend_count, loaded, seq, gate, gate_min, nullptr, blockIdx.x, p.n, gridDim.x);
 }
 // decisions only, direct stores, only the `allowed` byte column asked for: at most 80 scalar and 64 vector registers,
 // so that EIGHT blocks fit a CU (k_eval_sorted's 106 SGPRs admit six) -- the kernel waits on random memory, and what
 // hides that is resident waves
 // (ITEMS = 4: half as many blocks of twice the work, four per CU -- what skewed streams run fastest on; 512-thread blocks, the
 // same waves per CU in half as many blocks, measured slower on both streams: profiles/r04_v11_eval_block_ab.txt)
+// Round 6, the HOT ROLE (range_part.hpp, PART_RANK): a request of a hot slot is not grouped at all.  What the closed form of a
+// run needs of it is its rank among its slot's requests -- hot_P[tile][id] (requests of the slot in earlier tiles: the scan in
+// rs::k_finish) + its rank inside its tile (the partition left id << 16 | rank in info[i]) -- the run's length n[id], and the
+// slot's cell.  The first blocks of the lean kernel's grid walk the batch in REQUEST order: info and the decision bytes are
+// coalesced, the cells of at most 512 slots stay in the caches.  No lane may store a hot slot's new cell while lanes of other
+// blocks still read the old one, and nothing orders those blocks: the run's owner parks the cell in pend[id] (flag = seq), every
+// hot-role block counts itself done, and the LAST of them stores what was parked (no hot-role lane is left to read a cell by
+// then; the sorted part's blocks never touch a hot slot).  A first version committed in a one-block kernel behind this one:
+// exact, and a second hand-over on the engine's stream per batch -- 59 us per step where this form takes 3x.
+struct __attribute__((aligned(32))) PendHot {
+    Cell cell;
+    uint32_t flag;
+    uint32_t pad[3];
+};
+struct HotEval {
+    const uint32_t* info;    // nullptr: no hot role, the whole grid is the sorted part
+    const uint32_t* prefix;  // hot_P
+    const uint32_t* n;       // [ids] requests per hot id in this batch; [ids]: the sorted part's length
+    const uint32_t* slot;    // hot id -> slot
+    PendHot* pend;
+    uint32_t* done;          // hot-role blocks of this launch that have finished (zero between launches)
+    uint32_t ids, tile_shift, hot_blocks;
+};
+constexpr int hot_items(bool fixed) { return fixed ? 4 : 2; } // request positions per lane of a hot-role block (the 16-byte layout: fewer, or the kernel's 64 vector registers spill)
+
+template <bool FIXED>
+__device__ __forceinline__ void eval_hot_role(const Params& p, const HotEval& he, uint32_t seq, uint32_t* hint) {
+    constexpr int HOT_ITEMS = hot_items(FIXED);
+    const uint32_t n = p.n;
+    const bool class_by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS);
+    const RateClass rc_batch = p.classes[p.uniform_class];
+    uint32_t pos[HOT_ITEMS], info[HOT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < HOT_ITEMS; ++j) {
+        pos[j] = blockIdx.x * (BLOCK * HOT_ITEMS) + j * BLOCK + threadIdx.x;
+        info[j] = he.info[min(pos[j], n - 1u)];
+    }
+    uint32_t rk[HOT_ITEMS], len[HOT_ITEMS], slot[HOT_ITEMS], rid[HOT_ITEMS];
+    bool on[HOT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < HOT_ITEMS; ++j) {
+        on[j] = pos[j] < n && info[j] != 0xFFFFFFFFu;
+        const uint32_t id = on[j] ? info[j] >> 16 : 0u;
+        rk[j] = he.prefix[(size_t)(pos[j] >> he.tile_shift) * he.ids + id];
+        len[j] = he.n[id];
+        slot[j] = he.slot[id];
+        rid[j] = 0;
+    }
+    Cell cell[HOT_ITEMS];
+#pragma unroll
+    for (int j = 0; j < HOT_ITEMS; ++j) {
+        if (!on[j]) slot[j] = 0u;
+        if (class_by_slot) rid[j] = (uint32_t)p.rate_id[slot[j]];
+        cell[j] = load_raw<FIXED>(p, slot[j]);
+    }
+    uint32_t na = 0, nd = 0, ne = 0;
+#pragma unroll
+    for (int j = 0; j < HOT_ITEMS; ++j) {
+        if (!on[j]) continue;
+        const uint32_t r = rk[j] + (info[j] & 0xFFFFu), id = info[j] >> 16;
+        const bool is_last = r + 1u == len[j];
+        if (is_last && p.heavy_min != 0u && len[j] >= p.heavy_min) heavy_note(p, slot[j], len[j]);
+        const RateClass rc = class_by_slot ? p.classes[rid[j]] : rc_batch;
+        const Req rq = make_req_rc(p, slot[j], rc);
+        Decision d;
+        d.allowed = false;
+        d.remaining = d.reset_after = d.retry_after = 0;
+        if (rq.status != tc::ST_OK) {
+            ne += 1;
+            put_out<true>(p, pos[j], rq, d);
+            continue;
+        }
+        Cell c = FIXED ? tc::fixed_cell(cell[j].tat, rq.dvt) : cell[j];
+        const Decision d0 = tc::gcra_step<false>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
+        bool owner = false;
+        Cell v = c;
+        if (!d0.allowed) {
+            nd += 1; // request 0 denied => state untouched => every request of the run equals request 0
+            put_out<true>(p, pos[j], rq, d0);
+        } else if (len[j] == 1u) {
+            na += 1;
+            put_out<true>(p, pos[j], rq, d0);
+            owner = true;
+        } else {
+            // (the same closed form as the sorted part: tc::run_lite; the host proved every run of this batch regular)
+            const tc::RunLite f = tc::run_lite(c, rq.ei, rq.dvt, rq.q, rq.now);
+            if (!f.regular) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]);
+            const bool ok_r = r == 0u || tc::rank_allowed(f, r);
+            owner = ok_r && (is_last || !tc::rank_allowed(f, r + 1u));
+            if (owner && r != 0u) v = tc::cell_after(f.new0 + (int64_t)r * f.inc, rq.dvt, rq.now);
+            d.allowed = ok_r;
+            na += ok_r;
+            nd += !ok_r;
+            put_out<true>(p, pos[j], rq, r == 0u ? d0 : d);
+        }
+        if (owner) { // (agent-scope stores, like the general kernel's chain records: performed at the device's scope, no cache left to flush)
+            PendHot* o = &he.pend[id];
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&o->cell.tat), (unsigned long long)v.tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&o->cell.expiry), (unsigned long long)v.expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&o->flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    block_count3<BLOCK>(na, nd, ne, p.counters, nullptr);
+    (void)hint;
+    // the last hot-role block to get here commits the parked cells
+    __shared__ uint32_t s_last;
+    // this block's parked cells have been performed at the device's scope before it counts itself done  (NOT __threadfence():
+    // a release at agent scope writes the whole L2 of the XCD back -- once per block that was 173 us per batch)
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __builtin_amdgcn_s_waitcnt(0);
+    __atomic_signal_fence(__ATOMIC_SEQ_CST);
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(he.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == he.hot_blocks ? 1u : 0u;
+    __syncthreads();
+    if (s_last == 0u) return;
+    for (uint32_t id = threadIdx.x; id < he.ids; id += BLOCK) {
+        if (__hip_atomic_load(&he.pend[id].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) continue;
+        Cell c;
+        c.tat = (int64_t)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&he.pend[id].cell.tat), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c.expiry = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&he.pend[id].cell.expiry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        store_state<FIXED>(p, he.slot[id], c);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(he.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int ITEMS, bool FIXED, int BS = BLOCK>
 __global__ __launch_bounds__(BS, (ITEMS <= 2 ? TC_EVAL_LEAN_WAVES : TC_EVAL_LEAN_WAVES / 2)) __attribute__((amdgpu_num_sgpr(80))) void k_eval_sorted_lean(
     Params p, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ loaded, uint32_t seq, const uint32_t* __restrict__ gate,
-    uint32_t gate_min, uint32_t* hint) {
-    eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint);
+    uint32_t gate_min, uint32_t* hint, HotEval he) {
+    if (he.info != nullptr) { // (grid-uniform: BS == BLOCK when the kernel has a hot role)
+        if (blockIdx.x < he.hot_blocks) {
+            eval_hot_role<FIXED>(p, he, seq, hint);
+            return;
+        }
+        const uint32_t nc = he.n[he.ids]; // requests the ranges hold
+        if ((blockIdx.x - he.hot_blocks) * (uint32_t)(BS * ITEMS) >= nc) return;
+        eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, blockIdx.x - he.hot_blocks, nc,
+                                                               (nc + BS * ITEMS - 1) / (BS * ITEMS));
+        return;
+    }
+    eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, blockIdx.x, p.n, gridDim.x);
 }
 
 // ---------------------------------------------------------------------------

@@ -546,12 +546,15 @@ static __global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, c
     }
 }
 
-// Round 6: the evaluation's notes on heavy runs (ev::heavy_note) -> pinned host memory, the batch tag of the copy behind them.
-// One block; the notes are 8-byte words that the host validates one by one, so a copy taken while an evaluation is writing is as
-// good as any.  Enqueued now and then (slots.hip), never waited for.
-static __global__ __launch_bounds__(1024) void k_heavy_publish(unsigned long long* __restrict__ dst, const unsigned long long* __restrict__ src,
+// Round 6: the evaluation's notes on heavy runs (ev::heavy_note) -> pinned host memory, the sequence word of the copy behind them;
+// the table is cleared for the evaluations to come (this kernel runs on the engine's stream, between two of them).  One block.
+// Enqueued now and then (slots.hip), never waited for.
+static __global__ __launch_bounds__(1024) void k_heavy_publish(unsigned long long* __restrict__ dst, unsigned long long* __restrict__ src,
                                                                uint32_t words, unsigned long long seq) {
-    for (uint32_t i = threadIdx.x; i < words; i += 1024) dst[i] = __builtin_nontemporal_load(&src[i]);
+    for (uint32_t i = threadIdx.x; i < words; i += 1024) {
+        dst[i] = src[i];
+        src[i] = 0ull;
+    }
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&dst[words], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -590,7 +590,8 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                                                                const uint32_t* __restrict__ totals, uint32_t* __restrict__ totals_next, uint32_t n,
                                                                uint32_t tiles, uint32_t tile_len, uint32_t msd_mul, int sub_passes,
                                                                unsigned long long* __restrict__ range_hint, uint32_t stride,
-                                                               uint32_t totals_words) {
+                                                               uint32_t totals_words, uint32_t* __restrict__ hot_P, uint32_t* __restrict__ hot_n,
+                                                               uint32_t hot_ids) {
     __shared__ uint32_t s_idx[FIN_CAP];            // request index of position p (never moves)
     __shared__ uint32_t s_u[FIN_UNION_WORDS];      // the two ways of sorting a range share this
     // ballot path: offset inside the range << FIN_POS_BITS | p in the order reached so far (x2), per-wave digit counters, digit totals / starts
@@ -609,6 +610,37 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
     __shared__ uint32_t s_base;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t r = blockIdx.x;
+    if (r >= (uint32_t)NRANGE) {
+        // Round 6, the rank form (range_part.hpp, PART_RANK): blocks behind the ranges' scan the hot ids' columns of the table --
+        // hot_P[tile * hot_ids + id] = requests of hot id `id` in the tiles before `tile`, hot_n[id] = its requests in the
+        // batch: what the evaluation's hot role adds to a request's rank inside its tile.  32 ids x 16 stretches of tiles per
+        // block, the table's words of 32 neighbouring ids read and written side by side.
+        uint32_t (*s_seg)[32] = reinterpret_cast<uint32_t (*)[32]>(s_idx);
+        const uint32_t hl = threadIdx.x & 31u, seg = threadIdx.x >> 5, h = (r - (uint32_t)NRANGE) * 32u + hl;
+        const uint32_t per = (tiles + 15u) / 16u, t0 = min(seg * per, tiles), t1 = min(t0 + per, tiles);
+        uint32_t sum = 0;
+        if (h < hot_ids) {
+#pragma unroll 8
+            for (uint32_t t = t0; t < t1; ++t) sum += table[(size_t)t * stride + NRANGE + h] >> 16;
+        }
+        s_seg[seg][hl] = sum;
+        __syncthreads();
+        uint32_t at = 0, total = 0;
+        for (uint32_t q = 0; q < 16u; ++q) {
+            const uint32_t v = s_seg[q][hl];
+            if (q < seg) at += v;
+            total += v;
+        }
+        if (h < hot_ids) {
+#pragma unroll 8
+            for (uint32_t t = t0; t < t1; ++t) {
+                hot_P[(size_t)t * hot_ids + h] = at;
+                at += table[(size_t)t * stride + NRANGE + h] >> 16;
+            }
+            if (seg == 0u) hot_n[h] = total;
+        }
+        return;
+    }
     RS_STAMP(1, 0, 128);
     const uint32_t lo = range_lo(r, msd_mul);
     const uint32_t width = range_lo(r + 1u, msd_mul) - lo; // slots of my range (every offset inside it is below this)
@@ -669,6 +701,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 m0 = max(m0, s_part[FIN_WAVES + q]);
             }
             s_base = b0;
+            if (r == NRANGE - 1 && hot_n != nullptr) hot_n[hot_ids] = b0 + c; // (rank form: the requests the ranges hold = where the evaluation's sorted part ends)
             if (r == NRANGE - 1 && range_hint != nullptr)
                 __hip_atomic_store(range_hint, ((unsigned long long)n << 32) | m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

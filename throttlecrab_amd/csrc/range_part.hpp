@@ -85,11 +85,18 @@ static __global__ __launch_bounds__(PT_THREADS) void k_hot_install(HotList l, Ho
 // table[tile * stride + b] = (elements of bucket b in the tile) << 16 | where they start inside the tile;
 // totals[b] += elements of bucket b (zero on entry: rs::k_finish of the set's previous batch cleared it).
 // `fill` (TC_B_OUTPUTS_IDLE batches): the decision bytes, preset here (rs::k_hist).
-template <bool HOT>
+// MODE: PART_PLAIN (ranges only), PART_GATHER (hot slots in buckets of their own, written back with the tile: k_hot_gather
+// follows), PART_RANK (hot slots ranked but NOT written back: request i of a hot slot leaves hot id << 16 | rank inside its tile
+// in hot_info[i], every other request HOT_NONE; the tile's cold requests are written back alone -- for the evaluation's hot role,
+// eval_kernels.hpp, which needs a hot request's rank among its slot's requests and nothing else)
+constexpr int PART_PLAIN = 0, PART_GATHER = 1, PART_RANK = 2;
+constexpr uint32_t HOT_NONE = 0xFFFFFFFFu;
+template <int MODE>
 __global__ __launch_bounds__(PT_THREADS) void k_tile_part(const uint32_t* __restrict__ slot_in, uint64_t* __restrict__ elem_out,
                                                           uint32_t* __restrict__ table, uint32_t stride, uint32_t* __restrict__ totals, uint32_t n,
                                                           uint32_t cap, uint32_t msd_mul, uint8_t* __restrict__ fill, uint32_t fill_value,
-                                                          const HotDev* __restrict__ hot) {
+                                                          const HotDev* __restrict__ hot, uint32_t* __restrict__ hot_info) {
+    constexpr bool HOT = MODE != PART_PLAIN;
     constexpr uint32_t NB = HOT ? NB_HOT : NR;
     constexpr int DB = HOT ? 10 : 9; // bits of a bucket number
     static_assert(NB <= (1u << DB) && NB <= 2u * PT_THREADS, "bucket numbers fit DB bits; two buckets per thread at most");
@@ -204,7 +211,9 @@ __global__ __launch_bounds__(PT_THREADS) void k_tile_part(const uint32_t* __rest
                 const uint32_t start = (u == 0 ? carry0 : total0 + carry1) + incl[u] - run[u];
                 s_tstart[b] = start;
                 table[(size_t)tile * stride + b] = (run[u] << 16) | start;
-                if (run[u]) atomicAdd(&totals[b], run[u]); // the buckets' sizes over the whole batch; nothing here waits for it
+                // the buckets' sizes over the whole batch; nothing here waits for it  (PART_RANK: the hot ids' sizes come out of
+                // rs::k_finish's scan of the table)
+                if (run[u] && (MODE != PART_RANK || b < NR)) atomicAdd(&totals[b], run[u]);
             }
         }
     }
@@ -212,11 +221,20 @@ __global__ __launch_bounds__(PT_THREADS) void k_tile_part(const uint32_t* __rest
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; ++j) {
         const uint32_t pos = wbase + j * 64;
-        if (pos < n) s_elem[s_tstart[dig[j]] + (uint32_t)s_cnt[wave][dig[j]] + rank[j]] = ((uint64_t)key[j] << 32) | pos;
+        if (pos < n) {
+            const uint32_t in_bucket = (uint32_t)s_cnt[wave][dig[j]] + rank[j];
+            if (MODE == PART_RANK) {
+                const bool is_hot = dig[j] >= NR;
+                hot_info[pos] = is_hot ? ((dig[j] - NR) << 16) | in_bucket : HOT_NONE;
+                if (is_hot) continue;
+            }
+            s_elem[s_tstart[dig[j]] + in_bucket] = ((uint64_t)key[j] << 32) | pos;
+        }
     }
     __syncthreads();
     const uint32_t tile_first = tile * PT_TILE;
-    const uint32_t nvalid = (n - tile_first) < PT_TILE ? (n - tile_first) : PT_TILE;
+    uint32_t nvalid = (n - tile_first) < PT_TILE ? (n - tile_first) : PT_TILE;
+    if (MODE == PART_RANK) nvalid = s_tstart[NR]; // (the cold buckets come first: the tile's cold requests are [0, start of hot id 0))
 #pragma unroll
     for (int j = 0; j < PT_ITEMS; ++j) {
         const uint32_t i = j * PT_THREADS + threadIdx.x;

@@ -246,24 +246,23 @@ static bool outputs_back_in_one_launch(tc_engine* e, const tc_batch& b, hipStrea
 }
 
 // Round 6: the hot list (range_part.hpp).  The evaluations note every run of at least hot.heavy_min requests in a small device
-// table, a copy of which reaches pinned memory now and then; whenever a NEW copy has arrived the list is made afresh from the
-// notes of the last HOT_NOTE_AGE evaluations (two copies' worth: a stream that stops being skewed empties the list soon): the (up to) rp::HOT_MAX slots with the longest runs, heaviest first (the order the gather's
+// table, a copy of which reaches pinned memory now and then (the longest runs since the copy before: the table is cleared with
+// every copy, so a stream that stops being skewed empties the list with the next one); whenever a NEW copy has arrived the list
+// is made afresh from it: the (up to) rp::HOT_MAX slots with the longest runs, heaviest first (the order the gather's
 // units are cut for).  Never waits; a stream without heavy runs leaves the list empty.
-constexpr uint32_t HOT_NOTE_AGE = 16;
 static void hot_refresh(tc_engine* e) {
     tc_engine::Hot& h = e->hot;
     if (!h.on || !h.notes_host) return;
     const unsigned long long seq = *(volatile unsigned long long*)(h.notes_host + ev::HEAVY_SLOTS);
     if (seq == h.seq_seen) return;
     h.seq_seen = seq;
-    const uint32_t tag_mask = (1u << ev::HEAVY_TAG_BITS) - 1u, tag_now = (uint32_t)seq & tag_mask;
-    // one note per slot (the longest run), through a scratch hash: 4 096 notes at most, no sort of them all (this runs on the
+    // one note per slot (the longest run), through a scratch hash: 8 192 notes at most, no sort of them all (this runs on the
     // caller's thread between two enqueues: a first version sorted the notes twice and cost the pipeline 0.3 ms every 8th batch)
     constexpr uint32_t SCR = 2u * ev::HEAVY_SLOTS;
     if (h.scratch.size() != SCR) h.scratch.assign(SCR, 0ull);
     else std::fill(h.scratch.begin(), h.scratch.end(), 0ull);
     auto probe = [&](uint32_t slot) -> unsigned long long& { // entry: (slot + 1) << 32 | length
-        uint32_t at = (slot * 0x9E3779B1u) >> (32 - (ev::HEAVY_BITS + 1));
+        uint32_t at = (slot * 0x9E3779B1u) >> (32 - (ev::HEAVY_BITS + 2));
         while (h.scratch[at] != 0ull && (uint32_t)(h.scratch[at] >> 32) != slot + 1u) at = (at + 1u) & (SCR - 1u);
         return h.scratch[at];
     };
@@ -271,8 +270,8 @@ static void hot_refresh(tc_engine* e) {
     found.clear();
     for (uint32_t i = 0; i < ev::HEAVY_SLOTS; ++i) {
         const unsigned long long v = ((volatile unsigned long long*)h.notes_host)[i];
-        const uint32_t len = (uint32_t)(v >> ev::HEAVY_TAG_BITS) & ev::HEAVY_LEN_MAX, slot = (uint32_t)(v >> 32);
-        if (len < h.heavy_min || slot >= e->capacity || ((tag_now - (uint32_t)v) & tag_mask) >= HOT_NOTE_AGE) continue;
+        const uint32_t len = (uint32_t)(v >> 44), slot = (uint32_t)v;
+        if (len < h.heavy_min || slot >= e->capacity) continue;
         unsigned long long& en = probe(slot);
         if ((uint32_t)en < len) en = ((unsigned long long)(slot + 1u) << 32) | len;
     }
@@ -318,7 +317,7 @@ static void hot_refresh(tc_engine* e) {
 // stream, which every grouping mirrors into pinned memory (never waited for).  No hint yet, a hint that predicts a range beyond
 // what a block finishes in LDS and no hot list that could explain it, or a batch too large: the LSD passes.  A wrong guess costs
 // time, not correctness (k_finish sorts an oversized range through global memory).
-enum { GROUP_LSD = 0, GROUP_RANGE = 1, GROUP_RANGE_HOT = 2 };
+enum { GROUP_LSD = 0, GROUP_RANGE = 1, GROUP_RANGE_HOT = 2, GROUP_RANGE_RANK = 3 }; // (RANK: the hot form of a lean batch, chosen by the caller: the hot slots' requests are ranked, not gathered)
 static int range_applies(tc_engine* e, uint32_t n, bool piped, bool hot_allowed) {
     if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return GROUP_LSD;
     hot_refresh(e);
@@ -371,7 +370,7 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     if (ranged) {
         // round 6 (range_part.hpp): tiles of 4 096 requests on 1 024 threads, partitioned in place into elem_b by key range -- and,
         // in the hot form, by hot id: those buckets are gathered behind the ranges' elements, every range is finished into elem_a
-        const bool hotm = ranged == GROUP_RANGE_HOT;
+        const bool hotm = ranged != GROUP_RANGE, rankm = ranged == GROUP_RANGE_RANK;
         const uint32_t ptiles = (n + rp::PT_TILE - 1) / rp::PT_TILE, stride = hotm ? rp::NB_HOT : rp::NR;
         uint32_t* totals = ss.range_totals + (size_t)ss.range_parity * rp::NB_HOT;         // zero: cleared by the finish of the set's previous batch
         uint32_t* totals_next = ss.range_totals + (size_t)(ss.range_parity ^ 1u) * rp::NB_HOT;
@@ -384,24 +383,28 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
             ss.hot_version = e->hot.version;
         }
         prof_begin_m(e, TC_STAGE_SORT, s);
-        if (hotm) TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<true>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap,
-                              e->range_mul, fill, fill_value, (const rp::HotDev*)ss.hot_dev);
-        else TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<false>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap,
-                         e->range_mul, fill, fill_value, (const rp::HotDev*)nullptr);
+#define TC_PART(MODE, HOTP, INFO) \
+    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<MODE>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap, \
+                e->range_mul, fill, fill_value, (const rp::HotDev*)(HOTP), (uint32_t*)(INFO))
+        if (rankm) TC_PART(rp::PART_RANK, ss.hot_dev, ss.hot_info);
+        else if (hotm) TC_PART(rp::PART_GATHER, ss.hot_dev, nullptr);
+        else TC_PART(rp::PART_PLAIN, nullptr, nullptr);
+#undef TC_PART
         prof_end_m(e, s);
-        if (hotm) {
+        if (hotm && !rankm) {
             const uint32_t hb = rp::hg_grid(n, (uint32_t)std::min<size_t>(e->hot.slots.size(), rp::HOT_MAX), rp::hg_group(ptiles));
             prof_begin_m(e, TC_STAGE_SORT, s);
             TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, rp::k_hot_gather, dim3(hb), dim3(rp::HG_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)ss.part_table, stride,
                         (const uint32_t*)totals, bufs[0], ptiles, rp::PT_TILE, (const rp::HotDev*)ss.hot_dev);
             prof_end_m(e, s);
-            e->hot.batches_hot++;
         }
+        if (hotm) e->hot.batches_hot++;
         prof_begin_m(e, TC_STAGE_SORT, s);
         hipEvent_t stop = e->prof_on ? nullptr : stop_last;
-        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::NRANGE), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)ss.part_table, bufs[0],
-                    ss.elem_c, (const uint32_t*)totals, totals_next, n, ptiles, rp::PT_TILE, e->range_mul, e->range_sub_passes, hotm ? e->hot.hint_cold_dev : hint, stride,
-                    rp::NB_HOT);
+        // (rank form: HOT_MAX / 32 more blocks scan the hot ids' columns of the table)
+        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::NRANGE + (rankm ? rp::HOT_MAX / 32u : 0u)), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1],
+                    (const uint32_t*)ss.part_table, bufs[0], ss.elem_c, (const uint32_t*)totals, totals_next, n, ptiles, rp::PT_TILE, e->range_mul, e->range_sub_passes,
+                    hotm ? e->hot.hint_cold_dev : hint, stride, rp::NB_HOT, rankm ? ss.hot_P : (uint32_t*)nullptr, rankm ? ss.hot_n : (uint32_t*)nullptr, rp::HOT_MAX);
         prof_end_m(e, s);
         return bufs[0];
     }
@@ -478,7 +481,10 @@ static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, u
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
     if (lean) {
         if constexpr (ITEMS <= 4) {
-            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
+            const HotEval he = e->hot.he;
+            // (rank form: the first hot_blocks blocks walk the batch in request order for the hot slots' requests)
+            const dim3 lgrid(grid.x + (he.info ? he.hot_blocks : 0u));
+            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), lgrid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev, he);
             return;
         }
     }
@@ -721,7 +727,11 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
         // batches are not partitioned at all (the sort path alone is always correct), then the path is tried again.
         // (round 4: a batch the range path takes is grouped by it alone, in order as well: two grouping launches and the
         // evaluation, nothing enqueued twice)
-        const int ranged = range_applies(e, n, piped, !p.order);
+        int ranged = range_applies(e, n, piped, !p.order);
+        // a lean batch in the hot form: its hot slots' requests are ranked where they stand, not gathered (eval_kernels.hpp, the
+        // hot role); per-slot denial counters want a slot's requests side by side: the gather form
+        e->hot.he = HotEval{};
+        if (ranged == GROUP_RANGE_HOT && e->hot.rank_on && uniform && direct && lean_applies(e, full, direct, piped, p) && !p.denied) ranged = GROUP_RANGE_RANK;
         // The range hint is written by the grouping kernels of the sort paths (k_hist's range row, k_finish).  An in-order batch
         // on the bucket path leaves none: an engine that only ever sees in-order batches would stay on the bucket path for
         // good -- 84 us per 1 Mi batch where the range path takes 63, found by tools/batch_sizes.py; bench.py's in-order
@@ -744,7 +754,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             }
         }
         const bool bucketed = eligible;
-        e->last_grouping_path = ranged == GROUP_RANGE_HOT ? 5u : (ranged ? 1u : (bucketed ? 3u : 2u)); // (bucketed: decided on the device in the end -- tc_engine_info says what was enqueued)
+        e->last_grouping_path = ranged >= GROUP_RANGE_HOT ? 5u : (ranged ? 1u : (bucketed ? 3u : 2u)); // (bucketed: decided on the device in the end -- tc_engine_info says what was enqueued)
         // Grouped rows + a bitmask of them, every run regular: the evaluation's waves hold 64 consecutive rows each and
         // pack their decisions with one ballot (no byte column, no k_pack_bits launch).
         if (b.allowed_bits && p.order && direct) {
@@ -807,10 +817,27 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             }
             // (direct: the evaluation is the last reader of the set -- `consumed` can ride on its completion signal)
             consumed_rides = direct && e->stop_events && !e->prof_on;
+            const bool rankm = ranged == GROUP_RANGE_RANK;
+            if (rankm) {
+                HotEval& he = e->hot.he;
+                he.info = ss.hot_info;
+                he.prefix = ss.hot_P;
+                he.n = ss.hot_n;
+                he.slot = ss.hot_dev->slot; // (an address in device memory: nothing is read here)
+                he.pend = e->hot.pend;
+                he.done = e->hot.done;
+                he.ids = rp::HOT_MAX;
+                he.tile_shift = 12;
+                static_assert(rp::PT_TILE == 1u << 12, "the hot role finds a request's tile by a shift");
+                he.hot_blocks = (n + BLOCK * hot_items(e->fixed) - 1) / (BLOCK * hot_items(e->fixed));
+            }
             // (slim: the stream looked skewed to the range hint -- not merely "no hint yet" or a batch too large for the path)
-            const bool slim = piped && e->range_ok && (ranged == GROUP_RANGE_HOT || (!ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n));
+            // (rank form: what is left in the sorted part is the stream's uniform tail, and the hot role's blocks want the CU's eight
+            // block slots beside it: 2 positions per lane -- 36.6 us per Zipf batch against 39.2 with 4, profiles/r06_v12_zipf_items_ab.txt)
+            const bool slim = piped && e->range_ok && ranged != GROUP_RANGE_RANK && (ranged >= GROUP_RANGE_HOT || (!ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n));
             launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr, slim);
             prof_end_m(e, s);
+            e->hot.he = HotEval{};
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
                 hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells, e->tat8);
@@ -832,7 +859,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             const uint64_t k = ++e->hot.evals;
             if (k <= 4 || ((k & 7u) == 0u && (e->hot.stable_looks < 4u || (k & 31u) == 0u))) { // (a list that has settled is looked at every 32nd batch)
                 const unsigned long long seq = ((unsigned long long)(++e->hot.published) << ev::HEAVY_TAG_BITS) | p.heavy_tag;
-                hipLaunchKernelGGL(mk::k_heavy_publish, dim3(1), dim3(1024), 0, s, e->hot.notes_host_dev, (const unsigned long long*)e->hot.notes_dev, ev::HEAVY_SLOTS, seq);
+                hipLaunchKernelGGL(mk::k_heavy_publish, dim3(1), dim3(1024), 0, s, e->hot.notes_host_dev, e->hot.notes_dev, ev::HEAVY_SLOTS, seq);
             }
         }
         // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream
