@@ -56,10 +56,10 @@ def _run(fixed, general, piped, monkeypatch=None, markers=False, n_keys=200_000,
         assert (got == refs[b].allowed.astype(np.uint8)).all(), f"batch {b}: profiling changed a decision"
     passes = 3 if n_keys >= (1 << 16) else 2
     if hot:
-        # a batch is grouped by the LSD passes (k_hist + 3) until the host has a hot list, then in the hot form: the partition,
-        # the gather unless the batch is lean (the rank form), the finish
+        # a batch is grouped by the LSD passes (k_hist + 3) until the host has a hot list, then in the hot form: the partition
+        # and the finish
         lsd = prof["prep"][1]
-        assert 1 <= lsd < batches and prof["sort"][1] == passes * lsd + (3 if general else 2) * (batches - lsd) and prof["eval"][1] == batches, prof
+        assert 1 <= lsd < batches and prof["sort"][1] == passes * lsd + 2 * (batches - lsd) and prof["eval"][1] == batches, prof
         eng.close()
         return prof
     assert prof["prep"][1] == batches and prof["sort"][1] == passes * batches and prof["eval"][1] == batches, prof
@@ -77,9 +77,8 @@ def test_profiling_counts_every_launch_and_changes_nothing(fixed, general, piped
     _run(fixed, general, piped, monkeypatch)
 
 
-@pytest.mark.parametrize("general", [False, True], ids=["rank_form", "gather_form"])
-def test_profiling_counts_the_hot_forms_launches(general, monkeypatch):
-    _run(True, general, True, monkeypatch, batches=24, hot=True)
+def test_profiling_counts_the_hot_forms_launches(monkeypatch):
+    _run(True, False, True, monkeypatch, batches=24, hot=True)
 
 
 def test_marker_event_fallback(monkeypatch):

@@ -187,9 +187,10 @@ def test_hot_slots_are_peeled_out_of_the_range_partition(kind):
     gathered behind the ranges.  Who is hot comes from the evaluations' notes on long runs, through pinned memory -- so the
     first batches go through the LSD passes, and the engine must say when it changed over.  Every batch exact: decisions only
     (the RANK form: the hot slots' requests are not even gathered, the evaluation's hot role ranks them where they stand and a
-    commit kernel stores the cells it parked -- on both layouts), full results and a timestamp per request (the GATHER form,
-    both evaluation kernels); then the hot keys MOVE (the list is made afresh) and finally the stream turns uniform (the
-    list empties).  The resident state is compared at the end."""
+    last block stores the cells it parked -- on both layouts); batches that ask for full results or carry a timestamp per
+    request stay on the LSD passes (a gather form for them was built, measured slower and removed: range_part.hpp); then the
+    hot keys MOVE (the list is made afresh) and finally the stream turns uniform (the list empties).  The resident state is
+    compared at the end."""
     general, lean = kind == "timestamp_per_request", kind.startswith("decisions_only")
     import torch
 
@@ -234,6 +235,9 @@ def test_hot_slots_are_peeled_out_of_the_range_partition(kind):
     assert eng.selfcheck() == 0
     eng.close()
     hot = "range path, hot slots peeled"
-    assert paths[:30].count(hot) >= 15 and paths[30:60].count(hot) >= 10, paths
+    if lean:
+        assert paths[:30].count(hot) >= 15 and paths[30:60].count(hot) >= 10, paths
+        assert info["hot_batches"] >= 25
+    else:
+        assert paths[:60].count(hot) == 0 and paths[:60].count("LSD passes") >= 55, paths
     assert paths[-8:] == ["range path"] * 8 and info["hot_slots"] == 0, (paths[-20:], info)
-    assert info["hot_batches"] >= 25

@@ -826,6 +826,8 @@ struct HotEval {
     PendHot* pend;
     uint32_t* done;          // hot-role blocks of this launch that have finished (zero between launches)
     uint32_t ids, tile_shift, hot_blocks;
+    uint32_t cold_grid;      // blocks of the sorted part (the host's estimate of what is left in the ranges: a block takes more than one
+                             // stretch of positions if it was too low)
 };
 constexpr int hot_items(bool fixed) { return fixed ? 4 : 2; } // request positions per lane of a hot-role block (the 16-byte layout: fewer, or the kernel's 64 vector registers spill)
 
@@ -938,10 +940,16 @@ __global__ __launch_bounds__(BS, (ITEMS <= 2 ? TC_EVAL_LEAN_WAVES : TC_EVAL_LEAN
             eval_hot_role<FIXED>(p, he, seq, hint);
             return;
         }
-        const uint32_t nc = he.n[he.ids]; // requests the ranges hold
-        if ((blockIdx.x - he.hot_blocks) * (uint32_t)(BS * ITEMS) >= nc) return;
-        eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, blockIdx.x - he.hot_blocks, nc,
-                                                               (nc + BS * ITEMS - 1) / (BS * ITEMS));
+        // The sorted part: the requests the ranges hold.  How many they are is known on the device only; the host sized this part
+        // of the grid by a recent batch's count (a grid of 3 072 blocks of which 1 200 leave at once lengthened the hand-over
+        // to the next kernel on the stream: tools/gapbench).  A block takes the stretches bid, bid + cold_grid, ...: stretches
+        // are still started in position order by blocks dispatched in order, which is all the direct stores' waits rely on.
+        const uint32_t nc = he.n[he.ids];
+        for (uint32_t bid = blockIdx.x - he.hot_blocks; bid * (uint32_t)(BS * ITEMS) < nc; bid += he.cold_grid) {
+            eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, bid, nc,
+                                                                   (nc + BS * ITEMS - 1) / (BS * ITEMS));
+            __syncthreads(); // (the body's shared arrays are written again)
+        }
         return;
     }
     eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, blockIdx.x, p.n, gridDim.x);

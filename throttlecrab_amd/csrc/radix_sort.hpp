@@ -591,7 +591,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                                                                uint32_t tiles, uint32_t tile_len, uint32_t msd_mul, int sub_passes,
                                                                unsigned long long* __restrict__ range_hint, uint32_t stride,
                                                                uint32_t totals_words, uint32_t* __restrict__ hot_P, uint32_t* __restrict__ hot_n,
-                                                               uint32_t hot_ids) {
+                                                               uint32_t hot_ids, unsigned long long* __restrict__ cold_hint) {
     __shared__ uint32_t s_idx[FIN_CAP];            // request index of position p (never moves)
     __shared__ uint32_t s_u[FIN_UNION_WORDS];      // the two ways of sorting a range share this
     // ballot path: offset inside the range << FIN_POS_BITS | p in the order reached so far (x2), per-wave digit counters, digit totals / starts
@@ -701,7 +701,11 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 m0 = max(m0, s_part[FIN_WAVES + q]);
             }
             s_base = b0;
-            if (r == NRANGE - 1 && hot_n != nullptr) hot_n[hot_ids] = b0 + c; // (rank form: the requests the ranges hold = where the evaluation's sorted part ends)
+            if (r == NRANGE - 1 && hot_n != nullptr) {
+                hot_n[hot_ids] = b0 + c; // (rank form: the requests the ranges hold = where the evaluation's sorted part ends)
+                // ... mirrored for the host, which sizes the sorted part's grid of LATER batches by it (never waited for)
+                if (cold_hint != nullptr) __hip_atomic_store(cold_hint, ((unsigned long long)n << 32) | (b0 + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             if (r == NRANGE - 1 && range_hint != nullptr)
                 __hip_atomic_store(range_hint, ((unsigned long long)n << 32) | m0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }

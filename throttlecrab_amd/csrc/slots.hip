@@ -308,16 +308,18 @@ static void hot_refresh(tc_engine* e) {
     if (++h.version == 0u) h.version = 1u;
     h.backoff = 0;
     *(volatile unsigned long long*)h.hint_cold_host = 0ull; // (what the old list left of the ranges says nothing about the new one)
+    *(volatile unsigned long long*)(h.hint_cold_host + 1) = 0ull;
 }
 
 // How is this batch grouped?  GROUP_RANGE: the range path (radix_sort.hpp / range_part.hpp: every tile partitioned by key range
 // in place + one block per range that collects and finishes it in LDS -- two launches instead of a histogram and three LSD
-// passes); GROUP_RANGE_HOT: the same with the slots of the hot list peeled out of the partition and gathered behind the ranges
-// (three launches); GROUP_LSD: the passes.  The host cannot see the batch; it goes by the largest range of a RECENT batch of the
-// stream, which every grouping mirrors into pinned memory (never waited for).  No hint yet, a hint that predicts a range beyond
-// what a block finishes in LDS and no hot list that could explain it, or a batch too large: the LSD passes.  A wrong guess costs
-// time, not correctness (k_finish sorts an oversized range through global memory).
-enum { GROUP_LSD = 0, GROUP_RANGE = 1, GROUP_RANGE_HOT = 2, GROUP_RANGE_RANK = 3 }; // (RANK: the hot form of a lean batch, chosen by the caller: the hot slots' requests are ranked, not gathered)
+// passes); GROUP_RANGE_RANK (hot_allowed: a lean batch): the same with the slots of the hot list left out of the partition --
+// the evaluation's hot role ranks their requests where they stand; GROUP_LSD: the passes.  The host cannot see the batch; it
+// goes by the largest range of a RECENT batch of the stream, which every grouping mirrors into pinned memory (never waited
+// for).  No hint yet, a hint that predicts a range beyond what a block finishes in LDS and no hot list that could explain it,
+// or a batch too large: the LSD passes.  A wrong guess costs time, not correctness (k_finish sorts an oversized range through
+// global memory).
+enum { GROUP_LSD = 0, GROUP_RANGE = 1, GROUP_RANGE_RANK = 2 };
 static int range_applies(tc_engine* e, uint32_t n, bool piped, bool hot_allowed) {
     if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return GROUP_LSD;
     hot_refresh(e);
@@ -349,7 +351,7 @@ static int range_applies(tc_engine* e, uint32_t n, bool piped, bool hot_allowed)
         *(volatile unsigned long long*)hs.hint_cold_host = 0ull;
         return GROUP_LSD;
     }
-    return GROUP_RANGE_HOT;
+    return GROUP_RANGE_RANK;
 }
 
 // stable sort of (slot, index) by slot in scratch set `ss`, issued on stream `s`;
@@ -370,7 +372,7 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     if (ranged) {
         // round 6 (range_part.hpp): tiles of 4 096 requests on 1 024 threads, partitioned in place into elem_b by key range -- and,
         // in the hot form, by hot id: those buckets are gathered behind the ranges' elements, every range is finished into elem_a
-        const bool hotm = ranged != GROUP_RANGE, rankm = ranged == GROUP_RANGE_RANK;
+        const bool rankm = ranged == GROUP_RANGE_RANK, hotm = rankm;
         const uint32_t ptiles = (n + rp::PT_TILE - 1) / rp::PT_TILE, stride = hotm ? rp::NB_HOT : rp::NR;
         uint32_t* totals = ss.range_totals + (size_t)ss.range_parity * rp::NB_HOT;         // zero: cleared by the finish of the set's previous batch
         uint32_t* totals_next = ss.range_totals + (size_t)(ss.range_parity ^ 1u) * rp::NB_HOT;
@@ -387,24 +389,17 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
     TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<MODE>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap, \
                 e->range_mul, fill, fill_value, (const rp::HotDev*)(HOTP), (uint32_t*)(INFO))
         if (rankm) TC_PART(rp::PART_RANK, ss.hot_dev, ss.hot_info);
-        else if (hotm) TC_PART(rp::PART_GATHER, ss.hot_dev, nullptr);
         else TC_PART(rp::PART_PLAIN, nullptr, nullptr);
 #undef TC_PART
         prof_end_m(e, s);
-        if (hotm && !rankm) {
-            const uint32_t hb = rp::hg_grid(n, (uint32_t)std::min<size_t>(e->hot.slots.size(), rp::HOT_MAX), rp::hg_group(ptiles));
-            prof_begin_m(e, TC_STAGE_SORT, s);
-            TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, rp::k_hot_gather, dim3(hb), dim3(rp::HG_THREADS), 0, s, (const uint64_t*)bufs[1], (const uint32_t*)ss.part_table, stride,
-                        (const uint32_t*)totals, bufs[0], ptiles, rp::PT_TILE, (const rp::HotDev*)ss.hot_dev);
-            prof_end_m(e, s);
-        }
         if (hotm) e->hot.batches_hot++;
         prof_begin_m(e, TC_STAGE_SORT, s);
         hipEvent_t stop = e->prof_on ? nullptr : stop_last;
         // (rank form: HOT_MAX / 32 more blocks scan the hot ids' columns of the table)
         TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::NRANGE + (rankm ? rp::HOT_MAX / 32u : 0u)), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1],
                     (const uint32_t*)ss.part_table, bufs[0], ss.elem_c, (const uint32_t*)totals, totals_next, n, ptiles, rp::PT_TILE, e->range_mul, e->range_sub_passes,
-                    hotm ? e->hot.hint_cold_dev : hint, stride, rp::NB_HOT, rankm ? ss.hot_P : (uint32_t*)nullptr, rankm ? ss.hot_n : (uint32_t*)nullptr, rp::HOT_MAX);
+                    hotm ? e->hot.hint_cold_dev : hint, stride, rp::NB_HOT, rankm ? ss.hot_P : (uint32_t*)nullptr, rankm ? ss.hot_n : (uint32_t*)nullptr, rp::HOT_MAX,
+                    rankm ? e->hot.hint_cold_dev + 1 : (unsigned long long*)nullptr);
         prof_end_m(e, s);
         return bufs[0];
     }
@@ -483,8 +478,20 @@ static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, u
         if constexpr (ITEMS <= 4) {
             const HotEval he = e->hot.he;
             // (rank form: the first hot_blocks blocks walk the batch in request order for the hot slots' requests)
-            const dim3 lgrid(grid.x + (he.info ? he.hot_blocks : 0u));
-            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), lgrid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev, he);
+            HotEval hev = he;
+            if (he.info) {
+                // the sorted part's blocks: what a recent batch left in the ranges, scaled to this batch, + a quarter (too few: a
+                // block takes a second stretch; never more than the whole batch would need)
+                const unsigned long long ch = *(volatile unsigned long long*)(e->hot.hint_cold_host + 1);
+                uint32_t cg = grid.x;
+                if ((ch >> 32) != 0ull) {
+                    const uint64_t est = (ch & 0xFFFFFFFFull) * n / (ch >> 32);
+                    cg = (uint32_t)std::min<uint64_t>(grid.x, (est + est / 4u) / (BLOCK * ITEMS) + 32u);
+                }
+                hev.cold_grid = std::max(cg, 1u);
+            }
+            const dim3 lgrid((he.info ? hev.cold_grid + he.hot_blocks : grid.x));
+            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), lgrid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev, hev);
             return;
         }
     }
@@ -660,13 +667,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
     p.uniform_class = e->uniform_id;
     p.denied = e->denied;
     p.row_bits = nullptr;
-    // round 6: the evaluation notes its heavy runs for the host's hot list (hot_refresh); batches too small to care are left out
-    const bool notes = e->hot.on && e->hot.notes_dev != nullptr && n >= 16384u && !(b.flags & TC_B_UNIQUE_SLOTS);
-    if (notes) {
-        p.heavy = e->hot.notes_dev;
-        p.heavy_min = e->hot.heavy_min;
-        p.heavy_tag = (uint32_t)(e->hot.evals & ((1u << ev::HEAVY_TAG_BITS) - 1u));
-    }
+    bool notes = false; // round 6: the evaluation notes its heavy runs for the host's hot list (set below, where the batch's kind is known)
     p.capacity = e->capacity;
     p.counters = e->counters;
     if (b.flags & TC_B_REGISTERED_PARAMS) {
@@ -727,11 +728,19 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
         // batches are not partitioned at all (the sort path alone is always correct), then the path is tried again.
         // (round 4: a batch the range path takes is grouped by it alone, in order as well: two grouping launches and the
         // evaluation, nothing enqueued twice)
-        int ranged = range_applies(e, n, piped, !p.order);
-        // a lean batch in the hot form: its hot slots' requests are ranked where they stand, not gathered (eval_kernels.hpp, the
-        // hot role); per-slot denial counters want a slot's requests side by side: the gather form
+        // (the hot form is the lean kernel's: its hot role ranks the hot slots' requests where they stand -- eval_kernels.hpp; per-slot
+        // denial counters want a slot's requests side by side, grouped rows want them sorted: the LSD passes)
+        const bool rank_ok = e->hot.on && e->hot.rank_on && uniform && direct && lean_applies(e, full, direct, piped, p) && !p.denied && !p.order;
+        // Only the batches that could take the hot form pay for the notes it is chosen by (a general Zipf batch lost 7 us to them
+        // and to the copies for the host: profiles/r06_v15_hot_forms_driver_ab.txt); batches too small to care are left out.
+        notes = rank_ok && e->hot.notes_dev != nullptr && n >= 16384u;
+        if (notes) {
+            p.heavy = e->hot.notes_dev;
+            p.heavy_min = e->hot.heavy_min;
+            p.heavy_tag = (uint32_t)(e->hot.evals & ((1u << ev::HEAVY_TAG_BITS) - 1u));
+        }
+        const int ranged = range_applies(e, n, piped, rank_ok);
         e->hot.he = HotEval{};
-        if (ranged == GROUP_RANGE_HOT && e->hot.rank_on && uniform && direct && lean_applies(e, full, direct, piped, p) && !p.denied) ranged = GROUP_RANGE_RANK;
         // The range hint is written by the grouping kernels of the sort paths (k_hist's range row, k_finish).  An in-order batch
         // on the bucket path leaves none: an engine that only ever sees in-order batches would stay on the bucket path for
         // good -- 84 us per 1 Mi batch where the range path takes 63, found by tools/batch_sizes.py; bench.py's in-order
@@ -754,7 +763,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             }
         }
         const bool bucketed = eligible;
-        e->last_grouping_path = ranged >= GROUP_RANGE_HOT ? 5u : (ranged ? 1u : (bucketed ? 3u : 2u)); // (bucketed: decided on the device in the end -- tc_engine_info says what was enqueued)
+        e->last_grouping_path = ranged == GROUP_RANGE_RANK ? 5u : (ranged ? 1u : (bucketed ? 3u : 2u)); // (bucketed: decided on the device in the end -- tc_engine_info says what was enqueued)
         // Grouped rows + a bitmask of them, every run regular: the evaluation's waves hold 64 consecutive rows each and
         // pack their decisions with one ballot (no byte column, no k_pack_bits launch).
         if (b.allowed_bits && p.order && direct) {
@@ -834,7 +843,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // (slim: the stream looked skewed to the range hint -- not merely "no hint yet" or a batch too large for the path)
             // (rank form: what is left in the sorted part is the stream's uniform tail, and the hot role's blocks want the CU's eight
             // block slots beside it: 2 positions per lane -- 36.6 us per Zipf batch against 39.2 with 4, profiles/r06_v12_zipf_items_ab.txt)
-            const bool slim = piped && e->range_ok && ranged != GROUP_RANGE_RANK && (ranged >= GROUP_RANGE_HOT || (!ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n));
+            const bool slim = piped && e->range_ok && (!ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n);
             launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr, slim);
             prof_end_m(e, s);
             e->hot.he = HotEval{};

@@ -1,8 +1,8 @@
 // partbench.hip -- round 6: the range path (rp::k_tile_part, 1 024 threads per tile of 4 096 requests, 512 ranges + rs::k_finish,
-// 512-thread blocks) and its HOT form (rp::k_tile_part<true> + rp::k_hot_gather + rs::k_finish) against the LSD passes, on uniform
-// and skewed batches -- each result checked on the host:  (round 4's first half, rs::k_tile_ranges with 256 ranges, is gone: its
+// 512-thread blocks) and its RANK form (rp::k_tile_part<PART_RANK> + rs::k_finish with its scan blocks) against the LSD passes, on
+// uniform and skewed batches -- each result checked on the host:  (round 4's first half, rs::k_tile_ranges with 256 ranges, is gone: its
 // last figures beside the new kernel's are in profiles/r06_v1_partbench.txt) the plain form against std::sort, the hot form against
-// [the cold requests sorted by (slot, index)] [hot id 0's requests by index] [hot id 1's] ...
+// [the cold requests sorted by (slot, index)]; every hot request's hot_P[tile][id] + rank inside its tile == its rank among its slot's requests
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/partbench.hip -o tools/bin/partbench && tools/bin/partbench
 #include <hip/hip_runtime.h>
 #include <algorithm>
@@ -55,12 +55,13 @@ int main(int argc, char** argv) {
     const uint32_t mul = rs::range_mul(cap), width = rs::range_width(mul);
     const int sub_passes = width <= 256 ? 1 : 2;
     const uint32_t NMAX = 1u << 21, OLD_ITEMS = 16, old_tile = rs::THREADS * OLD_ITEMS;
-    uint32_t* d_slot; uint64_t *a, *b, *c3; uint32_t *wsmem, *table, *totals; unsigned long long* hint; rp::HotDev* hotd; uint32_t tpar = 0, parity = 0;
+    uint32_t* d_slot; uint64_t *a, *b, *c3; uint32_t *wsmem, *table, *totals; unsigned long long* hint; rp::HotDev* hotd; uint32_t *d_info, *d_P, *d_hn; uint32_t tpar = 0, parity = 0;
     const uint32_t max_tiles_old = (NMAX + old_tile - 1) / old_tile, max_tiles = (NMAX + rp::PT_TILE - 1) / rp::PT_TILE;
     const size_t words = rs::workspace_words(max_tiles_old);
     CK(hipMalloc(&d_slot, NMAX * 4)); CK(hipMalloc(&a, NMAX * 8)); CK(hipMalloc(&b, NMAX * 8)); CK(hipMalloc(&c3, NMAX * 8)); CK(hipMalloc(&wsmem, words * 4));
     CK(hipMalloc(&table, (size_t)max_tiles * rp::NB_HOT * 4)); CK(hipMalloc(&totals, 2 * rp::NB_HOT * 4)); CK(hipMemset(totals, 0, 2 * rp::NB_HOT * 4));
     CK(hipMalloc(&hotd, sizeof(rp::HotDev))); CK(hipMemset(hotd, 0, sizeof(rp::HotDev)));
+    CK(hipMalloc(&d_info, NMAX * 4)); CK(hipMalloc(&d_P, (size_t)max_tiles * rp::HOT_MAX * 4)); CK(hipMalloc(&d_hn, (rp::HOT_MAX + 8) * 4));
     CK(hipHostMalloc((void**)&hint, 64, hipHostMallocDefault));
     CK(hipMemset(wsmem, 0, words * 4));
     CK(hipDeviceSynchronize());
@@ -98,8 +99,7 @@ int main(int argc, char** argv) {
                 else cold.push_back(ref[i]);
             }
             std::sort(cold.begin(), cold.end());
-            ref_hot = cold;
-            for (auto& r : runs) ref_hot.insert(ref_hot.end(), r.begin(), r.end());
+            ref_hot = cold; // (the rank form's sorted part)
         }
         std::sort(ref.begin(), ref.end());
         const uint32_t tiles_old = (n + old_tile - 1) / old_tile, tiles = (n + rp::PT_TILE - 1) / rp::PT_TILE;
@@ -128,12 +128,12 @@ int main(int argc, char** argv) {
                 } else {
                     const bool hotm = mode == 3;
                     const uint32_t stride = hotm ? rp::NB_HOT : rp::NR;
-                    if (hotm) hipLaunchKernelGGL((rp::k_tile_part<true>), dim3(tiles), dim3(rp::PT_THREADS), 0, 0, d_slot, b, table, stride, tot, n, cap, mul, (uint8_t*)nullptr, 0u, (const rp::HotDev*)hotd);
-                    else hipLaunchKernelGGL((rp::k_tile_part<false>), dim3(tiles), dim3(rp::PT_THREADS), 0, 0, d_slot, b, table, stride, tot, n, cap, mul, (uint8_t*)nullptr, 0u, (const rp::HotDev*)nullptr);
+                    if (hotm) hipLaunchKernelGGL((rp::k_tile_part<rp::PART_RANK>), dim3(tiles), dim3(rp::PT_THREADS), 0, 0, d_slot, b, table, stride, tot, n, cap, mul, (uint8_t*)nullptr, 0u, (const rp::HotDev*)hotd, d_info);
+                    else hipLaunchKernelGGL((rp::k_tile_part<rp::PART_PLAIN>), dim3(tiles), dim3(rp::PT_THREADS), 0, 0, d_slot, b, table, stride, tot, n, cap, mul, (uint8_t*)nullptr, 0u, (const rp::HotDev*)nullptr, (uint32_t*)nullptr);
                     CK(hipEventRecord(ev[1]));
-                    if (hotm) hipLaunchKernelGGL(rp::k_hot_gather, dim3(rp::hg_grid(n, hl.count, rp::hg_group(tiles))), dim3(rp::HG_THREADS), 0, 0, (const uint64_t*)b, (const uint32_t*)table, stride, (const uint32_t*)tot, a, tiles, rp::PT_TILE, (const rp::HotDev*)hotd);
                     CK(hipEventRecord(ev[2]));
-                    hipLaunchKernelGGL(rs::k_finish, dim3(rs::NRANGE), dim3(rs::FIN_THREADS), 0, 0, (const uint64_t*)b, (const uint32_t*)table, a, c3, (const uint32_t*)tot, tot_next, n, tiles, rp::PT_TILE, mul, sub_passes, hint, stride, rp::NB_HOT);
+                    hipLaunchKernelGGL(rs::k_finish, dim3(rs::NRANGE + (hotm ? rp::HOT_MAX / 32u : 0u)), dim3(rs::FIN_THREADS), 0, 0, (const uint64_t*)b, (const uint32_t*)table, a, c3, (const uint32_t*)tot, tot_next, n, tiles,
+                                       rp::PT_TILE, mul, sub_passes, hint, stride, rp::NB_HOT, hotm ? d_P : (uint32_t*)nullptr, hotm ? d_hn : (uint32_t*)nullptr, rp::HOT_MAX, (unsigned long long*)nullptr);
                     tpar ^= 1u;
                     CK(hipEventRecord(ev[3]));
                 }
@@ -142,16 +142,33 @@ int main(int argc, char** argv) {
                 if (it >= 2) for (int k = 0; k < 3; ++k) { float ms; CK(hipEventElapsedTime(&ms, ev[k], ev[k + 1])); acc[k] += ms; }
             }
             CK(hipMemcpy(out.data(), a, (size_t)n * 8, hipMemcpyDeviceToHost));
-            const std::vector<uint64_t>& want = mode == 3 ? ref_hot : ref;
-            const bool ok = out == want;
-            bad += !ok;
+            bool ok;
+            if (mode == 3) {
+                // the sorted part: the cold requests; every hot request: its id and its rank among its slot's requests
+                const size_t n_cold = ref_hot.size();
+                std::vector<uint32_t> info(n), P((size_t)tiles * rp::HOT_MAX), hn(rp::HOT_MAX + 1);
+                CK(hipMemcpy(info.data(), d_info, (size_t)n * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(P.data(), d_P, P.size() * 4, hipMemcpyDeviceToHost));
+                CK(hipMemcpy(hn.data(), d_hn, hn.size() * 4, hipMemcpyDeviceToHost));
+                ok = hn[rp::HOT_MAX] == n_cold && std::equal(ref_hot.begin(), ref_hot.end(), out.begin());
+                std::vector<uint32_t> seen(hl.count, 0);
+                for (uint32_t i = 0; i < n && ok; ++i) {
+                    const auto it = hot_id.find(h[i]);
+                    if (it == hot_id.end()) ok = info[i] == rp::HOT_NONE;
+                    else ok = (info[i] >> 16) == it->second && P[(size_t)(i / rp::PT_TILE) * rp::HOT_MAX + it->second] + (info[i] & 0xFFFFu) == seen[it->second]++;
+                }
+                for (uint32_t k = 0; k < hl.count && ok; ++k) ok = hn[k] == seen[k];
+            } else {
+                ok = out == ref;
+            }
+            const std::vector<uint64_t>& want = ref;
             const unsigned long long hv = *(volatile unsigned long long*)hint;
-            static const char* names[4] = {"lsd", "range4", "part", "hot"};
-            static const char* cols[4][3] = {{"hist", "p0+p1", "p2"}, {"tiles", "-", "finish"}, {"part", "-", "finish"}, {"part", "gather", "finish"}};
+            static const char* names[4] = {"lsd", "range4", "part", "rank"};
+            static const char* cols[4][3] = {{"hist", "p0+p1", "p2"}, {"tiles", "-", "finish"}, {"part", "-", "finish"}, {"part", "-", "finish"}};
             printf("%-8s n=%8u hot %4u %-7s %-6s %5.1f us  %-6s %5.1f  %-6s %5.1f  total %6.1f   largest range %u  %s\n", cs.dist, n, mode == 3 ? hl.count : 0u, names[mode], cols[mode][0],
                    1e3 * acc[0] / iters, cols[mode][1], 1e3 * acc[1] / iters, cols[mode][2], 1e3 * acc[2] / iters, 1e3 * (acc[0] + acc[1] + acc[2]) / iters, (unsigned)(hv & 0xFFFFFFFFu),
                    ok ? "ok" : "WRONG");
-            if (!ok) {
+            if (!ok && mode != 3) {
                 uint32_t shown = 0;
                 for (uint32_t i = 0; i < n && shown < 4; ++i)
                     if (out[i] != want[i]) { printf("   first differences at %u: got %016llx want %016llx\n", i, (unsigned long long)out[i], (unsigned long long)want[i]); ++shown; }
