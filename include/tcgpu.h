@@ -27,6 +27,19 @@
  * caller at a time; results are ordered on one HIP stream per engine (the
  * engine may group and stage batches on internal streams of its own).
  * Plain pointers and sizes only; no C++/torch types cross this boundary.
+ *
+ * Environment variables.  The library reads a number of TCGPU_* variables when an engine is created.  They are UNSUPPORTED TUNING
+ * SWITCHES of the measurement scripts under tools/ (A/B of a kernel variant, a stream count, a threshold): none of them changes a
+ * result, none is part of this ABI, any may disappear.  As of round 6:
+ *   pipeline     TCGPU_AUX_STREAMS  TCGPU_PIPE_DEPTH  TCGPU_AUX_PRIORITY  TCGPU_PIPE_PROBE  TCGPU_ASSUME_CONCURRENT  TCGPU_STREAM_POOL
+ *                TCGPU_STOP_EVENTS  TCGPU_PROF_MARKERS
+ *   grouping     TCGPU_RANGE  TCGPU_RANGE_MAX_N  TCGPU_SORT_ITEMS_PIPED  TCGPU_HOT  TCGPU_HOT_MIN  TCGPU_HOT_RANK  TCGPU_BUCKET
+ *                TCGPU_BUCKET_PIPED  TCGPU_BUCKET_BACKOFF  TCGPU_BUCKET_MIN_N  TCGPU_BUCKET_SKEW  TCGPU_ROUTE_3PASS
+ *   evaluation   TCGPU_EVAL_ITEMS  TCGPU_EVAL_LEAN  TCGPU_PREFILL  TCGPU_GENERAL_EARLIER  TCGPU_GENERAL_RUNS  TCGPU_NO_SMALL_BATCH
+ *   host batches TCGPU_HOST_CHUNK  TCGPU_BOUNCE_MAX  TCGPU_COPY_KERNEL  TCGPU_ASYNC_COPY_KERNEL_N  TCGPU_SYNC_COPY_MAX
+ *   string keys  TCGPU_SPREAD_FREE        multi-GPU  TCGPU_EXCHANGE_WAIT_S
+ * One more, TCGPU_DEBUG_NO_DECISION_STORE (the lean kernel skips its decision bytes: wrong results, for timing only), exists
+ * only in libraries built with `make DEBUG_KNOBS=1` (-DTCGPU_DEBUG_KNOBS); the library this header ships with ignores it.
  */
 #ifndef TCGPU_H
 #define TCGPU_H
@@ -480,7 +493,9 @@ int tc_forward_segments(tc_engine* e, const tc_forward* f);
  * tc_exchange_step is those four in one call.  No collective, no host synchronisation in steady state (a phase only waits
  * when its inputs are not there yet).  The caller primes the pipeline: routes 0 .. route_ahead - 1, posts 0 .. post_ahead - 1.
  * tmpl: outputs, rate plan / quantity / timestamp and flags of the evaluation (device pointers; TC_B_INPUTS_READY is added);
- * a step larger than the engine's max_batch is evaluated in chunks, each writing behind the previous one.  */
+ * a step larger than the engine's max_batch is evaluated in chunks, each writing behind the previous one.  tmpl->n, if not 0, is
+ * the number of requests the output arrays hold: a step (tc_shard_evaluate: this rank's share of it) that is larger fails with
+ * TC_E_INVALID_ARG before anything is applied.  */
 #define TC_X_NONBLOCKING 0x1u    /* a phase whose turn has not come returns TC_E_AGAIN instead of waiting (ONE thread driving
                                   * several ranks, as the tests do); a repeated phase of a step already done is a no-op */
 typedef struct tc_exchange tc_exchange;
@@ -581,6 +596,8 @@ typedef struct tc_engine_info {
     uint64_t batches;              /* batches decided so far */
     uint64_t hot_slots;            /* slots on the hot list right now (made from the evaluations' notes on long runs; 0: none) */
     uint64_t hot_batches;          /* batches grouped with the hot slots peeled out so far */
+    uint64_t probes_pooled;        /* 1: the grouping streams came from the process's pool -- streams an earlier engine on this main stream
+                                    * had probed, re-checked against the main stream instead of probing sixteen new candidates */
 } tc_engine_info;
 int tc_engine_info_get(tc_engine* e, tc_engine_info* out);
 

@@ -151,8 +151,9 @@ pub struct Request<'a> {
 
 /// `RateLimiter<GpuStore>` with the decision on the device.
 pub struct GpuRateLimiter {
-    store: GpuStore,
+    // (fields drop in declaration order: the pinned staging first -- tc_host_free -- then the store, which destroys the engine)
     staging: Staging,
+    store: GpuStore,
 }
 
 fn decode(r: &ffi::tc_decision, limit: i64, quantity: i64) -> Result<(bool, RateLimitResult), CellError> {
@@ -308,11 +309,16 @@ impl<T> Pinned<T> {
             return;
         }
         let cap = n.next_power_of_two().max(1024);
-        unsafe {
-            ffi::tc_host_free(self.ptr as *mut std::os::raw::c_void);
-            self.ptr = ffi::tc_host_alloc(cap * std::mem::size_of::<T>()) as *mut T;
-        }
-        assert!(!self.ptr.is_null(), "tc_host_alloc failed");
+        //  nothing is left behind that a later, smaller batch could write through: cap goes to 0 with the old
+        // buffer and comes back only with a new one (a server that catches the panic below keeps a consistent Pinned)
+        let old = std::mem::replace(&mut self.ptr, std::ptr::null_mut());
+        self.cap = 0;
+        let fresh = unsafe {
+            ffi::tc_host_free(old as *mut std::os::raw::c_void);
+            ffi::tc_host_alloc(cap * std::mem::size_of::<T>()) as *mut T
+        };
+        assert!(!fresh.is_null(), "tc_host_alloc failed");
+        self.ptr = fresh;
         self.cap = cap;
     }
 }

@@ -96,3 +96,18 @@ def test_python_constants_match_the_header():
     assert L.tc_batch.order.offset == L.tc_batch.decisions.offset + 8
     assert L.tc_batch.n_segments.offset == L.tc_batch.order.offset + 8
     assert C.sizeof(L.tc_batch) == L.tc_batch.order.offset + 8 + 8 + 16
+
+
+def test_the_shipped_library_has_no_switch_that_corrupts_results():
+    """TCGPU_DEBUG_NO_DECISION_STORE (the lean kernel skips its decision bytes, for timing) exists in
+    `make DEBUG_KNOBS=1` builds only; the in-tree library must not even contain the variable's name.  The other TCGPU_*
+    variables are listed in tcgpu.h as unsupported tuning switches: every one the sources read must be on that list."""
+    import glob
+    import re
+    blob = open(os.path.join(ROOT, "throttlecrab_amd", "libtcgpu.so"), "rb").read()
+    assert b"TCGPU_DEBUG_NO_DECISION_STORE" not in blob
+    header = open(os.path.join(ROOT, "include", "tcgpu.h")).read()
+    read = set()
+    for path in glob.glob(os.path.join(ROOT, "throttlecrab_amd", "csrc", "*.h*")):
+        read |= set(re.findall(r'getenv\("(TCGPU_[A-Z0-9_]+)"\)', open(path).read()))
+    assert read and not [v for v in read if v not in header], sorted(v for v in read if v not in header)

@@ -409,3 +409,68 @@ def test_the_engine_says_when_its_pipeline_is_degraded(queues):
         assert a["grouping_streams"] == 3 and a["pipelining_degraded"] == 0, a
     else:   # main + one more queue at most: not three grouping streams that run beside the main stream
         assert a["grouping_streams"] < 3 and a["pipelining_degraded"] == 1 and a["rejected_same_queue"] + a["rejected_same_pipe"] > 0, a
+
+
+def test_a_second_engine_takes_the_probed_streams_from_the_pool():
+    """probing sixteen stream candidates costs 3-8 ms of GPU time on every engine's first pipelined batch.  The
+    streams that passed stay in a per-process pool.  An engine that runs on a stream of its own leaves the whole set behind (main
+    stream + grouping streams) and the next such engine takes it as it is; engines that share a stream of the caller's share
+    its probed grouping streams, while they live and afterwards.  tc_engine_info says so (probes_pooled); results stay exact."""
+    import torch
+
+    import throttlecrab_amd as t
+    from tests.test_gpu_slots import T0, _oracle
+    cap, n, plan = 300_000, 1 << 16, (5, 10, 60)
+    rng = np.random.default_rng(4)
+
+    def run(eng, orc, base):
+        held = []
+        for i in range(5):
+            slots = rng.integers(0, cap, n).astype(np.uint32)
+            ref = orc.batch_slots(slots, *plan, 1, T0 + (base + i) * 10**8)
+            d = torch.from_numpy(slots.astype(np.int32)).cuda()
+            torch.cuda.synchronize()
+            held.append((eng.rate_limit_batch_slots(d, registered=True, quantity=1, now_ns=T0 + (base + i) * 10**8, want=("allowed",), inputs_ready=True), ref, d))
+        eng.synchronize()
+        torch.cuda.synchronize()
+        for res, ref, _ in held:
+            assert np.array_equal(res.allowed.cpu().numpy(), ref.allowed)
+
+    def make(stream=None):
+        e = t.Engine(cap, n, fixed_params=True)
+        if stream is not None:
+            e.set_stream(stream.cuda_stream)
+        e.register_params_uniform(*plan)
+        return e, _oracle(cap)
+
+    # engines on streams of their own: two beside each other probe a set each, their successors take the sets over
+    a, oa = make()
+    b, ob = make()
+    run(a, oa, 0)
+    run(b, ob, 0)
+    assert a.info()["grouping_streams"] == 3 and b.info()["grouping_streams"] == 3
+    run(a, oa, 5)
+    a.close()
+    b.close()
+    c, oc = make()
+    d, od = make()
+    run(c, oc, 0)
+    run(d, od, 0)
+    for eng in (c, d):
+        info = eng.info()
+        assert info["probes_pooled"] == 1 and info["grouping_streams"] == 3 and info["pipelining_degraded"] == 0, info
+        assert eng.selfcheck() == 0
+    c.close()
+    d.close()
+    # engines on ONE stream of the caller's share its probed grouping streams
+    side = torch.cuda.Stream()
+    f, of = make(side)
+    run(f, of, 0)
+    g, og = make(side)
+    run(g, og, 0)
+    ig = g.info()
+    assert ig["probes_pooled"] == 1 and ig["grouping_streams"] == 3, ig
+    run(f, of, 5)
+    assert f.selfcheck() == 0 and g.selfcheck() == 0
+    f.close()
+    g.close()

@@ -483,3 +483,37 @@ def test_replicate_mode_as_one_library_call_per_step(stream_kind, world):
         with pytest.raises(t.TcError):
             ranks[r].step(steps, None, LA + 5, T0, outs[r])   # a look-ahead the ring cannot hold
         engs[r].close()
+
+
+def test_a_share_larger_than_the_output_arrays_is_refused_before_anything_is_written():
+    """tc_shard_evaluate decides a rank's SHARE of a global step -- a count that comes from the router, on the device.
+    The template's n is what the caller's output arrays hold; a skewed step whose share is larger used to be written past
+    them.  Now: TC_E_INVALID_ARG, nothing applied (the same step with arrays that are large enough then decides all of it)."""
+    import torch
+    import throttlecrab_amd as t
+    from tests.test_gpu_slots import T0
+    from throttlecrab_amd import sharded
+    world, cap, G = 2, 50_000, 40_000
+    rng = np.random.default_rng(3)
+    glob = rng.integers(0, world * cap, G).astype(np.uint32)
+    owner, _ = sharded.route(glob, world, cap)
+    share = int((owner == 0).sum())
+    e = t.Engine(cap, 65_536, fixed_params=True)
+    e.use_torch_stream()
+    e.register_params_uniform(5, 10, 60)
+    rank = sharded.ShardRank(e, 0, world, G, ring=3)
+    d = torch.from_numpy(glob.astype(np.int32)).cuda()
+    rank.route(0, d)
+    small = [t.BatchResult(allowed=torch.full((share - 100,), 7, dtype=torch.uint8, device="cuda"))]
+    guard = torch.full((4096,), 9, dtype=torch.uint8, device="cuda")   # (whatever lies behind the short array)
+    with pytest.raises(t.TcError) as err:
+        rank.evaluate(0, T0, small, want=("allowed",))
+    assert "larger than the output arrays" in str(err.value)
+    torch.cuda.synchronize()
+    assert int((small[0].allowed != 7).sum()) == 0 and int((guard != 9).sum()) == 0 and e.counters()["total"] == 0
+    big = [t.BatchResult(allowed=torch.zeros(G, dtype=torch.uint8, device="cuda"))]
+    assert rank.evaluate(0, T0, big, want=("allowed",)) == share
+    torch.cuda.synchronize()
+    assert e.counters()["total"] == share and e.selfcheck() == 0
+    rank.close()
+    e.close()

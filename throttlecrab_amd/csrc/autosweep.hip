@@ -55,7 +55,10 @@ static void ingest(tc_engine* e) {
     mk::PolicyFeed f;
     if (!read_feed(e, &f)) return;
     a.seen = f.seq_end;
-    a.host_ops += f.allowed - a.allowed_accounted; // operations: one per allowed request (one CAS / set_if_not_exists each)
+    // (tc_snapshot_load replaces the device's counter block: a total that went BACKWARDS is a new baseline, not 2^64
+    // operations -- which would have tripped the operation trigger, halved the adaptive interval and pinned new_share at 1)
+    auto since = [](unsigned long long total, uint64_t accounted) -> uint64_t { return total >= accounted ? total - accounted : 0ull; };
+    a.host_ops += since(f.allowed, a.allowed_accounted); // operations: one per allowed request (one CAS / set_if_not_exists each)
     a.allowed_accounted = f.allowed;
     a.entries = f.entries;
     a.free_slots = f.free_slots;
@@ -66,12 +69,12 @@ static void ingest(tc_engine* e) {
         a.keys_after.pop_front();
     }
     if (covered) {
-        const uint64_t fresh = f.inserted - a.inserted_seen;
+        const uint64_t fresh = since(f.inserted, a.inserted_seen);
         a.new_share[a.new_share_at++ % 8] = std::min(1.0, (double)fresh / (double)covered);
     }
     a.inserted_seen = f.inserted;
     if (a.pending && a.seen >= a.pending_seq) {
-        const uint64_t removed = f.swept - a.swept_accounted;
+        const uint64_t removed = since(f.swept, a.swept_accounted);
         if (a.kind == TC_SWEEP_ADAPTIVE) {
             a.adaptive.swept_result(removed, a.pending_entries);
             // A store that is still past the size trigger AFTER a cleanup is full of live keys.  The reference's map grows out
@@ -202,7 +205,7 @@ int auto_sweep_after(tc_engine* e, uint64_t n, bool key_batch, const int64_t* no
     tc_engine::AutoSweep& a = e->as;
     if (a.kind == TC_SWEEP_NONE) return TC_E_OK;
     TC_TRY(enqueue_feed(e, now_last_dev, now_scalar));
-    if (key_batch && e->key_mode) a.keys_after.emplace_back(a.issued, n);
+    if (key_batch && e->key_mode && !a.in_retry) a.keys_after.emplace_back(a.issued, n); // (a retried sub-batch: its requests were entered with the batch they come from)
     return TC_E_OK;
 }
 

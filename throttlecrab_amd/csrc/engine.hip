@@ -1,9 +1,42 @@
 // engine.hip -- engine life cycle: allocation, streams, rate plans, counters, profiling, test hooks (include/tcgpu.h)
 #include "engine.hpp"
+#include <mutex>
+
+namespace {
+struct SidePool {
+    int device;
+    hipStream_t main;
+    bool main_owned; // the main stream is one an engine created for itself: the whole set (it + its grouping streams) is one engine's at a time
+    int priority;
+    std::vector<hipStream_t> streams;
+    uint32_t users;
+    uint32_t tried, same_queue, same_pipe, second_best;
+    bool assumed;
+};
+std::mutex g_side_mu;
+std::vector<SidePool> g_side_pools;
+} // namespace
 
 hipStream_t cur_stream(tc_engine* e) {
     if (e->user_stream) return e->user_stream;
-    if (!e->own_stream && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (!e->own_stream) {
+        // a main stream an earlier engine of this process created for itself, probed grouping streams with, and left behind?
+        static const bool pool_on = [] { const char* v = getenv("TCGPU_STREAM_POOL"); return !v || atoi(v) != 0; }();
+        const char* as = getenv("TCGPU_ASSUME_CONCURRENT");
+        const bool assume = as && atoi(as) != 0;
+        const uint32_t want = e->n_aux_want + ((e->cfg_flags & TC_CFG_KEY_MODE) ? 1u : 0u);
+        if (pool_on) {
+            std::lock_guard<std::mutex> lk(g_side_mu);
+            for (SidePool& sp : g_side_pools)
+                if (sp.main_owned && sp.users == 0 && sp.device == e->device && sp.priority == e->aux_priority && sp.assumed == assume && sp.streams.size() >= want) {
+                    sp.users = 1;
+                    e->own_stream = sp.main;
+                    e->own_pooled = true;
+                    break;
+                }
+        }
+        if (!e->own_stream && hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    }
     return e->own_stream;
 }
 
@@ -118,7 +151,9 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_EVAL_LEAN")) e->eval_lean = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_STOP_EVENTS")) e->stop_events = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_PROF_MARKERS")) e->prof_markers = atoi(d) != 0;
+#ifdef TCGPU_DEBUG_KNOBS // (make DEBUG_KNOBS=1: measurement builds only -- the shipped library cannot be told to skip its results)
     if (const char* d = getenv("TCGPU_DEBUG_NO_DECISION_STORE")) e->debug_nostore = atoi(d) != 0;
+#endif
     if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_GENERAL_EARLIER")) e->general_earlier = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_GENERAL_RUNS")) e->general_runs = atoi(d) != 0;
@@ -385,24 +420,78 @@ static int streams_collide(tc_engine* e, hipStream_t a, hipStream_t b, bool* out
 // bench.py's -- any GPU work on the caller's stream before the engine's first pipelined batch -- the third grouping stream
 // landed four queues behind the main stream, and pipelined batches took 104 us instead of 42: tools/batch_sizes.py BS_PRE=1,
 // tools/pipeprobe.hip.  Candidates that collide with the main stream are dropped like the ones that share its queue.)
+// Round 6: what the probe found is kept per (process, device, main stream, priority).  Probing costs
+// 96-221 launches of a 35 us kernel -- 3.4-7.8 ms on the first pipelined batch of EVERY engine, more than half of all GPU time
+// in the driver's traces -- and its answer is a property of the streams, not of the engine: the grouping streams that passed
+// stay in a pool when their engine goes (or while it lives: engines of one process on one main stream share them; every
+// dependency is an event either way), and the next engine on that main stream takes them after one concurrency check of each
+// against the main stream (a main stream handle can be reused for a new stream) instead of probing sixteen candidates.
+
+void release_side_streams(tc_engine* e) {
+    std::vector<hipStream_t> mine;
+    if (e->key_stream) mine.push_back(e->key_stream);
+    for (hipStream_t& a : e->aux)
+        if (a) mine.push_back(a), a = nullptr;
+    e->key_stream = nullptr;
+    e->n_aux = 0;
+    for (hipStream_t s : mine) (void)hipStreamSynchronize(s);
+    if (e->side_pooled) {
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        for (SidePool& sp : g_side_pools)
+            if (!sp.main_owned && sp.device == e->device && sp.main == e->side_for && sp.priority == e->aux_priority && sp.users) --sp.users; // (the streams stay)
+    } else {
+        for (hipStream_t s : mine) (void)hipStreamDestroy(s);
+    }
+    e->side_pooled = false;
+    e->side_ready = false;
+}
+
 int ensure_side_streams(tc_engine* e) {
     hipStream_t m = cur_stream(e);
     if (e->side_ready && e->side_for == m) return TC_E_OK;
     TC_HIP(e, hipStreamSynchronize(m));
-    for (hipStream_t& a : e->aux)
-        if (a) {
-            TC_HIP(e, hipStreamSynchronize(a));
-            (void)hipStreamDestroy(a);
-            a = nullptr;
-        }
-    if (e->key_stream) {
-        TC_HIP(e, hipStreamSynchronize(e->key_stream));
-        (void)hipStreamDestroy(e->key_stream);
-        e->key_stream = nullptr;
-    }
+    release_side_streams(e);
     const uint32_t want = e->n_aux_want + (e->key_mode ? 1u : 0u);
     const char* as = getenv("TCGPU_ASSUME_CONCURRENT");
     const bool assume = as && atoi(as) != 0;
+    static const bool pool_on = [] { const char* v = getenv("TCGPU_STREAM_POOL"); return !v || atoi(v) != 0; }();
+    if (pool_on) {
+        std::unique_lock<std::mutex> lk(g_side_mu);
+        for (size_t pi = 0; pi < g_side_pools.size(); ++pi) {
+            SidePool& sp = g_side_pools[pi];
+            if (sp.device != e->device || sp.main != m || sp.priority != e->aux_priority || sp.assumed != assume || sp.streams.size() < want) continue;
+            if (sp.main_owned && !(e->own_pooled && m == e->own_stream)) continue; // (somebody else's set)
+            bool ok = true;
+            // Is it still the main stream the verdict was about (a handle can be reused for a new stream)?  One concurrency
+            // check per stream, ~0.3 ms; the pipe test is not repeated -- its sixteen tries per stream ARE the probe's cost, and
+            // which pipe a queue feeds does not change while the queue lives.
+            for (uint32_t k = 0; ok && !assume && !sp.main_owned && k < want; ++k) { // (an owned main stream never left the pool: nothing to re-check)
+                const int rc = streams_concurrent(e, m, sp.streams[k], &ok);
+                if (rc != TC_E_OK) return rc;
+            }
+            if (!ok) {
+                if (sp.users == 0) { // nobody holds them: drop the entry and probe afresh
+                    for (hipStream_t s : sp.streams) (void)hipStreamDestroy(s);
+                    g_side_pools.erase(g_side_pools.begin() + (long)pi);
+                }
+                break;
+            }
+            if (!sp.main_owned) ++sp.users;
+            size_t gi = 0;
+            if (e->key_mode) e->key_stream = sp.streams[gi++];
+            e->n_aux = 0;
+            for (; gi < want && e->n_aux < (uint32_t)AUX_MAX; ++gi) e->aux[e->n_aux++] = sp.streams[gi];
+            e->probe_tried = sp.tried, e->probe_same_queue = sp.same_queue, e->probe_same_pipe = sp.same_pipe, e->probe_second_best = sp.second_best;
+            e->probe_assumed = sp.assumed;
+            e->probe_pooled = true;
+            e->next_aux = 0;
+            e->side_for = m;
+            e->side_ready = true;
+            e->side_pooled = true;
+            return TC_E_OK;
+        }
+    }
+    e->probe_pooled = false;
     std::vector<hipStream_t> good, bad, soft;
     e->probe_tried = e->probe_same_queue = e->probe_same_pipe = e->probe_second_best = 0;
     e->probe_assumed = assume;
@@ -456,9 +545,24 @@ int ensure_side_streams(tc_engine* e) {
     if (e->key_mode && !good.empty()) e->key_stream = good[gi++];
     e->n_aux = 0;
     for (; gi < good.size() && e->n_aux < (uint32_t)AUX_MAX; ++gi) e->aux[e->n_aux++] = good[gi];
+    for (; gi < good.size(); ++gi) (void)hipStreamDestroy(good[gi]); // (more than an engine uses)
     e->next_aux = 0;
     e->side_for = m;
     e->side_ready = true;
+    if (pool_on && good.size() >= want && want != 0) { // the full set: worth keeping for the engines to come
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        bool have = false;
+        for (const SidePool& sp : g_side_pools) have = have || (sp.device == e->device && sp.main == m && sp.priority == e->aux_priority);
+        if (!have) {
+            const bool owned = m == e->own_stream && !e->user_stream;
+            SidePool sp{e->device, m, owned, e->aux_priority, {}, 1u, e->probe_tried, e->probe_same_queue, e->probe_same_pipe, e->probe_second_best, assume};
+            if (owned) e->own_pooled = true; // (the main stream stays with the set when this engine goes)
+            if (e->key_stream) sp.streams.push_back(e->key_stream);
+            for (uint32_t k = 0; k < e->n_aux; ++k) sp.streams.push_back(e->aux[k]);
+            g_side_pools.push_back(sp);
+            e->side_pooled = true;
+        }
+    }
     return TC_E_OK; // n_aux == 0: no free hardware queue, TC_B_INPUTS_READY batches run in order on the main stream
 }
 
@@ -505,11 +609,9 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     (void)hipSetDevice(e->device);
     if (e->user_stream) (void)hipStreamSynchronize(e->user_stream);
     if (e->own_stream) (void)hipStreamSynchronize(e->own_stream);
-    for (hipStream_t a : e->aux)
-        if (a) {
-            (void)hipStreamSynchronize(a);
-            (void)hipStreamDestroy(a);
-        }
+    hipStream_t key_stream_was = e->key_stream;
+    release_side_streams(e); // (back to the pool, or destroyed)
+    (void)key_stream_was;
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
@@ -523,10 +625,6 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
                     e->stage.out[1], e->stage.out[2], e->stage.out[3], e->stage.status, e->stage.result4, e->stage.decisions, e->stage.order};
     for (void* p : ptrs)
         if (p) (void)hipFree(p);
-    if (e->key_stream) {
-        (void)hipStreamSynchronize(e->key_stream);
-        (void)hipStreamDestroy(e->key_stream);
-    }
     if (e->bp_gate_host) (void)hipHostFree(e->bp_gate_host);
     if (e->host_results) (void)hipHostFree(e->host_results);
     if (e->bounce) (void)hipHostFree(e->bounce);
@@ -553,7 +651,13 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (hipEvent_t ev : e->prof_ev) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->async_done) (void)hipEventDestroy(ev);
     for (hipEvent_t ev : e->async_pool) (void)hipEventDestroy(ev);
-    if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
+    if (e->own_stream && e->own_pooled) { // back to the pool with its grouping streams: the next engine without a stream of the caller's takes the set
+        std::lock_guard<std::mutex> lk(g_side_mu);
+        for (SidePool& sp : g_side_pools)
+            if (sp.main_owned && sp.main == e->own_stream) sp.users = 0;
+    } else if (e->own_stream) {
+        (void)hipStreamDestroy(e->own_stream);
+    }
     delete e;
 }
 
@@ -842,6 +946,7 @@ extern "C" int tc_engine_info_get(tc_engine* e, tc_engine_info* out) {
     r.batches = e->batches;
     r.hot_slots = e->hot.slots.size();
     r.hot_batches = e->hot.batches_hot;
+    r.probes_pooled = (probed && e->probe_pooled) ? 1u : 0u;
     *out = r;
     return TC_E_OK;
 }

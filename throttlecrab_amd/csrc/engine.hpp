@@ -82,6 +82,7 @@ struct tc_engine {
     // queues (4 by default), and a main stream that shares a queue with an auxiliary stream
     // serialises the pipeline (measured: 12 -> 5.7 G decisions/s), so no stream is created idly.
     hipStream_t own_stream = nullptr;
+    bool own_pooled = false;             // own_stream belongs to a set of the process's stream pool (engine.hip): never destroyed, handed on
     hipStream_t user_stream = nullptr;
     uint64_t capacity = 0, max_batch = 0;
     uint32_t cfg_flags = 0;
@@ -152,6 +153,8 @@ struct tc_engine {
     // what the last probe found (tc_engine_info_get)
     uint32_t probe_tried = 0, probe_same_queue = 0, probe_same_pipe = 0, probe_second_best = 0;
     bool probe_assumed = false;
+    bool probe_pooled = false;           // the streams came from the process's pool: the verdict of an earlier probe, re-checked (tc_engine_info: probes_pooled)
+    bool side_pooled = false;            // ... and go back to it when the engine lets go of them
     uint32_t last_grouping_path = 0;     // 1 range path, 2 LSD passes, 3 bucket path, 4 no grouping (small batch / unique slots), 5 range path with hot slots peeled
     uint32_t next_set = 0;
     uint32_t sort_max_tiles = 0;
@@ -202,7 +205,7 @@ struct tc_engine {
     uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
     bool general_earlier = true;     // TCGPU_GENERAL_EARLIER=0: k_eval_general without the earlier-state rule (A/B)
     bool general_runs = true;        // TCGPU_GENERAL_RUNS=0: k_eval_general settles one allowed request per round (A/B)
-    bool debug_nostore = false; // TCGPU_DEBUG_NO_DECISION_STORE=1: MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)
+    bool debug_nostore = false; // builds with -DTCGPU_DEBUG_KNOBS only: TCGPU_DEBUG_NO_DECISION_STORE=1, MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)
     uint32_t loaded_seq = 0;
     // bounds over the registered rate plans (for all_runs_regular)
     int64_t cls_min_ei = INT64_MAX, cls_max_ei = 0, cls_min_dvt = INT64_MAX, cls_max_dvt = 0;

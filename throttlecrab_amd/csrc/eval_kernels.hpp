@@ -28,7 +28,11 @@ constexpr uint32_t F_PREFILL1 = 32u;     // ... to 1: the evaluation only stores
 constexpr uint32_t F_DEBUG_NO_ANNOUNCE = 64u; // tc_debug_break_wait: row 0 never announces (the watchdog's test)
 constexpr uint32_t F_NO_EARLIER = 128u;  // TCGPU_GENERAL_EARLIER=0 (A/B): k_eval_general without the earlier-state rule
 constexpr uint32_t F_GENERAL_RUNS = 256u; // k_eval_general settles a run of allowed requests in one round (TCGPU_GENERAL_RUNS=0: one per round)
-constexpr uint32_t F_DEBUG_NOSTORE = 8u; // measurement only (TCGPU_DEBUG_NO_DECISION_STORE): the lean kernel skips its decision bytes
+#ifdef TCGPU_DEBUG_KNOBS
+constexpr uint32_t F_DEBUG_NOSTORE = 8u; // measurement builds only (make DEBUG_KNOBS=1 + TCGPU_DEBUG_NO_DECISION_STORE=1): the lean kernel skips its decision bytes
+#else
+constexpr uint32_t F_DEBUG_NOSTORE = 0u; // (round 6: the shipped library has no switch that corrupts results -- the test compiles away)
+#endif
 constexpr uint32_t MAX_CLASSES = 65536;  // rate_id is u16; id 0 = "not registered"
 constexpr uint32_t TOPK_MAX = 10000;     // tc_top_denied: MAX_DENIED_KEYS_LIMIT (throttlecrab-server/src/metrics.rs:17)
 
@@ -1026,10 +1030,6 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     const int pend = lb ? lane + __builtin_ctzll(lb) : 63;
     const unsigned long long piece =
         (pend == 63 ? ~0ull : ((2ull << pend) - 1ull)) & ~((1ull << pstart) - 1ull);
-    if (p.heavy_min != 0u && is_last && slot < p.capacity) { // (round 6: heavy_note)
-        const uint32_t first = continued ? run_start_of(sorted, k - (uint32_t)lane, slot) : k - (uint32_t)(lane - pstart);
-        if (k - first + 1u >= p.heavy_min) heavy_note(p, slot, k - first + 1u);
-    }
 
     // State my piece starts from: the resident cell, or what the previous wave hands over.
     // A hot key's segment crosses hundreds of waves; waiting wave by wave would serialise

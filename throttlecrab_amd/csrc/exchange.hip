@@ -231,6 +231,8 @@ extern "C" int tc_exchange_evaluate(tc_exchange* x, uint64_t step, const tc_batc
     const uint64_t cap = e->max_batch;
     // (checked BEFORE any chunk is issued -- ADVICE r4: found while building the second chunk, the first had already changed
     // the resident state and the step's completion was never recorded)
+    //  tmpl->n, when given, is the capacity of the caller's output arrays
+    if (tmpl->n != 0 && total > tmpl->n) return fail(e, TC_E_INVALID_ARG, "tc_exchange_evaluate: the step is larger than the output arrays (tmpl->n)");
     if (total > cap && (b.flags & TC_B_GROUPED_OUTPUT)) return fail(e, TC_E_UNSUPPORTED, "tc_exchange_evaluate: grouped output of a step larger than max_batch");
     if (total > cap && b.allowed_bits) return fail(e, TC_E_UNSUPPORTED, "tc_exchange_evaluate: allowed_bits of a step larger than max_batch");
     // cut the concatenation into chunks of at most max_batch requests (the common case: one chunk, nothing copied)

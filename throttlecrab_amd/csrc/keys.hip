@@ -130,6 +130,12 @@ static int forget_errors(tc_engine* e, uint64_t k) {
     TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
+// ... but were not after all (the sweep or the second pass failed with something other than a full table -- the first
+// pass's Internal statuses stand, and so must their count)
+static void remember_errors(tc_engine* e, uint64_t k) {
+    hipLaunchKernelGGL(mk::k_counter_add, dim3(1), dim3(1), 0, cur_stream(e), e->counters + (TC_CNT_COUNT + 1) + 2, (unsigned long long)k);
+    (void)hipGetLastError();
+}
 
 // TC_B_ASYNC key batch: key arena and offsets are staged on the key stream (SDMA), resolved there, grouped on
 // an auxiliary stream, evaluated in order, results copied back behind the evaluation; nothing waits.  A full
@@ -296,7 +302,13 @@ static int retry_rejected(tc_engine* e, const tc_batch& b, bool small) {
     if (b.now_ns)
         for (uint32_t i : idx) newest = std::max(newest, b.now_ns[i]);
     TC_TRY(forget_errors(e, m));
-    TC_TRY(auto_sweep_for_retry(e, newest));
+    {
+        const int rcs = auto_sweep_for_retry(e, newest);
+        if (rcs != TC_E_OK) {
+            remember_errors(e, m);
+            return rcs;
+        }
+    }
     std::vector<uint8_t> arena;
     std::vector<uint32_t> off(m + 1, 0u);
     for (size_t k = 0; k < m; ++k) {
@@ -338,7 +350,10 @@ static int retry_rejected(tc_engine* e, const tc_batch& b, bool small) {
     e->as.in_retry = true;
     const int rc = tc_rate_limit_batch_keys(e, &sub);
     e->as.in_retry = false;
-    if (rc != TC_E_OK && rc != TC_E_TABLE_FULL) return rc; // (nothing more was applied; the first pass's results stand)
+    if (rc != TC_E_OK && rc != TC_E_TABLE_FULL) { // (nothing more was applied; the first pass's results stand)
+        remember_errors(e, m);
+        return rc;
+    }
     e->batches--; // one batch, as far as the caller is concerned
     for (size_t k = 0; k < m; ++k) {
         const uint32_t i = idx[k];
@@ -455,11 +470,16 @@ extern "C" int tc_rate_limit(tc_engine* e, const uint8_t* key, size_t key_len, i
             // where the reference's map would have grown: drop what has expired by now and apply the request once more
             // (the first attempt touched no state and was counted as an error: taken back)
             TC_TRY(forget_errors(e, 1));
-            TC_TRY(auto_sweep_for_retry(e, now_ns));
+            const int rcs = auto_sweep_for_retry(e, now_ns);
+            if (rcs != TC_E_OK) {
+                remember_errors(e, 1);
+                return rcs;
+            }
             e->as.in_retry = true;
             const int rc2 = tc_rate_limit(e, key, key_len, max_burst, count_per_period, period, quantity, now_ns, out);
             e->as.in_retry = false;
             e->batches--;
+            if (rc2 != TC_E_OK && rc2 != TC_E_TABLE_FULL) remember_errors(e, 1); // (the second attempt was not applied, nor counted)
             return rc2;
         }
         return fail(e, TC_E_TABLE_FULL, "key table full: the key got status Internal (raise capacity or sweep)");

@@ -133,6 +133,10 @@ extern "C" int tc_shard_evaluate(tc_shard* x, uint64_t step, const tc_batch* tmp
     b.flags |= TC_B_DEVICE_PTRS | TC_B_INPUTS_READY;
     b.n_segments = 0;
     const uint64_t cap = e->max_batch;
+    // tmpl->n, when given, is what the caller's output arrays hold: a skewed step whose share is larger must not write past them
+    // (the share comes from the router's count, nothing compared it with the arrays) -- checked before any chunk is issued
+    if (tmpl->n != 0 && mine > tmpl->n)
+        return fail(e, TC_E_INVALID_ARG, "tc_shard_evaluate: this rank's share of the step is larger than the output arrays (tmpl->n)");
     if (mine > cap && ((b.flags & TC_B_GROUPED_OUTPUT) || b.allowed_bits))
         return fail(e, TC_E_UNSUPPORTED, "tc_shard_evaluate: grouped output / allowed_bits of a share larger than max_batch");
     for (uint64_t at = 0; at < mine; at += cap) {

@@ -411,8 +411,15 @@ class ShardRank:
         b, res, keep = self.eng._prepare(n_out, True, None, None, None, quantity, now_ns, True, False, want, res, inputs_ready=True, outputs_idle=idle)
         return b, keep
 
+    def _hold_ids(self, step: int, ids):
+        #  the router of `step` reads `ids` later, on one of the engine's grouping streams: a tensor the caller drops
+        # must not go back to torch's allocator before that -- one reference per ring entry, as the C side keeps its columns
+        if not hasattr(self, "_ids_ring"):
+            self._ids_ring = {}
+        self._ids_ring[step % 64] = ids
+
     def route(self, step: int, global_ids):
-        self._keep_ids = global_ids
+        self._hold_ids(step, global_ids)
         self.eng._check(self._lib.tc_shard_route(self._h, step, global_ids.data_ptr(), global_ids.numel()))
 
     def evaluate(self, step: int, now_ns: int, outs, **kw) -> int:
@@ -426,7 +433,7 @@ class ShardRank:
         """route(step + route_ahead, ids_ahead) + evaluate(step): ONE library call -> requests this rank decided"""
         b, keep = self._template(now_ns, outs, step, **kw)
         decided = C.c_uint64(0)
-        self._keep_ids = ids_ahead
+        self._hold_ids(step + route_ahead, ids_ahead)
         self.eng._check(self._lib.tc_shard_step(self._h, step, ids_ahead.data_ptr() if ids_ahead is not None else None,
                                                 ids_ahead.numel() if ids_ahead is not None else 0, route_ahead, C.byref(b), C.byref(decided)))
         self._keep = keep

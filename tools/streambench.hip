@@ -22,6 +22,18 @@ __global__ __launch_bounds__(BS, 8) void k_gather(long long* __restrict__ tab, c
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) tab[s[j]] = v[j] + add;
 }
+// round 6: the same gathers and stores over a 4-BYTE column (a TAT kept as a 32-bit delta against a per-engine
+// epoch would make the column 40 MB for 10 M keys instead of 80): how much of the bare pattern's time is bytes?
+__global__ __launch_bounds__(BS, 8) void k_gather4(unsigned* __restrict__ tab, const unsigned* __restrict__ slots, unsigned n, unsigned add) {
+    const unsigned base = blockIdx.x * BS * ITEMS;
+    unsigned s[ITEMS], v[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) s[j] = slots[min(base + j * BS + threadIdx.x, n - 1)];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) v[j] = tab[s[j]];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) tab[s[j]] = v[j] + add;
+}
 template <int LDS_WORDS>
 __global__ __launch_bounds__(BS) void k_stream(long long* __restrict__ tab, const unsigned* __restrict__ slots, unsigned n, long long add, unsigned cap) {
     __shared__ long long win[LDS_WORDS];
@@ -62,20 +74,24 @@ int main(int argc, char** argv) {
     hipEventCreate(&a);
     hipEventCreate(&b);
     const dim3 grid(n / (BS * ITEMS));
-    for (int var = 0; var < 3; ++var) {
+    unsigned* tab4;
+    hipMalloc(&tab4, (size_t)cap * 4 + 1024);
+    hipMemset(tab4, 0, (size_t)cap * 4 + 1024);
+    for (int var = 0; var < 4; ++var) {
         float best = 1e9, sum = 0;
         for (int rep = 0; rep < 12; ++rep) {
             hipEventRecord(a);
             if (var == 0) hipLaunchKernelGGL(k_gather, grid, dim3(BS), 0, 0, tab, sl, n, 1LL);
             else if (var == 1) hipLaunchKernelGGL(k_stream<6144>, grid, dim3(BS), 0, 0, tab, sl, n, 1LL, cap);
-            else hipLaunchKernelGGL(k_stream<5120>, grid, dim3(BS), 0, 0, tab, sl, n, 1LL, cap);
+            else if (var == 2) hipLaunchKernelGGL(k_stream<5120>, grid, dim3(BS), 0, 0, tab, sl, n, 1LL, cap);
+            else hipLaunchKernelGGL(k_gather4, grid, dim3(BS), 0, 0, tab4, sl, n, 1u);
             hipEventRecord(b);
             hipEventSynchronize(b);
             float ms;
             hipEventElapsedTime(&ms, a, b);
             if (rep >= 2) best = std::min(best, ms), sum += ms;
         }
-        printf("%s: best %.1f us, mean %.1f us\n", var == 0 ? "gather (8 blocks/CU)          " : (var == 1 ? "stream via 48 KB LDS (3 blocks/CU)" : "stream via 40 KB LDS (4 blocks/CU)"), best * 1e3,
+        printf("%s: best %.1f us, mean %.1f us\n", var == 0 ? "gather, 8-byte column (8 blocks/CU)" : (var == 1 ? "stream via 48 KB LDS (3 blocks/CU)" : (var == 2 ? "stream via 40 KB LDS (4 blocks/CU)" : "gather, 4-BYTE column (8 blocks/CU)")), best * 1e3,
                sum / 10 * 1e3);
     }
     return 0;
