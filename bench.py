@@ -641,18 +641,33 @@ def abi_shape_bench(a, dev):
             pb = {c: eng.host_alloc(batches[k][c].size, batches[k][c].dtype) for c in ("key_bytes", "key_off") + ABI_COLS}
             for c in pb:
                 pb[c][:] = batches[k][c]
+            # ... and the same requests as the shims send them since round 6 (TC_B_PLAN_DICT: the distinct triples once, a 16-bit
+            # index per request, the quantities as u32 -- rust/throttlecrab-gpu batch_chunk, throttlecrab_gpu.hpp submit_batch)
+            dic, pid = t.Engine.encode_plans(batches[k]["max_burst"], batches[k]["count_per_period"], batches[k]["period"])
+            for name, arr in (("plan_dict", dic.reshape(-1)), ("plan_id", pid), ("quantity32", batches[k]["quantity"].astype(np.uint32))):
+                pb[name] = eng.host_alloc(arr.size, arr.dtype)
+                pb[name][:] = arr
             pinned.append((pb, t.BatchResult(decisions=eng.host_alloc(4 * n, np.int64))))
-        for mode in ("sync_pinned", "async_pinned_ring4"):
+        leg["bytes_in_per_request_dict"] = sum(int(pinned[0][0][c].nbytes) for c in ("key_bytes", "key_off", "now_ns", "plan_id", "quantity32")) / n
+
+        def call(pb, r_, asy, dict_form):
+            if dict_form:
+                return eng.rate_limit_batch_keys(pb["key_bytes"], pb["key_off"], now_ns=pb["now_ns"], plan_dict=(pb["plan_dict"], pb["plan_id"], pb["quantity32"]),
+                                                 want=("decisions",), out=r_, async_=asy)
+            return eng.rate_limit_batch_keys(pb["key_bytes"], pb["key_off"], **{c: pb[c] for c in ABI_COLS}, want=("decisions",), out=r_, async_=asy)
+
+        for mode in ("sync_pinned", "async_pinned_ring4", "sync_pinned_dict", "async_pinned_ring4_dict"):
             asy = mode.startswith("async")
+            dict_form = mode.endswith("_dict")
             # warm: a freshly pinned array stalls the submitting thread for 5-7 ms the first few times a transfer touches it
             # (tools/abi_stall.py: calls 1, 5, 11, 19 of a ring of 4 sets, then never again) -- a server's staging buffers live
             # as long as the server; here every leg pins new ones, so each set is used six times before the clock starts
-            n_warm = (6 if n >= (1 << 18) else 16) * distinct if mode == "sync_pinned" or asy else 0
+            n_warm = (6 if n >= (1 << 18) else 16) * distinct if mode == "sync_pinned" or asy else (2 * distinct if dict_form else 0)
             for i in range(n_warm):
                 pb, r_ = pinned[i % distinct]
                 if asy:
                     eng.wait_batches(distinct - 1)
-                eng.rate_limit_batch_keys(pb["key_bytes"], pb["key_off"], **{c: pb[c] for c in ABI_COLS}, want=("decisions",), out=r_, async_=asy)
+                call(pb, r_, asy, dict_form)
             eng.wait_batches(0)
             for i in range(n_warm):
                 k = i % distinct
@@ -662,7 +677,7 @@ def abi_shape_bench(a, dev):
                 pb, r_ = pinned[i % distinct]
                 if asy:
                     eng.wait_batches(distinct - 1)  # the oldest set of the ring is free again
-                eng.rate_limit_batch_keys(pb["key_bytes"], pb["key_off"], **{c: pb[c] for c in ABI_COLS}, want=("decisions",), out=r_, async_=asy)
+                call(pb, r_, asy, dict_form)
             if asy:
                 eng.wait_batches(0)
             dt = time.perf_counter() - t0
@@ -1303,7 +1318,7 @@ def main():
             def abi_shape():
                 ab = abi_shape_bench(a, dev)
                 detail["abi_shape"] = ab
-                result["abi_shape"] = {k: {m: _pick(v[m], ("value", "us_per_call")) for m in ("sync_pageable", "sync_pinned", "async_pinned_ring4")}
+                result["abi_shape"] = {k: {m: _pick(v[m], ("value", "us_per_call")) for m in ("sync_pageable", "sync_pinned", "async_pinned_ring4", "sync_pinned_dict", "async_pinned_ring4_dict")}
                                        for k, v in ab.items() if isinstance(v, dict) and "requests" in v}
                 result["abi_shape"]["verified"] = ab["verified"]["ok"]
                 verified["abi_shape"] = ab["verified"]

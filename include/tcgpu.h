@@ -152,6 +152,17 @@ struct tc_decision;
                                      * correct but waits for its transfers.  Results are those of the in-order
                                      * sequence of calls, as always. */
 
+#define TC_B_PLAN_DICT 0x80u         /* Round 6: the (max_burst, count_per_period, period) of every request as a 16-bit index into a
+                                      * DICTIONARY the batch carries: plan_dict[n_plans][3] + plan_id[n] replace the three 8-byte
+                                      * columns (which must be NULL), and quantity32[n], if given, replaces `quantity` -- 6 bytes per
+                                      * request instead of 32.  A server's requests carry a handful of distinct triples; the
+                                      * reference's signature rate_limit(key, max_burst, count_per_period, period, quantity, now)
+                                      * (rate_limiter.rs:102-110) stays what the SHIMS take (Rust rate_limit_batch(&[Request]), the
+                                      * C++ RateLimiter, the actor): they encode, falling back to the wide columns for a batch of more
+                                      * than 65 536 distinct triples.  Same results as the wide form, request by request.  An index
+                                      * >= n_plans decodes to (0, 0, 0): status TC_INVALID_RATE_LIMIT.  Host- and device-pointer
+                                      * batches, slots and keys; not with TC_B_REGISTERED_PARAMS. */
+
 typedef struct tc_batch {
     uint32_t struct_size; /* = sizeof(tc_batch) */
     uint32_t flags;       /* TC_B_* */
@@ -199,6 +210,13 @@ typedef struct tc_batch {
     uint32_t reserved_seg;
     const uint32_t* const* seg_slot; /* host array [n_segments] of device pointers */
     const uint32_t* seg_n;           /* host array [n_segments] */
+
+    /* TC_B_PLAN_DICT (round 6; a tc_batch of an older struct_size simply ends before these) */
+    const int64_t* plan_dict;   /* [n_plans][3]: max_burst, count_per_period, period (seconds) */
+    const uint16_t* plan_id;    /* [n] index into plan_dict */
+    const uint32_t* quantity32; /* [n] or NULL: the quantities as u32 (then `quantity` must be NULL) */
+    uint32_t n_plans;           /* 1 .. 65536 */
+    uint32_t reserved_dict;
 } tc_batch;
 #define TC_MAX_SEGMENTS 64
 

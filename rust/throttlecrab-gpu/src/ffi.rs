@@ -34,6 +34,7 @@ pub const TC_B_INPUTS_READY: u32 = 0x8;
 pub const TC_B_GROUPED_OUTPUT: u32 = 0x10;
 pub const TC_B_ASYNC: u32 = 0x20;
 pub const TC_B_OUTPUTS_IDLE: u32 = 0x40;
+pub const TC_B_PLAN_DICT: u32 = 0x80;
 
 pub const TC_ROUTE_AHEAD: u32 = 0x1;
 pub const TC_ROUTE_NO_READERS: u32 = 0x2;
@@ -200,6 +201,12 @@ pub struct tc_batch {
     pub reserved_seg: u32,
     pub seg_slot: *const *const u32,
     pub seg_n: *const u32,
+    // TC_B_PLAN_DICT (round 6)
+    pub plan_dict: *const i64,
+    pub plan_id: *const u16,
+    pub quantity32: *const u32,
+    pub n_plans: u32,
+    pub reserved_dict: u32,
 }
 
 #[repr(C)]

@@ -236,6 +236,13 @@ impl GpuRateLimiter {
         self.staging.reserve(n, key_bytes.max(1));
         let st = &mut self.staging;
         let mut at = 0usize;
+        // Round 6, TC_B_PLAN_DICT: a server's requests carry a handful of distinct (max_burst, count_per_period, period) triples.
+        // The shim -- not the caller: `rate_limit_batch(&[Request])` keeps the reference's shape -- sends each triple once, in a
+        // dictionary, and a 16-bit index per request; quantities that fit go as u32.  6 bytes per request cross PCIe instead of
+        // 32.  More than 65 536 distinct triples in one chunk, or a quantity outside u32: the wide columns, as before.
+        st.plans.clear();
+        st.plan_of.clear();
+        let mut compact = true;
         unsafe {
             *st.off.ptr = 0;
             for (i, r) in reqs.iter().enumerate() {
@@ -247,19 +254,37 @@ impl GpuRateLimiter {
                 *st.period.ptr.add(i) = r.period;
                 *st.qty.ptr.add(i) = r.quantity;
                 *st.now.ptr.add(i) = ns(r.now);
+                if compact {
+                    let triple = (r.max_burst, r.count_per_period, r.period);
+                    let next = st.plan_of.len();
+                    let id = *st.plan_of.entry(triple).or_insert(next);
+                    if id == next {
+                        st.plans.extend_from_slice(&[triple.0, triple.1, triple.2]);
+                    }
+                    compact = id < 65536 && r.quantity >= 0 && r.quantity <= u32::MAX as i64;
+                    if compact {
+                        *st.plan_id.ptr.add(i) = id as u16;
+                        *st.qty32.ptr.add(i) = r.quantity as u32;
+                    }
+                }
+            }
+            if compact {
+                st.dict.reserve(st.plans.len());
+                std::ptr::copy_nonoverlapping(st.plans.as_ptr(), st.dict.ptr, st.plans.len());
             }
         }
+        let null64: *const i64 = std::ptr::null();
         let b = ffi::tc_batch {
             struct_size: std::mem::size_of::<ffi::tc_batch>() as u32,
-            flags: 0,
+            flags: if compact { ffi::TC_B_PLAN_DICT } else { 0 },
             n: n as u64,
             slot: std::ptr::null(),
             key_bytes: st.arena.ptr,
             key_off: st.off.ptr,
-            max_burst: st.burst.ptr,
-            count_per_period: st.count.ptr,
-            period: st.period.ptr,
-            quantity: st.qty.ptr,
+            max_burst: if compact { null64 } else { st.burst.ptr },
+            count_per_period: if compact { null64 } else { st.count.ptr },
+            period: if compact { null64 } else { st.period.ptr },
+            quantity: if compact { null64 } else { st.qty.ptr },
             now_ns: st.now.ptr,
             max_burst_scalar: 0,
             count_per_period_scalar: 0,
@@ -280,6 +305,11 @@ impl GpuRateLimiter {
             reserved_seg: 0,
             seg_slot: std::ptr::null(),
             seg_n: std::ptr::null(),
+            plan_dict: if compact { st.dict.ptr } else { null64 },
+            plan_id: if compact { st.plan_id.ptr } else { std::ptr::null() },
+            quantity32: if compact { st.qty32.ptr } else { std::ptr::null() },
+            n_plans: if compact { (st.plans.len() / 3) as u32 } else { 0 },
+            reserved_dict: 0,
         };
         let rc = unsafe { ffi::tc_rate_limit_batch_keys(self.store.e, &b) };
         if rc != 0 && rc != ffi::TC_E_TABLE_FULL {
@@ -339,12 +369,19 @@ struct Staging {
     qty: Pinned<i64>,
     now: Pinned<i64>,
     dec: Pinned<ffi::tc_decision>,
+    // TC_B_PLAN_DICT: the chunk's dictionary (pinned), its 16-bit plan ids and u32 quantities; the encoder's map
+    dict: Pinned<i64>,
+    plan_id: Pinned<u16>,
+    qty32: Pinned<u32>,
+    plans: Vec<i64>,
+    plan_of: std::collections::HashMap<(i64, i64, i64), usize>,
 }
 
 impl Staging {
-    const fn new() -> Self {
+    fn new() -> Self {
         Staging { arena: Pinned::new(), off: Pinned::new(), burst: Pinned::new(), count: Pinned::new(), period: Pinned::new(), qty: Pinned::new(),
-                  now: Pinned::new(), dec: Pinned::new() }
+                  now: Pinned::new(), dec: Pinned::new(), dict: Pinned::new(), plan_id: Pinned::new(), qty32: Pinned::new(), plans: Vec::new(),
+                  plan_of: std::collections::HashMap::new() }
     }
     fn reserve(&mut self, n: usize, key_bytes: usize) {
         self.arena.reserve(key_bytes);
@@ -355,5 +392,7 @@ impl Staging {
         self.qty.reserve(n);
         self.now.reserve(n);
         self.dec.reserve(n);
+        self.plan_id.reserve(n);
+        self.qty32.reserve(n);
     }
 }

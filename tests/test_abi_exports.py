@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), f"libtcgpu.so does not export {name}"
     assert set(_lib.SYMBOLS) == set(declared), set(_lib.SYMBOLS) ^ set(declared)
     assert lib.tc_abi_version() == 1
-    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 10 * 8 + 8 + 16  # incl. result4, decisions, order, segments
+    assert ctypes.sizeof(_lib.tc_batch) == 8 + 8 + 8 * 8 + 5 * 8 + 10 * 8 + 8 + 16 + 3 * 8 + 8  # incl. result4, decisions, order, segments, the plan dictionary
     assert ctypes.sizeof(_lib.tc_config) == 40
 
 
@@ -95,7 +95,8 @@ def test_python_constants_match_the_header():
     assert L.tc_batch.decisions.offset == L.tc_batch.result4.offset + 8
     assert L.tc_batch.order.offset == L.tc_batch.decisions.offset + 8
     assert L.tc_batch.n_segments.offset == L.tc_batch.order.offset + 8
-    assert C.sizeof(L.tc_batch) == L.tc_batch.order.offset + 8 + 8 + 16
+    assert L.tc_batch.plan_dict.offset == L.tc_batch.order.offset + 8 + 8 + 16 and L.tc_batch.n_plans.offset == L.tc_batch.plan_dict.offset + 24
+    assert C.sizeof(L.tc_batch) == L.tc_batch.plan_dict.offset + 24 + 8
 
 
 def test_the_shipped_library_has_no_switch_that_corrupts_results():

@@ -21,6 +21,7 @@ TC_CFG_TRACK_DENIED = 0x2
 TC_CFG_FIXED_PARAMS = 0x4
 TC_B_DEVICE_PTRS, TC_B_REGISTERED_PARAMS, TC_B_UNIQUE_SLOTS, TC_B_INPUTS_READY, TC_B_GROUPED_OUTPUT = 0x1, 0x2, 0x4, 0x8, 0x10
 TC_B_ASYNC = 0x20
+TC_B_PLAN_DICT = 0x80
 TC_B_OUTPUTS_IDLE = 0x40
 TC_ROUTE_AHEAD = 0x1
 TC_ROUTE_NO_READERS = 0x2
@@ -47,7 +48,8 @@ class tc_batch(C.Structure):
                 ("allowed", C.c_void_p), ("allowed_bits", C.c_void_p), ("limit", C.c_void_p),
                 ("remaining", C.c_void_p), ("reset_after_ns", C.c_void_p), ("retry_after_ns", C.c_void_p),
                 ("status", C.c_void_p), ("result4", C.c_void_p), ("decisions", C.c_void_p), ("order", C.c_void_p),
-                ("n_segments", C.c_uint32), ("reserved_seg", C.c_uint32), ("seg_slot", C.c_void_p), ("seg_n", C.c_void_p)]
+                ("n_segments", C.c_uint32), ("reserved_seg", C.c_uint32), ("seg_slot", C.c_void_p), ("seg_n", C.c_void_p),
+                ("plan_dict", C.c_void_p), ("plan_id", C.c_void_p), ("quantity32", C.c_void_p), ("n_plans", C.c_uint32), ("reserved_dict", C.c_uint32)]
 
 
 class tc_forward(C.Structure):

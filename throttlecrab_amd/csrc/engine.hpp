@@ -118,6 +118,9 @@ struct tc_engine {
         uint32_t* k_slot = nullptr;                    // key mode: slots resolved for the batch using this set
         uint32_t* h_slot = nullptr;                    // TC_B_ASYNC: the host batch's slot column, staged (lazy)
         int64_t* h_in[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // ... and its request columns (lazy)
+        int64_t* h_dict = nullptr;                     // TC_B_PLAN_DICT: the batch's dictionary, plan ids and u32 quantities as they arrived (lazy)
+        uint16_t* h_plan_id = nullptr;
+        uint32_t* h_q32 = nullptr;
         uint8_t* h_key_bytes = nullptr;                // TC_B_ASYNC key batch: its key arena and offsets, staged (lazy)
         size_t h_key_cap = 0;
         uint32_t* h_key_off = nullptr;
@@ -239,7 +242,11 @@ struct tc_engine {
         tc_decision* decisions = nullptr;
         uint32_t* order = nullptr;
         uint8_t* status = nullptr;
+        int64_t* dict = nullptr;     // TC_B_PLAN_DICT (lazy): 65 536 x 3
+        uint16_t* plan_id = nullptr;
+        uint32_t* q32 = nullptr;
     } stage;
+    std::vector<int64_t> dict_wide[4]; // TC_B_PLAN_DICT batches that take a path without device-side decoding: the wide columns, made on the host
 
     // small host-pointer batches (k_small_batch): one pinned block the kernel reads its inputs from and writes
     // its results to (the caller's arrays are copied in and out by the host)
@@ -407,6 +414,11 @@ struct tc_engine {
 struct HostIn {
     const uint32_t* slot = nullptr;
     const int64_t* col[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; // burst, count, period, quantity, now
+    // TC_B_PLAN_DICT: the first three columns as a dictionary + 16-bit indices, the quantities as u32 (round 6)
+    const int64_t* plan_dict = nullptr;
+    const uint16_t* plan_id = nullptr;
+    const uint32_t* q32 = nullptr;
+    uint32_t n_plans = 0;
 };
 
 // ---- helpers shared by the units (defined in the unit named) ----------------------------------------------------
@@ -455,6 +467,7 @@ inline uint64_t host_bytes_per_request(const tc_batch& b) {
     if (b.key_off && b.key_bytes && b.n) in += 4 + (uint64_t(b.key_off[b.n]) - b.key_off[0]) / b.n;
     for (const void* c : {(const void*)b.max_burst, (const void*)b.count_per_period, (const void*)b.period, (const void*)b.quantity, (const void*)b.now_ns})
         in += c ? 8 : 0;
+    if (b.flags & TC_B_PLAN_DICT) in += 2 + (b.quantity32 ? 4 : 0);
     uint64_t out = (b.allowed ? 1 : 0) + (b.status ? 1 : 0) + (b.result4 ? 32 : 0) + (b.decisions ? 32 : 0);
     for (const void* c : {(const void*)b.limit, (const void*)b.remaining, (const void*)b.reset_after_ns, (const void*)b.retry_after_ns}) out += c ? 8 : 0;
     return in + out;
@@ -470,6 +483,16 @@ int wait_own_async(tc_engine* e, size_t mine);
 // host arrays -> device staging on stream s: ONE copy kernel (mk::k_copy_multi) when every source is pinned host memory, else one
 // hipMemcpyAsync each (count <= 8; a failed copy -- tc_debug_fail_copy -- fails the call before anything was applied, as before)
 int stage_in_multi(tc_engine* e, const void* const* src, void* const* dst, const size_t* bytes, uint32_t count, hipStream_t s);
+// TC_B_PLAN_DICT (round 6).  dict_check: the batch's compact columns are consistent (TC_E_INVALID_ARG otherwise);
+// dict_expand_on_host: b's wide columns made on the host (e->dict_wide), the flag cleared -- the paths that do not decode on the
+// device (one-launch small batches, retries); dict_expand_device: a DEVICE-pointer batch's, by a kernel on the engine's stream;
+// stage_compact: host arrays -> device (dict, ids, u32 quantities into the buffers given, allocated on first use) on stream s,
+// then mk::k_expand_plans into out[0..2] (and out[3] if there are u32 quantities)
+int dict_check(tc_engine* e, const tc_batch& b);
+void dict_expand_on_host(tc_engine* e, tc_batch& b);
+int dict_expand_device(tc_engine* e, tc_batch& b);
+int stage_compact(tc_engine* e, const int64_t* dict, uint32_t n_plans, const uint16_t* plan_id, const uint32_t* q32, uint32_t n, hipStream_t s, int64_t*& d_dict,
+                  uint16_t*& d_id, uint32_t*& d_q32, int64_t* const out[4]);
 struct Bounced {
     tc_batch bb;
     struct Out {

@@ -185,6 +185,11 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     d.max_burst = d.count_per_period = d.period = d.quantity = d.now_ns = nullptr;
     HostIn hin;
     hin.col[0] = b.max_burst, hin.col[1] = b.count_per_period, hin.col[2] = b.period, hin.col[3] = b.quantity, hin.col[4] = b.now_ns;
+    if (b.flags & TC_B_PLAN_DICT) {
+        hin.plan_dict = b.plan_dict, hin.plan_id = b.plan_id, hin.q32 = b.quantity32, hin.n_plans = b.n_plans;
+        d.flags &= ~TC_B_PLAN_DICT;
+        d.plan_dict = nullptr, d.plan_id = nullptr, d.quantity32 = nullptr, d.n_plans = 0;
+    }
     if (piped) e->wait_before_sort = e->k_done;
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d, &hin));
@@ -284,8 +289,8 @@ static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
 // turned away once more.  They are exactly the requests whose key got no slot -- every request of such a key, so the
 // sub-batch, in index order, IS the tail of those keys' sequences (keys are independent) -- and they touched no state.
 // `small`: the batch went through k_small_batch (its resolved slots are in the pinned block), else through the pipeline (e->k_slot).
-static int retry_rejected(tc_engine* e, const tc_batch& b, bool small) {
-    const size_t n = b.n;
+static int retry_rejected(tc_engine* e, const tc_batch& b0, bool small) {
+    const size_t n = b0.n;
     std::vector<uint32_t> slots(n);
     if (small) {
         memcpy(slots.data(), e->small_io + e->small_slots_at, n * sizeof(uint32_t));
@@ -293,6 +298,25 @@ static int retry_rejected(tc_engine* e, const tc_batch& b, bool small) {
         TC_HIP(e, hipMemcpyAsync(slots.data(), e->k_slot, n * sizeof(uint32_t), hipMemcpyDeviceToHost, cur_stream(e)));
         TC_HIP(e, hipStreamSynchronize(cur_stream(e)));
     }
+    // (TC_B_PLAN_DICT: the rejected requests go round again in the wide form -- the caller's arrays are only read)
+    std::vector<int64_t> wide[4];
+    tc_batch bw = b0;
+    if (bw.flags & TC_B_PLAN_DICT) {
+        for (int j = 0; j < 3; ++j) wide[j].resize(n);
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t k = bw.plan_id[i];
+            for (int j = 0; j < 3; ++j) wide[j][i] = k < bw.n_plans ? bw.plan_dict[3 * (size_t)k + j] : 0;
+        }
+        bw.max_burst = wide[0].data(), bw.count_per_period = wide[1].data(), bw.period = wide[2].data();
+        if (bw.quantity32) {
+            wide[3].resize(n);
+            for (size_t i = 0; i < n; ++i) wide[3][i] = (int64_t)bw.quantity32[i];
+            bw.quantity = wide[3].data();
+        }
+        bw.flags &= ~TC_B_PLAN_DICT;
+        bw.plan_dict = nullptr, bw.plan_id = nullptr, bw.quantity32 = nullptr, bw.n_plans = 0;
+    }
+    const tc_batch& b = bw;
     std::vector<uint32_t> idx;
     for (size_t i = 0; i < n; ++i)
         if (slots[i] == kt::NO_SLOT) idx.push_back((uint32_t)i);
@@ -385,6 +409,11 @@ extern "C" int tc_rate_limit_batch_keys(tc_engine* e, const tc_batch* bp) {
     if ((b.flags & TC_B_ASYNC) && (b.flags & TC_B_DEVICE_PTRS))
         return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
     TC_HIP(e, hipSetDevice(e->device));
+    // TC_B_PLAN_DICT (round 6; slots.hip): device batches decoded by a kernel here, small host batches on the host
+    TC_TRY(dict_check(e, b));
+    if (!(b.flags & TC_B_PLAN_DICT)) b.plan_dict = nullptr, b.plan_id = nullptr, b.quantity32 = nullptr, b.n_plans = 0;
+    else if (b.flags & TC_B_DEVICE_PTRS) TC_TRY(dict_expand_device(e, b));
+    else if (!(b.flags & TC_B_ASYNC) && b.n <= (uint64_t)SMALL_MAX) dict_expand_on_host(e, b);
     if (!auto_sweep_on(e)) return keys_batch_dispatch(e, b);
     // the engine cleans by itself (tc_set_sweep_policy): maybe_clean_expired in front of the batch, the feed behind it
     const bool dev = (b.flags & TC_B_DEVICE_PTRS) != 0;

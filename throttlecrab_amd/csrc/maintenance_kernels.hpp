@@ -560,6 +560,23 @@ static __global__ __launch_bounds__(1024) void k_heavy_publish(unsigned long lon
     if (threadIdx.x == 0) __hip_atomic_store(&dst[words], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Round 6, TC_B_PLAN_DICT: the batch's dictionary-coded plan column (and its u32 quantities) -> the wide staging columns every
+// evaluation kernel reads.  What the compact form saves is PCIe bytes (6 per request instead of 32); on the device the
+// expansion is 32 B of HBM writes per request, ~10 us per 1 Mi.  An index beyond the dictionary decodes to (0, 0, 0): the
+// request's status becomes TC_INVALID_RATE_LIMIT (rate_limiter.rs:114-117), like any other non-positive triple.
+static __global__ __launch_bounds__(BLOCK) void k_expand_plans(const int64_t* __restrict__ dict, uint32_t n_plans, const uint16_t* __restrict__ id,
+                                                              const uint32_t* __restrict__ q32, uint32_t n, int64_t* __restrict__ burst,
+                                                              int64_t* __restrict__ count, int64_t* __restrict__ period, int64_t* __restrict__ q) {
+    for (uint32_t i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
+        const uint32_t k = id[i];
+        const bool ok = k < n_plans;
+        burst[i] = ok ? dict[3 * (size_t)k] : 0;
+        count[i] = ok ? dict[3 * (size_t)k + 1] : 0;
+        period[i] = ok ? dict[3 * (size_t)k + 2] : 0;
+        if (q32 != nullptr) q[i] = (int64_t)q32[i];
+    }
+}
+
 // Several such copies in ONE launch (blockIdx.y = the segment): the input columns of a synchronous host batch from PINNED memory.
 // Seven hipMemcpyAsync calls on one stream cost ~10-18 us each before the first byte moves (a 4 Ki-request reference-shaped
 // call spent 70 of its 200 us there); one launch reads them all over PCIe side by side.

@@ -38,7 +38,7 @@ static int copy_back_async(tc_engine* e, void* host, const void* dev, size_t byt
 // from pinned arrays takes 77.  Two memcpys by the caller's own thread (a few hundred KB) and the pinned path are cheaper.
 bool bounce_in(tc_engine* e, const tc_batch& b, Bounced& bo) {
     bo.on = false;
-    if (!e->bounce_max || e->fault_countdown || (b.flags & (TC_B_DEVICE_PTRS | TC_B_ASYNC)) || b.n_segments) return false;
+    if (!e->bounce_max || e->fault_countdown || (b.flags & (TC_B_DEVICE_PTRS | TC_B_ASYNC | TC_B_PLAN_DICT)) || b.n_segments) return false;
     const uint64_t n = b.n;
     const size_t key_total = b.key_off ? b.key_off[n] : 0;
     size_t need = 0;
@@ -137,6 +137,64 @@ int stage_in_multi(tc_engine* e, const void* const* src, void* const* dst, const
     }
     for (uint32_t i = 0; i < count; ++i)
         if (bytes[i]) TC_HIP(e, copy_async(e, dst[i], src[i], bytes[i], hipMemcpyHostToDevice, s));
+    return TC_E_OK;
+}
+
+// ---- TC_B_PLAN_DICT (round 6) -----------------------------------------------------------------------------------------------
+int dict_check(tc_engine* e, const tc_batch& b) {
+    if (!(b.flags & TC_B_PLAN_DICT)) return TC_E_OK;
+    if (!b.plan_dict || !b.plan_id || b.n_plans == 0 || b.n_plans > 65536u) return fail(e, TC_E_INVALID_ARG, "TC_B_PLAN_DICT: plan_dict / plan_id / n_plans (1..65536)");
+    if (b.max_burst || b.count_per_period || b.period) return fail(e, TC_E_INVALID_ARG, "TC_B_PLAN_DICT: max_burst / count_per_period / period columns must be NULL");
+    if (b.quantity && b.quantity32) return fail(e, TC_E_INVALID_ARG, "TC_B_PLAN_DICT: quantity and quantity32 are both given");
+    if (b.flags & TC_B_REGISTERED_PARAMS) return fail(e, TC_E_INVALID_ARG, "TC_B_PLAN_DICT: a batch of registered plans carries no plans");
+    return TC_E_OK;
+}
+
+void dict_expand_on_host(tc_engine* e, tc_batch& b) {
+    const uint64_t n = b.n;
+    for (int j = 0; j < 3; ++j) e->dict_wide[j].resize(n);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint32_t k = b.plan_id[i];
+        const bool ok = k < b.n_plans;
+        for (int j = 0; j < 3; ++j) e->dict_wide[j][i] = ok ? b.plan_dict[3 * (size_t)k + j] : 0;
+    }
+    b.max_burst = e->dict_wide[0].data(), b.count_per_period = e->dict_wide[1].data(), b.period = e->dict_wide[2].data();
+    if (b.quantity32) {
+        e->dict_wide[3].resize(n);
+        for (uint64_t i = 0; i < n; ++i) e->dict_wide[3][i] = (int64_t)b.quantity32[i];
+        b.quantity = e->dict_wide[3].data();
+    }
+    b.flags &= ~TC_B_PLAN_DICT;
+    b.plan_dict = nullptr, b.plan_id = nullptr, b.quantity32 = nullptr, b.n_plans = 0;
+}
+
+int dict_expand_device(tc_engine* e, tc_batch& b) {
+    const uint32_t n = (uint32_t)b.n;
+    hipStream_t s = cur_stream(e);
+    for (int j = 0; j < (b.quantity32 ? 4 : 3); ++j) TC_TRY(stage_need(e, e->stage.in[j], e->max_batch));
+    // (the engine's staging columns: whatever read them last was enqueued on this stream before)
+    hipLaunchKernelGGL(mk::k_expand_plans, dim3(std::min<uint32_t>(nblocks(n), 2048u)), dim3(BLOCK), 0, s, b.plan_dict, b.n_plans, b.plan_id, b.quantity32, n, e->stage.in[0],
+                       e->stage.in[1], e->stage.in[2], e->stage.in[3]);
+    TC_HIP(e, hipGetLastError());
+    b.max_burst = e->stage.in[0], b.count_per_period = e->stage.in[1], b.period = e->stage.in[2];
+    if (b.quantity32) b.quantity = e->stage.in[3];
+    b.flags &= ~TC_B_PLAN_DICT;
+    b.plan_dict = nullptr, b.plan_id = nullptr, b.quantity32 = nullptr, b.n_plans = 0;
+    return TC_E_OK;
+}
+
+int stage_compact(tc_engine* e, const int64_t* dict, uint32_t n_plans, const uint16_t* plan_id, const uint32_t* q32, uint32_t n, hipStream_t s, int64_t*& d_dict,
+                  uint16_t*& d_id, uint32_t*& d_q32, int64_t* const out[4]) {
+    TC_TRY(stage_need(e, d_dict, (size_t)65536 * 3));
+    TC_TRY(stage_need(e, d_id, e->max_batch));
+    if (q32) TC_TRY(stage_need(e, d_q32, e->max_batch));
+    const void* src[3] = {dict, plan_id, q32};
+    void* dst[3] = {d_dict, d_id, d_q32};
+    const size_t bytes[3] = {(size_t)n_plans * 3 * sizeof(int64_t), (size_t)n * sizeof(uint16_t), q32 ? (size_t)n * sizeof(uint32_t) : 0};
+    TC_TRY(stage_in_multi(e, src, dst, bytes, 3, s)); // (one copy launch from pinned arrays, else a copy each)
+    hipLaunchKernelGGL(mk::k_expand_plans, dim3(std::min<uint32_t>(nblocks(n), 2048u)), dim3(BLOCK), 0, s, (const int64_t*)d_dict, n_plans, (const uint16_t*)d_id,
+                       q32 ? (const uint32_t*)d_q32 : (const uint32_t*)nullptr, n, out[0], out[1], out[2], out[3]);
+    TC_HIP(e, hipGetLastError());
     return TC_E_OK;
 }
 
@@ -604,6 +662,13 @@ static int stage_host_inputs(tc_engine* e, tc_engine::SortSet& ss, const HostIn&
         *dst[j] = ss.h_in[j];
     }
     if (c_n) TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, st));
+    if (hin.plan_id) { // TC_B_PLAN_DICT: the compact columns cross PCIe, the wide ones are made here
+        for (int j = 0; j < (hin.q32 ? 4 : 3); ++j)
+            if (!ss.h_in[j]) TC_HIP(e, hipMalloc(&ss.h_in[j], mb * sizeof(int64_t)));
+        TC_TRY(stage_compact(e, hin.plan_dict, hin.n_plans, hin.plan_id, hin.q32, n, st, ss.h_dict, ss.h_plan_id, ss.h_q32, ss.h_in));
+        p.burst = ss.h_in[0], p.count = ss.h_in[1], p.period = ss.h_in[2];
+        if (hin.q32) p.q = ss.h_in[3];
+    }
     return TC_E_OK;
 }
 
@@ -710,7 +775,9 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             piped = e->n_aux != 0; // no free hardware queue: in order on the main stream
         }
         // (the per-request columns of a TC_B_ASYNC host batch are still to be staged: they are in `hin`)
-        auto column = [&](const int64_t* dev, int j) { return dev != nullptr || (hin && hin->col[j] != nullptr); };
+        auto column = [&](const int64_t* dev, int j) {
+            return dev != nullptr || (hin && (hin->col[j] != nullptr || (hin->plan_id && j < 3) || (hin->q32 && j == 3)));
+        };
         const bool params_by_slot = (b.flags & TC_B_REGISTERED_PARAMS) || (!column(p.burst, 0) && !column(p.count, 1) && !column(p.period, 2));
         const bool uniform = !column(p.q, 3) && !column(p.now, 4) && params_by_slot;
         // direct: every run is regular whatever the cells hold: owners store directly, no commit launch
@@ -915,6 +982,14 @@ int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_f
     }
     // (the request columns: one launch from pinned arrays, else a copy each -- a key batch has sent them with its keys already)
     if (!columns_staged) TC_TRY(stage_in_multi(e, c_src, c_dst, c_bytes, c_n, s));
+    if (b.flags & TC_B_PLAN_DICT) { // the compact columns cross PCIe, the wide ones are made on the device
+        for (int j = 0; j < (b.quantity32 ? 4 : 3); ++j) TC_TRY(stage_need(e, e->stage.in[j], e->max_batch));
+        TC_TRY(stage_compact(e, b.plan_dict, b.n_plans, b.plan_id, b.quantity32, (uint32_t)n, s, e->stage.dict, e->stage.plan_id, e->stage.q32, e->stage.in));
+        d.max_burst = e->stage.in[0], d.count_per_period = e->stage.in[1], d.period = e->stage.in[2];
+        if (b.quantity32) d.quantity = e->stage.in[3];
+        d.flags &= ~TC_B_PLAN_DICT;
+        d.plan_dict = nullptr, d.plan_id = nullptr, d.quantity32 = nullptr, d.n_plans = 0;
+    }
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d));
     // Results back.  Round 5: into pinned arrays ONE copy launch behind the evaluation takes every output and the key-error word
@@ -960,14 +1035,21 @@ static int run_slots_host_async(tc_engine* e, const tc_batch& b) {
     HostIn hin;
     hin.slot = b.slot;
     hin.col[0] = b.max_burst, hin.col[1] = b.count_per_period, hin.col[2] = b.period, hin.col[3] = b.quantity, hin.col[4] = b.now_ns;
+    if (b.flags & TC_B_PLAN_DICT) {
+        hin.plan_dict = b.plan_dict, hin.plan_id = b.plan_id, hin.q32 = b.quantity32, hin.n_plans = b.n_plans;
+        d.flags &= ~TC_B_PLAN_DICT;
+        d.plan_dict = nullptr, d.plan_id = nullptr, d.quantity32 = nullptr, d.n_plans = 0;
+    }
     TC_TRY(stage_outputs(e, b, d));
     TC_TRY(run_slots_device(e, d, &hin));
     return finish_async(e, b);
 }
 
 bool host_arrays_pinned(const tc_batch& b) {
+    const bool dict = (b.flags & TC_B_PLAN_DICT) != 0;
     const void* arrays[] = {b.slot, b.key_bytes, b.key_off, b.max_burst, b.count_per_period, b.period, b.quantity, b.now_ns, b.allowed, b.allowed_bits,
-                            b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns, b.status, b.result4, b.decisions};
+                            b.limit, b.remaining, b.reset_after_ns, b.retry_after_ns, b.status, b.result4, b.decisions,
+                            dict ? (const void*)b.plan_dict : nullptr, dict ? (const void*)b.plan_id : nullptr, dict ? (const void*)b.quantity32 : nullptr};
     for (const void* a : arrays)
         if (a && !device_view_of_host(a)) return false;
     return true;
@@ -984,6 +1066,8 @@ void host_sub_batch(const tc_batch& b, uint64_t at, uint64_t cn, tc_batch& c) {
     if (c.period) c.period += at;
     if (c.quantity) c.quantity += at;
     if (c.now_ns) c.now_ns += at;
+    if ((c.flags & TC_B_PLAN_DICT) && c.plan_id) c.plan_id += at;
+    if ((c.flags & TC_B_PLAN_DICT) && c.quantity32) c.quantity32 += at;
     if (c.allowed) c.allowed += at;
     if (c.allowed_bits) c.allowed_bits += at / 64;
     if (c.limit) c.limit += at;
@@ -1182,6 +1266,12 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     int rc;
     const bool dev_ptrs = (b.flags & TC_B_DEVICE_PTRS) != 0;
     if (dev_ptrs && (b.flags & TC_B_ASYNC)) return fail(e, TC_E_INVALID_ARG, "TC_B_ASYNC is for host-pointer batches (device-pointer batches are asynchronous anyway)");
+    // TC_B_PLAN_DICT (round 6): a device batch is decoded by a kernel here; a host batch small enough for the one-launch path
+    // on the host (its inputs travel inside the launch's pinned block); every other host batch where its columns are staged
+    TC_TRY(dict_check(e, b));
+    if (!(b.flags & TC_B_PLAN_DICT)) b.plan_dict = nullptr, b.plan_id = nullptr, b.quantity32 = nullptr, b.n_plans = 0;
+    else if (dev_ptrs) TC_TRY(dict_expand_device(e, b));
+    else if (!(b.flags & TC_B_ASYNC) && b.n <= (uint64_t)SMALL_MAX) dict_expand_on_host(e, b);
     // the engine cleans by itself (tc_set_sweep_policy): maybe_clean_expired in front of the batch (autosweep.hip)
     if (auto_sweep_on(e)) TC_TRY(auto_sweep_before(e, b.n, false, !dev_ptrs || !b.now_ns, (!dev_ptrs && b.now_ns) ? b.now_ns[0] : b.now_ns_scalar));
     if (dev_ptrs) {

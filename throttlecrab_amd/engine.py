@@ -206,8 +206,18 @@ class Engine:
         keep.append(arr)
         setattr(batch, name, arr.ctypes.data)
 
+    @staticmethod
+    def encode_plans(max_burst, count_per_period, period):
+        """What the shims do for TC_B_PLAN_DICT: the three per-request columns -> (dictionary int64[k, 3], ids uint16[n]), or
+        None when the batch holds more than 65 536 distinct triples (the wide columns then)."""
+        rows = np.stack([np.asarray(max_burst, np.int64), np.asarray(count_per_period, np.int64), np.asarray(period, np.int64)], axis=1)
+        dic, ids = np.unique(rows, axis=0, return_inverse=True)
+        if len(dic) > 65536:
+            return None
+        return np.ascontiguousarray(dic), np.ascontiguousarray(ids.reshape(-1), dtype=np.uint16)
+
     def _prepare(self, n, dev, max_burst, count_per_period, period, quantity, now_ns, registered, unique,
-                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False, async_=False, outputs_idle=False):
+                 want, out: Optional[BatchResult], inputs_ready=False, grouped=False, async_=False, outputs_idle=False, plan_dict=None):
         keep = []
         b = L.tc_batch()
         b.struct_size = C.sizeof(L.tc_batch)
@@ -233,9 +243,33 @@ class Engine:
             if dev:
                 raise ValueError("async_ applies to host-array batches (CUDA-tensor batches are asynchronous anyway)")
             flags |= L.TC_B_ASYNC
+        if plan_dict is not None:
+            # TC_B_PLAN_DICT: (dictionary int64[k, 3], ids uint16[n], quantities uint32[n] or None) -- numpy for host batches, CUDA
+            # tensors (int64 / int16 / int32 views of the same bits) for device batches
+            flags |= L.TC_B_PLAN_DICT
+            dic, ids, q32 = plan_dict
+            if max_burst is not None or count_per_period is not None or period is not None or (q32 is not None and quantity is not None):
+                raise ValueError("plan_dict replaces max_burst / count_per_period / period (and quantity32 replaces quantity)")
+            for name, arr, dt in (("plan_dict", dic, np.int64), ("plan_id", ids, np.uint16), ("quantity32", q32, np.uint32)):
+                if arr is None:
+                    continue
+                if _is_torch(arr):
+                    assert dev and arr.is_cuda and arr.is_contiguous(), name
+                    keep.append(arr)
+                    setattr(b, name, arr.data_ptr())
+                else:
+                    if dev:
+                        raise ValueError(f"{name}: a CUDA tensor in a device-pointer batch")
+                    if arr.dtype != dt or not arr.flags["C_CONTIGUOUS"]:
+                        if async_:
+                            raise ValueError(f"async_: {name} must be a C-contiguous {np.dtype(dt).name} array (no hidden copies)")
+                        arr = np.ascontiguousarray(arr, dtype=dt)
+                    keep.append(arr)
+                    setattr(b, name, arr.ctypes.data)
+            b.n_plans = (dic.numel() if _is_torch(dic) else dic.size) // 3
         b.flags = flags
         b.quantity_scalar = 1
-        if not registered:
+        if not registered and plan_dict is None:
             if max_burst is None or count_per_period is None or period is None:
                 raise ValueError("max_burst/count_per_period/period required unless registered=True")
             self._column(b, "max_burst", max_burst, n, dev, keep)
@@ -277,7 +311,7 @@ class Engine:
     def rate_limit_batch_slots(self, slots, *, max_burst=None, count_per_period=None, period=None, quantity=None,
                                now_ns=None, registered=False, unique=False, want=ALL_FIELDS,
                                out: Optional[BatchResult] = None, inputs_ready=False, grouped=False,
-                               async_=False, outputs_idle=False, segments=None) -> BatchResult:
+                               async_=False, outputs_idle=False, segments=None, plan_dict=None) -> BatchResult:
         """rate_limit_batch over pre-resolved slots (sequential semantics, index order).
         segments=[(tensor, count), ...] (with slots=None): the slot column in pieces, e.g. one per source GPU.
         async_=True (TC_B_ASYNC, host arrays): only enqueue -- transfers and evaluation overlap with
@@ -319,7 +353,7 @@ class Engine:
             n = sl.size
             sp = sl.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, registered,
-                                   unique, want, out, inputs_ready, grouped, async_, outputs_idle)
+                                   unique, want, out, inputs_ready, grouped, async_, outputs_idle, plan_dict=plan_dict)
         b.slot = sp
         if seg_arrays is not None:
             b.n_segments = len(segments)
@@ -350,7 +384,7 @@ class Engine:
 
     def rate_limit_batch_keys(self, key_bytes, key_off, *, max_burst=None, count_per_period=None, period=None,
                               quantity=None, now_ns=None, want=ALL_FIELDS,
-                              out: Optional[BatchResult] = None, inputs_ready=False, async_=False) -> BatchResult:
+                              out: Optional[BatchResult] = None, inputs_ready=False, async_=False, plan_dict=None) -> BatchResult:
         """rate_limit_batch over string keys (arena bytes + offsets[n+1]).  inputs_ready: see
         rate_limit_batch_slots (here it covers the key arena and the offsets).  async_: see
         rate_limit_batch_slots (key_bytes: uint8, key_off: uint32 numpy arrays, no hidden copies)."""
@@ -371,7 +405,7 @@ class Engine:
             n = koff.size - 1
             kb, ko = kbytes.ctypes.data, koff.ctypes.data
         b, res, k2 = self._prepare(n, dev, max_burst, count_per_period, period, quantity, now_ns, False, False,
-                                   want, out, inputs_ready, False, async_)
+                                   want, out, inputs_ready, False, async_, plan_dict=plan_dict)
         b.key_bytes = kb
         b.key_off = ko
         if n:
