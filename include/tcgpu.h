@@ -35,7 +35,8 @@
  *                TCGPU_STOP_EVENTS  TCGPU_PROF_MARKERS
  *   grouping     TCGPU_RANGE  TCGPU_RANGE_MAX_N  TCGPU_SORT_ITEMS_PIPED  TCGPU_HOT  TCGPU_HOT_MIN  TCGPU_HOT_RANK  TCGPU_BUCKET
  *                TCGPU_BUCKET_PIPED  TCGPU_BUCKET_BACKOFF  TCGPU_BUCKET_MIN_N  TCGPU_BUCKET_SKEW  TCGPU_ROUTE_3PASS
- *   evaluation   TCGPU_EVAL_ITEMS  TCGPU_EVAL_LEAN  TCGPU_PREFILL  TCGPU_GENERAL_EARLIER  TCGPU_GENERAL_RUNS  TCGPU_NO_SMALL_BATCH
+ *   evaluation   TCGPU_EVAL_ITEMS  TCGPU_EVAL_LEAN  TCGPU_PREFILL  TCGPU_GENERAL_EARLIER  TCGPU_GENERAL_RUNS  TCGPU_GENERAL_LEAN
+ *                TCGPU_NO_SMALL_BATCH
  *   host batches TCGPU_HOST_CHUNK  TCGPU_BOUNCE_MAX  TCGPU_COPY_KERNEL  TCGPU_ASYNC_COPY_KERNEL_N  TCGPU_SYNC_COPY_MAX
  *   string keys  TCGPU_SPREAD_FREE        multi-GPU  TCGPU_EXCHANGE_WAIT_S
  * One more, TCGPU_DEBUG_NO_DECISION_STORE (the lean kernel skips its decision bytes: wrong results, for timing only), exists

@@ -157,6 +157,7 @@ int engine_alloc(tc_engine* e) {
     if (const char* d = getenv("TCGPU_PREFILL")) e->prefill_on = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_GENERAL_EARLIER")) e->general_earlier = atoi(d) != 0;
     if (const char* d = getenv("TCGPU_GENERAL_RUNS")) e->general_runs = atoi(d) != 0;
+    if (const char* d = getenv("TCGPU_GENERAL_LEAN")) e->general_lean = atoi(d) != 0;
     {
         TC_HIP(e, hipHostMalloc((void**)&e->fill_hint_host, 64, hipHostMallocDefault));
         *e->fill_hint_host = 1u;

@@ -208,6 +208,7 @@ struct tc_engine {
     uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
     bool general_earlier = true;     // TCGPU_GENERAL_EARLIER=0: k_eval_general without the earlier-state rule (A/B)
     bool general_runs = true;        // TCGPU_GENERAL_RUNS=0: k_eval_general settles one allowed request per round (A/B)
+    bool general_lean = false;       // TCGPU_GENERAL_LEAN=1: the variant compiled without the allowed-runs rule for drained streams (A/B: measured no better, profiles/r06_v19_general_lean_ab.txt)
     bool debug_nostore = false; // builds with -DTCGPU_DEBUG_KNOBS only: TCGPU_DEBUG_NO_DECISION_STORE=1, MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)
     uint32_t loaded_seq = 0;
     // bounds over the registered rate plans (for all_runs_regular)

@@ -996,7 +996,11 @@ __device__ __forceinline__ void write_out_general(const Params& p, uint32_t i, c
     write_out(p, i, r, d);
 }
 
-template <bool FULL>
+// RUNS (round 6): the allowed-runs rule compiled in.  A stream whose keys are drained -- most requests denied, what a skewed
+// stream looks like after its first batches -- never enters it, and without it the kernel needs fewer registers (one more wave
+// per SIMD): the host picks the variant by what most decisions of a recent batch were (the fill hint), batch by batch; both
+// variants give the same results (the rule only settles several allowed requests in one round).
+template <bool FULL, bool RUNS = true>
 __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t* __restrict__ sorted,
                                                         ChainRec* __restrict__ chain, uint32_t seq, uint32_t* hint) {
     const uint32_t n = p.n;
@@ -1004,14 +1008,21 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
     const int lane = threadIdx.x & 63;
     const uint32_t gw = k >> 6; // global wave number
     const bool valid = k < n;
-    const uint64_t me = valid ? sorted[k] : ~0ull;
+    // (round 6: the element and the row's edge neighbour as two unconditional loads issued together, like the lean kernel's -- a
+    // load under a branch waits for the loads before it)
+    uint32_t ek = min(k, n - 1u);
+    if (lane == 0 && ek > 0u) ek -= 1u;
+    if (lane == 63) ek = min(ek + 1u, n - 1u);
+    const uint64_t me_raw = sorted[min(k, n - 1u)];
+    const uint32_t edge = (uint32_t)(sorted[ek] >> 32);
+    const uint64_t me = valid ? me_raw : ~0ull;
     const uint32_t slot = (uint32_t)(me >> 32);
     const uint32_t idx = (uint32_t)me;
     const uint32_t orow = p.order ? k : idx;
     if (p.order && valid) p.order[k] = idx;
     uint32_t prev_slot = __shfl_up(slot, 1, 64), next_slot = __shfl_down(slot, 1, 64);
-    if (lane == 0 && valid && k > 0) prev_slot = (uint32_t)(sorted[k - 1] >> 32);
-    if (lane == 63 && k + 1 < n) next_slot = (uint32_t)(sorted[k + 1] >> 32);
+    if (lane == 0) prev_slot = edge;  // (k == 0: not looked at)
+    if (lane == 63) next_slot = edge; // (k + 1 >= n: not looked at)
     const bool head = valid && (k == 0 || prev_slot != slot);
     const bool is_last = valid && (k + 1 == n || next_slot != slot);
 
@@ -1253,7 +1264,7 @@ __global__ __launch_bounds__(BLOCK) void k_eval_general(Params p, const uint64_t
         // final -- exact by induction, no special cases.  (Round 3's general version -- a max-plus prefix scan in every round --
         // cost more registers and instructions than it saved once the keys were drained; this one is an arithmetic progression,
         // and it is only entered when some piece still has open lanes behind an allowed request: wave-uniform.)
-        if ((p.flags & F_GENERAL_RUNS) != 0u && __ballot(!fin && first < 64) != 0ull) {
+        if (RUNS && (p.flags & F_GENERAL_RUNS) != 0u && __ballot(!fin && first < 64) != 0ull) {
             const long long inc_me = tc::sat_mul(r.ei, r.q);
             const long long inc_f = __shfl(inc_me, src, 64), dvt_f = __shfl((long long)r.dvt, src, 64);
             const bool cand = !fin && first < 64; // (an open lane behind the allowed request of its piece)

@@ -924,8 +924,11 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // (the evaluation is the last reader of the set: `consumed` rides on its completion signal)
             consumed_rides = e->stop_events && !e->prof_on;
             hipEvent_t stop = consumed_rides ? ss.consumed : nullptr;
-            if (full) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<true>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
-            else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, k_eval_general<false>, grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
+            // (decisions only, most decisions of a recent batch denied: the variant without the allowed-runs rule -- see the kernel)
+            const bool drained = !full && e->general_lean && (*(volatile uint32_t*)e->fill_hint_host & 1u) == 0u;
+            if (full) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_general<true, true>), grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
+            else if (drained) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_general<false, false>), grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
+            else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_general<false, true>), grid, block, 0, s, p, sorted, e->chain, e->chain_seq, e->fill_hint_dev);
             prof_end_m(e, s);
         }
         e->wait_before_sort = nullptr;
