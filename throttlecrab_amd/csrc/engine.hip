@@ -195,9 +195,8 @@ int engine_alloc(tc_engine* e) {
                     e->hot.notes_host_dev = (unsigned long long*)dv;
                     e->hot.hint_cold_host = e->hot.notes_host + words; // (a line of its own behind the notes)
                     e->hot.hint_cold_dev = e->hot.notes_host_dev + words;
-                    TC_HIP(e, hipMalloc(&e->hot.pend, (rp::HOT_MAX + 1) * sizeof(ev::PendHot)));
-                    TC_HIP(e, hipMemsetAsync(e->hot.pend, 0, (rp::HOT_MAX + 1) * sizeof(ev::PendHot), (hipStream_t)0));
-                    e->hot.done = reinterpret_cast<uint32_t*>(e->hot.pend + rp::HOT_MAX);
+                    TC_HIP(e, hipMalloc(&e->hot.done, 64));
+                    TC_HIP(e, hipMemsetAsync(e->hot.done, 0, 64, (hipStream_t)0));
                 }
             }
         }
@@ -238,6 +237,12 @@ int engine_alloc(tc_engine* e) {
                 TC_HIP(e, hipMalloc(&ss.hot_info, std::min<uint64_t>(mb, e->range_max_n) * sizeof(uint32_t)));
                 TC_HIP(e, hipMalloc(&ss.hot_P, tiles * rp::HOT_MAX * sizeof(uint32_t)));
                 TC_HIP(e, hipMalloc(&ss.hot_n, (rp::HOT_MAX + 8) * sizeof(uint32_t)));
+                TC_HIP(e, hipMemsetAsync(ss.hot_n, 0, (rp::HOT_MAX + 8) * sizeof(uint32_t), (hipStream_t)0));
+                TC_HIP(e, hipMalloc(&ss.hot_eval, sizeof(ev::HotEval)));
+                ev::HotEval he{};
+                he.info = ss.hot_info, he.prefix = ss.hot_P, he.n = ss.hot_n, he.slot = ss.hot_dev->slot, he.count = &ss.hot_dev->count;
+                he.done = e->hot.done, he.ids = rp::HOT_MAX, he.tile_shift = 12;
+                TC_HIP(e, hipMemcpy(ss.hot_eval, &he, sizeof he, hipMemcpyHostToDevice));
             }
         }
         TC_HIP(e, hipMalloc(&ss.ws, words * sizeof(uint32_t)));
@@ -616,7 +621,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     for (tc_engine::SortSet& ss : e->sets) {
         if (ss.sorted) (void)hipEventDestroy(ss.sorted);
         if (ss.consumed) (void)hipEventDestroy(ss.consumed);
-        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.part_table, ss.hot_dev, ss.hot_info, ss.hot_P, ss.hot_n, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
+        void* sp[] = {ss.bp_scratch, ss.elem_a, ss.elem_b, ss.elem_c, ss.range_totals, ss.part_table, ss.hot_dev, ss.hot_info, ss.hot_P, ss.hot_n, ss.hot_eval, ss.ws, ss.h_slot, ss.h_in[0], ss.h_in[1], ss.h_in[2], ss.h_in[3], ss.h_in[4], ss.h_key_bytes, ss.h_key_off};
         for (void* p : sp)
             if (p) (void)hipFree(p);
     }
@@ -633,7 +638,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
     if (e->hot.notes_host) (void)hipHostFree(e->hot.notes_host);
     if (e->hot.notes_dev) (void)hipFree(e->hot.notes_dev);
-    if (e->hot.pend) (void)hipFree(e->hot.pend);
+    if (e->hot.done) (void)hipFree(e->hot.done);
     if (e->route_l0_done) (void)hipEventDestroy(e->route_l0_done);
     for (uint32_t k = 0; k < e->debug_fillers; ++k) {
         (void)hipStreamSynchronize(e->debug_filler[k]);

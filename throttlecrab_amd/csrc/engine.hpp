@@ -114,6 +114,7 @@ struct tc_engine {
         uint32_t* hot_info = nullptr;                  // rank form: hot id << 16 | rank inside its tile per request (max_batch words)
         uint32_t* hot_P = nullptr;                     // ... requests of a hot id in the tiles before (tiles x rp::HOT_MAX words)
         uint32_t* hot_n = nullptr;                     // ... requests per hot id in the batch; [rp::HOT_MAX]: requests the ranges hold
+        ev::HotEval* hot_eval = nullptr;               // ... the addresses above as the lean evaluation's hot role reads them (device memory, written once)
         uint32_t* ws = nullptr;                        // hist x2 | ticket | look-back status
         uint32_t* k_slot = nullptr;                    // key mode: slots resolved for the batch using this set
         uint32_t* h_slot = nullptr;                    // TC_B_ASYNC: the host batch's slot column, staged (lazy)
@@ -199,9 +200,8 @@ struct tc_engine {
         uint64_t batches_hot = 0;        // batches grouped in the hot form so far
         uint32_t stable_looks = 0;       // looks in a row that kept the list
         bool rank_on = true;             // TCGPU_HOT_RANK=0: lean batches also take the gather form (A/B)
-        ev::PendHot* pend = nullptr;     // rank form: the cells the evaluation's hot role parked (rp::HOT_MAX)
-        uint32_t* done = nullptr;        // ... and its count of finished hot-role blocks (the word behind pend[])
-        ev::HotEval he{};                // ... what the next lean evaluation is handed (info == nullptr: no hot role)
+        uint32_t* done = nullptr;        // rank form: the evaluation's count of finished hot-role blocks (zero between launches)
+        const ev::HotEval* he_dev = nullptr; // ... what the next lean evaluation is handed (nullptr: no hot role)
         std::vector<unsigned long long> scratch, found; // hot_refresh's workspace
     } hot;
     uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting

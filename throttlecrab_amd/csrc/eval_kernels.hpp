@@ -810,127 +810,124 @@ __global__ __launch_bounds__(BLOCK) void k_eval_sorted(Params p, const uint64_t*
 // same waves per CU in half as many blocks, measured slower on both streams: profiles/r04_v11_eval_block_ab.txt)
 // Round 6, the HOT ROLE (range_part.hpp, PART_RANK): a request of a hot slot is not grouped at all.  What the closed form of a
 // run needs of it is its rank among its slot's requests -- hot_P[tile][id] (requests of the slot in earlier tiles: the scan in
-// rs::k_finish) + its rank inside its tile (the partition left id << 16 | rank in info[i]) -- the run's length n[id], and the
-// slot's cell.  The first blocks of the lean kernel's grid walk the batch in REQUEST order: info and the decision bytes are
-// coalesced, the cells of at most 512 slots stay in the caches.  No lane may store a hot slot's new cell while lanes of other
-// blocks still read the old one, and nothing orders those blocks: the run's owner parks the cell in pend[id] (flag = seq), every
-// hot-role block counts itself done, and the LAST of them stores what was parked (no hot-role lane is left to read a cell by
-// then; the sorted part's blocks never touch a hot slot).  A first version committed in a one-block kernel behind this one:
-// exact, and a second hand-over on the engine's stream per batch -- 59 us per step where this form takes 3x.
-struct __attribute__((aligned(32))) PendHot {
-    Cell cell;
-    uint32_t flag;
-    uint32_t pad[3];
-};
+// rs::k_finish) + its rank inside its tile (the partition left id << 16 | rank in info[i]) -- and, of its slot, how many requests
+// of the run are allowed.  A lean batch's requests are all alike (one timestamp, one quantity, the slot's plan), so that number,
+// A[id] = the ranks r < requests in the batch with tc::rank_allowed(r), is a property of the SLOT: every hot-role block works it out for the
+// (at most 512) hot slots once, into LDS, together with the tile's row of hot_P -- and then walks its half tile of the batch in
+// REQUEST order: a request is allowed iff rank < A[id].  One coalesced load of info and at most one byte stored per request; no
+// gather left in the loop.  (A first version decided every request on its own: three dependent gathers per request -- prefix,
+// slot, cell -- made this role as slow as evaluating the sorted hot runs had been.)
+// The new cells -- each block computes the same ones -- are stored by the LAST hot-role block to finish: by then no block is left
+// that reads the old ones (the sorted part's blocks never touch a hot slot).  It also notes the runs for the host's hot list.
 struct HotEval {
     const uint32_t* info;    // nullptr: no hot role, the whole grid is the sorted part
     const uint32_t* prefix;  // hot_P
     const uint32_t* n;       // [ids] requests per hot id in this batch; [ids]: the sorted part's length
     const uint32_t* slot;    // hot id -> slot
-    PendHot* pend;
+    const uint32_t* count;   // hot ids in use
     uint32_t* done;          // hot-role blocks of this launch that have finished (zero between launches)
-    uint32_t ids, tile_shift, hot_blocks;
-    uint32_t cold_grid;      // blocks of the sorted part (the host's estimate of what is left in the ranges: a block takes more than one
-                             // stretch of positions if it was too low)
+    uint32_t ids, tile_shift;
 };
-constexpr int hot_items(bool fixed) { return fixed ? 4 : 2; } // request positions per lane of a hot-role block (the 16-byte layout: fewer, or the kernel's 64 vector registers spill)
+// (the record lives in DEVICE memory, one per scratch set, and the kernel is handed its address: by value its 14 scalar
+// registers, loaded at the kernel's entry for both roles, pushed the lean kernel over its 80 and into scratch)
+constexpr int HOT_SPLIT = 2;       // hot-role blocks per tile of the partition
+constexpr uint32_t HOT_IDS_MAX = 512; // (== rp::HOT_MAX: the LDS arrays below)
+constexpr uint32_t HOT_ERR = 0xFFFFFFFFu;
 
 template <bool FIXED>
-__device__ __forceinline__ void eval_hot_role(const Params& p, const HotEval& he, uint32_t seq, uint32_t* hint) {
-    constexpr int HOT_ITEMS = hot_items(FIXED);
-    const uint32_t n = p.n;
+__device__ __forceinline__ void eval_hot_role(const Params& p, const HotEval& he, uint32_t hot_blocks) {
+    __shared__ uint32_t s_allow[HOT_IDS_MAX];  // A[id]: requests of the slot's run that are allowed; HOT_ERR: the slot's requests are errors
+    __shared__ uint32_t s_before[HOT_IDS_MAX]; // hot_P[tile][id]
+    __shared__ uint32_t s_last;
+    // (the slots' new cells wait in LDS for step (3): in registers they cost the kernel -- both roles -- its 64-register budget)
+    __shared__ long long s_tat[HOT_IDS_MAX];
+    __shared__ unsigned long long s_exp[HOT_IDS_MAX];
+    __shared__ uint32_t s_len[HOT_IDS_MAX]; // requests of the slot in this batch | 0x80000000: its cell changes
+    const uint32_t n = p.n, tile_len = 1u << he.tile_shift;
+    const uint32_t tile = blockIdx.x / HOT_SPLIT, part = blockIdx.x % HOT_SPLIT;
+    const uint32_t count = min(*he.count, min(he.ids, HOT_IDS_MAX));
     const bool class_by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS);
-    const RateClass rc_batch = p.classes[p.uniform_class];
-    uint32_t pos[HOT_ITEMS], info[HOT_ITEMS];
+    // this half tile's notes, on their way while the slots are worked out
+    constexpr uint32_t PER = 4096u / HOT_SPLIT / BLOCK; // requests per lane (tile_len == 4096: checked by the host), in two rounds of
+    constexpr uint32_t HALF = PER / 2;                   // HALF: eight notes in registers at once cost the 64-register variants spills
+    uint32_t info[HALF], info2[HALF];
+    const uint32_t first = tile * tile_len + part * (tile_len / HOT_SPLIT) + threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < HOT_ITEMS; ++j) {
-        pos[j] = blockIdx.x * (BLOCK * HOT_ITEMS) + j * BLOCK + threadIdx.x;
-        info[j] = he.info[min(pos[j], n - 1u)];
+    for (uint32_t j = 0; j < HALF; ++j) info[j] = he.info[min(first + j * BLOCK, n - 1u)];
+    // (1) the hot slots: two per thread
+    for (uint32_t id = threadIdx.x; id < count; id += BLOCK) {
+        const uint32_t len = he.n[id], slot = he.slot[id];
+        s_before[id] = he.prefix[(size_t)tile * he.ids + id];
+        uint32_t allow = 0, changes = 0;
+        if (len != 0u) {
+            // (one load of the plan either way: a batch-wide copy selected against it made the compiler keep both on a stack)
+            const RateClass rc = p.classes[class_by_slot ? (uint32_t)p.rate_id[slot] : p.uniform_class];
+            const Req rq = make_req_rc(p, slot, rc);
+            if (rq.status != tc::ST_OK) {
+                allow = HOT_ERR;
+            } else {
+                const Cell raw = load_raw<FIXED>(p, slot);
+                Cell c = FIXED ? tc::fixed_cell(raw.tat, rq.dvt) : raw;
+                const Decision d0 = tc::gcra_step<false>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
+                if (d0.allowed) {
+                    allow = 1;
+                    if (len > 1u) {
+                        // (the same closed form as the sorted part's tc::run_lite / rank_allowed: rank r is allowed <=> r < n_tot;
+                        // the host proved every run of this batch regular)
+                        const tc::RunLite f = tc::run_lite(c, rq.ei, rq.dvt, rq.q, rq.now);
+                        if (!f.regular) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]);
+                        // the last allowed rank, by bisection over the very test the sorted part applies to each request
+                        // (monotone in the rank; ~20 steps per slot, no 64-bit division -- which costs this kernel a stack)
+                        uint32_t lo = 0, hi = len - 1u;
+                        while (lo < hi) {
+                            const uint32_t mid = lo + (hi - lo + 1u) / 2u;
+                            if (tc::rank_allowed(f, mid)) lo = mid;
+                            else hi = mid - 1u;
+                        }
+                        allow = lo + 1u;
+                        if (lo != 0u) c = tc::cell_after(f.new0 + (int64_t)lo * f.inc, rq.dvt, rq.now);
+                    }
+                    s_tat[id] = c.tat;
+                    s_exp[id] = c.expiry;
+                    changes = 0x80000000u;
+                }
+            }
+        }
+        s_allow[id] = allow;
+        s_len[id] = len | changes;
     }
-    uint32_t rk[HOT_ITEMS], len[HOT_ITEMS], slot[HOT_ITEMS], rid[HOT_ITEMS];
-    bool on[HOT_ITEMS];
-#pragma unroll
-    for (int j = 0; j < HOT_ITEMS; ++j) {
-        on[j] = pos[j] < n && info[j] != 0xFFFFFFFFu;
-        const uint32_t id = on[j] ? info[j] >> 16 : 0u;
-        rk[j] = he.prefix[(size_t)(pos[j] >> he.tile_shift) * he.ids + id];
-        len[j] = he.n[id];
-        slot[j] = he.slot[id];
-        rid[j] = 0;
-    }
-    Cell cell[HOT_ITEMS];
-#pragma unroll
-    for (int j = 0; j < HOT_ITEMS; ++j) {
-        if (!on[j]) slot[j] = 0u;
-        if (class_by_slot) rid[j] = (uint32_t)p.rate_id[slot[j]];
-        cell[j] = load_raw<FIXED>(p, slot[j]);
-    }
+    __syncthreads();
+    // (2) the requests
     uint32_t na = 0, nd = 0, ne = 0;
 #pragma unroll
-    for (int j = 0; j < HOT_ITEMS; ++j) {
-        if (!on[j]) continue;
-        const uint32_t r = rk[j] + (info[j] & 0xFFFFu), id = info[j] >> 16;
-        const bool is_last = r + 1u == len[j];
-        if (is_last && p.heavy_min != 0u && len[j] >= p.heavy_min) heavy_note(p, slot[j], len[j]);
-        const RateClass rc = class_by_slot ? p.classes[rid[j]] : rc_batch;
-        const Req rq = make_req_rc(p, slot[j], rc);
-        Decision d;
-        d.allowed = false;
-        d.remaining = d.reset_after = d.retry_after = 0;
-        if (rq.status != tc::ST_OK) {
-            ne += 1;
-            put_out<true>(p, pos[j], rq, d);
-            continue;
-        }
-        Cell c = FIXED ? tc::fixed_cell(cell[j].tat, rq.dvt) : cell[j];
-        const Decision d0 = tc::gcra_step<false>(c, rq.ei, rq.dvt, rq.q, rq.now); // c = cell after request 0
-        bool owner = false;
-        Cell v = c;
-        if (!d0.allowed) {
-            nd += 1; // request 0 denied => state untouched => every request of the run equals request 0
-            put_out<true>(p, pos[j], rq, d0);
-        } else if (len[j] == 1u) {
-            na += 1;
-            put_out<true>(p, pos[j], rq, d0);
-            owner = true;
-        } else {
-            // (the same closed form as the sorted part: tc::run_lite; the host proved every run of this batch regular)
-            const tc::RunLite f = tc::run_lite(c, rq.ei, rq.dvt, rq.q, rq.now);
-            if (!f.regular) tc::invariant_failed(&p.counters[(TC_CNT_COUNT + 1) + 3]);
-            const bool ok_r = r == 0u || tc::rank_allowed(f, r);
-            owner = ok_r && (is_last || !tc::rank_allowed(f, r + 1u));
-            if (owner && r != 0u) v = tc::cell_after(f.new0 + (int64_t)r * f.inc, rq.dvt, rq.now);
-            d.allowed = ok_r;
-            na += ok_r;
-            nd += !ok_r;
-            put_out<true>(p, pos[j], rq, r == 0u ? d0 : d);
-        }
-        if (owner) { // (agent-scope stores, like the general kernel's chain records: performed at the device's scope, no cache left to flush)
-            PendHot* o = &he.pend[id];
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&o->cell.tat), (unsigned long long)v.tat, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(&o->cell.expiry), (unsigned long long)v.expiry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&o->flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    for (uint32_t j = 0; j < HALF; ++j) info2[j] = he.info[min(first + (HALF + j) * BLOCK, n - 1u)];
+#pragma unroll
+    for (uint32_t j = 0; j < PER; ++j) {
+        const uint32_t pos = first + j * BLOCK, note = j < HALF ? info[j % HALF] : info2[j % HALF];
+        if (pos >= n || note == 0xFFFFFFFFu) continue;
+        const uint32_t id = note >> 16, a = s_allow[id];
+        const bool ok = a != HOT_ERR;
+        const bool al = ok && s_before[id] + (note & 0xFFFFu) < a;
+        na += al;
+        nd += ok && !al;
+        ne += !ok;
+        // (prefilled batches: the byte is already there unless this decision is the batch's minority one -- put_out<LEAN>)
+        if (!(p.flags & (al ? (F_PREFILL1 | F_DEBUG_NOSTORE) : (F_PREFILL0 | F_DEBUG_NOSTORE)))) p.allowed[pos] = al ? 1 : 0;
     }
     block_count3<BLOCK>(na, nd, ne, p.counters, nullptr);
-    (void)hint;
-    // the last hot-role block to get here commits the parked cells
-    __shared__ uint32_t s_last;
-    // this block's parked cells have been performed at the device's scope before it counts itself done  (NOT __threadfence():
-    // a release at agent scope writes the whole L2 of the XCD back -- once per block that was 173 us per batch)
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __builtin_amdgcn_s_waitcnt(0);
-    __atomic_signal_fence(__ATOMIC_SEQ_CST);
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(he.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == he.hot_blocks ? 1u : 0u;
+    // (3) the last hot-role block to get here stores the slots' new cells (its own copy of them: every block computed the same)
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(he.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == hot_blocks ? 1u : 0u;
     __syncthreads();
     if (s_last == 0u) return;
-    for (uint32_t id = threadIdx.x; id < he.ids; id += BLOCK) {
-        if (__hip_atomic_load(&he.pend[id].flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != seq) continue;
-        Cell c;
-        c.tat = (int64_t)__hip_atomic_load(reinterpret_cast<unsigned long long*>(&he.pend[id].cell.tat), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c.expiry = __hip_atomic_load(reinterpret_cast<unsigned long long*>(&he.pend[id].cell.expiry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        store_state<FIXED>(p, he.slot[id], c);
+    for (uint32_t id = threadIdx.x; id < count; id += BLOCK) {
+        const uint32_t len = s_len[id] & 0x7FFFFFFFu, slot = he.slot[id];
+        if (s_len[id] & 0x80000000u) {
+            Cell c;
+            c.tat = s_tat[id];
+            c.expiry = s_exp[id];
+            store_state<FIXED>(p, slot, c);
+        }
+        if (p.heavy_min != 0u && len >= p.heavy_min) heavy_note(p, slot, len);
     }
     if (threadIdx.x == 0) __hip_atomic_store(he.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -938,25 +935,31 @@ __device__ __forceinline__ void eval_hot_role(const Params& p, const HotEval& he
 template <int ITEMS, bool FIXED, int BS = BLOCK>
 __global__ __launch_bounds__(BS, (ITEMS <= 2 ? TC_EVAL_LEAN_WAVES : TC_EVAL_LEAN_WAVES / 2)) __attribute__((amdgpu_num_sgpr(80))) void k_eval_sorted_lean(
     Params p, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ loaded, uint32_t seq, const uint32_t* __restrict__ gate,
-    uint32_t gate_min, uint32_t* hint, HotEval he) {
-    if (he.info != nullptr) { // (grid-uniform: BS == BLOCK when the kernel has a hot role)
-        if (blockIdx.x < he.hot_blocks) {
-            eval_hot_role<FIXED>(p, he, seq, hint);
-            return;
-        }
-        // The sorted part: the requests the ranges hold.  How many they are is known on the device only; the host sized this part
-        // of the grid by a recent batch's count (a grid of 3 072 blocks of which 1 200 leave at once lengthened the hand-over
-        // to the next kernel on the stream: tools/gapbench).  A block takes the stretches bid, bid + cold_grid, ...: stretches
-        // are still started in position order by blocks dispatched in order, which is all the direct stores' waits rely on.
-        const uint32_t nc = he.n[he.ids];
-        for (uint32_t bid = blockIdx.x - he.hot_blocks; bid * (uint32_t)(BS * ITEMS) < nc; bid += he.cold_grid) {
-            eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, bid, nc,
-                                                                   (nc + BS * ITEMS - 1) / (BS * ITEMS));
-            __syncthreads(); // (the body's shared arrays are written again)
-        }
+    uint32_t gate_min, uint32_t* hint) {
+    eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, blockIdx.x, p.n, gridDim.x);
+}
+
+// The same with the HOT ROLE in front (a kernel of its own: the loop around the sorted part below costs the 64-register variant a
+// few spills, which the headline's kernel above must not pay).  Blocks [0, hot_blocks): the hot role; the others: the sorted
+// part -- the requests the ranges hold.  How many they are is known on the device only; the host sized that part of the grid
+// (cold_grid blocks) by a recent batch's count (a grid of 3 072 blocks of which 1 200 leave at once lengthened the hand-over to
+// the next kernel on the stream: tools/gapbench).  A block takes the stretches bid, bid + cold_grid, ...: stretches are still
+// started in position order by blocks dispatched in order, which is all the direct stores' waits rely on.
+template <int ITEMS, bool FIXED>
+// (six blocks per CU instead of the plain kernel's eight: 84 vector registers, nothing spilled)
+__global__ __launch_bounds__(BLOCK, (ITEMS <= 2 ? 6 : 4)) void k_eval_lean_hot(
+    Params p, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ loaded, uint32_t seq, uint32_t* hint, const HotEval* __restrict__ hep,
+    uint32_t hot_blocks, uint32_t cold_grid) {
+    if (blockIdx.x < hot_blocks) {
+        eval_hot_role<FIXED>(p, *hep, hot_blocks);
         return;
     }
-    eval_sorted_body<false, true, ITEMS, FIXED, true, BS>(p, sorted, nullptr, nullptr, loaded, seq, gate, gate_min, hint, blockIdx.x, p.n, gridDim.x);
+    const uint32_t nc = hep->n[hep->ids];
+    for (uint32_t bid = blockIdx.x - hot_blocks; bid * (uint32_t)(BLOCK * ITEMS) < nc; bid += cold_grid) {
+        eval_sorted_body<false, true, ITEMS, FIXED, true, BLOCK>(p, sorted, nullptr, nullptr, loaded, seq, nullptr, 0u, hint, bid, nc,
+                                                                  (nc + BLOCK * ITEMS - 1) / (BLOCK * ITEMS));
+        __syncthreads(); // (the body's shared arrays are written again)
+    }
 }
 
 // ---------------------------------------------------------------------------

@@ -534,22 +534,22 @@ static void launch_eval_items(tc_engine* e, bool full, bool direct, bool lean, u
     const dim3 grid((n + BLOCK * ITEMS - 1) / (BLOCK * ITEMS)), block(BLOCK);
     if (lean) {
         if constexpr (ITEMS <= 4) {
-            const HotEval he = e->hot.he;
-            // (rank form: the first hot_blocks blocks walk the batch in request order for the hot slots' requests)
-            HotEval hev = he;
-            if (he.info) {
-                // the sorted part's blocks: what a recent batch left in the ranges, scaled to this batch, + a quarter (too few: a
-                // block takes a second stretch; never more than the whole batch would need)
+            // (rank form: the first hot_blocks blocks walk the batch in request order for the hot slots' requests; the sorted part's
+            // blocks: what a recent batch left in the ranges, scaled to this batch, + a quarter -- too few: a block takes a second
+            // stretch; never more than the whole batch would need)
+            const HotEval* hep = e->hot.he_dev;
+            uint32_t hot_blocks = 0, cold_grid = grid.x;
+            if (hep) {
+                hot_blocks = ((n + rp::PT_TILE - 1) / rp::PT_TILE) * HOT_SPLIT; // (a block per half tile)
                 const unsigned long long ch = *(volatile unsigned long long*)(e->hot.hint_cold_host + 1);
-                uint32_t cg = grid.x;
                 if ((ch >> 32) != 0ull) {
                     const uint64_t est = (ch & 0xFFFFFFFFull) * n / (ch >> 32);
-                    cg = (uint32_t)std::min<uint64_t>(grid.x, (est + est / 4u) / (BLOCK * ITEMS) + 32u);
+                    cold_grid = (uint32_t)std::min<uint64_t>(grid.x, (est + est / 4u) / (BLOCK * ITEMS) + 32u);
                 }
-                hev.cold_grid = std::max(cg, 1u);
+                cold_grid = std::max(cold_grid, 1u);
             }
-            const dim3 lgrid((he.info ? hev.cold_grid + he.hot_blocks : grid.x));
-            TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), lgrid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev, hev);
+            if (hep) TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_lean_hot<ITEMS, FIXED>), dim3(cold_grid + hot_blocks), block, 0, s, p, sorted, e->loaded, seq, e->fill_hint_dev, hep, hot_blocks, cold_grid);
+            else TC_LAUNCH_T(e, TC_STAGE_EVAL, stop, (k_eval_sorted_lean<ITEMS, FIXED>), grid, block, 0, s, p, sorted, e->loaded, seq, gate, gate_min, e->fill_hint_dev);
             return;
         }
     }
@@ -807,7 +807,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             p.heavy_tag = (uint32_t)(e->hot.evals & ((1u << ev::HEAVY_TAG_BITS) - 1u));
         }
         const int ranged = range_applies(e, n, piped, rank_ok);
-        e->hot.he = HotEval{};
+        e->hot.he_dev = nullptr;
         // The range hint is written by the grouping kernels of the sort paths (k_hist's range row, k_finish).  An in-order batch
         // on the bucket path leaves none: an engine that only ever sees in-order batches would stay on the bucket path for
         // good -- 84 us per 1 Mi batch where the range path takes 63, found by tools/batch_sizes.py; bench.py's in-order
@@ -894,26 +894,15 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             // (direct: the evaluation is the last reader of the set -- `consumed` can ride on its completion signal)
             consumed_rides = direct && e->stop_events && !e->prof_on;
             const bool rankm = ranged == GROUP_RANGE_RANK;
-            if (rankm) {
-                HotEval& he = e->hot.he;
-                he.info = ss.hot_info;
-                he.prefix = ss.hot_P;
-                he.n = ss.hot_n;
-                he.slot = ss.hot_dev->slot; // (an address in device memory: nothing is read here)
-                he.pend = e->hot.pend;
-                he.done = e->hot.done;
-                he.ids = rp::HOT_MAX;
-                he.tile_shift = 12;
-                static_assert(rp::PT_TILE == 1u << 12, "the hot role finds a request's tile by a shift");
-                he.hot_blocks = (n + BLOCK * hot_items(e->fixed) - 1) / (BLOCK * hot_items(e->fixed));
-            }
+            static_assert(rp::PT_TILE == 1u << 12 && rp::HOT_MAX == HOT_IDS_MAX, "the hot role: a tile is 4 096 requests, its LDS arrays hold every hot id");
+            e->hot.he_dev = rankm ? ss.hot_eval : nullptr; // (the set's record of where the partition left its notes: device memory)
             // (slim: the stream looked skewed to the range hint -- not merely "no hint yet" or a batch too large for the path)
             // (rank form: what is left in the sorted part is the stream's uniform tail, and the hot role's blocks want the CU's eight
             // block slots beside it: 2 positions per lane -- 36.6 us per Zipf batch against 39.2 with 4, profiles/r06_v12_zipf_items_ab.txt)
             const bool slim = piped && e->range_ok && (!ranged && (*(volatile unsigned long long*)e->range_hint_host >> 32) != 0ull && n <= e->range_max_n);
             launch_eval_sorted(e, full, direct, piped, n, s, p, sorted, seq, gate, e->bp_skew, consumed_rides ? ss.consumed : nullptr, slim);
             prof_end_m(e, s);
-            e->hot.he = HotEval{};
+            e->hot.he_dev = nullptr;
             if (!direct) {
                 prof_begin(e, TC_STAGE_COMMIT, s);
                 hipLaunchKernelGGL(k_commit_list, dim3(64), block, 0, s, e->pend, e->pend_count, e->cells, e->tat8);
