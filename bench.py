@@ -54,11 +54,11 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec
 METRICS_EVERY = 32               # N > 1: RCCL all-gather of the counter blocks every this many steps (+ the last)
 
 
-KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rs::k_onesweep", "eval": "ev::k_eval_sorted", "commit": "ev::k_commit_list",
+KERNEL_OF_STAGE = {"prep": "rs::k_hist", "sort": "rp::k_tile_part + rs::k_finish (range path) / rs::k_onesweep (LSD passes)", "eval": "ev::k_eval_sorted", "commit": "ev::k_commit_list",
                    "pack": "ev::k_pack_bits", "hash": "kt::k_probe + k_bind + k_follow", "bucket_hist": "bp::k_tile_hist",
                    "bucket_scan": "bp::k_bucket_scan", "bucket_scatter": "bp::k_scatter", "bucket_eval": "bp::k_bucket_eval"}
 # kernel name fragments in the rocprofv3 summaries under profiles/
-PROFILE_NAME_OF_STAGE = {"prep": "rs::k_hist", "sort": "k_onesweep", "eval": "k_eval_sorted", "commit": "k_commit_list",
+PROFILE_NAME_OF_STAGE = {"prep": "rs::k_hist", "sort": ("k_onesweep", "k_tile_part", "rs::k_finish"), "eval": ("k_eval_sorted", "k_eval_lean_hot"), "commit": "k_commit_list",
                          "bucket_hist": "k_tile_hist", "bucket_scan": "k_bucket_scan", "bucket_scatter": "k_scatter",
                          "bucket_eval": "k_bucket_eval", "hash": "kt::k_probe", "eval_general": "k_eval_general"}
 COPY_CEILING_GBS = 6290.0        # MI355X_MICROARCH.md: measured copy ceiling (what line-granular traffic can reach)
@@ -88,7 +88,7 @@ def pmc_traffic(stage, stream, layout, launches_per_batch):
         total, names = 0.0, []
         for name, v in doc["kernels"].items():
             # (launches that left at once -- the gated-off path of a batch enqueued on both -- carry a few KB)
-            if want in name and v.get("launches", 0) >= 3 and 2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"] > 512.0:
+            if any(w in name for w in ((want,) if isinstance(want, str) else want)) and v.get("launches", 0) >= 3 and 2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"] > 512.0:
                 # several variants of one stage (first / later radix pass): weigh by launches
                 total += (2.0 * v["FETCH_SIZE_KB"] + v["WRITE_SIZE_KB"]) * 1024.0 * v["launches"]
                 names.append((name, v["launches"]))
@@ -349,7 +349,8 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
     alg = (ALG_BYTES_GENERAL if general else ALG_BYTES_PER_DECISION) * a.batch
     res = {"value": a.steps * a.batch * world / dt, "unit": "decisions/s", "ms_per_step": ms,
            "allowed_fraction": c["allowed"] / max(1, c["total"]), "whole_step_frac": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-           "pipelining_degraded": bool(engine_info["pipelining_degraded"]), "engine_info": engine_info}
+           "pipelining_degraded": bool(engine_info["pipelining_degraded"]), "engine_info": engine_info,
+           "grouping_path": engine_info.get("grouping_path")}
     if plans not in (None, "one"):
         res["plans"] = plans
     if rank == 0 and dist is None and seed_shift == 0 and not a.no_verify and not a.profile_run and not a.in_order and nb <= 400:
@@ -384,6 +385,8 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
         if ev:  # (no record: the launch went untimed -- the line then carries no roofline rather than a made-up one)
             # (pipelined, decisions only, every run regular: the evaluation the engine launches is the lean variant)
             kname = "ev::k_eval_general" if general else ("ev::k_eval_sorted_lean" if ev["kernel"] == "ev::k_eval_sorted" else ev["kernel"])
+            if not general and engine_info.get("grouping_path", "").endswith("hot slots peeled"):
+                kname = "ev::k_eval_lean_hot"   # (round 6: the skewed stream's lean batches -- hot role + the sorted part in one kernel)
             source = {"avg_ms": "start/stop HIP events on the kernel's own dispatch packet (hipExtLaunchKernelGGL), engine's "
                                 "stream, pipelined run of this process",
                       "traffic": (src or {}).get("file")}
@@ -1403,7 +1406,7 @@ def compact_line(result):
         r2 = (result.get(k) or {}).get("roofline") if isinstance(result.get(k), dict) else None
         if r2 and r2.get("frac") is not None and "invalid" not in r2:
             c["roofline_" + k.split("_")[0]] = _pick(r2, ("kernel", "avg_ms", "achieved", "frac", "traffic", "whole_step_frac"))
-    one = ("value", "ms_per_step", "whole_step_frac")
+    one = ("value", "ms_per_step", "whole_step_frac", "grouping_path")
     for k in ("zipf_stream", "uniform_stream", "wide_layout", "fixed_layout", "general_uniform", "general_zipf"):
         if isinstance(result.get(k), dict):
             c[k] = _pick(result[k], one)

@@ -23,7 +23,7 @@ def main():
     # a batch's grouping chain starts with k_hist (LSD passes) or with k_tile_ranges (range path: + k_finish)
     hist = [r for r in rows if "k_hist" in r[0] or "k_tile_ranges" in r[0] or "k_tile_part" in r[0]]
     sweeps = [r for r in rows if "k_onesweep" in r[0] or "k_finish" in r[0] or "k_hot_gather" in r[0]]
-    evals = [r for r in rows if "k_eval_sorted" in r[0] or "k_eval_general" in r[0]]
+    evals = [r for r in rows if "k_eval_sorted" in r[0] or "k_eval_general" in r[0] or "k_eval_lean_hot" in r[0]]
     print(f"# {len(hist)} chain heads (k_hist / k_tile_ranges), {len(sweeps)} k_onesweep / k_finish, {len(evals)} evaluations")
     # the i-th evaluation belongs to the i-th batch; its sort chain is the i-th k_hist (in START order the chains of
     # different streams interleave, so the passes are matched by stream)
