@@ -244,7 +244,4 @@ __global__ __launch_bounds__(PT_THREADS) void k_tile_part(const uint32_t* __rest
     }
 }
 
-// (what hot_refresh's "same list?" goes by: who is among the heaviest 8 / 64 -- the list is kept while the order at its head holds)
-constexpr uint32_t HG_A_IDS = 8, HG_B_END = 64;
-
 } // namespace rp

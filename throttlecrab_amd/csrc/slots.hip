@@ -342,19 +342,24 @@ static void hot_refresh(tc_engine* e) {
     std::sort(found.begin(), found.end(), std::greater<unsigned long long>());
     std::vector<uint32_t> now(found.size());
     for (size_t i = 0; i < found.size(); ++i) now[i] = 0xFFFFFFFFu - (uint32_t)found[i];
-    // Keep the installed tables while the list is nearly the same: who is among the heaviest 8 / 64 (the gather's single-id
-    // units, rp::HG_SINGLES) and nine in ten of the rest.  The tail of a skewed stream's list changes with every look (slots
-    // around heavy_min requests per batch come and go); a slot that stays on the list for nothing costs an empty bucket.
-    auto as_set = [](const std::vector<uint32_t>& v, size_t k) {
-        std::vector<uint32_t> c(v.begin(), v.begin() + std::min(k, v.size()));
-        std::sort(c.begin(), c.end());
-        return c;
-    };
-    bool same = !h.slots.empty() && as_set(now, rp::HG_A_IDS) == as_set(h.slots, rp::HG_A_IDS) && as_set(now, rp::HG_B_END) == as_set(h.slots, rp::HG_B_END);
+    // Keep the installed tables while the list still serves: nine in ten of its slots are still noted (else it is stale: made
+    // afresh, so that the table does not fill with slots that stopped being hot), and no slot with a run long enough to endanger a
+    // range (a quarter of what a block finishes) is missing from it.  Which slots are hot is all that counts -- the rank form
+    // does not care about their order -- and the tail of a skewed stream's list changes with every look (slots around heavy_min
+    // requests per batch come and go; in round 6's first version so did the boundary between the 64th and the 65th heaviest,
+    // and every change cost six installs and the hints about the ranges).
+    bool same = !h.slots.empty();
     if (same) {
+        std::vector<uint32_t> cur(h.slots);
+        std::sort(cur.begin(), cur.end());
+        for (size_t i = 0; i < found.size() && same; ++i) {
+            const uint32_t len = (uint32_t)(found[i] >> 32), sl = 0xFFFFFFFFu - (uint32_t)found[i];
+            if (len < rs::FIN_CAP / 4u) break; // (sorted by length, longest first)
+            same = std::binary_search(cur.begin(), cur.end(), sl);
+        }
         size_t both = 0;
         for (const uint32_t sl : h.slots) both += probe(sl) != 0ull ? 1u : 0u; // (noted at all: on the new list or just below its cut)
-        same = both * 10u >= h.slots.size() * 9u && now.size() * 10u <= h.slots.size() * 12u + 100u;
+        same = same && both * 10u >= h.slots.size() * 9u && now.size() * 4u <= h.slots.size() * 5u + 128u; // (... nor has a crowd of new hot slots turned up)
     }
     if (now.empty() && h.slots.empty()) same = true;
     if (same) {
