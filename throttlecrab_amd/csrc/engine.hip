@@ -185,6 +185,7 @@ int engine_alloc(tc_engine* e) {
                 if (const char* d = getenv("TCGPU_HOT")) e->hot.on = atoi(d) != 0;
                 if (const char* d = getenv("TCGPU_HOT_MIN")) e->hot.heavy_min = (uint32_t)std::max(atoi(d), 2);
                 if (const char* d = getenv("TCGPU_HOT_RANK")) e->hot.rank_on = atoi(d) != 0;
+                if (const char* d = getenv("TCGPU_HOT_THREAD")) e->hot.threaded = atoi(d) != 0;
                 if (e->hot.on) {
                     const size_t words = (size_t)ev::HEAVY_SLOTS + 8;
                     TC_HIP(e, hipMalloc(&e->hot.notes_dev, words * sizeof(unsigned long long)));
@@ -636,6 +637,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->bounce) (void)hipHostFree(e->bounce);
     if (e->fill_hint_host) (void)hipHostFree(e->fill_hint_host);
     if (e->range_hint_host) (void)hipHostFree(e->range_hint_host);
+    hot_worker_stop(e); // (it reads the pinned notes)
     if (e->hot.notes_host) (void)hipHostFree(e->hot.notes_host);
     if (e->hot.notes_dev) (void)hipFree(e->hot.notes_dev);
     if (e->hot.done) (void)hipFree(e->hot.done);

@@ -19,7 +19,11 @@
 #include <new>
 #include <string>
 #include <unordered_map>
+#include <atomic>
+#include <condition_variable>
 #include <deque>
+#include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/tcgpu.h"
@@ -198,11 +202,26 @@ struct tc_engine {
         unsigned long long* hint_cold_host = nullptr; // pinned: n << 32 | largest range of a recent batch grouped in the hot form (without its hot slots)
         unsigned long long* hint_cold_dev = nullptr;
         uint64_t batches_hot = 0;        // batches grouped in the hot form so far
-        uint32_t stable_looks = 0;       // looks in a row that kept the list
+        std::atomic<uint32_t> stable_looks{0}; // looks in a row that kept the list
         bool rank_on = true;             // TCGPU_HOT_RANK=0: lean batches also take the gather form (A/B)
         uint32_t* done = nullptr;        // rank form: the evaluation's count of finished hot-role blocks (zero between launches)
         const ev::HotEval* he_dev = nullptr; // ... what the next lean evaluation is handed (nullptr: no hot role)
-        std::vector<unsigned long long> scratch, found; // hot_refresh's workspace
+        std::vector<unsigned long long> scratch, found; // hot_make's workspace
+        // The list is MADE on a thread of the engine's own (slots.hip: hot_worker): reading 8 192 notes, deduplicating and ranking
+        // them took the caller's thread 60-90 us whenever a new copy had arrived -- seven times in an engine's first 24 batches,
+        // which is where the driver's 20-batch region lies (Zipf 47 us per batch there against 38 in later regions,
+        // tools/host_calls.py).  The caller's thread only TAKES a finished list (a swap under the mutex).
+        bool threaded = true;            // TCGPU_HOT_THREAD=0: made on the caller's thread, as before
+        std::vector<uint32_t> made;      // the list as last made (the maker's side; == slots once taken)
+        std::thread worker;
+        std::mutex mu;
+        std::condition_variable cv;
+        bool worker_on = false, stop = false;     // (stop: under mu)
+        std::vector<uint32_t> next;      // a finished list the caller has not taken yet (under mu)
+        std::atomic<bool> next_ready{false};
+        std::atomic<bool> asleep{false}; // the worker waits on cv: no call for a while (the next call wakes it)
+        std::atomic<int64_t> last_call_ns{0};
+        uint64_t lists_made = 0;         // (worker's)
     } hot;
     uint32_t* fill_hint_host = nullptr; // pinned: "most decisions of a recent batch were allowed", written by the evaluation, read here without waiting
     uint32_t* fill_hint_dev = nullptr;  // the same word as the device addresses it
@@ -211,6 +230,7 @@ struct tc_engine {
     bool general_lean = false;       // TCGPU_GENERAL_LEAN=1: the variant compiled without the allowed-runs rule for drained streams (A/B: measured no better, profiles/r06_v19_general_lean_ab.txt)
     bool debug_nostore = false; // builds with -DTCGPU_DEBUG_KNOBS only: TCGPU_DEBUG_NO_DECISION_STORE=1, MEASUREMENT ONLY -- the lean kernel skips its decision bytes (wrong results)
     uint32_t loaded_seq = 0;
+    bool kernels_preloaded = false; // slots.hip: preload_pipelined_kernels has run for this engine's device
     // bounds over the registered rate plans (for all_runs_regular)
     int64_t cls_min_ei = INT64_MAX, cls_max_ei = 0, cls_min_dvt = INT64_MAX, cls_max_dvt = 0;
     uint32_t* pend_count = nullptr;
@@ -509,6 +529,7 @@ void bounce_out(const Bounced& bo);                          // the results, fro
 int stage_outputs(tc_engine* e, const tc_batch& b, tc_batch& d);
 int copy_outputs_back(tc_engine* e, const tc_batch& b, hipStream_t s, bool by_kernel = false);
 int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin = nullptr);
+void hot_worker_stop(tc_engine* e); // slots.hip: the hot list's maker thread (joined by tc_engine_destroy)
 int run_slots_host_staged(tc_engine* e, const tc_batch& b, uint32_t* key_error_flag = nullptr, const uint32_t* d_slot = nullptr, bool columns_staged = false);
 int finish_async(tc_engine* e, const tc_batch& b);
 bool small_batch_applies(const tc_engine* e, const tc_batch& b);

@@ -271,12 +271,17 @@ __device__ __forceinline__ void block_count3(uint32_t a, uint32_t b, uint32_t c,
         s_cnt[2][wave] = c;
     }
     __syncthreads();
-    if (threadIdx.x < 3) {
+    // (opaque copies: inside k_eval_lean_hot's loop over stretches the compiler otherwise works these two addresses out ahead of
+    // the loop and keeps them -- on its stack: the kernel's only scratch, which costs its FIRST dispatch in a process a scratch
+    // allocation on the queue, hundreds of microseconds, in the middle of the stream)
+    uint32_t tx = threadIdx.x, bx = blockIdx.x;
+    asm volatile("" : "+v"(tx), "+s"(bx));
+    if (tx < 3) {
         uint32_t t = 0;
-        for (int w = 0; w < NT / 64; ++w) t += s_cnt[threadIdx.x][w];
+        for (int w = 0; w < NT / 64; ++w) t += s_cnt[tx][w];
         if (t) {
-            unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + (blockIdx.x % NSHARD) * SHARD_WORDS;
-            atomicAdd(&shard[threadIdx.x], (unsigned long long)t);
+            unsigned long long* shard = counters + (TC_CNT_COUNT + 1) + (bx % NSHARD) * SHARD_WORDS;
+            atomicAdd(&shard[tx], (unsigned long long)t);
         }
     }
     if (hint != nullptr && threadIdx.x == 64) {
@@ -534,16 +539,24 @@ struct __attribute__((aligned(16))) PendEntry {
 #ifndef TC_EVAL_LEAN_WAVES
 #define TC_EVAL_LEAN_WAVES 8 // waves per SIMD the LEAN variants are compiled for (= 256-thread blocks per CU)
 #endif
+#ifndef TC_LEAN_HOT_WAVES
+#define TC_LEAN_HOT_WAVES 6  // ... and k_eval_lean_hot (2 positions per lane; TC_LEAN_HOT_WAVES4: 4 positions)
+#endif
+#ifndef TC_LEAN_HOT_WAVES4
+#define TC_LEAN_HOT_WAVES4 4
+#endif
 template <bool FULL, bool DIRECT, int ITEMS, bool FIXED, bool LEAN, int BS = BLOCK>
 __device__ __forceinline__ void eval_sorted_body(const Params& p, const uint64_t* __restrict__ sorted,
                                                  PendEntry* __restrict__ pend, uint32_t* __restrict__ pend_count,
                                                  uint32_t* __restrict__ loaded, uint32_t seq,
                                                  const uint32_t* __restrict__ gate, uint32_t gate_min, uint32_t* hint, uint32_t bid, uint32_t n,
-                                                 uint32_t grid) {
+                                                 uint32_t grid, uint32_t opaque_zero = 0u) {
     // (bid, n, grid: this block's number among the `grid` blocks of the sorted part and the part's length -- blockIdx.x, p.n and
     // gridDim.x unless the kernel also runs the hot role, k_eval_sorted_lean)
     if (gate != nullptr && __builtin_nontemporal_load(gate) <= gate_min) return; // this batch took the bucket path (bucket_path.hpp)
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // (opaque_zero: 0 -- a value the compiler cannot see through when the body sits in k_eval_lean_hot's loop, so that what
+    // depends on `wave` is worked out inside the loop and not kept across it on the stack; see block_count3)
+    const int lane = threadIdx.x & 63, wave = (int)((threadIdx.x >> 6) + opaque_zero);
     const uint32_t block_start = bid * (BS * ITEMS);
     const bool class_by_slot = (p.flags & F_REGISTERED) && !(p.flags & F_UNIFORM_CLASS); // uniform over the grid
     const RateClass rc_batch = p.classes[p.uniform_class];                                // (class 0 if there is none)
@@ -946,18 +959,24 @@ __global__ __launch_bounds__(BS, (ITEMS <= 2 ? TC_EVAL_LEAN_WAVES : TC_EVAL_LEAN
 // the next kernel on the stream: tools/gapbench).  A block takes the stretches bid, bid + cold_grid, ...: stretches are still
 // started in position order by blocks dispatched in order, which is all the direct stores' waits rely on.
 template <int ITEMS, bool FIXED>
-// (six blocks per CU instead of the plain kernel's eight: 84 vector registers, nothing spilled)
-__global__ __launch_bounds__(BLOCK, (ITEMS <= 2 ? 6 : 4)) void k_eval_lean_hot(
+// (six blocks per CU instead of the plain kernel's eight: 74-77 vector registers and NO scratch -- the variants with 2 positions per
+// lane kept six loop-invariant words on the stack until the late days of round 6: nothing at run time, but a kernel that needs
+// scratch at all stalls its first dispatch in a process until the queue's scratch is allocated, which in the driver's form fell
+// into the timed region of the skewed stream; block_count3 and eval_sorted_body's `opaque_zero` are what keeps them off it)
+__global__ __launch_bounds__(BLOCK, (ITEMS <= 2 ? TC_LEAN_HOT_WAVES : TC_LEAN_HOT_WAVES4)) void k_eval_lean_hot(
     Params p, const uint64_t* __restrict__ sorted, uint32_t* __restrict__ loaded, uint32_t seq, uint32_t* hint, const HotEval* __restrict__ hep,
     uint32_t hot_blocks, uint32_t cold_grid) {
     if (blockIdx.x < hot_blocks) {
         eval_hot_role<FIXED>(p, *hep, hot_blocks);
         return;
     }
-    const uint32_t nc = hep->n[hep->ids];
+    // (a scalar: the loop's bounds and what the body derives from the part's length stay out of the vector registers)
+    const uint32_t nc = __builtin_amdgcn_readfirstlane(hep->n[hep->ids]);
     for (uint32_t bid = blockIdx.x - hot_blocks; bid * (uint32_t)(BLOCK * ITEMS) < nc; bid += cold_grid) {
+        uint32_t zero = 0u;
+        asm volatile("" : "+v"(zero));
         eval_sorted_body<false, true, ITEMS, FIXED, true, BLOCK>(p, sorted, nullptr, nullptr, loaded, seq, nullptr, 0u, hint, bid, nc,
-                                                                  (nc + BLOCK * ITEMS - 1) / (BLOCK * ITEMS));
+                                                                  (nc + BLOCK * ITEMS - 1) / (BLOCK * ITEMS), zero);
         __syncthreads(); // (the body's shared arrays are written again)
     }
 }

@@ -1,5 +1,6 @@
 // slots.hip -- tc_rate_limit_batch_slots: staging, grouping (radix sort / bucket path), evaluation, one-launch small batches
 #include "engine.hpp"
+#include <chrono>
 
 // ---- batch over slots -------------------------------------------------------
 // The device-side address of a pinned host array (tc_host_alloc / hipHostMalloc / hipHostRegister), or
@@ -303,19 +304,10 @@ static bool outputs_back_in_one_launch(tc_engine* e, const tc_batch& b, hipStrea
     return ok;
 }
 
-// Round 6: the hot list (range_part.hpp).  The evaluations note every run of at least hot.heavy_min requests in a small device
-// table, a copy of which reaches pinned memory now and then (the longest runs since the copy before: the table is cleared with
-// every copy, so a stream that stops being skewed empties the list with the next one); whenever a NEW copy has arrived the list
-// is made afresh from it: the (up to) rp::HOT_MAX slots with the longest runs, heaviest first (the order the gather's
-// units are cut for).  Never waits; a stream without heavy runs leaves the list empty.
-static void hot_refresh(tc_engine* e) {
-    tc_engine::Hot& h = e->hot;
-    if (!h.on || !h.notes_host) return;
-    const unsigned long long seq = *(volatile unsigned long long*)(h.notes_host + ev::HEAVY_SLOTS);
-    if (seq == h.seq_seen) return;
-    h.seq_seen = seq;
-    // one note per slot (the longest run), through a scratch hash: 8 192 notes at most, no sort of them all (this runs on the
-    // caller's thread between two enqueues: a first version sorted the notes twice and cost the pipeline 0.3 ms every 8th batch)
+// -> true: the list changed (h.made is the new one)
+static bool hot_make(tc_engine::Hot& h, uint64_t capacity) {
+    // one note per slot (the longest run), through a scratch hash: 8 192 notes at most, no sort of them all (a first version
+    // sorted the notes twice and cost the pipeline 0.3 ms every 8th batch)
     constexpr uint32_t SCR = 2u * ev::HEAVY_SLOTS;
     if (h.scratch.size() != SCR) h.scratch.assign(SCR, 0ull);
     else std::fill(h.scratch.begin(), h.scratch.end(), 0ull);
@@ -329,7 +321,7 @@ static void hot_refresh(tc_engine* e) {
     for (uint32_t i = 0; i < ev::HEAVY_SLOTS; ++i) {
         const unsigned long long v = ((volatile unsigned long long*)h.notes_host)[i];
         const uint32_t len = (uint32_t)(v >> 44), slot = (uint32_t)v;
-        if (len < h.heavy_min || slot >= e->capacity) continue;
+        if (len < h.heavy_min || slot >= capacity) continue;
         unsigned long long& en = probe(slot);
         if ((uint32_t)en < len) en = ((unsigned long long)(slot + 1u) << 32) | len;
     }
@@ -348,9 +340,9 @@ static void hot_refresh(tc_engine* e) {
     // does not care about their order -- and the tail of a skewed stream's list changes with every look (slots around heavy_min
     // requests per batch come and go; in round 6's first version so did the boundary between the 64th and the 65th heaviest,
     // and every change cost six installs and the hints about the ranges).
-    bool same = !h.slots.empty();
+    bool same = !h.made.empty();
     if (same) {
-        std::vector<uint32_t> cur(h.slots);
+        std::vector<uint32_t> cur(h.made);
         std::sort(cur.begin(), cur.end());
         for (size_t i = 0; i < found.size() && same; ++i) {
             const uint32_t len = (uint32_t)(found[i] >> 32), sl = 0xFFFFFFFFu - (uint32_t)found[i];
@@ -358,20 +350,107 @@ static void hot_refresh(tc_engine* e) {
             same = std::binary_search(cur.begin(), cur.end(), sl);
         }
         size_t both = 0;
-        for (const uint32_t sl : h.slots) both += probe(sl) != 0ull ? 1u : 0u; // (noted at all: on the new list or just below its cut)
-        same = same && both * 10u >= h.slots.size() * 9u && now.size() * 4u <= h.slots.size() * 5u + 128u; // (... nor has a crowd of new hot slots turned up)
+        for (const uint32_t sl : h.made) both += probe(sl) != 0ull ? 1u : 0u; // (noted at all: on the new list or just below its cut)
+        same = same && both * 10u >= h.made.size() * 9u && now.size() * 4u <= h.made.size() * 5u + 128u; // (... nor has a crowd of new hot slots turned up)
     }
-    if (now.empty() && h.slots.empty()) same = true;
+    if (now.empty() && h.made.empty()) same = true;
     if (same) {
-        h.stable_looks++;
-        return;
+        h.stable_looks.fetch_add(1u, std::memory_order_relaxed);
+        return false;
     }
-    h.stable_looks = 0;
-    h.slots.swap(now);
+    h.stable_looks.store(0u, std::memory_order_relaxed);
+    h.made.swap(now);
+    h.lists_made++;
+    return true;
+}
+
+static int64_t hot_clock_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// The maker's thread: while calls keep coming it looks at the copy's sequence word every ~100 us (so that a list is ready when
+// the caller comes back from a wait -- the driver's form: five batches, a device synchronisation, twenty timed batches); after
+// 20 ms without a call it sleeps until the next one.
+static void hot_worker(tc_engine::Hot* hp, uint64_t capacity) {
+    tc_engine::Hot& h = *hp;
+    constexpr int64_t IDLE_NS = 20'000'000;
+    std::unique_lock<std::mutex> lk(h.mu);
+    while (!h.stop) {
+        if (hot_clock_ns() - h.last_call_ns.load() > IDLE_NS) {
+            h.asleep.store(true);
+            if (hot_clock_ns() - h.last_call_ns.load() > IDLE_NS) h.cv.wait_for(lk, std::chrono::milliseconds(500)); // (a call that came in between saw `asleep` or is seen here)
+            h.asleep.store(false);
+            continue;
+        }
+        lk.unlock();
+        const unsigned long long seq = *(volatile unsigned long long*)(h.notes_host + ev::HEAVY_SLOTS);
+        if (seq != h.seq_seen) {
+            h.seq_seen = seq;
+            if (hot_make(h, capacity)) {
+                std::lock_guard<std::mutex> g(h.mu);
+                h.next = h.made;
+                h.next_ready.store(true, std::memory_order_release);
+            }
+        } else {
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        lk.lock();
+    }
+}
+
+void hot_worker_stop(tc_engine* e) { // (tc_engine_destroy, before the pinned notes are freed)
+    tc_engine::Hot& h = e->hot;
+    if (!h.worker_on) return;
+    {
+        std::lock_guard<std::mutex> g(h.mu);
+        h.stop = true;
+    }
+    h.cv.notify_all();
+    h.worker.join();
+    h.worker_on = false;
+}
+
+static void hot_taken(tc_engine* e) { // a new list in h.slots: the sets install it when they next need it
+    tc_engine::Hot& h = e->hot;
     if (++h.version == 0u) h.version = 1u;
     h.backoff = 0;
     *(volatile unsigned long long*)h.hint_cold_host = 0ull; // (what the old list left of the ranges says nothing about the new one)
     *(volatile unsigned long long*)(h.hint_cold_host + 1) = 0ull;
+}
+
+// Round 6: the hot list (range_part.hpp).  The evaluations note every run of at least hot.heavy_min requests in a small device
+// table, a copy of which reaches pinned memory now and then (the longest runs since the copy before: the table is cleared with
+// every copy, so a stream that stops being skewed empties the list with the next one); whenever a NEW copy has arrived the list
+// is made afresh from it: the (up to) rp::HOT_MAX slots with the longest runs, heaviest first.  Never waits; a stream without
+// heavy runs leaves the list empty.  (`starts`: this batch takes notes -- the maker's thread is worth having)
+static void hot_refresh(tc_engine* e, bool starts) {
+    tc_engine::Hot& h = e->hot;
+    if (!h.on || !h.notes_host) return;
+    if (!h.threaded) {
+        const unsigned long long seq = *(volatile unsigned long long*)(h.notes_host + ev::HEAVY_SLOTS);
+        if (seq == h.seq_seen) return;
+        h.seq_seen = seq;
+        if (hot_make(h, e->capacity)) {
+            h.slots = h.made;
+            hot_taken(e);
+        }
+        return;
+    }
+    h.last_call_ns.store(hot_clock_ns());
+    if (!h.worker_on) {
+        if (!starts) return;
+        h.worker = std::thread(hot_worker, &h, (uint64_t)e->capacity);
+        h.worker_on = true;
+    } else if (h.asleep.load()) {
+        std::lock_guard<std::mutex> g(h.mu);
+        h.cv.notify_one();
+    }
+    if (h.next_ready.load(std::memory_order_acquire)) {
+        {
+            std::lock_guard<std::mutex> g(h.mu);
+            h.slots.swap(h.next);
+            h.next_ready.store(false, std::memory_order_relaxed);
+        }
+        hot_taken(e);
+    }
 }
 
 // How is this batch grouped?  GROUP_RANGE: the range path (radix_sort.hpp / range_part.hpp: every tile partitioned by key range
@@ -385,7 +464,6 @@ static void hot_refresh(tc_engine* e) {
 enum { GROUP_LSD = 0, GROUP_RANGE = 1, GROUP_RANGE_RANK = 2 };
 static int range_applies(tc_engine* e, uint32_t n, bool piped, bool hot_allowed) {
     if (!e->range_ok || !(e->range_mode >= 2 || (e->range_mode == 1 && piped))) return GROUP_LSD;
-    hot_refresh(e);
     const unsigned long long h = *(volatile unsigned long long*)e->range_hint_host;
     const uint64_t hn = h >> 32, hmax = h & 0xFFFFFFFFull;
     // the share of a batch its largest range took (x 2^20), of the last RANGE_HINTS looks at the hint: a stream that
@@ -594,6 +672,54 @@ static void launch_eval_sorted(tc_engine* e, bool full, bool direct, bool piped,
     }
 }
 
+// The runtime builds a kernel's function object when it is FIRST launched (the symbol's lookup, its argument metadata: 40-150 us
+// on the calling thread).  A skewed stream's first batches go through the LSD passes and change over to the rank form once the
+// hot list has arrived -- in the driver's form (5 batches, a synchronisation, 20 timed batches) the change-over, and with it the
+// first launch of the rank form's three kernels, lay INSIDE the timed region.  Every kernel a pipelined slot batch can launch
+// is looked up once per process and device, where the side streams are probed (milliseconds anyway).
+static void preload_pipelined_kernels(tc_engine* e) {
+    if (e->kernels_preloaded) return;
+    e->kernels_preloaded = true;
+    static std::mutex mu;
+    static std::vector<int> done;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (std::find(done.begin(), done.end(), e->device) != done.end()) return;
+        done.push_back(e->device);
+    }
+    hipFuncAttributes at;
+#define TC_TOUCH(...) (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&__VA_ARGS__))
+    TC_TOUCH(rp::k_tile_part<rp::PART_PLAIN>);
+    TC_TOUCH(rp::k_tile_part<rp::PART_RANK>);
+    TC_TOUCH(rp::k_hot_install);
+    TC_TOUCH(rs::k_finish);
+    TC_TOUCH(rs::k_hist<rs::HIST_THREADS>);
+    TC_TOUCH(rs::k_onesweep<8, true>);
+    TC_TOUCH(rs::k_onesweep<8, false>);
+    TC_TOUCH(rs::k_onesweep<16, true>);
+    TC_TOUCH(rs::k_onesweep<16, false>);
+    TC_TOUCH(rs::k_onesweep<32, true>);
+    TC_TOUCH(rs::k_onesweep<32, false>);
+    TC_TOUCH(mk::k_heavy_publish);
+    TC_TOUCH(k_eval_lean_hot<1, true>);
+    TC_TOUCH(k_eval_lean_hot<2, true>);
+    TC_TOUCH(k_eval_lean_hot<4, true>);
+    TC_TOUCH(k_eval_lean_hot<1, false>);
+    TC_TOUCH(k_eval_lean_hot<2, false>);
+    TC_TOUCH(k_eval_lean_hot<4, false>);
+    TC_TOUCH(k_eval_sorted_lean<1, true>);
+    TC_TOUCH(k_eval_sorted_lean<2, true>);
+    TC_TOUCH(k_eval_sorted_lean<4, true>);
+    TC_TOUCH(k_eval_sorted_lean<1, false>);
+    TC_TOUCH(k_eval_sorted_lean<2, false>);
+    TC_TOUCH(k_eval_sorted_lean<4, false>);
+    TC_TOUCH(k_eval_general<true, true>);
+    TC_TOUCH(k_eval_general<false, true>);
+    TC_TOUCH(k_eval_general<false, false>);
+#undef TC_TOUCH
+    (void)hipGetLastError();
+}
+
 // ---- bucket path (bucket_path.hpp) -------------------------------------------------------------------
 // partition of the batch by key range, on stream `s` (k_tile_hist, k_bucket_scan, k_scatter)
 // (false: a launch was rejected -- the caller must not enqueue the bucket evaluation behind this partition)
@@ -778,6 +904,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             int rc = ensure_side_streams(e);
             if (rc != TC_E_OK) return rc;
             piped = e->n_aux != 0; // no free hardware queue: in order on the main stream
+            preload_pipelined_kernels(e);
         }
         // (the per-request columns of a TC_B_ASYNC host batch are still to be staged: they are in `hin`)
         auto column = [&](const int64_t* dev, int j) {
@@ -811,6 +938,7 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             p.heavy_min = e->hot.heavy_min;
             p.heavy_tag = (uint32_t)(e->hot.evals & ((1u << ev::HEAVY_TAG_BITS) - 1u));
         }
+        hot_refresh(e, notes);
         const int ranged = range_applies(e, n, piped, rank_ok);
         e->hot.he_dev = nullptr;
         // The range hint is written by the grouping kernels of the sort paths (k_hist's range row, k_finish).  An in-order batch
