@@ -372,6 +372,7 @@ def measure_stream(a, t, W, stream, dev, local, rank, seed_shift, dist, world, g
             dt_r, it = run_gpu(eng, d_batches, out, W.T0_NS, a.steps, 0, None, None, None, piped=True, nows=nows, it0=it)
             reps.append(1e3 * dt_r / a.steps)
         res["repeats"] = {"ms_per_step": reps, "median": float(np.median(reps)), "min": min(reps), "max": max(reps)}
+        log("  five regions, ms per step: " + " ".join(f"{x:.4f}" for x in reps))
     if rank == 0 and profile and not a.profile_run:
         piped = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it, piped=True, nows=nows)
         inorder = stage_profile(eng, d_batches, out, W.T0_NS, a.steps, it + a.steps, piped=False, nows=nows)

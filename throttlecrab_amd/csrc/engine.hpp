@@ -115,6 +115,7 @@ struct tc_engine {
         uint32_t* part_table = nullptr;                // round 6: rp::k_tile_part's table, rp::NB_HOT words per tile of rp::PT_TILE requests
         rp::HotDev* hot_dev = nullptr;                 // ... and the set's hot table, as of list version hot_version (0: none installed)
         uint32_t hot_version = 0;
+        unsigned long long publish_due = 0;            // a copy of the evaluations' notes to be enqueued when the set is next grouped aside (its sequence word; 0: none)
         uint32_t* hot_info = nullptr;                  // rank form: hot id << 16 | rank inside its tile per request (max_batch words)
         uint32_t* hot_P = nullptr;                     // ... requests of a hot id in the tiles before (tiles x rp::HOT_MAX words)
         uint32_t* hot_n = nullptr;                     // ... requests per hot id in the batch; [rp::HOT_MAX]: requests the ranges hold
@@ -204,7 +205,7 @@ struct tc_engine {
         uint64_t batches_hot = 0;        // batches grouped in the hot form so far
         std::atomic<uint32_t> stable_looks{0}; // looks in a row that kept the list
         bool rank_on = true;             // TCGPU_HOT_RANK=0: lean batches also take the gather form (A/B)
-        uint32_t* done = nullptr;        // rank form: the evaluation's count of finished hot-role blocks (zero between launches)
+        uint32_t* done = nullptr;        // rank form: the evaluation's count of finished hot-role blocks (zero between launches); word 8: k_heavy_publish's
         const ev::HotEval* he_dev = nullptr; // ... what the next lean evaluation is handed (nullptr: no hot role)
         std::vector<unsigned long long> scratch, found; // hot_make's workspace
         // The list is MADE on a thread of the engine's own (slots.hip: hot_worker): reading 8 192 notes, deduplicating and ranking

@@ -547,17 +547,26 @@ static __global__ __launch_bounds__(BLOCK) void k_copy(void* __restrict__ dst, c
 }
 
 // Round 6: the evaluation's notes on heavy runs (ev::heavy_note) -> pinned host memory, the sequence word of the copy behind them;
-// the table is cleared for the evaluations to come (this kernel runs on the engine's stream, between two of them).  One block.
-// Enqueued now and then (slots.hip), never waited for.
+// the table is cleared for the evaluations to come.  Enqueued now and then (slots.hip), never waited for.  1 024 words per block;
+// the last block to finish writes the sequence word.  (At first ONE block on the engine's stream, between two evaluations: 11-16 us
+// there, and a kernel boundary more on the stream every step waits for -- three times in the driver's twenty batches of a skewed
+// stream.  Now on the grouping stream of the next pipelined batch, beside the evaluations: a note that lands while the copy
+// runs is in this copy or the next one.)
 static __global__ __launch_bounds__(1024) void k_heavy_publish(unsigned long long* __restrict__ dst, unsigned long long* __restrict__ src,
-                                                               uint32_t words, unsigned long long seq) {
-    for (uint32_t i = threadIdx.x; i < words; i += 1024) {
-        dst[i] = src[i];
-        src[i] = 0ull;
+                                                               uint32_t words, unsigned long long seq, uint32_t* __restrict__ done) {
+    const uint32_t i = blockIdx.x * 1024u + threadIdx.x;
+    if (i < words) {
+        dst[i] = __hip_atomic_exchange(&src[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(&dst[words], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            __hip_atomic_store(&dst[words], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
 }
 
 // Round 6, TC_B_PLAN_DICT: the batch's dictionary-coded plan column (and its u32 quantities) -> the wide staging columns every

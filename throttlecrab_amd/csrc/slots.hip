@@ -408,12 +408,20 @@ void hot_worker_stop(tc_engine* e) { // (tc_engine_destroy, before the pinned no
     h.worker_on = false;
 }
 
-static void hot_taken(tc_engine* e) { // a new list in h.slots: the sets install it when they next need it
+static void hot_publish(tc_engine* e, hipStream_t st, unsigned long long seq) {
+    static_assert(ev::HEAVY_SLOTS % 1024u == 0u, "k_heavy_publish: 1 024 words per block");
+    hipLaunchKernelGGL(mk::k_heavy_publish, dim3(ev::HEAVY_SLOTS / 1024u), dim3(1024), 0, st, e->hot.notes_host_dev, e->hot.notes_dev, ev::HEAVY_SLOTS, seq,
+                       e->hot.done + 8);
+}
+
+static void hot_taken(tc_engine* e, bool had_list) { // a new list in h.slots: the sets install it when they next need it
     tc_engine::Hot& h = e->hot;
     if (++h.version == 0u) h.version = 1u;
     h.backoff = 0;
     *(volatile unsigned long long*)h.hint_cold_host = 0ull; // (what the old list left of the ranges says nothing about the new one)
-    *(volatile unsigned long long*)(h.hint_cold_host + 1) = 0ull;
+    // (how many requests the ranges held sizes the sorted part's grid, with a quarter to spare and a second stretch per block if
+    // that is short: a list that replaces another one moves it little -- kept, or the next evaluations would get the whole batch's grid)
+    if (!had_list) *(volatile unsigned long long*)(h.hint_cold_host + 1) = 0ull;
 }
 
 // Round 6: the hot list (range_part.hpp).  The evaluations note every run of at least hot.heavy_min requests in a small device
@@ -429,8 +437,9 @@ static void hot_refresh(tc_engine* e, bool starts) {
         if (seq == h.seq_seen) return;
         h.seq_seen = seq;
         if (hot_make(h, e->capacity)) {
+            const bool had = !h.slots.empty();
             h.slots = h.made;
-            hot_taken(e);
+            hot_taken(e, had);
         }
         return;
     }
@@ -444,12 +453,14 @@ static void hot_refresh(tc_engine* e, bool starts) {
         h.cv.notify_one();
     }
     if (h.next_ready.load(std::memory_order_acquire)) {
+        bool had;
         {
             std::lock_guard<std::mutex> g(h.mu);
+            had = !h.slots.empty();
             h.slots.swap(h.next);
             h.next_ready.store(false, std::memory_order_relaxed);
         }
-        hot_taken(e);
+        hot_taken(e, had);
     }
 }
 
@@ -983,6 +994,10 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             hipStream_t ax = e->aux[e->next_aux];
             e->next_aux = (e->next_aux + 1) % e->n_aux;
             if (ss.in_use) TC_HIP(e, hipStreamWaitEvent(ax, ss.consumed, 0)); // the evaluation that read this set is done
+            if (ss.publish_due) { // ... and the notes it took go to the host's hot list
+                hot_publish(e, ax, ss.publish_due);
+                ss.publish_due = 0ull;
+            }
             // (the request columns do not depend on the key stage: their transfer goes out before the wait for it -- round 5: it
             // used to sit behind that wait, so that a chunk's columns only started to cross PCIe once its keys were resolved)
             if (hin) TC_TRY(stage_host_inputs(e, ss, *hin, n, ax, p, &d_slot)); // PCIe transfer overlaps earlier evaluations
@@ -1060,7 +1075,11 @@ int run_slots_device(tc_engine* e, const tc_batch& b, const HostIn* hin) {
             const uint64_t k = ++e->hot.evals;
             if (k <= 4 || ((k & 7u) == 0u && (e->hot.stable_looks < 4u || (k & 31u) == 0u))) { // (a list that has settled is looked at every 32nd batch)
                 const unsigned long long seq = ((unsigned long long)(++e->hot.published) << ev::HEAVY_TAG_BITS) | p.heavy_tag;
-                hipLaunchKernelGGL(mk::k_heavy_publish, dim3(1), dim3(1024), 0, s, e->hot.notes_host_dev, e->hot.notes_dev, ev::HEAVY_SLOTS, seq);
+                // (A pipelined stream past its first batches: on the grouping stream of the batch that next uses this set, which waits
+                // for this evaluation anyway -- a few batches later, a copy of whole evaluations as before, and not a kernel more on the
+                // stream every step waits for.  The first four: at once, the list they are for is what a skewed stream is waiting for.)
+                if (piped && k > 4) ss.publish_due = seq;
+                else hot_publish(e, s, seq);
             }
         }
         // a later TC_B_INPUTS_READY batch may re-sort into this set on the auxiliary stream
