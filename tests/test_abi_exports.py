@@ -112,3 +112,33 @@ def test_the_shipped_library_has_no_switch_that_corrupts_results():
     for path in glob.glob(os.path.join(ROOT, "throttlecrab_amd", "csrc", "*.h*")):
         read |= set(re.findall(r'getenv\("(TCGPU_[A-Z0-9_]+)"\)', open(path).read()))
     assert read and not [v for v in read if v not in header], sorted(v for v in read if v not in header)
+
+
+def test_no_kernel_of_the_library_needs_scratch(tmp_path):
+    """Round 6: a kernel with a private segment stalls its FIRST dispatch in a process until the runtime has allocated
+    the queue's scratch -- hundreds of microseconds in the middle of a pipelined stream (`k_eval_lean_hot` kept six
+    loop-invariant words on the stack and paid for it inside the driver's timed region).  Every gfx950 code object of the
+    in-tree library is taken out of it and its kernels' metadata read: `.private_segment_fixed_size` must be 0 everywhere."""
+    import shutil
+    import subprocess
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not (os.path.exists(os.path.join(llvm, "llvm-objdump")) and os.path.exists(os.path.join(llvm, "llvm-readelf"))):
+        pytest.skip("no ROCm LLVM tools here")
+    lib = shutil.copy(os.path.join(ROOT, "throttlecrab_amd", "libtcgpu.so"), tmp_path / "libtcgpu.so")
+    subprocess.run([os.path.join(llvm, "llvm-objdump"), "--offloading", str(lib)], check=True, capture_output=True, cwd=tmp_path)
+    objs = [f for f in os.listdir(tmp_path) if "gfx950" in f]
+    assert len(objs) >= 5, objs   # (one per translation unit that launches kernels)
+    kernels, with_scratch = 0, []
+    for f in objs:
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", str(tmp_path / f)], check=True, capture_output=True, text=True).stdout
+        name = None
+        for line in notes.splitlines():
+            m = re.match(r"\s*\.name:\s+(\S+)", line)
+            if m:
+                name = m.group(1)
+            m = re.match(r"\s*\.private_segment_fixed_size:\s+(\d+)", line)
+            if m:
+                kernels += 1
+                if int(m.group(1)) != 0:
+                    with_scratch.append((name, int(m.group(1))))
+    assert kernels > 100 and not with_scratch, with_scratch

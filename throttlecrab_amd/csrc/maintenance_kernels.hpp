@@ -391,12 +391,18 @@ static __global__ __launch_bounds__(BLOCK) void k_gather_keyrecs(kt::Table t, co
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const uint32_t s = slots[i];
-    kt::KeyRec r;
-    r.hash = 0;
-    r.len = kt::NO_SLOT;
-    r.pos = 0;
-    if (s < t.capacity && t.bound[s]) r = t.rec[s];
-    out[i] = r;
+    // (eight 16-byte words, no record on the stack: this was the library's last kernel with scratch -- see k_eval_lean_hot)
+    typedef unsigned long long v2u64 __attribute__((ext_vector_type(2)));
+    static_assert(sizeof(kt::KeyRec) == 128, "eight 16-byte words");
+    const bool have = s < t.capacity && t.bound[s];
+    const v2u64* __restrict__ src = reinterpret_cast<const v2u64*>(&t.rec[have ? s : 0u]);
+    v2u64* __restrict__ dst = reinterpret_cast<v2u64*>(&out[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v2u64 v = src[j];
+        if (!have) v = j == 0 ? v2u64{0ull, (unsigned long long)kt::NO_SLOT} : v2u64{0ull, 0ull}; // hash 0, len NO_SLOT, pos 0
+        dst[j] = v;
+    }
 }
 
 static __global__ __launch_bounds__(BLOCK) void k_fill_i64(int64_t* __restrict__ a, uint64_t n, int64_t v) {
