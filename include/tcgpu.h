@@ -38,7 +38,7 @@
  *   evaluation   TCGPU_EVAL_ITEMS  TCGPU_EVAL_LEAN  TCGPU_PREFILL  TCGPU_GENERAL_EARLIER  TCGPU_GENERAL_RUNS  TCGPU_GENERAL_LEAN
  *                TCGPU_NO_SMALL_BATCH
  *   host batches TCGPU_HOST_CHUNK  TCGPU_BOUNCE_MAX  TCGPU_COPY_KERNEL  TCGPU_ASYNC_COPY_KERNEL_N  TCGPU_SYNC_COPY_MAX
- *   string keys  TCGPU_SPREAD_FREE        multi-GPU  TCGPU_EXCHANGE_WAIT_S
+ *   string keys  TCGPU_SPREAD_FREE  TCGPU_SWEEP_ASIDE        multi-GPU  TCGPU_EXCHANGE_WAIT_S
  * One more, TCGPU_DEBUG_NO_DECISION_STORE (the lean kernel skips its decision bytes: wrong results, for timing only), exists
  * only in libraries built with `make DEBUG_KNOBS=1` (-DTCGPU_DEBUG_KNOBS); the library this header ships with ignores it.
  */
@@ -617,6 +617,9 @@ typedef struct tc_engine_info {
     uint64_t hot_batches;          /* batches grouped with the hot slots peeled out so far */
     uint64_t probes_pooled;        /* 1: the grouping streams came from the process's pool -- streams an earlier engine on this main stream
                                     * had probed, re-checked against the main stream instead of probing sixteen new candidates */
+    uint64_t sweeps_aside;         /* string mode, round 6: explicit sweeps (tc_sweep_expired right behind a pipelined key batch) that ran on
+                                    * the key stream BESIDE that batch's evaluation instead of behind it (TCGPU_SWEEP_ASIDE=0: never).  A caller
+                                    * built against the struct without this field passes its smaller struct_size and gets the fields it knows */
 } tc_engine_info;
 int tc_engine_info_get(tc_engine* e, tc_engine_info* out);
 

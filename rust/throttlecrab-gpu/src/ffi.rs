@@ -126,6 +126,7 @@ pub struct tc_engine_info {
     pub hot_slots: u64,
     pub hot_batches: u64,
     pub probes_pooled: u64,
+    pub sweeps_aside: u64,
 }
 
 /// one rank's side of `replicate` mode (opaque)

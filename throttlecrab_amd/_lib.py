@@ -91,7 +91,7 @@ class tc_engine_info(C.Structure):
                 ("probes_assumed", C.c_uint32), ("pipelining_degraded", C.c_uint32), ("scratch_sets", C.c_uint32),
                 ("grouping_path", C.c_uint32), ("range_path_possible", C.c_uint32), ("range_hint_requests", C.c_uint64),
                 ("range_hint_largest", C.c_uint64), ("host_chunk_requests", C.c_uint64), ("batches", C.c_uint64),
-                ("hot_slots", C.c_uint64), ("hot_batches", C.c_uint64), ("probes_pooled", C.c_uint64)]
+                ("hot_slots", C.c_uint64), ("hot_batches", C.c_uint64), ("probes_pooled", C.c_uint64), ("sweeps_aside", C.c_uint64)]
 
 
 class tc_shard_config(C.Structure):

@@ -367,6 +367,9 @@ int key_mode_alloc(tc_engine* e, uint64_t key_arena_bytes) {
     TC_HIP(e, hipMemcpyAsync(t.free_top, &top, sizeof top, hipMemcpyHostToDevice, (hipStream_t)0));
     TC_HIP(e, hipMalloc(&e->k_slot, mb * 4));
     for (uint32_t si = 0; si < e->depth; ++si) TC_HIP(e, hipMalloc(&e->sets[si].k_slot, mb * 4));
+    TC_HIP(e, hipMalloc(&e->touched, (cap + 15) / 16 * 16 + 16));
+    TC_HIP(e, hipMemsetAsync(e->touched, 0, (cap + 15) / 16 * 16 + 16, (hipStream_t)0));
+    if (const char* d = getenv("TCGPU_SWEEP_ASIDE")) e->sweep_aside = atoi(d) != 0;
     TC_HIP(e, hipEventCreateWithFlags(&e->k_done, hipEventDisableTiming));
     TC_HIP(e, hipEventCreateWithFlags(&e->m_done, hipEventDisableTiming));
     TC_HIP(e, hipMalloc(&e->k_state, mb));
@@ -652,7 +655,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
     if (e->m_done) (void)hipEventDestroy(e->m_done);
     for (tc_engine::SortSet& ss : e->sets)
         if (ss.k_slot) (void)hipFree(ss.k_slot);
-    void* kptrs[] = {e->sweep_part, e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_stage_bytes, e->k_stage_off};
+    void* kptrs[] = {e->sweep_part, e->retired, e->kt_block, e->k_slot, e->k_state, e->k_aux, e->k_claim, e->k_stage_bytes, e->k_stage_off, e->touched};
     for (void* p : kptrs)
         if (p) (void)hipFree(p);
     if (e->small_io) (void)hipHostFree(e->small_io);
@@ -671,6 +674,7 @@ extern "C" void tc_engine_destroy(tc_engine* e) {
 
 extern "C" int tc_engine_set_stream(tc_engine* e, void* hip_stream) {
     if (!e) return TC_E_INVALID_ARG;
+    e->api_seq++;
     TC_HIP(e, hipSetDevice(e->device));
     if (e->user_stream || e->own_stream) TC_HIP(e, hipStreamSynchronize(cur_stream(e))); // drain the old one first
     e->user_stream = (hipStream_t)hip_stream;
@@ -812,6 +816,7 @@ extern "C" int tc_register_params(tc_engine* e, uint64_t n, const uint32_t* slot
 
 extern "C" int tc_counters_refresh(tc_engine* e) {
     if (!e) return TC_E_INVALID_ARG;
+    e->api_seq++;
     TC_HIP(e, hipSetDevice(e->device));
     hipLaunchKernelGGL(k_fold_counters, dim3(1), dim3(NSHARD), 0, cur_stream(e), e->counters);
     TC_HIP(e, hipGetLastError());
@@ -925,10 +930,11 @@ extern "C" int tc_debug_fail_copy(tc_engine* e, uint32_t nth) {
 // Internal invariant violations seen so far (0 unless there is a bug): runs that turned out
 // irregular in a batch the host had proved regular (k_eval_sorted<DIRECT>).
 extern "C" int tc_engine_info_get(tc_engine* e, tc_engine_info* out) {
-    if (!e || !out || out->struct_size < sizeof(tc_engine_info)) return TC_E_INVALID_ARG;
+    if (!e || !out || out->struct_size < offsetof(tc_engine_info, sweeps_aside)) return TC_E_INVALID_ARG;
+    const uint32_t caller_size = std::min<uint32_t>(out->struct_size, (uint32_t)sizeof(tc_engine_info));
     tc_engine_info r;
     memset(&r, 0, sizeof r);
-    r.struct_size = sizeof r;
+    r.struct_size = caller_size;
     const bool probed = e->side_ready && e->side_for == cur_stream(e);
     r.side_streams_probed = probed ? 1u : 0u;
     r.grouping_streams_wanted = e->n_aux_want;
@@ -955,12 +961,14 @@ extern "C" int tc_engine_info_get(tc_engine* e, tc_engine_info* out) {
     r.hot_slots = e->hot.slots.size();
     r.hot_batches = e->hot.batches_hot;
     r.probes_pooled = (probed && e->probe_pooled) ? 1u : 0u;
-    *out = r;
+    r.sweeps_aside = e->sweeps_aside;
+    memcpy(out, &r, caller_size);
     return TC_E_OK;
 }
 
 extern "C" int tc_selfcheck(tc_engine* e, uint64_t* violations) {
     if (!e || !violations) return TC_E_INVALID_ARG;
+    e->api_seq++;
     TC_HIP(e, hipSetDevice(e->device));
     unsigned long long v = 0;
     TC_HIP(e, hipMemcpyAsync(&v, e->counters + (TC_CNT_COUNT + 1) + 3, sizeof v, hipMemcpyDeviceToHost, cur_stream(e)));

@@ -136,6 +136,7 @@ struct tc_engine {
         hipEvent_t sorted = nullptr;   // recorded on the auxiliary stream after the last pass
         hipEvent_t consumed = nullptr; // recorded on `stream` after the evaluation that read this set
         bool in_use = false;
+        uint32_t k_n = 0;              // string mode: requests of the pipelined key batch whose slots are in k_slot (the sweep beside evaluations)
         bool grouped_aside = false;    // the set's last batch was grouped on an auxiliary stream (`sorted` says when)
         // the caller-owned slot columns this set's batches read (the latest few: a set is reused every `depth` batches).
         // tc_route_batch (TC_ROUTE_AHEAD) orders itself behind the readers of the buffer it overwrites: waiting for the
@@ -367,6 +368,20 @@ struct tc_engine {
     hipStream_t key_stream = nullptr;
     hipEvent_t k_done = nullptr, m_done = nullptr;
     bool k_busy = false, m_busy = false;
+    // Round 6 (late): an explicit sweep right behind pipelined key batches can run on the KEY stream, beside the newest batches'
+    // evaluations instead of behind them (keys.hip: sweep_keys_device) -- the slots those batches asked for are marked, left out of the
+    // scan and looked at once the newest evaluation is done (mk::k_sweep_fixup).  Exact (tests/test_gpu_sweep_aside.py) and OFF by
+    // default: the key stream's idle time around a sweep stays what it was (238 -> 242 us in the traces, configs[4] 0-2 % either way,
+    // profiles/r06_v45_sweep_aside_ab.txt) -- beside two batches' grouping and evaluation the sweep's kernels take twice as long.
+    bool sweep_aside = false;       // TCGPU_SWEEP_ASIDE=1: on
+    uint8_t* touched = nullptr;     // [capacity rounded up to 16, + 16] the marks (zero outside such a sweep)
+    int aside_set = -1;             // the scratch set of the newest pipelined key batch (its slot column, its evaluation's event);
+                                    //   -1: something else has touched the cells or the table since
+    uint32_t aside_streak = 0;      // pipelined key batches in a row with nothing else between them (a sweep goes aside from 2: the
+                                    // evaluation of the batch before the newest is then the last thing in front of the newest on the engine's stream)
+    uint64_t sweeps_aside = 0;
+    uint64_t api_seq = 0;           // entry points called so far (TC_CHECK_POISON)
+    uint64_t aside_seq = 0;         // ... when the newest pipelined key batch was noted
     hipEvent_t wait_before_sort = nullptr; // piped key batch: the auxiliary sort waits for its key stage
     uint8_t* k_stage_bytes = nullptr; // host-pointer batches: staged key arena
     size_t k_stage_bytes_cap = 0;
@@ -420,10 +435,13 @@ struct tc_engine {
         if (_trc != TC_E_OK) return _trc; \
     } while (0)
 
+// (every entry point that takes an engine comes through here: `api_seq` lets the sweep beside an evaluation -- keys.hip:
+// sweep_keys_device -- see that nothing was called between the newest pipelined key batch and itself)
 #define TC_CHECK_POISON(e)              \
     do {                                \
         int _prc = poisoned(e);         \
         if (_prc != TC_E_OK) return _prc; \
+        (e)->api_seq++;                 \
     } while (0)
 
 #define TC_TRY(call)                  \
@@ -553,14 +571,26 @@ int auto_sweep_after(tc_engine* e, uint64_t n, bool key_batch, const int64_t* no
 // a synchronous call ran out of slots: sweep at now_ns and wait (the caller applies the rejected requests again)
 int auto_sweep_for_retry(tc_engine* e, int64_t now_ns);
 inline bool auto_sweep_on(const tc_engine* e) { return e->as.kind != TC_SWEEP_NONE; }
+// The sweep beside an evaluation (keys.hip: sweep_keys_device).  `aside_streak` pipelined key batches in a row, with nothing between
+// them on the engine's stream but sweeps that went aside themselves (those run on the key stream): the evaluation of the batch before
+// the newest is then the last thing in front of the newest batch's on the engine's stream.  `aside_seq` = api_seq when the chain was
+// last extended: the call being served continues it only if it is the very next one.
+inline void aside_reset(tc_engine* e) { e->aside_set = -1, e->aside_streak = 0; }
+inline bool aside_fresh(const tc_engine* e) { return e->aside_streak != 0u && e->api_seq == e->aside_seq + 1; }
+inline uint32_t aside_chain(const tc_engine* e) { return aside_fresh(e) ? e->aside_streak : 0u; } // (taken before the batch resets it)
+inline void aside_note(tc_engine* e, uint32_t chain, int set_index, uint32_t n) {
+    e->aside_set = set_index, e->sets[set_index].k_n = n, e->aside_streak = chain + 1u, e->aside_seq = e->api_seq;
+}
+// a sweep went aside: the chain goes on, but a second sweep behind the same batch goes behind everything
+inline void aside_swept(tc_engine* e) { e->aside_set = -1, e->aside_seq = e->api_seq; }
 // maint.hip
-int sweep_enqueue(tc_engine* e, int64_t now_ns); // tc_sweep_expired without the wait
+int sweep_enqueue(tc_engine* e, int64_t now_ns, bool may_go_aside = false); // tc_sweep_expired without the wait
 // keys.hip
 int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert, uint32_t* out_slot, bool on_key_stream);
 int stage_keys(tc_engine* e, const uint8_t* key_bytes, const uint32_t* key_off, uint64_t n, const uint8_t** d_bytes, const uint32_t** d_off,
                const tc_batch* cols = nullptr);
 int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool insert, uint32_t* slot);
-int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_scratch);
+int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_scratch, bool aside = false);
 
 inline void prof_begin_m(tc_engine* e, int stage, hipStream_t s) {
     if (e->prof_markers) prof_begin(e, stage, s);

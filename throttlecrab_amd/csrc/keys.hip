@@ -10,6 +10,7 @@ int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_
         if (e->m_busy) TC_HIP(e, hipStreamWaitEvent(s, e->m_done, 0));
     } else {
         if (e->k_busy) TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        aside_reset(e); // (key work on the engine's stream: the next sweep goes behind it)
     }
     const dim3 grid(nblocks(n)), block(kt::THREADS);
     bool carried = false;
@@ -90,20 +91,52 @@ int resolve_one_key(tc_engine* e, const uint8_t* key, size_t key_len, bool inser
 // a key-mode sweep on the engine's stream (maintenance_kernels.hpp: k_sweep_keys, k_sweep_decide, k_sweep_tombstones), then the
 // rare work: the table rebuilt once tombstones + the keys just unbound exceed 1/4 of it, the overflow arena (keys longer than
 // 112 bytes) compacted once more than half of it is handed out -- both decided on the device, near-empty launches otherwise
-int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_scratch) {
+// `aside` (round 6, maint.hip decides): the newest work on the table was a pipelined key batch's key stage, and the last `aside_streak`
+// things on the engine's stream are the evaluations of such batches, nothing else.  The sweep then goes onto the KEY stream: wait for
+// the evaluation in front of the newest TWO (done, or nearly: the evaluations run one to two batches behind the key stages), mark the
+// slots those two batches asked for, scan / decide / tombstones (/ rebuild) leaving the marked slots alone -- beside those batches'
+// grouping and evaluation, which touch nothing but the marked slots' cells --, then wait for the newest evaluation and look at the
+// marked slots (mk::k_sweep_fixup).  The key stages of later batches follow on the same stream.  configs[4]: the key stream used to
+// idle 240-280 us around every sweep, 120-130 of them waiting for the grouping and the evaluations in front of it.
+int sweep_keys_device(tc_engine* e, int64_t now_ns, unsigned long long* removed_scratch, bool aside) {
     kt::Table& t = e->kt;
-    hipStream_t s = cur_stream(e);
+    hipStream_t s = aside ? e->key_stream : cur_stream(e);
     uint32_t* flag = t.error_flag + 1; // spare word of the table's misc block
     int* top_save = reinterpret_cast<int*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 48);
     unsigned long long* oflag = reinterpret_cast<unsigned long long*>(reinterpret_cast<uint8_t*>(t.overflow_used) + 32);
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(nblocks(e->capacity), mk::SWEEP_GRID);
     const dim3 block(kt::THREADS);
-    hipLaunchKernelGGL(mk::k_sweep_keys, dim3(blocks), dim3(BLOCK), 0, s, e->cells, t, now_ns, e->sweep_work, e->denied);
+    tc_engine::SortSet* last = aside ? &e->sets[e->aside_set] : nullptr;
+    if (aside) {
+        // the newest `marked` batches' slots are marked (2 of a streak of 3 or more); the evaluation in front of them is waited for
+        const uint32_t marked = std::min<uint32_t>(std::min<uint32_t>(e->aside_streak - 1u, e->depth - 1u), 2u);
+        tc_engine::SortSet& before = e->sets[(e->aside_set + e->depth - marked) % e->depth];
+        if (before.in_use) TC_HIP(e, hipStreamWaitEvent(s, before.consumed, 0));
+        for (uint32_t k = 0; k < marked; ++k) {
+            const tc_engine::SortSet& ms = e->sets[(e->aside_set + e->depth - k) % e->depth];
+            hipLaunchKernelGGL(mk::k_touch_mark, dim3(nblocks(ms.k_n)), dim3(BLOCK), 0, s, (const uint32_t*)ms.k_slot, ms.k_n, (uint32_t)e->capacity, e->touched);
+        }
+    }
+    hipLaunchKernelGGL(mk::k_sweep_keys, dim3(blocks), dim3(BLOCK), 0, s, e->cells, t, now_ns, e->sweep_work, e->denied, aside ? (const uint8_t*)e->touched : (const uint8_t*)nullptr);
     hipLaunchKernelGGL(mk::k_sweep_decide, dim3(1), dim3(mk::DECIDE_THREADS), 0, s, t, e->sweep_work, blocks, top_save, flag, oflag,
                        removed_scratch, e->counters);
     hipLaunchKernelGGL(mk::k_sweep_tombstones, dim3(blocks), dim3(BLOCK), 0, s, t, e->sweep_work, (const int*)top_save, (const uint32_t*)flag,
                        e->spread_free ? 1u : 0u);
     hipLaunchKernelGGL(kt::k_table_clear_compact, dim3(std::min<uint64_t>(nblocks(t.nb_mask + 1), 4096)), block, 0, s, t, (const uint32_t*)flag, oflag);
+    if (aside) {
+        hipLaunchKernelGGL(kt::k_table_reinsert, dim3(std::min<uint64_t>((t.capacity + kt::RE_TILE - 1) / kt::RE_TILE, 2048)), block, 0, s, t, (const uint32_t*)flag,
+                           (const unsigned long long*)oflag);
+        TC_HIP(e, hipStreamWaitEvent(s, last->consumed, 0)); // the newest batch's evaluation
+        // (the sweep's completion event -- work on the engine's stream that touches the table waits for it -- rides on its last kernel)
+        TC_LAUNCH(e->k_done, mk::k_sweep_fixup, dim3(std::min<uint64_t>(nblocks((e->capacity + 15) / 16), 4096)), dim3(BLOCK), 0, s, e->cells, t, now_ns, e->touched,
+                  e->denied, removed_scratch, e->counters);
+        TC_HIP(e, hipGetLastError());
+        e->k_busy = true;
+        e->m_busy = false;
+        e->sweeps_aside++;
+        aside_swept(e);
+        return TC_E_OK;
+    }
     // (the sweep's completion event -- later key stages on the key stream wait for it -- rides on its last kernel)
     TC_LAUNCH(e->m_done, kt::k_table_reinsert, dim3(std::min<uint64_t>((t.capacity + kt::RE_TILE - 1) / kt::RE_TILE, 2048)), block, 0, s, t, (const uint32_t*)flag,
               (const unsigned long long*)oflag);
@@ -192,7 +225,11 @@ static int run_keys_host_async(tc_engine* e, const tc_batch& b) {
     }
     if (piped) e->wait_before_sort = e->k_done;
     TC_TRY(stage_outputs(e, b, d));
+    const int set_index = (int)e->next_set; // (== &ss: run_slots_device takes this set)
+    const uint32_t chained = aside_chain(e);
+    aside_reset(e);
     TC_TRY(run_slots_device(e, d, &hin));
+    if (piped) aside_note(e, chained, set_index, n);
     return finish_async(e, b);
 }
 
@@ -269,7 +306,12 @@ static int keys_batch_dispatch(tc_engine* e, const tc_batch& b) {
         if (piped) e->wait_before_sort = e->k_done;
         else s.flags &= ~TC_B_INPUTS_READY; // the slots were resolved on the main stream: group there too
         s.slot = ss.k_slot;
-        return run_slots_device(e, s);
+        const int set_index = (int)e->next_set; // (run_slots_device takes this set)
+        const uint32_t chained = aside_chain(e);
+        aside_reset(e);
+        rc = run_slots_device(e, s);
+        if (rc == TC_E_OK && piped && e->n_aux != 0) aside_note(e, chained, set_index, (uint32_t)b.n);
+        return rc;
     }
     int rc = resolve_keys_device(e, d_bytes, d_off, (uint32_t)b.n, true, e->k_slot, false);
     if (rc != TC_E_OK) return rc;
@@ -631,6 +673,7 @@ extern "C" int tc_lookup_slot(tc_engine* e, const uint8_t* key, size_t key_len, 
 extern "C" int tc_slot_keys(tc_engine* e, uint32_t n, const uint32_t* slots, uint8_t* key_bytes, size_t key_bytes_cap,
                             uint32_t* key_off) {
     if (!e || (n && (!slots || !key_off)) || (key_bytes_cap && !key_bytes)) return TC_E_INVALID_ARG;
+    e->api_seq++;
     if (!e->key_mode) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_KEY_MODE");
     if (n == 0) return TC_E_OK;
     TC_HIP(e, hipSetDevice(e->device));

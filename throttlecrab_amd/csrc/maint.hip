@@ -73,9 +73,14 @@ static int compact_retired(tc_engine* e, bool force, std::vector<std::pair<std::
 // AdaptiveStore::cleanup at now_ns, enqueued on the engine's stream (tc_sweep_expired without the wait; the engine's own
 // cleanups, autosweep.hip, come through here too).  The number removed lands in counters[TC_CNT_COUNT] (scratch) and is added
 // to TC_CNT_SWEPT.
-int sweep_enqueue(tc_engine* e, int64_t now_ns) {
+int sweep_enqueue(tc_engine* e, int64_t now_ns, bool may_go_aside) {
     hipStream_t s = cur_stream(e);
     unsigned long long* scratch = e->counters + TC_CNT_COUNT;
+    // (round 6: right behind a pipelined key batch, on the key stream and beside that batch's evaluation -- keys.hip)
+    if (may_go_aside && e->key_mode && e->sweep_aside && e->touched && e->key_stream && e->k_busy && !e->m_busy && aside_fresh(e) && e->aside_set >= 0 && e->aside_streak >= 2u && e->depth >= 2 &&
+        !e->prof_on && e->sets[e->aside_set].in_use)
+        return sweep_keys_device(e, now_ns, scratch, true);
+    aside_reset(e);
     if (e->k_busy) { // key stages still in flight on the key stream come first
         TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
         e->k_busy = false;
@@ -99,9 +104,14 @@ extern "C" int tc_sweep_expired(tc_engine* e, int64_t now_ns, uint64_t* removed)
     if (!e) return TC_E_INVALID_ARG;
     TC_CHECK_POISON(e);
     TC_HIP(e, hipSetDevice(e->device));
-    TC_TRY(sweep_enqueue(e, now_ns));
+    // (the engine's own cleanups read the sweep's outcome with kernels on the engine's stream: autosweep.hip -- they stay there)
+    TC_TRY(sweep_enqueue(e, now_ns, !auto_sweep_on(e)));
     if (!removed) return TC_E_OK; // asynchronous: the count goes to TC_CNT_SWEPT
     hipStream_t s = cur_stream(e);
+    if (e->k_busy) { // (the sweep ran on the key stream)
+        TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
+        e->k_busy = false;
+    }
     unsigned long long r = 0;
     TC_HIP(e, hipMemcpyAsync(&r, e->counters + TC_CNT_COUNT, sizeof r, hipMemcpyDeviceToHost, s));
     TC_HIP(e, hipStreamSynchronize(s));
@@ -213,6 +223,7 @@ extern "C" int tc_top_denied(tc_engine* e, uint32_t k, uint32_t* slots, uint64_t
 
 extern "C" int tc_denied_reset(tc_engine* e) {
     if (!e) return TC_E_INVALID_ARG;
+    e->api_seq++;
     if (!e->denied) return fail(e, TC_E_UNSUPPORTED, "engine was created without TC_CFG_TRACK_DENIED");
     TC_HIP(e, hipSetDevice(e->device));
     if (e->retired) TC_TRY(drain_key_work(e)); // (a bind kernel on the key stream may be moving counts out of the table)

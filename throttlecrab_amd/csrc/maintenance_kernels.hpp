@@ -149,8 +149,12 @@ __host__ __device__ __forceinline__ uint64_t sweep_per_block(uint64_t capacity, 
     return ((capacity + blocks - 1) / blocks + BLOCK - 1) / BLOCK * BLOCK;
 }
 
+// `touched` (round 6, the sweep BESIDE the newest batch's evaluation -- keys.hip: sweep_keys_device): a byte per slot, non-zero for
+// the slots that batch asked for.  Its evaluation may still be writing their cells, so they are left alone here (counted live,
+// which they are unless their request was an error or denied on a key that had expired) and looked at by k_sweep_fixup once that
+// evaluation is done.  nullptr: the sweep runs behind every evaluation, as before.
 static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ cells, kt::Table t, int64_t now, SweepWork work,
-                                                      uint32_t* __restrict__ denied) {
+                                                      uint32_t* __restrict__ denied, const uint8_t* __restrict__ touched) {
     uint32_t removed = 0, live = 0, fill = 0; // fill is uniform over the block
     const uint64_t per_block = sweep_per_block(t.capacity, gridDim.x);
     const uint64_t first = (uint64_t)blockIdx.x * per_block;
@@ -169,18 +173,26 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
             const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
             bnd[j] = i < last ? t.bound[i] : (uint8_t)0;
         }
+        uint8_t tch[SWEEP_ITEMS];
+#pragma unroll
+        for (int j = 0; j < SWEEP_ITEMS; ++j) {
+            const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
+            tch[j] = (touched != nullptr && i < last) ? touched[i] : (uint8_t)0; // (wave-uniform branch)
+        }
         // (only the bound slots' cells: between sweeps a quarter of configs[4]'s slots are bound, and free slots come in stretches --
         // the others all ask for the block's first cell, one line)
 #pragma unroll
         for (int j = 0; j < SWEEP_ITEMS; ++j) {
             const uint64_t i = base + (uint64_t)j * BLOCK + threadIdx.x;
-            exp_[j] = cells[bnd[j] ? i : first].expiry;
+            exp_[j] = cells[(bnd[j] && !tch[j]) ? i : first].expiry;
         }
         uint32_t mine = 0;
 #pragma unroll
         for (int j = 0; j < SWEEP_ITEMS; ++j) {
             unbind[j] = false;
-            if (bnd[j]) {
+            if (bnd[j] && tch[j]) {
+                live++; // (k_sweep_fixup takes it back if the evaluation left the cell expired)
+            } else if (bnd[j]) {
                 if (!(exp_[j] > (uint64_t)now)) {
                     if (exp_[j] != 0) removed++; // the reference's map only ever held written entries
                     unbind[j] = true;
@@ -230,6 +242,80 @@ static __global__ __launch_bounds__(BLOCK) void k_sweep_keys(Cell* __restrict__ 
     }
     sweep_block_counts(removed, live, work.part);
     if (threadIdx.x == 0) work.part[blockIdx.x] = fill;
+}
+
+// A batch's slots, marked for the sweep that runs beside its evaluation (value != 0: mark, 0: not used -- the marks are
+// taken off by k_sweep_fixup).  Unresolved keys (slot >= capacity) have no slot to mark.
+static __global__ __launch_bounds__(BLOCK) void k_touch_mark(const uint32_t* __restrict__ slots, uint32_t n, uint32_t capacity, uint8_t* __restrict__ touched) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sl = slots[i];
+    if (sl < capacity) touched[sl] = (uint8_t)1;
+}
+
+// ... and, once the newest evaluation is done, the marked slots: the mark column is read sixteen slots per lane (most words are zero),
+// every marked slot's cell is requested, the marks are taken off.  A cell still expired at `now` -- the request was an error, or was
+// denied on a key that had expired, or the caller sweeps at a later time than the batch's -- and the key loses its slot exactly as in
+// k_sweep_keys / k_sweep_tombstones: cell cleared, unbound, its denials retired, the entry a tombstone, the slot on the free stack (an
+// atomic on the stack pointer: these are a handful unless the sweep's time is far ahead), the counters corrected (k_sweep_decide has
+// run).  A marked slot need not be bound any more: of two marked batches the older one's slots may have gone in a sweep between the
+// two (and may or may not have been handed out again since) -- the `bound` column is read beside the marks.
+static __global__ __launch_bounds__(BLOCK) void k_sweep_fixup(Cell* __restrict__ cells, kt::Table t, int64_t now, uint8_t* __restrict__ touched,
+                                                       uint32_t* __restrict__ denied, unsigned long long* __restrict__ removed_out,
+                                                       unsigned long long* __restrict__ counters) {
+    uint32_t removed = 0, unbound = 0;
+    const uint64_t vecs = ((uint64_t)t.capacity + 15u) / 16u; // (the column is allocated and zero up to a multiple of 16)
+    uint4* __restrict__ marks = reinterpret_cast<uint4*>(touched);
+    for (uint64_t v = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; v < vecs; v += (uint64_t)gridDim.x * BLOCK) {
+        const uint4 m = marks[v];
+        if ((m.x | m.y | m.z | m.w) == 0u) continue;
+        const uint4 bd = *reinterpret_cast<const uint4*>(t.bound + v * 16u); // (hipMalloc aligns `bound`; its last vector may reach past the
+                                                                              // capacity into the block's padding: no marks there)
+        const uint32_t w[4] = {m.x, m.y, m.z, m.w}, bw[4] = {bd.x, bd.y, bd.z, bd.w};
+        uint64_t ex[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const bool on = ((w[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0u && ((bw[j >> 2] >> (8 * (j & 3))) & 0xFFu) != 0u;
+            ex[j] = on ? cells[v * 16u + (uint64_t)j].expiry : ~0ull;
+        }
+        marks[v] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (ex[j] > (uint64_t)now) continue; // (not marked: ~0)
+            const uint32_t sl = (uint32_t)(v * 16u) + (uint32_t)j;
+            if (ex[j] != 0) removed++; // the reference's map only ever held written entries
+            unbound++;
+            Cell z;
+            z.tat = 0;
+            z.expiry = 0;
+            cells[sl] = z;
+            t.bound[sl] = 0;
+            if (denied) {
+                const uint32_t dc = denied[sl];
+                if (dc) {
+                    const uint32_t klen = t.rec[sl].len;
+                    if (klen != kt::NO_SLOT) kt::retire_denials(t, t.rec[sl].hash, kt::stored_key(t, sl, klen), klen, dc);
+                    denied[sl] = 0;
+                }
+            }
+            const uint32_t pos = t.pos_col[sl];
+            *reinterpret_cast<uint32_t*>(&t.ktab[pos].w) = kt::VAL_TOMB; // (little-endian: the `val` half)
+            atomicAdd(&t.tombs[pos % kt::TOMB_SHARDS], 1u);
+            const int at = atomicAdd(t.free_top, 1);
+            t.free_slots[at] = sl;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        removed += __shfl_down(removed, off, 64);
+        unbound += __shfl_down(unbound, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && unbound != 0u) {
+        if (removed) {
+            atomicAdd(removed_out, (unsigned long long)removed);
+            atomicAdd(&counters[TC_CNT_SWEPT], (unsigned long long)removed);
+        }
+        atomicAdd(&counters[TC_CNT_LIVE_SLOTS], 0ull - (unsigned long long)unbound);
+    }
 }
 
 constexpr int DECIDE_THREADS = 1024;

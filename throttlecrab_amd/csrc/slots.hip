@@ -1269,6 +1269,7 @@ bool small_batch_applies(const tc_engine* e, const tc_batch& b) {
 // Host-pointer batch of at most SMALL_MAX requests, slot or string mode.  Same results as the big pipeline
 // (the run walker is the plain sequence); ordering against key stages on the key stream as tc_rate_limit.
 int run_small_batch(tc_engine* e, const tc_batch& b) {
+    aside_reset(e); // (resolves its keys inside the kernel, on the engine's stream)
     const size_t n = b.n;
     if (!e->small_io) {
         const size_t bytes = 64 + SMALL_KEY_BYTES + (size_t)SMALL_MAX * (4 + 4 + 4 + 5 * 8 + 1 + 1 + 4 * 8 + 32 + 32) + 16 * 16;
@@ -1388,6 +1389,7 @@ extern "C" int tc_rate_limit_batch_slots(tc_engine* e, const tc_batch* bp) {
     memcpy(&b, bp, std::min<size_t>(bp->struct_size, sizeof b));
     if (b.n == 0) return TC_E_OK;
     if (b.n > e->max_batch) return fail(e, TC_E_BATCH_TOO_LARGE, "batch larger than max_batch");
+    aside_reset(e); // (a key engine's cells touched by slot: the next sweep goes behind it -- keys.hip: sweep_keys_device)
     const bool segmented = b.n_segments != 0;
     if (segmented) {
         if (!(b.flags & TC_B_DEVICE_PTRS) || (b.flags & (TC_B_UNIQUE_SLOTS | TC_B_ASYNC)))

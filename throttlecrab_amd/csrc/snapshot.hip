@@ -140,6 +140,7 @@ extern "C" int tc_snapshot_load(tc_engine* e, const char* path) {
     if (!e || !path) return TC_E_INVALID_ARG;
     int rc = drain_for_snapshot(e);
     if (rc != TC_E_OK) return rc;
+    aside_reset(e);
     FILE* f = fopen(path, "rb");
     if (!f) return fail(e, TC_E_INVALID_ARG, "tc_snapshot_load: cannot open file");
     SnapHeader h;
