@@ -33,7 +33,7 @@
  * result, none is part of this ABI, any may disappear.  As of round 6:
  *   pipeline     TCGPU_AUX_STREAMS  TCGPU_PIPE_DEPTH  TCGPU_AUX_PRIORITY  TCGPU_PIPE_PROBE  TCGPU_ASSUME_CONCURRENT  TCGPU_STREAM_POOL
  *                TCGPU_STOP_EVENTS  TCGPU_PROF_MARKERS
- *   grouping     TCGPU_RANGE  TCGPU_RANGE_MAX_N  TCGPU_SORT_ITEMS_PIPED  TCGPU_HOT  TCGPU_HOT_MIN  TCGPU_HOT_RANK  TCGPU_HOT_THREAD  TCGPU_BUCKET
+ *   grouping     TCGPU_RANGE  TCGPU_RANGE_ILV  TCGPU_RANGE_MAX_N  TCGPU_SORT_ITEMS_PIPED  TCGPU_HOT  TCGPU_HOT_MIN  TCGPU_HOT_RANK  TCGPU_HOT_THREAD  TCGPU_BUCKET
  *                TCGPU_BUCKET_PIPED  TCGPU_BUCKET_BACKOFF  TCGPU_BUCKET_MIN_N  TCGPU_BUCKET_SKEW  TCGPU_ROUTE_3PASS
  *   evaluation   TCGPU_EVAL_ITEMS  TCGPU_EVAL_LEAN  TCGPU_PREFILL  TCGPU_GENERAL_EARLIER  TCGPU_GENERAL_RUNS  TCGPU_GENERAL_LEAN
  *                TCGPU_NO_SMALL_BATCH

@@ -172,7 +172,11 @@ int engine_alloc(tc_engine* e) {
         if (const char* d = getenv("TCGPU_RANGE_MAX_N")) e->range_max_n = (uint32_t)std::max(atoll(d), 1ll);
         if (e->range_mode != 0 && cap > 65536 && cap < 0xFFFFFFFFull) {
             e->range_mul = rs::range_mul((uint32_t)cap);
-            const uint32_t width = rs::range_width(e->range_mul);
+            // string mode: a key table hands neighbouring slots to the keys of one batch -- interleaved ranges (radix_sort.hpp)
+            e->range_ilv = (e->cfg_flags & TC_CFG_KEY_MODE) != 0;
+            if (const char* d = getenv("TCGPU_RANGE_ILV")) e->range_ilv = atoi(d) != 0;
+            if (e->range_ilv && rs::ilv_width((uint32_t)cap) > 65536u) e->range_ilv = false;
+            const uint32_t width = e->range_ilv ? rs::ilv_width((uint32_t)cap) : rs::range_width(e->range_mul);
             if (width <= 65536u) {
                 e->range_sub_passes = width <= 256u ? 1 : 2;
                 e->range_ok = true;

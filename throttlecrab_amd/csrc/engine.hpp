@@ -180,6 +180,7 @@ struct tc_engine {
     int range_mode = 2;                  // TCGPU_RANGE: 0 off, 1 pipelined batches only, 2 every batch
     bool range_ok = false;               // the key space fits (more than 65536 keys, widest range <= 65536 slots)
     uint32_t range_mul = 0;
+    bool range_ilv = false;     // string mode (round 6, late): the ranges interleaved chunk by chunk (radix_sort.hpp: RANGE_ILV; TCGPU_RANGE_ILV=0: contiguous)
     int range_sub_passes = 0;            // 8-bit digits of a slot's offset inside its range
     uint32_t range_max_n = 0;            // batches above this are sorted (TCGPU_RANGE_MAX_N)
     unsigned long long* range_hint_host = nullptr; // pinned: n << 32 | largest range of a recent batch, written by the first pass

@@ -122,6 +122,27 @@ __host__ __device__ inline uint32_t range_lo(uint32_t d, uint32_t mul) { return 
 // widest range (slots), conservatively
 __host__ __device__ inline uint32_t range_width(uint32_t mul) { return (uint32_t)((1ull << 32) / mul) + 2u; }
 
+// Round 6 (late), string mode: INTERLEAVED ranges.  A key table hands out neighbouring slots to the keys of one batch (its new keys
+// pop consecutive entries of the free stack, a benchmark's hot keys were bound one after the other): a fifth of a configs[4] batch
+// falls into a handful of the contiguous ranges above, and key batches stayed on the LSD passes.  With ILV the ranges take turns
+// chunk by chunk -- a chunk is 8 neighbouring slots, one 128-byte line of 16-byte cells --: slot s lies in range (s >> 3) mod NRANGE,
+// at offset ((s >> 12) << 3) | (s & 7) inside it.  Any stretch of consecutive slots spreads evenly over all ranges; requests of one
+// slot still meet in one range, and a range is still finished in ascending order of its offsets.  The sorted batch is then grouped
+// by slot, not ascending in it -- nothing that reads it needs more (the evaluations look at neighbours for EQUAL slots only).
+// msd_mul = RANGE_ILV selects it (a plain multiplier is below 2^25: the path wants more than 65 536 slots).
+constexpr uint32_t RANGE_ILV = 0x80000000u;
+constexpr uint32_t ILV_CHUNK_BITS = 3, ILV_RANGE_BITS = 9;
+static_assert(NRANGE == (1 << ILV_RANGE_BITS), "interleaved ranges: NRANGE is a power of two");
+__host__ __device__ inline uint32_t ilv_digit(uint32_t slot) { return (slot >> ILV_CHUNK_BITS) & (uint32_t)(NRANGE - 1); }
+__host__ __device__ inline uint32_t ilv_sub(uint32_t slot) {
+    return ((slot >> (ILV_CHUNK_BITS + ILV_RANGE_BITS)) << ILV_CHUNK_BITS) | (slot & ((1u << ILV_CHUNK_BITS) - 1u));
+}
+__host__ __device__ inline uint32_t ilv_slot(uint32_t r, uint32_t sub) {
+    return ((sub >> ILV_CHUNK_BITS) << (ILV_CHUNK_BITS + ILV_RANGE_BITS)) | (r << ILV_CHUNK_BITS) | (sub & ((1u << ILV_CHUNK_BITS) - 1u));
+}
+// offsets inside a range are below this (cap itself, the sentinel of out-of-range slots, included)
+__host__ __device__ inline uint32_t ilv_width(uint32_t cap) { return ((cap >> (ILV_CHUNK_BITS + ILV_RANGE_BITS)) + 1u) << ILV_CHUNK_BITS; }
+
 __host__ __device__ inline uint32_t groups_of(uint32_t tiles) { return (tiles + GROUP - 1) / GROUP; }
 __host__ __device__ inline size_t pass_status_words(uint32_t max_tiles, uint32_t max_groups) {
     return ((size_t)max_tiles + 2 * (size_t)max_groups) * RADIX;
@@ -217,13 +238,13 @@ __global__ __launch_bounds__(NT) void k_hist(const uint32_t* __restrict__ slot, 
             for (int u = 0; u < 4; ++u) {
                 const uint32_t kk = clamp_slot(k[u], cap);
                 for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-                if (msd_mul) atomicAdd(&(&s_h[MSD_ROW][0])[__umulhi(kk, msd_mul)], 1u); // (NRANGE words: rows MSD_ROW ..)
+                if (msd_mul) atomicAdd(&(&s_h[MSD_ROW][0])[(msd_mul & RANGE_ILV) ? ilv_digit(kk) : __umulhi(kk, msd_mul)], 1u); // (NRANGE words: rows MSD_ROW ..)
             }
         }
         for (; i < n; i += stride) {
             const uint32_t kk = clamp_slot(slot[i], cap);
             for (int p = 0; p < passes; ++p) atomicAdd(&s_h[p][(kk >> (8 * p)) & 255u], 1u);
-            if (msd_mul) atomicAdd(&(&s_h[MSD_ROW][0])[__umulhi(kk, msd_mul)], 1u); // (NRANGE words: rows MSD_ROW ..)
+            if (msd_mul) atomicAdd(&(&s_h[MSD_ROW][0])[(msd_mul & RANGE_ILV) ? ilv_digit(kk) : __umulhi(kk, msd_mul)], 1u); // (NRANGE words: rows MSD_ROW ..)
         }
     }
     __syncthreads();
@@ -585,7 +606,9 @@ __device__ __forceinline__ void fin_scan_digits(const uint32_t* s_tot, uint32_t*
 // early then sat on their CU waiting for the late ones, 41 us per launch in the pipelined run against 14 alone);
 // sub_passes = 8-bit digits of the offset inside a range (1 or 2: the host takes this path only when the widest range
 // is at most 65536 slots); `range_hint`: n << 32 | largest range, into pinned host memory (block NRANGE - 1).
-static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* __restrict__ tiled, const uint32_t* __restrict__ table,
+// ILV: interleaved ranges (above) -- msd_mul then carries the capacity (the ranges' width follows from it)
+template <bool ILV>
+__global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* __restrict__ tiled, const uint32_t* __restrict__ table,
                                                                uint64_t* __restrict__ elem_out, uint64_t* __restrict__ scratch,
                                                                const uint32_t* __restrict__ totals, uint32_t* __restrict__ totals_next, uint32_t n,
                                                                uint32_t tiles, uint32_t tile_len, uint32_t msd_mul, int sub_passes,
@@ -642,8 +665,10 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
         return;
     }
     RS_STAMP(1, 0, 128);
-    const uint32_t lo = range_lo(r, msd_mul);
-    const uint32_t width = range_lo(r + 1u, msd_mul) - lo; // slots of my range (every offset inside it is below this)
+    const uint32_t lo = ILV ? 0u : range_lo(r, msd_mul);
+    const uint32_t width = ILV ? ilv_width(msd_mul) : range_lo(r + 1u, msd_mul) - lo; // slots of my range (every offset inside it is below this)
+    auto sub_of = [&](uint32_t slot) -> uint32_t { return ILV ? ilv_sub(slot) : slot - lo; };
+    auto slot_of = [&](uint32_t sub) -> uint32_t { return ILV ? ilv_slot(r, sub) : lo + sub; };
     // my range's pieces: one table word per tile; exclusive scan of the counts over the tiles
     uint32_t c, tot_early = 0;
     {
@@ -764,7 +789,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                     const uint32_t t = s_owner[p];
                     const uint64_t e = tiled[(size_t)t * tile_len + s_st[t] + (p - s_pos[t])];
                     s_idx[p] = (uint32_t)e;
-                    const uint32_t sub = (uint32_t)(e >> 32) - lo;
+                    const uint32_t sub = sub_of((uint32_t)(e >> 32));
                     kv[j] = (sub << FIN_POS_BITS) | p;
                     const uint32_t sh = 8u * (sub & 3u);
                     arr[j] = (atomicAdd(&c_cnt[sub >> 2], 1u << sh) >> sh) & 255u;
@@ -831,7 +856,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 uint64_t* out = elem_out + base;
                 for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) {
                     const uint32_t v = c_fin[q];
-                    out[q] = ((uint64_t)(lo + (v >> FIN_POS_BITS)) << 32) | s_idx[v & (FIN_CAP - 1u)];
+                    out[q] = ((uint64_t)slot_of(v >> FIN_POS_BITS) << 32) | s_idx[v & (FIN_CAP - 1u)];
                 }
                 RS_STAMP(1, 14, 128);
                 return;
@@ -854,7 +879,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 const uint32_t t = s_owner[p];
                 const uint64_t e = tiled[(size_t)t * tile_len + s_st[t] + (p - s_pos[t])];
                 s_idx[p] = (uint32_t)e;
-                kv[j] = (((uint32_t)(e >> 32) - lo) << FIN_POS_BITS) | p;
+                kv[j] = (sub_of((uint32_t)(e >> 32)) << FIN_POS_BITS) | p;
             }
         }
         RS_STAMP(1, 5, 128);
@@ -886,7 +911,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
         const uint32_t* fin = s_kv[(sub_passes - 1) & 1];
         for (uint32_t q = threadIdx.x; q < c; q += FIN_THREADS) {
             const uint32_t v = fin[q];
-            out[q] = ((uint64_t)(lo + (v >> FIN_POS_BITS)) << 32) | s_idx[v & (FIN_CAP - 1u)];
+            out[q] = ((uint64_t)slot_of(v >> FIN_POS_BITS) << 32) | s_idx[v & (FIN_CAP - 1u)];
         }
         RS_STAMP(1, 14, 128);
         return;
@@ -919,7 +944,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
         for (uint32_t q0 = 0; q0 < c; q0 += FIN_THREADS) { // histogram of the digit over the whole range
             const uint32_t q = q0 + threadIdx.x;
             const bool v = q < c;
-            const uint32_t d = v ? ((((uint32_t)(ld_l2(&src[q]) >> 32) - lo) >> shift) & 255u) : 0u;
+            const uint32_t d = v ? ((sub_of((uint32_t)(ld_l2(&src[q]) >> 32)) >> shift) & 255u) : 0u;
             unsigned long long m = __ballot(v);
 #pragma unroll
             for (int bt = 0; bt < 8; ++bt) {
@@ -941,7 +966,7 @@ static __global__ __launch_bounds__(FIN_THREADS) void k_finish(const uint64_t* _
                 const uint32_t p = c0 + (uint32_t)wave * (64u * FIN_ITEMS) + (uint32_t)j * 64u + (uint32_t)lane;
                 valid[j] = p < c;
                 el[j] = valid[j] ? ld_l2(&src[p]) : 0ull;
-                dig[j] = (((uint32_t)(el[j] >> 32) - lo) >> shift) & 255u;
+                dig[j] = (sub_of((uint32_t)(el[j] >> 32)) >> shift) & 255u;
             }
             fin_rank<FIN_ITEMS>(dig, valid, rank, s_cnt, s_tot);
 #pragma unroll

@@ -93,7 +93,8 @@ static __global__ __launch_bounds__(PT_THREADS) void k_hot_install(HotList l, Ho
 // rank inside its tile in hot_info[i], every other request HOT_NONE; the tile's cold requests are written back alone)
 constexpr int PART_PLAIN = 0, PART_RANK = 2;
 constexpr uint32_t HOT_NONE = 0xFFFFFFFFu;
-template <int MODE>
+// ILV: the ranges interleaved chunk by chunk (radix_sort.hpp: string mode)
+template <int MODE, bool ILV = false>
 __global__ __launch_bounds__(PT_THREADS) void k_tile_part(const uint32_t* __restrict__ slot_in, uint64_t* __restrict__ elem_out,
                                                           uint32_t* __restrict__ table, uint32_t stride, uint32_t* __restrict__ totals, uint32_t n,
                                                           uint32_t cap, uint32_t msd_mul, uint8_t* __restrict__ fill, uint32_t fill_value,
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(PT_THREADS) void k_tile_part(const uint32_t* __rest
     for (int j = 0; j < PT_ITEMS; ++j) {
         const bool valid = (wbase + j * 64) < n;
         key[j] = rs::clamp_slot(key[j], cap);
-        uint32_t d = valid ? __umulhi(key[j], msd_mul) : 0u;
+        uint32_t d = valid ? (ILV ? rs::ilv_digit(key[j]) : __umulhi(key[j], msd_mul)) : 0u;
         if (HOT && valid) {
             uint32_t h = hot_hash(key[j]);
             while (true) {

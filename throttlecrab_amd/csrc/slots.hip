@@ -537,28 +537,36 @@ static const uint64_t* sort_by_slot(tc_engine* e, tc_engine::SortSet& ss, hipStr
             ss.hot_version = e->hot.version;
         }
         prof_begin_m(e, TC_STAGE_SORT, s);
-#define TC_PART(MODE, HOTP, INFO) \
-    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<MODE>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap, \
+#define TC_PART(MODE, ILV, HOTP, INFO) \
+    TC_LAUNCH_T(e, TC_STAGE_SORT, (hipEvent_t) nullptr, (rp::k_tile_part<MODE, ILV>), dim3(ptiles), dim3(rp::PT_THREADS), 0, s, d_slot, bufs[1], ss.part_table, stride, totals, n, cap, \
                 e->range_mul, fill, fill_value, (const rp::HotDev*)(HOTP), (uint32_t*)(INFO))
-        if (rankm) TC_PART(rp::PART_RANK, ss.hot_dev, ss.hot_info);
-        else TC_PART(rp::PART_PLAIN, nullptr, nullptr);
+        // (string mode: the ranges interleaved chunk by chunk -- radix_sort.hpp)
+        if (e->range_ilv) {
+            if (rankm) TC_PART(rp::PART_RANK, true, ss.hot_dev, ss.hot_info);
+            else TC_PART(rp::PART_PLAIN, true, nullptr, nullptr);
+        } else if (rankm) TC_PART(rp::PART_RANK, false, ss.hot_dev, ss.hot_info);
+        else TC_PART(rp::PART_PLAIN, false, nullptr, nullptr);
 #undef TC_PART
         prof_end_m(e, s);
         if (hotm) e->hot.batches_hot++;
         prof_begin_m(e, TC_STAGE_SORT, s);
         hipEvent_t stop = e->prof_on ? nullptr : stop_last;
         // (rank form: HOT_MAX / 32 more blocks scan the hot ids' columns of the table)
-        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish, dim3(rs::NRANGE + (rankm ? rp::HOT_MAX / 32u : 0u)), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1],
-                    (const uint32_t*)ss.part_table, bufs[0], ss.elem_c, (const uint32_t*)totals, totals_next, n, ptiles, rp::PT_TILE, e->range_mul, e->range_sub_passes,
-                    hotm ? e->hot.hint_cold_dev : hint, stride, rp::NB_HOT, rankm ? ss.hot_P : (uint32_t*)nullptr, rankm ? ss.hot_n : (uint32_t*)nullptr, rp::HOT_MAX,
-                    rankm ? e->hot.hint_cold_dev + 1 : (unsigned long long*)nullptr);
+#define TC_FIN(ILV, MUL) \
+        TC_LAUNCH_T(e, TC_STAGE_SORT, stop, rs::k_finish<ILV>, dim3(rs::NRANGE + (rankm ? rp::HOT_MAX / 32u : 0u)), dim3(rs::FIN_THREADS), 0, s, (const uint64_t*)bufs[1], \
+                    (const uint32_t*)ss.part_table, bufs[0], ss.elem_c, (const uint32_t*)totals, totals_next, n, ptiles, rp::PT_TILE, (MUL), e->range_sub_passes, \
+                    hotm ? e->hot.hint_cold_dev : hint, stride, rp::NB_HOT, rankm ? ss.hot_P : (uint32_t*)nullptr, rankm ? ss.hot_n : (uint32_t*)nullptr, rp::HOT_MAX, \
+                    rankm ? e->hot.hint_cold_dev + 1 : (unsigned long long*)nullptr)
+        if (e->range_ilv) TC_FIN(true, cap); // (interleaved: the kernel derives the ranges' width from the capacity)
+        else TC_FIN(false, e->range_mul);
+#undef TC_FIN
         prof_end_m(e, s);
         return bufs[0];
     }
     ss.hist_parity ^= 1u;
     // the range histogram is counted beside the LSD digits (one more LDS atomic per request) whenever the key space admits
     // the range path: it is where the hint comes from while a stream is on the LSD passes
-    const uint32_t msd_mul = e->range_ok ? e->range_mul : 0u;
+    const uint32_t msd_mul = e->range_ok ? (e->range_ilv ? rs::RANGE_ILV : e->range_mul) : 0u;
     prof_begin_m(e, TC_STAGE_PREP, s);
     TC_LAUNCH_T(e, TC_STAGE_PREP, (hipEvent_t) nullptr, rs::k_hist<rs::HIST_THREADS>, dim3(rs::HIST_BLOCKS), dim3(rs::HIST_THREADS), 0, s, d_slot, n, cap, passes, ws, tiles, gate, gate_min, fill, fill_value, msd_mul);
     prof_end_m(e, s);
@@ -700,10 +708,14 @@ static void preload_pipelined_kernels(tc_engine* e) {
     }
     hipFuncAttributes at;
 #define TC_TOUCH(...) (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&__VA_ARGS__))
-    TC_TOUCH(rp::k_tile_part<rp::PART_PLAIN>);
-    TC_TOUCH(rp::k_tile_part<rp::PART_RANK>);
+    // (once per process and device: both forms of the ranges -- the next engine may be of the other kind)
+    TC_TOUCH(rp::k_tile_part<rp::PART_PLAIN, false>);
+    TC_TOUCH(rp::k_tile_part<rp::PART_RANK, false>);
+    TC_TOUCH(rs::k_finish<false>);
+    TC_TOUCH(rp::k_tile_part<rp::PART_PLAIN, true>);
+    TC_TOUCH(rp::k_tile_part<rp::PART_RANK, true>);
+    TC_TOUCH(rs::k_finish<true>);
     TC_TOUCH(rp::k_hot_install);
-    TC_TOUCH(rs::k_finish);
     TC_TOUCH(rs::k_hist<rs::HIST_THREADS>);
     TC_TOUCH(rs::k_onesweep<8, true>);
     TC_TOUCH(rs::k_onesweep<8, false>);

@@ -132,7 +132,7 @@ int main(int argc, char** argv) {
                     else hipLaunchKernelGGL((rp::k_tile_part<rp::PART_PLAIN>), dim3(tiles), dim3(rp::PT_THREADS), 0, 0, d_slot, b, table, stride, tot, n, cap, mul, (uint8_t*)nullptr, 0u, (const rp::HotDev*)nullptr, (uint32_t*)nullptr);
                     CK(hipEventRecord(ev[1]));
                     CK(hipEventRecord(ev[2]));
-                    hipLaunchKernelGGL(rs::k_finish, dim3(rs::NRANGE + (hotm ? rp::HOT_MAX / 32u : 0u)), dim3(rs::FIN_THREADS), 0, 0, (const uint64_t*)b, (const uint32_t*)table, a, c3, (const uint32_t*)tot, tot_next, n, tiles,
+                    hipLaunchKernelGGL(rs::k_finish<false>, dim3(rs::NRANGE + (hotm ? rp::HOT_MAX / 32u : 0u)), dim3(rs::FIN_THREADS), 0, 0, (const uint64_t*)b, (const uint32_t*)table, a, c3, (const uint32_t*)tot, tot_next, n, tiles,
                                        rp::PT_TILE, mul, sub_passes, hint, stride, rp::NB_HOT, hotm ? d_P : (uint32_t*)nullptr, hotm ? d_hn : (uint32_t*)nullptr, rp::HOT_MAX, (unsigned long long*)nullptr);
                     tpar ^= 1u;
                     CK(hipEventRecord(ev[3]));
