@@ -381,6 +381,7 @@ struct tc_engine {
     uint32_t aside_streak = 0;      // pipelined key batches in a row with nothing else between them (a sweep goes aside from 2: the
                                     // evaluation of the batch before the newest is then the last thing in front of the newest on the engine's stream)
     uint64_t sweeps_aside = 0;
+    bool sweep_kernels_preloaded = false; // keys.hip: preload_sweep_kernels
     uint64_t api_seq = 0;           // entry points called so far (TC_CHECK_POISON)
     uint64_t aside_seq = 0;         // ... when the newest pipelined key batch was noted
     hipEvent_t wait_before_sort = nullptr; // piped key batch: the auxiliary sort waits for its key stage

@@ -1,12 +1,39 @@
 // keys.hip -- string keys: key stages on the key stream, tc_rate_limit_batch_keys, tc_rate_limit, the `trait Store` shims, key introspection
 #include "engine.hpp"
 
+// The runtime builds a kernel's function object when it is first launched (40-150 us on the calling thread: slots.hip,
+// preload_pipelined_kernels).  A string-mode server's first sweep -- five kernels nobody has launched yet -- comes in the middle of its
+// pipelined key batches; they are looked up once per process and device where the first pipelined key stage is enqueued.
+static void preload_sweep_kernels(tc_engine* e) {
+    static std::mutex mu;
+    static std::vector<int> done;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        if (std::find(done.begin(), done.end(), e->device) != done.end()) return;
+        done.push_back(e->device);
+    }
+    hipFuncAttributes at;
+#define TC_TOUCH(...) (void)hipFuncGetAttributes(&at, reinterpret_cast<const void*>(&__VA_ARGS__))
+    TC_TOUCH(mk::k_sweep_keys);
+    TC_TOUCH(mk::k_sweep_decide);
+    TC_TOUCH(mk::k_sweep_tombstones);
+    TC_TOUCH(kt::k_table_clear_compact);
+    TC_TOUCH(kt::k_table_reinsert);
+    TC_TOUCH(mk::k_touch_mark);
+    TC_TOUCH(mk::k_sweep_fixup);
+#undef TC_TOUCH
+}
+
 // keys (device arena) -> out_slot[0..n): found slot, freshly bound slot, or NO_SLOT.
 // on_key_stream: issue on the key stream (the caller vouched for the inputs), else on the main stream.
 int resolve_keys_device(tc_engine* e, const uint8_t* d_bytes, const uint32_t* d_off, uint32_t n, bool insert,
                                uint32_t* out_slot, bool on_key_stream) {
     hipStream_t s = on_key_stream ? e->key_stream : cur_stream(e);
     if (on_key_stream) {
+        if (!e->sweep_kernels_preloaded) {
+            e->sweep_kernels_preloaded = true;
+            preload_sweep_kernels(e);
+        }
         if (e->m_busy) TC_HIP(e, hipStreamWaitEvent(s, e->m_done, 0));
     } else {
         if (e->k_busy) TC_HIP(e, hipStreamWaitEvent(s, e->k_done, 0));
