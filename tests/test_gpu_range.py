@@ -181,8 +181,9 @@ def _zipf_like(rng, cap, n, hot_keys=400, s=1.1):
     return out
 
 
-@pytest.mark.parametrize("kind", ["decisions_only", "full_results", "timestamp_per_request", "decisions_only_wide"])
-def test_hot_slots_are_peeled_out_of_the_range_partition(kind):
+@pytest.mark.parametrize("kind", ["decisions_only", "full_results", "timestamp_per_request", "decisions_only_wide",
+                                  "decisions_only_interleaved", "decisions_only_wide_interleaved"])
+def test_hot_slots_are_peeled_out_of_the_range_partition(kind, monkeypatch):
     """Round 6 (csrc/range_part.hpp): a stream whose skew is a few hot keys takes the range path with those keys' requests
     gathered behind the ranges.  Who is hot comes from the evaluations' notes on long runs, through pinned memory -- so the
     first batches go through the LSD passes, and the engine must say when it changed over.  Every batch exact: decisions only
@@ -191,6 +192,9 @@ def test_hot_slots_are_peeled_out_of_the_range_partition(kind):
     request stay on the LSD passes (a gather form for them was built, measured slower and removed: range_part.hpp); then the
     hot keys MOVE (the list is made afresh) and finally the stream turns uniform (the list empties).  The resident state is
     compared at the end."""
+    if kind.endswith("_interleaved"):   # (the rank form over interleaved ranges: k_tile_part<PART_RANK, true>, k_finish<true> with its scan blocks)
+        monkeypatch.setenv("TCGPU_RANGE_ILV", "1")
+        kind = kind[:-len("_interleaved")]
     general, lean = kind == "timestamp_per_request", kind.startswith("decisions_only")
     import torch
 
