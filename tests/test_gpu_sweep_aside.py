@@ -149,3 +149,25 @@ def test_sweep_beside_an_evaluation_with_the_table_nearly_full(monkeypatch):
     assert eng.info()["sweeps_aside"] == nb // 2
     assert eng.debug_check_keys() == 0
     eng.close()
+
+
+def test_engine_info_serves_callers_built_against_the_struct_without_sweeps_aside():
+    """tc_engine_info grew by `sweeps_aside` (appended): a caller that passes the old, smaller struct_size gets the fields it knows and
+    nothing written behind them; a struct_size below the old one is still refused."""
+    import ctypes as C
+    from throttlecrab_amd import _lib as L
+    eng = _engine(1000, 256)
+    lib = L.load()
+    old_size = L.tc_engine_info.sweeps_aside.offset
+    buf = (C.c_uint8 * (C.sizeof(L.tc_engine_info) + 16))()
+    C.memset(buf, 0xAB, len(buf))
+    info = L.tc_engine_info.from_buffer(buf)
+    info.struct_size = old_size
+    assert lib.tc_engine_info_get(eng._h, C.byref(info)) == 0
+    assert info.struct_size == old_size and info.scratch_sets >= 1
+    assert bytes(buf[old_size:]) == b"\xab" * (len(buf) - old_size)   # nothing written past what the caller said it has
+    info.struct_size = old_size - 8
+    assert lib.tc_engine_info_get(eng._h, C.byref(info)) != 0
+    info.struct_size = C.sizeof(L.tc_engine_info)
+    assert lib.tc_engine_info_get(eng._h, C.byref(info)) == 0 and info.sweeps_aside == 0
+    eng.close()
