@@ -885,6 +885,10 @@ def run_exchange(a, t, W, dev, local, rank, world, dist, fab):
     for _ in range(a.warmup):
         step(it)
         it += 1
+    # (the counter block's all-gather falls on every METRICS_EVERY-th step: a short warmup holds none, and the first call of a
+    # collective kind pays RCCL's set-up for it -- one untimed call here)
+    eng.counters_refresh()
+    dist.all_gather_into_tensor(gathered, cnt_view)
     dist.barrier()
     torch.cuda.synchronize()
     decided = 0
@@ -1040,6 +1044,9 @@ def run_sharded(a, t, W, dev, local, rank, world, dist):
     for _ in range(a.warmup):
         evaluate(it)
         it += 1
+    # (one untimed all-gather of the counter block: a short warmup holds none -- see run_exchange)
+    eng.counters_refresh()
+    dist.all_gather_into_tensor(gathered, cnt_view)
     dist.barrier()
     torch.cuda.synchronize()
     decided = 0
